@@ -1,0 +1,312 @@
+"""
+ctypes view of include/dqn_mi355x.h: struct layouts, function prototypes and a
+thin handle class.  Standalone (no package-relative imports) so that the test
+infrastructure can bind the CPU twin (oracle/_ref/libdqn_ref.so, prefix "ref_")
+with the very same struct layouts as the product library (prefix "dqn_").
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+LAYER_DENSE, LAYER_CONV = 0, 1
+ACT_IDENTITY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+STREAM_BASE, STREAM_VAL, STREAM_ADV = 0, 1, 2
+OBS_F32, OBS_U8 = 0, 1
+NET_ONLINE, NET_TARGET = 0, 1
+
+
+class LayerDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("act", C.c_int32), ("stream", C.c_int32),
+                ("n_in", C.c_int32), ("n_out", C.c_int32),
+                ("cin", C.c_int32), ("cout", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+                ("sh", C.c_int32), ("sw", C.c_int32)]
+
+
+class LayerPlan(C.Structure):
+    _fields_ = [("fwd_kc", C.c_int32), ("dx_kc", C.c_int32), ("dw_kc", C.c_int32)]
+
+    def astuple(self):
+        return (self.fwd_kc, self.dx_kc, self.dw_kc)
+
+
+class HParams(C.Structure):
+    _fields_ = [("batch_size", C.c_int32), ("n_actions", C.c_int32),
+                ("obs_c", C.c_int32), ("obs_h", C.c_int32), ("obs_w", C.c_int32), ("obs_dtype", C.c_int32),
+                ("learning_rate", C.c_float),
+                ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
+                ("adam_f64_scalars", C.c_int32),
+                ("gamma", C.c_float),
+                ("double_q", C.c_int32), ("dueling", C.c_int32), ("prioritized_replay", C.c_int32),
+                ("buffer_size", C.c_int64),
+                ("prio_alpha", C.c_float), ("prio_beta", C.c_float), ("prio_eps", C.c_float),
+                ("seed", C.c_uint64),
+                ("use_graph", C.c_int32), ("use_mfma", C.c_int32),
+                ("reserved", C.c_int32 * 6)]
+
+
+def default_hparams(**kw) -> HParams:
+    """Reference defaults: src/solver.jl:3-27, src/prioritized_experience_replay.jl:42-45."""
+    hp = HParams()
+    hp.batch_size, hp.n_actions = 32, 0
+    hp.obs_c, hp.obs_h, hp.obs_w, hp.obs_dtype = 0, 1, 1, OBS_F32
+    hp.learning_rate = 1e-4
+    hp.adam_beta1, hp.adam_beta2, hp.adam_eps, hp.adam_f64_scalars = 0.9, 0.999, 1e-8, 1
+    hp.gamma = 1.0
+    hp.double_q, hp.dueling, hp.prioritized_replay = 1, 1, 1
+    hp.buffer_size = 1000
+    hp.prio_alpha, hp.prio_beta, hp.prio_eps = 0.6, 0.4, 1e-3
+    hp.seed = 0
+    hp.use_graph, hp.use_mfma = 1, 1
+    for k, v in kw.items():
+        if not hasattr(hp, k):
+            raise AttributeError(k)
+        setattr(hp, k, v)
+    return hp
+
+
+_P = C.POINTER
+_f32p, _i32p, _i64p, _u8p, _f64p = _P(C.c_float), _P(C.c_int32), _P(C.c_int64), _P(C.c_uint8), _P(C.c_double)
+_vp, _sz = C.c_void_p, C.c_size_t
+
+# name -> argtypes (without prefix).  All return int unless listed in _RESTYPE.
+PROTOS = {
+    "plan_default": [_P(LayerDesc), C.c_int, _P(HParams), _P(LayerPlan)],
+    "engine_create": [_P(LayerDesc), C.c_int, _P(HParams), _P(LayerPlan), C.c_int, _P(_vp)],
+    "engine_destroy": [_vp],
+    "engine_get_plan": [_vp, _P(LayerPlan)],
+    "n_params": [_vp, _P(_sz)],
+    "set_params": [_vp, C.c_int, _f32p, _sz],
+    "get_params": [_vp, C.c_int, _f32p, _sz],
+    "sync_target": [_vp],
+    "get_adam_state": [_vp, _f32p, _f32p, _f64p, _sz],
+    "set_adam_state": [_vp, _f32p, _f32p, _f64p, _sz],
+    "replay_add": [_vp, _vp, _i32p, _f32p, _vp, _u8p, _f32p, C.c_int],
+    "replay_size": [_vp, _i64p, _i64p],
+    "replay_get_priorities": [_vp, _f32p, C.c_int64],
+    "replay_sample": [_vp, _i64p],
+    "replay_get_batch": [_vp, _i64p, _f32p, _i32p, _f32p, _f32p, _f32p, _f32p],
+    "update_priorities": [_vp, _i64p, _f32p, C.c_int],
+    "train_step": [_vp, _i64p, _f32p, _f32p, _f32p],
+    "train_steps": [_vp, C.c_int, _f32p, _f32p],
+    "get_last_q": [_vp, _f32p, _f32p, _f32p, _i32p, _f32p],
+    "get_last_indices": [_vp, _i64p],
+    "get_grads": [_vp, _f32p, _sz],
+    "forward": [_vp, C.c_int, _f32p, C.c_int, _f32p],
+    "greedy_action": [_vp, _f32p, C.c_int, _i32p],
+    "comm_unique_id": [_vp],
+    "comm_init": [_vp, _vp, C.c_int, C.c_int],
+    "stream_sync": [_vp],
+    "stream_handle": [_vp, _P(_vp)],
+    "profile_step": [_vp, C.c_int, _P(C.c_char_p), _f32p, _P(C.c_int)],
+    "hparams_default": [_P(HParams)],
+}
+# twin spellings that differ from the product's
+_TWIN_ALIASES = {"engine_create": "create", "engine_destroy": "destroy", "engine_get_plan": "get_plan"}
+
+
+class DQNError(RuntimeError):
+    """Mirrors the reference's thrown Strings / AssertionErrors."""
+
+
+def bind(lib: C.CDLL, prefix: str):
+    """Attach prototypes; returns {name: callable} for every symbol the library exports."""
+    fns = {}
+    for name, args in PROTOS.items():
+        sym = prefix + name
+        f = getattr(lib, sym, None)
+        if f is None and prefix == "ref_":
+            f = getattr(lib, prefix + _TWIN_ALIASES.get(name, name), None)
+        if f is None:
+            continue
+        if name == "engine_create" and prefix == "ref_":
+            f.argtypes = [_P(LayerDesc), C.c_int, _P(HParams), _P(LayerPlan), _P(_vp)]
+        else:
+            f.argtypes = args
+        f.restype = C.c_int
+        fns[name] = f
+    le = getattr(lib, prefix + "last_error")
+    le.restype = C.c_char_p
+    fns["last_error"] = le
+    return fns
+
+
+def _ptr(a, ty):
+    return None if a is None else a.ctypes.data_as(ty)
+
+
+def _as(a, dtype):
+    return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+
+class Handle:
+    """NumPy-friendly wrapper over one engine handle (product or twin)."""
+
+    def __init__(self, fns, layers, hp: HParams, plan=None, device=0, is_twin=False):
+        self.f, self.hp, self.is_twin = fns, hp, is_twin
+        self.layers = (LayerDesc * len(layers))(*layers)
+        self.n_layers = len(layers)
+        self.B, self.nA = hp.batch_size, hp.n_actions
+        self.obs_elems = hp.obs_c * hp.obs_h * hp.obs_w
+        self.obs_shape = (hp.obs_c, hp.obs_h, hp.obs_w)
+        self.obs_np = np.uint8 if hp.obs_dtype == OBS_U8 else np.float32
+        parr = None
+        if plan is not None:
+            parr = (LayerPlan * len(layers))(*[LayerPlan(*p) for p in plan])
+        h = C.c_void_p()
+        if is_twin:
+            rc = fns["engine_create"](self.layers, self.n_layers, C.byref(hp), parr, C.byref(h))
+        else:
+            rc = fns["engine_create"](self.layers, self.n_layers, C.byref(hp), parr, device, C.byref(h))
+        self._h = h
+        self._check(rc)
+        n = C.c_size_t()
+        self._check(fns["n_params"](h, C.byref(n)))
+        self.P = n.value
+
+    def _check(self, rc):
+        if rc != 0:
+            raise DQNError(self.f["last_error"]().decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.f["engine_destroy"](self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- plan / params
+    def plan(self):
+        p = (LayerPlan * self.n_layers)()
+        self._check(self.f["engine_get_plan"](self._h, p))
+        return [x.astuple() for x in p]
+
+    def set_params(self, flat, which=NET_ONLINE):
+        flat = _as(flat, np.float32).reshape(-1)
+        self._check(self.f["set_params"](self._h, which, _ptr(flat, _f32p), flat.size))
+
+    def get_params(self, which=NET_ONLINE):
+        out = np.empty(self.P, np.float32)
+        self._check(self.f["get_params"](self._h, which, _ptr(out, _f32p), out.size))
+        return out
+
+    def get_grads(self):
+        out = np.empty(self.P, np.float32)
+        self._check(self.f["get_grads"](self._h, _ptr(out, _f32p), out.size))
+        return out
+
+    def get_adam_state(self):
+        m, v, bp = np.empty(self.P, np.float32), np.empty(self.P, np.float32), np.empty(2, np.float64)
+        self._check(self.f["get_adam_state"](self._h, _ptr(m, _f32p), _ptr(v, _f32p), _ptr(bp, _f64p), self.P))
+        return m, v, bp
+
+    def sync_target(self):
+        self._check(self.f["sync_target"](self._h))
+
+    # ---- replay
+    def replay_add(self, s, a, r, sp, done, td_err=None):
+        s = _as(s, self.obs_np).reshape(-1, self.obs_elems)
+        sp = _as(sp, self.obs_np).reshape(-1, self.obs_elems)
+        n = s.shape[0]
+        a, r, done = _as(np.atleast_1d(a), np.int32), _as(np.atleast_1d(r), np.float32), _as(np.atleast_1d(done), np.uint8)
+        td = None if td_err is None else _as(np.atleast_1d(td_err), np.float32)
+        assert sp.shape[0] == n and a.size == n and r.size == n and done.size == n
+        self._check(self.f["replay_add"](self._h, s.ctypes.data_as(_vp), _ptr(a, _i32p), _ptr(r, _f32p),
+                                         sp.ctypes.data_as(_vp), _ptr(done, _u8p), _ptr(td, _f32p), n))
+
+    def replay_size(self):
+        cur, cap = C.c_int64(), C.c_int64()
+        self._check(self.f["replay_size"](self._h, C.byref(cur), C.byref(cap)))
+        return cur.value, cap.value
+
+    def replay_priorities(self):
+        n = self.replay_size()[0]
+        out = np.empty(n, np.float32)
+        self._check(self.f["replay_get_priorities"](self._h, _ptr(out, _f32p), n))
+        return out
+
+    def replay_sample(self):
+        idx = np.empty(self.B, np.int64)
+        self._check(self.f["replay_sample"](self._h, _ptr(idx, _i64p)))
+        return idx
+
+    def get_batch(self, idx):
+        idx = _as(idx, np.int64)
+        B = self.B
+        s = np.empty((B,) + self.obs_shape, np.float32)
+        sp = np.empty_like(s)
+        a, r, done, w = np.empty(B, np.int32), np.empty(B, np.float32), np.empty(B, np.float32), np.empty(B, np.float32)
+        self._check(self.f["replay_get_batch"](self._h, _ptr(idx, _i64p), _ptr(s, _f32p), _ptr(a, _i32p), _ptr(r, _f32p),
+                                               _ptr(sp, _f32p), _ptr(done, _f32p), _ptr(w, _f32p)))
+        return s, a, r, sp, done, w
+
+    def update_priorities(self, idx, td):
+        idx, td = _as(idx, np.int64), _as(td, np.float32)
+        self._check(self.f["update_priorities"](self._h, _ptr(idx, _i64p), _ptr(td, _f32p), idx.size))
+
+    # ---- train
+    def train_step(self, idx=None, want_td=True, sync=True):
+        """batch_train! -> (loss_val, grad_norm[, td]) (src/solver.jl:235)."""
+        idx = _as(idx, np.int64)
+        if not sync:
+            self._check(self.f["train_step"](self._h, _ptr(idx, _i64p), None, None, None))
+            return None
+        loss, gn = C.c_float(), C.c_float()
+        td = np.empty(self.B, np.float32) if want_td else None
+        self._check(self.f["train_step"](self._h, _ptr(idx, _i64p), C.byref(loss), C.byref(gn), _ptr(td, _f32p)))
+        return (loss.value, gn.value, td) if want_td else (loss.value, gn.value)
+
+    def train_steps(self, n):
+        loss, gn = C.c_float(), C.c_float()
+        self._check(self.f["train_steps"](self._h, n, C.byref(loss), C.byref(gn)))
+        return loss.value, gn.value
+
+    def last_q(self):
+        B, nA = self.B, self.nA
+        qs, qsp, qt = (np.empty((B, nA), np.float32) for _ in range(3))
+        best, y = np.empty(B, np.int32), np.empty(B, np.float32)
+        self._check(self.f["get_last_q"](self._h, _ptr(qs, _f32p), _ptr(qsp, _f32p), _ptr(qt, _f32p), _ptr(best, _i32p), _ptr(y, _f32p)))
+        return dict(q_on_s=qs, q_on_sp=qsp, q_tg_sp=qt, best_a=best, y=y)
+
+    def last_indices(self):
+        idx = np.empty(self.B, np.int64)
+        self._check(self.f["get_last_indices"](self._h, _ptr(idx, _i64p)))
+        return idx
+
+    # ---- policy
+    def forward(self, obs, which=NET_ONLINE):
+        obs = _as(obs, np.float32).reshape(-1, self.obs_elems)
+        q = np.empty((obs.shape[0], self.nA), np.float32)
+        self._check(self.f["forward"](self._h, which, _ptr(obs, _f32p), obs.shape[0], _ptr(q, _f32p)))
+        return q
+
+    def greedy_action(self, obs):
+        obs = _as(obs, np.float32).reshape(-1, self.obs_elems)
+        a = np.empty(obs.shape[0], np.int32)
+        self._check(self.f["greedy_action"](self._h, _ptr(obs, _f32p), obs.shape[0], _ptr(a, _i32p)))
+        return a
+
+    # ---- misc (product only)
+    def sync(self):
+        self._check(self.f["stream_sync"](self._h))
+
+    def stream_handle(self):
+        p = C.c_void_p()
+        self._check(self.f["stream_handle"](self._h, C.byref(p)))
+        return p.value
+
+    def profile_step(self, max_entries=128):
+        names = (C.c_char_p * max_entries)()
+        ms = np.zeros(max_entries, np.float32)
+        n = C.c_int()
+        self._check(self.f["profile_step"](self._h, max_entries, names, _ptr(ms, _f32p), C.byref(n)))
+        return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+    def comm_init(self, id128: bytes, rank: int, world: int):
+        buf = C.create_string_buffer(id128, 128)
+        self._check(self.f["comm_init"](self._h, C.cast(buf, _vp), rank, world))

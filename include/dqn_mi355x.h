@@ -1,0 +1,178 @@
+/*
+ * dqn_mi355x.h -- C ABI of libdqn_mi355x.so, the MI355X-native (gfx950) engine for
+ * the DeepQLearning.jl hot path: PrioritizedReplayBuffer + batch_train!.
+ *
+ * The reference (JuliaPOMDP/DeepQLearning.jl v0.7.1) has NO FFI: its extension
+ * mechanism is Julia multiple dispatch.  Each entry point below replaces one
+ * dispatch seam of the reference; the `ccall` stubs a maintainer adds are in
+ * INTEGRATION.md and deepqlearning.jl_amd/julia/DeepQLearningMI355X.jl.
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 on error; dqn_last_error() gives the
+ *    message (thread-local).  Reference errors are thrown Strings
+ *    ("DeepQLearningError: ...", src/solver.jl:46, src/dueling.jl:47) and @assert
+ *    (src/prioritized_experience_replay.jl:66,78,83-84,90); the shim re-throws.
+ *  - host arrays are taken AS JULIA LAYS THEM OUT (column-major, batch last):
+ *      obs (W,H,C)  == C float[C][H][W];    batch (W,H,C,B) == float[B][C][H][W]
+ *      Dense weight (out,in) == float[in][out];  Conv weight (kw,kh,cin,cout) ==
+ *      float[cout][cin][kh][kw], UN-flipped (the engine applies NNlib's true
+ *      convolution itself);  Q-values (nA,B) == float[B][nA].
+ *  - flat parameter vectors are in Flux.params order: base, val, adv streams
+ *    (src/dueling.jl:2-6,13), per layer weight then bias.
+ *  - action indices are 0-BASED at the ABI (the Julia shim subtracts 1 from the
+ *    reference's 1-based index, src/solver.jl:84).
+ *  - the caller owns every host pointer and may free it when the call returns.
+ *  - an engine is NOT thread-safe (the reference is strictly sequential); distinct
+ *    engines (one per GPU) are independent.
+ *  - no torch / HIP types appear in any signature.
+ */
+#ifndef DQN_MI355X_H
+#define DQN_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dqn_engine dqn_engine_t;
+
+enum { DQN_LAYER_DENSE = 0, DQN_LAYER_CONV = 1 };
+enum { DQN_ACT_IDENTITY = 0, DQN_ACT_RELU = 1, DQN_ACT_TANH = 2, DQN_ACT_SIGMOID = 3 };
+enum { DQN_STREAM_BASE = 0, DQN_STREAM_VAL = 1, DQN_STREAM_ADV = 2 };
+enum { DQN_OBS_F32 = 0, DQN_OBS_U8 = 1 }; /* u8: stored byte, consumed as (float)byte/255f0 (test/test_env.jl:59) */
+enum { DQN_NET_ONLINE = 0, DQN_NET_TARGET = 1 };
+
+/* One layer of solver.qnetwork (a Flux.Chain of Conv / Dense, src/solver.jl:2,
+ * README.md:64-70) AFTER create_dueling_network (src/dueling.jl:36-58) has split
+ * it: the shim passes base layers, then val layers, then adv layers.
+ * flattenbatch (src/helpers.jl:6-8) is implicit between a Conv and a Dense. */
+typedef struct {
+    int32_t kind;   /* DQN_LAYER_* */
+    int32_t act;    /* DQN_ACT_* */
+    int32_t stream; /* DQN_STREAM_*; all BASE when dueling == 0 */
+    int32_t n_in, n_out;               /* Dense(in,out) */
+    int32_t cin, cout, kh, kw, sh, sw; /* Conv((kh,kw), cin=>cout; stride=(sh,sw)), pad 0 */
+} dqn_layer_desc;
+
+/* Summation-order plan of one layer: the K dimension of each contraction is cut
+ * into chunks of `*_kc` elements; inside a chunk products are accumulated as ONE
+ * k-ascending fp32 fma chain starting at +0 (== gfx950 fp32 MFMA numerics), and
+ * chunk sums are added in ascending chunk order.  0 = no split.  The plan only
+ * fixes rounding order; DESIGN.md section 4 states it. */
+typedef struct {
+    int32_t fwd_kc; /* forward:  K = n_in            | cin*kh*kw           */
+    int32_t dx_kc;  /* dX:       K = n_out           | (conv: never split)  */
+    int32_t dw_kc;  /* dW, db:   K = batch           | out_positions*batch  */
+} dqn_layer_plan;
+
+/* DeepQLearningSolver fields that reach the hot path (src/solver.jl:1-28) plus the
+ * PrioritizedReplayBuffer constructor defaults (src/prioritized_experience_replay.jl:39-45;
+ * NB the reference never forwards the solver's alpha/beta/epsilon, src/solver.jl:185). */
+typedef struct {
+    int32_t batch_size;        /* solver.batch_size (32) */
+    int32_t n_actions;         /* length(actions(env)) */
+    int32_t obs_c, obs_h, obs_w; /* obs as float[C][H][W]; vector obs of length n: (n,1,1) */
+    int32_t obs_dtype;         /* DQN_OBS_* replay storage type */
+    float   learning_rate;     /* solver.learning_rate (1f-4) -> Adam eta */
+    double  adam_beta1, adam_beta2, adam_eps; /* Flux Adam defaults 0.9, 0.999, 1e-8 */
+    int32_t adam_f64_scalars;  /* 1: Flux 0.14 semantics (Float64 eta/beta/eps, evaluate in f64, round on store) */
+    float   gamma;             /* discount (src/solver.jl:208, helpers.jl:83-85) */
+    int32_t double_q;          /* solver.double_q */
+    int32_t dueling;           /* solver.dueling */
+    int32_t prioritized_replay;/* solver.prioritized_replay: 0 => priorities are not updated (src/solver.jl:231) */
+    int64_t buffer_size;       /* solver.buffer_size */
+    float   prio_alpha, prio_beta, prio_eps; /* 0.6, 0.4, 1e-3 */
+    uint64_t seed;             /* sampler key (Philox4x32-10 counter RNG) */
+    int32_t use_graph;         /* 1: replay the train step from a captured hipGraph */
+    int32_t use_mfma;          /* 1: fp32 MFMA kernels where shapes allow (bit-identical to the VALU path) */
+    int32_t reserved[6];
+} dqn_hparams;
+
+const char* dqn_last_error(void);
+int dqn_version(void);
+
+/* Fill `hp` with the reference defaults (src/solver.jl:3-27, ...replay.jl:42-45). */
+int dqn_hparams_default(dqn_hparams* hp);
+
+/* Host-only (no GPU needed): the default summation-order plan the engine would use
+ * for this network, one entry per layer. */
+int dqn_plan_default(const dqn_layer_desc* layers, int n_layers, const dqn_hparams* hp,
+                     dqn_layer_plan* plan_out);
+
+/* solve(): src/solver.jl:40-57 builds replay + (dueling) network + policy; the
+ * engine owns their device state.  plan_or_null overrides the default plan. */
+int dqn_engine_create(const dqn_layer_desc* layers, int n_layers, const dqn_hparams* hp,
+                      const dqn_layer_plan* plan_or_null, int device, dqn_engine_t** out);
+int dqn_engine_destroy(dqn_engine_t* e);
+int dqn_engine_get_plan(dqn_engine_t* e, dqn_layer_plan* plan_out /* n_layers entries */);
+int dqn_n_params(dqn_engine_t* e, size_t* n);
+
+/* Flux.params(active_q) / Flux.loadparams! (src/solver.jl:143-144, :292, :314-315). */
+int dqn_set_params(dqn_engine_t* e, int which, const float* flat, size_t n);
+int dqn_get_params(dqn_engine_t* e, int which, float* flat, size_t n);
+/* target_q <- active_q every target_update_freq steps (src/solver.jl:142-145). */
+int dqn_sync_target(dqn_engine_t* e);
+/* Adam state (no reference equivalent: the reference cannot resume an optimizer). */
+int dqn_get_adam_state(dqn_engine_t* e, float* m, float* v, double* beta_pow /*[2]*/, size_t n);
+int dqn_set_adam_state(dqn_engine_t* e, const float* m, const float* v, const double* beta_pow, size_t n);
+
+/* add_exp!(r, DQExperience(s,a,r,sp,done), td_err) for n transitions
+ * (src/prioritized_experience_replay.jl:65-74; n > 1 serves vectorised envs).
+ * s, sp: n rows of obs in the replay storage dtype; td_err may be NULL => |r| (:65). */
+int dqn_replay_add(dqn_engine_t* e, const void* s, const int32_t* a, const float* r,
+                   const void* sp, const uint8_t* done, const float* td_err, int n);
+int dqn_replay_size(dqn_engine_t* e, int64_t* cur, int64_t* cap); /* _curr_size, max_size (:61-63) */
+int dqn_replay_get_priorities(dqn_engine_t* e, float* prio, int64_t n); /* r._priorities[1:n] */
+
+/* StatsBase.sample(r) (:82-87).  The reference draws B distinct indices with
+ * probability proportional to priority (StatsBase A-ExpJ, O(n)); the engine uses a
+ * stratified sum-tree descent (O(B log n)); parity is defined on GIVEN indices via
+ * the two calls below.  idx_out (host, B int64, 0-based) may be NULL. */
+int dqn_replay_sample(dqn_engine_t* e, int64_t* idx_out);
+/* get_batch(r, idx) (:89-104): the deterministic seam.  Any output may be NULL.
+ * s, sp: float[B][C][H][W]; a: int32[B]; r, done, w: float[B]. */
+int dqn_replay_get_batch(dqn_engine_t* e, const int64_t* idx, float* s, int32_t* a, float* r,
+                         float* sp, float* done, float* w);
+/* update_priorities!(r, idx, td) (:76-80). */
+int dqn_update_priorities(dqn_engine_t* e, const int64_t* idx, const float* td, int n);
+
+/* batch_train!(solver, env, policy, optimizer, target_q, replay) (src/solver.jl:191-236):
+ * sample (or use idx) -> gather + IS weights -> double-Q Bellman target -> Huber(w*td)/B ->
+ * backward -> max-abs grad norm -> Adam -> priority update.  Returns (loss_val, grad_norm)
+ * like the reference (:235).  All outputs optional; with every output NULL the call only
+ * enqueues work on the engine's stream (no host sync). */
+int dqn_train_step(dqn_engine_t* e, const int64_t* idx_or_null, float* loss, float* grad_norm,
+                   float* td_out /* B */);
+/* run `n_steps` sampled train steps back to back; returns the last step's scalars. */
+int dqn_train_steps(dqn_engine_t* e, int n_steps, float* loss, float* grad_norm);
+
+/* Results of the last train step (parity checks; not on the hot path). */
+int dqn_get_last_q(dqn_engine_t* e, float* q_on_s, float* q_on_sp, float* q_tg_sp /* each [B][nA] */,
+                   int32_t* best_a /* B */, float* q_targets /* B */);
+int dqn_get_last_indices(dqn_engine_t* e, int64_t* idx /* B */);
+int dqn_get_grads(dqn_engine_t* e, float* flat, size_t n); /* Flux.params order/layout */
+
+/* NNPolicy: actionvalues / action / value (src/policy.jl:38-64) for n observations
+ * (n = 1 in the reference; n > 1 serves vectorised envs).  obs: float[n][C][H][W]. */
+int dqn_forward(dqn_engine_t* e, int which, const float* obs, int n, float* q_out /* [n][nA] */);
+int dqn_greedy_action(dqn_engine_t* e, const float* obs, int n, int32_t* a_out /* first-max tie rule */);
+
+/* data-parallel replicas: all-reduce (SUM over ranks, then * 1/world) of the flat
+ * gradient between backward and Adam, over RCCL (dlopen'ed librccl; no reference
+ * equivalent).  unique_id: 128 bytes from dqn_comm_unique_id on rank 0. */
+int dqn_comm_unique_id(void* id128);
+int dqn_comm_init(dqn_engine_t* e, const void* id128, int rank, int world);
+
+/* raw access for harnesses that time kernels on the engine's own stream. */
+int dqn_stream_sync(dqn_engine_t* e);
+int dqn_stream_handle(dqn_engine_t* e, void** hip_stream);
+/* per-kernel timing of the last dqn_profile_step call: names (static strings) and
+ * milliseconds measured with HIP events on the engine stream. */
+int dqn_profile_step(dqn_engine_t* e, int max_entries, const char** names, float* ms, int* n_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DQN_MI355X_H */

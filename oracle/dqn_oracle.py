@@ -1,0 +1,482 @@
+"""
+oracle/dqn_oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A NumPy restatement (dtype-generic: float64 = "mathematical truth", float32 =
+"reference precision") of the DeepQLearning.jl hot path:
+
+    PrioritizedReplayBuffer  src/prioritized_experience_replay.jl:19-104
+    batch_train!             src/solver.jl:191-236
+    DuelingNetwork           src/dueling.jl:8-11, 36-58
+    huber_loss / globalnorm  src/helpers.jl:14-19, 38-46
+    NNPolicy greedy action   src/policy.jl:38-64
+    EpisodeReplayBuffer      src/episode_replay.jl:62-95   (DRQN, config 4)
+    batch_train! (DRQN)      src/solver.jl:239-287
+
+PARITY UNPINNED BY THE REFERENCE: the reference is pure Julia, there is no
+`julia` binary in this image, its arithmetic lives in un-vendored Flux 0.14 /
+NNlib / Zygote / StatsBase, and its own tests hold no golden vectors for this
+path.  This oracle is therefore pinned by
+  (1) closed-form known answers that follow from the cited lines
+      (tests/test_oracle_known_answers.py),
+  (2) an independent torch-CPU autograd cross-check of every gradient
+      (oracle/make_golden.py, run in the build container; fixtures under
+      tests/golden/).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product (deepqlearning.jl_amd) never does.
+
+Array conventions: a Julia array of size (d1,...,dn) (column-major) is held as
+a NumPy C-order array of shape (dn,...,d1) -- same bytes.  So
+    obs (W,H,C)            -> (C,H,W)         batch (W,H,C,B) -> (B,C,H,W)
+    Dense weight (out,in)  -> (in,out)        Q-values (nA,B) -> (B,nA)
+    Conv weight (kw,kh,cin,cout) -> (cout,cin,kh,kw)
+Action indices are 0-based here (the reference's are 1-based, solver.jl:84).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# --------------------------------------------------------------------------
+# network description (mirrors Flux Chain of Conv / Dense; flattenbatch is
+# implicit between the last Conv and the first Dense, src/helpers.jl:6-8)
+# --------------------------------------------------------------------------
+ACT_IDENTITY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+
+
+def act_fwd(y, act):
+    if act == ACT_IDENTITY:
+        return y
+    if act == ACT_RELU:
+        return np.maximum(y, 0)
+    if act == ACT_TANH:
+        return np.tanh(y)
+    if act == ACT_SIGMOID:
+        return 1.0 / (1.0 + np.exp(-y))
+    raise ValueError(act)
+
+
+def act_bwd_from_output(y, act):
+    """d act / d pre, expressed from the post-activation output y."""
+    if act == ACT_IDENTITY:
+        return np.ones_like(y)
+    if act == ACT_RELU:
+        return (y > 0).astype(y.dtype)
+    if act == ACT_TANH:
+        return 1 - y * y
+    if act == ACT_SIGMOID:
+        return y * (1 - y)
+    raise ValueError(act)
+
+
+class Dense:
+    """Flux Dense(in,out,act): act.(W*x .+ b); W held as (in,out)."""
+
+    def __init__(self, n_in, n_out, act=ACT_IDENTITY):
+        self.kind = "dense"
+        self.n_in, self.n_out, self.act = n_in, n_out, act
+
+    def param_shapes(self):
+        return [(self.n_in, self.n_out), (self.n_out,)]
+
+    def out_shape(self, in_shape):
+        assert int(np.prod(in_shape)) == self.n_in, (in_shape, self.n_in)
+        return (self.n_out,)
+
+
+class Conv:
+    """Flux Conv((kh,kw), cin=>cout, act; stride): TRUE convolution (kernel
+    flipped, NNlib default flipkernel=false), no padding.  W held as
+    (cout,cin,kh,kw) = bytes of Julia's (kw,kh,cin,cout)."""
+
+    def __init__(self, k, cin, cout, act=ACT_IDENTITY, stride=1):
+        self.kind = "conv"
+        self.kh, self.kw = (k, k) if np.isscalar(k) else k
+        self.sh, self.sw = (stride, stride) if np.isscalar(stride) else stride
+        self.cin, self.cout, self.act = cin, cout, act
+
+    def param_shapes(self):
+        return [(self.cout, self.cin, self.kh, self.kw), (self.cout,)]
+
+    def out_shape(self, in_shape):
+        c, h, w = in_shape
+        assert c == self.cin
+        return (self.cout, (h - self.kh) // self.sh + 1, (w - self.kw) // self.sw + 1)
+
+
+def create_dueling_network(layers):
+    """src/dueling.jl:36-58.  Returns (base, val, adv) layer lists.  `val` is
+    all trailing Dense layers but the last, plus a fresh Dense(in_of_last, 1);
+    `adv` is all trailing Dense layers; `base` is everything before."""
+    duel_layer = -1
+    n = len(layers)
+    for i in range(1, n + 1):
+        l = layers[n - i]
+        if l.kind != "dense":
+            duel_layer = n - i + 1  # 1-based index of the last non-Dense layer
+            break
+        elif i == n:
+            duel_layer = 0
+    if duel_layer == -1:
+        raise ValueError("DeepQLearningError: the qnetwork provided is incompatible with dueling")
+    trailing = layers[duel_layer:]
+    last = trailing[-1]
+    val = [Dense(l.n_in, l.n_out, l.act) for l in trailing[:-1]] + [Dense(last.n_in, 1)]
+    adv = [Dense(l.n_in, l.n_out, l.act) for l in trailing]
+    base = list(layers[:duel_layer])
+    return base, val, adv
+
+
+class Network:
+    """A Q-network: either a plain chain (`base` only) or a DuelingNetwork
+    (base, val, adv).  Parameter order = Flux.params order: base, val, adv;
+    within a layer weight then bias (src/dueling.jl:2-6,13)."""
+
+    def __init__(self, obs_shape, base, val=None, adv=None):
+        self.obs_shape = tuple(obs_shape)
+        self.base, self.val, self.adv = list(base), val, adv
+        self.dueling = val is not None
+        shp = self.obs_shape
+        for l in self.base:
+            shp = l.out_shape(shp)
+        self.base_out_shape = shp
+        if self.dueling:
+            s = shp
+            for l in self.val:
+                s = l.out_shape(s)
+            assert s == (1,)
+            s = shp
+            for l in self.adv:
+                s = l.out_shape(s)
+            self.n_actions = s[0]
+        else:
+            assert len(shp) == 1
+            self.n_actions = shp[0]
+
+    def all_layers(self):
+        return self.base + (self.val + self.adv if self.dueling else [])
+
+    def param_shapes(self):
+        out = []
+        for l in self.all_layers():
+            out += l.param_shapes()
+        return out
+
+    def n_params(self):
+        return int(sum(int(np.prod(s)) for s in self.param_shapes()))
+
+    def unflatten(self, flat):
+        ps, off = [], 0
+        for s in self.param_shapes():
+            n = int(np.prod(s))
+            ps.append(np.asarray(flat[off:off + n]).reshape(s))
+            off += n
+        assert off == len(flat)
+        return ps
+
+    @staticmethod
+    def flatten(ps):
+        return np.concatenate([np.asarray(p).reshape(-1) for p in ps])
+
+
+def glorot_uniform(rng, shape, fan_in, fan_out):
+    """Flux.glorot_uniform: (rand(Float32, dims) .- 0.5f0) .* sqrt(24f0/(fan_in+fan_out))
+    (third-party; recalled).  The RNG stream is NumPy's, not Julia's."""
+    return ((rng.random(shape, dtype=np.float32) - np.float32(0.5)) *
+            np.sqrt(np.float32(24.0) / np.float32(fan_in + fan_out))).astype(np.float32)
+
+
+def init_params(net: Network, seed=1):
+    rng = np.random.default_rng(seed)
+    ps = []
+    for l in net.all_layers():
+        if l.kind == "dense":
+            ps.append(glorot_uniform(rng, (l.n_in, l.n_out), l.n_in, l.n_out))
+            ps.append(np.zeros(l.n_out, np.float32))
+        else:
+            kk = l.kh * l.kw
+            ps.append(glorot_uniform(rng, (l.cout, l.cin, l.kh, l.kw), kk * l.cin, kk * l.cout))
+            ps.append(np.zeros(l.cout, np.float32))
+    return ps
+
+
+# --------------------------------------------------------------------------
+# layer forward / backward (im2col formulation; independent of the product's
+# batch-innermost layout and of the C twin's loop order)
+# --------------------------------------------------------------------------
+def _im2col(x, l: Conv):
+    B, C, H, W = x.shape
+    oh = (H - l.kh) // l.sh + 1
+    ow = (W - l.kw) // l.sw + 1
+    cols = np.empty((B, oh, ow, C, l.kh, l.kw), x.dtype)
+    for ky in range(l.kh):
+        for kx in range(l.kw):
+            cols[:, :, :, :, ky, kx] = x[:, :, ky:ky + l.sh * oh:l.sh, kx:kx + l.sw * ow:l.sw].transpose(0, 2, 3, 1)
+    return cols.reshape(B, oh, ow, C * l.kh * l.kw), oh, ow
+
+
+def _flipped_matrix(W):
+    # true convolution == cross-correlation with the spatially flipped kernel
+    cout = W.shape[0]
+    return W[:, :, ::-1, ::-1].reshape(cout, -1)  # (cout, cin*kh*kw)
+
+
+def layer_forward(l, x, W, b):
+    if l.kind == "dense":
+        x2 = x.reshape(x.shape[0], -1)  # flattenbatch, helpers.jl:6-8
+        y = x2 @ W + b
+        return act_fwd(y, l.act), x2
+    cols, oh, ow = _im2col(x, l)
+    y = cols @ _flipped_matrix(W).T + b  # (B,oh,ow,cout)
+    y = y.transpose(0, 3, 1, 2)
+    return act_fwd(y, l.act), cols
+
+
+def layer_backward(l, cache, x_shape, y, dy, W):
+    """returns dx, dW, db given upstream dy (wrt post-activation output y)."""
+    dpre = dy * act_bwd_from_output(y, l.act)
+    if l.kind == "dense":
+        x2 = cache
+        dW = x2.T @ dpre
+        db = dpre.sum(0)
+        dx = (dpre @ W.T).reshape(x_shape)
+        return dx, dW, db
+    cols = cache  # (B,oh,ow,K)
+    B, C, H, Wd = x_shape
+    d2 = dpre.transpose(0, 2, 3, 1)  # (B,oh,ow,cout)
+    oh, ow = d2.shape[1], d2.shape[2]
+    dWf = np.tensordot(d2, cols, axes=([0, 1, 2], [0, 1, 2]))  # (cout,K)
+    dW = dWf.reshape(l.cout, l.cin, l.kh, l.kw)[:, :, ::-1, ::-1]
+    db = d2.sum((0, 1, 2))
+    dcols = (d2 @ _flipped_matrix(W)).reshape(B, oh, ow, C, l.kh, l.kw)
+    dx = np.zeros(x_shape, dpre.dtype)
+    for ky in range(l.kh):
+        for kx in range(l.kw):
+            dx[:, :, ky:ky + l.sh * oh:l.sh, kx:kx + l.sw * ow:l.sw] += dcols[:, :, :, :, ky, kx].transpose(0, 3, 1, 2)
+    return dx, dW, db
+
+
+def _chain_forward(layers, ps, x):
+    caches = []
+    for i, l in enumerate(layers):
+        W, b = ps[2 * i], ps[2 * i + 1]
+        xin_shape = x.shape
+        y, cache = layer_forward(l, x, W, b)
+        caches.append((cache, xin_shape, y))
+        x = y
+    return x, caches
+
+
+def _chain_backward(layers, ps, caches, dy):
+    grads = [None] * (2 * len(layers))
+    for i in reversed(range(len(layers))):
+        cache, xin_shape, y = caches[i]
+        dy, dW, db = layer_backward(layers[i], cache, xin_shape, y, dy, ps[2 * i])
+        grads[2 * i], grads[2 * i + 1] = dW, db
+    return dy, grads
+
+
+def network_forward(net: Network, params, x, want_cache=False):
+    """Q(x): (B,nA).  Dueling: Q = val .+ adv .- mean(adv, dims=1)
+    (src/dueling.jl:8-11).  The reference evaluates adv(x) twice; same value."""
+    dt = x.dtype
+    ps = [np.asarray(p, dt) for p in params]
+    nb = 2 * len(net.base)
+    xb, cb = _chain_forward(net.base, ps[:nb], x)
+    if not net.dueling:
+        return (xb, (cb,)) if want_cache else xb
+    nv = 2 * len(net.val)
+    v, cv = _chain_forward(net.val, ps[nb:nb + nv], xb)
+    a, ca = _chain_forward(net.adv, ps[nb + nv:], xb)
+    q = v + a - a.mean(axis=1, keepdims=True)
+    return (q, (cb, cv, ca, xb.shape)) if want_cache else q
+
+
+def network_backward(net: Network, params, cache, dq):
+    dt = dq.dtype
+    ps = [np.asarray(p, dt) for p in params]
+    nb = 2 * len(net.base)
+    if not net.dueling:
+        _, g = _chain_backward(net.base, ps[:nb], cache[0], dq)
+        return g
+    cb, cv, ca, xb_shape = cache
+    nv = 2 * len(net.val)
+    dv = dq.sum(axis=1, keepdims=True)
+    da = dq - dq.mean(axis=1, keepdims=True)
+    dxv, gv = _chain_backward(net.val, ps[nb:nb + nv], cv, dv)
+    dxa, ga = _chain_backward(net.adv, ps[nb + nv:], ca, da)
+    dxb = (dxv + dxa).reshape(xb_shape)
+    _, gb = _chain_backward(net.base, ps[:nb], cb, dxb)
+    return gb + gv + ga
+
+
+# --------------------------------------------------------------------------
+# loss pieces
+# --------------------------------------------------------------------------
+def huber_loss(x):
+    """src/helpers.jl:14-19."""
+    abserror = np.abs(x)
+    quadratic = np.minimum(abserror, 1)
+    linear = abserror - quadratic
+    return 0.5 * quadratic * quadratic + linear
+
+
+def priority_from_td(td_abs, eps, alpha, dtype=np.float32):
+    """(td_err + eps)^alpha, src/prioritized_experience_replay.jl:67,77.
+    Julia's Float32^Float32 is evaluated through Float64 and rounded once."""
+    base = (np.asarray(td_abs, dtype) + dtype(eps)).astype(np.float64)
+    return (base ** np.float64(dtype(alpha))).astype(dtype)
+
+
+def is_weights(prio_batch, prio_all, beta, dtype=np.float32):
+    """src/prioritized_experience_replay.jl:101-102:
+        p = w ./ sum(prio[1:n]); weights = (n .* p) .^ (-beta)
+    no max-normalisation, beta not annealed."""
+    n = len(prio_all)
+    tot = np.sum(np.asarray(prio_all, np.float64)) if dtype == np.float64 else np.sum(np.asarray(prio_all, dtype), dtype=dtype)
+    p = np.asarray(prio_batch, dtype) / dtype(tot)
+    x = (dtype(n) * p).astype(np.float64)
+    return (x ** (-np.float64(np.float32(beta)))).astype(dtype)
+
+
+def bellman_targets(q_on_sp, q_tg_sp, r, done, gamma, double_q):
+    """src/solver.jl:209-217.  np.argmax == Julia argmax first-max tie rule."""
+    B = len(r)
+    if double_q:
+        best = np.argmax(q_on_sp, axis=1)
+        q_sp_max = q_tg_sp[np.arange(B), best]
+    else:
+        best = np.argmax(q_tg_sp, axis=1)
+        q_sp_max = q_tg_sp.max(axis=1)
+    dt = q_tg_sp.dtype
+    y = r.astype(dt) + (dt.type(1) - done.astype(dt)) * dt.type(gamma) * q_sp_max
+    return y, best
+
+
+class AdamState:
+    """Flux 0.14 Optimise.Adam (third-party; recalled):
+    eta/beta/eps/beta-powers are Float64, m/v are arrays of the parameter type;
+    every broadcast is evaluated in Float64 and rounded on store."""
+
+    def __init__(self, params, lr, beta=(0.9, 0.999), eps=1e-8, f64_scalars=True):
+        self.m = [np.zeros_like(p) for p in params]
+        self.v = [np.zeros_like(p) for p in params]
+        self.f64 = f64_scalars
+        self.eta = float(np.float32(lr)) if f64_scalars else np.float32(lr)
+        self.beta = (float(beta[0]), float(beta[1]))
+        self.eps = float(eps)
+        self.bp = [self.beta[0], self.beta[1]]
+
+
+def adam_update(params, grads, st: AdamState):
+    new = []
+    b1, b2 = st.beta
+    for i, (p, g) in enumerate(zip(params, grads)):
+        dt = p.dtype
+        if st.f64:
+            g64 = g.astype(np.float64)
+            m = (b1 * st.m[i].astype(np.float64) + (1 - b1) * g64).astype(dt)
+            v = (b2 * st.v[i].astype(np.float64) + (1 - b2) * g64 * g64).astype(dt)
+            d = (m.astype(np.float64) / (1 - st.bp[0]) /
+                 (np.sqrt(v.astype(np.float64) / (1 - st.bp[1])) + st.eps) * st.eta).astype(dt)
+        else:
+            f = dt.type
+            m = f(b1) * st.m[i] + (f(1) - f(b1)) * g
+            v = f(b2) * st.v[i] + (f(1) - f(b2)) * g * g
+            d = m / (f(1) - f(st.bp[0])) / (np.sqrt(v / (f(1) - f(st.bp[1]))) + f(st.eps)) * f(st.eta)
+        st.m[i], st.v[i] = m, v
+        new.append((p - d).astype(dt))
+    st.bp[0] *= b1
+    st.bp[1] *= b2
+    return new
+
+
+def globalnorm(grads):
+    """src/helpers.jl:38-46: max-abs over all gradient arrays."""
+    return max(float(np.max(np.abs(g))) for g in grads)
+
+
+def batch_train_step(net, params_on, params_tg, batch, *, gamma, double_q, adam: AdamState | None,
+                     dtype=np.float64):
+    """One batch_train! (src/solver.jl:191-236) on a given batch
+    (s,a,r,sp,done,weights) -- the output of get_batch.  Returns a dict."""
+    s, a, r, sp, done, w = batch
+    dt = np.dtype(dtype)
+    s = np.asarray(s, dt)
+    sp = np.asarray(sp, dt)
+    w = np.asarray(w, dt)
+    B = s.shape[0]
+    pon = [np.asarray(p, dt) for p in params_on]
+    ptg = [np.asarray(p, dt) for p in params_tg]
+    q_tg_sp = network_forward(net, ptg, sp)
+    q_on_sp = network_forward(net, pon, sp) if double_q else q_tg_sp
+    y, best = bellman_targets(q_on_sp, q_tg_sp, np.asarray(r, dt), np.asarray(done, dt), gamma, double_q)
+    q, cache = network_forward(net, pon, s, want_cache=True)
+    q_sa = q[np.arange(B), a]
+    td = q_sa - y
+    x = w * td
+    loss = huber_loss(x).sum() / dt.type(B)
+    dq = np.zeros_like(q)
+    dq[np.arange(B), a] = w * np.clip(x, -1, 1) / dt.type(B)
+    grads = network_backward(net, pon, cache, dq)
+    out = dict(loss=loss, td=td, q=q, q_on_sp=q_on_sp, q_tg_sp=q_tg_sp, best_a=best, y=y,
+               grads=grads, grad_norm=globalnorm(grads))
+    if adam is not None:
+        out["new_params"] = adam_update(pon, grads, adam)
+    return out
+
+
+# --------------------------------------------------------------------------
+# PrioritizedReplayBuffer restatement
+# --------------------------------------------------------------------------
+class PrioritizedReplay:
+    """src/prioritized_experience_replay.jl:19-104 (0-based indices)."""
+
+    def __init__(self, obs_shape, max_size, batch_size, alpha=0.6, beta=0.4, eps=1e-3):
+        self.max_size, self.batch_size = max_size, batch_size
+        self.alpha, self.beta, self.eps = np.float32(alpha), np.float32(beta), np.float32(eps)
+        self.curr_size, self.idx = 0, 0
+        self.prio = np.zeros(max_size, np.float32)
+        self.s = np.zeros((max_size,) + tuple(obs_shape), np.float32)
+        self.sp = np.zeros_like(self.s)
+        self.a = np.zeros(max_size, np.int32)
+        self.r = np.zeros(max_size, np.float32)
+        self.done = np.zeros(max_size, np.uint8)
+
+    def add_exp(self, s, a, r, sp, done, td_err=None):
+        td_err = abs(np.float32(r)) if td_err is None else np.float32(td_err)
+        assert td_err + self.eps > 0
+        i = self.idx
+        self.s[i], self.a[i], self.r[i], self.sp[i], self.done[i] = s, a, r, sp, done
+        self.prio[i] = priority_from_td(td_err, self.eps, self.alpha)
+        self.idx = (self.idx + 1) % self.max_size  # mod1 ring, :70
+        self.curr_size = min(self.curr_size + 1, self.max_size)
+
+    def update_priorities(self, indices, td):
+        newp = priority_from_td(np.abs(np.asarray(td, np.float32)), self.eps, self.alpha)
+        assert np.all(newp > 0)
+        for i, p in zip(indices, newp):  # duplicates: last write wins, :79
+            self.prio[i] = p
+
+    def get_batch(self, indices, dtype=np.float32):
+        idx = np.asarray(indices)
+        assert len(idx) == self.batch_size
+        n = self.curr_size
+        w = is_weights(self.prio[idx], self.prio[:n], self.beta, dtype)
+        return (self.s[idx], self.a[idx].copy(), self.r[idx].copy(), self.sp[idx],
+                self.done[idx].astype(np.float32), w)
+
+
+# --------------------------------------------------------------------------
+# NNPolicy (src/policy.jl:38-64)
+# --------------------------------------------------------------------------
+def actionvalues(net, params, o, dtype=np.float32):
+    if np.ndim(o) != len(net.obs_shape):
+        raise ValueError(f"NNPolicyError: was expecting an array with {len(net.obs_shape)} dimensions, got {np.ndim(o)}")
+    return network_forward(net, [np.asarray(p, dtype) for p in params], np.asarray(o, dtype)[None])[0]
+
+
+def greedy_action(net, params, o, dtype=np.float32):
+    return int(np.argmax(actionvalues(net, params, o, dtype)))
+
+
+def value(net, params, o, dtype=np.float32):
+    return float(np.max(actionvalues(net, params, o, dtype)))

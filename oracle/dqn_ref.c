@@ -1,0 +1,583 @@
+/*
+ * oracle/dqn_ref.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * "libdqn_ref": a plain-C, CPU, canonical-summation-order restatement of the
+ * DeepQLearning.jl hot path, used (a) as the BIT-EXACT checker of the HIP engine
+ * (TD loss, greedy actions, parameters after N steps) and (b) as the timed CPU
+ * baseline ("port") in bench.py.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it; the product never does.
+ *
+ * PARITY UNPINNED BY THE REFERENCE (no Julia in the image, no golden vectors in
+ * the reference's tests).  This twin is pinned against
+ * oracle/dqn_oracle.py (NumPy fp64, itself cross-checked with torch autograd) to
+ * fp32 round-off, and against the committed fixtures in tests/golden/.
+ *
+ * What it restates (reference file:line):
+ *   add_exp!            src/prioritized_experience_replay.jl:65-74
+ *   update_priorities!  src/prioritized_experience_replay.jl:76-80
+ *   get_batch           src/prioritized_experience_replay.jl:89-104
+ *   DuelingNetwork      src/dueling.jl:8-11
+ *   huber_loss          src/helpers.jl:14-19
+ *   globalnorm          src/helpers.jl:38-46
+ *   batch_train!        src/solver.jl:191-236
+ *   NNPolicy forward    src/policy.jl:38-64
+ *   Flux Dense/Conv/Adam (third-party; semantics recalled)
+ *
+ * Canonical order: every contraction is a k-ascending fp32
+ * fma chain from +0 per chunk of the layer plan, chunk sums added in ascending
+ * order, then bias, then activation.  This is exactly what gfx950's fp32 MFMA
+ * computes, which is why the GPU can match this file bit for bit.
+ * Build: see oracle/Makefile (-O2 -ffp-contract=off -mavx2 -mfma -fopenmp).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/dqn_mi355x.h"
+
+#define MAXL 32
+
+typedef struct {
+    int kind, act, stream;
+    int K, N;                 /* contraction dims of the forward GEMM */
+    int cin, cout, kh, kw, sh, sw, ih, iw, oh, ow;
+    int in_feat, out_feat;
+    int src;                  /* producing layer index, -1 = observation */
+    size_t w_off, b_off;      /* offsets in the flat parameter vector */
+    dqn_layer_plan plan;
+} RLayer;
+
+typedef struct ref_engine {
+    int nl; RLayer L[MAXL];
+    dqn_hparams hp;
+    int B, nA, obs_elems;
+    int last_base, last_val, last_adv; /* layer indices (-1 if none) */
+    size_t P;
+    float *p_on, *p_tg, *grad, *m, *v;
+    double bp1, bp2;
+    /* replay */
+    int64_t cap, cap2, size, widx; uint64_t sample_ctr;
+    float *s_f32, *sp_f32; uint8_t *s_u8, *sp_u8;
+    int32_t* a; float* r; uint8_t* done; float* tree; /* tree[1]=root, leaves at cap2+i */
+    /* step workspace */
+    int64_t* idx; float *x0; /* [obs][2B] */
+    float *act_on[MAXL], *act_tg[MAXL], *dact[MAXL]; /* dact: grad wrt layer output, [out_feat][B] */
+    float *w_is, *rew, *donef, *td, *qon_s, *qon_sp, *qtg_sp, *ytarget; int32_t *abatch, *best;
+    float loss, gnorm;
+    int nthreads;
+} ref_engine;
+
+static char g_err[512];
+const char* ref_last_error(void) { return g_err; }
+#define FAIL(...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return -1; } while (0)
+
+/* ---------------------------------------------------------------- helpers */
+static inline float act_f(float y, int act) {
+    switch (act) {
+    case DQN_ACT_RELU: return y > 0.0f ? y : 0.0f;
+    case DQN_ACT_TANH: return (float)tanh((double)y);          /* f64-evaluated, rounded once */
+    case DQN_ACT_SIGMOID: return (float)(1.0 / (1.0 + exp(-(double)y)));
+    default: return y;
+    }
+}
+static inline float dact_f(float dy, float y, int act) {
+    switch (act) {
+    case DQN_ACT_RELU: return y > 0.0f ? dy : 0.0f;
+    case DQN_ACT_TANH: { float t = y * y; float u = 1.0f - t; return dy * u; }
+    case DQN_ACT_SIGMOID: { float u = 1.0f - y; float t = y * u; return dy * t; }
+    default: return dy;
+    }
+}
+static inline float prio_f(float td_abs, float eps, float alpha) {
+    /* (td + eps)^alpha, Julia Float32^Float32 evaluates through Float64 (...replay.jl:67,77) */
+    float base = td_abs + eps;
+    return (float)pow((double)base, (double)alpha);
+}
+static inline int nchunks(int K, int kc) { return (kc <= 0 || kc >= K) ? 1 : (K + kc - 1) / kc; }
+static inline int chunk_len(int K, int kc) { return (kc <= 0 || kc >= K) ? K : kc; }
+
+/* Philox4x32-10 */
+static inline void philox(uint32_t k0, uint32_t k1, uint32_t c[4]) {
+    for (int i = 0; i < 10; i++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+/* ---------------------------------------------------------------- plan */
+int ref_plan_default(const dqn_layer_desc* d, int n, const dqn_hparams* hp, dqn_layer_plan* out) {
+    /* independent restatement of the rule in DESIGN.md section 4 (the tests check it
+     * equals dqn_plan_default of the product) */
+    int c = hp->obs_c, h = hp->obs_h, w = hp->obs_w; int bc = c, bh = h, bw = w; int seen_val = 0, seen_adv = 0;
+    for (int i = 0; i < n; i++) {
+        if (d[i].stream == DQN_STREAM_VAL && !seen_val) { seen_val = 1; c = bc; h = bh; w = bw; }
+        if (d[i].stream == DQN_STREAM_ADV && !seen_adv) { seen_adv = 1; c = bc; h = bh; w = bw; }
+        int K, posB;
+        if (d[i].kind == DQN_LAYER_CONV) {
+            int oh = (h - d[i].kh) / d[i].sh + 1, ow = (w - d[i].kw) / d[i].sw + 1;
+            K = d[i].cin * d[i].kh * d[i].kw; c = d[i].cout; h = oh; w = ow; posB = 1;
+        } else { K = d[i].n_in; c = d[i].n_out; h = 1; w = 1; posB = 0; }
+        if (d[i].stream == DQN_STREAM_BASE) { bc = c; bh = h; bw = w; }
+        int B = hp->batch_size;
+        out[i].fwd_kc = 0;
+        if (K > 1024) { int s = (K + 511) / 512; int kc = (K + s - 1) / s; kc = (kc + 3) / 4 * 4; out[i].fwd_kc = kc; }
+        out[i].dx_kc = 0;
+        if (d[i].kind == DQN_LAYER_DENSE && d[i].n_out > 512) out[i].dx_kc = 256;
+        out[i].dw_kc = 0;
+        if (posB) { int ppc = 256 / B; if (ppc < 1) ppc = 1; out[i].dw_kc = ppc * B; }
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- create */
+int ref_create(const dqn_layer_desc* d, int n, const dqn_hparams* hp, const dqn_layer_plan* plan, ref_engine** out) {
+    if (n <= 0 || n > MAXL) FAIL("bad layer count %d", n);
+    ref_engine* e = (ref_engine*)calloc(1, sizeof *e);
+    e->nl = n; e->hp = *hp; e->B = hp->batch_size; e->nA = hp->n_actions;
+    e->obs_elems = hp->obs_c * hp->obs_h * hp->obs_w;
+    e->last_base = e->last_val = e->last_adv = -1;
+    dqn_layer_plan defp[MAXL];
+    if (!plan) { ref_plan_default(d, n, hp, defp); plan = defp; }
+    size_t off = 0;
+    for (int i = 0; i < n; i++) {
+        RLayer* L = &e->L[i];
+        L->kind = d[i].kind; L->act = d[i].act; L->stream = d[i].stream; L->plan = plan[i];
+        int prev;
+        if (d[i].stream == DQN_STREAM_BASE) prev = e->last_base;
+        else if (d[i].stream == DQN_STREAM_VAL) prev = e->last_val >= 0 ? e->last_val : e->last_base;
+        else prev = e->last_adv >= 0 ? e->last_adv : e->last_base;
+        L->src = prev;
+        int c, h, w;
+        if (prev < 0) { c = hp->obs_c; h = hp->obs_h; w = hp->obs_w; }
+        else if (e->L[prev].kind == DQN_LAYER_CONV) { c = e->L[prev].cout; h = e->L[prev].oh; w = e->L[prev].ow; }
+        else { c = e->L[prev].N; h = 1; w = 1; }
+        L->in_feat = c * h * w;
+        if (L->kind == DQN_LAYER_CONV) {
+            L->cin = d[i].cin; L->cout = d[i].cout; L->kh = d[i].kh; L->kw = d[i].kw; L->sh = d[i].sh; L->sw = d[i].sw;
+            if (L->cin != c) { free(e); FAIL("layer %d: conv cin %d != incoming channels %d", i, L->cin, c); }
+            L->ih = h; L->iw = w; L->oh = (h - L->kh) / L->sh + 1; L->ow = (w - L->kw) / L->sw + 1;
+            L->K = L->cin * L->kh * L->kw; L->N = L->cout; L->out_feat = L->cout * L->oh * L->ow;
+        } else {
+            if (d[i].n_in != L->in_feat) { free(e); FAIL("layer %d: dense n_in %d != incoming features %d", i, d[i].n_in, L->in_feat); }
+            L->K = d[i].n_in; L->N = d[i].n_out; L->out_feat = L->N;
+        }
+        L->w_off = off; off += (size_t)L->K * L->N; L->b_off = off; off += L->N;
+        if (d[i].stream == DQN_STREAM_BASE) e->last_base = i;
+        else if (d[i].stream == DQN_STREAM_VAL) e->last_val = i; else e->last_adv = i;
+    }
+    e->P = off;
+    if (hp->dueling) {
+        if (e->last_val < 0 || e->last_adv < 0 || e->L[e->last_val].out_feat != 1 || e->L[e->last_adv].out_feat != e->nA) {
+            free(e); FAIL("DeepQLearningError: the qnetwork provided is incompatible with dueling");
+        }
+    } else if (e->last_base < 0 || e->L[e->last_base].out_feat != e->nA) { free(e); FAIL("network output != n_actions"); }
+    int B = e->B;
+    e->p_on = calloc(e->P, 4); e->p_tg = calloc(e->P, 4); e->grad = calloc(e->P, 4); e->m = calloc(e->P, 4); e->v = calloc(e->P, 4);
+    e->bp1 = hp->adam_beta1; e->bp2 = hp->adam_beta2;
+    e->cap = hp->buffer_size; e->cap2 = 1; while (e->cap2 < e->cap) e->cap2 <<= 1;
+    if (hp->obs_dtype == DQN_OBS_U8) { e->s_u8 = calloc((size_t)e->cap * e->obs_elems, 1); e->sp_u8 = calloc((size_t)e->cap * e->obs_elems, 1); }
+    else { e->s_f32 = calloc((size_t)e->cap * e->obs_elems, 4); e->sp_f32 = calloc((size_t)e->cap * e->obs_elems, 4); }
+    e->a = calloc(e->cap, 4); e->r = calloc(e->cap, 4); e->done = calloc(e->cap, 1); e->tree = calloc(2 * (size_t)e->cap2, 4);
+    e->idx = calloc(B, 8); e->x0 = calloc((size_t)e->obs_elems * 2 * B, 4);
+    for (int i = 0; i < n; i++) {
+        e->act_on[i] = calloc((size_t)e->L[i].out_feat * 2 * B, 4);
+        e->act_tg[i] = calloc((size_t)e->L[i].out_feat * B, 4);
+        e->dact[i] = calloc((size_t)e->L[i].out_feat * B, 4);
+    }
+    e->w_is = calloc(B, 4); e->rew = calloc(B, 4); e->donef = calloc(B, 4); e->td = calloc(B, 4);
+    e->qon_s = calloc((size_t)B * e->nA, 4); e->qon_sp = calloc((size_t)B * e->nA, 4); e->qtg_sp = calloc((size_t)B * e->nA, 4);
+    e->ytarget = calloc(B, 4); e->abatch = calloc(B, 4); e->best = calloc(B, 4);
+    e->nthreads = 1;
+    *out = e; return 0;
+}
+int ref_set_threads(ref_engine* e, int n) {
+    e->nthreads = n < 1 ? 1 : n;
+#ifdef _OPENMP
+    omp_set_num_threads(e->nthreads);
+#endif
+    return 0;
+}
+int ref_destroy(ref_engine* e) {
+    if (!e) return 0;
+    free(e->p_on); free(e->p_tg); free(e->grad); free(e->m); free(e->v);
+    free(e->s_f32); free(e->sp_f32); free(e->s_u8); free(e->sp_u8); free(e->a); free(e->r); free(e->done); free(e->tree);
+    free(e->idx); free(e->x0);
+    for (int i = 0; i < e->nl; i++) { free(e->act_on[i]); free(e->act_tg[i]); free(e->dact[i]); }
+    free(e->w_is); free(e->rew); free(e->donef); free(e->td); free(e->qon_s); free(e->qon_sp); free(e->qtg_sp);
+    free(e->ytarget); free(e->abatch); free(e->best); free(e); return 0;
+}
+int ref_n_params(ref_engine* e, size_t* n) { *n = e->P; return 0; }
+int ref_get_plan(ref_engine* e, dqn_layer_plan* p) { for (int i = 0; i < e->nl; i++) p[i] = e->L[i].plan; return 0; }
+
+/* external (Flux.params, Julia memory order) <-> internal ([K][N], conv kernels flipped) */
+static void convert_params(const ref_engine* e, const float* src, float* dst, int to_internal) {
+    for (int i = 0; i < e->nl; i++) {
+        const RLayer* L = &e->L[i];
+        if (L->kind == DQN_LAYER_DENSE) memcpy(dst + L->w_off, src + L->w_off, (size_t)L->K * L->N * 4);
+        else for (int co = 0; co < L->cout; co++) for (int ci = 0; ci < L->cin; ci++)
+            for (int ky = 0; ky < L->kh; ky++) for (int kx = 0; kx < L->kw; kx++) {
+                size_t ext = L->w_off + (((size_t)co * L->cin + ci) * L->kh + (L->kh - 1 - ky)) * L->kw + (L->kw - 1 - kx);
+                size_t in = L->w_off + ((size_t)(ci * L->kh + ky) * L->kw + kx) * L->cout + co;
+                if (to_internal) dst[in] = src[ext]; else dst[ext] = src[in];
+            }
+        memcpy(dst + L->b_off, src + L->b_off, (size_t)L->N * 4);
+    }
+}
+int ref_set_params(ref_engine* e, int which, const float* flat, size_t n) {
+    if (n != e->P) FAIL("set_params: got %zu values, network has %zu", n, e->P);
+    convert_params(e, flat, which == DQN_NET_TARGET ? e->p_tg : e->p_on, 1); return 0;
+}
+int ref_get_params(ref_engine* e, int which, float* flat, size_t n) {
+    if (n != e->P) FAIL("get_params: size mismatch");
+    convert_params(e, which == DQN_NET_TARGET ? e->p_tg : e->p_on, flat, 0); return 0;
+}
+int ref_get_grads(ref_engine* e, float* flat, size_t n) { if (n != e->P) FAIL("size"); convert_params(e, e->grad, flat, 0); return 0; }
+int ref_sync_target(ref_engine* e) { memcpy(e->p_tg, e->p_on, e->P * 4); return 0; }
+int ref_get_adam_state(ref_engine* e, float* m, float* v, double* bp, size_t n) {
+    if (n != e->P) FAIL("size");
+    if (m) convert_params(e, e->m, m, 0);
+    if (v) convert_params(e, e->v, v, 0);
+    if (bp) { bp[0] = e->bp1; bp[1] = e->bp2; } return 0;
+}
+
+/* ---------------------------------------------------------------- replay */
+static void tree_fix_leaf(ref_engine* e, int64_t leaf) {
+    for (int64_t node = (e->cap2 + leaf) >> 1; node >= 1; node >>= 1) e->tree[node] = e->tree[2 * node] + e->tree[2 * node + 1];
+}
+int ref_replay_add(ref_engine* e, const void* s, const int32_t* a, const float* r, const void* sp, const uint8_t* done,
+                   const float* td_err, int n) {
+    size_t row = (size_t)e->obs_elems * (e->hp.obs_dtype == DQN_OBS_U8 ? 1 : 4);
+    for (int i = 0; i < n; i++) {
+        float td = td_err ? td_err[i] : fabsf(r[i]);
+        if (!(td + e->hp.prio_eps > 0.0f)) FAIL("AssertionError: td_err + eps > 0");
+        int64_t w = e->widx;
+        if (a[i] < 0 || a[i] >= e->nA) FAIL("action index %d out of range", a[i]);
+        if (e->hp.obs_dtype == DQN_OBS_U8) { memcpy(e->s_u8 + w * row, (const uint8_t*)s + i * row, row); memcpy(e->sp_u8 + w * row, (const uint8_t*)sp + i * row, row); }
+        else { memcpy((uint8_t*)e->s_f32 + w * row, (const uint8_t*)s + i * row, row); memcpy((uint8_t*)e->sp_f32 + w * row, (const uint8_t*)sp + i * row, row); }
+        e->a[w] = a[i]; e->r[w] = r[i]; e->done[w] = done[i] ? 1 : 0;
+        e->tree[e->cap2 + w] = prio_f(td, e->hp.prio_eps, e->hp.prio_alpha);
+        tree_fix_leaf(e, w);
+        e->widx = (w + 1) % e->cap; if (e->size < e->cap) e->size++;
+    }
+    return 0;
+}
+int ref_replay_size(ref_engine* e, int64_t* cur, int64_t* cap) { if (cur) *cur = e->size; if (cap) *cap = e->cap; return 0; }
+int ref_replay_get_priorities(ref_engine* e, float* p, int64_t n) { memcpy(p, e->tree + e->cap2, (size_t)n * 4); return 0; }
+
+int ref_replay_sample(ref_engine* e, int64_t* idx_out) {
+    int B = e->B;
+    if (e->size < B) FAIL("AssertionError: r._curr_size >= r.batch_size");
+    float total = e->tree[1], seg = total / (float)B;
+    uint64_t ctr = e->sample_ctr++;
+    for (int i = 0; i < B; i++) {
+        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)i, 0x5A4D504Cu};
+        philox((uint32_t)e->hp.seed, (uint32_t)(e->hp.seed >> 32), c);
+        float u = (float)(c[0] >> 8) * (1.0f / 16777216.0f);
+        float t = ((float)i + u) * seg;
+        int64_t node = 1;
+        while (node < e->cap2) {
+            float l = e->tree[2 * node], rg = e->tree[2 * node + 1];
+            if (t < l || !(rg > 0.0f)) node = 2 * node; else { t -= l; node = 2 * node + 1; }
+        }
+        int64_t leaf = node - e->cap2; if (leaf >= e->size) leaf = e->size - 1;
+        e->idx[i] = leaf;
+    }
+    if (idx_out) memcpy(idx_out, e->idx, (size_t)B * 8);
+    return 0;
+}
+static inline float obs_at(const ref_engine* e, int sp, int64_t row, int f) {
+    if (e->hp.obs_dtype == DQN_OBS_U8) { const uint8_t* p = sp ? e->sp_u8 : e->s_u8; return (float)p[row * e->obs_elems + f] / 255.0f; }
+    const float* p = sp ? e->sp_f32 : e->s_f32; return p[row * e->obs_elems + f];
+}
+static int check_idx(ref_engine* e, const int64_t* idx, int n) {
+    for (int i = 0; i < n; i++) if (idx[i] < 0 || idx[i] >= e->size) FAIL("BoundsError: index %lld outside 0..%lld", (long long)idx[i], (long long)e->size - 1);
+    return 0;
+}
+static void is_weights(ref_engine* e, const int64_t* idx, float* w) {
+    /* p = prio ./ sum(prio[1:n]); w = (n .* p) .^ (-beta)   (...replay.jl:101-102); the sum is the
+     * canonical sum-tree root */
+    float total = e->tree[1];
+    for (int i = 0; i < e->B; i++) {
+        float p = e->tree[e->cap2 + idx[i]] / total;
+        float x = (float)e->size * p;
+        w[i] = (float)pow((double)x, -(double)e->hp.prio_beta);
+    }
+}
+int ref_replay_get_batch(ref_engine* e, const int64_t* idx, float* s, int32_t* a, float* r, float* sp, float* done, float* w) {
+    if (check_idx(e, idx, e->B)) return -1;
+    for (int i = 0; i < e->B; i++) {
+        if (s) for (int f = 0; f < e->obs_elems; f++) s[(size_t)i * e->obs_elems + f] = obs_at(e, 0, idx[i], f);
+        if (sp) for (int f = 0; f < e->obs_elems; f++) sp[(size_t)i * e->obs_elems + f] = obs_at(e, 1, idx[i], f);
+        if (a) a[i] = e->a[idx[i]]; if (r) r[i] = e->r[idx[i]]; if (done) done[i] = (float)e->done[idx[i]];
+    }
+    if (w) is_weights(e, idx, w);
+    return 0;
+}
+int ref_update_priorities(ref_engine* e, const int64_t* idx, const float* td, int n) {
+    if (check_idx(e, idx, n)) return -1;
+    for (int i = 0; i < n; i++) { /* duplicates: last write wins (...replay.jl:79) */
+        float p = prio_f(fabsf(td[i]), e->hp.prio_eps, e->hp.prio_alpha);
+        if (!(p > 0.0f)) FAIL("AssertionError: all(new_priorities .> 0f0)");
+        e->tree[e->cap2 + idx[i]] = p; tree_fix_leaf(e, idx[i]);
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- layers */
+/* input X[in_feat][ldx] at column col0, ncols columns -> Y[out_feat][ncols] */
+static void layer_forward(const RLayer* L, const float* P, const float* X, int ldx, int col0, int ncols, float* Y) {
+    const float* W = P + L->w_off; const float* bias = P + L->b_off;
+    const int K = L->K, N = L->N, kc = chunk_len(K, L->plan.fwd_kc), S = nchunks(K, L->plan.fwd_kc);
+    const int npos = L->kind == DQN_LAYER_CONV ? L->oh * L->ow : 1;
+    int* koff = (int*)malloc(sizeof(int) * K);
+    for (int k = 0; k < K; k++) {
+        if (L->kind == DQN_LAYER_CONV) { int ci = k / (L->kh * L->kw), ky = (k / L->kw) % L->kh, kx = k % L->kw; koff[k] = (ci * L->ih + ky) * L->iw + kx; }
+        else koff[k] = k;
+    }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < N; n++) for (int pos = 0; pos < npos; pos++) {
+        float acc[1024], tot[1024];
+        int xb = 0; if (L->kind == DQN_LAYER_CONV) { int oy = pos / L->ow, ox = pos % L->ow; xb = oy * L->sh * L->iw + ox * L->sw; }
+        for (int c0 = 0; c0 < ncols; c0 += 1024) {
+            int nc = ncols - c0 < 1024 ? ncols - c0 : 1024;
+            for (int s = 0; s < S; s++) {
+                for (int b = 0; b < nc; b++) acc[b] = 0.0f;
+                int k1 = (s + 1) * kc < K ? (s + 1) * kc : K;
+                for (int k = s * kc; k < k1; k++) {
+                    const float w = W[(size_t)k * N + n]; const float* xr = X + (size_t)(xb + koff[k]) * ldx + col0 + c0;
+                    for (int b = 0; b < nc; b++) acc[b] = fmaf(xr[b], w, acc[b]);
+                }
+                if (s == 0) for (int b = 0; b < nc; b++) tot[b] = acc[b]; else for (int b = 0; b < nc; b++) tot[b] = tot[b] + acc[b];
+            }
+            float* yr = Y + ((size_t)n * npos + pos) * ncols + c0;
+            for (int b = 0; b < nc; b++) yr[b] = act_f(tot[b] + bias[n], L->act);
+        }
+    }
+    free(koff);
+}
+
+/* dpre[out_feat][B] (already multiplied by act') ; X = layer input [in_feat][ldx] cols 0..B-1 */
+static void layer_backward_w(const RLayer* L, const float* X, int ldx, const float* dpre, int B, float* G) {
+    float* dW = G + L->w_off; float* db = G + L->b_off;
+    const int K = L->K, N = L->N; const int npos = L->kind == DQN_LAYER_CONV ? L->oh * L->ow : 1;
+    const int KK = npos * B; const int kc = chunk_len(KK, L->plan.dw_kc), S = nchunks(KK, L->plan.dw_kc);
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < K; k++) {
+        int ko = k; if (L->kind == DQN_LAYER_CONV) { int ci = k / (L->kh * L->kw), ky = (k / L->kw) % L->kh, kx = k % L->kw; ko = (ci * L->ih + ky) * L->iw + kx; }
+        float acc[512], tot[512];
+        for (int n0 = 0; n0 < N; n0 += 512) {
+            int nn = N - n0 < 512 ? N - n0 : 512;
+            for (int s = 0; s < S; s++) {
+                for (int n = 0; n < nn; n++) acc[n] = 0.0f;
+                int j1 = (s + 1) * kc < KK ? (s + 1) * kc : KK;
+                for (int j = s * kc; j < j1; j++) {
+                    int pos = j / B, b = j % B; int xb = 0;
+                    if (L->kind == DQN_LAYER_CONV) { int oy = pos / L->ow, ox = pos % L->ow; xb = oy * L->sh * L->iw + ox * L->sw; }
+                    const float x = X[(size_t)(xb + ko) * ldx + b];
+                    for (int n = 0; n < nn; n++) acc[n] = fmaf(x, dpre[((size_t)(n0 + n) * npos + pos) * B + b], acc[n]);
+                }
+                if (s == 0) for (int n = 0; n < nn; n++) tot[n] = acc[n]; else for (int n = 0; n < nn; n++) tot[n] = tot[n] + acc[n];
+            }
+            for (int n = 0; n < nn; n++) dW[(size_t)k * N + n0 + n] = tot[n];
+        }
+    }
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; n++) {
+        float tot = 0.0f;
+        for (int s = 0; s < S; s++) {
+            float acc = 0.0f; int j1 = (s + 1) * kc < KK ? (s + 1) * kc : KK;
+            for (int j = s * kc; j < j1; j++) { int pos = j / B, b = j % B; acc = acc + dpre[((size_t)n * npos + pos) * B + b]; }
+            tot = s == 0 ? acc : tot + acc;
+        }
+        db[n] = tot;
+    }
+}
+/* dX[in_feat][B] = W * dpre (dense: chunks over n; conv: valid taps (ky,kx) ascending, co innermost, unsplit) */
+static void layer_backward_x(const RLayer* L, const float* P, const float* dpre, int B, float* dX) {
+    const float* W = P + L->w_off; const int N = L->N;
+    if (L->kind == DQN_LAYER_DENSE) {
+        const int kc = chunk_len(N, L->plan.dx_kc), S = nchunks(N, L->plan.dx_kc);
+#pragma omp parallel for schedule(static)
+        for (int k = 0; k < L->K; k++) {
+            float acc[1024], tot[1024];
+            for (int c0 = 0; c0 < B; c0 += 1024) {
+                int nc = B - c0 < 1024 ? B - c0 : 1024;
+                for (int s = 0; s < S; s++) {
+                    for (int b = 0; b < nc; b++) acc[b] = 0.0f;
+                    int n1 = (s + 1) * kc < N ? (s + 1) * kc : N;
+                    for (int n = s * kc; n < n1; n++) { const float w = W[(size_t)k * N + n]; const float* d = dpre + (size_t)n * B + c0; for (int b = 0; b < nc; b++) acc[b] = fmaf(d[b], w, acc[b]); }
+                    if (s == 0) for (int b = 0; b < nc; b++) tot[b] = acc[b]; else for (int b = 0; b < nc; b++) tot[b] = tot[b] + acc[b];
+                }
+                for (int b = 0; b < nc; b++) dX[(size_t)k * B + c0 + b] = tot[b];
+            }
+        }
+        return;
+    }
+    const int npos = L->oh * L->ow;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int ci = 0; ci < L->cin; ci++) for (int ip = 0; ip < L->ih * L->iw; ip++) {
+        int iy = ip / L->iw, ix = ip % L->iw; float acc[1024];
+        for (int c0 = 0; c0 < B; c0 += 1024) {
+            int nc = B - c0 < 1024 ? B - c0 : 1024;
+            for (int b = 0; b < nc; b++) acc[b] = 0.0f;
+            for (int ky = 0; ky < L->kh; ky++) {
+                int ty = iy - ky; if (ty < 0 || ty % L->sh) continue; int oy = ty / L->sh; if (oy >= L->oh) continue;
+                for (int kx = 0; kx < L->kw; kx++) {
+                    int tx = ix - kx; if (tx < 0 || tx % L->sw) continue; int ox = tx / L->sw; if (ox >= L->ow) continue;
+                    const size_t krow = (size_t)((ci * L->kh + ky) * L->kw + kx) * N; const int pos = oy * L->ow + ox;
+                    for (int co = 0; co < N; co++) { const float w = W[krow + co]; const float* d = dpre + ((size_t)co * npos + pos) * B + c0; for (int b = 0; b < nc; b++) acc[b] = fmaf(d[b], w, acc[b]); }
+                }
+            }
+            for (int b = 0; b < nc; b++) dX[((size_t)ci * L->ih * L->iw + ip) * B + c0 + b] = acc[b];
+        }
+    }
+}
+
+static void net_forward(ref_engine* e, const float* P, float** act, const float* X0, int ld0, int col0, int ncols) {
+    for (int i = 0; i < e->nl; i++) {
+        const RLayer* L = &e->L[i];
+        if (L->src < 0) layer_forward(L, P, X0, ld0, col0, ncols, act[i]);
+        else layer_forward(L, P, act[L->src], ncols, 0, ncols, act[i]);
+    }
+}
+/* Q[a] for column b: dueling (val .+ adv) .- mean(adv)  with mean = (sum ascending)/nA  (dueling.jl:10) */
+static void q_column(const ref_engine* e, float** act, int ld, int col, float* q) {
+    int nA = e->nA;
+    if (!e->hp.dueling) { for (int a = 0; a < nA; a++) q[a] = act[e->last_base][(size_t)a * ld + col]; return; }
+    const float* A = act[e->last_adv]; float v = act[e->last_val][col];
+    float sum = A[col]; for (int a = 1; a < nA; a++) sum = sum + A[(size_t)a * ld + col];
+    float mean = sum / (float)nA;
+    for (int a = 0; a < nA; a++) q[a] = (v + A[(size_t)a * ld + col]) - mean;
+}
+static inline int argmax_first(const float* q, int n) { int bi = 0; for (int a = 1; a < n; a++) if (q[a] > q[bi]) bi = a; return bi; }
+
+/* ---------------------------------------------------------------- train step (solver.jl:191-236) */
+int ref_train_step(ref_engine* e, const int64_t* idx_or_null, float* loss_out, float* gnorm_out, float* td_out) {
+    const int B = e->B, nA = e->nA, E = e->obs_elems, ld0 = 2 * B;
+    if (idx_or_null) { if (check_idx(e, idx_or_null, B)) return -1; memcpy(e->idx, idx_or_null, (size_t)B * 8); }
+    else if (ref_replay_sample(e, NULL)) return -1;
+    /* get_batch: gather into the batch-innermost arena X0[f][2B]: cols 0..B-1 = s, B..2B-1 = sp */
+#pragma omp parallel for schedule(static)
+    for (int f = 0; f < E; f++) for (int b = 0; b < B; b++) {
+        e->x0[(size_t)f * ld0 + b] = obs_at(e, 0, e->idx[b], f);
+        e->x0[(size_t)f * ld0 + B + b] = obs_at(e, 1, e->idx[b], f);
+    }
+    for (int b = 0; b < B; b++) { e->abatch[b] = e->a[e->idx[b]]; e->rew[b] = e->r[e->idx[b]]; e->donef[b] = (float)e->done[e->idx[b]]; }
+    is_weights(e, e->idx, e->w_is);
+    /* forwards: online on [s ; sp] (or just s), target on sp */
+    const int ncon = e->hp.double_q ? 2 * B : B;
+    net_forward(e, e->p_on, e->act_on, e->x0, ld0, 0, ncon);
+    net_forward(e, e->p_tg, e->act_tg, e->x0, ld0, B, B);
+    /* TD, Huber, dL/dQ */
+    const float gamma = e->hp.gamma, invB = 1.0f / (float)B;
+    float lsum = 0.0f; float q[64], qt[64];
+    if (nA > 64) FAIL("n_actions > 64 unsupported in the twin");
+    const int lastv = e->last_val, lasta = e->hp.dueling ? e->last_adv : e->last_base;
+    for (int b = 0; b < B; b++) {
+        q_column(e, e->act_tg, B, b, qt); memcpy(e->qtg_sp + (size_t)b * nA, qt, nA * 4);
+        float qsp; int best;
+        if (e->hp.double_q) { q_column(e, e->act_on, ncon, B + b, q); memcpy(e->qon_sp + (size_t)b * nA, q, nA * 4); best = argmax_first(q, nA); qsp = qt[best]; }
+        else { best = argmax_first(qt, nA); qsp = qt[best]; memcpy(e->qon_sp + (size_t)b * nA, qt, nA * 4); }
+        e->best[b] = best;
+        float t1 = 1.0f - e->donef[b]; float t2 = t1 * gamma; float t3 = t2 * qsp; float y = e->rew[b] + t3;  /* :217 */
+        e->ytarget[b] = y;
+        q_column(e, e->act_on, ncon, b, q); memcpy(e->qon_s + (size_t)b * nA, q, nA * 4);
+        float td = q[e->abatch[b]] - y; e->td[b] = td;                                           /* :220-222 */
+        float x = e->w_is[b] * td; float ab = fabsf(x); float qd = ab < 1.0f ? ab : 1.0f; float lin = ab - qd;
+        float hl = (0.5f * qd) * qd + lin;                                                        /* helpers.jl:14-19 */
+        lsum = lsum + hl;
+        float cl = x < -1.0f ? -1.0f : (x > 1.0f ? 1.0f : x);
+        float g = (invB * cl) * e->w_is[b];
+        /* dL/d(last layer outputs) */
+        if (e->hp.dueling) {
+            e->dact[lastv][b] = g;
+            float gm = g / (float)nA;
+            for (int a = 0; a < nA; a++) e->dact[lasta][(size_t)a * B + b] = (a == e->abatch[b] ? g : 0.0f) - gm;
+        } else for (int a = 0; a < nA; a++) e->dact[lasta][(size_t)a * B + b] = (a == e->abatch[b] ? g : 0.0f);
+    }
+    e->loss = lsum / (float)B;                                                                    /* :223-224 */
+    /* backward (reverse layer order; val/adv first-layer input grads are joined into the base output grad) */
+    int joined = 0;
+    for (int i = e->nl - 1; i >= 0; i--) {
+        const RLayer* L = &e->L[i];
+        float* d = e->dact[i]; const float* y = e->act_on[i];
+        for (size_t t = 0; t < (size_t)L->out_feat; t++) for (int b = 0; b < B; b++) d[t * B + b] = dact_f(d[t * B + b], y[t * ncon + b], L->act);
+        const float* X = L->src < 0 ? e->x0 : e->act_on[L->src]; int ldx = L->src < 0 ? ld0 : ncon;
+        layer_backward_w(L, X, ldx, d, B, e->grad);
+        if (L->src >= 0) {
+            int src = L->src; size_t n = (size_t)e->L[src].out_feat * B;
+            int is_join = e->hp.dueling && src == e->last_base && L->stream != DQN_STREAM_BASE;
+            if (!is_join) layer_backward_x(L, e->p_on, d, B, e->dact[src]);
+            else {
+                /* processed in reverse order: the adv stream reaches the join first, then val; canonical
+                 * join order is dX_val + dX_adv */
+                float* tmp = (float*)malloc(n * 4); layer_backward_x(L, e->p_on, d, B, tmp);
+                if (!joined) { memcpy(e->dact[src], tmp, n * 4); joined = 1; }
+                else for (size_t t = 0; t < n; t++) e->dact[src][t] = tmp[t] + e->dact[src][t];
+                free(tmp);
+            }
+        }
+    }
+    /* globalnorm (helpers.jl:38-46) and Flux Adam */
+    float gn = 0.0f; for (size_t i = 0; i < e->P; i++) { float a = fabsf(e->grad[i]); if (a > gn) gn = a; }
+    e->gnorm = gn;
+    if (e->hp.adam_f64_scalars) {
+        const double b1 = e->hp.adam_beta1, b2 = e->hp.adam_beta2, eps = e->hp.adam_eps, eta = (double)e->hp.learning_rate;
+        const double omb1 = 1.0 - b1, omb2 = 1.0 - b2, c1 = 1.0 - e->bp1, c2 = 1.0 - e->bp2;
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < e->P; i++) {
+            double g = (double)e->grad[i];
+            double t1 = b1 * (double)e->m[i]; double t2 = omb1 * g; float mn = (float)(t1 + t2);
+            double u1 = b2 * (double)e->v[i]; double u2 = omb2 * g; double u3 = u2 * g; float vn = (float)(u1 + u3);
+            double mh = (double)mn / c1; double vh = (double)vn / c2; double den = sqrt(vh) + eps; double q1 = mh / den; float dl = (float)(q1 * eta);
+            e->m[i] = mn; e->v[i] = vn; e->p_on[i] = e->p_on[i] - dl;
+        }
+    } else {
+        const float b1 = (float)e->hp.adam_beta1, b2 = (float)e->hp.adam_beta2, eps = (float)e->hp.adam_eps, eta = e->hp.learning_rate;
+        const float omb1 = 1.0f - b1, omb2 = 1.0f - b2, c1 = 1.0f - (float)e->bp1, c2 = 1.0f - (float)e->bp2;
+        for (size_t i = 0; i < e->P; i++) {
+            float g = e->grad[i];
+            float t1 = b1 * e->m[i]; float t2 = omb1 * g; float mn = t1 + t2;
+            float u1 = b2 * e->v[i]; float u2 = omb2 * g; float u3 = u2 * g; float vn = u1 + u3;
+            float mh = mn / c1; float vh = vn / c2; float den = sqrtf(vh) + eps; float q1 = mh / den; float dl = q1 * eta;
+            e->m[i] = mn; e->v[i] = vn; e->p_on[i] = e->p_on[i] - dl;
+        }
+    }
+    e->bp1 *= e->hp.adam_beta1; e->bp2 *= e->hp.adam_beta2;
+    if (e->hp.prioritized_replay) if (ref_update_priorities(e, e->idx, e->td, B)) return -1;   /* :231-233, unweighted td */
+    if (loss_out) *loss_out = e->loss; if (gnorm_out) *gnorm_out = e->gnorm; if (td_out) memcpy(td_out, e->td, (size_t)B * 4);
+    return 0;
+}
+int ref_train_steps(ref_engine* e, int n, float* loss, float* gn) {
+    for (int i = 0; i < n; i++) if (ref_train_step(e, NULL, loss, gn, NULL)) return -1; return 0;
+}
+int ref_get_last_q(ref_engine* e, float* qs, float* qsp, float* qt, int32_t* best, float* y) {
+    size_t n = (size_t)e->B * e->nA * 4;
+    if (qs) memcpy(qs, e->qon_s, n); if (qsp) memcpy(qsp, e->qon_sp, n); if (qt) memcpy(qt, e->qtg_sp, n);
+    if (best) memcpy(best, e->best, (size_t)e->B * 4); if (y) memcpy(y, e->ytarget, (size_t)e->B * 4); return 0;
+}
+int ref_get_last_indices(ref_engine* e, int64_t* idx) { memcpy(idx, e->idx, (size_t)e->B * 8); return 0; }
+
+/* ---------------------------------------------------------------- policy (policy.jl:38-64) */
+int ref_forward(ref_engine* e, int which, const float* obs, int n, float* q_out) {
+    const float* P = which == DQN_NET_TARGET ? e->p_tg : e->p_on; int E = e->obs_elems;
+    float* x = (float*)malloc((size_t)E * n * 4); float* act[MAXL];
+    for (int f = 0; f < E; f++) for (int b = 0; b < n; b++) x[(size_t)f * n + b] = obs[(size_t)b * E + f];
+    for (int i = 0; i < e->nl; i++) act[i] = (float*)malloc((size_t)e->L[i].out_feat * n * 4);
+    net_forward(e, P, act, x, n, 0, n);
+    for (int b = 0; b < n; b++) q_column(e, act, n, b, q_out + (size_t)b * e->nA);
+    for (int i = 0; i < e->nl; i++) free(act[i]); free(x); return 0;
+}
+int ref_greedy_action(ref_engine* e, const float* obs, int n, int32_t* a_out) {
+    float* q = (float*)malloc((size_t)n * e->nA * 4); ref_forward(e, DQN_NET_ONLINE, obs, n, q);
+    for (int b = 0; b < n; b++) a_out[b] = argmax_first(q + (size_t)b * e->nA, e->nA);
+    free(q); return 0;
+}

@@ -1,0 +1,160 @@
+"""
+oracle/make_golden.py -- TEST INFRASTRUCTURE.  Run in the BUILD container only:
+
+    python oracle/make_golden.py
+
+Pins the NumPy oracle (oracle/dqn_oracle.py) with an INDEPENDENT torch-CPU
+float64 autograd implementation of the same reference math
+(src/solver.jl:191-236, src/dueling.jl:8-11, src/helpers.jl:14-19) and writes
+small fixtures (inputs + expected outputs) to tests/golden/*.npz.  The
+reference itself (Julia/Flux) cannot run in this image, so torch autograd is
+the strongest independent check available; the fixtures travel to the GPU box,
+torch-as-oracle does not need to.
+
+The torch model below shares NO code with dqn_oracle.py: conv via
+torch.nn.functional.conv2d on the flipped kernel (true convolution, NNlib
+default), gradients via autograd, Adam via torch.optim.Adam.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import dqn_oracle as O  # noqa: E402
+
+GOLD = os.path.join(HERE, "..", "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+torch.set_default_dtype(torch.float64)
+torch.set_num_threads(8)
+
+
+def torch_act(y, act):
+    return [lambda t: t, torch.relu, torch.tanh, torch.sigmoid][act](y)
+
+
+def torch_chain(layers, ps, x):
+    for i, l in enumerate(layers):
+        W, b = ps[2 * i], ps[2 * i + 1]
+        if l.kind == "dense":
+            x = torch_act(x.reshape(x.shape[0], -1) @ W + b, l.act)
+        else:
+            x = torch_act(F.conv2d(x, W.flip(2, 3), b, stride=(l.sh, l.sw)), l.act)
+    return x
+
+
+def torch_q(net, ps, x):
+    nb = 2 * len(net.base)
+    xb = torch_chain(net.base, ps[:nb], x)
+    if not net.dueling:
+        return xb
+    nv = 2 * len(net.val)
+    v = torch_chain(net.val, ps[nb:nb + nv], xb)
+    a = torch_chain(net.adv, ps[nb + nv:], xb)
+    a2 = torch_chain(net.adv, ps[nb + nv:], xb)  # evaluated twice, dueling.jl:10
+    return v + a - a2.mean(dim=1, keepdim=True)
+
+
+def torch_huber(x):
+    ab = x.abs()
+    q = torch.minimum(ab, torch.ones_like(ab))
+    return 0.5 * q * q + (ab - q)
+
+
+def torch_step(net, p_on, p_tg, batch, gamma, double_q, lr):
+    s, a, r, sp, done, w = [torch.tensor(np.asarray(t)) for t in batch]
+    s, sp, r, done, w = s.double(), sp.double(), r.double(), done.double(), w.double()
+    a = a.long()
+    pon = [torch.tensor(np.asarray(p, np.float64), requires_grad=True) for p in p_on]
+    ptg = [torch.tensor(np.asarray(p, np.float64)) for p in p_tg]
+    B = s.shape[0]
+    with torch.no_grad():
+        q_tg_sp = torch_q(net, ptg, sp)
+        if double_q:
+            q_on_sp = torch_q(net, pon, sp)
+            best = q_on_sp.argmax(dim=1)
+            qmax = q_tg_sp[torch.arange(B), best]
+        else:
+            qmax = q_tg_sp.max(dim=1).values
+        y = r + (1 - done) * gamma * qmax
+    q = torch_q(net, pon, s)
+    td = q[torch.arange(B), a] - y
+    loss = torch_huber(w * td).sum() / B
+    opt = torch.optim.Adam(pon, lr=float(np.float32(lr)), betas=(0.9, 0.999), eps=1e-8)
+    loss.backward()
+    grads = [p.grad.detach().numpy().copy() for p in pon]
+    opt.step()
+    return dict(loss=loss.item(), td=td.detach().numpy(), q=q.detach().numpy(), grads=grads,
+                new_params=[p.detach().numpy().copy() for p in pon])
+
+
+def make_case(name, net, B, seed, gamma, double_q, lr=1e-4, store_params=True, obs_scale=1.0):
+    rng = np.random.default_rng(seed)
+    p_on = O.init_params(net, seed=seed + 1)
+    p_tg = O.init_params(net, seed=seed + 2)
+    # non-zero biases so bias paths are exercised
+    for i in range(1, len(p_on), 2):
+        p_on[i] = (0.1 * rng.standard_normal(p_on[i].shape)).astype(np.float32)
+        p_tg[i] = (0.1 * rng.standard_normal(p_tg[i].shape)).astype(np.float32)
+    s = (obs_scale * rng.random((B,) + net.obs_shape)).astype(np.float32)
+    sp = (obs_scale * rng.random((B,) + net.obs_shape)).astype(np.float32)
+    a = rng.integers(0, net.n_actions, B).astype(np.int32)
+    r = rng.standard_normal(B).astype(np.float32) * 3  # large enough to hit the linear Huber branch
+    done = (rng.random(B) < 0.25).astype(np.float32)
+    w = (0.5 + rng.random(B)).astype(np.float32)
+    batch = (s, a, r, sp, done, w)
+
+    adam = O.AdamState([np.asarray(p, np.float64) for p in p_on], lr)
+    o = O.batch_train_step(net, p_on, p_tg, batch, gamma=gamma, double_q=double_q, adam=adam, dtype=np.float64)
+    t = torch_step(net, p_on, p_tg, batch, gamma, double_q, lr)
+
+    def rel(x, y):
+        return float(np.max(np.abs(np.asarray(x) - np.asarray(y))) / (1e-300 + np.max(np.abs(np.asarray(y)))))
+
+    errs = dict(loss=rel(o["loss"], t["loss"]), td=rel(o["td"], t["td"]), q=rel(o["q"], t["q"]),
+                grads=max(rel(g, h) for g, h in zip(o["grads"], t["grads"])),
+                new_params=max(rel(g, h) for g, h in zip(o["new_params"], t["new_params"])))
+    print(f"[{name}] oracle-vs-torch-autograd relative errors: {errs}")
+    assert max(errs.values()) < 1e-9, errs
+
+    out = dict(B=B, seed=seed, gamma=gamma, double_q=int(double_q), lr=lr,
+               s=s, a=a, r=r, sp=sp, done=done, w=w,
+               loss=np.float64(t["loss"]), td=t["td"], q=t["q"], grad_norm=np.float64(max(np.abs(g).max() for g in t["grads"])),
+               grad_sums=np.array([g.sum() for g in t["grads"]]),
+               grad_abs_sums=np.array([np.abs(g).sum() for g in t["grads"]]),
+               newp_sums=np.array([p.sum() for p in t["new_params"]]))
+    if store_params:
+        out["p_on"] = O.Network.flatten(p_on)
+        out["p_tg"] = O.Network.flatten(p_tg)
+        out["grads"] = O.Network.flatten(t["grads"])
+        out["new_params"] = O.Network.flatten(t["new_params"])
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+
+
+def nets():
+    R, I, T = O.ACT_RELU, O.ACT_IDENTITY, O.ACT_TANH
+    # config 1: README.md:38 Chain(Dense(2,32), Dense(32,4)) + dueling (nothing shared)
+    mlp = [O.Dense(2, 32, I), O.Dense(32, 4, I)]
+    b, v, a = O.create_dueling_network(mlp)
+    yield "cfg1_gridworld_mlp_dueling", O.Network((2,), b, v, a), 32, 11, 0.95, True, True, 10.0
+    # test/runtests.jl:45-61 style: flattenbatch, Dense(100,8,tanh), Dense(8,4); plain DQN
+    yield "testmdp_mlp_tanh_plain", O.Network((4, 5, 5), [O.Dense(100, 8, T), O.Dense(8, 4, I)]), 32, 12, 0.99, False, True, 1.0
+    # shrunk conv dueling net (exercises stride>1, true-convolution flip, rectangular maps)
+    conv = [O.Conv(4, 3, 8, R, 2), O.Conv(3, 8, 16, R, 1), O.Dense(16 * 3 * 4, 32, R), O.Dense(32, 5, I)]
+    b, v, a = O.create_dueling_network(conv)
+    yield "small_conv_dueling", O.Network((3, 12, 14), b, v, a), 16, 13, 0.99, True, True, 1.0
+    yield "small_conv_plain_single_q", O.Network((3, 12, 14), conv), 16, 14, 0.9, False, True, 1.0
+    # config 2: Nature-DQN dueling on 84x84x4, B=4 (params regenerated from the seed in tests)
+    nat = [O.Conv(8, 4, 32, R, 4), O.Conv(4, 32, 64, R, 2), O.Conv(3, 64, 64, R, 1),
+           O.Dense(3136, 512, R), O.Dense(512, 4, I)]
+    b, v, a = O.create_dueling_network(nat)
+    yield "cfg2_nature_dueling_b4", O.Network((4, 84, 84), b, v, a), 4, 15, 0.99, True, False, 1.0
+
+
+if __name__ == "__main__":
+    for name, net, B, seed, gamma, dq, store, scale in nets():
+        make_case(name, net, B, seed, gamma, dq, store_params=store, obs_scale=scale)
+    print("fixtures written to", os.path.abspath(GOLD))

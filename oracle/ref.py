@@ -1,0 +1,88 @@
+"""
+oracle/ref.py -- TEST INFRASTRUCTURE.  ctypes loader for the CPU twin
+(oracle/_ref/libdqn_ref.so, built by oracle/Makefile from oracle/dqn_ref.c) and
+glue between the NumPy oracle's network description and the C-ABI structs.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import importlib.util
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+_spec = importlib.util.spec_from_file_location("dqn_abi_for_oracle", os.path.join(ROOT, "deepqlearning.jl_amd", "_abi.py"))
+abi = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(abi)
+
+LIB_PATH = os.path.join(HERE, "_ref", "libdqn_ref.so")
+_fns = None
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(os.path.join(HERE, "dqn_ref.c")):
+        subprocess.run(["make", "-C", HERE, "-B" if force else "-s"], check=True, capture_output=True)
+    return LIB_PATH
+
+
+def fns():
+    global _fns
+    if _fns is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        lib = C.CDLL(LIB_PATH)
+        _fns = abi.bind(lib, "ref_")
+        lib.ref_set_threads.argtypes = [C.c_void_p, C.c_int]
+        _fns["set_threads"] = lib.ref_set_threads
+    return _fns
+
+
+def layers_from_network(net):
+    """oracle.dqn_oracle.Network -> list[LayerDesc] (base, val, adv order)."""
+    out = []
+
+    def add(layers, stream):
+        for l in layers:
+            d = abi.LayerDesc()
+            d.act, d.stream = l.act, stream
+            if l.kind == "dense":
+                d.kind, d.n_in, d.n_out = abi.LAYER_DENSE, l.n_in, l.n_out
+            else:
+                d.kind = abi.LAYER_CONV
+                d.cin, d.cout, d.kh, d.kw, d.sh, d.sw = l.cin, l.cout, l.kh, l.kw, l.sh, l.sw
+            out.append(d)
+
+    add(net.base, abi.STREAM_BASE)
+    if net.dueling:
+        add(net.val, abi.STREAM_VAL)
+        add(net.adv, abi.STREAM_ADV)
+    return out
+
+
+def hparams_for(net, **kw):
+    shp = net.obs_shape
+    c, h, w = (shp if len(shp) == 3 else (int(np.prod(shp)), 1, 1))
+    base = dict(n_actions=net.n_actions, obs_c=c, obs_h=h, obs_w=w, dueling=int(net.dueling))
+    base.update(kw)
+    return abi.default_hparams(**base)
+
+
+def default_plan(layers, hp):
+    f = fns()
+    arr = (abi.LayerDesc * len(layers))(*layers)
+    plan = (abi.LayerPlan * len(layers))()
+    f["plan_default"](arr, len(layers), C.byref(hp), plan)
+    return [p.astuple() for p in plan]
+
+
+class Twin(abi.Handle):
+    def __init__(self, layers, hp, plan=None, threads=1):
+        super().__init__(fns(), layers, hp, plan=plan, is_twin=True)
+        self.f["set_threads"](self._h, threads)
+
+    def set_threads(self, n):
+        self.f["set_threads"](self._h, n)
