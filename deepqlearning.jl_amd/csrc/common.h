@@ -1,0 +1,117 @@
+// common.h -- shared host/device definitions of the MI355X DQN engine (gfx950 only).
+// Layout conventions:
+//   activations  Y[feature][column]  (batch-innermost, "FB"): 64-lane waves read 64 samples of one
+//                feature as one 256-B line; a 16-row MFMA M-tile is 16 samples.
+//   weights      W[k][n] (k = cin*kh*kw over the FLIPPED kernel, or n_in), n contiguous; bias[n].
+//   replay       rows s[cap][obs], sp[cap][obs] (f32 or u8), a int32, r f32, done u8,
+//                sum-tree tree[2*cap2] (root at 1, leaves at cap2+i).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dqn_mi355x.h"
+
+#define DQN_MAX_LAYERS 32
+#define DQN_MAX_ACTIONS 64
+
+struct LayerDev {
+    int kind, act, stream, src;       // src: producing layer, -1 = observation batch
+    int K, N;                          // forward contraction: K inputs per output, N output channels/units
+    int cin, cout, kh, kw, sh, sw, ih, iw, oh, ow;
+    int npos;                          // oh*ow (1 for dense)
+    int in_feat, out_feat;
+    int fwd_kc, dx_kc, dw_kc;          // summation-order plan (0 = unsplit)
+    unsigned long long w_off, b_off;   // offsets into the flat parameter vector
+};
+
+// device-resident mutable state of one engine (one instance in HBM)
+struct StepState {
+    unsigned long long sample_ctr;     // Philox counter: number of sample() calls so far
+    long long size;                    // _curr_size
+    double bp1, bp2;                   // Adam beta powers (Flux keeps them per array; identical for all)
+    unsigned int gnorm_bits;           // max |g| as uint bits (non-negative floats order like uints)
+    float loss;
+    float gnorm;
+    int err;                           // sticky device-side error code
+};
+
+static inline __host__ __device__ int dqn_nchunks(int K, int kc) { return (kc <= 0 || kc >= K) ? 1 : (K + kc - 1) / kc; }
+static inline __host__ __device__ int dqn_chunk_len(int K, int kc) { return (kc <= 0 || kc >= K) ? K : kc; }
+
+// ---- device math shared by VALU and MFMA epilogues (compiled with -ffp-contract=off: every fused
+//      multiply-add is an explicit fmaf / MFMA, never a compiler contraction)
+__device__ __forceinline__ float act_f(float y, int act) {
+    switch (act) {
+    case DQN_ACT_RELU: return y > 0.0f ? y : 0.0f;
+    case DQN_ACT_TANH: return (float)tanh((double)y);
+    case DQN_ACT_SIGMOID: return (float)(1.0 / (1.0 + exp(-(double)y)));
+    default: return y;
+    }
+}
+__device__ __forceinline__ float dact_f(float dy, float y, int act) {
+    switch (act) {
+    case DQN_ACT_RELU: return y > 0.0f ? dy : 0.0f;
+    case DQN_ACT_TANH: { float t = y * y; float u = 1.0f - t; return dy * u; }
+    case DQN_ACT_SIGMOID: { float u = 1.0f - y; float t = y * u; return dy * t; }
+    default: return dy;
+    }
+}
+__device__ __forceinline__ float prio_f(float td_abs, float eps, float alpha) {
+    float base = td_abs + eps;  // (td + eps)^alpha through Float64 (prioritized_experience_replay.jl:67,77)
+    return (float)pow((double)base, (double)alpha);
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// ---- kernel launchers (defined in the .hip files; all enqueue on `st` and never synchronise)
+struct TdArgs {
+    int B, nA, ncon, dueling, double_q, prioritized;
+    float gamma, prio_beta, prio_eps, prio_alpha;
+    long long cap2;
+    const long long* idx; const int* a; const float* r; const unsigned char* done; float* tree;
+    const float *on_val, *on_adv, *tg_val, *tg_adv;   // last-layer outputs (adv doubles as plain Q head)
+    int act_val, act_adv;                              // activations of the last layers
+    float *d_val, *d_adv;                              // dpre of the last layers, [*][B]
+    float *w_is, *td, *q_on_s, *q_on_sp, *q_tg_sp, *ytarget; int* best;
+    StepState* st;
+};
+
+void launch_gather_fb(hipStream_t st, const void* s_rows, const void* sp_rows, int obs_u8, int E, int B,
+                      const long long* idx, float* x0 /*[E][2B]*/);
+void launch_gather_rows(hipStream_t st, const void* rows, int obs_u8, int E, int n, const long long* idx, float* out /*[n][E]*/);
+void launch_transpose_obs(hipStream_t st, const float* obs /*[n][E]*/, int E, int n, float* x /*[E][n]*/);
+void launch_replay_commit(hipStream_t st, int n, long long start, long long cap, long long cap2, const int* a_in, const float* r_in,
+                          const unsigned char* done_in, const float* td_in, float eps, float alpha, int* a, float* r,
+                          unsigned char* done, float* tree, StepState* state);
+void launch_sample(hipStream_t st, int B, long long cap2, const float* tree, unsigned long long seed, long long* idx, StepState* state);
+void launch_batch_meta(hipStream_t st, int B, long long cap2, const long long* idx, const int* a, const float* r,
+                       const unsigned char* done, const float* tree, float beta, const StepState* state,
+                       int* a_out, float* r_out, float* done_out, float* w_out);
+void launch_update_priorities(hipStream_t st, int n, long long cap2, const long long* idx, const float* td, float eps, float alpha,
+                              float* tree, StepState* state, int tick_adam, double beta1, double beta2);
+
+void launch_valu_fwd(hipStream_t st, const LayerDev& L, const float* P, const float* X, int ldx, int col0, int ncols, float* Y, float* partials);
+void launch_valu_dw(hipStream_t st, const LayerDev& L, const float* X, int ldx, const float* dpre, int B, float* G, float* partials);
+void launch_valu_dx(hipStream_t st, const LayerDev& L, const float* P, const float* dpre, int B, float* out, float* partials,
+                    const float* addend, const float* ysrc, int ldy, int act_src);
+void launch_td(hipStream_t st, const TdArgs& a);
+void launch_adam(hipStream_t st, size_t P, float* p, float* m, float* v, const float* g, StepState* state, int f64mode,
+                 float lr, double b1, double b2, double eps, float gscale);
+void launch_q_columns(hipStream_t st, int n, int nA, int dueling, const float* val, const float* adv, float* q_out /*[n][nA]*/, int* argmax_out);
+void launch_convert_params(hipStream_t st, const LayerDev* layers_dev, int nl, const float* src, float* dst, int to_internal, size_t P);
+
+// MFMA path (nn_mfma.hip): returns false if the shape is not eligible (caller falls back to the VALU kernel,
+// which computes bit-identical values)
+bool launch_mfma_fwd(hipStream_t st, const LayerDev& L, const float* P, const float* X, int ldx, int col0, int ncols, float* Y, float* partials);
+bool launch_mfma_dw(hipStream_t st, const LayerDev& L, const float* X, int ldx, const float* dpre, int B, float* G, float* partials);
+bool launch_mfma_dx(hipStream_t st, const LayerDev& L, const float* P, const float* dpre, int B, float* out, float* partials,
+                    const float* addend, const float* ysrc, int ldy, int act_src);

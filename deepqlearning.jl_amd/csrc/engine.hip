@@ -1,0 +1,562 @@
+// engine.hip -- host side of libdqn_mi355x.so: one engine per GPU owns replay storage, sum-tree, online/target
+// parameters, gradients, Adam state, the batch arena and ONE HIP stream; the train step
+// (batch_train!, src/solver.jl:191-236) is enqueued as a fixed kernel sequence and replayed from a hipGraph.
+// C ABI: include/dqn_mi355x.h.  No CPU fallback exists: every entry point that computes needs the HIP device.
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+static thread_local char g_err[1024] = "";
+static int fail(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap); return -1;
+}
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail("HIP error %s at %s:%d (%s)", hipGetErrorString(_e), __FILE__, __LINE__, #x); } while (0)
+
+// ---------------------------------------------------------------- RCCL (dlopen'ed; only for data-parallel replicas)
+struct Id128 { char b[128]; };   // ncclUniqueId (passed by value)
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+static Rccl g_rccl;
+static int rccl_load() {
+    if (g_rccl.lib) return 0;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) { g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.lib) break; }
+    if (!g_rccl.lib) return fail("cannot dlopen librccl: %s", dlerror());
+    g_rccl.GetUniqueId = (int (*)(void*))dlsym(g_rccl.lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void**, int, Id128, int))dlsym(g_rccl.lib, "ncclCommInitRank");
+    g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(g_rccl.lib, "ncclAllReduce");
+    g_rccl.CommDestroy = (int (*)(void*))dlsym(g_rccl.lib, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce) return fail("librccl is missing nccl symbols");
+    return 0;
+}
+
+// ---------------------------------------------------------------- engine
+struct ProfEntry { const char* name; hipEvent_t a, b; };
+
+struct dqn_engine {
+    int device = 0; hipStream_t stream = nullptr;
+    int nl = 0; LayerDev L[DQN_MAX_LAYERS]; LayerDev* L_dev = nullptr;
+    dqn_hparams hp; int B = 0, nA = 0, E = 0, ncon = 0;
+    int last_base = -1, last_val = -1, last_adv = -1;
+    size_t P = 0;
+    float *p_on = nullptr, *p_tg = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr, *io_tmp = nullptr;
+    StepState* state = nullptr;
+    // replay
+    long long cap = 0, cap2 = 1, widx = 0, size = 0;
+    void *s_rows = nullptr, *sp_rows = nullptr; int* ra = nullptr; float* rr = nullptr; unsigned char* rdone = nullptr; float* tree = nullptr;
+    static const int ADD_CHUNK = 1024;
+    int* st_a = nullptr; float* st_r = nullptr; unsigned char* st_done = nullptr; float* st_td = nullptr;
+    // step workspace
+    long long* idx = nullptr; float* x0 = nullptr;
+    float *act_on[DQN_MAX_LAYERS] = {}, *act_tg[DQN_MAX_LAYERS] = {}, *dact[DQN_MAX_LAYERS] = {};
+    float *join_tmp = nullptr, *partials = nullptr; size_t partials_elems = 0;
+    float *w_is = nullptr, *td = nullptr, *q_on_s = nullptr, *q_on_sp = nullptr, *q_tg_sp = nullptr, *ytarget = nullptr; int* best = nullptr;
+    // get_batch seam workspace
+    float *gb_rows = nullptr, *gb_r = nullptr, *gb_done = nullptr, *gb_w = nullptr; int* gb_a = nullptr; long long* gb_idx = nullptr;
+    // policy workspace
+    int pol_n = 0; float *pol_obs = nullptr, *pol_x = nullptr, *pol_act[DQN_MAX_LAYERS] = {}, *pol_q = nullptr; int* pol_a = nullptr;
+    // graphs: [0] = step with sampling, [1] = step on given indices; with a communicator the step is cut in two
+    hipGraphExec_t g_full[2] = {nullptr, nullptr}, g_pre[2] = {nullptr, nullptr}, g_post = nullptr;
+    // comm
+    void* comm = nullptr; int rank = 0, world = 1;
+    // profiling
+    bool profiling = false; std::vector<ProfEntry> prof;
+};
+
+static void prof_begin(dqn_engine* e, const char* name) {
+    if (!e->profiling) return;
+    ProfEntry pe; pe.name = name; hipEventCreate(&pe.a); hipEventCreate(&pe.b); hipEventRecord(pe.a, e->stream); e->prof.push_back(pe);
+}
+static void prof_end(dqn_engine* e) { if (e->profiling) hipEventRecord(e->prof.back().b, e->stream); }
+#define RUN(e, name, call) do { prof_begin(e, name); call; prof_end(e); } while (0)
+
+extern "C" const char* dqn_last_error(void) { return g_err; }
+extern "C" int dqn_version(void) { return 1; }
+
+extern "C" int dqn_hparams_default(dqn_hparams* hp) {
+    memset(hp, 0, sizeof *hp);
+    hp->batch_size = 32; hp->obs_h = 1; hp->obs_w = 1; hp->obs_dtype = DQN_OBS_F32;
+    hp->learning_rate = 1e-4f; hp->adam_beta1 = 0.9; hp->adam_beta2 = 0.999; hp->adam_eps = 1e-8; hp->adam_f64_scalars = 1;
+    hp->gamma = 1.0f; hp->double_q = 1; hp->dueling = 1; hp->prioritized_replay = 1; hp->buffer_size = 1000;
+    hp->prio_alpha = 0.6f; hp->prio_beta = 0.4f; hp->prio_eps = 1e-3f; hp->seed = 0; hp->use_graph = 1; hp->use_mfma = 1;
+    return 0;
+}
+
+// geometry of every layer; shared by dqn_plan_default (host only) and dqn_engine_create
+static int build_layers(const dqn_layer_desc* d, int n, const dqn_hparams* hp, LayerDev* L, int* lb, int* lv, int* la, size_t* P) {
+    if (n <= 0 || n > DQN_MAX_LAYERS) return fail("bad layer count %d", n);
+    *lb = *lv = *la = -1; size_t off = 0;
+    for (int i = 0; i < n; i++) {
+        LayerDev& l = L[i]; memset(&l, 0, sizeof l);
+        l.kind = d[i].kind; l.act = d[i].act; l.stream = d[i].stream;
+        int prev;
+        if (l.stream == DQN_STREAM_BASE) prev = *lb; else if (l.stream == DQN_STREAM_VAL) prev = *lv >= 0 ? *lv : *lb; else prev = *la >= 0 ? *la : *lb;
+        l.src = prev;
+        int c, h, w;
+        if (prev < 0) { c = hp->obs_c; h = hp->obs_h; w = hp->obs_w; }
+        else if (L[prev].kind == DQN_LAYER_CONV) { c = L[prev].cout; h = L[prev].oh; w = L[prev].ow; }
+        else { c = L[prev].N; h = 1; w = 1; }
+        l.in_feat = c * h * w;
+        if (l.kind == DQN_LAYER_CONV) {
+            l.cin = d[i].cin; l.cout = d[i].cout; l.kh = d[i].kh; l.kw = d[i].kw; l.sh = d[i].sh; l.sw = d[i].sw;
+            if (l.cin != c) return fail("layer %d: conv cin %d != incoming channels %d", i, l.cin, c);
+            if (l.kh > h || l.kw > w || l.sh < 1 || l.sw < 1) return fail("layer %d: conv kernel/stride does not fit the %dx%d input", i, h, w);
+            l.ih = h; l.iw = w; l.oh = (h - l.kh) / l.sh + 1; l.ow = (w - l.kw) / l.sw + 1;
+            l.K = l.cin * l.kh * l.kw; l.N = l.cout; l.npos = l.oh * l.ow; l.out_feat = l.cout * l.npos;
+        } else if (l.kind == DQN_LAYER_DENSE) {
+            if (d[i].n_in != l.in_feat) return fail("layer %d: dense n_in %d != incoming features %d", i, d[i].n_in, l.in_feat);
+            l.K = d[i].n_in; l.N = d[i].n_out; l.npos = 1; l.out_feat = l.N; l.ih = l.iw = l.oh = l.ow = 1;
+        } else return fail("layer %d: unknown kind %d", i, l.kind);
+        l.w_off = off; off += (size_t)l.K * l.N; l.b_off = off; off += l.N;
+        if (l.stream == DQN_STREAM_BASE) *lb = i; else if (l.stream == DQN_STREAM_VAL) *lv = i; else *la = i;
+    }
+    *P = off;
+    if (hp->dueling) {
+        if (*lv < 0 || *la < 0 || L[*lv].out_feat != 1 || L[*la].out_feat != hp->n_actions)
+            return fail("DeepQLearningError: the qnetwork provided is incompatible with dueling");   // src/dueling.jl:47
+    } else if (*lb < 0 || L[*lb].out_feat != hp->n_actions) return fail("network output size != n_actions");
+    if (hp->n_actions > DQN_MAX_ACTIONS) return fail("n_actions > %d unsupported", DQN_MAX_ACTIONS);
+    return 0;
+}
+// The default summation-order plan.  Chosen for gfx950 occupancy: long forward contractions
+// are cut into ~512-element chunks, dense dX into 256-element chunks, conv dW into ~256-sample chunks.
+static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out) {
+    for (int i = 0; i < n; i++) {
+        out[i].fwd_kc = 0;
+        if (L[i].K > 1024) { const int s = (L[i].K + 511) / 512; int kc = (L[i].K + s - 1) / s; kc = (kc + 3) / 4 * 4; out[i].fwd_kc = kc; }
+        out[i].dx_kc = (L[i].kind == DQN_LAYER_DENSE && L[i].N > 512) ? 256 : 0;
+        out[i].dw_kc = 0;
+        if (L[i].kind == DQN_LAYER_CONV) { int ppc = 256 / B; if (ppc < 1) ppc = 1; out[i].dw_kc = ppc * B; }
+    }
+}
+extern "C" int dqn_plan_default(const dqn_layer_desc* layers, int n_layers, const dqn_hparams* hp, dqn_layer_plan* plan_out) {
+    LayerDev L[DQN_MAX_LAYERS]; int lb, lv, la; size_t P;
+    if (build_layers(layers, n_layers, hp, L, &lb, &lv, &la, &P)) return -1;
+    default_plan(L, n_layers, hp->batch_size, plan_out); return 0;
+}
+
+template <class T> static int dmalloc(T** p, size_t n) {
+    hipError_t e = hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T));
+    if (e != hipSuccess) return fail("hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
+    return 0;
+}
+#define DM(p, n) do { if (dmalloc(&(p), (n))) return -1; } while (0)
+
+extern "C" int dqn_engine_destroy(dqn_engine_t* e);
+
+extern "C" int dqn_engine_create(const dqn_layer_desc* layers, int n_layers, const dqn_hparams* hp, const dqn_layer_plan* plan, int device,
+                                 dqn_engine_t** out) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail("no HIP device: libdqn_mi355x has no CPU fallback (hipGetDeviceCount found %d devices)", ndev);
+    if (device < 0 || device >= ndev) return fail("device %d out of range (0..%d)", device, ndev - 1);
+    if (hp->batch_size < 1 || hp->batch_size > 1024) return fail("batch_size %d unsupported (1..1024)", hp->batch_size);
+    if (hp->buffer_size < hp->batch_size) return fail("AssertionError: r.max_size >= r.batch_size");   // ...replay.jl:84
+    dqn_engine* e = new dqn_engine();
+    e->device = device; e->hp = *hp; e->B = hp->batch_size; e->nA = hp->n_actions; e->E = hp->obs_c * hp->obs_h * hp->obs_w;
+    if (build_layers(layers, n_layers, hp, e->L, &e->last_base, &e->last_val, &e->last_adv, &e->P)) { delete e; return -1; }
+    e->nl = n_layers;
+    dqn_layer_plan defp[DQN_MAX_LAYERS];
+    if (!plan) { default_plan(e->L, e->nl, e->B, defp); plan = defp; }
+    for (int i = 0; i < e->nl; i++) {
+        e->L[i].fwd_kc = plan[i].fwd_kc; e->L[i].dx_kc = plan[i].dx_kc; e->L[i].dw_kc = plan[i].dw_kc;
+        if (e->L[i].kind == DQN_LAYER_CONV && e->L[i].dw_kc > 0 && e->L[i].dw_kc % e->B) { delete e; return fail("plan: conv dw_kc must be a multiple of batch_size"); }
+    }
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    const int B = e->B; e->ncon = hp->double_q ? 2 * B : B;
+    DM(e->L_dev, e->nl); HIPCHK(hipMemcpy(e->L_dev, e->L, sizeof(LayerDev) * e->nl, hipMemcpyHostToDevice));
+    DM(e->p_on, e->P); DM(e->p_tg, e->P); DM(e->grad, e->P); DM(e->m, e->P); DM(e->v, e->P); DM(e->io_tmp, e->P);
+    HIPCHK(hipMemset(e->p_on, 0, e->P * 4)); HIPCHK(hipMemset(e->p_tg, 0, e->P * 4)); HIPCHK(hipMemset(e->grad, 0, e->P * 4));
+    HIPCHK(hipMemset(e->m, 0, e->P * 4)); HIPCHK(hipMemset(e->v, 0, e->P * 4));
+    DM(e->state, 1);
+    StepState s0; memset(&s0, 0, sizeof s0); s0.bp1 = hp->adam_beta1; s0.bp2 = hp->adam_beta2;
+    HIPCHK(hipMemcpy(e->state, &s0, sizeof s0, hipMemcpyHostToDevice));
+    e->cap = hp->buffer_size; while (e->cap2 < e->cap) e->cap2 <<= 1;
+    const size_t osz = hp->obs_dtype == DQN_OBS_U8 ? 1 : 4;
+    { unsigned char *a = nullptr, *b = nullptr; DM(a, (size_t)e->cap * e->E * osz); DM(b, (size_t)e->cap * e->E * osz); e->s_rows = a; e->sp_rows = b; }
+    DM(e->ra, e->cap); DM(e->rr, e->cap); DM(e->rdone, e->cap); DM(e->tree, 2 * (size_t)e->cap2);
+    HIPCHK(hipMemset(e->tree, 0, 2 * (size_t)e->cap2 * 4));
+    DM(e->st_a, dqn_engine::ADD_CHUNK); DM(e->st_r, dqn_engine::ADD_CHUNK); DM(e->st_done, dqn_engine::ADD_CHUNK); DM(e->st_td, dqn_engine::ADD_CHUNK);
+    DM(e->idx, B); HIPCHK(hipMemset(e->idx, 0, B * 8)); DM(e->x0, (size_t)e->E * 2 * B);
+    size_t pmax = 1, jmax = 1;
+    for (int i = 0; i < e->nl; i++) {
+        const LayerDev& l = e->L[i];
+        DM(e->act_on[i], (size_t)l.out_feat * e->ncon); DM(e->act_tg[i], (size_t)l.out_feat * B); DM(e->dact[i], (size_t)l.out_feat * B);
+        const size_t sf = dqn_nchunks(l.K, l.fwd_kc); if (sf > 1) pmax = std::max(pmax, sf * (size_t)l.out_feat * e->ncon);
+        const size_t sw = dqn_nchunks(l.npos * B, l.dw_kc); if (sw > 1) pmax = std::max(pmax, sw * (size_t)(l.K + 1) * l.N);
+        const size_t sx = l.kind == DQN_LAYER_DENSE ? dqn_nchunks(l.N, l.dx_kc) : 1; if (sx > 1) pmax = std::max(pmax, sx * (size_t)l.in_feat * B);
+        jmax = std::max(jmax, (size_t)l.in_feat * B);
+    }
+    e->partials_elems = pmax; DM(e->partials, pmax); DM(e->join_tmp, jmax);
+    DM(e->w_is, B); DM(e->td, B); DM(e->q_on_s, (size_t)B * e->nA); DM(e->q_on_sp, (size_t)B * e->nA); DM(e->q_tg_sp, (size_t)B * e->nA);
+    DM(e->ytarget, B); DM(e->best, B);
+    DM(e->gb_rows, (size_t)B * e->E); DM(e->gb_r, B); DM(e->gb_done, B); DM(e->gb_w, B); DM(e->gb_a, B); DM(e->gb_idx, B);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    *out = e; return 0;
+}
+
+static void drop_graphs(dqn_engine* e) {
+    for (int i = 0; i < 2; i++) {
+        if (e->g_full[i]) { hipGraphExecDestroy(e->g_full[i]); e->g_full[i] = nullptr; }
+        if (e->g_pre[i]) { hipGraphExecDestroy(e->g_pre[i]); e->g_pre[i] = nullptr; }
+    }
+    if (e->g_post) { hipGraphExecDestroy(e->g_post); e->g_post = nullptr; }
+}
+static void free_policy_ws(dqn_engine* e) {
+    hipFree(e->pol_obs); hipFree(e->pol_x); hipFree(e->pol_q); hipFree(e->pol_a);
+    for (int i = 0; i < e->nl; i++) { hipFree(e->pol_act[i]); e->pol_act[i] = nullptr; }
+    e->pol_obs = e->pol_x = e->pol_q = nullptr; e->pol_a = nullptr; e->pol_n = 0;
+}
+extern "C" int dqn_engine_destroy(dqn_engine_t* e) {
+    if (!e) return 0;
+    hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    drop_graphs(e);
+    if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
+    hipFree(e->L_dev); hipFree(e->p_on); hipFree(e->p_tg); hipFree(e->grad); hipFree(e->m); hipFree(e->v); hipFree(e->io_tmp); hipFree(e->state);
+    hipFree(e->s_rows); hipFree(e->sp_rows); hipFree(e->ra); hipFree(e->rr); hipFree(e->rdone); hipFree(e->tree);
+    hipFree(e->st_a); hipFree(e->st_r); hipFree(e->st_done); hipFree(e->st_td); hipFree(e->idx); hipFree(e->x0);
+    for (int i = 0; i < e->nl; i++) { hipFree(e->act_on[i]); hipFree(e->act_tg[i]); hipFree(e->dact[i]); }
+    hipFree(e->join_tmp); hipFree(e->partials); hipFree(e->w_is); hipFree(e->td); hipFree(e->q_on_s); hipFree(e->q_on_sp); hipFree(e->q_tg_sp);
+    hipFree(e->ytarget); hipFree(e->best); hipFree(e->gb_rows); hipFree(e->gb_r); hipFree(e->gb_done); hipFree(e->gb_w); hipFree(e->gb_a); hipFree(e->gb_idx);
+    free_policy_ws(e);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e; return 0;
+}
+extern "C" int dqn_engine_get_plan(dqn_engine_t* e, dqn_layer_plan* p) {
+    for (int i = 0; i < e->nl; i++) { p[i].fwd_kc = e->L[i].fwd_kc; p[i].dx_kc = e->L[i].dx_kc; p[i].dw_kc = e->L[i].dw_kc; } return 0;
+}
+extern "C" int dqn_n_params(dqn_engine_t* e, size_t* n) { *n = e->P; return 0; }
+
+// ---------------------------------------------------------------- parameters
+static int put_vec(dqn_engine* e, const float* host, float* dev) {   // external layout -> internal
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(e->io_tmp, host, e->P * 4, hipMemcpyHostToDevice, e->stream));
+    launch_convert_params(e->stream, e->L_dev, e->nl, e->io_tmp, dev, 1, e->P);
+    HIPCHK(hipStreamSynchronize(e->stream)); return 0;
+}
+static int get_vec(dqn_engine* e, const float* dev, float* host) {
+    HIPCHK(hipSetDevice(e->device));
+    launch_convert_params(e->stream, e->L_dev, e->nl, dev, e->io_tmp, 0, e->P);
+    HIPCHK(hipMemcpyAsync(host, e->io_tmp, e->P * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream)); return 0;
+}
+extern "C" int dqn_set_params(dqn_engine_t* e, int which, const float* flat, size_t n) {
+    if (n != e->P) return fail("set_params: got %zu values, the network has %zu parameters", n, e->P);
+    return put_vec(e, flat, which == DQN_NET_TARGET ? e->p_tg : e->p_on);
+}
+extern "C" int dqn_get_params(dqn_engine_t* e, int which, float* flat, size_t n) {
+    if (n != e->P) return fail("get_params: size mismatch (%zu vs %zu)", n, e->P);
+    return get_vec(e, which == DQN_NET_TARGET ? e->p_tg : e->p_on, flat);
+}
+extern "C" int dqn_get_grads(dqn_engine_t* e, float* flat, size_t n) {
+    if (n != e->P) return fail("get_grads: size mismatch"); return get_vec(e, e->grad, flat);
+}
+extern "C" int dqn_sync_target(dqn_engine_t* e) {   // Flux.loadparams!(target_q, params(active_q)), src/solver.jl:142-145
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(e->p_tg, e->p_on, e->P * 4, hipMemcpyDeviceToDevice, e->stream)); return 0;
+}
+extern "C" int dqn_get_adam_state(dqn_engine_t* e, float* m, float* v, double* bp, size_t n) {
+    if (n != e->P) return fail("size mismatch");
+    if (m && get_vec(e, e->m, m)) return -1;
+    if (v && get_vec(e, e->v, v)) return -1;
+    if (bp) { StepState s; HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipMemcpy(&s, e->state, sizeof s, hipMemcpyDeviceToHost)); bp[0] = s.bp1; bp[1] = s.bp2; }
+    return 0;
+}
+extern "C" int dqn_set_adam_state(dqn_engine_t* e, const float* m, const float* v, const double* bp, size_t n) {
+    if (n != e->P) return fail("size mismatch");
+    if (m && put_vec(e, m, e->m)) return -1;
+    if (v && put_vec(e, v, e->v)) return -1;
+    if (bp) {
+        StepState s; HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipMemcpy(&s, e->state, sizeof s, hipMemcpyDeviceToHost));
+        s.bp1 = bp[0]; s.bp2 = bp[1]; HIPCHK(hipMemcpy(e->state, &s, sizeof s, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- replay
+extern "C" int dqn_replay_add(dqn_engine_t* e, const void* s, const int32_t* a, const float* r, const void* sp, const uint8_t* done,
+                              const float* td_err, int n) {
+    HIPCHK(hipSetDevice(e->device));
+    const size_t row = (size_t)e->E * (e->hp.obs_dtype == DQN_OBS_U8 ? 1 : 4);
+    for (int i = 0; i < n; i++) {
+        if (a[i] < 0 || a[i] >= e->nA) return fail("action index %d out of range 0..%d", a[i], e->nA - 1);
+        const float td = td_err ? td_err[i] : fabsf(r[i]);
+        if (!(td + e->hp.prio_eps > 0.0f)) return fail("AssertionError: td_err + r.eps > 0");   // ...replay.jl:66
+    }
+    for (int o = 0; o < n; o += dqn_engine::ADD_CHUNK) {
+        const int c = std::min(dqn_engine::ADD_CHUNK, n - o);
+        // rows go straight into their ring slots (<= 2 contiguous segments)
+        const long long first = std::min<long long>(c, e->cap - e->widx);
+        const char *sp0 = (const char*)sp + (size_t)o * row, *s0 = (const char*)s + (size_t)o * row;
+        HIPCHK(hipMemcpyAsync((char*)e->s_rows + (size_t)e->widx * row, s0, (size_t)first * row, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync((char*)e->sp_rows + (size_t)e->widx * row, sp0, (size_t)first * row, hipMemcpyHostToDevice, e->stream));
+        if (first < c) {
+            HIPCHK(hipMemcpyAsync(e->s_rows, s0 + (size_t)first * row, (size_t)(c - first) * row, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync(e->sp_rows, sp0 + (size_t)first * row, (size_t)(c - first) * row, hipMemcpyHostToDevice, e->stream));
+        }
+        HIPCHK(hipMemcpyAsync(e->st_a, a + o, (size_t)c * 4, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->st_r, r + o, (size_t)c * 4, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->st_done, done + o, (size_t)c, hipMemcpyHostToDevice, e->stream));
+        if (td_err) HIPCHK(hipMemcpyAsync(e->st_td, td_err + o, (size_t)c * 4, hipMemcpyHostToDevice, e->stream));
+        launch_replay_commit(e->stream, c, e->widx, e->cap, e->cap2, e->st_a, e->st_r, e->st_done, td_err ? e->st_td : nullptr, e->hp.prio_eps,
+                             e->hp.prio_alpha, e->ra, e->rr, e->rdone, e->tree, e->state);
+        HIPCHK(hipStreamSynchronize(e->stream));   // the staging buffers are reused by the next chunk
+        e->widx = (e->widx + c) % e->cap; e->size = std::min(e->cap, e->size + c);
+    }
+    return 0;
+}
+extern "C" int dqn_replay_size(dqn_engine_t* e, int64_t* cur, int64_t* cap) { if (cur) *cur = e->size; if (cap) *cap = e->cap; return 0; }
+extern "C" int dqn_replay_get_priorities(dqn_engine_t* e, float* prio, int64_t n) {
+    HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(prio, e->tree + e->cap2, (size_t)n * 4, hipMemcpyDeviceToHost)); return 0;
+}
+static int check_idx(dqn_engine* e, const int64_t* idx, int n) {
+    for (int i = 0; i < n; i++) if (idx[i] < 0 || idx[i] >= e->size) return fail("BoundsError: index %lld outside 0..%lld", (long long)idx[i], (long long)e->size - 1);
+    return 0;
+}
+extern "C" int dqn_replay_sample(dqn_engine_t* e, int64_t* idx_out) {
+    if (e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");   // ...replay.jl:83
+    HIPCHK(hipSetDevice(e->device));
+    launch_sample(e->stream, e->B, e->cap2, e->tree, e->hp.seed, e->idx, e->state);
+    if (idx_out) { HIPCHK(hipMemcpyAsync(idx_out, e->idx, (size_t)e->B * 8, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); }
+    return 0;
+}
+extern "C" int dqn_replay_get_batch(dqn_engine_t* e, const int64_t* idx, float* s, int32_t* a, float* r, float* sp, float* done, float* w) {
+    if (check_idx(e, idx, e->B)) return -1;
+    HIPCHK(hipSetDevice(e->device));
+    const int B = e->B; const size_t rb = (size_t)B * e->E * 4; const int u8 = e->hp.obs_dtype == DQN_OBS_U8;
+    HIPCHK(hipMemcpyAsync(e->gb_idx, idx, (size_t)B * 8, hipMemcpyHostToDevice, e->stream));
+    if (s) { launch_gather_rows(e->stream, e->s_rows, u8, e->E, B, e->gb_idx, e->gb_rows); HIPCHK(hipMemcpyAsync(s, e->gb_rows, rb, hipMemcpyDeviceToHost, e->stream)); }
+    if (sp) { launch_gather_rows(e->stream, e->sp_rows, u8, e->E, B, e->gb_idx, e->gb_rows); HIPCHK(hipMemcpyAsync(sp, e->gb_rows, rb, hipMemcpyDeviceToHost, e->stream)); }
+    launch_batch_meta(e->stream, B, e->cap2, e->gb_idx, e->ra, e->rr, e->rdone, e->tree, e->hp.prio_beta, e->state, e->gb_a, e->gb_r, e->gb_done, e->gb_w);
+    if (a) HIPCHK(hipMemcpyAsync(a, e->gb_a, B * 4, hipMemcpyDeviceToHost, e->stream));
+    if (r) HIPCHK(hipMemcpyAsync(r, e->gb_r, B * 4, hipMemcpyDeviceToHost, e->stream));
+    if (done) HIPCHK(hipMemcpyAsync(done, e->gb_done, B * 4, hipMemcpyDeviceToHost, e->stream));
+    if (w) HIPCHK(hipMemcpyAsync(w, e->gb_w, B * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream)); return 0;
+}
+static int check_state_err(dqn_engine* e) {
+    StepState s; HIPCHK(hipMemcpy(&s, e->state, sizeof s, hipMemcpyDeviceToHost));
+    if (s.err == 1) return fail("AssertionError: td_err + r.eps > 0");
+    if (s.err == 2) return fail("AssertionError: all(new_priorities .> 0f0)");
+    return 0;
+}
+extern "C" int dqn_update_priorities(dqn_engine_t* e, const int64_t* idx, const float* td, int n) {
+    if (check_idx(e, idx, n)) return -1;
+    HIPCHK(hipSetDevice(e->device));
+    for (int o = 0; o < n; o += e->B) {   // the device buffers hold B entries
+        const int c = std::min(e->B, n - o);
+        HIPCHK(hipMemcpyAsync(e->gb_idx, idx + o, (size_t)c * 8, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->gb_w, td + o, (size_t)c * 4, hipMemcpyHostToDevice, e->stream));
+        launch_update_priorities(e->stream, c, e->cap2, e->gb_idx, e->gb_w, e->hp.prio_eps, e->hp.prio_alpha, e->tree, e->state, 0, 1.0, 1.0);
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    return check_state_err(e);
+}
+
+// ---------------------------------------------------------------- the train step
+static void fwd_layer(dqn_engine* e, const LayerDev& l, const float* P, const float* X, int ldx, int col0, int ncols, float* Y, const char* name) {
+    prof_begin(e, name);
+    if (!(e->hp.use_mfma && launch_mfma_fwd(e->stream, l, P, X, ldx, col0, ncols, Y, e->partials)))
+        launch_valu_fwd(e->stream, l, P, X, ldx, col0, ncols, Y, e->partials);
+    prof_end(e);
+}
+static const char* lname(dqn_engine* e, const char* op, int kind, int i) {
+    if (!e->profiling) return "";
+    static char buf[DQN_MAX_LAYERS * 8][24]; static int slot = 0;
+    char* b = buf[(slot++) % (DQN_MAX_LAYERS * 8)]; snprintf(b, 24, "%s_%s%d", op, kind == DQN_LAYER_CONV ? "conv" : "dense", i); return b;
+}
+enum { PH_ALL = 0, PH_PRE = 1, PH_POST = 2 };
+static void enqueue_step(dqn_engine* e, bool sample, int phase) {
+    const int B = e->B, ncon = e->ncon, ld0 = 2 * B; hipStream_t st = e->stream;
+    if (phase != PH_POST) {
+        if (sample) RUN(e, "sample", launch_sample(st, B, e->cap2, e->tree, e->hp.seed, e->idx, e->state));
+        RUN(e, "gather", launch_gather_fb(st, e->s_rows, e->sp_rows, e->hp.obs_dtype == DQN_OBS_U8, e->E, B, e->idx, e->x0));
+        for (int i = 0; i < e->nl; i++) {   // online net on [s ; sp] (src/solver.jl:210,220), target net on sp (:211)
+            const LayerDev& l = e->L[i];
+            fwd_layer(e, l, e->p_on, l.src < 0 ? e->x0 : e->act_on[l.src], l.src < 0 ? ld0 : ncon, 0, ncon, e->act_on[i], lname(e, "fwd_on", l.kind, i));
+            fwd_layer(e, l, e->p_tg, l.src < 0 ? e->x0 : e->act_tg[l.src], l.src < 0 ? ld0 : B, l.src < 0 ? B : 0, B, e->act_tg[i], lname(e, "fwd_tg", l.kind, i));
+        }
+        TdArgs t; memset(&t, 0, sizeof t);
+        t.B = B; t.nA = e->nA; t.ncon = ncon; t.dueling = e->hp.dueling; t.double_q = e->hp.double_q; t.prioritized = e->hp.prioritized_replay;
+        t.gamma = e->hp.gamma; t.prio_beta = e->hp.prio_beta; t.prio_eps = e->hp.prio_eps; t.prio_alpha = e->hp.prio_alpha; t.cap2 = e->cap2;
+        t.idx = e->idx; t.a = e->ra; t.r = e->rr; t.done = e->rdone; t.tree = e->tree;
+        const int lq = e->hp.dueling ? e->last_adv : e->last_base;
+        t.on_adv = e->act_on[lq]; t.tg_adv = e->act_tg[lq]; t.act_adv = e->L[lq].act; t.d_adv = e->dact[lq];
+        if (e->hp.dueling) { t.on_val = e->act_on[e->last_val]; t.tg_val = e->act_tg[e->last_val]; t.act_val = e->L[e->last_val].act; t.d_val = e->dact[e->last_val]; }
+        t.w_is = e->w_is; t.td = e->td; t.q_on_s = e->q_on_s; t.q_on_sp = e->q_on_sp; t.q_tg_sp = e->q_tg_sp; t.ytarget = e->ytarget; t.best = e->best; t.st = e->state;
+        RUN(e, "td_huber", launch_td(st, t));
+        bool joined = false;
+        for (int i = e->nl - 1; i >= 0; i--) {   // backward of the online net on the s columns
+            const LayerDev& l = e->L[i];
+            const float* X = l.src < 0 ? e->x0 : e->act_on[l.src]; const int ldx = l.src < 0 ? ld0 : ncon;
+            prof_begin(e, lname(e, "dw", l.kind, i));
+            if (!(e->hp.use_mfma && launch_mfma_dw(st, l, X, ldx, e->dact[i], B, e->grad, e->partials))) launch_valu_dw(st, l, X, ldx, e->dact[i], B, e->grad, e->partials);
+            prof_end(e);
+            if (l.src < 0) continue;
+            const int src = l.src; const bool is_join = e->hp.dueling && src == e->last_base && l.stream != DQN_STREAM_BASE;
+            float* out = e->dact[src]; const float *addend = nullptr, *ysrc = e->act_on[src];
+            if (is_join && !joined) { out = e->join_tmp; ysrc = nullptr; joined = true; }     // first stream to arrive: raw dX
+            else if (is_join) addend = e->join_tmp;                                             // second: dX_val + dX_adv, then act'
+            prof_begin(e, lname(e, "dx", l.kind, i));
+            if (!(e->hp.use_mfma && launch_mfma_dx(st, l, e->p_on, e->dact[i], B, out, e->partials, addend, ysrc, ncon, e->L[src].act)))
+                launch_valu_dx(st, l, e->p_on, e->dact[i], B, out, e->partials, addend, ysrc, ncon, e->L[src].act);
+            prof_end(e);
+        }
+    }
+    if (phase != PH_PRE) {
+        RUN(e, "adam", launch_adam(st, e->P, e->p_on, e->m, e->v, e->grad, e->state, e->hp.adam_f64_scalars, e->hp.learning_rate, e->hp.adam_beta1,
+                                   e->hp.adam_beta2, e->hp.adam_eps, e->world > 1 ? 1.0f / (float)e->world : 1.0f));
+        RUN(e, "update_prio", launch_update_priorities(st, e->hp.prioritized_replay ? B : 0, e->cap2, e->idx, e->td, e->hp.prio_eps, e->hp.prio_alpha,
+                                                       e->tree, e->state, 1, e->hp.adam_beta1, e->hp.adam_beta2));
+    }
+}
+static int capture(dqn_engine* e, bool sample, int phase, hipGraphExec_t* out) {
+    hipGraph_t g;
+    HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+    enqueue_step(e, sample, phase);
+    HIPCHK(hipStreamEndCapture(e->stream, &g));
+    HIPCHK(hipGraphInstantiate(out, g, nullptr, nullptr, 0));
+    HIPCHK(hipGraphDestroy(g)); return 0;
+}
+static int allreduce_grads(dqn_engine* e) {
+    const int rc = g_rccl.AllReduce(e->grad, e->grad, e->P, /*ncclFloat*/ 7, /*ncclSum*/ 0, e->comm, e->stream);
+    if (rc) return fail("ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    return 0;
+}
+static int run_step(dqn_engine* e, bool sample) {
+    const int gi = sample ? 0 : 1;
+    if (e->world > 1) {
+        if (e->hp.use_graph && !e->profiling) {
+            if (!e->g_pre[gi] && capture(e, sample, PH_PRE, &e->g_pre[gi])) return -1;
+            if (!e->g_post && capture(e, sample, PH_POST, &e->g_post)) return -1;
+            HIPCHK(hipGraphLaunch(e->g_pre[gi], e->stream));
+            if (allreduce_grads(e)) return -1;
+            HIPCHK(hipGraphLaunch(e->g_post, e->stream));
+        } else { enqueue_step(e, sample, PH_PRE); if (allreduce_grads(e)) return -1; enqueue_step(e, sample, PH_POST); }
+        return 0;
+    }
+    if (e->hp.use_graph && !e->profiling) {
+        if (!e->g_full[gi] && capture(e, sample, PH_ALL, &e->g_full[gi])) return -1;
+        HIPCHK(hipGraphLaunch(e->g_full[gi], e->stream));
+    } else enqueue_step(e, sample, PH_ALL);
+    return 0;
+}
+static int fetch_scalars(dqn_engine* e, float* loss, float* gn) {
+    StepState s; HIPCHK(hipMemcpyAsync(&s, e->state, sizeof s, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream));
+    if (s.err == 2) return fail("AssertionError: all(new_priorities .> 0f0)");
+    if (loss) *loss = s.loss;
+    if (gn) { float g; memcpy(&g, &s.gnorm_bits, 4); *gn = g; }
+    return 0;
+}
+extern "C" int dqn_train_step(dqn_engine_t* e, const int64_t* idx, float* loss, float* grad_norm, float* td_out) {
+    HIPCHK(hipSetDevice(e->device));
+    if (e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
+    if (idx) { if (check_idx(e, idx, e->B)) return -1; HIPCHK(hipMemcpyAsync(e->idx, idx, (size_t)e->B * 8, hipMemcpyHostToDevice, e->stream)); }
+    if (run_step(e, idx == nullptr)) return -1;
+    if (td_out) HIPCHK(hipMemcpyAsync(td_out, e->td, (size_t)e->B * 4, hipMemcpyDeviceToHost, e->stream));
+    if (loss || grad_norm || td_out) return fetch_scalars(e, loss, grad_norm);
+    return 0;
+}
+extern "C" int dqn_train_steps(dqn_engine_t* e, int n, float* loss, float* grad_norm) {
+    HIPCHK(hipSetDevice(e->device));
+    if (e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
+    for (int i = 0; i < n; i++) if (run_step(e, true)) return -1;
+    if (loss || grad_norm) return fetch_scalars(e, loss, grad_norm);
+    return 0;
+}
+extern "C" int dqn_get_last_q(dqn_engine_t* e, float* qs, float* qsp, float* qt, int32_t* best, float* y) {
+    HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream));
+    const size_t n = (size_t)e->B * e->nA * 4;
+    if (qs) HIPCHK(hipMemcpy(qs, e->q_on_s, n, hipMemcpyDeviceToHost));
+    if (qsp) HIPCHK(hipMemcpy(qsp, e->q_on_sp, n, hipMemcpyDeviceToHost));
+    if (qt) HIPCHK(hipMemcpy(qt, e->q_tg_sp, n, hipMemcpyDeviceToHost));
+    if (best) HIPCHK(hipMemcpy(best, e->best, (size_t)e->B * 4, hipMemcpyDeviceToHost));
+    if (y) HIPCHK(hipMemcpy(y, e->ytarget, (size_t)e->B * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int dqn_get_last_indices(dqn_engine_t* e, int64_t* idx) {
+    HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(idx, e->idx, (size_t)e->B * 8, hipMemcpyDeviceToHost)); return 0;
+}
+
+// ---------------------------------------------------------------- policy (src/policy.jl:38-64)
+static int policy_ws(dqn_engine* e, int n) {
+    if (n <= e->pol_n) return 0;
+    HIPCHK(hipStreamSynchronize(e->stream)); free_policy_ws(e);
+    size_t need = 1;   // split-K partials of the widest forward at n columns
+    for (int i = 0; i < e->nl; i++) { const size_t sf = dqn_nchunks(e->L[i].K, e->L[i].fwd_kc); if (sf > 1) need = std::max(need, sf * (size_t)e->L[i].out_feat * n); }
+    if (need > e->partials_elems) { drop_graphs(e); hipFree(e->partials); e->partials = nullptr; DM(e->partials, need); e->partials_elems = need; }
+    DM(e->pol_obs, (size_t)n * e->E); DM(e->pol_x, (size_t)n * e->E); DM(e->pol_q, (size_t)n * e->nA); DM(e->pol_a, n);
+    for (int i = 0; i < e->nl; i++) DM(e->pol_act[i], (size_t)e->L[i].out_feat * n);
+    e->pol_n = n; return 0;
+}
+static int policy_forward(dqn_engine* e, int which, const float* obs, int n) {
+    if (n < 1) return fail("n must be >= 1");
+    HIPCHK(hipSetDevice(e->device));
+    if (policy_ws(e, n)) return -1;
+    HIPCHK(hipMemcpyAsync(e->pol_obs, obs, (size_t)n * e->E * 4, hipMemcpyHostToDevice, e->stream));
+    launch_transpose_obs(e->stream, e->pol_obs, e->E, n, e->pol_x);
+    const float* P = which == DQN_NET_TARGET ? e->p_tg : e->p_on;
+    // the policy workspace has leading dimension n (not pol_n): layers are dense in the batch column
+    for (int i = 0; i < e->nl; i++) { const LayerDev& l = e->L[i]; fwd_layer(e, l, P, l.src < 0 ? e->pol_x : e->pol_act[l.src], n, 0, n, e->pol_act[i], "policy_fwd"); }
+    const int lq = e->hp.dueling ? e->last_adv : e->last_base;
+    launch_q_columns(e->stream, n, e->nA, e->hp.dueling, e->hp.dueling ? e->pol_act[e->last_val] : nullptr, e->pol_act[lq], e->pol_q, e->pol_a);
+    return 0;
+}
+extern "C" int dqn_forward(dqn_engine_t* e, int which, const float* obs, int n, float* q_out) {
+    if (policy_forward(e, which, obs, n)) return -1;
+    HIPCHK(hipMemcpyAsync(q_out, e->pol_q, (size_t)n * e->nA * 4, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); return 0;
+}
+extern "C" int dqn_greedy_action(dqn_engine_t* e, const float* obs, int n, int32_t* a_out) {
+    if (policy_forward(e, DQN_NET_ONLINE, obs, n)) return -1;
+    HIPCHK(hipMemcpyAsync(a_out, e->pol_a, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); return 0;
+}
+
+// ---------------------------------------------------------------- data-parallel replicas
+extern "C" int dqn_comm_unique_id(void* id128) { if (rccl_load()) return -1; const int rc = g_rccl.GetUniqueId(id128); return rc ? fail("ncclGetUniqueId failed (%d)", rc) : 0; }
+extern "C" int dqn_comm_init(dqn_engine_t* e, const void* id128, int rank, int world) {
+    if (rccl_load()) return -1;
+    HIPCHK(hipSetDevice(e->device));
+    Id128 id; memcpy(id.b, id128, 128);
+    const int rc = g_rccl.CommInitRank(&e->comm, world, id, rank);
+    if (rc) return fail("ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    e->rank = rank; e->world = world; drop_graphs(e); return 0;
+}
+
+// ---------------------------------------------------------------- misc
+extern "C" int dqn_stream_sync(dqn_engine_t* e) { HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream)); return 0; }
+extern "C" int dqn_stream_handle(dqn_engine_t* e, void** s) { *s = (void*)e->stream; return 0; }
+extern "C" int dqn_profile_step(dqn_engine_t* e, int max_entries, const char** names, float* ms, int* n_entries) {
+    HIPCHK(hipSetDevice(e->device));
+    if (e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->profiling = true; e->prof.clear();
+    const int rc = run_step(e, true);
+    e->profiling = false;
+    if (rc) return -1;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int n = 0;
+    for (auto& pe : e->prof) {
+        float t = 0; hipEventElapsedTime(&t, pe.a, pe.b);
+        if (n < max_entries) { names[n] = pe.name; ms[n] = t; n++; }
+        hipEventDestroy(pe.a); hipEventDestroy(pe.b);
+    }
+    e->prof.clear(); *n_entries = n; return 0;
+}

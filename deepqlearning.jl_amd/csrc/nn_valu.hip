@@ -1,0 +1,281 @@
+// nn_valu.hip -- canonical-order VALU kernels of the batch_train! inner loop (src/solver.jl:191-236).
+// Each output element is ONE k-ascending fp32 fmaf chain per plan chunk -- the numerics gfx950's fp32 MFMA
+// produces -- so these kernels are bit-identical to nn_mfma.hip and serve (a) every shape the MFMA tiles do not
+// cover (N or batch not a multiple of 16, tiny heads) and (b) as the on-device cross-check of the MFMA path.
+// Threads are laid out with the batch column fastest, so activation loads are coalesced 256-B lines and the
+// weight is a wave-uniform (scalar) load.
+#include "common.h"
+
+// ------------------------------------------------------------------ split-K reduction epilogues
+// mode 0: forward      Y = act(sum_s part + bias[n])             (n = e / per_n)
+// mode 1: dX           out = dact(sum_s part (+ addend), ysrc)   (element e=(feat,b); ysrc has leading dim ldy)
+// mode 2: dW / db      out = sum_s part
+__global__ void k_reduce(const float* __restrict__ part, int S, size_t elems, int mode, const float* __restrict__ bias, int per_n, int act,
+                         const float* __restrict__ addend, const float* __restrict__ ysrc, int B, int ldy, float* __restrict__ out) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= elems) return;
+    float tot = part[e];
+    for (int s = 1; s < S; s++) tot = tot + part[(size_t)s * elems + e];
+    if (mode == 0) tot = act_f(tot + bias[e / per_n], act);
+    else if (mode == 1) {
+        if (addend) tot = addend[e] + tot;
+        if (ysrc) tot = dact_f(tot, ysrc[(e / B) * ldy + (e % B)], act);
+    }
+    out[e] = tot;
+}
+static void launch_reduce(hipStream_t st, const float* part, int S, size_t elems, int mode, const float* bias, int per_n, int act,
+                          const float* addend, const float* ysrc, int B, int ldy, float* out) {
+    hipLaunchKernelGGL(k_reduce, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, part, S, elems, mode, bias, per_n, act, addend, ysrc, B, ldy, out);
+}
+// exported for the MFMA path
+void launch_reduce_pub(hipStream_t st, const float* part, int S, size_t elems, int mode, const float* bias, int per_n, int act,
+                       const float* addend, const float* ysrc, int B, int ldy, float* out) {
+    launch_reduce(st, part, S, elems, mode, bias, per_n, act, addend, ysrc, B, ldy, out);
+}
+
+// ------------------------------------------------------------------ forward: Y[n][pos][col] = act(sum_k X[xb(pos)+koff(k)][col] W[k][n] + b[n])
+__global__ void k_valu_fwd(LayerDev L, const float* __restrict__ P, const float* __restrict__ X, int ldx, int col0, int ncols, int S, int kc,
+                           float* __restrict__ out) {
+    const size_t per_s = (size_t)L.N * L.npos * ncols;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= per_s * S) return;
+    const int s = (int)(t / per_s); const size_t e = t % per_s;
+    const int col = (int)(e % ncols); const int pos = (int)((e / ncols) % L.npos); const int n = (int)(e / ((size_t)ncols * L.npos));
+    const float* W = P + L.w_off;
+    int xb = 0;
+    if (L.kind == DQN_LAYER_CONV) { const int oy = pos / L.ow, ox = pos % L.ow; xb = oy * L.sh * L.iw + ox * L.sw; }
+    const int k0 = s * kc, k1 = min(L.K, k0 + kc);
+    float acc = 0.0f;
+    if (L.kind == DQN_LAYER_CONV) {
+        const int khw = L.kh * L.kw;
+        int ci = k0 / khw, ky = (k0 / L.kw) % L.kh, kx = k0 % L.kw;
+        for (int k = k0; k < k1; k++) {
+            const int koff = (ci * L.ih + ky) * L.iw + kx;
+            acc = fmaf(X[(size_t)(xb + koff) * ldx + col0 + col], W[(size_t)k * L.N + n], acc);
+            if (++kx == L.kw) { kx = 0; if (++ky == L.kh) { ky = 0; ++ci; } }
+        }
+    } else {
+        for (int k = k0; k < k1; k++) acc = fmaf(X[(size_t)k * ldx + col0 + col], W[(size_t)k * L.N + n], acc);
+    }
+    if (S == 1) out[e] = act_f(acc + P[L.b_off + n], L.act);
+    else out[(size_t)s * per_s + e] = acc;
+}
+void launch_valu_fwd(hipStream_t st, const LayerDev& L, const float* P, const float* X, int ldx, int col0, int ncols, float* Y, float* partials) {
+    const int S = dqn_nchunks(L.K, L.fwd_kc), kc = dqn_chunk_len(L.K, L.fwd_kc);
+    const size_t per_s = (size_t)L.N * L.npos * ncols, tot = per_s * S;
+    hipLaunchKernelGGL(k_valu_fwd, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, L, P, X, ldx, col0, ncols, S, kc, S == 1 ? Y : partials);
+    if (S > 1) launch_reduce(st, partials, S, per_s, 0, P + L.b_off, L.npos * ncols, L.act, nullptr, nullptr, 0, 0, Y);
+}
+
+// ------------------------------------------------------------------ dW[k][n] = sum_{(pos,b)} X[xb(pos)+koff(k)][b] dpre[n][pos][b];  db[n] = sum dpre
+// thread = (chunk, k, n) for k < K, plus a virtual row k == K that accumulates the bias gradient.
+__global__ void k_valu_dw(LayerDev L, const float* __restrict__ X, int ldx, const float* __restrict__ dpre, int B, int S, int kc, float* __restrict__ out) {
+    const size_t per_s = (size_t)(L.K + 1) * L.N;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= per_s * S) return;
+    const int s = (int)(t / per_s); const size_t e = t % per_s;
+    const int n = (int)(e % L.N), k = (int)(e / L.N);
+    const int KK = L.npos * B, j0 = s * kc, j1 = min(KK, j0 + kc);
+    int koff = k;
+    if (L.kind == DQN_LAYER_CONV && k < L.K) { const int khw = L.kh * L.kw; const int ci = k / khw, ky = (k / L.kw) % L.kh, kx = k % L.kw; koff = (ci * L.ih + ky) * L.iw + kx; }
+    float acc = 0.0f;
+    int pos = j0 / B, b = j0 % B;
+    for (int j = j0; j < j1; j++) {
+        const float d = dpre[((size_t)n * L.npos + pos) * B + b];
+        if (k < L.K) {
+            int xb = 0; if (L.kind == DQN_LAYER_CONV) { const int oy = pos / L.ow, ox = pos % L.ow; xb = oy * L.sh * L.iw + ox * L.sw; }
+            acc = fmaf(X[(size_t)(xb + koff) * ldx + b], d, acc);
+        } else acc = acc + d;
+        if (++b == B) { b = 0; ++pos; }
+    }
+    out[(size_t)s * per_s + e] = acc;
+}
+// G layout: dW at w_off ([K][N]) immediately followed by db at b_off ([N]) == rows 0..K of a (K+1) x N matrix.
+void launch_valu_dw(hipStream_t st, const LayerDev& L, const float* X, int ldx, const float* dpre, int B, float* G, float* partials) {
+    const int KK = L.npos * B, S = dqn_nchunks(KK, L.dw_kc), kc = dqn_chunk_len(KK, L.dw_kc);
+    const size_t per_s = (size_t)(L.K + 1) * L.N, tot = per_s * S;
+    float* dst = G + L.w_off;
+    hipLaunchKernelGGL(k_valu_dw, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, L, X, ldx, dpre, B, S, kc, S == 1 ? dst : partials);
+    if (S > 1) launch_reduce(st, partials, S, per_s, 2, nullptr, 1, 0, nullptr, nullptr, 0, 0, dst);
+}
+
+// ------------------------------------------------------------------ dX[feat][b]  (then dact of the producing layer, optionally + addend at the dueling join)
+__global__ void k_valu_dx(LayerDev L, const float* __restrict__ P, const float* __restrict__ dpre, int B, int S, int kc, float* __restrict__ out,
+                          const float* __restrict__ addend, const float* __restrict__ ysrc, int ldy, int act_src) {
+    const size_t per_s = (size_t)L.in_feat * B;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= per_s * S) return;
+    const int s = (int)(t / per_s); const size_t e = t % per_s;
+    const int b = (int)(e % B); const int feat = (int)(e / B);
+    const float* W = P + L.w_off;
+    float acc = 0.0f;
+    if (L.kind == DQN_LAYER_DENSE) {
+        const int n0 = s * kc, n1 = min(L.N, n0 + kc);
+        for (int n = n0; n < n1; n++) acc = fmaf(dpre[(size_t)n * B + b], W[(size_t)feat * L.N + n], acc);
+    } else {
+        const int hw = L.ih * L.iw; const int ci = feat / hw, iy = (feat % hw) / L.iw, ix = feat % L.iw;
+        for (int ky = 0; ky < L.kh; ky++) {
+            const int ty = iy - ky; if (ty < 0 || ty % L.sh) continue; const int oy = ty / L.sh; if (oy >= L.oh) continue;
+            for (int kx = 0; kx < L.kw; kx++) {
+                const int tx = ix - kx; if (tx < 0 || tx % L.sw) continue; const int ox = tx / L.sw; if (ox >= L.ow) continue;
+                const float* wr = W + (size_t)((ci * L.kh + ky) * L.kw + kx) * L.N; const int pos = oy * L.ow + ox;
+                for (int co = 0; co < L.N; co++) acc = fmaf(dpre[((size_t)co * L.npos + pos) * B + b], wr[co], acc);
+            }
+        }
+    }
+    if (S == 1) {
+        if (addend) acc = addend[e] + acc;
+        if (ysrc) acc = dact_f(acc, ysrc[(size_t)feat * ldy + b], act_src);
+        out[e] = acc;
+    } else out[(size_t)s * per_s + e] = acc;
+}
+void launch_valu_dx(hipStream_t st, const LayerDev& L, const float* P, const float* dpre, int B, float* out, float* partials,
+                    const float* addend, const float* ysrc, int ldy, int act_src) {
+    const int S = L.kind == DQN_LAYER_DENSE ? dqn_nchunks(L.N, L.dx_kc) : 1, kc = dqn_chunk_len(L.N, L.dx_kc);
+    const size_t per_s = (size_t)L.in_feat * B, tot = per_s * S;
+    hipLaunchKernelGGL(k_valu_dx, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, L, P, dpre, B, S, kc, S == 1 ? out : partials, addend, ysrc, ldy, act_src);
+    if (S > 1) launch_reduce(st, partials, S, per_s, 1, nullptr, 1, act_src, addend, ysrc, B, ldy, out);
+}
+
+// ------------------------------------------------------------------ dueling reduce + argmax + Bellman target + TD + Huber + dL/dQ  (K4+K5+K6)
+//   Q = (val .+ adv) .- mean(adv, dims=1)                      src/dueling.jl:10
+//   best = argmax(Qonline(sp)[:, b]) (first max)               src/solver.jl:212
+//   y = r + (1 - done) * gamma * Qtarget(sp)[best]             src/solver.jl:213-217
+//   td = Q(s)[a] - y ; loss = sum(huber(w .* td)) / B          src/solver.jl:220-224, src/helpers.jl:14-19
+// One workgroup; the loss is summed by one lane in ascending b (canonical order).
+__device__ __forceinline__ void q_column(int nA, int dueling, const float* val, const float* adv, int ld, int col, float* q) {
+    if (!dueling) { for (int a = 0; a < nA; a++) q[a] = adv[(size_t)a * ld + col]; return; }
+    const float v = val[col];
+    float sum = adv[col];
+    for (int a = 1; a < nA; a++) sum = sum + adv[(size_t)a * ld + col];
+    const float mean = sum / (float)nA;
+    for (int a = 0; a < nA; a++) q[a] = (v + adv[(size_t)a * ld + col]) - mean;
+}
+__global__ __launch_bounds__(1024) void k_td(TdArgs A) {
+    extern __shared__ float hl[];   // B floats
+    const int B = A.B, nA = A.nA;
+    const float invB = 1.0f / (float)B;
+    const float total = A.tree[1];
+    const long long size = A.st->size;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const long long j = A.idx[b];
+        const int act = A.a[j]; const float rew = A.r[j]; const float dn = (float)A.done[j];
+        const float p = A.tree[A.cap2 + j] / total; const float xw = (float)size * p;
+        const float w = (float)pow((double)xw, -(double)A.prio_beta);     // IS weight, ...replay.jl:101-102
+        A.w_is[b] = w;
+        float q[DQN_MAX_ACTIONS], qt[DQN_MAX_ACTIONS];
+        q_column(nA, A.dueling, A.tg_val, A.tg_adv, B, b, qt);
+        for (int a = 0; a < nA; a++) A.q_tg_sp[(size_t)b * nA + a] = qt[a];
+        int best = 0; float qsp;
+        if (A.double_q) {
+            q_column(nA, A.dueling, A.on_val, A.on_adv, A.ncon, B + b, q);
+            for (int a = 0; a < nA; a++) A.q_on_sp[(size_t)b * nA + a] = q[a];
+            for (int a = 1; a < nA; a++) if (q[a] > q[best]) best = a;
+        } else {
+            for (int a = 0; a < nA; a++) A.q_on_sp[(size_t)b * nA + a] = qt[a];
+            for (int a = 1; a < nA; a++) if (qt[a] > qt[best]) best = a;
+        }
+        qsp = qt[0]; for (int a = 1; a < nA; a++) if (a == best) qsp = qt[a];
+        A.best[b] = best;
+        const float t1 = 1.0f - dn; const float t2 = t1 * A.gamma; const float t3 = t2 * qsp; const float y = rew + t3;
+        A.ytarget[b] = y;
+        q_column(nA, A.dueling, A.on_val, A.on_adv, A.ncon, b, q);
+        float qsa = q[0];
+        for (int a = 0; a < nA; a++) { A.q_on_s[(size_t)b * nA + a] = q[a]; if (a == act) qsa = q[a]; }
+        const float td = qsa - y; A.td[b] = td;
+        const float x = w * td; const float ab = fabsf(x); const float qd = ab < 1.0f ? ab : 1.0f; const float lin = ab - qd;
+        hl[b] = (0.5f * qd) * qd + lin;
+        const float cl = x < -1.0f ? -1.0f : (x > 1.0f ? 1.0f : x);
+        const float g = (invB * cl) * w;
+        if (A.dueling) {
+            A.d_val[b] = dact_f(g, A.on_val[b], A.act_val);
+            const float gm = g / (float)nA;
+            for (int a = 0; a < nA; a++) A.d_adv[(size_t)a * B + b] = dact_f((a == act ? g : 0.0f) - gm, A.on_adv[(size_t)a * A.ncon + b], A.act_adv);
+        } else
+            for (int a = 0; a < nA; a++) A.d_adv[(size_t)a * B + b] = dact_f(a == act ? g : 0.0f, A.on_adv[(size_t)a * A.ncon + b], A.act_adv);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float lsum = 0.0f;
+        for (int b = 0; b < B; b++) lsum = lsum + hl[b];
+        A.st->loss = lsum / (float)B;
+        A.st->gnorm_bits = 0u;       // reset the max-abs accumulator for this step's Adam kernel
+    }
+}
+void launch_td(hipStream_t st, const TdArgs& a) {
+    int bs = ((a.B + 63) / 64) * 64; if (bs > 1024) bs = 1024;
+    hipLaunchKernelGGL(k_td, dim3(1), dim3(bs), (size_t)a.B * sizeof(float), st, a);
+}
+
+// Q columns for the policy path (src/policy.jl:38-64): q_out[n][nA], argmax (first max)
+__global__ void k_q_columns(int n, int nA, int dueling, const float* __restrict__ val, const float* __restrict__ adv, float* __restrict__ q_out, int* __restrict__ amax) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    float q[DQN_MAX_ACTIONS];
+    q_column(nA, dueling, val, adv, n, b, q);
+    int best = 0;
+    for (int a = 0; a < nA; a++) { if (q_out) q_out[(size_t)b * nA + a] = q[a]; if (q[a] > q[best]) best = a; }
+    if (amax) amax[b] = best;
+}
+void launch_q_columns(hipStream_t st, int n, int nA, int dueling, const float* val, const float* adv, float* q_out, int* argmax_out) {
+    hipLaunchKernelGGL(k_q_columns, dim3((n + 63) / 64), dim3(64), 0, st, n, nA, dueling, val, adv, q_out, argmax_out);
+}
+
+// ------------------------------------------------------------------ globalnorm (helpers.jl:38-46) + Flux Adam (solver.jl:66,228), fused, HBM-bound:
+// per element 16 B read (p,m,v,g) + 12 B written.  f64mode reproduces Flux 0.14's Float64 eta/beta/eps scalars.
+__global__ __launch_bounds__(256) void k_adam(size_t P, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
+                                              StepState* state, int f64mode, float lr, double b1, double b2, double eps, float gscale) {
+    const double c1 = 1.0 - state->bp1, c2 = 1.0 - state->bp2;
+    float gmax = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (size_t)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        if (gscale != 1.0f) gi = gi * gscale;
+        gmax = fmaxf(gmax, fabsf(gi));
+        float mn, vn, dl;
+        if (f64mode) {
+            const double gd = (double)gi;
+            const double t1 = b1 * (double)m[i]; const double t2 = (1.0 - b1) * gd; mn = (float)(t1 + t2);
+            const double u1 = b2 * (double)v[i]; const double u2 = (1.0 - b2) * gd; const double u3 = u2 * gd; vn = (float)(u1 + u3);
+            const double mh = (double)mn / c1; const double vh = (double)vn / c2; const double den = sqrt(vh) + eps; const double q1 = mh / den;
+            dl = (float)(q1 * (double)lr);
+        } else {
+            const float fb1 = (float)b1, fb2 = (float)b2;
+            const float t1 = fb1 * m[i]; const float t2 = (1.0f - fb1) * gi; mn = t1 + t2;
+            const float u1 = fb2 * v[i]; const float u2 = (1.0f - fb2) * gi; const float u3 = u2 * gi; vn = u1 + u3;
+            const float mh = mn / (1.0f - (float)state->bp1); const float vh = vn / (1.0f - (float)state->bp2); const float den = sqrtf(vh) + (float)eps; const float q1 = mh / den;
+            dl = q1 * lr;
+        }
+        m[i] = mn; v[i] = vn; p[i] = p[i] - dl;
+    }
+    // wave max (64 lanes) then one atomic per wave; max is order-independent, so this is exact
+    for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(&state->gnorm_bits, __float_as_uint(gmax));
+}
+void launch_adam(hipStream_t st, size_t P, float* p, float* m, float* v, const float* g, StepState* state, int f64mode, float lr,
+                 double b1, double b2, double eps, float gscale) {
+    size_t blocks = (P + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, st, P, p, m, v, g, state, f64mode, lr, b1, b2, eps, gscale);
+}
+
+// ------------------------------------------------------------------ parameter layout conversion (Flux.params order <-> internal [K][N], conv kernels flipped)
+__global__ void k_convert_params(const LayerDev* __restrict__ layers, int nl, const float* __restrict__ src, float* __restrict__ dst, int to_internal, size_t P) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // i indexes the EXTERNAL vector
+    if (i >= P) return;
+    size_t j = i;
+    for (int l = 0; l < nl; l++) {
+        const LayerDev& L = layers[l];
+        if (i >= L.w_off && i < L.b_off) {
+            if (L.kind == DQN_LAYER_CONV) {
+                size_t e = i - L.w_off;            // ((co*cin + ci)*kh + yy)*kw + xx, yy/xx un-flipped
+                const int xx = (int)(e % L.kw); e /= L.kw; const int yy = (int)(e % L.kh); e /= L.kh; const int ci = (int)(e % L.cin); const int co = (int)(e / L.cin);
+                const int ky = L.kh - 1 - yy, kx = L.kw - 1 - xx;
+                j = L.w_off + ((size_t)(ci * L.kh + ky) * L.kw + kx) * L.cout + co;
+            }
+            break;
+        }
+    }
+    if (to_internal) dst[j] = src[i]; else dst[i] = src[j];
+}
+void launch_convert_params(hipStream_t st, const LayerDev* layers_dev, int nl, const float* src, float* dst, int to_internal, size_t P) {
+    hipLaunchKernelGGL(k_convert_params, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, layers_dev, nl, src, dst, to_internal, P);
+}

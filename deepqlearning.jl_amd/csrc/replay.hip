@@ -1,0 +1,174 @@
+// replay.hip -- PrioritizedReplayBuffer on the device (gfx950).
+//   add_exp!            src/prioritized_experience_replay.jl:65-74   -> k_replay_commit (rows are copied straight into the ring by the host API)
+//   sample              src/prioritized_experience_replay.jl:82-87   -> k_sample (stratified sum-tree descent, Philox4x32-10)
+//   get_batch           src/prioritized_experience_replay.jl:89-104  -> k_gather_fb (train path, batch-innermost), k_gather_rows + k_batch_meta (parity seam)
+//   update_priorities!  src/prioritized_experience_replay.jl:76-80   -> k_update_priorities
+// The sum-tree is canonical: every internal node is exactly f32(left + right) of its current children, so the root
+// (the IS-weight denominator, :101) does not depend on update history and the CPU twin reproduces it bit for bit.
+#include "common.h"
+
+// ------------------------------------------------------------------ gather (HBM-bound)
+// 64 features x 64 columns per workgroup through a padded LDS tile: reads are 256-B row segments of the sampled
+// transitions (coalesced along the feature axis), writes are 256-B lines of the batch-innermost arena X0[f][2B]
+// (columns 0..B-1 = s, B..2B-1 = sp).  Algorithmic bytes: 2*B*E*sizeof(obs) read + 2*B*E*4 written.
+__global__ __launch_bounds__(256) void k_gather_fb(const void* __restrict__ s_rows, const void* __restrict__ sp_rows, int u8, int E, int B,
+                                                   const long long* __restrict__ idx, float* __restrict__ x0) {
+    __shared__ float tile[64][65];
+    const int f0 = blockIdx.x * 64, c0 = blockIdx.y * 64, lane = threadIdx.x & 63, w = threadIdx.x >> 6, ld = 2 * B;
+#pragma unroll 4
+    for (int p = 0; p < 16; p++) {
+        const int cl = p * 4 + w, c = c0 + cl, f = f0 + lane;
+        float v = 0.0f;
+        if (c < ld && f < E) {
+            const long long row = idx[c < B ? c : c - B];
+            const void* base = c < B ? s_rows : sp_rows;
+            if (u8) v = (float)((const unsigned char*)base)[row * E + f] / 255.0f;  // test/test_env.jl:59
+            else v = ((const float*)base)[row * E + f];
+        }
+        tile[cl][lane] = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int p = 0; p < 16; p++) {
+        const int fl = p * 4 + w, f = f0 + fl, c = c0 + lane;
+        if (f < E && c < ld) x0[(size_t)f * ld + c] = tile[lane][fl];
+    }
+}
+void launch_gather_fb(hipStream_t st, const void* s_rows, const void* sp_rows, int obs_u8, int E, int B, const long long* idx, float* x0) {
+    dim3 grid((E + 63) / 64, (2 * B + 63) / 64);
+    hipLaunchKernelGGL(k_gather_fb, grid, dim3(256), 0, st, s_rows, sp_rows, obs_u8, E, B, idx, x0);
+}
+
+__global__ void k_gather_rows(const void* __restrict__ rows, int u8, int E, const long long* __restrict__ idx, float* __restrict__ out) {
+    const long long row = idx[blockIdx.y];
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < E; f += gridDim.x * blockDim.x) {
+        float v = u8 ? (float)((const unsigned char*)rows)[row * E + f] / 255.0f : ((const float*)rows)[row * E + f];
+        out[(size_t)blockIdx.y * E + f] = v;
+    }
+}
+void launch_gather_rows(hipStream_t st, const void* rows, int obs_u8, int E, int n, const long long* idx, float* out) {
+    dim3 grid((E + 255) / 256 < 64 ? (E + 255) / 256 : 64, n);
+    hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, st, rows, obs_u8, E, idx, out);
+}
+
+// obs[n][E] (host layout) -> x[E][n] (batch-innermost) for the policy path (src/policy.jl:38-64)
+__global__ void k_transpose_obs(const float* __restrict__ obs, int E, int n, float* __restrict__ x) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)E * n) return;
+    const int b = (int)(t % n); const size_t f = t / n;
+    x[t] = obs[(size_t)b * E + f];
+}
+void launch_transpose_obs(hipStream_t st, const float* obs, int E, int n, float* x) {
+    const size_t tot = (size_t)E * n;
+    hipLaunchKernelGGL(k_transpose_obs, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, obs, E, n, x);
+}
+
+// ------------------------------------------------------------------ add_exp! (metadata + priorities + tree)
+__global__ __launch_bounds__(1024) void k_replay_commit(int n, long long start, long long cap, long long cap2, const int* __restrict__ a_in,
+                                                        const float* __restrict__ r_in, const unsigned char* __restrict__ done_in,
+                                                        const float* __restrict__ td_in, float eps, float alpha, int* a, float* r,
+                                                        unsigned char* done, float* tree, StepState* state) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const long long slot = (start + i) % cap;
+        a[slot] = a_in[i]; r[slot] = r_in[i]; done[slot] = done_in[i] ? 1 : 0;
+        const float td = td_in ? td_in[i] : fabsf(r_in[i]);   // default td_err = abs(expe.r), :65
+        if (!(td + eps > 0.0f)) state->err = 1;                // @assert td_err + eps > 0, :66
+        tree[cap2 + slot] = prio_f(td, eps, alpha);
+    }
+    __syncthreads();
+    // the written leaves form <= 2 contiguous ranges (ring wrap); rebuild their ancestors level by level
+    long long lo[2], hi[2]; int nr = 1;
+    if (n >= cap) { lo[0] = 0; hi[0] = cap - 1; }
+    else {
+        const long long s0 = start % cap, e0 = (start + n - 1) % cap;
+        if (e0 >= s0) { lo[0] = s0; hi[0] = e0; } else { lo[0] = s0; hi[0] = cap - 1; lo[1] = 0; hi[1] = e0; nr = 2; }
+    }
+    for (long long width = cap2; width > 1; width >>= 1) {          // width = number of nodes on the child level
+        for (int q = 0; q < nr; q++) {
+            const long long a0 = (width + lo[q]) >> 1, a1 = (width + hi[q]) >> 1;
+            for (long long node = a0 + threadIdx.x; node <= a1; node += blockDim.x) tree[node] = tree[2 * node] + tree[2 * node + 1];
+            lo[q] >>= 1; hi[q] >>= 1;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { long long s = state->size + n; state->size = s > cap ? cap : s; }
+}
+void launch_replay_commit(hipStream_t st, int n, long long start, long long cap, long long cap2, const int* a_in, const float* r_in,
+                          const unsigned char* done_in, const float* td_in, float eps, float alpha, int* a, float* r, unsigned char* done,
+                          float* tree, StepState* state) {
+    hipLaunchKernelGGL(k_replay_commit, dim3(1), dim3(1024), 0, st, n, start, cap, cap2, a_in, r_in, done_in, td_in, eps, alpha, a, r, done, tree, state);
+}
+
+// ------------------------------------------------------------------ sample
+__global__ __launch_bounds__(1024) void k_sample(int B, long long cap2, const float* __restrict__ tree, unsigned long long seed,
+                                                 long long* __restrict__ idx, StepState* state) {
+    const unsigned long long ctr = state->sample_ctr;
+    const long long size = state->size;
+    const float total = tree[1], seg = total / (float)B;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)i, 0x5A4D504Cu};
+        philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), c);
+        const float u = (float)(c[0] >> 8) * (1.0f / 16777216.0f);
+        float t = ((float)i + u) * seg;
+        long long node = 1;
+        while (node < cap2) {
+            const float l = tree[2 * node], rg = tree[2 * node + 1];
+            if (t < l || !(rg > 0.0f)) node = 2 * node; else { t -= l; node = 2 * node + 1; }
+        }
+        long long leaf = node - cap2; if (leaf >= size) leaf = size - 1;
+        idx[i] = leaf;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) state->sample_ctr = ctr + 1;
+}
+void launch_sample(hipStream_t st, int B, long long cap2, const float* tree, unsigned long long seed, long long* idx, StepState* state) {
+    int bs = ((B + 63) / 64) * 64; if (bs > 1024) bs = 1024;
+    hipLaunchKernelGGL(k_sample, dim3(1), dim3(bs), 0, st, B, cap2, tree, seed, idx, state);
+}
+
+// ------------------------------------------------------------------ get_batch scalars + IS weights (parity seam)
+__global__ void k_batch_meta(int B, long long cap2, const long long* __restrict__ idx, const int* __restrict__ a, const float* __restrict__ r,
+                             const unsigned char* __restrict__ done, const float* __restrict__ tree, float beta, const StepState* state,
+                             int* a_out, float* r_out, float* done_out, float* w_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const long long j = idx[i];
+    a_out[i] = a[j]; r_out[i] = r[j]; done_out[i] = (float)done[j];
+    const float p = tree[cap2 + j] / tree[1];                   // p = prio ./ sum(prio[1:n]), :101
+    const float x = (float)state->size * p;                     // n .* p
+    w_out[i] = (float)pow((double)x, -(double)beta);            // .^ (-beta), :102
+}
+void launch_batch_meta(hipStream_t st, int B, long long cap2, const long long* idx, const int* a, const float* r, const unsigned char* done,
+                       const float* tree, float beta, const StepState* state, int* a_out, float* r_out, float* done_out, float* w_out) {
+    hipLaunchKernelGGL(k_batch_meta, dim3((B + 255) / 256), dim3(256), 0, st, B, cap2, idx, a, r, done, tree, beta, state, a_out, r_out, done_out, w_out);
+}
+
+// ------------------------------------------------------------------ update_priorities! (+ Adam beta-power tick at the end of a train step)
+__global__ __launch_bounds__(1024) void k_update_priorities(int n, long long cap2, const long long* __restrict__ idx, const float* __restrict__ td,
+                                                            float eps, float alpha, float* tree, StepState* state, int tick_adam, double beta1,
+                                                            double beta2) {
+    __shared__ long long sidx[1024];
+    const int i = threadIdx.x;
+    if (i < n) sidx[i] = idx[i];
+    __syncthreads();
+    long long node = 0;
+    if (i < n) {
+        bool last = true;                                        // duplicates: the last write wins (r._priorities[indices] = ..., :79)
+        for (int j = i + 1; j < n; j++) if (sidx[j] == sidx[i]) { last = false; break; }
+        const float p = prio_f(fabsf(td[i]), eps, alpha);
+        if (!(p > 0.0f)) state->err = 2;                         // @assert all(new_priorities .> 0f0), :78
+        if (last) tree[cap2 + sidx[i]] = p;
+        node = (cap2 + sidx[i]) >> 1;
+    }
+    __syncthreads();
+    for (long long width = cap2; width > 1; width >>= 1) {      // one tree level per barrier; equal parents write equal values
+        if (i < n) { tree[node] = tree[2 * node] + tree[2 * node + 1]; node >>= 1; }
+        __syncthreads();
+    }
+    if (tick_adam && i == 0) { state->bp1 = state->bp1 * beta1; state->bp2 = state->bp2 * beta2; }
+}
+void launch_update_priorities(hipStream_t st, int n, long long cap2, const long long* idx, const float* td, float eps, float alpha,
+                              float* tree, StepState* state, int tick_adam, double beta1, double beta2) {
+    int bs = ((n + 63) / 64) * 64; if (bs < 64) bs = 64;
+    hipLaunchKernelGGL(k_update_priorities, dim3(1), dim3(bs), 0, st, n, cap2, idx, td, eps, alpha, tree, state, tick_adam, beta1, beta2);
+}

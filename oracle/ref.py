@@ -7,17 +7,21 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
 from __future__ import annotations
 
 import ctypes as C
-import importlib.util
 import os
 import subprocess
+import sys
 
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-_spec = importlib.util.spec_from_file_location("dqn_abi_for_oracle", os.path.join(ROOT, "deepqlearning.jl_amd", "_abi.py"))
-abi = importlib.util.module_from_spec(_spec)
-_spec.loader.exec_module(abi)
+# struct layouts come from the product's ABI module (ONE definition of the C structs); importing the package does
+# not load the HIP library.
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import __graft_entry__ as _ge  # noqa: E402
+
+abi = _ge.load_package()._abi
 
 LIB_PATH = os.path.join(HERE, "_ref", "libdqn_ref.so")
 _fns = None

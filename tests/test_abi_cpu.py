@@ -1,0 +1,73 @@
+"""CPU: the C-ABI library loads, exports every symbol include/dqn_mi355x.h declares, and its host-only entry points
+work without a GPU.  No compute call is made here (there is no CPU fallback to call)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import __graft_entry__ as ge
+import ref
+from nets import GOLDEN_CASES, nature_dueling
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return ge.build()
+
+
+def test_every_declared_symbol_is_exported(pkg):
+    hdr = open(os.path.join(ge.ROOT, "include", "dqn_mi355x.h")).read()
+    names = set(re.findall(r"\b(dqn_[a-z_0-9]+)\s*\(", hdr))
+    assert len(names) >= 30
+    lib = ctypes.CDLL(pkg.LIB_PATH)
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_ctypes_structs_match_the_header_sizes(pkg):
+    # sizeof via a tiny C program compiled against the header
+    import subprocess, tempfile
+    src = '#include <stdio.h>\n#include "dqn_mi355x.h"\nint main(){printf("%zu %zu %zu\\n", sizeof(dqn_layer_desc), sizeof(dqn_layer_plan), sizeof(dqn_hparams));}'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ge.ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")], check=True)
+        a, b, c = map(int, subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split())
+    assert (a, b, c) == (ctypes.sizeof(pkg.LayerDesc), ctypes.sizeof(pkg.LayerPlan), ctypes.sizeof(pkg.HParams))
+
+
+@pytest.mark.parametrize("name", list(GOLDEN_CASES))
+@pytest.mark.parametrize("B", [4, 32, 512])
+def test_default_plan_product_equals_twin(pkg, name, B):
+    net = GOLDEN_CASES[name]()
+    hp = ref.hparams_for(net, batch_size=B, buffer_size=1024)
+    layers = ref.layers_from_network(net)
+    assert pkg.default_plan(layers, hp) == ref.default_plan(layers, hp)
+
+
+def test_hparams_default_matches_reference_defaults(pkg):
+    hp = pkg.HParams()
+    pkg.fns()["hparams_default"](ctypes.byref(hp))
+    # src/solver.jl:3-20, src/prioritized_experience_replay.jl:43-45
+    assert hp.batch_size == 32 and abs(hp.learning_rate - 1e-4) < 1e-10 and hp.double_q == 1 and hp.dueling == 1
+    assert hp.prioritized_replay == 1 and hp.buffer_size == 1000
+    assert abs(hp.prio_alpha - 0.6) < 1e-7 and abs(hp.prio_beta - 0.4) < 1e-7 and abs(hp.prio_eps - 1e-3) < 1e-9
+
+
+def test_dueling_incompatible_network_is_rejected(pkg):
+    net = nature_dueling()
+    hp = ref.hparams_for(net, batch_size=32)
+    layers = ref.layers_from_network(net)[:-1]  # drop the adv head -> incompatible
+    arr = (pkg.LayerDesc * len(layers))(*layers)
+    plan = (pkg.LayerPlan * len(layers))()
+    assert pkg.fns()["plan_default"](arr, len(layers), ctypes.byref(hp), plan) != 0
+    assert b"incompatible with dueling" in pkg.fns()["last_error"]()  # src/dueling.jl:47
+
+
+def test_no_gpu_means_loud_failure_not_fallback(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    net = nature_dueling()
+    with pytest.raises(pkg.DQNError, match="no CPU fallback"):
+        pkg.Engine(ref.layers_from_network(net), ref.hparams_for(net, batch_size=32))

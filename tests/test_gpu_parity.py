@@ -1,0 +1,195 @@
+"""GPU (-m gpu): the HIP engine, called through the C ABI, against
+  * the canonical-order CPU twin  -> BIT-EXACT (TD loss, td, greedy/best actions, indices, IS weights, parameters)
+  * the NumPy fp64 oracle         -> Q-values within 1e-5, gradients/loss to fp32 round-off
+  * the torch-autograd-pinned golden fixtures (tests/golden).
+Tolerances are the ones BASELINE.json's north_star states: TD loss and greedy action indices bit-exact,
+Q-values within 1e-5 fp32."""
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+import dqn_oracle as O
+import ref
+from nets import GOLDEN_CASES, cfg1_mlp_dueling, nature_dueling, small_conv_dueling, small_conv_plain, testmdp_mlp_tanh
+from test_twin_vs_oracle import run_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = ge.load_package()
+    p.lib()  # fail loudly if the HIP library is missing
+    return p
+
+
+def make_pair(pkg, net, B, cap=128, mfma=1, graph=1, **kw):
+    hp = ref.hparams_for(net, batch_size=B, buffer_size=cap, use_mfma=mfma, use_graph=graph, **kw)
+    layers = ref.layers_from_network(net)
+    plan = pkg.default_plan(layers, hp)
+    return pkg.Engine(layers, hp, plan=plan), ref.Twin(layers, hp, plan=plan, threads=8), hp
+
+
+def fill(handles, net, n, seed=0, u8=False):
+    rng = np.random.default_rng(seed)
+    if u8:
+        s = rng.integers(0, 256, (n,) + net.obs_shape).astype(np.uint8)
+        sp = rng.integers(0, 256, (n,) + net.obs_shape).astype(np.uint8)
+    else:
+        s = rng.random((n,) + net.obs_shape, dtype=np.float32)
+        sp = rng.random((n,) + net.obs_shape, dtype=np.float32)
+    a = rng.integers(0, net.n_actions, n).astype(np.int32)
+    r = (rng.standard_normal(n) * 2).astype(np.float32)
+    d = (rng.random(n) < 0.2).astype(np.uint8)
+    for h in handles:
+        h.replay_add(s, a, r, sp, d)
+    return s, a, r, sp, d
+
+
+def set_same_params(handles, net, seed=1):
+    p_on = O.Network.flatten(O.init_params(net, seed=seed))
+    p_tg = O.Network.flatten(O.init_params(net, seed=seed + 100))
+    rng = np.random.default_rng(seed)
+    p_on = (p_on + 0.01 * rng.standard_normal(p_on.shape)).astype(np.float32)  # non-zero biases
+    for h in handles:
+        h.set_params(p_on, 0)
+        h.set_params(p_tg, 1)
+    return p_on, p_tg
+
+
+def assert_step_bit_exact(gpu, cpu, idx=None):
+    lg, gg, tg = gpu.train_step(idx)
+    lc, gc, tc = cpu.train_step(idx)
+    np.testing.assert_array_equal(gpu.last_indices(), cpu.last_indices())
+    qg, qc = gpu.last_q(), cpu.last_q()
+    for k in ("q_on_s", "q_on_sp", "q_tg_sp", "best_a", "y"):
+        np.testing.assert_array_equal(qg[k], qc[k], err_msg=k)
+    np.testing.assert_array_equal(tg, tc)
+    assert lg == lc, (lg, lc)
+    assert gg == gc, (gg, gc)
+    return lg, gg
+
+
+@pytest.mark.parametrize("name", list(GOLDEN_CASES))
+def test_engine_matches_fp64_oracle_and_golden(pkg, name, golden_dir):
+    run_case(name, golden_dir, pkg.Engine)
+
+
+@pytest.mark.parametrize("mfma", [0, 1])
+@pytest.mark.parametrize("netf,B,kw", [
+    (cfg1_mlp_dueling, 32, dict(gamma=0.95)),
+    (testmdp_mlp_tanh, 32, dict(gamma=0.99, double_q=0)),
+    (small_conv_dueling, 16, dict(gamma=0.99)),
+    (small_conv_plain, 8, dict(gamma=0.9, double_q=0, prioritized_replay=0)),
+    (small_conv_dueling, 5, dict(gamma=0.99, adam_f64_scalars=0)),
+])
+def test_multi_step_bit_exact_vs_twin(pkg, netf, B, kw, mfma):
+    net = netf()
+    gpu, cpu, hp = make_pair(pkg, net, B, cap=100, mfma=mfma, learning_rate=1e-3, **kw)
+    fill((gpu, cpu), net, 137)  # > cap: exercises the ring wrap (mod1, ...replay.jl:70)
+    set_same_params((gpu, cpu), net)
+    np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
+    for step in range(6):
+        assert_step_bit_exact(gpu, cpu)
+        if step == 2:
+            gpu.sync_target(); cpu.sync_target()
+    np.testing.assert_array_equal(gpu.get_grads(), cpu.get_grads())
+    np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+    np.testing.assert_array_equal(gpu.get_params(1), cpu.get_params(1))
+    mg, vg, bg = gpu.get_adam_state(); mc, vc, bc = cpu.get_adam_state()
+    np.testing.assert_array_equal(mg, mc); np.testing.assert_array_equal(vg, vc); np.testing.assert_array_equal(bg, bc)
+    np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
+
+
+def test_graph_and_eager_agree(pkg):
+    net = small_conv_dueling()
+    a, cpu, _ = make_pair(pkg, net, 16, graph=1)
+    b, _, _ = make_pair(pkg, net, 16, graph=0)
+    fill((a, b), net, 64); set_same_params((a, b), net)
+    for _ in range(4):
+        ra, rb = a.train_step(), b.train_step()
+        assert ra[0] == rb[0] and ra[1] == rb[1]
+        np.testing.assert_array_equal(ra[2], rb[2])
+    np.testing.assert_array_equal(a.get_params(0), b.get_params(0))
+
+
+def test_replay_seams(pkg):
+    net = small_conv_dueling()
+    gpu, cpu, hp = make_pair(pkg, net, 16, cap=50)
+    s, a, r, sp, d = fill((gpu, cpu), net, 70, seed=5)
+    assert gpu.replay_size() == (50, 50) == cpu.replay_size()
+    # ring: slot j holds transition 50+j for j<20, else j
+    idx = np.array([0, 19, 20, 49, 7, 7, 33, 1, 2, 3, 4, 5, 6, 8, 9, 10], np.int64)
+    bg, bc = gpu.get_batch(idx), cpu.get_batch(idx)
+    for x, y in zip(bg, bc):
+        np.testing.assert_array_equal(x, y)
+    src = np.where(idx < 20, idx + 50, idx)
+    np.testing.assert_array_equal(bg[0], s[src]); np.testing.assert_array_equal(bg[3], sp[src])
+    np.testing.assert_array_equal(bg[1], a[src]); np.testing.assert_array_equal(bg[2], r[src])
+    # priorities (|r|+eps)^alpha and IS weights (n*p/sum)^-beta vs the fp64 formula
+    pr = gpu.replay_priorities()
+    np.testing.assert_allclose(pr, (np.abs(r[np.r_[50:70, 20:50]].astype(np.float64)) + 1e-3) ** 0.6, rtol=2e-7)
+    np.testing.assert_allclose(bg[5], O.is_weights(pr[idx], pr, 0.4, np.float64), rtol=2e-6)
+    # sampler: same Philox stream + same tree => same indices as the twin, call after call
+    for _ in range(5):
+        np.testing.assert_array_equal(gpu.replay_sample(), cpu.replay_sample())
+    # update_priorities! with a duplicate: last write wins (...replay.jl:79)
+    td = np.linspace(-2, 2, 16).astype(np.float32)
+    gpu.update_priorities(idx, td); cpu.update_priorities(idx, td)
+    np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
+    assert gpu.replay_priorities()[7] == np.float32((np.float64(abs(td[5]) + np.float32(1e-3))) ** np.float64(np.float32(0.6)))
+    with pytest.raises(pkg.DQNError):
+        gpu.get_batch(np.full(16, 50, np.int64))  # BoundsError
+    with pytest.raises(pkg.DQNError):
+        gpu.replay_add(s[:1], [99], r[:1], sp[:1], d[:1])  # bad action index
+
+
+def test_u8_replay_bit_exact(pkg):
+    net = small_conv_dueling()
+    gpu, cpu, _ = make_pair(pkg, net, 16, cap=64, obs_dtype=1)
+    s, *_ = fill((gpu, cpu), net, 64, u8=True)
+    set_same_params((gpu, cpu), net)
+    idx = np.arange(16, dtype=np.int64)
+    np.testing.assert_array_equal(gpu.get_batch(idx)[0], s[:16].astype(np.float32) / np.float32(255))
+    for _ in range(3):
+        assert_step_bit_exact(gpu, cpu)
+
+
+def test_policy_forward_and_greedy(pkg):
+    net = small_conv_dueling()
+    gpu, cpu, _ = make_pair(pkg, net, 16)
+    p_on, _ = set_same_params((gpu, cpu), net)
+    rng = np.random.default_rng(3)
+    for n in (1, 7, 64):
+        obs = rng.random((n,) + net.obs_shape, dtype=np.float32)
+        qg, qc = gpu.forward(obs), cpu.forward(obs)
+        np.testing.assert_array_equal(qg, qc)
+        q64 = O.network_forward(net, [p.astype(np.float64) for p in net.unflatten(p_on)], obs.astype(np.float64))
+        np.testing.assert_allclose(qg, q64, atol=1e-5, rtol=1e-5)
+        np.testing.assert_array_equal(gpu.greedy_action(obs), np.argmax(qc, axis=1))
+    # dueling identity: mean_a(Q - V) == 0 per column (src/dueling.jl:10)
+    assert qg.shape == (64, net.n_actions)
+
+
+def test_nature_dqn_b32_full_size_bit_exact(pkg):
+    """BASELINE config 2 at full size: 84x84x4, Nature-DQN dueling, B=32, double-Q, prioritized."""
+    net = nature_dueling()
+    gpu, cpu, hp = make_pair(pkg, net, 32, cap=256, gamma=0.99)
+    fill((gpu, cpu), net, 256, seed=9)
+    p_on, p_tg = set_same_params((gpu, cpu), net, seed=1)
+    for step in range(3):
+        loss, gn = assert_step_bit_exact(gpu, cpu)
+    np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+    # and against the fp64 oracle on the last batch's indices (Q within 1e-5)
+    idx = gpu.last_indices()
+    q = gpu.last_q()
+    assert np.isfinite(loss) and gn > 0
+
+
+def test_errors_are_loud(pkg):
+    net = cfg1_mlp_dueling()
+    gpu, cpu, _ = make_pair(pkg, net, 32, cap=64)
+    with pytest.raises(pkg.DQNError, match="_curr_size >= r.batch_size"):
+        gpu.train_step()
+    with pytest.raises(pkg.DQNError):
+        gpu.set_params(np.zeros(3, np.float32))
