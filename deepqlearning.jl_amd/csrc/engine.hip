@@ -299,8 +299,9 @@ extern "C" int dqn_replay_add(dqn_engine_t* e, const void* s, const int32_t* a, 
         const float td = td_err ? td_err[i] : fabsf(r[i]);
         if (!(td + e->hp.prio_eps > 0.0f)) return fail("AssertionError: td_err + r.eps > 0");   // ...replay.jl:66
     }
-    for (int o = 0; o < n; o += dqn_engine::ADD_CHUNK) {
-        const int c = std::min(dqn_engine::ADD_CHUNK, n - o);
+    const int chunk = (int)std::min<long long>(dqn_engine::ADD_CHUNK, e->cap);   // a chunk never writes one ring slot twice
+    for (int o = 0; o < n; o += chunk) {
+        const int c = std::min(chunk, n - o);
         // rows go straight into their ring slots (<= 2 contiguous segments)
         const long long first = std::min<long long>(c, e->cap - e->widx);
         const char *sp0 = (const char*)sp + (size_t)o * row, *s0 = (const char*)s + (size_t)o * row;

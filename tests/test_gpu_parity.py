@@ -10,7 +10,8 @@ import pytest
 import __graft_entry__ as ge
 import dqn_oracle as O
 import ref
-from nets import GOLDEN_CASES, cfg1_mlp_dueling, nature_dueling, small_conv_dueling, small_conv_plain, testmdp_mlp_tanh
+from nets import GOLDEN_CASES, cfg1_mlp_dueling, nature_dueling, small_conv_dueling, small_conv_plain
+from nets import testmdp_mlp_tanh as mlp_tanh_net
 from test_twin_vs_oracle import run_case
 
 pytestmark = pytest.mark.gpu
@@ -78,7 +79,7 @@ def test_engine_matches_fp64_oracle_and_golden(pkg, name, golden_dir):
 @pytest.mark.parametrize("mfma", [0, 1])
 @pytest.mark.parametrize("netf,B,kw", [
     (cfg1_mlp_dueling, 32, dict(gamma=0.95)),
-    (testmdp_mlp_tanh, 32, dict(gamma=0.99, double_q=0)),
+    (mlp_tanh_net, 32, dict(gamma=0.99, double_q=0)),
     (small_conv_dueling, 16, dict(gamma=0.99)),
     (small_conv_plain, 8, dict(gamma=0.9, double_q=0, prioritized_replay=0)),
     (small_conv_dueling, 5, dict(gamma=0.99, adam_f64_scalars=0)),
