@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""
+bench.py -- train steps/sec of the MI355X DQN engine on BASELINE.json's metric:
+    "train steps/sec (batch=32, 84x84x4 obs)": Synthetic 84x84x4 image MDP (the reference's own TestMDP((84,84),4,6),
+    test/test_env.jl), Nature-DQN 3-conv+2-dense dueling head, batch=32, double-Q, prioritized replay  (configs[1]).
+One step = one batch_train! (src/solver.jl:191-236): sum-tree sample -> gather + IS weights -> online([s;sp]) and
+target(sp) forwards -> double-Q Bellman target -> Huber(w*td)/B -> backward -> max-abs grad norm -> Adam -> priority update.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+N > 1: one process per GPU, per-rank envs + replay (weak scaling: B=32 per rank), gradients all-reduced over RCCL
+between backward and Adam.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_HBM_GBS = 8000.0          # HBM3E spec
+
+
+def build_workload(pkg, args, rank, device):
+    nn, envs = pkg.nn, pkg.envs
+    chain = nn.nature_dqn(n_actions=4, in_channels=4)
+    net = nn.create_dueling_network(chain)
+    layers, dueling = nn.lower(net)
+    hp = pkg.default_hparams(batch_size=args.batch, n_actions=4, obs_c=4, obs_h=84, obs_w=84, obs_dtype=pkg.OBS_U8 if args.u8 else pkg.OBS_F32,
+                             learning_rate=1e-4, gamma=0.99, double_q=1, dueling=1, prioritized_replay=1, buffer_size=args.replay,
+                             seed=1234 + rank, use_graph=0 if args.no_graph else 1, use_mfma=0 if args.no_mfma else 1)
+    eng = pkg.Engine(layers, hp, device=device)
+    params = nn.glorot_params(net, seed=1)           # identical replicas on every rank
+    eng.set_params(params, pkg.NET_ONLINE)
+    eng.set_params(params, pkg.NET_TARGET)
+    # replay pre-filled by a uniform-random policy on this rank's shard of the vectorised envs
+    env = envs.TestMDP((84, 84), 4, 6, n=args.envs_per_rank, seed=7, u8=args.u8)
+    env.rng = np.random.default_rng(1000 + rank)
+    filled = 0
+    o = env.observe()
+    while filled < args.replay:
+        a = env.rng.integers(0, 4, env.n)
+        r = env.act(a)
+        op = env.observe()
+        d = env.terminated()
+        eng.replay_add(o, a.astype(np.int32), r, op, d.astype(np.uint8))   # priority (|r|+eps)^alpha (...replay.jl:122)
+        filled += env.n
+        env.reset(d)
+        o = env.observe()
+    return eng, layers, hp, net, params, env
+
+
+def op_cost(name, eng_layers, B, ncon, E, P):
+    """algorithmic (flops, bytes) of one profiled op by name."""
+    parts = name.split("_")
+    if name == "gather":
+        return 0.0, 2.0 * B * E * 4 * 2          # rows read + batch arena written
+    if name == "adam":
+        return 0.0, P * 28.0                      # p,m,v,g read + p,m,v written
+    if parts[0] in ("fwd", "dw", "dx"):
+        li = int("".join(ch for ch in parts[-1] if ch.isdigit()))
+        K, N, npos = eng_layers[li]
+        cols = {"on": ncon, "tg": B}.get(parts[1], B)
+        return 2.0 * K * N * npos * cols, 0.0
+    return 0.0, 0.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--replay", type=int, default=10000, help="transitions per rank (the reference fixes none for this shape)")
+    ap.add_argument("--envs-per-rank", type=int, default=32, help="config 3: 256 envs / 8 ranks")
+    ap.add_argument("--u8", action="store_true", help="u8 replay storage (config 5 style)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-mfma", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--profile-steps", type=int, default=20)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+    if not torch.cuda.is_available():
+        print("bench.py: no HIP device visible; the engine has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = ge.load_package()
+    if not os.path.exists(pkg.LIB_PATH):
+        ge.build()
+    import importlib
+    pkg.nn = importlib.import_module(pkg.__name__ + ".nn")
+    pkg.envs = importlib.import_module(pkg.__name__ + ".envs")
+
+    eng, layers, hp, net, params, env = build_workload(pkg, args, rank, local_rank)
+    if world > 1:
+        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(pkg.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        eng.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.sync()
+
+    eng.train_steps(max(1, args.warmup))
+    barrier()
+    t0 = time.perf_counter()
+    loss, gnorm = eng.train_steps(args.steps)       # K graph replays back to back; one host sync at the end
+    eng.sync()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.steps / elapsed            # whole-job train steps/s (each rank runs its own B=32 step)
+
+    out = None
+    if rank == 0:
+        B, ncon, E, P = args.batch, 2 * args.batch, 4 * 84 * 84, eng.P
+        # ---- per-kernel durations, measured live with HIP events on the engine's own stream (eager launches)
+        geo = []
+        for d in layers:
+            if d.kind == pkg._abi.LAYER_CONV:
+                geo.append((d.cin * d.kh * d.kw, d.cout, None))
+            else:
+                geo.append((d.n_in, d.n_out, 1))
+        # npos of conv layers from the 84x84 geometry
+        h = w = 84
+        g2 = []
+        for d, (K, N, npos) in zip(layers, geo):
+            if npos is None:
+                h, w = (h - d.kh) // d.sh + 1, (w - d.kw) // d.sw + 1
+                npos = h * w
+            g2.append((K, N, npos))
+        acc = {}
+        for _ in range(args.profile_steps):
+            for name, ms in eng.profile_step():
+                a = acc.setdefault(name, [0.0, 0])
+                a[0] += ms
+                a[1] += 1
+        kern = {k: v[0] / v[1] for k, v in acc.items()}
+        dom = max(kern, key=kern.get)
+        fl, by = op_cost(dom, g2, B, ncon, E, P)
+        if fl > 0:
+            roof = dict(kernel=dom, bound="mfma", achieved=fl / (kern[dom] * 1e-3) / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", traffic=None)
+        else:
+            roof = dict(kernel=dom, bound="hbm", achieved=by / (kern[dom] * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", traffic=None)
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["avg_launch_ms"] = kern[dom]
+        step_flops = sum(op_cost(k, g2, B, ncon, E, P)[0] for k in kern)
+        roof["step_flops"] = step_flops
+        roof["step_mfma_frac"] = (value / world) * step_flops / (PEAK_F32_MFMA_TFLOPS * 1e12)
+        roof["eager_kernel_ms"] = {k: round(v, 5) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])[:12]}
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(pkg, layers, hp, params, env, args)
+        out = {
+            "metric": "train steps/sec (batch=32, 84x84x4 obs)", "value": value, "unit": "steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: TestMDP((84,84),4,6) image MDP, Nature-DQN 3-conv+2-dense dueling, double-Q, prioritized replay",
+                       "batch_per_rank": args.batch, "global_batch": args.batch * world, "replay_per_rank": args.replay,
+                       "replay_dtype": "u8" if args.u8 else "f32", "envs_per_rank": args.envs_per_rank, "n_params": int(P),
+                       "parallelism": f"dp{world} (per-rank replay, RCCL grad all-reduce)" if world > 1 else "single GPU",
+                       "hip_graph": not args.no_graph, "mfma": not args.no_mfma, "last_loss": loss, "last_grad_norm": gnorm},
+            "samples_per_s": value * args.batch,
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+def cpu_baseline(pkg, layers, hp, params, env, args):
+    """The canonical-order CPU twin (oracle/dqn_ref.c, kind "port") timed on the host cores on a bounded sample of the
+    same workload: same network, batch and step, a 512-transition replay instead of 10 000."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref
+    cores = os.cpu_count() or 1
+    hp2 = pkg.default_hparams(**{f: getattr(hp, f) for f, _ in hp._fields_ if f != "reserved"})
+    hp2.buffer_size = 512
+    tw = ref.Twin(layers, hp2, plan=None, threads=cores)
+    tw.set_params(params, 0)
+    tw.set_params(params, 1)
+    env.reset()
+    o = env.observe()
+    n = 0
+    while n < 512:
+        a = env.rng.integers(0, 4, env.n)
+        r = env.act(a)
+        op = env.observe()
+        d = env.terminated()
+        tw.replay_add(o, a.astype(np.int32), r, op, d.astype(np.uint8))
+        n += env.n
+        env.reset(d)
+        o = env.observe()
+    tw.train_step()
+    t0 = time.perf_counter()
+    tw.train_step()
+    one = time.perf_counter() - t0
+    k = int(max(3, min(200, args.cpu_seconds / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(k):
+        tw.train_step()
+    dt = time.perf_counter() - t0
+    tw.close()
+    return {"value": k / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{k} train steps of the same config (B={hp.batch_size}, Nature-DQN dueling) on a 512-transition replay, "
+                      f"oracle/dqn_ref.c with OpenMP over {cores} threads; the Julia/Flux reference cannot run in this image"}
+
+
+if __name__ == "__main__":
+    main()

@@ -97,14 +97,15 @@ void launch_batch_meta(hipStream_t st, int B, long long cap2, const long long* i
                        const unsigned char* done, const float* tree, float beta, const StepState* state,
                        int* a_out, float* r_out, float* done_out, float* w_out);
 void launch_update_priorities(hipStream_t st, int n, long long cap2, const long long* idx, const float* td, float eps, float alpha,
-                              float* tree, StepState* state, int tick_adam, double beta1, double beta2);
+                              float* tree, StepState* state, int tick_adam, double beta1, double beta2, const float* gmax_part, int n_gmax);
 
 void launch_valu_fwd(hipStream_t st, const LayerDev& L, const float* P, const float* X, int ldx, int col0, int ncols, float* Y, float* partials);
 void launch_valu_dw(hipStream_t st, const LayerDev& L, const float* X, int ldx, const float* dpre, int B, float* G, float* partials);
 void launch_valu_dx(hipStream_t st, const LayerDev& L, const float* P, const float* dpre, int B, float* out, float* partials,
                     const float* addend, const float* ysrc, int ldy, int act_src);
 void launch_td(hipStream_t st, const TdArgs& a);
-void launch_adam(hipStream_t st, size_t P, float* p, float* m, float* v, const float* g, StepState* state, int f64mode,
+int adam_blocks(size_t P);
+void launch_adam(hipStream_t st, size_t P, float* p, float* m, float* v, const float* g, StepState* state, float* gmax_part, int f64mode,
                  float lr, double b1, double b2, double eps, float gscale);
 void launch_q_columns(hipStream_t st, int n, int nA, int dueling, const float* val, const float* adv, float* q_out /*[n][nA]*/, int* argmax_out);
 void launch_convert_params(hipStream_t st, const LayerDev* layers_dev, int nl, const float* src, float* dst, int to_internal, size_t P);

@@ -63,7 +63,7 @@ struct dqn_engine {
     // step workspace
     long long* idx = nullptr; float* x0 = nullptr;
     float *act_on[DQN_MAX_LAYERS] = {}, *act_tg[DQN_MAX_LAYERS] = {}, *dact[DQN_MAX_LAYERS] = {};
-    float *join_tmp = nullptr, *partials = nullptr; size_t partials_elems = 0;
+    float *join_tmp = nullptr, *partials = nullptr, *gmax_part = nullptr; size_t partials_elems = 0;
     float *w_is = nullptr, *td = nullptr, *q_on_s = nullptr, *q_on_sp = nullptr, *q_tg_sp = nullptr, *ytarget = nullptr; int* best = nullptr;
     // get_batch seam workspace
     float *gb_rows = nullptr, *gb_r = nullptr, *gb_done = nullptr, *gb_w = nullptr; int* gb_a = nullptr; long long* gb_idx = nullptr;
@@ -202,7 +202,7 @@ extern "C" int dqn_engine_create(const dqn_layer_desc* layers, int n_layers, con
         const size_t sx = l.kind == DQN_LAYER_DENSE ? dqn_nchunks(l.N, l.dx_kc) : 1; if (sx > 1) pmax = std::max(pmax, sx * (size_t)l.in_feat * B);
         jmax = std::max(jmax, (size_t)l.in_feat * B);
     }
-    e->partials_elems = pmax; DM(e->partials, pmax); DM(e->join_tmp, jmax);
+    e->partials_elems = pmax; DM(e->partials, pmax); DM(e->join_tmp, jmax); DM(e->gmax_part, adam_blocks(e->P));
     DM(e->w_is, B); DM(e->td, B); DM(e->q_on_s, (size_t)B * e->nA); DM(e->q_on_sp, (size_t)B * e->nA); DM(e->q_tg_sp, (size_t)B * e->nA);
     DM(e->ytarget, B); DM(e->best, B);
     DM(e->gb_rows, (size_t)B * e->E); DM(e->gb_r, B); DM(e->gb_done, B); DM(e->gb_w, B); DM(e->gb_a, B); DM(e->gb_idx, B);
@@ -232,7 +232,7 @@ extern "C" int dqn_engine_destroy(dqn_engine_t* e) {
     hipFree(e->s_rows); hipFree(e->sp_rows); hipFree(e->ra); hipFree(e->rr); hipFree(e->rdone); hipFree(e->tree);
     hipFree(e->st_a); hipFree(e->st_r); hipFree(e->st_done); hipFree(e->st_td); hipFree(e->idx); hipFree(e->x0);
     for (int i = 0; i < e->nl; i++) { hipFree(e->act_on[i]); hipFree(e->act_tg[i]); hipFree(e->dact[i]); }
-    hipFree(e->join_tmp); hipFree(e->partials); hipFree(e->w_is); hipFree(e->td); hipFree(e->q_on_s); hipFree(e->q_on_sp); hipFree(e->q_tg_sp);
+    hipFree(e->join_tmp); hipFree(e->partials); hipFree(e->gmax_part); hipFree(e->w_is); hipFree(e->td); hipFree(e->q_on_s); hipFree(e->q_on_sp); hipFree(e->q_tg_sp);
     hipFree(e->ytarget); hipFree(e->best); hipFree(e->gb_rows); hipFree(e->gb_r); hipFree(e->gb_done); hipFree(e->gb_w); hipFree(e->gb_a); hipFree(e->gb_idx);
     free_policy_ws(e);
     if (e->stream) hipStreamDestroy(e->stream);
@@ -365,7 +365,7 @@ extern "C" int dqn_update_priorities(dqn_engine_t* e, const int64_t* idx, const 
         const int c = std::min(e->B, n - o);
         HIPCHK(hipMemcpyAsync(e->gb_idx, idx + o, (size_t)c * 8, hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipMemcpyAsync(e->gb_w, td + o, (size_t)c * 4, hipMemcpyHostToDevice, e->stream));
-        launch_update_priorities(e->stream, c, e->cap2, e->gb_idx, e->gb_w, e->hp.prio_eps, e->hp.prio_alpha, e->tree, e->state, 0, 1.0, 1.0);
+        launch_update_priorities(e->stream, c, e->cap2, e->gb_idx, e->gb_w, e->hp.prio_eps, e->hp.prio_alpha, e->tree, e->state, 0, 1.0, 1.0, nullptr, 0);
         HIPCHK(hipStreamSynchronize(e->stream));
     }
     return check_state_err(e);
@@ -422,10 +422,10 @@ static void enqueue_step(dqn_engine* e, bool sample, int phase) {
         }
     }
     if (phase != PH_PRE) {
-        RUN(e, "adam", launch_adam(st, e->P, e->p_on, e->m, e->v, e->grad, e->state, e->hp.adam_f64_scalars, e->hp.learning_rate, e->hp.adam_beta1,
+        RUN(e, "adam", launch_adam(st, e->P, e->p_on, e->m, e->v, e->grad, e->state, e->gmax_part, e->hp.adam_f64_scalars, e->hp.learning_rate, e->hp.adam_beta1,
                                    e->hp.adam_beta2, e->hp.adam_eps, e->world > 1 ? 1.0f / (float)e->world : 1.0f));
         RUN(e, "update_prio", launch_update_priorities(st, e->hp.prioritized_replay ? B : 0, e->cap2, e->idx, e->td, e->hp.prio_eps, e->hp.prio_alpha,
-                                                       e->tree, e->state, 1, e->hp.adam_beta1, e->hp.adam_beta2));
+                                                       e->tree, e->state, 1, e->hp.adam_beta1, e->hp.adam_beta2, e->gmax_part, adam_blocks(e->P)));
     }
 }
 static int capture(dqn_engine* e, bool sample, int phase, hipGraphExec_t* out) {

@@ -55,7 +55,16 @@ __global__ void k_valu_fwd(LayerDev L, const float* __restrict__ P, const float*
             if (++kx == L.kw) { kx = 0; if (++ky == L.kh) { ky = 0; ++ci; } }
         }
     } else {
-        for (int k = k0; k < k1; k++) acc = fmaf(X[(size_t)k * ldx + col0 + col], W[(size_t)k * L.N + n], acc);
+        const float* xp = X + col0 + col; const float* wp = W + n;
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {     // 16 independent loads in flight; the fma chain stays k-ascending
+            float xv[8], wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { xv[u] = xp[(size_t)(k + u) * ldx]; wv[u] = wp[(size_t)(k + u) * L.N]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc = fmaf(xv[u], wv[u], acc);
+        }
+        for (; k < k1; k++) acc = fmaf(xp[(size_t)k * ldx], wp[(size_t)k * L.N], acc);
     }
     if (S == 1) out[e] = act_f(acc + P[L.b_off + n], L.act);
     else out[(size_t)s * per_s + e] = acc;
@@ -199,7 +208,6 @@ __global__ __launch_bounds__(1024) void k_td(TdArgs A) {
         float lsum = 0.0f;
         for (int b = 0; b < B; b++) lsum = lsum + hl[b];
         A.st->loss = lsum / (float)B;
-        A.st->gnorm_bits = 0u;       // reset the max-abs accumulator for this step's Adam kernel
     }
 }
 void launch_td(hipStream_t st, const TdArgs& a) {
@@ -224,7 +232,9 @@ void launch_q_columns(hipStream_t st, int n, int nA, int dueling, const float* v
 // ------------------------------------------------------------------ globalnorm (helpers.jl:38-46) + Flux Adam (solver.jl:66,228), fused, HBM-bound:
 // per element 16 B read (p,m,v,g) + 12 B written.  f64mode reproduces Flux 0.14's Float64 eta/beta/eps scalars.
 __global__ __launch_bounds__(256) void k_adam(size_t P, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
-                                              StepState* state, int f64mode, float lr, double b1, double b2, double eps, float gscale) {
+                                              StepState* state, float* __restrict__ gmax_part, int f64mode, float lr, double b1, double b2, double eps,
+                                              float gscale) {
+    __shared__ float wmax[4];
     const double c1 = 1.0 - state->bp1, c2 = 1.0 - state->bp2;
     float gmax = 0.0f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (size_t)gridDim.x * blockDim.x) {
@@ -249,12 +259,14 @@ __global__ __launch_bounds__(256) void k_adam(size_t P, float* __restrict__ p, f
     }
     // wave max (64 lanes) then one atomic per wave; max is order-independent, so this is exact
     for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(&state->gnorm_bits, __float_as_uint(gmax));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = gmax;
+    __syncthreads();
+    if (threadIdx.x == 0) gmax_part[blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));   // folded by k_update_priorities
 }
-void launch_adam(hipStream_t st, size_t P, float* p, float* m, float* v, const float* g, StepState* state, int f64mode, float lr,
+int adam_blocks(size_t P) { size_t blocks = (P + 255) / 256; if (blocks > 2048) blocks = 2048; return (int)blocks; }
+void launch_adam(hipStream_t st, size_t P, float* p, float* m, float* v, const float* g, StepState* state, float* gmax_part, int f64mode, float lr,
                  double b1, double b2, double eps, float gscale) {
-    size_t blocks = (P + 255) / 256; if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, st, P, p, m, v, g, state, f64mode, lr, b1, b2, eps, gscale);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)adam_blocks(P)), dim3(256), 0, st, P, p, m, v, g, state, gmax_part, f64mode, lr, b1, b2, eps, gscale);
 }
 
 // ------------------------------------------------------------------ parameter layout conversion (Flux.params order <-> internal [K][N], conv kernels flipped)

@@ -146,8 +146,17 @@ void launch_batch_meta(hipStream_t st, int B, long long cap2, const long long* i
 // ------------------------------------------------------------------ update_priorities! (+ Adam beta-power tick at the end of a train step)
 __global__ __launch_bounds__(1024) void k_update_priorities(int n, long long cap2, const long long* __restrict__ idx, const float* __restrict__ td,
                                                             float eps, float alpha, float* tree, StepState* state, int tick_adam, double beta1,
-                                                            double beta2) {
+                                                            double beta2, const float* __restrict__ gmax_part, int n_gmax) {
     __shared__ long long sidx[1024];
+    __shared__ float smax[16];
+    if (tick_adam) {   // globalnorm (helpers.jl:38-46): fold the Adam kernel's per-block max-abs (max is order-independent => exact)
+        float g = 0.0f;
+        for (int j = threadIdx.x; j < n_gmax; j += blockDim.x) g = fmaxf(g, gmax_part[j]);
+        for (int off = 32; off > 0; off >>= 1) g = fmaxf(g, __shfl_xor(g, off));
+        if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = g;
+        __syncthreads();
+        if (threadIdx.x == 0) { for (int w = 1; w < (int)(blockDim.x >> 6); w++) g = fmaxf(g, smax[w]); state->gnorm_bits = __float_as_uint(g); }
+    }
     const int i = threadIdx.x;
     if (i < n) sidx[i] = idx[i];
     __syncthreads();
@@ -168,7 +177,8 @@ __global__ __launch_bounds__(1024) void k_update_priorities(int n, long long cap
     if (tick_adam && i == 0) { state->bp1 = state->bp1 * beta1; state->bp2 = state->bp2 * beta2; }
 }
 void launch_update_priorities(hipStream_t st, int n, long long cap2, const long long* idx, const float* td, float eps, float alpha,
-                              float* tree, StepState* state, int tick_adam, double beta1, double beta2) {
+                              float* tree, StepState* state, int tick_adam, double beta1, double beta2, const float* gmax_part, int n_gmax) {
     int bs = ((n + 63) / 64) * 64; if (bs < 64) bs = 64;
-    hipLaunchKernelGGL(k_update_priorities, dim3(1), dim3(bs), 0, st, n, cap2, idx, td, eps, alpha, tree, state, tick_adam, beta1, beta2);
+    if (tick_adam && bs < 256) bs = 256;
+    hipLaunchKernelGGL(k_update_priorities, dim3(1), dim3(bs), 0, st, n, cap2, idx, td, eps, alpha, tree, state, tick_adam, beta1, beta2, gmax_part, n_gmax);
 }
