@@ -21,7 +21,8 @@ struct LayerDev {
     int npos;                          // oh*ow (1 for dense)
     int in_feat, out_feat;
     int fwd_kc, dx_kc, dw_kc;          // summation-order plan (0 = unsplit)
-    unsigned long long w_off, b_off;   // offsets into the flat parameter vector
+    unsigned long long w_off, b_off;   // offsets into the INTERNAL flat parameter vector (w_off 16-B aligned; b_off = w_off + K*N)
+    unsigned long long ew_off, eb_off; // offsets into the EXTERNAL (Flux.params order, unpadded) vector
 };
 
 // device-resident mutable state of one engine (one instance in HBM)
@@ -72,6 +73,15 @@ __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t
     }
 }
 
+// XCD-aware workgroup remap (bijective for any n): hardware block b runs on XCD b % 8 (observed dispatch order; used for
+// L2 locality only, never for correctness).  Logical ids are handed out so that each XCD owns one CONTIGUOUS range of
+// logical workgroups == a contiguous band of output positions, whose activations then stay in that XCD's private 4 MB L2
+// instead of being re-fetched over the fabric by all eight.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
 // ---- kernel launchers (defined in the .hip files; all enqueue on `st` and never synchronise)
 struct TdArgs {
     int B, nA, ncon, dueling, double_q, prioritized;
@@ -108,7 +118,11 @@ int adam_blocks(size_t P);
 void launch_adam(hipStream_t st, size_t P, float* p, float* m, float* v, const float* g, StepState* state, float* gmax_part, int f64mode,
                  float lr, double b1, double b2, double eps, float gscale);
 void launch_q_columns(hipStream_t st, int n, int nA, int dueling, const float* val, const float* adv, float* q_out /*[n][nA]*/, int* argmax_out);
-void launch_convert_params(hipStream_t st, const LayerDev* layers_dev, int nl, const float* src, float* dst, int to_internal, size_t P);
+void launch_convert_params(hipStream_t st, const LayerDev* layers_dev, int nl, const float* src, float* dst, int to_internal, size_t P_ext);
+
+// LDS-tiled MFMA path (nn_gemm.hip): up to two problems (online / target net) of one layer per launch
+bool launch_gemm_fwd2(hipStream_t st, const LayerDev& L, int nprob, const float* const* P, const float* const* X, const int* ldx, const int* col0,
+                      const int* ncols, float* const* Y, float* const* partials);
 
 // MFMA path (nn_mfma.hip): returns false if the shape is not eligible (caller falls back to the VALU kernel,
 // which computes bit-identical values)

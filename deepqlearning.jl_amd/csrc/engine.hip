@@ -52,7 +52,7 @@ struct dqn_engine {
     int nl = 0; LayerDev L[DQN_MAX_LAYERS]; LayerDev* L_dev = nullptr;
     dqn_hparams hp; int B = 0, nA = 0, E = 0, ncon = 0;
     int last_base = -1, last_val = -1, last_adv = -1;
-    size_t P = 0;
+    size_t P = 0, Pint = 0;   // external (Flux.params) and internal (16-B aligned arrays) parameter counts
     float *p_on = nullptr, *p_tg = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr, *io_tmp = nullptr;
     StepState* state = nullptr;
     // replay
@@ -97,9 +97,9 @@ extern "C" int dqn_hparams_default(dqn_hparams* hp) {
 }
 
 // geometry of every layer; shared by dqn_plan_default (host only) and dqn_engine_create
-static int build_layers(const dqn_layer_desc* d, int n, const dqn_hparams* hp, LayerDev* L, int* lb, int* lv, int* la, size_t* P) {
+static int build_layers(const dqn_layer_desc* d, int n, const dqn_hparams* hp, LayerDev* L, int* lb, int* lv, int* la, size_t* P, size_t* Pint) {
     if (n <= 0 || n > DQN_MAX_LAYERS) return fail("bad layer count %d", n);
-    *lb = *lv = *la = -1; size_t off = 0;
+    *lb = *lv = *la = -1; size_t off = 0, eoff = 0;
     for (int i = 0; i < n; i++) {
         LayerDev& l = L[i]; memset(&l, 0, sizeof l);
         l.kind = d[i].kind; l.act = d[i].act; l.stream = d[i].stream;
@@ -121,10 +121,11 @@ static int build_layers(const dqn_layer_desc* d, int n, const dqn_hparams* hp, L
             if (d[i].n_in != l.in_feat) return fail("layer %d: dense n_in %d != incoming features %d", i, d[i].n_in, l.in_feat);
             l.K = d[i].n_in; l.N = d[i].n_out; l.npos = 1; l.out_feat = l.N; l.ih = l.iw = l.oh = l.ow = 1;
         } else return fail("layer %d: unknown kind %d", i, l.kind);
-        l.w_off = off; off += (size_t)l.K * l.N; l.b_off = off; off += l.N;
+        l.ew_off = eoff; eoff += (size_t)l.K * l.N; l.eb_off = eoff; eoff += l.N;
+        off = (off + 3) / 4 * 4; l.w_off = off; off += (size_t)l.K * l.N; l.b_off = off; off += l.N;
         if (l.stream == DQN_STREAM_BASE) *lb = i; else if (l.stream == DQN_STREAM_VAL) *lv = i; else *la = i;
     }
-    *P = off;
+    *P = eoff; *Pint = (off + 3) / 4 * 4;
     if (hp->dueling) {
         if (*lv < 0 || *la < 0 || L[*lv].out_feat != 1 || L[*la].out_feat != hp->n_actions)
             return fail("DeepQLearningError: the qnetwork provided is incompatible with dueling");   // src/dueling.jl:47
@@ -138,14 +139,15 @@ static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out) {
     for (int i = 0; i < n; i++) {
         out[i].fwd_kc = 0;
         if (L[i].K > 1024) { const int s = (L[i].K + 511) / 512; int kc = (L[i].K + s - 1) / s; kc = (kc + 3) / 4 * 4; out[i].fwd_kc = kc; }
+        else if (L[i].kind == DQN_LAYER_DENSE && L[i].N < 16 && L[i].K >= 128) out[i].fwd_kc = 32;   // heads: 16+ short chains instead of one long one
         out[i].dx_kc = (L[i].kind == DQN_LAYER_DENSE && L[i].N > 512) ? 256 : 0;
         out[i].dw_kc = 0;
         if (L[i].kind == DQN_LAYER_CONV) { int ppc = 256 / B; if (ppc < 1) ppc = 1; out[i].dw_kc = ppc * B; }
     }
 }
 extern "C" int dqn_plan_default(const dqn_layer_desc* layers, int n_layers, const dqn_hparams* hp, dqn_layer_plan* plan_out) {
-    LayerDev L[DQN_MAX_LAYERS]; int lb, lv, la; size_t P;
-    if (build_layers(layers, n_layers, hp, L, &lb, &lv, &la, &P)) return -1;
+    LayerDev L[DQN_MAX_LAYERS]; int lb, lv, la; size_t P, Pi;
+    if (build_layers(layers, n_layers, hp, L, &lb, &lv, &la, &P, &Pi)) return -1;
     default_plan(L, n_layers, hp->batch_size, plan_out); return 0;
 }
 
@@ -168,7 +170,7 @@ extern "C" int dqn_engine_create(const dqn_layer_desc* layers, int n_layers, con
     if (hp->buffer_size < hp->batch_size) return fail("AssertionError: r.max_size >= r.batch_size");   // ...replay.jl:84
     dqn_engine* e = new dqn_engine();
     e->device = device; e->hp = *hp; e->B = hp->batch_size; e->nA = hp->n_actions; e->E = hp->obs_c * hp->obs_h * hp->obs_w;
-    if (build_layers(layers, n_layers, hp, e->L, &e->last_base, &e->last_val, &e->last_adv, &e->P)) { delete e; return -1; }
+    if (build_layers(layers, n_layers, hp, e->L, &e->last_base, &e->last_val, &e->last_adv, &e->P, &e->Pint)) { delete e; return -1; }
     e->nl = n_layers;
     dqn_layer_plan defp[DQN_MAX_LAYERS];
     if (!plan) { default_plan(e->L, e->nl, e->B, defp); plan = defp; }
@@ -180,9 +182,9 @@ extern "C" int dqn_engine_create(const dqn_layer_desc* layers, int n_layers, con
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     const int B = e->B; e->ncon = hp->double_q ? 2 * B : B;
     DM(e->L_dev, e->nl); HIPCHK(hipMemcpy(e->L_dev, e->L, sizeof(LayerDev) * e->nl, hipMemcpyHostToDevice));
-    DM(e->p_on, e->P); DM(e->p_tg, e->P); DM(e->grad, e->P); DM(e->m, e->P); DM(e->v, e->P); DM(e->io_tmp, e->P);
-    HIPCHK(hipMemset(e->p_on, 0, e->P * 4)); HIPCHK(hipMemset(e->p_tg, 0, e->P * 4)); HIPCHK(hipMemset(e->grad, 0, e->P * 4));
-    HIPCHK(hipMemset(e->m, 0, e->P * 4)); HIPCHK(hipMemset(e->v, 0, e->P * 4));
+    DM(e->p_on, e->Pint); DM(e->p_tg, e->Pint); DM(e->grad, e->Pint); DM(e->m, e->Pint); DM(e->v, e->Pint); DM(e->io_tmp, e->P);
+    HIPCHK(hipMemset(e->p_on, 0, e->Pint * 4)); HIPCHK(hipMemset(e->p_tg, 0, e->Pint * 4)); HIPCHK(hipMemset(e->grad, 0, e->Pint * 4));
+    HIPCHK(hipMemset(e->m, 0, e->Pint * 4)); HIPCHK(hipMemset(e->v, 0, e->Pint * 4));
     DM(e->state, 1);
     StepState s0; memset(&s0, 0, sizeof s0); s0.bp1 = hp->adam_beta1; s0.bp2 = hp->adam_beta2;
     HIPCHK(hipMemcpy(e->state, &s0, sizeof s0, hipMemcpyHostToDevice));
@@ -202,7 +204,8 @@ extern "C" int dqn_engine_create(const dqn_layer_desc* layers, int n_layers, con
         const size_t sx = l.kind == DQN_LAYER_DENSE ? dqn_nchunks(l.N, l.dx_kc) : 1; if (sx > 1) pmax = std::max(pmax, sx * (size_t)l.in_feat * B);
         jmax = std::max(jmax, (size_t)l.in_feat * B);
     }
-    e->partials_elems = pmax; DM(e->partials, pmax); DM(e->join_tmp, jmax); DM(e->gmax_part, adam_blocks(e->P));
+    e->partials_elems = pmax; DM(e->partials, 2 * pmax);   // second half: the target net's split-K partials (fused on+tg launches)
+    DM(e->join_tmp, jmax); DM(e->gmax_part, adam_blocks(e->Pint));
     DM(e->w_is, B); DM(e->td, B); DM(e->q_on_s, (size_t)B * e->nA); DM(e->q_on_sp, (size_t)B * e->nA); DM(e->q_tg_sp, (size_t)B * e->nA);
     DM(e->ytarget, B); DM(e->best, B);
     DM(e->gb_rows, (size_t)B * e->E); DM(e->gb_r, B); DM(e->gb_done, B); DM(e->gb_w, B); DM(e->gb_a, B); DM(e->gb_idx, B);
@@ -269,7 +272,7 @@ extern "C" int dqn_get_grads(dqn_engine_t* e, float* flat, size_t n) {
 }
 extern "C" int dqn_sync_target(dqn_engine_t* e) {   // Flux.loadparams!(target_q, params(active_q)), src/solver.jl:142-145
     HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipMemcpyAsync(e->p_tg, e->p_on, e->P * 4, hipMemcpyDeviceToDevice, e->stream)); return 0;
+    HIPCHK(hipMemcpyAsync(e->p_tg, e->p_on, e->Pint * 4, hipMemcpyDeviceToDevice, e->stream)); return 0;
 }
 extern "C" int dqn_get_adam_state(dqn_engine_t* e, float* m, float* v, double* bp, size_t n) {
     if (n != e->P) return fail("size mismatch");
@@ -391,6 +394,17 @@ static void enqueue_step(dqn_engine* e, bool sample, int phase) {
         RUN(e, "gather", launch_gather_fb(st, e->s_rows, e->sp_rows, e->hp.obs_dtype == DQN_OBS_U8, e->E, B, e->idx, e->x0));
         for (int i = 0; i < e->nl; i++) {   // online net on [s ; sp] (src/solver.jl:210,220), target net on sp (:211)
             const LayerDev& l = e->L[i];
+            if (e->hp.use_mfma) {           // both nets of this layer in ONE launch of the LDS-tiled MFMA kernel
+                const float* Ps[2] = {e->p_on, e->p_tg};
+                const float* Xs[2] = {l.src < 0 ? e->x0 : e->act_on[l.src], l.src < 0 ? e->x0 : e->act_tg[l.src]};
+                const int lds[2] = {l.src < 0 ? ld0 : ncon, l.src < 0 ? ld0 : B}, c0s[2] = {0, l.src < 0 ? B : 0}, ncs[2] = {ncon, B};
+                float* Ys[2] = {e->act_on[i], e->act_tg[i]}; float* Pt[2] = {e->partials, e->partials + e->partials_elems};
+                prof_begin(e, lname(e, "fwd2", l.kind, i));
+                const bool ok = launch_gemm_fwd2(st, l, 2, Ps, Xs, lds, c0s, ncs, Ys, Pt);
+                prof_end(e);
+                if (ok) continue;
+                if (e->profiling) { hipEventDestroy(e->prof.back().a); hipEventDestroy(e->prof.back().b); e->prof.pop_back(); }
+            }
             fwd_layer(e, l, e->p_on, l.src < 0 ? e->x0 : e->act_on[l.src], l.src < 0 ? ld0 : ncon, 0, ncon, e->act_on[i], lname(e, "fwd_on", l.kind, i));
             fwd_layer(e, l, e->p_tg, l.src < 0 ? e->x0 : e->act_tg[l.src], l.src < 0 ? ld0 : B, l.src < 0 ? B : 0, B, e->act_tg[i], lname(e, "fwd_tg", l.kind, i));
         }
@@ -422,10 +436,10 @@ static void enqueue_step(dqn_engine* e, bool sample, int phase) {
         }
     }
     if (phase != PH_PRE) {
-        RUN(e, "adam", launch_adam(st, e->P, e->p_on, e->m, e->v, e->grad, e->state, e->gmax_part, e->hp.adam_f64_scalars, e->hp.learning_rate, e->hp.adam_beta1,
+        RUN(e, "adam", launch_adam(st, e->Pint, e->p_on, e->m, e->v, e->grad, e->state, e->gmax_part, e->hp.adam_f64_scalars, e->hp.learning_rate, e->hp.adam_beta1,
                                    e->hp.adam_beta2, e->hp.adam_eps, e->world > 1 ? 1.0f / (float)e->world : 1.0f));
         RUN(e, "update_prio", launch_update_priorities(st, e->hp.prioritized_replay ? B : 0, e->cap2, e->idx, e->td, e->hp.prio_eps, e->hp.prio_alpha,
-                                                       e->tree, e->state, 1, e->hp.adam_beta1, e->hp.adam_beta2, e->gmax_part, adam_blocks(e->P)));
+                                                       e->tree, e->state, 1, e->hp.adam_beta1, e->hp.adam_beta2, e->gmax_part, adam_blocks(e->Pint)));
     }
 }
 static int capture(dqn_engine* e, bool sample, int phase, hipGraphExec_t* out) {
@@ -437,7 +451,7 @@ static int capture(dqn_engine* e, bool sample, int phase, hipGraphExec_t* out) {
     HIPCHK(hipGraphDestroy(g)); return 0;
 }
 static int allreduce_grads(dqn_engine* e) {
-    const int rc = g_rccl.AllReduce(e->grad, e->grad, e->P, /*ncclFloat*/ 7, /*ncclSum*/ 0, e->comm, e->stream);
+    const int rc = g_rccl.AllReduce(e->grad, e->grad, e->Pint, /*ncclFloat*/ 7, /*ncclSum*/ 0, e->comm, e->stream);
     if (rc) return fail("ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
     return 0;
 }
@@ -503,7 +517,7 @@ static int policy_ws(dqn_engine* e, int n) {
     HIPCHK(hipStreamSynchronize(e->stream)); free_policy_ws(e);
     size_t need = 1;   // split-K partials of the widest forward at n columns
     for (int i = 0; i < e->nl; i++) { const size_t sf = dqn_nchunks(e->L[i].K, e->L[i].fwd_kc); if (sf > 1) need = std::max(need, sf * (size_t)e->L[i].out_feat * n); }
-    if (need > e->partials_elems) { drop_graphs(e); hipFree(e->partials); e->partials = nullptr; DM(e->partials, need); e->partials_elems = need; }
+    if (need > e->partials_elems) { drop_graphs(e); hipFree(e->partials); e->partials = nullptr; DM(e->partials, 2 * need); e->partials_elems = need; }
     DM(e->pol_obs, (size_t)n * e->E); DM(e->pol_x, (size_t)n * e->E); DM(e->pol_q, (size_t)n * e->nA); DM(e->pol_a, n);
     for (int i = 0; i < e->nl; i++) DM(e->pol_act[i], (size_t)e->L[i].out_feat * n);
     e->pol_n = n; return 0;

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void k_mfma_fwd(LayerDev L, FwdProb p, int S, 
         __syncthreads();
     }
     const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
-    int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    int task = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6));
     if (task >= ntasks) return;
     const int ngroups = L.N / (16 * NT), mgroups = p.ncols / (16 * MT);
     const int ng = task % ngroups; task /= ngroups;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_mfma_dx(LayerDev L, const float* __rest
                                                  float* __restrict__ out, const float* __restrict__ addend, const float* __restrict__ ysrc, int ldy,
                                                  int act_src, int ntasks) {
     const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
-    int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    int task = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6));
     if (task >= ntasks) return;
     const int mgroups = B / (16 * MT);
     const int mg = task % mgroups; task /= mgroups;
@@ -259,7 +259,7 @@ template <int NT>
 __global__ __launch_bounds__(256) void k_mfma_dw(LayerDev L, const float* __restrict__ X, int ldx, const float* __restrict__ dpre, int B, int S, int kc,
                                                  float* __restrict__ out, int ntasks) {
     const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
-    int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    int task = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6));
     if (task >= ntasks) return;
     const int ngroups = L.N / (16 * NT), mtiles = (L.K + 1 + 15) / 16;
     const int ng = task % ngroups; task /= ngroups;

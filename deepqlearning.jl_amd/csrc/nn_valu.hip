@@ -276,15 +276,17 @@ __global__ void k_convert_params(const LayerDev* __restrict__ layers, int nl, co
     size_t j = i;
     for (int l = 0; l < nl; l++) {
         const LayerDev& L = layers[l];
-        if (i >= L.w_off && i < L.b_off) {
-            if (L.kind == DQN_LAYER_CONV) {
-                size_t e = i - L.w_off;            // ((co*cin + ci)*kh + yy)*kw + xx, yy/xx un-flipped
+        const size_t wn = (size_t)L.K * L.N;
+        if (i >= L.ew_off && i < L.ew_off + wn) {
+            size_t e = i - L.ew_off;
+            if (L.kind == DQN_LAYER_CONV) {      // external ((co*cin + ci)*kh + yy)*kw + xx, yy/xx un-flipped
                 const int xx = (int)(e % L.kw); e /= L.kw; const int yy = (int)(e % L.kh); e /= L.kh; const int ci = (int)(e % L.cin); const int co = (int)(e / L.cin);
                 const int ky = L.kh - 1 - yy, kx = L.kw - 1 - xx;
-                j = L.w_off + ((size_t)(ci * L.kh + ky) * L.kw + kx) * L.cout + co;
+                e = ((size_t)(ci * L.kh + ky) * L.kw + kx) * L.cout + co;
             }
-            break;
+            j = L.w_off + e; break;
         }
+        if (i >= L.eb_off && i < L.eb_off + (size_t)L.N) { j = L.b_off + (i - L.eb_off); break; }
     }
     if (to_internal) dst[j] = src[i]; else dst[i] = src[j];
 }
