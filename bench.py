@@ -64,10 +64,10 @@ def op_cost(name, eng_layers, B, ncon, E, P):
         return 0.0, 2.0 * B * E * 4 * 2          # rows read + batch arena written
     if name == "adam":
         return 0.0, P * 28.0                      # p,m,v,g read + p,m,v written
-    if parts[0] in ("fwd", "dw", "dx"):
+    if parts[0] in ("fwd", "fwd2", "dw", "dx"):
         li = int("".join(ch for ch in parts[-1] if ch.isdigit()))
         K, N, npos = eng_layers[li]
-        cols = {"on": ncon, "tg": B}.get(parts[1], B)
+        cols = ncon + B if parts[0] == "fwd2" else {"on": ncon, "tg": B}.get(parts[1], B)   # fwd2 = online [s;sp] + target sp in one launch
         return 2.0 * K * N * npos * cols, 0.0
     return 0.0, 0.0
 
@@ -101,29 +101,20 @@ def main():
         print("bench.py: no HIP device visible; the engine has no CPU fallback", file=sys.stderr)
         sys.exit(3)
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
     pkg = ge.load_package()
     if not os.path.exists(pkg.LIB_PATH):
         ge.build()
     import importlib
     pkg.nn = importlib.import_module(pkg.__name__ + ".nn")
     pkg.envs = importlib.import_module(pkg.__name__ + ".envs")
+    par = importlib.import_module(pkg.__name__ + ".parallel")
+    group = par.Group(backend="nccl", device=torch.device("cuda", local_rank))   # "nccl" IS RCCL on ROCm
 
     eng, layers, hp, net, params, env = build_workload(pkg, args, rank, local_rank)
-    if world > 1:
-        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(pkg.comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(idt, 0)
-        eng.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+    group.attach_engine(pkg, eng)          # RCCL communicator inside the engine (gradient all-reduce on its stream)
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        group.barrier()
         torch.cuda.synchronize()
         eng.sync()
 
@@ -134,12 +125,8 @@ def main():
     eng.sync()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        dist.barrier()
+    elapsed = group.max_over_ranks(t1 - t0)
+    group.barrier()
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps / elapsed            # whole-job train steps/s (each rank runs its own B=32 step)
 
@@ -197,10 +184,9 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.barrier()
     eng.close()
+    group.close()
 
 
 def cpu_baseline(pkg, layers, hp, params, env, args):
@@ -208,10 +194,10 @@ def cpu_baseline(pkg, layers, hp, params, env, args):
     same workload: same network, batch and step, a 512-transition replay instead of 10 000."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ref
-    cores = os.cpu_count() or 1
+    ncpu = os.cpu_count() or 1
     hp2 = pkg.default_hparams(**{f: getattr(hp, f) for f, _ in hp._fields_ if f != "reserved"})
     hp2.buffer_size = 512
-    tw = ref.Twin(layers, hp2, plan=None, threads=cores)
+    tw = ref.Twin(layers, hp2, plan=None, threads=1)
     tw.set_params(params, 0)
     tw.set_params(params, 1)
     env.reset()
@@ -227,9 +213,18 @@ def cpu_baseline(pkg, layers, hp, params, env, args):
         env.reset(d)
         o = env.observe()
     tw.train_step()
-    t0 = time.perf_counter()
-    tw.train_step()
-    one = time.perf_counter() - t0
+    # OpenMP scaling of the twin is poor past a few dozen threads (short loops): take the fastest of a few counts
+    best, cores = None, 1
+    for th in sorted({1, min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu)}):
+        tw.set_threads(th)
+        tw.train_step()
+        t0 = time.perf_counter()
+        tw.train_step()
+        dt1 = time.perf_counter() - t0
+        if best is None or dt1 < best:
+            best, cores = dt1, th
+    tw.set_threads(cores)
+    one = best
     k = int(max(3, min(200, args.cpu_seconds / max(one, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(k):
@@ -238,7 +233,7 @@ def cpu_baseline(pkg, layers, hp, params, env, args):
     tw.close()
     return {"value": k / dt, "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"{k} train steps of the same config (B={hp.batch_size}, Nature-DQN dueling) on a 512-transition replay, "
-                      f"oracle/dqn_ref.c with OpenMP over {cores} threads; the Julia/Flux reference cannot run in this image"}
+                      f"oracle/dqn_ref.c with OpenMP over {cores} threads (best of 1/8/16/32/64 on a {ncpu}-CPU host); the Julia/Flux reference cannot run in this image"}
 
 
 if __name__ == "__main__":

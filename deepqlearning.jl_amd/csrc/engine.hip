@@ -558,13 +558,23 @@ extern "C" int dqn_comm_init(dqn_engine_t* e, const void* id128, int rank, int w
 // ---------------------------------------------------------------- misc
 extern "C" int dqn_stream_sync(dqn_engine_t* e) { HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream)); return 0; }
 extern "C" int dqn_stream_handle(dqn_engine_t* e, void** s) { *s = (void*)e->stream; return 0; }
+// Holds the stream until the host has enqueued the whole profiled step, so that the HIP events around each kernel time
+// the kernel and not the host's launch latency.  Bounded spin (~0.2 s) so a dead host can never hang the GPU.
+__global__ void k_gate(volatile int* flag) {
+    for (long i = 0; i < 2000000 && *flag == 0; i++) __builtin_amdgcn_s_sleep(32);
+}
 extern "C" int dqn_profile_step(dqn_engine_t* e, int max_entries, const char** names, float* ms, int* n_entries) {
     HIPCHK(hipSetDevice(e->device));
     if (e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
     HIPCHK(hipStreamSynchronize(e->stream));
+    static int* gate = nullptr;
+    if (!gate) HIPCHK(hipHostMalloc((void**)&gate, sizeof(int), hipHostMallocMapped));
+    *gate = 0;
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, e->stream, (volatile int*)gate);
     e->profiling = true; e->prof.clear();
     const int rc = run_step(e, true);
     e->profiling = false;
+    __atomic_store_n(gate, 1, __ATOMIC_SEQ_CST);
     if (rc) return -1;
     HIPCHK(hipStreamSynchronize(e->stream));
     int n = 0;

@@ -1,0 +1,163 @@
+# DeepQLearningMI355X.jl -- thin `ccall` shim that plugs libdqn_mi355x.so (include/dqn_mi355x.h) into
+# DeepQLearning.jl v0.7.1 WITHOUT touching the package: it adds one replay type and one policy type and lets Julia's
+# multiple dispatch route the hot path to the GPU:
+#
+#   batch_train!(solver, env, policy, optimizer, target_q, replay::HIPReplayBuffer)   <- src/solver.jl:191-198 seam
+#   add_exp!, sample, get_batch, update_priorities!, populate_replay_buffer!            <- src/prioritized_experience_replay.jl:61-134
+#   AbstractNNPolicy interface: getnetwork, resetstate!, actionmap, action, actionvalues, value  <- src/policy.jl:1-76
+#
+# NOT EXECUTED IN THIS BUILD: neither the build container nor the GPU box has a `julia` binary (SURVEY.md), so this file
+# ships as reviewed source.  Every call below goes through exactly the C entry points that tests/ exercise from Python
+# (ctypes) with the same buffers, so its behaviour is pinned by the same fixtures.
+module DeepQLearningMI355X
+
+using DeepQLearning, Flux, POMDPs, POMDPTools, Random
+import DeepQLearning: batch_train!, add_exp!, update_priorities!, get_batch, populate_replay_buffer!, is_full, max_size,
+                      getnetwork, resetstate!, actionmap, AbstractNNPolicy, DQExperience, DeepQLearningSolver
+import CommonRLInterface: AbstractEnv, observe, actions
+import StatsBase
+
+const LIB = get(ENV, "DQN_MI355X_LIB", "libdqn_mi355x.so")
+
+# ---- C structs (must match include/dqn_mi355x.h field for field)
+struct LayerDesc
+    kind::Int32; act::Int32; stream::Int32
+    n_in::Int32; n_out::Int32
+    cin::Int32; cout::Int32; kh::Int32; kw::Int32; sh::Int32; sw::Int32
+end
+mutable struct HParams
+    batch_size::Int32; n_actions::Int32
+    obs_c::Int32; obs_h::Int32; obs_w::Int32; obs_dtype::Int32
+    learning_rate::Float32
+    adam_beta1::Float64; adam_beta2::Float64; adam_eps::Float64
+    adam_f64_scalars::Int32
+    gamma::Float32
+    double_q::Int32; dueling::Int32; prioritized_replay::Int32
+    buffer_size::Int64
+    prio_alpha::Float32; prio_beta::Float32; prio_eps::Float32
+    seed::UInt64
+    use_graph::Int32; use_mfma::Int32
+    reserved::NTuple{6,Int32}
+    HParams() = new()
+end
+
+check(rc) = rc == 0 ? nothing : throw(unsafe_string(ccall((:dqn_last_error, LIB), Cstring, ())))  # reference errors are thrown Strings
+
+const ACT = Dict(identity => 0, relu => 1, tanh => 2, sigmoid => 3)
+
+function lower_layer(l, stream)::LayerDesc
+    if l isa Dense
+        return LayerDesc(0, ACT[l.σ], stream, size(l.weight, 2), size(l.weight, 1), 0, 0, 0, 0, 0, 0)
+    elseif l isa Conv
+        kw, kh, cin, cout = size(l.weight)
+        all(==(0), l.pad) || throw("DeepQLearningError: the MI355X engine supports Conv with pad=0 only")
+        return LayerDesc(1, ACT[l.σ], stream, 0, 0, cin, cout, kh, kw, l.stride[2], l.stride[1])
+    end
+    throw("DeepQLearningError: unsupported layer $(typeof(l)) (Conv / Dense / flattenbatch only)")
+end
+is_glue(l) = l === identity || l === flattenbatch || l isa Function
+function lower(q)
+    descs = LayerDesc[]
+    if q isa DeepQLearning.DuelingNetwork
+        for (chain, s) in ((q.base, 0), (q.val, 1), (q.adv, 2)), l in chain.layers
+            is_glue(l) || push!(descs, lower_layer(l, Int32(s)))
+        end
+    else
+        for l in q.layers; is_glue(l) || push!(descs, lower_layer(l, Int32(0))); end
+    end
+    descs
+end
+flatparams(q) = reduce(vcat, [vec(Float32.(w)) for w in Flux.params(q)])   # Flux.params order, Julia memory order: exactly the ABI layout
+
+# ---- engine handle
+mutable struct Engine
+    h::Ptr{Cvoid}
+    B::Int; nA::Int; obs_dims::Tuple
+end
+function Engine(solver::DeepQLearningSolver, env::AbstractEnv, q; device=0, obs_u8=false)
+    o = observe(env); dims = size(o)
+    c, h, w = length(dims) == 3 ? (dims[3], dims[2], dims[1]) : (prod(dims), 1, 1)   # Julia (W,H,C) -> C [C][H][W]
+    hp = HParams(); check(ccall((:dqn_hparams_default, LIB), Cint, (Ref{HParams},), hp))
+    hp.batch_size = solver.batch_size; hp.n_actions = length(actions(env))
+    hp.obs_c, hp.obs_h, hp.obs_w, hp.obs_dtype = c, h, w, obs_u8 ? 1 : 0
+    hp.learning_rate = solver.learning_rate; hp.gamma = Float32(DeepQLearning.default_discount(env))
+    hp.double_q = solver.double_q; hp.dueling = q isa DeepQLearning.DuelingNetwork; hp.prioritized_replay = solver.prioritized_replay
+    hp.buffer_size = solver.buffer_size
+    descs = lower(q); out = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:dqn_engine_create, LIB), Cint, (Ptr{LayerDesc}, Cint, Ref{HParams}, Ptr{Cvoid}, Cint, Ref{Ptr{Cvoid}}),
+                descs, length(descs), hp, C_NULL, device, out))
+    e = Engine(out[], solver.batch_size, length(actions(env)), dims)
+    finalizer(x -> ccall((:dqn_engine_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), e)
+    p = flatparams(q)
+    check(ccall((:dqn_set_params, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Float32}, Csize_t), e.h, 0, p, length(p)))
+    check(ccall((:dqn_sync_target, LIB), Cint, (Ptr{Cvoid},), e.h))
+    e
+end
+
+# ---- replay protocol (src/prioritized_experience_replay.jl)
+mutable struct HIPReplayBuffer
+    e::Engine
+    rng::AbstractRNG
+end
+max_size(r::HIPReplayBuffer) = (cap = Ref{Int64}(); ccall((:dqn_replay_size, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ref{Int64}), r.e.h, C_NULL, cap); cap[])
+cur_size(r::HIPReplayBuffer) = (cur = Ref{Int64}(); ccall((:dqn_replay_size, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}, Ptr{Int64}), r.e.h, cur, C_NULL); cur[])
+is_full(r::HIPReplayBuffer) = cur_size(r) == max_size(r)
+
+function add_exp!(r::HIPReplayBuffer, expe::DQExperience, td_err=abs(expe.r))      # :65-74
+    s = Float32.(vec(expe.s)); sp = Float32.(vec(expe.sp))
+    check(ccall((:dqn_replay_add, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int32}, Ref{Float32}, Ptr{Cvoid}, Ref{UInt8}, Ref{Float32}, Cint),
+                r.e.h, s, Int32(expe.a - 1), Float32(expe.r), sp, UInt8(expe.done), Float32(td_err), 1))   # 1-based -> 0-based action
+end
+function update_priorities!(r::HIPReplayBuffer, indices::Vector{Int64}, td_errors)  # :76-80
+    check(ccall((:dqn_update_priorities, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Float32}, Cint), r.e.h, indices .- 1, Float32.(td_errors), length(indices)))
+end
+function get_batch(r::HIPReplayBuffer, idx::Vector{Int64})                           # :89-104
+    B = r.e.B
+    s = zeros(Float32, r.e.obs_dims..., B); sp = similar(s)
+    a = zeros(Int32, B); rew = zeros(Float32, B); done = zeros(Float32, B); w = zeros(Float32, B)
+    check(ccall((:dqn_replay_get_batch, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Float32}, Ptr{Int32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+                r.e.h, idx .- 1, s, a, rew, sp, done, w))
+    return s, [CartesianIndex(Int(a[i]) + 1, i) for i in 1:B], rew, sp, done, idx, w
+end
+function StatsBase.sample(r::HIPReplayBuffer)                                        # :82-87 (sum-tree on the device)
+    idx = zeros(Int64, r.e.B)
+    check(ccall((:dqn_replay_sample, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), r.e.h, idx))
+    get_batch(r, idx .+ 1)
+end
+
+# ---- the hot path: ONE ccall per batch_train!  (src/solver.jl:191-236)
+function batch_train!(solver::DeepQLearningSolver, env::AbstractEnv, policy::AbstractNNPolicy, optimizer, target_q,
+                      replay::HIPReplayBuffer; discount=DeepQLearning.default_discount(env))
+    loss = Ref{Float32}(0); gn = Ref{Float32}(0)
+    check(ccall((:dqn_train_step, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ref{Float32}, Ref{Float32}, Ptr{Float32}), replay.e.h, C_NULL, loss, gn, C_NULL))
+    return loss[], gn[]
+end
+
+# ---- policy (src/policy.jl)
+struct HIPNNPolicy{P,A} <: AbstractNNPolicy
+    problem::P
+    e::Engine
+    qnetwork::Any            # the Flux model, refreshed on demand by getnetwork
+    action_map::Vector{A}
+    n_input_dims::Int64
+end
+function getnetwork(p::HIPNNPolicy)                    # Flux.params(active_q) <- engine (BSON save path keeps working, src/solver.jl:292)
+    ps = Flux.params(p.qnetwork); n = sum(length, ps); flat = zeros(Float32, n)
+    check(ccall((:dqn_get_params, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Float32}, Csize_t), p.e.h, 0, flat, n))
+    off = 0; for w in ps; copyto!(w, reshape(flat[off+1:off+length(w)], size(w))); off += length(w); end
+    p.qnetwork
+end
+resetstate!(p::HIPNNPolicy) = nothing
+actionmap(p::HIPNNPolicy) = p.action_map
+function _q(p::HIPNNPolicy, o)
+    ndims(o) == p.n_input_dims || throw("NNPolicyError: was expecting an array with $(p.n_input_dims) dimensions, got $(ndims(o))")
+    q = zeros(Float32, p.e.nA)
+    check(ccall((:dqn_forward, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Float32}, Cint, Ptr{Float32}), p.e.h, 0, Float32.(vec(o)), 1, q))
+    q
+end
+POMDPs.action(p::HIPNNPolicy, o::AbstractArray) = p.action_map[argmax(_q(p, o))]
+POMDPTools.actionvalues(p::HIPNNPolicy, o::AbstractArray) = _q(p, o)
+POMDPs.value(p::HIPNNPolicy, o::AbstractArray) = maximum(_q(p, o))
+sync_target!(p::HIPNNPolicy) = check(ccall((:dqn_sync_target, LIB), Cint, (Ptr{Cvoid},), p.e.h))   # replaces Flux.loadparams! at src/solver.jl:142-145
+
+end # module
