@@ -64,11 +64,16 @@ def op_cost(name, eng_layers, B, ncon, E, P):
         return 0.0, 2.0 * B * E * 4 * 2          # rows read + batch arena written
     if name == "adam":
         return 0.0, P * 28.0                      # p,m,v,g read + p,m,v written
-    if parts[0] in ("fwd", "fwd2", "dw", "dx"):
-        li = int("".join(ch for ch in parts[-1] if ch.isdigit()))
+    digits = "".join(ch for ch in parts[-1] if ch.isdigit())
+    if parts[0] in ("fwd", "dw", "dx") and digits and len(parts) == 2 or (len(parts) == 3 and parts[1] in ("on", "tg", "valu")):
+        li = int(digits)
         K, N, npos = eng_layers[li]
-        cols = ncon + B if parts[0] == "fwd2" else {"on": ncon, "tg": B}.get(parts[1], B)   # fwd2 = online [s;sp] + target sp in one launch
-        return 2.0 * K * N * npos * cols, 0.0
+        if parts[0] == "fwd":
+            # a forward launch covers the online net on [s;sp] and the target net on sp, for every sibling layer of its level
+            sib = [j for j, g in enumerate(eng_layers) if g == eng_layers[li] and j >= li] if len(parts) == 2 else [li]
+            cols = {"on": ncon, "tg": B}.get(parts[1], ncon + B) if len(parts) == 3 else ncon + B
+            return 2.0 * K * N * npos * cols * max(1, len(sib)), 0.0
+        return 2.0 * K * N * npos * B, 0.0
     return 0.0, 0.0
 
 

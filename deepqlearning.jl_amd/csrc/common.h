@@ -29,7 +29,8 @@ struct LayerDev {
 struct StepState {
     unsigned long long sample_ctr;     // Philox counter: number of sample() calls so far
     long long size;                    // _curr_size
-    double bp1, bp2;                   // Adam beta powers (Flux keeps them per array; identical for all)
+    unsigned long long step;           // train steps started so far (bumped by k_td); Adam reads bp[step & 1], writes bp[(step+1) & 1]
+    double bp[2][2];                   // Adam beta powers (Flux keeps them per array; identical for all), double-buffered
     unsigned int gnorm_bits;           // max |g| as uint bits (non-negative floats order like uints)
     float loss;
     float gnorm;
@@ -83,20 +84,36 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 }
 
 // ---- kernel launchers (defined in the .hip files; all enqueue on `st` and never synchronise)
+// a head tensor as seen by k_td: finished activation (S <= 1) or split-K partial slabs to be reduced on the fly
+struct HeadSrc { const float* p; int ld; int S; unsigned long long per_s; const float* bias; int act; };
 struct TdArgs {
-    int B, nA, ncon, dueling, double_q, prioritized;
+    int B, nA, ncon, dueling, double_q, prioritized, bump_sample_ctr;
     float gamma, prio_beta, prio_eps, prio_alpha;
     long long cap2;
     const long long* idx; const int* a; const float* r; const unsigned char* done; float* tree;
-    const float *on_val, *on_adv, *tg_val, *tg_adv;   // last-layer outputs (adv doubles as plain Q head)
-    int act_val, act_adv;                              // activations of the last layers
+    HeadSrc on_val, on_adv, tg_val, tg_adv;            // last-layer outputs (adv doubles as the plain Q head)
     float *d_val, *d_adv;                              // dpre of the last layers, [*][B]
     float *w_is, *td, *q_on_s, *q_on_sp, *q_tg_sp, *ytarget; int* best;
     StepState* st;
 };
 
+// task / segment tables of the batched small kernels (device-resident, built once per engine)
+struct VTask {
+    int kind;                          // 0 forward, 1 dW/db, 2 dX
+    LayerDev L; const float* P; const float* X; int ldx, col0, ncols; const float* dpre; int B; float* out; int S, kc;
+    const float* addend; const float* ysrc; int ldy, act_src; unsigned first_block;
+};
+struct RSeg {
+    const float* part; int S, S2; unsigned long long elems; int mode; const float* bias; int per_n, act;
+    const float* addend; const float* ysrc; int B, ldy; float* out; unsigned first_block;
+};
+unsigned valu_task_blocks(const VTask& T);
+void launch_valu_multi(hipStream_t st, const VTask* tasks_dev, int ntasks, unsigned total_blocks);
+void launch_reduce_multi(hipStream_t st, const RSeg* segs_dev, int nseg, unsigned total_blocks);
+
 void launch_gather_fb(hipStream_t st, const void* s_rows, const void* sp_rows, int obs_u8, int E, int B,
-                      const long long* idx, float* x0 /*[E][2B]*/);
+                      long long* idx, float* x0 /*[E][2B]*/, int do_sample, long long cap2, const float* tree, unsigned long long seed,
+                      const StepState* state);
 void launch_gather_rows(hipStream_t st, const void* rows, int obs_u8, int E, int n, const long long* idx, float* out /*[n][E]*/);
 void launch_transpose_obs(hipStream_t st, const float* obs /*[n][E]*/, int E, int n, float* x /*[E][n]*/);
 void launch_replay_commit(hipStream_t st, int n, long long start, long long cap, long long cap2, const int* a_in, const float* r_in,
@@ -121,12 +138,17 @@ void launch_q_columns(hipStream_t st, int n, int nA, int dueling, const float* v
 void launch_convert_params(hipStream_t st, const LayerDev* layers_dev, int nl, const float* src, float* dst, int to_internal, size_t P_ext);
 
 // LDS-tiled MFMA path (nn_gemm.hip): up to two problems (online / target net) of one layer per launch
-bool launch_gemm_fwd2(hipStream_t st, const LayerDev& L, int nprob, const float* const* P, const float* const* X, const int* ldx, const int* col0,
-                      const int* ncols, float* const* Y, float* const* partials);
+bool gemm_fwd_eligible(const LayerDev& L, int nprob, const int* ldx, const int* col0, const int* ncols);
+void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* const* W, const float* const* bias, const float* const* X,
+                     const int* ldx, const int* col0, const int* ncols, float* const* out /* Y, or split-K partial slabs */);
 
 // MFMA path (nn_mfma.hip): returns false if the shape is not eligible (caller falls back to the VALU kernel,
 // which computes bit-identical values)
-bool launch_mfma_fwd(hipStream_t st, const LayerDev& L, const float* P, const float* X, int ldx, int col0, int ncols, float* Y, float* partials);
-bool launch_mfma_dw(hipStream_t st, const LayerDev& L, const float* X, int ldx, const float* dpre, int B, float* G, float* partials);
+// (reduce == false leaves split-K partial slabs in `partials` for the caller's batched k_reduce_multi)
+bool mfma_fwd_ok(const LayerDev& L, int ncols);
+bool mfma_dw_ok(const LayerDev& L, int B);
+bool mfma_dx_ok(const LayerDev& L, int B, int ldy);
+bool launch_mfma_fwd(hipStream_t st, const LayerDev& L, const float* P, const float* X, int ldx, int col0, int ncols, float* Y, float* partials, bool reduce = true);
+bool launch_mfma_dw(hipStream_t st, const LayerDev& L, const float* X, int ldx, const float* dpre, int B, float* G, float* partials, bool reduce = true);
 bool launch_mfma_dx(hipStream_t st, const LayerDev& L, const float* P, const float* dpre, int B, float* out, float* partials,
-                    const float* addend, const float* ysrc, int ldy, int act_src);
+                    const float* addend, const float* ysrc, int ldy, int act_src, bool reduce = true);

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -73,6 +74,10 @@ struct dqn_engine {
     hipGraphExec_t g_full[2] = {nullptr, nullptr}, g_pre[2] = {nullptr, nullptr}, g_post = nullptr;
     // comm
     void* comm = nullptr; int rank = 0, world = 1;
+    // static launch program
+    struct Step { const char* name; std::function<void(dqn_engine*)> fn; };
+    std::vector<Step> prog; size_t prog_post_begin = 0; bool prog_built = false, step_sampled = true;
+    std::vector<void*> prog_allocs; std::vector<std::string> prog_names;
     // profiling
     bool profiling = false; std::vector<ProfEntry> prof;
 };
@@ -186,7 +191,7 @@ extern "C" int dqn_engine_create(const dqn_layer_desc* layers, int n_layers, con
     HIPCHK(hipMemset(e->p_on, 0, e->Pint * 4)); HIPCHK(hipMemset(e->p_tg, 0, e->Pint * 4)); HIPCHK(hipMemset(e->grad, 0, e->Pint * 4));
     HIPCHK(hipMemset(e->m, 0, e->Pint * 4)); HIPCHK(hipMemset(e->v, 0, e->Pint * 4));
     DM(e->state, 1);
-    StepState s0; memset(&s0, 0, sizeof s0); s0.bp1 = hp->adam_beta1; s0.bp2 = hp->adam_beta2;
+    StepState s0; memset(&s0, 0, sizeof s0); s0.bp[0][0] = s0.bp[1][0] = hp->adam_beta1; s0.bp[0][1] = s0.bp[1][1] = hp->adam_beta2;
     HIPCHK(hipMemcpy(e->state, &s0, sizeof s0, hipMemcpyHostToDevice));
     e->cap = hp->buffer_size; while (e->cap2 < e->cap) e->cap2 <<= 1;
     const size_t osz = hp->obs_dtype == DQN_OBS_U8 ? 1 : 4;
@@ -238,6 +243,7 @@ extern "C" int dqn_engine_destroy(dqn_engine_t* e) {
     hipFree(e->join_tmp); hipFree(e->partials); hipFree(e->gmax_part); hipFree(e->w_is); hipFree(e->td); hipFree(e->q_on_s); hipFree(e->q_on_sp); hipFree(e->q_tg_sp);
     hipFree(e->ytarget); hipFree(e->best); hipFree(e->gb_rows); hipFree(e->gb_r); hipFree(e->gb_done); hipFree(e->gb_w); hipFree(e->gb_a); hipFree(e->gb_idx);
     free_policy_ws(e);
+    for (void* p : e->prog_allocs) hipFree(p);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e; return 0;
 }
@@ -278,7 +284,7 @@ extern "C" int dqn_get_adam_state(dqn_engine_t* e, float* m, float* v, double* b
     if (n != e->P) return fail("size mismatch");
     if (m && get_vec(e, e->m, m)) return -1;
     if (v && get_vec(e, e->v, v)) return -1;
-    if (bp) { StepState s; HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipMemcpy(&s, e->state, sizeof s, hipMemcpyDeviceToHost)); bp[0] = s.bp1; bp[1] = s.bp2; }
+    if (bp) { StepState s; HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipMemcpy(&s, e->state, sizeof s, hipMemcpyDeviceToHost)); const int sl = (int)((s.step + 1) & 1); bp[0] = s.bp[sl][0]; bp[1] = s.bp[sl][1]; }
     return 0;
 }
 extern "C" int dqn_set_adam_state(dqn_engine_t* e, const float* m, const float* v, const double* bp, size_t n) {
@@ -287,7 +293,7 @@ extern "C" int dqn_set_adam_state(dqn_engine_t* e, const float* m, const float* 
     if (v && put_vec(e, v, e->v)) return -1;
     if (bp) {
         StepState s; HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipMemcpy(&s, e->state, sizeof s, hipMemcpyDeviceToHost));
-        s.bp1 = bp[0]; s.bp2 = bp[1]; HIPCHK(hipMemcpy(e->state, &s, sizeof s, hipMemcpyHostToDevice));
+        s.bp[0][0] = s.bp[1][0] = bp[0]; s.bp[0][1] = s.bp[1][1] = bp[1]; HIPCHK(hipMemcpy(e->state, &s, sizeof s, hipMemcpyHostToDevice));
     }
     return 0;
 }
@@ -387,60 +393,169 @@ static const char* lname(dqn_engine* e, const char* op, int kind, int i) {
     char* b = buf[(slot++) % (DQN_MAX_LAYERS * 8)]; snprintf(b, 24, "%s_%s%d", op, kind == DQN_LAYER_CONV ? "conv" : "dense", i); return b;
 }
 enum { PH_ALL = 0, PH_PRE = 1, PH_POST = 2 };
-static void enqueue_step(dqn_engine* e, bool sample, int phase) {
-    const int B = e->B, ncon = e->ncon, ld0 = 2 * B; hipStream_t st = e->stream;
-    if (phase != PH_POST) {
-        if (sample) RUN(e, "sample", launch_sample(st, B, e->cap2, e->tree, e->hp.seed, e->idx, e->state));
-        RUN(e, "gather", launch_gather_fb(st, e->s_rows, e->sp_rows, e->hp.obs_dtype == DQN_OBS_U8, e->E, B, e->idx, e->x0));
-        for (int i = 0; i < e->nl; i++) {   // online net on [s ; sp] (src/solver.jl:210,220), target net on sp (:211)
-            const LayerDev& l = e->L[i];
-            if (e->hp.use_mfma) {           // both nets of this layer in ONE launch of the LDS-tiled MFMA kernel
-                const float* Ps[2] = {e->p_on, e->p_tg};
-                const float* Xs[2] = {l.src < 0 ? e->x0 : e->act_on[l.src], l.src < 0 ? e->x0 : e->act_tg[l.src]};
-                const int lds[2] = {l.src < 0 ? ld0 : ncon, l.src < 0 ? ld0 : B}, c0s[2] = {0, l.src < 0 ? B : 0}, ncs[2] = {ncon, B};
-                float* Ys[2] = {e->act_on[i], e->act_tg[i]}; float* Pt[2] = {e->partials, e->partials + e->partials_elems};
-                prof_begin(e, lname(e, "fwd2", l.kind, i));
-                const bool ok = launch_gemm_fwd2(st, l, 2, Ps, Xs, lds, c0s, ncs, Ys, Pt);
-                prof_end(e);
-                if (ok) continue;
-                if (e->profiling) { hipEventDestroy(e->prof.back().a); hipEventDestroy(e->prof.back().b); e->prof.pop_back(); }
-            }
-            fwd_layer(e, l, e->p_on, l.src < 0 ? e->x0 : e->act_on[l.src], l.src < 0 ? ld0 : ncon, 0, ncon, e->act_on[i], lname(e, "fwd_on", l.kind, i));
-            fwd_layer(e, l, e->p_tg, l.src < 0 ? e->x0 : e->act_tg[l.src], l.src < 0 ? ld0 : B, l.src < 0 ? B : 0, B, e->act_tg[i], lname(e, "fwd_tg", l.kind, i));
+
+// ---------------------------------------------------------------- static launch program
+// Every pointer, shape and plan is fixed at engine creation, so the train step is compiled ONCE into a list of launches
+// (closures) and merely replayed (and captured into a hipGraph).  Small independent kernels are batched: one k_valu_multi
+// launch per network level, one k_reduce_multi per level, head reductions folded into k_td.
+template <class T> static T* upload(dqn_engine* e, const std::vector<T>& v) {
+    T* d = nullptr; hipMalloc((void**)&d, sizeof(T) * v.size()); hipMemcpy(d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice);
+    e->prog_allocs.push_back(d); return d;
+}
+static float* palloc(dqn_engine* e, size_t n) { float* d = nullptr; hipMalloc((void**)&d, n * 4); e->prog_allocs.push_back(d); return d; }
+static bool same_geo(const LayerDev& a, const LayerDev& b) {
+    return a.kind == b.kind && a.act == b.act && a.K == b.K && a.N == b.N && a.npos == b.npos && a.cin == b.cin && a.kh == b.kh && a.kw == b.kw &&
+           a.sh == b.sh && a.sw == b.sw && a.ih == b.ih && a.iw == b.iw && a.fwd_kc == b.fwd_kc && a.src == b.src;
+}
+static void add_valu(dqn_engine* e, std::vector<VTask>& pend, const VTask& t) { pend.push_back(t); }
+static void flush_valu(dqn_engine* e, std::vector<VTask>& pend, const char* name) {
+    if (pend.empty()) return;
+    unsigned blocks = 0;
+    for (auto& t : pend) { t.first_block = blocks; blocks += valu_task_blocks(t); }
+    VTask* dev = upload(e, pend); const int n = (int)pend.size();
+    e->prog.push_back({name, [=](dqn_engine* en) { launch_valu_multi(en->stream, dev, n, blocks); }});
+    pend.clear();
+}
+static void emit_reduce(dqn_engine* e, std::vector<RSeg>& segs, const char* name) {
+    if (segs.empty()) return;
+    unsigned blocks = 0;
+    for (auto& r : segs) { r.first_block = blocks; blocks += (unsigned)((r.elems + 255) / 256); }
+    RSeg* dev = upload(e, segs); const int n = (int)segs.size();
+    e->prog.push_back({name, [=](dqn_engine* en) { launch_reduce_multi(en->stream, dev, n, blocks); }});
+    segs.clear();
+}
+static const char* pname(dqn_engine* e, const char* op, int kind, int i) {
+    char b[32]; snprintf(b, sizeof b, "%s_%s%d", op, kind == DQN_LAYER_CONV ? "conv" : "dense", i); e->prog_names.push_back(b); return e->prog_names.back().c_str();
+}
+static int build_program(dqn_engine* e) {
+    if (e->prog_built) return 0;
+    HIPCHK(hipSetDevice(e->device));
+    e->prog_names.reserve(512);
+    const int B = e->B, ncon = e->ncon, ld0 = 2 * B;
+    const bool mf = e->hp.use_mfma != 0;
+    std::vector<std::vector<int>> levels; std::vector<int> val, adv;
+    for (int i = 0; i < e->nl; i++) { if (e->L[i].stream == DQN_STREAM_BASE) levels.push_back({i}); else if (e->L[i].stream == DQN_STREAM_VAL) val.push_back(i); else adv.push_back(i); }
+    for (size_t j = 0; j < std::max(val.size(), adv.size()); j++) { std::vector<int> lv; if (j < val.size()) lv.push_back(val[j]); if (j < adv.size()) lv.push_back(adv[j]); levels.push_back(lv); }
+    HeadSrc head[DQN_MAX_LAYERS][2];   // per (layer, net): where k_td finds the layer's output
+    // ---------------- forward: online net on [s ; sp] (src/solver.jl:210,220), target net on sp (:211)
+    for (size_t li = 0; li < levels.size(); li++) {
+        const auto& lv = levels[li]; const bool last = li + 1 == levels.size();
+        struct Prob { int l, net; const float *P, *X; int ldx, col0, ncols; float *Y, *part; int S; };
+        std::vector<Prob> pr;
+        for (int l : lv) for (int net = 0; net < 2; net++) {
+            const LayerDev& L = e->L[l]; Prob q; q.l = l; q.net = net; q.P = net ? e->p_tg : e->p_on;
+            float** act = net ? e->act_tg : e->act_on;
+            q.X = L.src < 0 ? e->x0 : act[L.src]; q.ldx = L.src < 0 ? ld0 : (net ? B : ncon); q.col0 = (L.src < 0 && net) ? B : 0; q.ncols = net ? B : ncon;
+            q.Y = act[l]; q.S = dqn_nchunks(L.K, L.fwd_kc); q.part = q.S > 1 ? palloc(e, (size_t)q.S * L.out_feat * q.ncols) : nullptr;
+            pr.push_back(q);
         }
+        bool geo = true; for (int l : lv) geo = geo && same_geo(e->L[lv[0]], e->L[l]);
+        std::vector<bool> done(pr.size(), false);
+        auto emit_gemm = [&](const std::vector<int>& ids, const char* name) {
+            const LayerDev L = e->L[pr[ids[0]].l]; const int n = (int)ids.size();
+            struct A { const float *W[4], *bias[4], *X[4]; int ldx[4], col0[4], ncols[4]; float* out[4]; } a;
+            for (int i = 0; i < n; i++) { const Prob& q = pr[ids[i]]; const LayerDev& Lq = e->L[q.l]; a.W[i] = q.P + Lq.w_off; a.bias[i] = q.P + Lq.b_off; a.X[i] = q.X; a.ldx[i] = q.ldx; a.col0[i] = q.col0; a.ncols[i] = q.ncols; a.out[i] = q.S > 1 ? q.part : q.Y; }
+            e->prog.push_back({name, [=](dqn_engine* en) { launch_gemm_fwd(en->stream, L, n, a.W, a.bias, a.X, a.ldx, a.col0, a.ncols, a.out); }});
+            for (int id : ids) done[id] = true;
+        };
+        if (mf) {
+            std::vector<int> all; int ldx[4], c0[4], nc[4];
+            for (size_t i = 0; i < pr.size() && i < 4; i++) { all.push_back((int)i); ldx[i] = pr[i].ldx; c0[i] = pr[i].col0; nc[i] = pr[i].ncols; }
+            if (geo && pr.size() <= 4 && gemm_fwd_eligible(e->L[lv[0]], (int)pr.size(), ldx, c0, nc)) emit_gemm(all, pname(e, "fwd", e->L[lv[0]].kind, lv[0]));
+            else for (size_t i = 0; i + 1 < pr.size(); i += 2) {
+                int l2[2] = {pr[i].ldx, pr[i + 1].ldx}, c2[2] = {pr[i].col0, pr[i + 1].col0}, n2[2] = {pr[i].ncols, pr[i + 1].ncols};
+                if (gemm_fwd_eligible(e->L[pr[i].l], 2, l2, c2, n2)) emit_gemm({(int)i, (int)i + 1}, pname(e, "fwd", e->L[pr[i].l].kind, pr[i].l));
+            }
+        }
+        std::vector<VTask> pend;
+        for (size_t i = 0; i < pr.size(); i++) {
+            if (done[i]) continue;
+            const Prob q = pr[i]; const LayerDev L = e->L[q.l];
+            if (mf && mfma_fwd_ok(L, q.ncols)) {
+                e->prog.push_back({pname(e, q.net ? "fwd_tg" : "fwd_on", L.kind, q.l), [=](dqn_engine* en) { launch_mfma_fwd(en->stream, L, q.P, q.X, q.ldx, q.col0, q.ncols, q.Y, q.part, false); }});
+            } else {
+                VTask t; memset(&t, 0, sizeof t); t.kind = 0; t.L = L; t.P = q.P; t.X = q.X; t.ldx = q.ldx; t.col0 = q.col0; t.ncols = q.ncols; t.S = q.S; t.kc = dqn_chunk_len(L.K, L.fwd_kc);
+                t.out = q.S > 1 ? q.part : q.Y; add_valu(e, pend, t);
+            }
+        }
+        flush_valu(e, pend, pname(e, "fwd_valu", e->L[lv[0]].kind, lv[0]));
+        std::vector<RSeg> segs;
+        for (const Prob& q : pr) {
+            const LayerDev& L = e->L[q.l];
+            HeadSrc h; h.p = q.Y; h.ld = q.ncols; h.S = 1; h.per_s = 0; h.bias = q.P + L.b_off; h.act = L.act;
+            if (q.S > 1) {
+                if (last) { h.p = q.part; h.S = q.S; h.per_s = (unsigned long long)L.out_feat * q.ncols; }   // reduced on the fly by k_td
+                else { RSeg r; memset(&r, 0, sizeof r); r.part = q.part; r.S = q.S; r.elems = (unsigned long long)L.out_feat * q.ncols; r.mode = 0; r.bias = q.P + L.b_off; r.per_n = L.npos * q.ncols; r.act = L.act; r.out = q.Y; segs.push_back(r); }
+            }
+            head[q.l][q.net] = h;
+        }
+        emit_reduce(e, segs, pname(e, "fwd_reduce", e->L[lv[0]].kind, lv[0]));
+    }
+    // ---------------- dueling reduce + argmax + Bellman target + TD + Huber + dL/dQ + priority update
+    {
         TdArgs t; memset(&t, 0, sizeof t);
         t.B = B; t.nA = e->nA; t.ncon = ncon; t.dueling = e->hp.dueling; t.double_q = e->hp.double_q; t.prioritized = e->hp.prioritized_replay;
         t.gamma = e->hp.gamma; t.prio_beta = e->hp.prio_beta; t.prio_eps = e->hp.prio_eps; t.prio_alpha = e->hp.prio_alpha; t.cap2 = e->cap2;
         t.idx = e->idx; t.a = e->ra; t.r = e->rr; t.done = e->rdone; t.tree = e->tree;
         const int lq = e->hp.dueling ? e->last_adv : e->last_base;
-        t.on_adv = e->act_on[lq]; t.tg_adv = e->act_tg[lq]; t.act_adv = e->L[lq].act; t.d_adv = e->dact[lq];
-        if (e->hp.dueling) { t.on_val = e->act_on[e->last_val]; t.tg_val = e->act_tg[e->last_val]; t.act_val = e->L[e->last_val].act; t.d_val = e->dact[e->last_val]; }
+        t.on_adv = head[lq][0]; t.tg_adv = head[lq][1]; t.d_adv = e->dact[lq];
+        if (e->hp.dueling) { t.on_val = head[e->last_val][0]; t.tg_val = head[e->last_val][1]; t.d_val = e->dact[e->last_val]; }
         t.w_is = e->w_is; t.td = e->td; t.q_on_s = e->q_on_s; t.q_on_sp = e->q_on_sp; t.q_tg_sp = e->q_tg_sp; t.ytarget = e->ytarget; t.best = e->best; t.st = e->state;
-        RUN(e, "td_huber", launch_td(st, t));
-        bool joined = false;
-        for (int i = e->nl - 1; i >= 0; i--) {   // backward of the online net on the s columns
-            const LayerDev& l = e->L[i];
-            const float* X = l.src < 0 ? e->x0 : e->act_on[l.src]; const int ldx = l.src < 0 ? ld0 : ncon;
-            prof_begin(e, lname(e, "dw", l.kind, i));
-            if (!(e->hp.use_mfma && launch_mfma_dw(st, l, X, ldx, e->dact[i], B, e->grad, e->partials))) launch_valu_dw(st, l, X, ldx, e->dact[i], B, e->grad, e->partials);
-            prof_end(e);
-            if (l.src < 0) continue;
-            const int src = l.src; const bool is_join = e->hp.dueling && src == e->last_base && l.stream != DQN_STREAM_BASE;
-            float* out = e->dact[src]; const float *addend = nullptr, *ysrc = e->act_on[src];
-            if (is_join && !joined) { out = e->join_tmp; ysrc = nullptr; joined = true; }     // first stream to arrive: raw dX
-            else if (is_join) addend = e->join_tmp;                                             // second: dX_val + dX_adv, then act'
-            prof_begin(e, lname(e, "dx", l.kind, i));
-            if (!(e->hp.use_mfma && launch_mfma_dx(st, l, e->p_on, e->dact[i], B, out, e->partials, addend, ysrc, ncon, e->L[src].act)))
-                launch_valu_dx(st, l, e->p_on, e->dact[i], B, out, e->partials, addend, ysrc, ncon, e->L[src].act);
-            prof_end(e);
+        e->prog.push_back({"td_huber_prio", [=](dqn_engine* en) { TdArgs a = t; a.bump_sample_ctr = en->step_sampled ? 1 : 0; launch_td(en->stream, a); }});
+    }
+    // ---------------- backward of the online net on the s columns (Zygote through src/solver.jl:219-225)
+    std::vector<RSeg> final_segs;   // dW split-K slabs: nothing reads the gradient before Adam, so ONE reduce launch at the end
+    bool joined = false;
+    for (int li = (int)levels.size() - 1; li >= 0; li--) {
+        const auto& lv = levels[li];
+        std::vector<VTask> pend;
+        for (int k = (int)lv.size() - 1; k >= 0; k--) {
+            const int l = lv[k]; const LayerDev L = e->L[l];
+            const float* X = L.src < 0 ? e->x0 : e->act_on[L.src]; const int ldx = L.src < 0 ? ld0 : ncon;
+            float* dpre = e->dact[l];
+            {   // dW / db
+                const int S = dqn_nchunks(L.npos * B, L.dw_kc);
+                float* part = S > 1 ? palloc(e, (size_t)S * (L.K + 1) * L.N) : nullptr;
+                float* grad = e->grad;
+                if (mf && mfma_dw_ok(L, B)) e->prog.push_back({pname(e, "dw", L.kind, l), [=](dqn_engine* en) { launch_mfma_dw(en->stream, L, X, ldx, dpre, B, grad, part, false); }});
+                else { VTask t; memset(&t, 0, sizeof t); t.kind = 1; t.L = L; t.X = X; t.ldx = ldx; t.dpre = dpre; t.B = B; t.S = S; t.kc = dqn_chunk_len(L.npos * B, L.dw_kc); t.out = S > 1 ? part : grad + L.w_off; add_valu(e, pend, t); }
+                if (S > 1) { RSeg r; memset(&r, 0, sizeof r); r.part = part; r.S = S; r.elems = (unsigned long long)(L.K + 1) * L.N; r.mode = 2; r.out = grad + L.w_off; final_segs.push_back(r); }
+            }
+            if (L.src < 0) continue;
+            // dX, then act' of the producing layer; the two streams of a dueling net meet at the base output (dX_val + dX_adv)
+            const int src = L.src; const bool is_join = e->hp.dueling && src == e->last_base && L.stream != DQN_STREAM_BASE;
+            float* out = e->dact[src]; const float *addend = nullptr, *ysrc = e->act_on[src]; const int act_src = e->L[src].act;
+            if (is_join && !joined) { out = e->join_tmp; ysrc = nullptr; joined = true; }
+            else if (is_join) { addend = e->join_tmp; flush_valu(e, pend, pname(e, "bwd_valu", L.kind, l)); }   // depends on the first stream's dX
+            const bool dense = L.kind == DQN_LAYER_DENSE; const int S = dense ? dqn_nchunks(L.N, L.dx_kc) : 1;
+            float* part = S > 1 ? palloc(e, (size_t)S * L.in_feat * B) : nullptr;
+            const float* P = e->p_on;
+            if (mf && mfma_dx_ok(L, B, ncon)) e->prog.push_back({pname(e, "dx", L.kind, l), [=](dqn_engine* en) { launch_mfma_dx(en->stream, L, P, dpre, B, out, part, addend, ysrc, ncon, act_src, false); }});
+            else { VTask t; memset(&t, 0, sizeof t); t.kind = 2; t.L = L; t.P = P; t.dpre = dpre; t.B = B; t.S = S; t.kc = dqn_chunk_len(L.N, L.dx_kc); t.out = S > 1 ? part : out; t.addend = addend; t.ysrc = ysrc; t.ldy = ncon; t.act_src = act_src; add_valu(e, pend, t); }
+            if (S > 1) {
+                flush_valu(e, pend, pname(e, "bwd_valu", L.kind, l));
+                std::vector<RSeg> one; RSeg r; memset(&r, 0, sizeof r); r.part = part; r.S = S; r.elems = (unsigned long long)L.in_feat * B; r.mode = 1; r.act = act_src; r.addend = addend; r.ysrc = ysrc; r.B = B; r.ldy = ncon; r.out = out; one.push_back(r);
+                emit_reduce(e, one, pname(e, "dx_reduce", L.kind, l));
+            }
         }
+        flush_valu(e, pend, pname(e, "bwd_valu", e->L[lv[0]].kind, lv[0]));
     }
-    if (phase != PH_PRE) {
-        RUN(e, "adam", launch_adam(st, e->Pint, e->p_on, e->m, e->v, e->grad, e->state, e->gmax_part, e->hp.adam_f64_scalars, e->hp.learning_rate, e->hp.adam_beta1,
-                                   e->hp.adam_beta2, e->hp.adam_eps, e->world > 1 ? 1.0f / (float)e->world : 1.0f));
-        RUN(e, "update_prio", launch_update_priorities(st, e->hp.prioritized_replay ? B : 0, e->cap2, e->idx, e->td, e->hp.prio_eps, e->hp.prio_alpha,
-                                                       e->tree, e->state, 1, e->hp.adam_beta1, e->hp.adam_beta2, e->gmax_part, adam_blocks(e->Pint)));
+    emit_reduce(e, final_segs, "dw_reduce_all");
+    e->prog_post_begin = e->prog.size();
+    e->prog.push_back({"adam", [](dqn_engine* en) {
+        launch_adam(en->stream, en->Pint, en->p_on, en->m, en->v, en->grad, en->state, en->gmax_part, en->hp.adam_f64_scalars, en->hp.learning_rate,
+                    en->hp.adam_beta1, en->hp.adam_beta2, en->hp.adam_eps, en->world > 1 ? 1.0f / (float)en->world : 1.0f); }});
+    e->prog_built = true;
+    return 0;
+}
+static void enqueue_step(dqn_engine* e, bool sample, int phase) {
+    e->step_sampled = sample;
+    if (phase != PH_POST) {
+        RUN(e, sample ? "sample_gather" : "gather", launch_gather_fb(e->stream, e->s_rows, e->sp_rows, e->hp.obs_dtype == DQN_OBS_U8, e->E, e->B, e->idx, e->x0,
+                                                                   sample ? 1 : 0, e->cap2, e->tree, e->hp.seed, e->state));
+        for (size_t i = 0; i < e->prog_post_begin; i++) RUN(e, e->prog[i].name, e->prog[i].fn(e));
     }
+    if (phase != PH_PRE) for (size_t i = e->prog_post_begin; i < e->prog.size(); i++) RUN(e, e->prog[i].name, e->prog[i].fn(e));
 }
 static int capture(dqn_engine* e, bool sample, int phase, hipGraphExec_t* out) {
     hipGraph_t g;
@@ -456,6 +571,7 @@ static int allreduce_grads(dqn_engine* e) {
     return 0;
 }
 static int run_step(dqn_engine* e, bool sample) {
+    if (build_program(e)) return -1;
     const int gi = sample ? 0 : 1;
     if (e->world > 1) {
         if (e->hp.use_graph && !e->profiling) {
@@ -474,6 +590,8 @@ static int run_step(dqn_engine* e, bool sample) {
     return 0;
 }
 static int fetch_scalars(dqn_engine* e, float* loss, float* gn) {
+    // globalnorm (helpers.jl:38-46): fold the Adam kernel's per-block maxima only when the host asks for the scalar
+    if (gn) launch_update_priorities(e->stream, 0, e->cap2, e->idx, e->td, e->hp.prio_eps, e->hp.prio_alpha, e->tree, e->state, 1, 1.0, 1.0, e->gmax_part, adam_blocks(e->Pint));
     StepState s; HIPCHK(hipMemcpyAsync(&s, e->state, sizeof s, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream));
     if (s.err == 2) return fail("AssertionError: all(new_priorities .> 0f0)");
     if (loss) *loss = s.loss;

@@ -22,14 +22,15 @@ void launch_reduce_pub(hipStream_t st, const float* part, int S, size_t elems, i
 // workgroup tile = 4 M-tiles (16 columns each, drawn from consecutive (pos, column-tile) pairs; wave w owns M-tile w)
 //                  x NT N-tiles (16*NT output channels), K walked in tiles of 32.
 // =====================================================================================================================
-struct GFwdProb { const float* P; const float* X; int ldx, col0, ncols; float* out; int mtiles, mgroups; };
+struct GFwdProb { const float* W; const float* bias; const float* X; int ldx, col0, ncols; float* out; int mtiles, mgroups; };
+struct GFwdProbs { GFwdProb p[4]; int wg_end[4]; };   // up to 4 problems of one geometry per launch: {val,adv} x {online,target}
 
 constexpr int F_KT = 32;        // K tile depth
 constexpr int F_SA = 80;        // A tile row stride (64 columns + 16 pad): ds_read_b32 of lanes (i, kq) hits banks 16*kq + i
 template <int NT> struct FwdCfg { static constexpr int NW = 16 * NT; static constexpr int SB = (NW % 32 == 0) ? NW + 16 : NW + 32; };
 
 template <int NT>
-__global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProb p0, GFwdProb p1, int wgs0, int S, int kc) {
+__global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S, int kc) {
     constexpr int NW = FwdCfg<NT>::NW, SB = FwdCfg<NT>::SB;
     extern __shared__ float lds[];
     float* As = lds;                                   // [2][F_KT][F_SA]
@@ -41,9 +42,11 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProb p0, GFwdPr
         const int khw = L.kh * L.kw;
         for (int k = tid; k < L.K; k += 256) { const int ci = k / khw, ky = (k / L.kw) % L.kh, kx = k % L.kw; koff_lds[k] = (ci * L.ih + ky) * L.iw + kx; }
     }
-    const bool second = (int)blockIdx.x >= wgs0;
-    const GFwdProb& p = second ? p1 : p0;
-    int w = second ? xcd_remap(blockIdx.x - wgs0, gridDim.x - wgs0) : xcd_remap(blockIdx.x, wgs0);
+    int pi = 0;
+    while (pi < 3 && (int)blockIdx.x >= pr.wg_end[pi]) pi++;
+    const GFwdProb& p = pr.p[pi];
+    const int wg_begin = pi == 0 ? 0 : pr.wg_end[pi - 1];
+    int w = xcd_remap(blockIdx.x - wg_begin, pr.wg_end[pi] - wg_begin);
     const int ngroups = L.N / NW;
     const int ng = w % ngroups; w /= ngroups;
     const int mgrp = w % p.mgroups; const int s = w / p.mgroups;
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProb p0, GFwdPr
     // ---- B tile slice: NW/4 float4 per row
     constexpr int BF4 = NW / 4;                        // float4 per B row
     constexpr int BQ = (F_KT * BF4 + 255) / 256;       // float4 per thread (1 or 2)
-    const float* Wp = p.P + L.w_off + n0;
+    const float* Wp = p.W + n0;
 
     if (conv) __syncthreads();                         // koff table ready
     // Register staging with HAND-COUNTED waits.  hipcc's waitcnt pass drains vmcnt(0) before every prefetch issue in a
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProb p0, GFwdPr
         const int n = n0 + 16 * t + l15;
         f32x4 v = acc[t];
         if (S == 1) {
-            const float bias = p.P[L.b_off + n];
+            const float bias = p.bias[n];
             v.x = act_f(v.x + bias, L.act); v.y = act_f(v.y + bias, L.act); v.z = act_f(v.z + bias, L.act); v.w = act_f(v.w + bias, L.act);
         }
         *reinterpret_cast<f32x4*>(p.out + (size_t)s * per_s + ((size_t)n * L.npos + pos) * p.ncols + ct * 16 + 4 * kq) = v;
@@ -161,29 +164,32 @@ static int fwd_pick_nt(const LayerDev& L, long mgroups_total, int S) {
     return best;
 }
 
-// one launch for up to two problems sharing the layer geometry (online net on [s;sp], target net on sp)
-bool launch_gemm_fwd2(hipStream_t st, const LayerDev& L, int nprob, const float* const* P, const float* const* X, const int* ldx, const int* col0,
-                      const int* ncols, float* const* Y, float* const* partials) {
+// one launch for up to four problems sharing the layer geometry (sibling layers x {online net on [s;sp], target net on sp});
+// split-K partial slabs are left for the caller to reduce (k_reduce_multi, or folded into the consumer)
+bool gemm_fwd_eligible(const LayerDev& L, int nprob, const int* ldx, const int* col0, const int* ncols) {
     const int S = dqn_nchunks(L.K, L.fwd_kc), kc = dqn_chunk_len(L.K, L.fwd_kc);
-    if (L.N % 16 || L.K % F_KT || (S > 1 && kc % F_KT) || L.K > 8192) return false;
+    if (L.N % 16 || L.K % F_KT || (S > 1 && kc % F_KT) || L.K > 8192 || L.w_off % 4) return false;
     for (int i = 0; i < nprob; i++) if (ncols[i] % 16 || ldx[i] % 4 || col0[i] % 4) return false;
-    GFwdProb pr[2]; long mg_total = 0;
-    for (int i = 0; i < 2; i++) {
+    return true;
+}
+void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* const* W, const float* const* bias, const float* const* X,
+                     const int* ldx, const int* col0, const int* ncols, float* const* out) {
+    const int S = dqn_nchunks(L.K, L.fwd_kc), kc = dqn_chunk_len(L.K, L.fwd_kc);
+    GFwdProbs pr; long mg_total = 0;
+    for (int i = 0; i < 4; i++) {
         const int j = i < nprob ? i : 0;
-        pr[i].P = P[j]; pr[i].X = X[j]; pr[i].ldx = ldx[j]; pr[i].col0 = col0[j]; pr[i].ncols = ncols[j]; pr[i].out = S == 1 ? Y[j] : partials[j];
-        pr[i].mtiles = L.npos * (ncols[j] / 16); pr[i].mgroups = (pr[i].mtiles + 3) / 4;
-        if (i < nprob) mg_total += pr[i].mgroups;
+        GFwdProb& q = pr.p[i];
+        q.W = W[j]; q.bias = bias[j]; q.X = X[j]; q.ldx = ldx[j]; q.col0 = col0[j]; q.ncols = ncols[j]; q.out = out[j];
+        q.mtiles = L.npos * (ncols[j] / 16); q.mgroups = (q.mtiles + 3) / 4;
+        if (i < nprob) mg_total += q.mgroups;
     }
     const int NT = fwd_pick_nt(L, mg_total, S);
     const int ngroups = L.N / (16 * NT);
-    const int wgs0 = pr[0].mgroups * ngroups * S, wgs1 = nprob > 1 ? pr[1].mgroups * ngroups * S : 0;
+    int end = 0;
+    for (int i = 0; i < 4; i++) { if (i < nprob) end += pr.p[i].mgroups * ngroups * S; pr.wg_end[i] = end; }
     const int SB = NT == 4 ? FwdCfg<4>::SB : (NT == 2 ? FwdCfg<2>::SB : FwdCfg<1>::SB);
     const size_t lds = (size_t)(2 * F_KT * F_SA + 2 * F_KT * SB) * 4 + (L.kind == DQN_LAYER_CONV ? (size_t)L.K * 4 : 0);
-    if (NT == 4) hipLaunchKernelGGL((k_fwd_lds<4>), dim3(wgs0 + wgs1), dim3(256), lds, st, L, pr[0], pr[1], wgs0, S, kc);
-    else if (NT == 2) hipLaunchKernelGGL((k_fwd_lds<2>), dim3(wgs0 + wgs1), dim3(256), lds, st, L, pr[0], pr[1], wgs0, S, kc);
-    else hipLaunchKernelGGL((k_fwd_lds<1>), dim3(wgs0 + wgs1), dim3(256), lds, st, L, pr[0], pr[1], wgs0, S, kc);
-    if (S > 1)
-        for (int i = 0; i < nprob; i++)
-            launch_reduce_pub(st, partials[i], S, (size_t)L.N * L.npos * ncols[i], 0, P[i] + L.b_off, L.npos * ncols[i], L.act, nullptr, nullptr, 0, 0, Y[i]);
-    return true;
+    if (NT == 4) hipLaunchKernelGGL((k_fwd_lds<4>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
+    else if (NT == 2) hipLaunchKernelGGL((k_fwd_lds<2>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
+    else hipLaunchKernelGGL((k_fwd_lds<1>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
 }

@@ -130,15 +130,19 @@ static void fwd_launch(hipStream_t st, const LayerDev& L, const FwdProb& p, int 
     const size_t lds = L.kind == DQN_LAYER_CONV ? (size_t)L.K * sizeof(int) : 0;
     hipLaunchKernelGGL((k_mfma_fwd<MT, NT>), dim3((ntasks + 3) / 4), dim3(256), lds, st, L, p, S, kc, ntasks);
 }
-bool launch_mfma_fwd(hipStream_t st, const LayerDev& L, const float* P, const float* X, int ldx, int col0, int ncols, float* Y, float* partials) {
+bool mfma_fwd_ok(const LayerDev& L, int ncols) {
     const int S = dqn_nchunks(L.K, L.fwd_kc), kc = dqn_chunk_len(L.K, L.fwd_kc);
-    if (L.N % 16 || ncols % 16 || L.K % 4 || (S > 1 && kc % 4) || L.K > 16384) return false;
+    return !(L.N % 16 || ncols % 16 || L.K % 4 || (S > 1 && kc % 4) || L.K > 16384);
+}
+bool launch_mfma_fwd(hipStream_t st, const LayerDev& L, const float* P, const float* X, int ldx, int col0, int ncols, float* Y, float* partials, bool reduce) {
+    const int S = dqn_nchunks(L.K, L.fwd_kc), kc = dqn_chunk_len(L.K, L.fwd_kc);
+    if (!mfma_fwd_ok(L, ncols)) return false;
     FwdProb p{P, X, ldx, col0, ncols, S == 1 ? Y : partials};
     int MT, NT; pick_tile(ncols / 16, L.N / 16, (long)L.npos * S, &MT, &NT, 4, 2);
 #define FWD_CASE(m, n) if (MT == m && NT == n) fwd_launch<m, n>(st, L, p, S, kc)
     FWD_CASE(1, 1); else FWD_CASE(2, 1); else FWD_CASE(4, 1); else FWD_CASE(1, 2); else FWD_CASE(2, 2); else FWD_CASE(4, 2);
 #undef FWD_CASE
-    if (S > 1) launch_reduce_pub(st, partials, S, (size_t)L.N * L.npos * ncols, 0, P + L.b_off, L.npos * ncols, L.act, nullptr, nullptr, 0, 0, Y);
+    if (S > 1 && reduce) launch_reduce_pub(st, partials, S, (size_t)L.N * L.npos * ncols, 0, P + L.b_off, L.npos * ncols, L.act, nullptr, nullptr, 0, 0, Y);
     return true;
 }
 
@@ -235,19 +239,24 @@ __global__ __launch_bounds__(256) void k_mfma_dx(LayerDev L, const float* __rest
         *reinterpret_cast<f32x4*>(out + (size_t)s * per_s + e) = v;
     }
 }
-bool launch_mfma_dx(hipStream_t st, const LayerDev& L, const float* P, const float* dpre, int B, float* out, float* partials,
-                    const float* addend, const float* ysrc, int ldy, int act_src) {
+bool mfma_dx_ok(const LayerDev& L, int B, int ldy) {
     const bool dense = L.kind == DQN_LAYER_DENSE;
     const int S = dense ? dqn_nchunks(L.N, L.dx_kc) : 1, kc = dqn_chunk_len(L.N, L.dx_kc);
     if (B % 16 || L.N % 4 || (S > 1 && kc % 4) || ldy % 4) return false;
-    if (dense ? (L.K % 16 != 0) : (L.cin % 16 != 0)) return false;
+    return dense ? (L.K % 16 == 0) : (L.cin % 16 == 0);
+}
+bool launch_mfma_dx(hipStream_t st, const LayerDev& L, const float* P, const float* dpre, int B, float* out, float* partials,
+                    const float* addend, const float* ysrc, int ldy, int act_src, bool reduce) {
+    const bool dense = L.kind == DQN_LAYER_DENSE;
+    const int S = dense ? dqn_nchunks(L.N, L.dx_kc) : 1, kc = dqn_chunk_len(L.N, L.dx_kc);
+    if (!mfma_dx_ok(L, B, ldy)) return false;
     const long ftiles = dense ? L.K / 16 : (long)(L.cin / 16) * L.ih * L.iw;
     int MT, NT; pick_tile(B / 16, 1, ftiles * S, &MT, &NT, 2, 1);
     const int ntasks = (int)((B / (16 * MT)) * ftiles * S);
     float* dst = S == 1 ? out : partials;
     if (MT == 2) hipLaunchKernelGGL((k_mfma_dx<2>), dim3((ntasks + 3) / 4), dim3(256), 0, st, L, P, dpre, B, S, kc, dst, addend, ysrc, ldy, act_src, ntasks);
     else hipLaunchKernelGGL((k_mfma_dx<1>), dim3((ntasks + 3) / 4), dim3(256), 0, st, L, P, dpre, B, S, kc, dst, addend, ysrc, ldy, act_src, ntasks);
-    if (S > 1) launch_reduce_pub(st, partials, S, (size_t)L.in_feat * B, 1, nullptr, 1, act_src, addend, ysrc, B, ldy, out);
+    if (S > 1 && reduce) launch_reduce_pub(st, partials, S, (size_t)L.in_feat * B, 1, nullptr, 1, act_src, addend, ysrc, B, ldy, out);
     return true;
 }
 
@@ -313,9 +322,13 @@ __global__ __launch_bounds__(256) void k_mfma_dw(LayerDev L, const float* __rest
         }
     }
 }
-bool launch_mfma_dw(hipStream_t st, const LayerDev& L, const float* X, int ldx, const float* dpre, int B, float* G, float* partials) {
+bool mfma_dw_ok(const LayerDev& L, int B) {
     const int KK = L.npos * B, S = dqn_nchunks(KK, L.dw_kc), kc = dqn_chunk_len(KK, L.dw_kc);
-    if (L.N % 16 || B % 4 || (S > 1 && kc % B)) return false;
+    return !(L.N % 16 || B % 4 || (S > 1 && kc % B));
+}
+bool launch_mfma_dw(hipStream_t st, const LayerDev& L, const float* X, int ldx, const float* dpre, int B, float* G, float* partials, bool reduce) {
+    const int KK = L.npos * B, S = dqn_nchunks(KK, L.dw_kc), kc = dqn_chunk_len(KK, L.dw_kc);
+    if (!mfma_dw_ok(L, B)) return false;
     const long mtiles = (L.K + 1 + 15) / 16;
     int MT, NT; pick_tile(1, L.N / 16, mtiles * S, &MT, &NT, 1, 4);
     const int ntasks = (int)((L.N / (16 * NT)) * mtiles * S);
@@ -323,6 +336,6 @@ bool launch_mfma_dw(hipStream_t st, const LayerDev& L, const float* X, int ldx, 
     if (NT == 4) hipLaunchKernelGGL((k_mfma_dw<4>), dim3((ntasks + 3) / 4), dim3(256), 0, st, L, X, ldx, dpre, B, S, kc, dst, ntasks);
     else if (NT == 2) hipLaunchKernelGGL((k_mfma_dw<2>), dim3((ntasks + 3) / 4), dim3(256), 0, st, L, X, ldx, dpre, B, S, kc, dst, ntasks);
     else hipLaunchKernelGGL((k_mfma_dw<1>), dim3((ntasks + 3) / 4), dim3(256), 0, st, L, X, ldx, dpre, B, S, kc, dst, ntasks);
-    if (S > 1) launch_reduce_pub(st, partials, S, (size_t)(L.K + 1) * L.N, 2, nullptr, 1, 0, nullptr, nullptr, 0, 0, G + L.w_off);
+    if (S > 1 && reduce) launch_reduce_pub(st, partials, S, (size_t)(L.K + 1) * L.N, 2, nullptr, 1, 0, nullptr, nullptr, 0, 0, G + L.w_off);
     return true;
 }

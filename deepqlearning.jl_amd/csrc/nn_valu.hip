@@ -23,6 +23,31 @@ __global__ void k_reduce(const float* __restrict__ part, int S, size_t elems, in
     }
     out[e] = tot;
 }
+// several reductions in one launch (segment table in device memory).  mode 1 with S2 > 0 is the dueling JOIN:
+// out = dact( (sum of the first S slabs) + (sum of the next S2 slabs) ) == dX_val + dX_adv, then act' of the base output.
+__global__ __launch_bounds__(256) void k_reduce_multi(const RSeg* __restrict__ segs, int nseg) {
+    int si = 0;
+    while (si + 1 < nseg && blockIdx.x >= segs[si + 1].first_block) si++;
+    const RSeg& R = segs[si];
+    const size_t e = (size_t)(blockIdx.x - R.first_block) * 256 + threadIdx.x;
+    if (e >= R.elems) return;
+    float tot = R.part[e];
+    for (int s = 1; s < R.S; s++) tot = tot + R.part[(size_t)s * R.elems + e];
+    if (R.S2 > 0) {
+        float t2 = R.part[(size_t)R.S * R.elems + e];
+        for (int s = 1; s < R.S2; s++) t2 = t2 + R.part[(size_t)(R.S + s) * R.elems + e];
+        tot = tot + t2;
+    }
+    if (R.mode == 0) tot = act_f(tot + R.bias[e / R.per_n], R.act);
+    else if (R.mode == 1) {
+        if (R.addend) tot = R.addend[e] + tot;
+        if (R.ysrc) tot = dact_f(tot, R.ysrc[(e / R.B) * R.ldy + (e % R.B)], R.act);
+    }
+    R.out[e] = tot;
+}
+void launch_reduce_multi(hipStream_t st, const RSeg* segs_dev, int nseg, unsigned total_blocks) {
+    hipLaunchKernelGGL(k_reduce_multi, dim3(total_blocks), dim3(256), 0, st, segs_dev, nseg);
+}
 static void launch_reduce(hipStream_t st, const float* part, int S, size_t elems, int mode, const float* bias, int per_n, int act,
                           const float* addend, const float* ysrc, int B, int ldy, float* out) {
     hipLaunchKernelGGL(k_reduce, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, part, S, elems, mode, bias, per_n, act, addend, ysrc, B, ldy, out);
@@ -34,10 +59,9 @@ void launch_reduce_pub(hipStream_t st, const float* part, int S, size_t elems, i
 }
 
 // ------------------------------------------------------------------ forward: Y[n][pos][col] = act(sum_k X[xb(pos)+koff(k)][col] W[k][n] + b[n])
-__global__ void k_valu_fwd(LayerDev L, const float* __restrict__ P, const float* __restrict__ X, int ldx, int col0, int ncols, int S, int kc,
-                           float* __restrict__ out) {
+__device__ __forceinline__ void valu_fwd_body(const LayerDev& L, const float* __restrict__ P, const float* __restrict__ X, int ldx, int col0, int ncols,
+                                              int S, int kc, float* __restrict__ out, size_t t) {
     const size_t per_s = (size_t)L.N * L.npos * ncols;
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= per_s * S) return;
     const int s = (int)(t / per_s); const size_t e = t % per_s;
     const int col = (int)(e % ncols); const int pos = (int)((e / ncols) % L.npos); const int n = (int)(e / ((size_t)ncols * L.npos));
@@ -69,6 +93,10 @@ __global__ void k_valu_fwd(LayerDev L, const float* __restrict__ P, const float*
     if (S == 1) out[e] = act_f(acc + P[L.b_off + n], L.act);
     else out[(size_t)s * per_s + e] = acc;
 }
+__global__ void k_valu_fwd(LayerDev L, const float* __restrict__ P, const float* __restrict__ X, int ldx, int col0, int ncols, int S, int kc,
+                           float* __restrict__ out) {
+    valu_fwd_body(L, P, X, ldx, col0, ncols, S, kc, out, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
 void launch_valu_fwd(hipStream_t st, const LayerDev& L, const float* P, const float* X, int ldx, int col0, int ncols, float* Y, float* partials) {
     const int S = dqn_nchunks(L.K, L.fwd_kc), kc = dqn_chunk_len(L.K, L.fwd_kc);
     const size_t per_s = (size_t)L.N * L.npos * ncols, tot = per_s * S;
@@ -78,9 +106,9 @@ void launch_valu_fwd(hipStream_t st, const LayerDev& L, const float* P, const fl
 
 // ------------------------------------------------------------------ dW[k][n] = sum_{(pos,b)} X[xb(pos)+koff(k)][b] dpre[n][pos][b];  db[n] = sum dpre
 // thread = (chunk, k, n) for k < K, plus a virtual row k == K that accumulates the bias gradient.
-__global__ void k_valu_dw(LayerDev L, const float* __restrict__ X, int ldx, const float* __restrict__ dpre, int B, int S, int kc, float* __restrict__ out) {
+__device__ __forceinline__ void valu_dw_body(const LayerDev& L, const float* __restrict__ X, int ldx, const float* __restrict__ dpre, int B, int S, int kc,
+                                             float* __restrict__ out, size_t t) {
     const size_t per_s = (size_t)(L.K + 1) * L.N;
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= per_s * S) return;
     const int s = (int)(t / per_s); const size_t e = t % per_s;
     const int n = (int)(e % L.N), k = (int)(e / L.N);
@@ -99,6 +127,9 @@ __global__ void k_valu_dw(LayerDev L, const float* __restrict__ X, int ldx, cons
     }
     out[(size_t)s * per_s + e] = acc;
 }
+__global__ void k_valu_dw(LayerDev L, const float* __restrict__ X, int ldx, const float* __restrict__ dpre, int B, int S, int kc, float* __restrict__ out) {
+    valu_dw_body(L, X, ldx, dpre, B, S, kc, out, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
 // G layout: dW at w_off ([K][N]) immediately followed by db at b_off ([N]) == rows 0..K of a (K+1) x N matrix.
 void launch_valu_dw(hipStream_t st, const LayerDev& L, const float* X, int ldx, const float* dpre, int B, float* G, float* partials) {
     const int KK = L.npos * B, S = dqn_nchunks(KK, L.dw_kc), kc = dqn_chunk_len(KK, L.dw_kc);
@@ -109,10 +140,9 @@ void launch_valu_dw(hipStream_t st, const LayerDev& L, const float* X, int ldx, 
 }
 
 // ------------------------------------------------------------------ dX[feat][b]  (then dact of the producing layer, optionally + addend at the dueling join)
-__global__ void k_valu_dx(LayerDev L, const float* __restrict__ P, const float* __restrict__ dpre, int B, int S, int kc, float* __restrict__ out,
-                          const float* __restrict__ addend, const float* __restrict__ ysrc, int ldy, int act_src) {
+__device__ __forceinline__ void valu_dx_body(const LayerDev& L, const float* __restrict__ P, const float* __restrict__ dpre, int B, int S, int kc,
+                                             float* __restrict__ out, const float* __restrict__ addend, const float* __restrict__ ysrc, int ldy, int act_src, size_t t) {
     const size_t per_s = (size_t)L.in_feat * B;
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= per_s * S) return;
     const int s = (int)(t / per_s); const size_t e = t % per_s;
     const int b = (int)(e % B); const int feat = (int)(e / B);
@@ -138,6 +168,31 @@ __global__ void k_valu_dx(LayerDev L, const float* __restrict__ P, const float* 
         out[e] = acc;
     } else out[(size_t)s * per_s + e] = acc;
 }
+__global__ void k_valu_dx(LayerDev L, const float* __restrict__ P, const float* __restrict__ dpre, int B, int S, int kc, float* __restrict__ out,
+                          const float* __restrict__ addend, const float* __restrict__ ysrc, int ldy, int act_src) {
+    valu_dx_body(L, P, dpre, B, S, kc, out, addend, ysrc, ldy, act_src, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// One launch for a TABLE of independent small tasks (head forwards of both nets, head dW + dX, ...): the per-launch floor
+// (~4.6 us on MI355X) dominates these tiny kernels, so they are batched.  Tasks live in device memory (static schedule).
+__global__ __launch_bounds__(256) void k_valu_multi(const VTask* __restrict__ tasks, int ntasks) {
+    int ti = 0;
+    while (ti + 1 < ntasks && blockIdx.x >= tasks[ti + 1].first_block) ti++;
+    const VTask& T = tasks[ti];
+    const size_t t = (size_t)(blockIdx.x - T.first_block) * 256 + threadIdx.x;
+    if (T.kind == 0) valu_fwd_body(T.L, T.P, T.X, T.ldx, T.col0, T.ncols, T.S, T.kc, T.out, t);
+    else if (T.kind == 1) valu_dw_body(T.L, T.X, T.ldx, T.dpre, T.B, T.S, T.kc, T.out, t);
+    else valu_dx_body(T.L, T.P, T.dpre, T.B, T.S, T.kc, T.out, T.addend, T.ysrc, T.ldy, T.act_src, t);
+}
+unsigned valu_task_blocks(const VTask& T) {
+    size_t n;
+    if (T.kind == 0) n = (size_t)T.L.N * T.L.npos * T.ncols * T.S;
+    else if (T.kind == 1) n = (size_t)(T.L.K + 1) * T.L.N * T.S;
+    else n = (size_t)T.L.in_feat * T.B * T.S;
+    return (unsigned)((n + 255) / 256);
+}
+void launch_valu_multi(hipStream_t st, const VTask* tasks_dev, int ntasks, unsigned total_blocks) {
+    hipLaunchKernelGGL(k_valu_multi, dim3(total_blocks), dim3(256), 0, st, tasks_dev, ntasks);
+}
 void launch_valu_dx(hipStream_t st, const LayerDev& L, const float* P, const float* dpre, int B, float* out, float* partials,
                     const float* addend, const float* ysrc, int ldy, int act_src) {
     const int S = L.kind == DQN_LAYER_DENSE ? dqn_nchunks(L.N, L.dx_kc) : 1, kc = dqn_chunk_len(L.N, L.dx_kc);
@@ -160,24 +215,68 @@ __device__ __forceinline__ void q_column(int nA, int dueling, const float* val, 
     const float mean = sum / (float)nA;
     for (int a = 0; a < nA; a++) q[a] = (v + adv[(size_t)a * ld + col]) - mean;
 }
+// head output (n, col): either the finished activation, or -- when the head's forward ran split-K and its reduction is
+// folded into this kernel -- act(sum_s partial + bias)
+__device__ __forceinline__ float head_val(const HeadSrc& h, int n, int col) {
+    const size_t e = (size_t)n * h.ld + col;
+    if (h.S <= 1) return h.p[e];
+    float tot = h.p[e];
+    for (int s = 1; s < h.S; s++) tot = tot + h.p[(size_t)s * h.per_s + e];
+    return act_f(tot + h.bias[n], h.act);
+}
+__device__ __forceinline__ void q_column_h(int nA, int dueling, const HeadSrc& val, const HeadSrc& adv, int col, float* q, float* vout, float* araw) {
+    for (int a = 0; a < nA; a++) araw[a] = head_val(adv, a, col);
+    if (!dueling) { for (int a = 0; a < nA; a++) q[a] = araw[a]; *vout = 0.0f; return; }
+    const float v = head_val(val, 0, col); *vout = v;
+    float sum = araw[0];
+    for (int a = 1; a < nA; a++) sum = sum + araw[a];
+    const float mean = sum / (float)nA;
+    for (int a = 0; a < nA; a++) q[a] = (v + araw[a]) - mean;
+}
+__device__ __forceinline__ void q_from_lds(int nA, int dueling, const float* v, const float* a, int ld, int col, float* q, float* vout, float* araw) {
+    for (int i = 0; i < nA; i++) araw[i] = a[i * ld + col];
+    if (!dueling) { for (int i = 0; i < nA; i++) q[i] = araw[i]; *vout = 0.0f; return; }
+    const float vv = v[col]; *vout = vv;
+    float sum = araw[0];
+    for (int i = 1; i < nA; i++) sum = sum + araw[i];
+    const float mean = sum / (float)nA;
+    for (int i = 0; i < nA; i++) q[i] = (vv + araw[i]) - mean;
+}
 __global__ __launch_bounds__(1024) void k_td(TdArgs A) {
-    extern __shared__ float hl[];   // B floats
-    const int B = A.B, nA = A.nA;
+    extern __shared__ float hl[];   // [B] Huber terms | [B] long long indices | head outputs: on_val[ncon] on_adv[nA][ncon] tg_val[B] tg_adv[nA][B]
+    const int B = A.B, nA = A.nA, ncon = A.ncon;
+    long long* sidx = reinterpret_cast<long long*>(hl + ((B + 1) & ~1));
+    float* hv_on_val = reinterpret_cast<float*>(sidx + B);
+    float* hv_on_adv = hv_on_val + ncon;
+    float* hv_tg_val = hv_on_adv + nA * ncon;
+    float* hv_tg_adv = hv_tg_val + B;
+    // phase 1: every lane of the workgroup finishes head outputs (split-K slabs of the head layers are reduced here)
+    {
+        const int n_on = (A.dueling ? 1 : 0) * ncon, n_oa = nA * ncon, n_tv = (A.dueling ? 1 : 0) * B, n_ta = nA * B;
+        for (int e = threadIdx.x; e < n_on + n_oa + n_tv + n_ta; e += blockDim.x) {
+            if (e < n_on) hv_on_val[e] = head_val(A.on_val, 0, e);
+            else if (e < n_on + n_oa) { const int i = e - n_on; hv_on_adv[i] = head_val(A.on_adv, i / ncon, i % ncon); }
+            else if (e < n_on + n_oa + n_tv) { const int i = e - n_on - n_oa; hv_tg_val[i] = head_val(A.tg_val, 0, i); }
+            else { const int i = e - n_on - n_oa - n_tv; hv_tg_adv[i] = head_val(A.tg_adv, i / B, i % B); }
+        }
+    }
+    __syncthreads();
     const float invB = 1.0f / (float)B;
     const float total = A.tree[1];
     const long long size = A.st->size;
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         const long long j = A.idx[b];
+        sidx[b] = j;
         const int act = A.a[j]; const float rew = A.r[j]; const float dn = (float)A.done[j];
         const float p = A.tree[A.cap2 + j] / total; const float xw = (float)size * p;
         const float w = (float)pow((double)xw, -(double)A.prio_beta);     // IS weight, ...replay.jl:101-102
         A.w_is[b] = w;
-        float q[DQN_MAX_ACTIONS], qt[DQN_MAX_ACTIONS];
-        q_column(nA, A.dueling, A.tg_val, A.tg_adv, B, b, qt);
+        float q[DQN_MAX_ACTIONS], qt[DQN_MAX_ACTIONS], araw[DQN_MAX_ACTIONS], vraw;
+        q_from_lds(nA, A.dueling, hv_tg_val, hv_tg_adv, B, b, qt, &vraw, araw);
         for (int a = 0; a < nA; a++) A.q_tg_sp[(size_t)b * nA + a] = qt[a];
         int best = 0; float qsp;
         if (A.double_q) {
-            q_column(nA, A.dueling, A.on_val, A.on_adv, A.ncon, B + b, q);
+            q_from_lds(nA, A.dueling, hv_on_val, hv_on_adv, ncon, B + b, q, &vraw, araw);
             for (int a = 0; a < nA; a++) A.q_on_sp[(size_t)b * nA + a] = q[a];
             for (int a = 1; a < nA; a++) if (q[a] > q[best]) best = a;
         } else {
@@ -188,7 +287,7 @@ __global__ __launch_bounds__(1024) void k_td(TdArgs A) {
         A.best[b] = best;
         const float t1 = 1.0f - dn; const float t2 = t1 * A.gamma; const float t3 = t2 * qsp; const float y = rew + t3;
         A.ytarget[b] = y;
-        q_column(nA, A.dueling, A.on_val, A.on_adv, A.ncon, b, q);
+        q_from_lds(nA, A.dueling, hv_on_val, hv_on_adv, ncon, b, q, &vraw, araw);
         float qsa = q[0];
         for (int a = 0; a < nA; a++) { A.q_on_s[(size_t)b * nA + a] = q[a]; if (a == act) qsa = q[a]; }
         const float td = qsa - y; A.td[b] = td;
@@ -197,22 +296,43 @@ __global__ __launch_bounds__(1024) void k_td(TdArgs A) {
         const float cl = x < -1.0f ? -1.0f : (x > 1.0f ? 1.0f : x);
         const float g = (invB * cl) * w;
         if (A.dueling) {
-            A.d_val[b] = dact_f(g, A.on_val[b], A.act_val);
+            A.d_val[b] = dact_f(g, vraw, A.on_val.act);
             const float gm = g / (float)nA;
-            for (int a = 0; a < nA; a++) A.d_adv[(size_t)a * B + b] = dact_f((a == act ? g : 0.0f) - gm, A.on_adv[(size_t)a * A.ncon + b], A.act_adv);
+            for (int a = 0; a < nA; a++) A.d_adv[(size_t)a * B + b] = dact_f((a == act ? g : 0.0f) - gm, araw[a], A.on_adv.act);
         } else
-            for (int a = 0; a < nA; a++) A.d_adv[(size_t)a * B + b] = dact_f(a == act ? g : 0.0f, A.on_adv[(size_t)a * A.ncon + b], A.act_adv);
+            for (int a = 0; a < nA; a++) A.d_adv[(size_t)a * B + b] = dact_f(a == act ? g : 0.0f, araw[a], A.on_adv.act);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         float lsum = 0.0f;
         for (int b = 0; b < B; b++) lsum = lsum + hl[b];
         A.st->loss = lsum / (float)B;
+        A.st->step = A.st->step + 1;                 // read by k_adam (beta-power slot) later in this step
+        if (A.bump_sample_ctr) A.st->sample_ctr = A.st->sample_ctr + 1;   // the fused sample+gather kernel cannot bump it itself
+    }
+    // update_priorities!(replay, indices, td) with the UNWEIGHTED td (src/solver.jl:231-233, ...replay.jl:76-80): IS weights above
+    // were read from the old priorities; the tree is next used by the following step's sampler.
+    if (A.prioritized) {
+        long long node = 0;
+        for (int b = threadIdx.x; b < B; b += blockDim.x) {
+            bool last = true;
+            for (int j = b + 1; j < B; j++) if (sidx[j] == sidx[b]) { last = false; break; }
+            const float p = prio_f(fabsf(A.td[b]), A.prio_eps, A.prio_alpha);
+            if (!(p > 0.0f)) A.st->err = 2;
+            if (last) A.tree[A.cap2 + sidx[b]] = p;
+        }
+        __syncthreads();
+        if (threadIdx.x < B) node = (A.cap2 + sidx[threadIdx.x]) >> 1;      // B <= blockDim here (launch_td guarantees it when prioritized)
+        for (long long width = A.cap2; width > 1; width >>= 1) {
+            if (threadIdx.x < B) { A.tree[node] = A.tree[2 * node] + A.tree[2 * node + 1]; node >>= 1; }
+            __syncthreads();
+        }
     }
 }
 void launch_td(hipStream_t st, const TdArgs& a) {
-    int bs = ((a.B + 63) / 64) * 64; if (bs > 1024) bs = 1024;
-    hipLaunchKernelGGL(k_td, dim3(1), dim3(bs), (size_t)a.B * sizeof(float), st, a);
+    int bs = ((a.B + 63) / 64) * 64; if (bs < 512) bs = 512; if (bs > 1024) bs = 1024;
+    const size_t lds = (size_t)((a.B + 1) & ~1) * sizeof(float) + (size_t)a.B * sizeof(long long) + (size_t)(1 + a.nA) * (a.ncon + a.B) * sizeof(float);
+    hipLaunchKernelGGL(k_td, dim3(1), dim3(bs), lds, st, a);
 }
 
 // Q columns for the policy path (src/policy.jl:38-64): q_out[n][nA], argmax (first max)
@@ -235,7 +355,12 @@ __global__ __launch_bounds__(256) void k_adam(size_t P, float* __restrict__ p, f
                                               StepState* state, float* __restrict__ gmax_part, int f64mode, float lr, double b1, double b2, double eps,
                                               float gscale) {
     __shared__ float wmax[4];
-    const double c1 = 1.0 - state->bp1, c2 = 1.0 - state->bp2;
+    // beta powers are double-buffered by step parity: this step reads slot (step & 1) and block 0 writes slot ((step+1) & 1)
+    // (Flux: bp .= bp .* beta AFTER the update), so no block can observe a half-updated value.
+    const int slot = (int)(state->step & 1ull);
+    const double bp1 = state->bp[slot][0], bp2 = state->bp[slot][1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { state->bp[slot ^ 1][0] = bp1 * b1; state->bp[slot ^ 1][1] = bp2 * b2; }
+    const double c1 = 1.0 - bp1, c2 = 1.0 - bp2;
     float gmax = 0.0f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (size_t)gridDim.x * blockDim.x) {
         float gi = g[i];
@@ -252,7 +377,7 @@ __global__ __launch_bounds__(256) void k_adam(size_t P, float* __restrict__ p, f
             const float fb1 = (float)b1, fb2 = (float)b2;
             const float t1 = fb1 * m[i]; const float t2 = (1.0f - fb1) * gi; mn = t1 + t2;
             const float u1 = fb2 * v[i]; const float u2 = (1.0f - fb2) * gi; const float u3 = u2 * gi; vn = u1 + u3;
-            const float mh = mn / (1.0f - (float)state->bp1); const float vh = vn / (1.0f - (float)state->bp2); const float den = sqrtf(vh) + (float)eps; const float q1 = mh / den;
+            const float mh = mn / (1.0f - (float)bp1); const float vh = vn / (1.0f - (float)bp2); const float den = sqrtf(vh) + (float)eps; const float q1 = mh / den;
             dl = q1 * lr;
         }
         m[i] = mn; v[i] = vn; p[i] = p[i] - dl;

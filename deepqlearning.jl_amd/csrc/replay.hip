@@ -11,16 +11,48 @@
 // 64 features x 64 columns per workgroup through a padded LDS tile: reads are 256-B row segments of the sampled
 // transitions (coalesced along the feature axis), writes are 256-B lines of the batch-innermost arena X0[f][2B]
 // (columns 0..B-1 = s, B..2B-1 = sp).  Algorithmic bytes: 2*B*E*sizeof(obs) read + 2*B*E*4 written.
+// With do_sample, every workgroup first repeats the (cheap, deterministic) stratified sum-tree descent for the 2B columns
+// it needs -- B descents of log2(cap) dependent L2 hits -- instead of waiting for a separate single-workgroup sample
+// launch (~4.6 us floor); workgroup (0,0) publishes the indices for k_td.  The Philox counter is bumped by k_td.
+__device__ __forceinline__ long long tree_descend(const float* __restrict__ tree, long long cap2, long long size, unsigned long long seed,
+                                                  unsigned long long ctr, int i, float seg) {
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)i, 0x5A4D504Cu};
+    philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), c);
+    const float u = (float)(c[0] >> 8) * (1.0f / 16777216.0f);
+    float t = ((float)i + u) * seg;
+    long long node = 1;
+    while (node < cap2) {
+        const float l = tree[2 * node], rg = tree[2 * node + 1];
+        if (t < l || !(rg > 0.0f)) node = 2 * node; else { t -= l; node = 2 * node + 1; }
+    }
+    long long leaf = node - cap2; if (leaf >= size) leaf = size - 1;
+    return leaf;
+}
 __global__ __launch_bounds__(256) void k_gather_fb(const void* __restrict__ s_rows, const void* __restrict__ sp_rows, int u8, int E, int B,
-                                                   const long long* __restrict__ idx, float* __restrict__ x0) {
+                                                   long long* __restrict__ idx, float* __restrict__ x0, int do_sample, long long cap2,
+                                                   const float* __restrict__ tree, unsigned long long seed, const StepState* __restrict__ state) {
     __shared__ float tile[64][65];
+    __shared__ long long rows[64];
     const int f0 = blockIdx.x * 64, c0 = blockIdx.y * 64, lane = threadIdx.x & 63, w = threadIdx.x >> 6, ld = 2 * B;
+    if (threadIdx.x < 64) {
+        const int c = c0 + threadIdx.x;
+        long long r = 0;
+        if (c < ld) {
+            const int i = c < B ? c : c - B;
+            if (do_sample) {
+                r = tree_descend(tree, cap2, state->size, seed, state->sample_ctr, i, tree[1] / (float)B);
+                if (blockIdx.x == 0 && c < B) idx[i] = r;
+            } else r = idx[i];
+        }
+        rows[threadIdx.x] = r;
+    }
+    __syncthreads();
 #pragma unroll 4
     for (int p = 0; p < 16; p++) {
         const int cl = p * 4 + w, c = c0 + cl, f = f0 + lane;
         float v = 0.0f;
         if (c < ld && f < E) {
-            const long long row = idx[c < B ? c : c - B];
+            const long long row = rows[cl];
             const void* base = c < B ? s_rows : sp_rows;
             if (u8) v = (float)((const unsigned char*)base)[row * E + f] / 255.0f;  // test/test_env.jl:59
             else v = ((const float*)base)[row * E + f];
@@ -34,9 +66,10 @@ __global__ __launch_bounds__(256) void k_gather_fb(const void* __restrict__ s_ro
         if (f < E && c < ld) x0[(size_t)f * ld + c] = tile[lane][fl];
     }
 }
-void launch_gather_fb(hipStream_t st, const void* s_rows, const void* sp_rows, int obs_u8, int E, int B, const long long* idx, float* x0) {
+void launch_gather_fb(hipStream_t st, const void* s_rows, const void* sp_rows, int obs_u8, int E, int B, long long* idx, float* x0, int do_sample,
+                      long long cap2, const float* tree, unsigned long long seed, const StepState* state) {
     dim3 grid((E + 63) / 64, (2 * B + 63) / 64);
-    hipLaunchKernelGGL(k_gather_fb, grid, dim3(256), 0, st, s_rows, sp_rows, obs_u8, E, B, idx, x0);
+    hipLaunchKernelGGL(k_gather_fb, grid, dim3(256), 0, st, s_rows, sp_rows, obs_u8, E, B, idx, x0, do_sample, cap2, tree, seed, state);
 }
 
 __global__ void k_gather_rows(const void* __restrict__ rows, int u8, int E, const long long* __restrict__ idx, float* __restrict__ out) {
@@ -105,19 +138,7 @@ __global__ __launch_bounds__(1024) void k_sample(int B, long long cap2, const fl
     const unsigned long long ctr = state->sample_ctr;
     const long long size = state->size;
     const float total = tree[1], seg = total / (float)B;
-    for (int i = threadIdx.x; i < B; i += blockDim.x) {
-        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)i, 0x5A4D504Cu};
-        philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), c);
-        const float u = (float)(c[0] >> 8) * (1.0f / 16777216.0f);
-        float t = ((float)i + u) * seg;
-        long long node = 1;
-        while (node < cap2) {
-            const float l = tree[2 * node], rg = tree[2 * node + 1];
-            if (t < l || !(rg > 0.0f)) node = 2 * node; else { t -= l; node = 2 * node + 1; }
-        }
-        long long leaf = node - cap2; if (leaf >= size) leaf = size - 1;
-        idx[i] = leaf;
-    }
+    for (int i = threadIdx.x; i < B; i += blockDim.x) idx[i] = tree_descend(tree, cap2, size, seed, ctr, i, seg);
     __syncthreads();
     if (threadIdx.x == 0) state->sample_ctr = ctr + 1;
 }
@@ -143,7 +164,7 @@ void launch_batch_meta(hipStream_t st, int B, long long cap2, const long long* i
     hipLaunchKernelGGL(k_batch_meta, dim3((B + 255) / 256), dim3(256), 0, st, B, cap2, idx, a, r, done, tree, beta, state, a_out, r_out, done_out, w_out);
 }
 
-// ------------------------------------------------------------------ update_priorities! (+ Adam beta-power tick at the end of a train step)
+// ------------------------------------------------------------------ update_priorities! (host-called seam) / grad-norm fold (tick_adam != 0, on demand)
 __global__ __launch_bounds__(1024) void k_update_priorities(int n, long long cap2, const long long* __restrict__ idx, const float* __restrict__ td,
                                                             float eps, float alpha, float* tree, StepState* state, int tick_adam, double beta1,
                                                             double beta2, const float* __restrict__ gmax_part, int n_gmax) {
@@ -174,7 +195,6 @@ __global__ __launch_bounds__(1024) void k_update_priorities(int n, long long cap
         if (i < n) { tree[node] = tree[2 * node] + tree[2 * node + 1]; node >>= 1; }
         __syncthreads();
     }
-    if (tick_adam && i == 0) { state->bp1 = state->bp1 * beta1; state->bp2 = state->bp2 * beta2; }
 }
 void launch_update_priorities(hipStream_t st, int n, long long cap2, const long long* idx, const float* td, float eps, float alpha,
                               float* tree, StepState* state, int tick_adam, double beta1, double beta2, const float* gmax_part, int n_gmax) {

@@ -5,7 +5,7 @@ import sys
 
 c = sqlite3.connect(sys.argv[1])
 rows = c.execute("select name, start, end, grid_x, workgroup_x, lds_size, vgpr_count from kernels order by start").fetchall()
-idxs = [i for i, r in enumerate(rows) if r[0].startswith("k_sample")]
+idxs = [i for i, r in enumerate(rows) if r[0].startswith("k_gather_fb")]
 a, b = idxs[-3], idxs[-2]
 t0 = rows[a][1]
 print(f"{'t_us':>9s} {'dur_us':>8s} {'grid':>8s} {'wg':>4s} {'lds':>6s} {'vgpr':>4s}  kernel")
