@@ -144,6 +144,13 @@ void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* 
 
 // MFMA path (nn_mfma.hip): returns false if the shape is not eligible (caller falls back to the VALU kernel,
 // which computes bit-identical values)
+bool gemm_dw_eligible(const LayerDev& L, int B, int ldx);
+void launch_gemm_dw(hipStream_t st, const LayerDev& L, int nprob, const float* const* X, int ldx, const float* const* dpre, int B, float* const* out);
+
+bool gemm_dx_eligible(const LayerDev& L, int B, int ldy);
+void launch_gemm_dx(hipStream_t st, const LayerDev& L, int nsrc, const float* const* W, const float* const* dpre, int B, float* out /* dact or partial slabs */,
+                    const float* ysrc, int ldy, int act_src);
+
 // (reduce == false leaves split-K partial slabs in `partials` for the caller's batched k_reduce_multi)
 bool mfma_fwd_ok(const LayerDev& L, int ncols);
 bool mfma_dw_ok(const LayerDev& L, int B);

@@ -147,7 +147,9 @@ static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out) {
         else if (L[i].kind == DQN_LAYER_DENSE && L[i].N < 16 && L[i].K >= 128) out[i].fwd_kc = 32;   // heads: 16+ short chains instead of one long one
         out[i].dx_kc = (L[i].kind == DQN_LAYER_DENSE && L[i].N > 512) ? 256 : 0;
         out[i].dw_kc = 0;
-        if (L[i].kind == DQN_LAYER_CONV) { int ppc = 256 / B; if (ppc < 1) ppc = 1; out[i].dw_kc = ppc * B; }
+        if (L[i].kind == DQN_LAYER_CONV) {   // positions per chunk so that (K/64 row tiles) x chunks >= ~512 workgroups
+            const int st = (512 + (L[i].K + 63) / 64 - 1) / ((L[i].K + 63) / 64); int ppc = L[i].npos / st; if (ppc < 1) ppc = 1; out[i].dw_kc = ppc * B;
+        }
     }
 }
 extern "C" int dqn_plan_default(const dqn_layer_desc* layers, int n_layers, const dqn_hparams* hp, dqn_layer_plan* plan_out) {
@@ -509,6 +511,7 @@ static int build_program(dqn_engine* e) {
     for (int li = (int)levels.size() - 1; li >= 0; li--) {
         const auto& lv = levels[li];
         std::vector<VTask> pend;
+        bool dw_done_sibling = false;   // the level's two sibling layers got their dW from one fused launch
         for (int k = (int)lv.size() - 1; k >= 0; k--) {
             const int l = lv[k]; const LayerDev L = e->L[l];
             const float* X = L.src < 0 ? e->x0 : e->act_on[L.src]; const int ldx = L.src < 0 ? ld0 : ncon;
@@ -517,20 +520,51 @@ static int build_program(dqn_engine* e) {
                 const int S = dqn_nchunks(L.npos * B, L.dw_kc);
                 float* part = S > 1 ? palloc(e, (size_t)S * (L.K + 1) * L.N) : nullptr;
                 float* grad = e->grad;
-                if (mf && mfma_dw_ok(L, B)) e->prog.push_back({pname(e, "dw", L.kind, l), [=](dqn_engine* en) { launch_mfma_dw(en->stream, L, X, ldx, dpre, B, grad, part, false); }});
-                else { VTask t; memset(&t, 0, sizeof t); t.kind = 1; t.L = L; t.X = X; t.ldx = ldx; t.dpre = dpre; t.B = B; t.S = S; t.kc = dqn_chunk_len(L.npos * B, L.dw_kc); t.out = S > 1 ? part : grad + L.w_off; add_valu(e, pend, t); }
-                if (S > 1) { RSeg r; memset(&r, 0, sizeof r); r.part = part; r.S = S; r.elems = (unsigned long long)(L.K + 1) * L.N; r.mode = 2; r.out = grad + L.w_off; final_segs.push_back(r); }
+                float* dst = S > 1 ? part : grad + L.w_off;
+                if (mf && gemm_dw_eligible(L, B, ldx)) {
+                    // sibling layers of this level with identical geometry and the same input share ONE launch
+                    if (k == (int)lv.size() - 1 && lv.size() == 2 && same_geo(e->L[lv[0]], e->L[lv[1]]) && e->L[lv[0]].dw_kc == e->L[lv[1]].dw_kc) {
+                        const LayerDev L0 = e->L[lv[0]]; const int S0 = S;
+                        float* part0 = S0 > 1 ? palloc(e, (size_t)S0 * (L0.K + 1) * L0.N) : nullptr;
+                        struct A { const float* X[2]; const float* d[2]; float* o[2]; } a;
+                        a.X[0] = X; a.d[0] = dpre; a.o[0] = dst; a.X[1] = X; a.d[1] = e->dact[lv[0]]; a.o[1] = S0 > 1 ? part0 : grad + L0.w_off;
+                        e->prog.push_back({pname(e, "dw2", L.kind, l), [=](dqn_engine* en) { launch_gemm_dw(en->stream, L, 2, a.X, ldx, a.d, B, a.o); }});
+                        if (S0 > 1) { RSeg r; memset(&r, 0, sizeof r); r.part = part0; r.S = S0; r.elems = (unsigned long long)(L0.K + 1) * L0.N; r.mode = 2; r.out = grad + L0.w_off; final_segs.push_back(r); }
+                        dw_done_sibling = true;
+                    } else if (!(dw_done_sibling && k == 0 && lv.size() == 2)) {
+                        struct A { const float* X[1]; const float* d[1]; float* o[1]; } a; a.X[0] = X; a.d[0] = dpre; a.o[0] = dst;
+                        e->prog.push_back({pname(e, "dw", L.kind, l), [=](dqn_engine* en) { launch_gemm_dw(en->stream, L, 1, a.X, ldx, a.d, B, a.o); }});
+                    }
+                }
+                else if (mf && mfma_dw_ok(L, B)) e->prog.push_back({pname(e, "dw", L.kind, l), [=](dqn_engine* en) { launch_mfma_dw(en->stream, L, X, ldx, dpre, B, grad, part, false); }});
+                else { VTask t; memset(&t, 0, sizeof t); t.kind = 1; t.L = L; t.X = X; t.ldx = ldx; t.dpre = dpre; t.B = B; t.S = S; t.kc = dqn_chunk_len(L.npos * B, L.dw_kc); t.out = dst; add_valu(e, pend, t); }
+                if (S > 1 && !(dw_done_sibling && k == 0 && lv.size() == 2)) { RSeg r; memset(&r, 0, sizeof r); r.part = part; r.S = S; r.elems = (unsigned long long)(L.K + 1) * L.N; r.mode = 2; r.out = grad + L.w_off; final_segs.push_back(r); }
             }
             if (L.src < 0) continue;
             // dX, then act' of the producing layer; the two streams of a dueling net meet at the base output (dX_val + dX_adv)
             const int src = L.src; const bool is_join = e->hp.dueling && src == e->last_base && L.stream != DQN_STREAM_BASE;
-            float* out = e->dact[src]; const float *addend = nullptr, *ysrc = e->act_on[src]; const int act_src = e->L[src].act;
+            const bool dense = L.kind == DQN_LAYER_DENSE; const int S = dense ? dqn_nchunks(L.N, L.dx_kc) : 1;
+            const float* P = e->p_on; const int act_src = e->L[src].act;
+            if (is_join && lv.size() == 2 && S == 1 && mf && same_geo(e->L[lv[0]], e->L[lv[1]]) && gemm_dx_eligible(L, B, ncon)) {
+                // both streams in ONE launch: the kernel accumulates dX_val and dX_adv separately and adds them (val first)
+                if (k == (int)lv.size() - 1) {
+                    const LayerDev Lv = e->L[lv[0]], La = e->L[lv[1]];
+                    struct A2 { const float* W[2]; const float* d[2]; } a; a.W[0] = P + Lv.w_off; a.d[0] = e->dact[lv[0]]; a.W[1] = P + La.w_off; a.d[1] = e->dact[lv[1]];
+                    float* out = e->dact[src]; const float* ysrc = e->act_on[src];
+                    e->prog.push_back({pname(e, "dx_join", L.kind, l), [=](dqn_engine* en) { launch_gemm_dx(en->stream, Lv, 2, a.W, a.d, B, out, ysrc, ncon, act_src); }});
+                }
+                continue;
+            }
+            float* out = e->dact[src]; const float *addend = nullptr, *ysrc = e->act_on[src];
             if (is_join && !joined) { out = e->join_tmp; ysrc = nullptr; joined = true; }
             else if (is_join) { addend = e->join_tmp; flush_valu(e, pend, pname(e, "bwd_valu", L.kind, l)); }   // depends on the first stream's dX
-            const bool dense = L.kind == DQN_LAYER_DENSE; const int S = dense ? dqn_nchunks(L.N, L.dx_kc) : 1;
             float* part = S > 1 ? palloc(e, (size_t)S * L.in_feat * B) : nullptr;
-            const float* P = e->p_on;
-            if (mf && mfma_dx_ok(L, B, ncon)) e->prog.push_back({pname(e, "dx", L.kind, l), [=](dqn_engine* en) { launch_mfma_dx(en->stream, L, P, dpre, B, out, part, addend, ysrc, ncon, act_src, false); }});
+            if (mf && !addend && gemm_dx_eligible(L, B, ncon)) {
+                struct A1 { const float* W[1]; const float* d[1]; } a; a.W[0] = P + L.w_off; a.d[0] = dpre;
+                float* dst = S > 1 ? part : out; const float* ys = S > 1 ? nullptr : ysrc;
+                e->prog.push_back({pname(e, "dx", L.kind, l), [=](dqn_engine* en) { launch_gemm_dx(en->stream, L, 1, a.W, a.d, B, dst, ys, ncon, act_src); }});
+            }
+            else if (mf && mfma_dx_ok(L, B, ncon)) e->prog.push_back({pname(e, "dx", L.kind, l), [=](dqn_engine* en) { launch_mfma_dx(en->stream, L, P, dpre, B, out, part, addend, ysrc, ncon, act_src, false); }});
             else { VTask t; memset(&t, 0, sizeof t); t.kind = 2; t.L = L; t.P = P; t.dpre = dpre; t.B = B; t.S = S; t.kc = dqn_chunk_len(L.N, L.dx_kc); t.out = S > 1 ? part : out; t.addend = addend; t.ysrc = ysrc; t.ldy = ncon; t.act_src = act_src; add_valu(e, pend, t); }
             if (S > 1) {
                 flush_valu(e, pend, pname(e, "bwd_valu", L.kind, l));

@@ -193,3 +193,271 @@ void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* 
     else if (NT == 2) hipLaunchKernelGGL((k_fwd_lds<2>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
     else hipLaunchKernelGGL((k_fwd_lds<1>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
 }
+
+// =====================================================================================================================
+// dW / db:  G[k][n] = sum_{(pos,b)} X[xb(pos)+koff(k)][b] * dpre[n][pos][b]      db[n] = sum_{(pos,b)} dpre[n][pos][b]
+// Both operands have the CONTRACTION index (the sample b) contiguous in memory, so tiles are fetched as full 128-B row
+// segments (32 samples) and transposed through LDS: A tile = 64 weight rows x 32 samples, B tile = NW channels x 32 samples.
+// workgroup = 64 weight rows (wave w owns rows 16w..16w+15) x NW channels x one split-K chunk; the chunk is walked in
+// K tiles of 32 samples (position-major, sample-minor == the canonical chain order).  The workgroup of weight-row tile 0
+// also accumulates the bias gradient from the B tile (ascending sample order).
+// =====================================================================================================================
+struct GDwProb { const float* X; const float* dpre; float* out; };   // out: G + w_off (S == 1) or the partial slab base
+struct GDwProbs { GDwProb p[2]; };
+constexpr int W_ST = 36;     // LDS row stride (32 samples + 4 pad): 16-B aligned rows, fragment reads at most 2-way conflicted
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_dw_lds(LayerDev L, GDwProbs pr, int nprob, int ldx, int B, int S, int kc) {
+    constexpr int NW = 16 * NT;
+    constexpr int BQ = (NW * 8 + 255) / 256;          // float4 per thread for the B tile (1 or 2)
+    extern __shared__ float lds[];
+    float* As = lds;                                   // [2][64][W_ST]
+    float* Bs = lds + 2 * 64 * W_ST;                   // [2][NW][W_ST]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const bool conv = L.kind == DQN_LAYER_CONV;
+    const int mrows = (L.K + 63) / 64, ngroups = L.N / NW;
+    int w = xcd_remap(blockIdx.x, gridDim.x);
+    const int pi = w % nprob; w /= nprob;
+    const int ng = w % ngroups; w /= ngroups;
+    const int mr = w % mrows; const int s = w / mrows;
+    const GDwProb& p = pr.p[pi];
+    const int n0 = ng * NW;
+    const int KK = L.npos * B, j0 = s * kc, j1 = min(KK, j0 + kc);
+    const int nsub = B / 32, nkt = (j1 - j0) / 32, pos0 = j0 / B;
+    // ---- A tile slice of this thread: rows tid>>3 and +32, float4 (tid & 7)
+    const int f4 = tid & 7;
+    int koff0, koff1;
+    {
+        const int k0r = min(mr * 64 + (tid >> 3), L.K - 1), k1r = min(mr * 64 + (tid >> 3) + 32, L.K - 1);
+        if (conv) {
+            const int khw = L.kh * L.kw;
+            koff0 = ((k0r / khw) * L.ih + (k0r / L.kw) % L.kh) * L.iw + k0r % L.kw;
+            koff1 = ((k1r / khw) * L.ih + (k1r / L.kw) % L.kh) * L.iw + k1r % L.kw;
+        } else { koff0 = k0r; koff1 = k1r; }
+    }
+    const float* Xa = p.X + 4 * f4;
+    // ---- B tile slice: channel rows q>>3 (clamped), float4 (q & 7)
+    const int bq0 = tid < NW * 8 ? tid : NW * 8 - 1, bq1 = tid + 256 < NW * 8 ? tid + 256 : NW * 8 - 1;
+    const float* Db0 = p.dpre + (size_t)(n0 + (bq0 >> 3)) * L.npos * B + 4 * (bq0 & 7);
+    const float* Db1 = p.dpre + (size_t)(n0 + (bq1 >> 3)) * L.npos * B + 4 * (bq1 & 7);
+    constexpr int LPS = 2 + BQ;
+    struct Stage { f32x4 a0, a1, b0, b1; };
+    auto gld = [](const float* ptr) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory"); return v; };
+    auto gload = [&](int kt, Stage& r) {
+        kt = min(kt, nkt - 1);
+        const int pos = pos0 + kt / nsub, bo = (kt % nsub) * 32;
+        int xb = 0;
+        if (conv) { const int oy = pos / L.ow, ox = pos % L.ow; xb = oy * L.sh * L.iw + ox * L.sw; }
+        r.a0 = gld(Xa + (unsigned)(xb + koff0) * (unsigned)ldx + bo);
+        r.a1 = gld(Xa + (unsigned)(xb + koff1) * (unsigned)ldx + bo);
+        r.b0 = gld(Db0 + (unsigned)pos * (unsigned)B + bo);
+        if (BQ > 1) r.b1 = gld(Db1 + (unsigned)pos * (unsigned)B + bo);
+    };
+    auto lstore = [&](int buf, const Stage& r) {
+        *reinterpret_cast<f32x4*>(As + (buf * 64 + (tid >> 3)) * W_ST + 4 * f4) = r.a0;
+        *reinterpret_cast<f32x4*>(As + (buf * 64 + (tid >> 3) + 32) * W_ST + 4 * f4) = r.a1;
+        if (tid < NW * 8) *reinterpret_cast<f32x4*>(Bs + (buf * NW + (tid >> 3)) * W_ST + 4 * f4) = r.b0;
+        if (BQ > 1) *reinterpret_cast<f32x4*>(Bs + (buf * NW + ((tid + 256) >> 3)) * W_ST + 4 * f4) = r.b1;
+    };
+#define STAGE_WAIT(N, r) do { if (BQ > 1) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r.a0), "+v"(r.a1), "+v"(r.b0), "+v"(r.b1) : "n"(N) : "memory"); \
+                              else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r.a0), "+v"(r.a1), "+v"(r.b0) : "n"(N) : "memory"); } while (0)
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float dbacc = 0.0f;
+    const bool do_bias = mr == 0 && tid < NW;
+    auto compute = [&](int buf) {
+        const float* Ab = As + (buf * 64 + 16 * wave + l15) * W_ST + kq;
+        const float* Bb = Bs + (buf * NW + l15) * W_ST + kq;
+#pragma unroll
+        for (int st = 0; st < 8; st++) {
+            const float a = Ab[4 * st];
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = MFMA(a, Bb[16 * t * W_ST + 4 * st], acc[t]);
+        }
+        if (do_bias) {
+            const float* br = Bs + (buf * NW + tid) * W_ST;
+#pragma unroll
+            for (int b = 0; b < 32; b++) dbacc = dbacc + br[b];
+        }
+    };
+    Stage r0, r1;
+    r0.b1 = r1.b1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    gload(0, r0); STAGE_WAIT(0, r0); lstore(0, r0); __syncthreads();
+    gload(1, r0);
+    for (int kt = 0; kt < nkt; kt += 2) {
+        gload(kt + 2, r1);
+        compute(0);
+        STAGE_WAIT(LPS, r0); lstore(1, r0);
+        __syncthreads();
+        gload(kt + 3, r0);
+        if (kt + 1 < nkt) compute(1);
+        STAGE_WAIT(LPS, r1); lstore(0, r1);
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef STAGE_WAIT
+    const size_t per_s = (size_t)(L.K + 1) * L.N;
+    float* out = p.out + (size_t)s * per_s;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const int n = n0 + 16 * t + l15;
+        const float v[4] = {acc[t].x, acc[t].y, acc[t].z, acc[t].w};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int k = mr * 64 + 16 * wave + 4 * kq + r;
+            if (k < L.K) out[(size_t)k * L.N + n] = v[r];
+        }
+    }
+    if (do_bias) out[(size_t)L.K * L.N + n0 + tid] = dbacc;
+}
+bool gemm_dw_eligible(const LayerDev& L, int B, int ldx) {
+    const int KK = L.npos * B, S = dqn_nchunks(KK, L.dw_kc), kc = dqn_chunk_len(KK, L.dw_kc);
+    return !(L.N % 16 || B % 32 || ldx % 4 || L.K < 16 || (S > 1 && kc % B));
+}
+// nprob (<= 2) sibling layers of identical geometry in one launch; out[i] = gradient base (S == 1) or partial slab base
+void launch_gemm_dw(hipStream_t st, const LayerDev& L, int nprob, const float* const* X, int ldx, const float* const* dpre, int B, float* const* out) {
+    const int KK = L.npos * B, S = dqn_nchunks(KK, L.dw_kc), kc = dqn_chunk_len(KK, L.dw_kc);
+    GDwProbs pr;
+    for (int i = 0; i < 2; i++) { const int j = i < nprob ? i : 0; pr.p[i].X = X[j]; pr.p[i].dpre = dpre[j]; pr.p[i].out = out[j]; }
+    const int NT = L.N % 64 == 0 ? 4 : (L.N % 32 == 0 ? 2 : 1);
+    const int grid = ((L.K + 63) / 64) * (L.N / (16 * NT)) * S * nprob;
+    const size_t lds = (size_t)(2 * 64 * W_ST + 2 * 16 * NT * W_ST) * 4;
+    if (NT == 4) hipLaunchKernelGGL((k_dw_lds<4>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc);
+    else if (NT == 2) hipLaunchKernelGGL((k_dw_lds<2>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc);
+    else hipLaunchKernelGGL((k_dw_lds<1>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc);
+}
+
+// =====================================================================================================================
+// dX (+ act' of the producing layer, + the dueling join):
+//   dense: dX[f][b] = sum_n dpre[n][b] W[f][n]                 conv: dX[ci][iy][ix][b] = sum_{valid taps} sum_co dpre[co][oy][ox][b] W[(ci,tap)][co]
+// workgroup = 32 input features (dense: rows f; conv: channels ci at ONE input position) x 32 samples; wave w owns
+// feature tile (w & 1) and sample tile (w >> 1).  K tiles are 32 deep: A tile = 32 dpre rows x 32 samples (row = n / co),
+// B tile = 32 weight rows x 32 k (k contiguous in memory, transposed through LDS).
+// Up to two SOURCES are accumulated separately and added at the end -- the two streams of a dueling network meeting at
+// the base output (dX_val + dX_adv, src/dueling.jl:10 backward) -- so the join costs no extra launch.
+// =====================================================================================================================
+struct GDxSrc { const float* W; const float* dpre; };
+struct GDxArgs { GDxSrc src[2]; int nsrc; float* out; const float* ysrc; int ldy, act_src; };
+constexpr int X_SA = 48;     // A tile row stride (32 samples + 16 pad): fragment reads hit banks 16*kq + i
+constexpr int X_SB = 36;     // B tile row stride (32 k + 4 pad)
+
+__global__ __launch_bounds__(256) void k_dx_lds(LayerDev L, GDxArgs A, int B, int S, int kc) {
+    extern __shared__ float lds[];
+    float* As = lds;                                  // [2][32][X_SA]
+    float* Bs = lds + 2 * 32 * X_SA;                  // [2][32][X_SB]
+    int* taps = (int*)(Bs + 2 * 32 * X_SB);           // conv: valid taps of this input position, (tap << 16) | pos; taps[255] = count
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const bool dense = L.kind == DQN_LAYER_DENSE;
+    const int ft = wave & 1, mt = wave >> 1;
+    const int b0 = blockIdx.y * 32;
+    int w = xcd_remap(blockIdx.x, gridDim.x);
+    int f0, s = 0, ip = 0;                            // f0: first feature row (dense) / first input channel (conv)
+    const int nfeat = dense ? L.K : L.cin;
+    if (dense) { const int ftiles = (L.K + 31) / 32; f0 = (w % ftiles) * 32; s = w / ftiles; }
+    else { const int ctiles = L.cin / 32; f0 = (w % ctiles) * 32; ip = w / ctiles; }
+    int nkt;                                           // K tiles per source
+    const int khw = L.kh * L.kw;
+    if (dense) { const int n0 = s * kc, n1 = min(L.N, n0 + kc); nkt = (n1 - n0) / 32; }
+    else {
+        if (tid == 0) {
+            const int iy = ip / L.iw, ix = ip % L.iw; int c = 0;
+            for (int ky = 0; ky < L.kh; ky++) {
+                const int ty = iy - ky; if (ty < 0 || ty % L.sh) continue; const int oy = ty / L.sh; if (oy >= L.oh) continue;
+                for (int kx = 0; kx < L.kw; kx++) {
+                    const int tx = ix - kx; if (tx < 0 || tx % L.sw) continue; const int ox = tx / L.sw; if (ox >= L.ow) continue;
+                    taps[c++] = ((ky * L.kw + kx) << 16) | (oy * L.ow + ox);
+                }
+            }
+            taps[255] = c;
+        }
+        __syncthreads();
+        nkt = taps[255] * (L.N / 32);
+    }
+    const int total = nkt * A.nsrc;
+    // ---- staging slices: A row (tid >> 3), float4 (tid & 7); B row (tid >> 3), float4 (tid & 7)
+    const int row = tid >> 3, f4 = tid & 7;
+    const int frow = min(f0 + row, nfeat - 1);
+    struct Stage { f32x4 a, b; };
+    auto gld = [](const float* ptr) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory"); return v; };
+    auto gload = [&](int kt, Stage& r) {
+        kt = min(kt, total - 1);
+        const int si = kt >= nkt ? 1 : 0; const int k = kt - si * nkt;
+        const GDxSrc& sr = A.src[si];
+        if (dense) {
+            const int nb = s * kc + k * 32;
+            r.a = gld(sr.dpre + (size_t)(nb + row) * B + b0 + 4 * f4);
+            r.b = gld(sr.W + (size_t)frow * L.N + nb + 4 * f4);
+        } else {
+            const int cot = L.N / 32; const int tp = taps[k / cot]; const int cob = (k % cot) * 32;
+            const int tap = tp >> 16, pos = tp & 0xffff;
+            r.a = gld(sr.dpre + ((size_t)(cob + row) * L.npos + pos) * B + b0 + 4 * f4);
+            r.b = gld(sr.W + ((size_t)frow * khw + tap) * L.N + cob + 4 * f4);
+        }
+    };
+    auto lstore = [&](int buf, const Stage& r) {
+        *reinterpret_cast<f32x4*>(As + (buf * 32 + row) * X_SA + 4 * f4) = r.a;
+        *reinterpret_cast<f32x4*>(Bs + (buf * 32 + row) * X_SB + 4 * f4) = r.b;
+    };
+#define STAGE_WAIT(N, r) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.a), "+v"(r.b) : "n"(N) : "memory")
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf, bool second) {
+        const float* Ab = As + buf * 32 * X_SA + 16 * mt + l15;
+        const float* Bb = Bs + (buf * 32 + 16 * ft + l15) * X_SB + kq;
+        if (!second) {
+#pragma unroll
+            for (int st = 0; st < 8; st++) acc0 = MFMA(Ab[(4 * st + kq) * X_SA], Bb[4 * st], acc0);
+        } else {
+#pragma unroll
+            for (int st = 0; st < 8; st++) acc1 = MFMA(Ab[(4 * st + kq) * X_SA], Bb[4 * st], acc1);
+        }
+    };
+    if (total > 0) {
+        Stage r0, r1;
+        gload(0, r0); STAGE_WAIT(0, r0); lstore(0, r0); __syncthreads();
+        gload(1, r0);
+        for (int kt = 0; kt < total; kt += 2) {
+            gload(kt + 2, r1);
+            compute(0, kt >= nkt);
+            STAGE_WAIT(2, r0); lstore(1, r0);
+            __syncthreads();
+            gload(kt + 3, r0);
+            if (kt + 1 < total) compute(1, kt + 1 >= nkt);
+            STAGE_WAIT(2, r1); lstore(0, r1);
+            __syncthreads();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#undef STAGE_WAIT
+    // ---- epilogue
+    const int fl = f0 + 16 * ft + l15;
+    if (fl >= nfeat) return;
+    const size_t feat = dense ? (size_t)fl : (size_t)fl * L.ih * L.iw + ip;
+    const int bcol = b0 + 16 * mt + 4 * kq;
+    f32x4 v = acc0;
+    if (A.nsrc > 1) { v.x = v.x + acc1.x; v.y = v.y + acc1.y; v.z = v.z + acc1.z; v.w = v.w + acc1.w; }
+    const size_t per_s = (size_t)L.in_feat * B;
+    if (S == 1 && A.ysrc) {
+        const f32x4 y = *reinterpret_cast<const f32x4*>(A.ysrc + feat * A.ldy + bcol);
+        v.x = dact_f(v.x, y.x, A.act_src); v.y = dact_f(v.y, y.y, A.act_src); v.z = dact_f(v.z, y.z, A.act_src); v.w = dact_f(v.w, y.w, A.act_src);
+    }
+    *reinterpret_cast<f32x4*>(A.out + (size_t)s * per_s + feat * B + bcol) = v;
+}
+bool gemm_dx_eligible(const LayerDev& L, int B, int ldy) {
+    const bool dense = L.kind == DQN_LAYER_DENSE;
+    const int S = dense ? dqn_nchunks(L.N, L.dx_kc) : 1, kc = dqn_chunk_len(L.N, L.dx_kc);
+    if (B % 32 || ldy % 4 || L.N % 32 || (S > 1 && kc % 32) || L.w_off % 4) return false;
+    if (!dense && (L.cin % 32 || L.kh * L.kw > 255 || L.npos > 65535)) return false;
+    return true;
+}
+// nsrc == 2: the two dueling streams (identical geometry, S == 1), out = dact(dX_src0 + dX_src1)
+void launch_gemm_dx(hipStream_t st, const LayerDev& L, int nsrc, const float* const* W, const float* const* dpre, int B, float* out,
+                    const float* ysrc, int ldy, int act_src) {
+    const bool dense = L.kind == DQN_LAYER_DENSE;
+    const int S = dense ? dqn_nchunks(L.N, L.dx_kc) : 1, kc = dqn_chunk_len(L.N, L.dx_kc);
+    GDxArgs a; a.nsrc = nsrc; a.out = out; a.ysrc = ysrc; a.ldy = ldy; a.act_src = act_src;
+    for (int i = 0; i < 2; i++) { const int j = i < nsrc ? i : 0; a.src[i].W = W[j]; a.src[i].dpre = dpre[j]; }
+    const int gx = dense ? ((L.K + 31) / 32) * S : (L.cin / 32) * L.ih * L.iw;
+    const size_t lds = (size_t)(2 * 32 * X_SA + 2 * 32 * X_SB) * 4 + 256 * 4;
+    hipLaunchKernelGGL(k_dx_lds, dim3(gx, B / 32), dim3(256), lds, st, L, a, B, S, kc);
+}

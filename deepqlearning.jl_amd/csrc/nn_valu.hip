@@ -32,7 +32,18 @@ __global__ __launch_bounds__(256) void k_reduce_multi(const RSeg* __restrict__ s
     const size_t e = (size_t)(blockIdx.x - R.first_block) * 256 + threadIdx.x;
     if (e >= R.elems) return;
     float tot = R.part[e];
-    for (int s = 1; s < R.S; s++) tot = tot + R.part[(size_t)s * R.elems + e];
+    {   // slab loads are issued 8 at a time (independent), the adds stay in ascending slab order
+        const float* pp = R.part + e; const size_t st = R.elems;
+        int s = 1;
+        for (; s + 8 <= R.S; s += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = pp[(size_t)(s + u) * st];
+#pragma unroll
+            for (int u = 0; u < 8; u++) tot = tot + v[u];
+        }
+        for (; s < R.S; s++) tot = tot + pp[(size_t)s * st];
+    }
     if (R.S2 > 0) {
         float t2 = R.part[(size_t)R.S * R.elems + e];
         for (int s = 1; s < R.S2; s++) t2 = t2 + R.part[(size_t)(R.S + s) * R.elems + e];
