@@ -83,6 +83,30 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// update_priorities!(r, idx, td) (src/prioritized_experience_replay.jl:76-80) executed by ONE workgroup: leaves
+// p = (|td| + eps)^alpha (duplicates: last write wins, :79; assert p > 0, :78), then the ancestors level by level (one
+// barrier per level; equal parents are written with equal values).  `sidx` is >= n long longs of LDS.
+__device__ __forceinline__ void prio_update_block(int n, long long cap2, const long long* __restrict__ idx, const float* __restrict__ td, float eps,
+                                                  float alpha, float* tree, StepState* state, long long* sidx) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) sidx[i] = idx[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        bool last = true;
+        for (int j = i + 1; j < n; j++) if (sidx[j] == sidx[i]) { last = false; break; }
+        const float p = prio_f(fabsf(td[i]), eps, alpha);
+        if (!(p > 0.0f)) state->err = 2;
+        if (last) tree[cap2 + sidx[i]] = p;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) sidx[i] = (cap2 + sidx[i]) >> 1;
+    __syncthreads();
+    for (long long width = cap2; width > 1; width >>= 1) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) { const long long node = sidx[i]; tree[node] = tree[2 * node] + tree[2 * node + 1]; sidx[i] = node >> 1; }
+        __syncthreads();
+    }
+}
+struct PrioArgs { int n; long long cap2; const long long* idx; const float* td; float eps, alpha; float* tree; };
+
 // ---- kernel launchers (defined in the .hip files; all enqueue on `st` and never synchronise)
 // a head tensor as seen by k_td: finished activation (S <= 1) or split-K partial slabs to be reduced on the fly
 struct HeadSrc { const float* p; int ld; int S; unsigned long long per_s; const float* bias; int act; };
@@ -133,7 +157,7 @@ void launch_valu_dx(hipStream_t st, const LayerDev& L, const float* P, const flo
 void launch_td(hipStream_t st, const TdArgs& a);
 int adam_blocks(size_t P);
 void launch_adam(hipStream_t st, size_t P, float* p, float* m, float* v, const float* g, StepState* state, float* gmax_part, int f64mode,
-                 float lr, double b1, double b2, double eps, float gscale);
+                 float lr, double b1, double b2, double eps, float gscale, const PrioArgs& prio);
 void launch_q_columns(hipStream_t st, int n, int nA, int dueling, const float* val, const float* adv, float* q_out /*[n][nA]*/, int* argmax_out);
 void launch_convert_params(hipStream_t st, const LayerDev* layers_dev, int nl, const float* src, float* dst, int to_internal, size_t P_ext);
 

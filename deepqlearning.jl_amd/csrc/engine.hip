@@ -49,7 +49,7 @@ static int rccl_load() {
 struct ProfEntry { const char* name; hipEvent_t a, b; };
 
 struct dqn_engine {
-    int device = 0; hipStream_t stream = nullptr;
+    int device = 0; hipStream_t stream = nullptr, stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int nl = 0; LayerDev L[DQN_MAX_LAYERS]; LayerDev* L_dev = nullptr;
     dqn_hparams hp; int B = 0, nA = 0, E = 0, ncon = 0;
     int last_base = -1, last_val = -1, last_adv = -1;
@@ -187,6 +187,8 @@ extern "C" int dqn_engine_create(const dqn_layer_desc* layers, int n_layers, con
     }
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     const int B = e->B; e->ncon = hp->double_q ? 2 * B : B;
     DM(e->L_dev, e->nl); HIPCHK(hipMemcpy(e->L_dev, e->L, sizeof(LayerDev) * e->nl, hipMemcpyHostToDevice));
     DM(e->p_on, e->Pint); DM(e->p_tg, e->Pint); DM(e->grad, e->Pint); DM(e->m, e->Pint); DM(e->v, e->Pint); DM(e->io_tmp, e->P);
@@ -247,6 +249,9 @@ extern "C" int dqn_engine_destroy(dqn_engine_t* e) {
     free_policy_ws(e);
     for (void* p : e->prog_allocs) hipFree(p);
     if (e->stream) hipStreamDestroy(e->stream);
+    if (e->stream2) hipStreamDestroy(e->stream2);
+    if (e->ev_fork) hipEventDestroy(e->ev_fork);
+    if (e->ev_join) hipEventDestroy(e->ev_join);
     delete e; return 0;
 }
 extern "C" int dqn_engine_get_plan(dqn_engine_t* e, dqn_layer_plan* p) {
@@ -503,7 +508,7 @@ static int build_program(dqn_engine* e) {
         t.on_adv = head[lq][0]; t.tg_adv = head[lq][1]; t.d_adv = e->dact[lq];
         if (e->hp.dueling) { t.on_val = head[e->last_val][0]; t.tg_val = head[e->last_val][1]; t.d_val = e->dact[e->last_val]; }
         t.w_is = e->w_is; t.td = e->td; t.q_on_s = e->q_on_s; t.q_on_sp = e->q_on_sp; t.q_tg_sp = e->q_tg_sp; t.ytarget = e->ytarget; t.best = e->best; t.st = e->state;
-        e->prog.push_back({"td_huber_prio", [=](dqn_engine* en) { TdArgs a = t; a.bump_sample_ctr = en->step_sampled ? 1 : 0; launch_td(en->stream, a); }});
+        e->prog.push_back({"td_huber", [=](dqn_engine* en) { TdArgs a = t; a.bump_sample_ctr = en->step_sampled ? 1 : 0; launch_td(en->stream, a); }});
     }
     // ---------------- backward of the online net on the s columns (Zygote through src/solver.jl:219-225)
     std::vector<RSeg> final_segs;   // dW split-K slabs: nothing reads the gradient before Adam, so ONE reduce launch at the end
@@ -577,8 +582,9 @@ static int build_program(dqn_engine* e) {
     emit_reduce(e, final_segs, "dw_reduce_all");
     e->prog_post_begin = e->prog.size();
     e->prog.push_back({"adam", [](dqn_engine* en) {
+        PrioArgs pa; pa.n = en->hp.prioritized_replay ? en->B : 0; pa.cap2 = en->cap2; pa.idx = en->idx; pa.td = en->td; pa.eps = en->hp.prio_eps; pa.alpha = en->hp.prio_alpha; pa.tree = en->tree;
         launch_adam(en->stream, en->Pint, en->p_on, en->m, en->v, en->grad, en->state, en->gmax_part, en->hp.adam_f64_scalars, en->hp.learning_rate,
-                    en->hp.adam_beta1, en->hp.adam_beta2, en->hp.adam_eps, en->world > 1 ? 1.0f / (float)en->world : 1.0f); }});
+                    en->hp.adam_beta1, en->hp.adam_beta2, en->hp.adam_eps, en->world > 1 ? 1.0f / (float)en->world : 1.0f, pa); }});
     e->prog_built = true;
     return 0;
 }

@@ -232,7 +232,15 @@ __device__ __forceinline__ float head_val(const HeadSrc& h, int n, int col) {
     const size_t e = (size_t)n * h.ld + col;
     if (h.S <= 1) return h.p[e];
     float tot = h.p[e];
-    for (int s = 1; s < h.S; s++) tot = tot + h.p[(size_t)s * h.per_s + e];
+    int s = 1;
+    for (; s + 8 <= h.S; s += 8) {      // 8 independent slab loads in flight, adds in ascending order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = h.p[(size_t)(s + u) * h.per_s + e];
+#pragma unroll
+        for (int u = 0; u < 8; u++) tot = tot + v[u];
+    }
+    for (; s < h.S; s++) tot = tot + h.p[(size_t)s * h.per_s + e];
     return act_f(tot + h.bias[n], h.act);
 }
 __device__ __forceinline__ void q_column_h(int nA, int dueling, const HeadSrc& val, const HeadSrc& adv, int col, float* q, float* vout, float* araw) {
@@ -256,8 +264,7 @@ __device__ __forceinline__ void q_from_lds(int nA, int dueling, const float* v, 
 __global__ __launch_bounds__(1024) void k_td(TdArgs A) {
     extern __shared__ float hl[];   // [B] Huber terms | [B] long long indices | head outputs: on_val[ncon] on_adv[nA][ncon] tg_val[B] tg_adv[nA][B]
     const int B = A.B, nA = A.nA, ncon = A.ncon;
-    long long* sidx = reinterpret_cast<long long*>(hl + ((B + 1) & ~1));
-    float* hv_on_val = reinterpret_cast<float*>(sidx + B);
+    float* hv_on_val = hl + B;
     float* hv_on_adv = hv_on_val + ncon;
     float* hv_tg_val = hv_on_adv + nA * ncon;
     float* hv_tg_adv = hv_tg_val + B;
@@ -277,7 +284,6 @@ __global__ __launch_bounds__(1024) void k_td(TdArgs A) {
     const long long size = A.st->size;
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         const long long j = A.idx[b];
-        sidx[b] = j;
         const int act = A.a[j]; const float rew = A.r[j]; const float dn = (float)A.done[j];
         const float p = A.tree[A.cap2 + j] / total; const float xw = (float)size * p;
         const float w = (float)pow((double)xw, -(double)A.prio_beta);     // IS weight, ...replay.jl:101-102
@@ -321,28 +327,11 @@ __global__ __launch_bounds__(1024) void k_td(TdArgs A) {
         A.st->step = A.st->step + 1;                 // read by k_adam (beta-power slot) later in this step
         if (A.bump_sample_ctr) A.st->sample_ctr = A.st->sample_ctr + 1;   // the fused sample+gather kernel cannot bump it itself
     }
-    // update_priorities!(replay, indices, td) with the UNWEIGHTED td (src/solver.jl:231-233, ...replay.jl:76-80): IS weights above
-    // were read from the old priorities; the tree is next used by the following step's sampler.
-    if (A.prioritized) {
-        long long node = 0;
-        for (int b = threadIdx.x; b < B; b += blockDim.x) {
-            bool last = true;
-            for (int j = b + 1; j < B; j++) if (sidx[j] == sidx[b]) { last = false; break; }
-            const float p = prio_f(fabsf(A.td[b]), A.prio_eps, A.prio_alpha);
-            if (!(p > 0.0f)) A.st->err = 2;
-            if (last) A.tree[A.cap2 + sidx[b]] = p;
-        }
-        __syncthreads();
-        if (threadIdx.x < B) node = (A.cap2 + sidx[threadIdx.x]) >> 1;      // B <= blockDim here (launch_td guarantees it when prioritized)
-        for (long long width = A.cap2; width > 1; width >>= 1) {
-            if (threadIdx.x < B) { A.tree[node] = A.tree[2 * node] + A.tree[2 * node + 1]; node >>= 1; }
-            __syncthreads();
-        }
-    }
+    // update_priorities! runs as k_update_priorities on a forked graph branch (it only needs td; it overlaps the backward pass)
 }
 void launch_td(hipStream_t st, const TdArgs& a) {
     int bs = ((a.B + 63) / 64) * 64; if (bs < 512) bs = 512; if (bs > 1024) bs = 1024;
-    const size_t lds = (size_t)((a.B + 1) & ~1) * sizeof(float) + (size_t)a.B * sizeof(long long) + (size_t)(1 + a.nA) * (a.ncon + a.B) * sizeof(float);
+    const size_t lds = (size_t)a.B * sizeof(float) + (size_t)(1 + a.nA) * (a.ncon + a.B) * sizeof(float);
     hipLaunchKernelGGL(k_td, dim3(1), dim3(bs), lds, st, a);
 }
 
@@ -364,16 +353,25 @@ void launch_q_columns(hipStream_t st, int n, int nA, int dueling, const float* v
 // per element 16 B read (p,m,v,g) + 12 B written.  f64mode reproduces Flux 0.14's Float64 eta/beta/eps scalars.
 __global__ __launch_bounds__(256) void k_adam(size_t P, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
                                               StepState* state, float* __restrict__ gmax_part, int f64mode, float lr, double b1, double b2, double eps,
-                                              float gscale) {
+                                              float gscale, PrioArgs prio) {
     __shared__ float wmax[4];
+    __shared__ long long sidx[1024];
+    // update_priorities!(replay, indices, td) (src/solver.jl:231-233): one DEDICATED extra workgroup (block 0) walks the sum-tree
+    // while the other blocks stream the parameters -- its latency-bound levels ride inside this bandwidth-bound kernel instead of
+    // costing a launch of their own; the tree is next read by the following step's sampler.
+    int bid = blockIdx.x, nblk = gridDim.x;
+    if (prio.n > 0) {
+        if (blockIdx.x == 0) { prio_update_block(prio.n, prio.cap2, prio.idx, prio.td, prio.eps, prio.alpha, prio.tree, state, sidx); return; }
+        bid = blockIdx.x - 1; nblk = gridDim.x - 1;
+    }
     // beta powers are double-buffered by step parity: this step reads slot (step & 1) and block 0 writes slot ((step+1) & 1)
     // (Flux: bp .= bp .* beta AFTER the update), so no block can observe a half-updated value.
     const int slot = (int)(state->step & 1ull);
     const double bp1 = state->bp[slot][0], bp2 = state->bp[slot][1];
-    if (blockIdx.x == 0 && threadIdx.x == 0) { state->bp[slot ^ 1][0] = bp1 * b1; state->bp[slot ^ 1][1] = bp2 * b2; }
+    if (bid == 0 && threadIdx.x == 0) { state->bp[slot ^ 1][0] = bp1 * b1; state->bp[slot ^ 1][1] = bp2 * b2; }
     const double c1 = 1.0 - bp1, c2 = 1.0 - bp2;
     float gmax = 0.0f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = (size_t)bid * blockDim.x + threadIdx.x; i < P; i += (size_t)nblk * blockDim.x) {
         float gi = g[i];
         if (gscale != 1.0f) gi = gi * gscale;
         gmax = fmaxf(gmax, fabsf(gi));
@@ -393,16 +391,16 @@ __global__ __launch_bounds__(256) void k_adam(size_t P, float* __restrict__ p, f
         }
         m[i] = mn; v[i] = vn; p[i] = p[i] - dl;
     }
-    // wave max (64 lanes) then one atomic per wave; max is order-independent, so this is exact
+    // wave max (64 lanes) then one value per block; max is order-independent, so this is exact
     for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off));
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = gmax;
     __syncthreads();
-    if (threadIdx.x == 0) gmax_part[blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));   // folded by k_update_priorities
+    if (threadIdx.x == 0) gmax_part[bid] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));   // folded on demand by k_update_priorities
 }
 int adam_blocks(size_t P) { size_t blocks = (P + 255) / 256; if (blocks > 2048) blocks = 2048; return (int)blocks; }
 void launch_adam(hipStream_t st, size_t P, float* p, float* m, float* v, const float* g, StepState* state, float* gmax_part, int f64mode, float lr,
-                 double b1, double b2, double eps, float gscale) {
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)adam_blocks(P)), dim3(256), 0, st, P, p, m, v, g, state, gmax_part, f64mode, lr, b1, b2, eps, gscale);
+                 double b1, double b2, double eps, float gscale, const PrioArgs& prio) {
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)adam_blocks(P) + (prio.n > 0 ? 1u : 0u)), dim3(256), 0, st, P, p, m, v, g, state, gmax_part, f64mode, lr, b1, b2, eps, gscale, prio);
 }
 
 // ------------------------------------------------------------------ parameter layout conversion (Flux.params order <-> internal [K][N], conv kernels flipped)

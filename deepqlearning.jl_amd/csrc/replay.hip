@@ -7,6 +7,8 @@
 // (the IS-weight denominator, :101) does not depend on update history and the CPU twin reproduces it bit for bit.
 #include "common.h"
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // ------------------------------------------------------------------ gather (HBM-bound)
 // 64 features x 64 columns per workgroup through a padded LDS tile: reads are 256-B row segments of the sampled
 // transitions (coalesced along the feature axis), writes are 256-B lines of the batch-innermost arena X0[f][2B]
@@ -47,17 +49,34 @@ __global__ __launch_bounds__(256) void k_gather_fb(const void* __restrict__ s_ro
         rows[threadIdx.x] = r;
     }
     __syncthreads();
-#pragma unroll 4
-    for (int p = 0; p < 16; p++) {
-        const int cl = p * 4 + w, c = c0 + cl, f = f0 + lane;
-        float v = 0.0f;
-        if (c < ld && f < E) {
-            const long long row = rows[cl];
-            const void* base = c < B ? s_rows : sp_rows;
-            if (u8) v = (float)((const unsigned char*)base)[row * E + f] / 255.0f;  // test/test_env.jl:59
-            else v = ((const float*)base)[row * E + f];
+    if (!u8 && (E & 3) == 0) {
+        // f32 rows: 4 independent 16-B loads per thread are issued before any is consumed (HBM latency overlapped); a 64-feature
+        // row segment is 16 lanes x 16 B = one 256-B burst of a sampled transition
+        f32x4 v[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int q = threadIdx.x + 256 * p, cl = q >> 4, c = c0 + cl, f = f0 + 4 * (q & 15);
+            v[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (c < ld && f < E) v[p] = *reinterpret_cast<const f32x4*>((const float*)(c < B ? s_rows : sp_rows) + rows[cl] * E + f);
         }
-        tile[cl][lane] = v;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int q = threadIdx.x + 256 * p, cl = q >> 4, fl = 4 * (q & 15);
+            tile[cl][fl] = v[p].x; tile[cl][fl + 1] = v[p].y; tile[cl][fl + 2] = v[p].z; tile[cl][fl + 3] = v[p].w;
+        }
+    } else {
+#pragma unroll 4
+        for (int p = 0; p < 16; p++) {
+            const int cl = p * 4 + w, c = c0 + cl, f = f0 + lane;
+            float v = 0.0f;
+            if (c < ld && f < E) {
+                const long long row = rows[cl];
+                const void* base = c < B ? s_rows : sp_rows;
+                if (u8) v = (float)((const unsigned char*)base)[row * E + f] / 255.0f;  // test/test_env.jl:59
+                else v = ((const float*)base)[row * E + f];
+            }
+            tile[cl][lane] = v;
+        }
     }
     __syncthreads();
 #pragma unroll 4
@@ -178,23 +197,7 @@ __global__ __launch_bounds__(1024) void k_update_priorities(int n, long long cap
         __syncthreads();
         if (threadIdx.x == 0) { for (int w = 1; w < (int)(blockDim.x >> 6); w++) g = fmaxf(g, smax[w]); state->gnorm_bits = __float_as_uint(g); }
     }
-    const int i = threadIdx.x;
-    if (i < n) sidx[i] = idx[i];
-    __syncthreads();
-    long long node = 0;
-    if (i < n) {
-        bool last = true;                                        // duplicates: the last write wins (r._priorities[indices] = ..., :79)
-        for (int j = i + 1; j < n; j++) if (sidx[j] == sidx[i]) { last = false; break; }
-        const float p = prio_f(fabsf(td[i]), eps, alpha);
-        if (!(p > 0.0f)) state->err = 2;                         // @assert all(new_priorities .> 0f0), :78
-        if (last) tree[cap2 + sidx[i]] = p;
-        node = (cap2 + sidx[i]) >> 1;
-    }
-    __syncthreads();
-    for (long long width = cap2; width > 1; width >>= 1) {      // one tree level per barrier; equal parents write equal values
-        if (i < n) { tree[node] = tree[2 * node] + tree[2 * node + 1]; node >>= 1; }
-        __syncthreads();
-    }
+    if (n > 0) prio_update_block(n, cap2, idx, td, eps, alpha, tree, state, sidx);
 }
 void launch_update_priorities(hipStream_t st, int n, long long cap2, const long long* idx, const float* td, float eps, float alpha,
                               float* tree, StepState* state, int tick_adam, double beta1, double beta2, const float* gmax_part, int n_gmax) {
