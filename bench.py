@@ -58,23 +58,39 @@ def build_workload(pkg, args, rank, device):
 
 
 def op_cost(name, eng_layers, B, ncon, E, P):
-    """algorithmic (flops, bytes) of one profiled op by name."""
+    """algorithmic (flops, bytes) of one profiled launch by its program name.
+    fwd_<l>      forward of layer l AND its sibling (val/adv) for the online net on [s;sp] and the target net on sp
+    dw_<l>/dw2_<l>  dW+db of layer l (dw2: both sibling layers);  dx_<l>/dx_join_<l>  dX of layer l (join: both streams)"""
     parts = name.split("_")
-    if name == "gather":
+    if name in ("gather", "sample_gather"):
         return 0.0, 2.0 * B * E * 4 * 2          # rows read + batch arena written
     if name == "adam":
         return 0.0, P * 28.0                      # p,m,v,g read + p,m,v written
     digits = "".join(ch for ch in parts[-1] if ch.isdigit())
-    if parts[0] in ("fwd", "dw", "dx") and digits and len(parts) == 2 or (len(parts) == 3 and parts[1] in ("on", "tg", "valu")):
-        li = int(digits)
-        K, N, npos = eng_layers[li]
-        if parts[0] == "fwd":
-            # a forward launch covers the online net on [s;sp] and the target net on sp, for every sibling layer of its level
-            sib = [j for j, g in enumerate(eng_layers) if g == eng_layers[li] and j >= li] if len(parts) == 2 else [li]
-            cols = {"on": ncon, "tg": B}.get(parts[1], ncon + B) if len(parts) == 3 else ncon + B
-            return 2.0 * K * N * npos * cols * max(1, len(sib)), 0.0
-        return 2.0 * K * N * npos * B, 0.0
-    return 0.0, 0.0
+    if not digits or parts[0] not in ("fwd", "dw", "dw2", "dx"):
+        return 0.0, 0.0
+    li = int(digits)
+    K, N, npos = eng_layers[li]
+    f1 = 2.0 * K * N * npos
+    nsib = sum(1 for g in eng_layers if g == eng_layers[li]) if (K, N, npos).count(0) == 0 else 1
+    if parts[0] == "fwd":
+        if len(parts) == 3 and parts[1] in ("on", "tg"):
+            return f1 * (ncon if parts[1] == "on" else B), 0.0
+        if len(parts) == 3:                       # fwd_valu_<l>: the whole level (both heads, both nets)
+            return 0.0, 0.0                       # heads are accounted by their own geometry below (negligible)
+        return f1 * (ncon + B) * nsib, 0.0
+    if parts[0] == "dw2" or (parts[0] == "dx" and len(parts) == 3 and parts[1] == "join"):
+        return f1 * B * 2, 0.0
+    return f1 * B, 0.0
+
+
+def step_flops_analytic(eng_layers, B, ncon):
+    """forward on (2B + B) columns for every layer, backward dW for every layer and dX for every layer with a producer."""
+    tot = 0.0
+    for i, (K, N, npos) in enumerate(eng_layers):
+        f1 = 2.0 * K * N * npos
+        tot += f1 * (ncon + B) + f1 * B + (f1 * B if i > 0 else 0.0)
+    return tot
 
 
 def main():
@@ -168,7 +184,7 @@ def main():
             roof = dict(kernel=dom, bound="hbm", achieved=by / (kern[dom] * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", traffic=None)
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["avg_launch_ms"] = kern[dom]
-        step_flops = sum(op_cost(k, g2, B, ncon, E, P)[0] for k in kern)
+        step_flops = step_flops_analytic(g2, B, ncon)
         roof["step_flops"] = step_flops
         roof["step_mfma_frac"] = (value / world) * step_flops / (PEAK_F32_MFMA_TFLOPS * 1e12)
         roof["eager_kernel_ms"] = {k: round(v, 5) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])[:12]}
