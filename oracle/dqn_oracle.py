@@ -480,3 +480,238 @@ def greedy_action(net, params, o, dtype=np.float32):
 
 def value(net, params, o, dtype=np.float32):
     return float(np.max(actionvalues(net, params, o, dtype)))
+
+
+# ==========================================================================
+# DRQN: EpisodeReplayBuffer (src/episode_replay.jl:3-95) and the recurrent
+# batch_train! (src/solver.jl:239-287).  Flux 0.14 LSTM(in,out) =
+# Recur(LSTMCell) (third-party; recalled):
+#   g = Wi*x .+ Wh*h .+ b ; gates in order input, forget, cell, output
+#   c' = sigm(f) .* c .+ sigm(i) .* tanh(g_cell) ; h' = sigm(o) .* tanh(c')
+#   trainable state0 = (h0, c0), each (out,1), broadcast over the batch;
+#   Flux.params order: Wi (4out,in), Wh (4out,out), b (4out), h0, c0.
+# ==========================================================================
+class LSTM:
+    kind = "lstm"
+
+    def __init__(self, n_in, n_out):
+        self.n_in, self.n_out, self.act = n_in, n_out, ACT_IDENTITY
+
+    def param_shapes(self):
+        h = self.n_out
+        return [(self.n_in, 4 * h), (h, 4 * h), (4 * h,), (h,), (h,)]
+
+    def out_shape(self, in_shape):
+        assert int(np.prod(in_shape)) == self.n_in
+        return (self.n_out,)
+
+
+def _nparams(l):
+    return len(l.param_shapes())
+
+
+def _sigm(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+class RecurrentNetwork(Network):
+    """Network whose base chain may contain LSTM layers (val/adv streams stay feed-forward, as create_dueling_network builds them)."""
+
+    def param_slices(self):
+        out, off = [], 0
+        for l in self.all_layers():
+            n = _nparams(l)
+            out.append((off, off + n))
+            off += n
+        return out
+
+
+def init_params_recurrent(net, seed=1):
+    rng = np.random.default_rng(seed)
+    ps = []
+    for l in net.all_layers():
+        if l.kind == "lstm":
+            h = l.n_out
+            ps.append(glorot_uniform(rng, (l.n_in, 4 * h), l.n_in, 4 * h))
+            ps.append(glorot_uniform(rng, (h, 4 * h), h, 4 * h))
+            b = np.zeros(4 * h, np.float32)
+            b[h:2 * h] = 1.0                      # Flux: forget-gate bias initialised to 1
+            ps += [b, np.zeros(h, np.float32), np.zeros(h, np.float32)]
+        elif l.kind == "dense":
+            ps += [glorot_uniform(rng, (l.n_in, l.n_out), l.n_in, l.n_out), np.zeros(l.n_out, np.float32)]
+        else:
+            kk = l.kh * l.kw
+            ps += [glorot_uniform(rng, (l.cout, l.cin, l.kh, l.kw), kk * l.cin, kk * l.cout), np.zeros(l.cout, np.float32)]
+    return ps
+
+
+def _seq_forward(net, params, xs):
+    """xs: list of T arrays (B, obs...).  Runs the network over the sequence from the reset state (Flux.reset!).
+    Returns list of Q (B,nA) and a cache for BPTT."""
+    dt = xs[0].dtype
+    ps = [np.asarray(p, dt) for p in params]
+    sl = net.param_slices()
+    nb = len(net.base)
+    B = xs[0].shape[0]
+    state = {}
+    for li, l in enumerate(net.base):
+        if l.kind == "lstm":
+            Wi, Wh, b, h0, c0 = ps[sl[li][0]:sl[li][1]]
+            state[li] = (np.repeat(h0[None], B, 0), np.repeat(c0[None], B, 0))
+    qs, caches = [], []
+    for x in xs:
+        cache_t = []
+        for li, l in enumerate(net.base):
+            if l.kind == "lstm":
+                Wi, Wh, b, h0, c0 = ps[sl[li][0]:sl[li][1]]
+                hp, cp = state[li]
+                x2 = x.reshape(B, -1)
+                g = x2 @ Wi + hp @ Wh + b
+                H = l.n_out
+                i, f, gc, o = _sigm(g[:, :H]), _sigm(g[:, H:2 * H]), np.tanh(g[:, 2 * H:3 * H]), _sigm(g[:, 3 * H:])
+                c = f * cp + i * gc
+                tc = np.tanh(c)
+                h = o * tc
+                cache_t.append(("lstm", x2, x.shape, hp, cp, i, f, gc, o, tc))
+                state[li] = (h, c)
+                x = h
+            else:
+                W, b = ps[sl[li][0]:sl[li][1]]
+                xin = x.shape
+                y, c_ = layer_forward(l, x, W, b)
+                cache_t.append(("ff", c_, xin, y))
+                x = y
+        xb = x
+        if net.dueling:
+            nv = len(net.val)
+            pv = [p for (a, b_) in sl[nb:nb + nv] for p in ps[a:b_]]
+            pa = [p for (a, b_) in sl[nb + nv:] for p in ps[a:b_]]
+            v, cv = _chain_forward(net.val, pv, xb)
+            a_, ca = _chain_forward(net.adv, pa, xb)
+            q = v + a_ - a_.mean(axis=1, keepdims=True)
+            cache_t.append(("duel", cv, ca, xb.shape))
+        else:
+            q = xb
+        qs.append(q)
+        caches.append(cache_t)
+    return qs, caches
+
+
+def _seq_backward(net, params, caches, dqs):
+    dt = dqs[0].dtype
+    ps = [np.asarray(p, dt) for p in params]
+    sl = net.param_slices()
+    nb = len(net.base)
+    grads = [np.zeros_like(p) for p in ps]
+    T = len(dqs)
+    dstate = {li: None for li, l in enumerate(net.base) if l.kind == "lstm"}
+    for t in reversed(range(T)):
+        cache_t = caches[t]
+        dq = dqs[t]
+        if net.dueling:
+            _, cv, ca, xb_shape = cache_t[-1]
+            nv = len(net.val)
+            pv = [p for (a, b_) in sl[nb:nb + nv] for p in ps[a:b_]]
+            pa = [p for (a, b_) in sl[nb + nv:] for p in ps[a:b_]]
+            dv = dq.sum(axis=1, keepdims=True)
+            da = dq - dq.mean(axis=1, keepdims=True)
+            dxv, gv = _chain_backward(net.val, pv, cv, dv)
+            dxa, ga = _chain_backward(net.adv, pa, ca, da)
+            flat = gv + ga
+            k = 0
+            for (a, b_) in sl[nb:]:
+                for j in range(a, b_):
+                    grads[j] = grads[j] + flat[k]
+                    k += 1
+            dx = (dxv + dxa).reshape(xb_shape)
+        else:
+            dx = dq
+        for li in reversed(range(nb)):
+            l = net.base[li]
+            c = cache_t[li]
+            a, b_ = sl[li]
+            if l.kind == "lstm":
+                _, x2, xshape, hp, cp, i, f, gc, o, tc = c
+                Wi, Wh = ps[a], ps[a + 1]
+                dh = dx.reshape(x2.shape[0], -1)
+                dc = np.zeros_like(dh)
+                if dstate[li] is not None:
+                    dh = dh + dstate[li][0]
+                    dc = dc + dstate[li][1]
+                do = dh * tc
+                dc = dc + dh * o * (1 - tc * tc)
+                di, df, dgc, dcp = dc * gc, dc * cp, dc * i, dc * f
+                dg = np.concatenate([di * i * (1 - i), df * f * (1 - f), dgc * (1 - gc * gc), do * o * (1 - o)], axis=1)
+                grads[a] = grads[a] + x2.T @ dg
+                grads[a + 1] = grads[a + 1] + hp.T @ dg
+                grads[a + 2] = grads[a + 2] + dg.sum(0)
+                dhp = dg @ Wh.T
+                dstate[li] = (dhp, dcp)
+                if t == 0:
+                    grads[a + 3] = grads[a + 3] + dhp.sum(0)
+                    grads[a + 4] = grads[a + 4] + dcp.sum(0)
+                dx = (dg @ Wi.T).reshape(xshape)
+            else:
+                _, c_, xin, y = c
+                dx, dW, db = layer_backward(l, c_, xin, y, dx, ps[a])
+                grads[a] = grads[a] + dW
+                grads[a + 1] = grads[a + 1] + db
+    return grads
+
+
+def drqn_train_step(net, params_on, params_tg, batch, *, gamma, double_q, adam=None, dtype=np.float64):
+    """batch_train!(…, replay::EpisodeReplayBuffer) (src/solver.jl:239-287) on a given sampled batch:
+    batch = (s[T], a[T], r[T], sp[T], done[T], mask[T]) with s[t]: (B, obs...), a[t]: (B,) 0-based, mask[t]: (B,) 0/1."""
+    s, a, r, sp, done, mask = batch
+    dt = np.dtype(dtype)
+    T, B = len(s), s[0].shape[0]
+    s = [np.asarray(x, dt) for x in s]
+    sp = [np.asarray(x, dt) for x in sp]
+    pon = [np.asarray(p, dt) for p in params_on]
+    ptg = [np.asarray(p, dt) for p in params_tg]
+    # targets: both nets run over sp[1..T] from the reset state, hidden state carried step to step (:249-269)
+    q_tg, _ = _seq_forward(net, ptg, sp)
+    q_on_sp, _ = _seq_forward(net, pon, sp) if double_q else (q_tg, None)
+    ys = []
+    for t in range(T):
+        y, _ = bellman_targets(q_on_sp[t], q_tg[t], np.asarray(r[t], dt), np.asarray(done[t], dt), gamma, double_q)
+        ys.append(y)
+    # loss over s[1..T] from the reset state (:271-282); the mask multiplies INSIDE huber; no IS weights
+    qs, caches = _seq_forward(net, pon, s)
+    loss, dqs, tds = dt.type(0), [], []
+    for t in range(T):
+        m = np.asarray(mask[t], dt)
+        td = qs[t][np.arange(B), a[t]] - ys[t]
+        x = m * td
+        loss = loss + huber_loss(x).sum() / dt.type(B)
+        dq = np.zeros_like(qs[t])
+        dq[np.arange(B), a[t]] = m * np.clip(x, -1, 1) / dt.type(B) / dt.type(T)
+        dqs.append(dq)
+        tds.append(td)
+    loss = loss / dt.type(T)
+    grads = _seq_backward(net, pon, caches, dqs)
+    out = dict(loss=loss, td=np.stack(tds), q=np.stack(qs), y=np.stack(ys), grads=grads, grad_norm=globalnorm(grads))
+    if adam is not None:
+        out["new_params"] = adam_update(pon, grads, adam)
+    return out
+
+
+def episode_sample(episodes, ep_idx, ep_start, T, obs_shape):
+    """StatsBase.sample(r::EpisodeReplayBuffer) for GIVEN episode indices and start draws (src/episode_replay.jl:71-95),
+    0-based ep_start in [0, len).  The reference's quirk is reproduced: `for j = ep_start:min(len, T)` copies ep[t] with t
+    counting from 1, i.e. always the episode PREFIX, of length max(0, min(len,T) - ep_start) in 0-based terms; the rest
+    stays zero with mask 0 and a = first action.  episodes: list of lists of (s, a, r, sp, done)."""
+    B = len(ep_idx)
+    s = [np.zeros((B,) + tuple(obs_shape), np.float32) for _ in range(T)]
+    sp = [np.zeros((B,) + tuple(obs_shape), np.float32) for _ in range(T)]
+    a = [np.zeros(B, np.int32) for _ in range(T)]
+    r = [np.zeros(B, np.float32) for _ in range(T)]
+    d = [np.zeros(B, np.float32) for _ in range(T)]
+    m = [np.zeros(B, np.int32) for _ in range(T)]
+    for i, (e, st) in enumerate(zip(ep_idx, ep_start)):
+        ep = episodes[e]
+        n = max(0, min(len(ep), T) - st)
+        for t in range(n):
+            s[t][i], a[t][i], r[t][i], sp[t][i], d[t][i] = ep[t]
+            m[t][i] = 1
+    return s, a, r, sp, d, m

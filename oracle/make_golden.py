@@ -158,3 +158,109 @@ if __name__ == "__main__":
     for name, net, B, seed, gamma, dq, store, scale in nets():
         make_case(name, net, B, seed, gamma, dq, store_params=store, obs_scale=scale)
     print("fixtures written to", os.path.abspath(GOLD))
+
+
+# ------------------------------------------------------------------ DRQN (src/solver.jl:239-287) cross-check
+def torch_lstm_seq(net, ps, xs):
+    sl = net.param_slices()
+    B = xs[0].shape[0]
+    state = {}
+    for li, l in enumerate(net.base):
+        if l.kind == "lstm":
+            Wi, Wh, b, h0, c0 = ps[sl[li][0]:sl[li][1]]
+            state[li] = (h0[None].expand(B, -1), c0[None].expand(B, -1))
+    qs = []
+    nb = len(net.base)
+    for x in xs:
+        for li, l in enumerate(net.base):
+            a, b_ = sl[li]
+            if l.kind == "lstm":
+                Wi, Wh, b, h0, c0 = ps[a:b_]
+                hp, cp = state[li]
+                g = x.reshape(B, -1) @ Wi + hp @ Wh + b
+                H = l.n_out
+                i, f, gc, o = torch.sigmoid(g[:, :H]), torch.sigmoid(g[:, H:2 * H]), torch.tanh(g[:, 2 * H:3 * H]), torch.sigmoid(g[:, 3 * H:])
+                c = f * cp + i * gc
+                h = o * torch.tanh(c)
+                state[li] = (h, c)
+                x = h
+            else:
+                x = torch_chain([l], ps[a:b_], x)
+        if net.dueling:
+            nv = len(net.val)
+            pv = [p for (a, b_) in sl[nb:nb + nv] for p in ps[a:b_]]
+            pa = [p for (a, b_) in sl[nb + nv:] for p in ps[a:b_]]
+            v = torch_chain(net.val, pv, x)
+            ad = torch_chain(net.adv, pa, x)
+            x = v + ad - ad.mean(dim=1, keepdim=True)
+        qs.append(x)
+    return qs
+
+
+def make_drqn_case(name, net, B, T, seed, gamma, double_q, lr=1e-3):
+    rng = np.random.default_rng(seed)
+    p_on = O.init_params_recurrent(net, seed + 1)
+    p_tg = O.init_params_recurrent(net, seed + 2)
+    p_on = [(p + 0.05 * rng.standard_normal(p.shape)).astype(np.float32) for p in p_on]   # non-zero biases / initial states
+    p_tg = [(p + 0.05 * rng.standard_normal(p.shape)).astype(np.float32) for p in p_tg]
+    s = [rng.random((B,) + net.obs_shape).astype(np.float32) for _ in range(T)]
+    sp = [rng.random((B,) + net.obs_shape).astype(np.float32) for _ in range(T)]
+    a = [rng.integers(0, net.n_actions, B).astype(np.int32) for _ in range(T)]
+    r = [(3 * rng.standard_normal(B)).astype(np.float32) for _ in range(T)]
+    d = [(rng.random(B) < 0.2).astype(np.float32) for _ in range(T)]
+    lens = rng.integers(0, T + 1, B)
+    m = [(t < lens).astype(np.int32) for t in range(T)]
+    batch = (s, a, r, sp, d, m)
+    adam = O.AdamState([np.asarray(p, np.float64) for p in p_on], lr)
+    o = O.drqn_train_step(net, p_on, p_tg, batch, gamma=gamma, double_q=double_q, adam=adam)
+    # torch
+    pon = [torch.tensor(np.asarray(p, np.float64), requires_grad=True) for p in p_on]
+    ptg = [torch.tensor(np.asarray(p, np.float64)) for p in p_tg]
+    ts = [torch.tensor(x).double() for x in s]
+    tsp = [torch.tensor(x).double() for x in sp]
+    with torch.no_grad():
+        qt = torch_lstm_seq(net, ptg, tsp)
+        qo = torch_lstm_seq(net, pon, tsp) if double_q else qt
+        ys = []
+        for t in range(T):
+            best = qo[t].argmax(dim=1)
+            qmax = qt[t][torch.arange(B), best] if double_q else qt[t].max(dim=1).values
+            ys.append(torch.tensor(r[t]).double() + (1 - torch.tensor(d[t]).double()) * gamma * qmax)
+    qs = torch_lstm_seq(net, pon, ts)
+    loss = 0.0
+    for t in range(T):
+        td = qs[t][torch.arange(B), torch.tensor(a[t]).long()] - ys[t]
+        loss = loss + torch_huber(torch.tensor(m[t]).double() * td).sum() / B
+    loss = loss / T
+    opt = torch.optim.Adam(pon, lr=float(np.float32(lr)), betas=(0.9, 0.999), eps=1e-8)
+    loss.backward()
+    tg = [p.grad.detach().numpy().copy() for p in pon]
+    opt.step()
+
+    def rel(x, y):
+        return float(np.max(np.abs(np.asarray(x) - np.asarray(y))) / (1e-300 + np.max(np.abs(np.asarray(y)))))
+    errs = dict(loss=rel(o["loss"], loss.item()), grads=max(rel(g, h) for g, h in zip(o["grads"], tg)),
+                q=rel(o["q"], np.stack([q.detach().numpy() for q in qs])),
+                new_params=max(rel(g, h.detach().numpy()) for g, h in zip(o["new_params"], pon)))
+    print(f"[{name}] DRQN oracle-vs-torch-autograd relative errors: {errs}")
+    assert max(errs.values()) < 1e-9, errs
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), B=B, T=T, seed=seed, gamma=gamma, double_q=int(double_q), lr=lr,
+                        s=np.stack(s), a=np.stack(a), r=np.stack(r), sp=np.stack(sp), done=np.stack(d), mask=np.stack(m),
+                        p_on=O.Network.flatten(p_on), p_tg=O.Network.flatten(p_tg), loss=np.float64(loss.item()),
+                        q=np.stack([q.detach().numpy() for q in qs]), grads=O.Network.flatten(tg),
+                        new_params=O.Network.flatten([p.detach().numpy() for p in pon]))
+
+
+def drqn_nets():
+    I = O.ACT_IDENTITY
+    # BASELINE config 4 shape: TestMDP((5,5),1,6) obs 25, Chain(flattenbatch, LSTM(25,32), Dense(32,4)), trace_length 8 (benchmark/flux_dqn.jl:35-36)
+    yield "drqn_cfg4_lstm_plain", O.RecurrentNetwork((1, 5, 5), [O.LSTM(25, 32), O.Dense(32, 4, I)]), 8, 8, 21, 0.99, True
+    # test/runtests.jl:131-147 style: LSTM + dueling (base = LSTM, val = Dense(h,1), adv = Dense(h,nA)), Dense in front
+    base = [O.Dense(6, 12, O.ACT_RELU), O.LSTM(12, 16)]
+    yield "drqn_dense_lstm_dueling", O.RecurrentNetwork((6,), base, [O.Dense(16, 1, I)], [O.Dense(16, 5, I)]), 6, 5, 22, 0.95, True
+    yield "drqn_lstm_single_q", O.RecurrentNetwork((6,), [O.LSTM(6, 8), O.Dense(8, 3, I)]), 4, 3, 23, 0.9, False
+
+
+if __name__ == "__main__":
+    for name, net, B, T, seed, gamma, dq in drqn_nets():
+        make_drqn_case(name, net, B, T, seed, gamma, dq)
