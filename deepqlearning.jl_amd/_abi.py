@@ -10,7 +10,7 @@ import ctypes as C
 
 import numpy as np
 
-LAYER_DENSE, LAYER_CONV = 0, 1
+LAYER_DENSE, LAYER_CONV, LAYER_LSTM = 0, 1, 2
 ACT_IDENTITY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 STREAM_BASE, STREAM_VAL, STREAM_ADV = 0, 1, 2
 OBS_F32, OBS_U8 = 0, 1
@@ -43,7 +43,8 @@ class HParams(C.Structure):
                 ("prio_alpha", C.c_float), ("prio_beta", C.c_float), ("prio_eps", C.c_float),
                 ("seed", C.c_uint64),
                 ("use_graph", C.c_int32), ("use_mfma", C.c_int32),
-                ("reserved", C.c_int32 * 6)]
+                ("recurrence", C.c_int32), ("trace_length", C.c_int32),
+                ("reserved", C.c_int32 * 4)]
 
 
 def default_hparams(**kw) -> HParams:
@@ -59,6 +60,7 @@ def default_hparams(**kw) -> HParams:
     hp.prio_alpha, hp.prio_beta, hp.prio_eps = 0.6, 0.4, 1e-3
     hp.seed = 0
     hp.use_graph, hp.use_mfma = 1, 1
+    hp.recurrence, hp.trace_length = 0, 40
     for k, v in kw.items():
         if not hasattr(hp, k):
             raise AttributeError(k)
@@ -101,6 +103,14 @@ PROTOS = {
     "stream_handle": [_vp, _P(_vp)],
     "profile_step": [_vp, C.c_int, _P(C.c_char_p), _f32p, _P(C.c_int)],
     "hparams_default": [_P(HParams)],
+    "episode_add": [_vp, _vp, _i32p, _f32p, _vp, _u8p, C.c_int],
+    "episode_commit": [_vp],
+    "episode_count": [_vp, _i64p, _i64p],
+    "episode_get_batch": [_vp, _i64p, _i32p, _f32p, _i32p, _f32p, _f32p, _f32p, _i32p],
+    "train_step_drqn": [_vp, _i64p, _i32p, _f32p, _f32p],
+    "reset_state": [_vp],
+    "get_hidden": [_vp, _f32p, _sz],
+    "set_hidden": [_vp, _f32p, _sz],
 }
 # twin spellings that differ from the product's
 _TWIN_ALIASES = {"engine_create": "create", "engine_destroy": "destroy", "engine_get_plan": "get_plan"}
@@ -290,6 +300,41 @@ class Handle:
         a = np.empty(obs.shape[0], np.int32)
         self._check(self.f["greedy_action"](self._h, _ptr(obs, _f32p), obs.shape[0], _ptr(a, _i32p)))
         return a
+
+    # ---- DRQN
+    def episode_add(self, s, a, r, sp, done):
+        s = _as(s, self.obs_np).reshape(-1, self.obs_elems)
+        sp = _as(sp, self.obs_np).reshape(-1, self.obs_elems)
+        n = s.shape[0]
+        a, r, done = _as(np.atleast_1d(a), np.int32), _as(np.atleast_1d(r), np.float32), _as(np.atleast_1d(done), np.uint8)
+        self._check(self.f["episode_add"](self._h, s.ctypes.data_as(_vp), _ptr(a, _i32p), _ptr(r, _f32p), sp.ctypes.data_as(_vp), _ptr(done, _u8p), n))
+
+    def episode_commit(self):
+        self._check(self.f["episode_commit"](self._h))
+
+    def episode_count(self):
+        cur, cap = C.c_int64(), C.c_int64()
+        self._check(self.f["episode_count"](self._h, C.byref(cur), C.byref(cap)))
+        return cur.value, cap.value
+
+    def episode_get_batch(self, ep_idx, ep_start):
+        T, B = self.hp.trace_length, self.B
+        ep_idx, ep_start = _as(ep_idx, np.int64), _as(ep_start, np.int32)
+        s = np.empty((T, B) + self.obs_shape, np.float32); sp = np.empty_like(s)
+        a, m = np.empty((T, B), np.int32), np.empty((T, B), np.int32)
+        r, d = np.empty((T, B), np.float32), np.empty((T, B), np.float32)
+        self._check(self.f["episode_get_batch"](self._h, _ptr(ep_idx, _i64p), _ptr(ep_start, _i32p), _ptr(s, _f32p), _ptr(a, _i32p), _ptr(r, _f32p),
+                                                _ptr(sp, _f32p), _ptr(d, _f32p), _ptr(m, _i32p)))
+        return s, a, r, sp, d, m
+
+    def train_step_drqn(self, ep_idx=None, ep_start=None):
+        ep_idx, ep_start = _as(ep_idx, np.int64), _as(ep_start, np.int32)
+        loss, gn = C.c_float(), C.c_float()
+        self._check(self.f["train_step_drqn"](self._h, _ptr(ep_idx, _i64p), _ptr(ep_start, _i32p), C.byref(loss), C.byref(gn)))
+        return loss.value, gn.value
+
+    def reset_state(self):
+        self._check(self.f["reset_state"](self._h))
 
     # ---- misc (product only)
     def sync(self):

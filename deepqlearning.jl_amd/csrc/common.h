@@ -23,6 +23,9 @@ struct LayerDev {
     int fwd_kc, dx_kc, dw_kc;          // summation-order plan (0 = unsplit)
     unsigned long long w_off, b_off;   // offsets into the INTERNAL flat parameter vector (w_off 16-B aligned; b_off = w_off + K*N)
     unsigned long long ew_off, eb_off; // offsets into the EXTERNAL (Flux.params order, unpadded) vector
+    // LSTM (Flux Recur(LSTMCell)): K = n_in, N = 4H.  internal block [Wi K x 4H][b 4H][Wh H x 4H][junk 4H][h0 H][c0 H][zeros 4H]:
+    // Wi|b and Wh|junk are (K+1) x N blocks for the dW kernels; `zeros` is the bias of the bias-free input projection.
+    int H; unsigned long long wh_off, h0_off, c0_off, z_off, ewh_off, eh0_off, ec0_off;
 };
 
 // device-resident mutable state of one engine (one instance in HBM)
@@ -165,6 +168,33 @@ void launch_convert_params(hipStream_t st, const LayerDev* layers_dev, int nl, c
 bool gemm_fwd_eligible(const LayerDev& L, int nprob, const int* ldx, const int* col0, const int* ncols);
 void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* const* W, const float* const* bias, const float* const* X,
                      const int* ldx, const int* col0, const int* ncols, float* const* out /* Y, or split-K partial slabs */);
+
+// ---- DRQN (drqn.hip): EpisodeReplayBuffer gather, LSTM recurrence / BPTT steps, recurrent TD
+struct LstmSeq {          // one sequence set advancing one time step: B columns starting at column c0 (+ t*B) of [*][ld] arrays
+    const float* Gx; float* Hout; float* Cst; int ld, c0;
+    const float *Wh, *bias;
+    const float* hprev; int hp_ld, hp_bs;     // h_{t-1}(j,b) = hprev[j*hp_ld + b*hp_bs]   (h0 broadcast: ld 1, bs 0)
+    const float* cprev; int cp_ld, cp_bs;
+    float *gates, *tc, *hprev_out, *cprev_out; int keep_ld, keep_c0;   // BPTT stash (online s-sequence) or null
+};
+struct LstmStepArgs { LstmSeq s[3]; int nseq, H, B; };
+void launch_lstm_step_t(hipStream_t st, const LstmStepArgs& a, int t);
+struct LstmBwdArgs {
+    int t, T, H, B, TB; const float *gates, *tc, *cprev, *Wh; const float* dH; float* dG; float *dhn, *dcn; float *g_h0, *g_c0;
+};
+void launch_lstm_bwd_step(hipStream_t st, const LstmBwdArgs& a);
+struct EpGatherArgs {
+    const float *ep_s, *ep_sp; const int* ep_a; const float* ep_r; const unsigned char* ep_done; const int* ep_len;
+    const long long* ep_idx; const int* ep_start; int E, B, T; float* x0; int* a_out; float *r_out, *done_out, *mask_out;
+};
+void launch_gather_episodes(hipStream_t st, const EpGatherArgs& a);
+struct TdDrqnArgs {
+    int B, T, nA, ncon, dueling, double_q; float gamma;
+    HeadSrc on_val, on_adv, tg_val, tg_adv; float *d_val, *d_adv;
+    const int* a; const float *r, *done, *mask; float* td; StepState* st;
+};
+void launch_td_drqn(hipStream_t st, const TdDrqnArgs& a);
+void launch_bcast_state(hipStream_t st, const float* src, int H, int n, float* dst);
 
 // MFMA path (nn_mfma.hip): returns false if the shape is not eligible (caller falls back to the VALU kernel,
 // which computes bit-identical values)

@@ -74,6 +74,14 @@ struct dqn_engine {
     hipGraphExec_t g_full[2] = {nullptr, nullptr}, g_pre[2] = {nullptr, nullptr}, g_post = nullptr;
     // comm
     void* comm = nullptr; int rank = 0, world = 1;
+    // DRQN (recurrence = true): column count per sequence set Bc = T*B (B otherwise); EpisodeReplayBuffer storage; LSTM workspaces
+    int Bc = 0, T = 1; long long ep_cap = 0, ep_size = 0, ep_widx = 0, ep_cur_len = 0; std::vector<int> ep_len_host;
+    float *ep_s = nullptr, *ep_sp = nullptr, *ep_r = nullptr; int* ep_a = nullptr; unsigned char* ep_done = nullptr; int* ep_len = nullptr;
+    long long* ep_idx = nullptr; int* ep_start = nullptr; int* r_a = nullptr; float *r_r = nullptr, *r_done = nullptr, *r_mask = nullptr;
+    float *gx_on[DQN_MAX_LAYERS] = {}, *gx_tg[DQN_MAX_LAYERS] = {}, *cst_on[DQN_MAX_LAYERS] = {}, *cst_tg[DQN_MAX_LAYERS] = {}, *gates[DQN_MAX_LAYERS] = {}, *tcb[DQN_MAX_LAYERS] = {},
+          *hprev_buf[DQN_MAX_LAYERS] = {}, *cprev_buf[DQN_MAX_LAYERS] = {}, *dG[DQN_MAX_LAYERS] = {}, *dhn[DQN_MAX_LAYERS] = {}, *dcn[DQN_MAX_LAYERS] = {};
+    float *pol_h[DQN_MAX_LAYERS][2] = {}, *pol_c[DQN_MAX_LAYERS][2] = {}, *pol_gx[DQN_MAX_LAYERS] = {}; int pol_flip = 0, pol_state_n = 0; uint64_t drqn_draws = 0;
+    hipGraphExec_t g_drqn = nullptr;
     // static launch program
     struct Step { const char* name; std::function<void(dqn_engine*)> fn; };
     std::vector<Step> prog; size_t prog_post_begin = 0; bool prog_built = false, step_sampled = true;
@@ -114,7 +122,7 @@ static int build_layers(const dqn_layer_desc* d, int n, const dqn_hparams* hp, L
         int c, h, w;
         if (prev < 0) { c = hp->obs_c; h = hp->obs_h; w = hp->obs_w; }
         else if (L[prev].kind == DQN_LAYER_CONV) { c = L[prev].cout; h = L[prev].oh; w = L[prev].ow; }
-        else { c = L[prev].N; h = 1; w = 1; }
+        else { c = L[prev].out_feat; h = 1; w = 1; }
         l.in_feat = c * h * w;
         if (l.kind == DQN_LAYER_CONV) {
             l.cin = d[i].cin; l.cout = d[i].cout; l.kh = d[i].kh; l.kw = d[i].kw; l.sh = d[i].sh; l.sw = d[i].sw;
@@ -125,9 +133,21 @@ static int build_layers(const dqn_layer_desc* d, int n, const dqn_hparams* hp, L
         } else if (l.kind == DQN_LAYER_DENSE) {
             if (d[i].n_in != l.in_feat) return fail("layer %d: dense n_in %d != incoming features %d", i, d[i].n_in, l.in_feat);
             l.K = d[i].n_in; l.N = d[i].n_out; l.npos = 1; l.out_feat = l.N; l.ih = l.iw = l.oh = l.ow = 1;
+        } else if (l.kind == DQN_LAYER_LSTM) {
+            if (!hp->recurrence) return fail("DeepQLearningError: you passed in a recurrent model but recurrence is set to false");   // src/solver.jl:45-47
+            if (l.stream != DQN_STREAM_BASE) return fail("LSTM layers are supported in the base chain only");
+            if (d[i].n_in != l.in_feat) return fail("layer %d: LSTM n_in %d != incoming features %d", i, d[i].n_in, l.in_feat);
+            l.H = d[i].n_out; l.K = d[i].n_in; l.N = 4 * l.H; l.npos = 1; l.out_feat = l.H; l.act = DQN_ACT_IDENTITY; l.ih = l.iw = l.oh = l.ow = 1;
         } else return fail("layer %d: unknown kind %d", i, l.kind);
-        l.ew_off = eoff; eoff += (size_t)l.K * l.N; l.eb_off = eoff; eoff += l.N;
-        off = (off + 3) / 4 * 4; l.w_off = off; off += (size_t)l.K * l.N; l.b_off = off; off += l.N;
+        if (l.kind == DQN_LAYER_LSTM) {
+            const size_t kn = (size_t)l.K * l.N, hn = (size_t)l.H * l.N;
+            l.ew_off = eoff; eoff += kn; l.ewh_off = eoff; eoff += hn; l.eb_off = eoff; eoff += l.N; l.eh0_off = eoff; eoff += l.H; l.ec0_off = eoff; eoff += l.H;
+            off = (off + 3) / 4 * 4; l.w_off = off; off += kn; l.b_off = off; off += l.N; l.wh_off = off; off += hn; off += l.N /* junk bias row of the Wh dW pass */;
+            l.h0_off = off; off += l.H; l.c0_off = off; off += l.H; off = (off + 3) / 4 * 4; l.z_off = off; off += l.N;
+        } else {
+            l.ew_off = eoff; eoff += (size_t)l.K * l.N; l.eb_off = eoff; eoff += l.N;
+            off = (off + 3) / 4 * 4; l.w_off = off; off += (size_t)l.K * l.N; l.b_off = off; off += l.N;
+        }
         if (l.stream == DQN_STREAM_BASE) *lb = i; else if (l.stream == DQN_STREAM_VAL) *lv = i; else *la = i;
     }
     *P = eoff; *Pint = (off + 3) / 4 * 4;
@@ -145,7 +165,7 @@ static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out) {
         out[i].fwd_kc = 0;
         if (L[i].K > 1024) { const int s = (L[i].K + 511) / 512; int kc = (L[i].K + s - 1) / s; kc = (kc + 3) / 4 * 4; out[i].fwd_kc = kc; }
         else if (L[i].kind == DQN_LAYER_DENSE && L[i].N < 16 && L[i].K >= 128) out[i].fwd_kc = 32;   // heads: 16+ short chains instead of one long one
-        out[i].dx_kc = (L[i].kind == DQN_LAYER_DENSE && L[i].N > 512) ? 256 : 0;
+        out[i].dx_kc = (L[i].kind != DQN_LAYER_CONV && L[i].N > 512) ? 256 : 0;
         out[i].dw_kc = 0;
         if (L[i].kind == DQN_LAYER_CONV) {   // positions per chunk so that (K/64 row tiles) x chunks >= ~512 workgroups
             const int st = (512 + (L[i].K + 63) / 64 - 1) / ((L[i].K + 63) / 64); int ppc = L[i].npos / st; if (ppc < 1) ppc = 1; out[i].dw_kc = ppc * B;
@@ -189,7 +209,11 @@ extern "C" int dqn_engine_create(const dqn_layer_desc* layers, int n_layers, con
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
-    const int B = e->B; e->ncon = hp->double_q ? 2 * B : B;
+    const int B = e->B;
+    e->T = hp->recurrence ? hp->trace_length : 1;
+    if (hp->recurrence && (e->T < 1 || (long long)e->T * B > 65536)) return fail("trace_length %d unsupported", e->T);
+    const int Bc = e->Bc = e->T * B;            // columns per sequence set: B, or T*B time-major columns for DRQN
+    e->ncon = hp->double_q ? 2 * Bc : Bc;
     DM(e->L_dev, e->nl); HIPCHK(hipMemcpy(e->L_dev, e->L, sizeof(LayerDev) * e->nl, hipMemcpyHostToDevice));
     DM(e->p_on, e->Pint); DM(e->p_tg, e->Pint); DM(e->grad, e->Pint); DM(e->m, e->Pint); DM(e->v, e->Pint); DM(e->io_tmp, e->P);
     HIPCHK(hipMemset(e->p_on, 0, e->Pint * 4)); HIPCHK(hipMemset(e->p_tg, 0, e->Pint * 4)); HIPCHK(hipMemset(e->grad, 0, e->Pint * 4));
@@ -197,25 +221,37 @@ extern "C" int dqn_engine_create(const dqn_layer_desc* layers, int n_layers, con
     DM(e->state, 1);
     StepState s0; memset(&s0, 0, sizeof s0); s0.bp[0][0] = s0.bp[1][0] = hp->adam_beta1; s0.bp[0][1] = s0.bp[1][1] = hp->adam_beta2;
     HIPCHK(hipMemcpy(e->state, &s0, sizeof s0, hipMemcpyHostToDevice));
-    e->cap = hp->buffer_size; while (e->cap2 < e->cap) e->cap2 <<= 1;
+    e->cap = hp->recurrence ? B : hp->buffer_size; while (e->cap2 < e->cap) e->cap2 <<= 1;   // DRQN keeps episodes instead (below)
     const size_t osz = hp->obs_dtype == DQN_OBS_U8 ? 1 : 4;
     { unsigned char *a = nullptr, *b = nullptr; DM(a, (size_t)e->cap * e->E * osz); DM(b, (size_t)e->cap * e->E * osz); e->s_rows = a; e->sp_rows = b; }
     DM(e->ra, e->cap); DM(e->rr, e->cap); DM(e->rdone, e->cap); DM(e->tree, 2 * (size_t)e->cap2);
     HIPCHK(hipMemset(e->tree, 0, 2 * (size_t)e->cap2 * 4));
     DM(e->st_a, dqn_engine::ADD_CHUNK); DM(e->st_r, dqn_engine::ADD_CHUNK); DM(e->st_done, dqn_engine::ADD_CHUNK); DM(e->st_td, dqn_engine::ADD_CHUNK);
-    DM(e->idx, B); HIPCHK(hipMemset(e->idx, 0, B * 8)); DM(e->x0, (size_t)e->E * 2 * B);
+    DM(e->idx, B); HIPCHK(hipMemset(e->idx, 0, B * 8)); DM(e->x0, (size_t)e->E * 2 * Bc);
     size_t pmax = 1, jmax = 1;
     for (int i = 0; i < e->nl; i++) {
         const LayerDev& l = e->L[i];
-        DM(e->act_on[i], (size_t)l.out_feat * e->ncon); DM(e->act_tg[i], (size_t)l.out_feat * B); DM(e->dact[i], (size_t)l.out_feat * B);
+        DM(e->act_on[i], (size_t)l.out_feat * e->ncon); DM(e->act_tg[i], (size_t)l.out_feat * Bc); DM(e->dact[i], (size_t)l.out_feat * Bc);
         const size_t sf = dqn_nchunks(l.K, l.fwd_kc); if (sf > 1) pmax = std::max(pmax, sf * (size_t)l.out_feat * e->ncon);
-        const size_t sw = dqn_nchunks(l.npos * B, l.dw_kc); if (sw > 1) pmax = std::max(pmax, sw * (size_t)(l.K + 1) * l.N);
-        const size_t sx = l.kind == DQN_LAYER_DENSE ? dqn_nchunks(l.N, l.dx_kc) : 1; if (sx > 1) pmax = std::max(pmax, sx * (size_t)l.in_feat * B);
-        jmax = std::max(jmax, (size_t)l.in_feat * B);
+        const size_t sw = dqn_nchunks(l.npos * Bc, l.dw_kc); if (sw > 1) pmax = std::max(pmax, sw * (size_t)(l.K + 1) * l.N);
+        const size_t sx = l.kind != DQN_LAYER_CONV ? dqn_nchunks(l.N, l.dx_kc) : 1; if (sx > 1) pmax = std::max(pmax, sx * (size_t)l.in_feat * Bc);
+        jmax = std::max(jmax, (size_t)l.in_feat * Bc);
+        if (l.kind == DQN_LAYER_LSTM) {
+            DM(e->gx_on[i], (size_t)l.N * e->ncon); DM(e->gx_tg[i], (size_t)l.N * Bc); DM(e->cst_on[i], (size_t)l.H * e->ncon); DM(e->cst_tg[i], (size_t)l.H * Bc);
+            DM(e->gates[i], (size_t)l.N * Bc); DM(e->tcb[i], (size_t)l.H * Bc); DM(e->hprev_buf[i], (size_t)l.H * Bc); DM(e->cprev_buf[i], (size_t)l.H * Bc);
+            DM(e->dG[i], (size_t)l.N * Bc); DM(e->dhn[i], (size_t)l.H * B); DM(e->dcn[i], (size_t)l.H * B);
+        }
+    }
+    if (hp->recurrence) {   // EpisodeReplayBuffer (src/episode_replay.jl:3-40): buffer_size EPISODES, first trace_length transitions of each
+        e->ep_cap = hp->buffer_size; e->ep_len_host.assign((size_t)e->ep_cap, 0);
+        if (hp->obs_dtype != DQN_OBS_F32) return fail("DRQN episode storage is float32 only");
+        DM(e->ep_s, (size_t)e->ep_cap * e->T * e->E); DM(e->ep_sp, (size_t)e->ep_cap * e->T * e->E); DM(e->ep_a, (size_t)e->ep_cap * e->T); DM(e->ep_r, (size_t)e->ep_cap * e->T);
+        DM(e->ep_done, (size_t)e->ep_cap * e->T); DM(e->ep_len, e->ep_cap); HIPCHK(hipMemset(e->ep_len, 0, (size_t)e->ep_cap * 4));
+        DM(e->ep_idx, B); DM(e->ep_start, B); DM(e->r_a, Bc); DM(e->r_r, Bc); DM(e->r_done, Bc); DM(e->r_mask, Bc);
     }
     e->partials_elems = pmax; DM(e->partials, 2 * pmax);   // second half: the target net's split-K partials (fused on+tg launches)
     DM(e->join_tmp, jmax); DM(e->gmax_part, adam_blocks(e->Pint));
-    DM(e->w_is, B); DM(e->td, B); DM(e->q_on_s, (size_t)B * e->nA); DM(e->q_on_sp, (size_t)B * e->nA); DM(e->q_tg_sp, (size_t)B * e->nA);
+    DM(e->w_is, B); DM(e->td, Bc); DM(e->q_on_s, (size_t)B * e->nA); DM(e->q_on_sp, (size_t)B * e->nA); DM(e->q_tg_sp, (size_t)B * e->nA);
     DM(e->ytarget, B); DM(e->best, B);
     DM(e->gb_rows, (size_t)B * e->E); DM(e->gb_r, B); DM(e->gb_done, B); DM(e->gb_w, B); DM(e->gb_a, B); DM(e->gb_idx, B);
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -248,6 +284,11 @@ extern "C" int dqn_engine_destroy(dqn_engine_t* e) {
     hipFree(e->ytarget); hipFree(e->best); hipFree(e->gb_rows); hipFree(e->gb_r); hipFree(e->gb_done); hipFree(e->gb_w); hipFree(e->gb_a); hipFree(e->gb_idx);
     free_policy_ws(e);
     for (void* p : e->prog_allocs) hipFree(p);
+    hipFree(e->ep_s); hipFree(e->ep_sp); hipFree(e->ep_a); hipFree(e->ep_r); hipFree(e->ep_done); hipFree(e->ep_len); hipFree(e->ep_idx); hipFree(e->ep_start);
+    hipFree(e->r_a); hipFree(e->r_r); hipFree(e->r_done); hipFree(e->r_mask);
+    for (int i = 0; i < e->nl; i++) { hipFree(e->gx_on[i]); hipFree(e->gx_tg[i]); hipFree(e->cst_on[i]); hipFree(e->cst_tg[i]); hipFree(e->gates[i]); hipFree(e->tcb[i]); hipFree(e->hprev_buf[i]);
+        hipFree(e->cprev_buf[i]); hipFree(e->dG[i]); hipFree(e->dhn[i]); hipFree(e->dcn[i]); for (int k = 0; k < 2; k++) { hipFree(e->pol_h[i][k]); hipFree(e->pol_c[i][k]); } hipFree(e->pol_gx[i]); }
+    if (e->g_drqn) hipGraphExecDestroy(e->g_drqn);
     if (e->stream) hipStreamDestroy(e->stream);
     if (e->stream2) hipStreamDestroy(e->stream2);
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
@@ -309,6 +350,7 @@ extern "C" int dqn_set_adam_state(dqn_engine_t* e, const float* m, const float* 
 extern "C" int dqn_replay_add(dqn_engine_t* e, const void* s, const int32_t* a, const float* r, const void* sp, const uint8_t* done,
                               const float* td_err, int n) {
     HIPCHK(hipSetDevice(e->device));
+    if (e->hp.recurrence) return fail("recurrence = true: use dqn_episode_add (EpisodeReplayBuffer, src/episode_replay.jl)");
     const size_t row = (size_t)e->E * (e->hp.obs_dtype == DQN_OBS_U8 ? 1 : 4);
     for (int i = 0; i < n; i++) {
         if (a[i] < 0 || a[i] >= e->nA) return fail("action index %d out of range 0..%d", a[i], e->nA - 1);
@@ -438,46 +480,53 @@ static int build_program(dqn_engine* e) {
     if (e->prog_built) return 0;
     HIPCHK(hipSetDevice(e->device));
     e->prog_names.reserve(512);
-    const int B = e->B, ncon = e->ncon, ld0 = 2 * B;
-    const bool mf = e->hp.use_mfma != 0;
+    const int B = e->Bc /* columns of one sequence set: batch_size, or T*batch_size for DRQN */, ncon = e->ncon, ld0 = 2 * B, Bb = e->B, T = e->T;
+    const bool mf = e->hp.use_mfma != 0, rec = e->hp.recurrence != 0;
+    // forward views: an LSTM layer's batched part is its bias-free input projection Gx = Wi*x over ALL columns (a dense layer
+    // K = n_in, N = 4H writing gx_*); the recurrence then runs as T small launches.
+    LayerDev LV[DQN_MAX_LAYERS]; float *fwd_on[DQN_MAX_LAYERS], *fwd_tg[DQN_MAX_LAYERS];
+    for (int i = 0; i < e->nl; i++) {
+        LV[i] = e->L[i]; fwd_on[i] = e->act_on[i]; fwd_tg[i] = e->act_tg[i];
+        if (e->L[i].kind == DQN_LAYER_LSTM) { LV[i].kind = DQN_LAYER_DENSE; LV[i].out_feat = LV[i].N; LV[i].b_off = LV[i].z_off; LV[i].act = DQN_ACT_IDENTITY; fwd_on[i] = e->gx_on[i]; fwd_tg[i] = e->gx_tg[i]; }
+    }
     std::vector<std::vector<int>> levels; std::vector<int> val, adv;
     for (int i = 0; i < e->nl; i++) { if (e->L[i].stream == DQN_STREAM_BASE) levels.push_back({i}); else if (e->L[i].stream == DQN_STREAM_VAL) val.push_back(i); else adv.push_back(i); }
     for (size_t j = 0; j < std::max(val.size(), adv.size()); j++) { std::vector<int> lv; if (j < val.size()) lv.push_back(val[j]); if (j < adv.size()) lv.push_back(adv[j]); levels.push_back(lv); }
     HeadSrc head[DQN_MAX_LAYERS][2];   // per (layer, net): where k_td finds the layer's output
     // ---------------- forward: online net on [s ; sp] (src/solver.jl:210,220), target net on sp (:211)
     for (size_t li = 0; li < levels.size(); li++) {
-        const auto& lv = levels[li]; const bool last = li + 1 == levels.size();
+        const auto& lv = levels[li]; const bool last = li + 1 == levels.size() && !rec;
         struct Prob { int l, net; const float *P, *X; int ldx, col0, ncols; float *Y, *part; int S; };
         std::vector<Prob> pr;
         for (int l : lv) for (int net = 0; net < 2; net++) {
-            const LayerDev& L = e->L[l]; Prob q; q.l = l; q.net = net; q.P = net ? e->p_tg : e->p_on;
+            const LayerDev& L = LV[l]; Prob q; q.l = l; q.net = net; q.P = net ? e->p_tg : e->p_on;
             float** act = net ? e->act_tg : e->act_on;
             q.X = L.src < 0 ? e->x0 : act[L.src]; q.ldx = L.src < 0 ? ld0 : (net ? B : ncon); q.col0 = (L.src < 0 && net) ? B : 0; q.ncols = net ? B : ncon;
-            q.Y = act[l]; q.S = dqn_nchunks(L.K, L.fwd_kc); q.part = q.S > 1 ? palloc(e, (size_t)q.S * L.out_feat * q.ncols) : nullptr;
+            q.Y = net ? fwd_tg[l] : fwd_on[l]; q.S = dqn_nchunks(L.K, L.fwd_kc); q.part = q.S > 1 ? palloc(e, (size_t)q.S * L.out_feat * q.ncols) : nullptr;
             pr.push_back(q);
         }
-        bool geo = true; for (int l : lv) geo = geo && same_geo(e->L[lv[0]], e->L[l]);
+        bool geo = true; for (int l : lv) geo = geo && same_geo(LV[lv[0]], LV[l]);
         std::vector<bool> done(pr.size(), false);
         auto emit_gemm = [&](const std::vector<int>& ids, const char* name) {
-            const LayerDev L = e->L[pr[ids[0]].l]; const int n = (int)ids.size();
+            const LayerDev L = LV[pr[ids[0]].l]; const int n = (int)ids.size();
             struct A { const float *W[4], *bias[4], *X[4]; int ldx[4], col0[4], ncols[4]; float* out[4]; } a;
-            for (int i = 0; i < n; i++) { const Prob& q = pr[ids[i]]; const LayerDev& Lq = e->L[q.l]; a.W[i] = q.P + Lq.w_off; a.bias[i] = q.P + Lq.b_off; a.X[i] = q.X; a.ldx[i] = q.ldx; a.col0[i] = q.col0; a.ncols[i] = q.ncols; a.out[i] = q.S > 1 ? q.part : q.Y; }
+            for (int i = 0; i < n; i++) { const Prob& q = pr[ids[i]]; const LayerDev& Lq = LV[q.l]; a.W[i] = q.P + Lq.w_off; a.bias[i] = q.P + Lq.b_off; a.X[i] = q.X; a.ldx[i] = q.ldx; a.col0[i] = q.col0; a.ncols[i] = q.ncols; a.out[i] = q.S > 1 ? q.part : q.Y; }
             e->prog.push_back({name, [=](dqn_engine* en) { launch_gemm_fwd(en->stream, L, n, a.W, a.bias, a.X, a.ldx, a.col0, a.ncols, a.out); }});
             for (int id : ids) done[id] = true;
         };
         if (mf) {
             std::vector<int> all; int ldx[4], c0[4], nc[4];
             for (size_t i = 0; i < pr.size() && i < 4; i++) { all.push_back((int)i); ldx[i] = pr[i].ldx; c0[i] = pr[i].col0; nc[i] = pr[i].ncols; }
-            if (geo && pr.size() <= 4 && gemm_fwd_eligible(e->L[lv[0]], (int)pr.size(), ldx, c0, nc)) emit_gemm(all, pname(e, "fwd", e->L[lv[0]].kind, lv[0]));
+            if (geo && pr.size() <= 4 && gemm_fwd_eligible(LV[lv[0]], (int)pr.size(), ldx, c0, nc)) emit_gemm(all, pname(e, "fwd", e->L[lv[0]].kind, lv[0]));
             else for (size_t i = 0; i + 1 < pr.size(); i += 2) {
                 int l2[2] = {pr[i].ldx, pr[i + 1].ldx}, c2[2] = {pr[i].col0, pr[i + 1].col0}, n2[2] = {pr[i].ncols, pr[i + 1].ncols};
-                if (gemm_fwd_eligible(e->L[pr[i].l], 2, l2, c2, n2)) emit_gemm({(int)i, (int)i + 1}, pname(e, "fwd", e->L[pr[i].l].kind, pr[i].l));
+                if (gemm_fwd_eligible(LV[pr[i].l], 2, l2, c2, n2)) emit_gemm({(int)i, (int)i + 1}, pname(e, "fwd", e->L[pr[i].l].kind, pr[i].l));
             }
         }
         std::vector<VTask> pend;
         for (size_t i = 0; i < pr.size(); i++) {
             if (done[i]) continue;
-            const Prob q = pr[i]; const LayerDev L = e->L[q.l];
+            const Prob q = pr[i]; const LayerDev L = LV[q.l];
             if (mf && mfma_fwd_ok(L, q.ncols)) {
                 e->prog.push_back({pname(e, q.net ? "fwd_tg" : "fwd_on", L.kind, q.l), [=](dqn_engine* en) { launch_mfma_fwd(en->stream, L, q.P, q.X, q.ldx, q.col0, q.ncols, q.Y, q.part, false); }});
             } else {
@@ -488,7 +537,7 @@ static int build_program(dqn_engine* e) {
         flush_valu(e, pend, pname(e, "fwd_valu", e->L[lv[0]].kind, lv[0]));
         std::vector<RSeg> segs;
         for (const Prob& q : pr) {
-            const LayerDev& L = e->L[q.l];
+            const LayerDev& L = LV[q.l];
             HeadSrc h; h.p = q.Y; h.ld = q.ncols; h.S = 1; h.per_s = 0; h.bias = q.P + L.b_off; h.act = L.act;
             if (q.S > 1) {
                 if (last) { h.p = q.part; h.S = q.S; h.per_s = (unsigned long long)L.out_feat * q.ncols; }   // reduced on the fly by k_td
@@ -497,6 +546,25 @@ static int build_program(dqn_engine* e) {
             head[q.l][q.net] = h;
         }
         emit_reduce(e, segs, pname(e, "fwd_reduce", e->L[lv[0]].kind, lv[0]));
+        if (e->L[lv[0]].kind == DQN_LAYER_LSTM) {
+            // the recurrence: T launches, each advancing the online s-sequence, the online sp-sequence (double-Q) and the target
+            // sp-sequence by one step from the reset state (Flux.reset!, src/solver.jl:249-250,271)
+            const int l = lv[0]; const LayerDev L = e->L[l]; const int H = L.H;
+            for (int t = 0; t < T; t++) {
+                LstmStepArgs a; memset(&a, 0, sizeof a); a.H = H; a.B = Bb; int ns = 0;
+                auto seq = [&](const float* P, const float* gx, float* hout, float* cst, int ld, int c0, bool keep) {
+                    LstmSeq& q = a.s[ns++]; q.Gx = gx; q.Hout = hout; q.Cst = cst; q.ld = ld; q.c0 = c0; q.Wh = P + L.wh_off; q.bias = P + L.b_off;
+                    if (t == 0) { q.hprev = P + L.h0_off; q.hp_ld = 1; q.hp_bs = 0; q.cprev = P + L.c0_off; q.cp_ld = 1; q.cp_bs = 0; }
+                    else { q.hprev = hout + c0 + (t - 1) * Bb; q.hp_ld = ld; q.hp_bs = 1; q.cprev = cst + c0 + (t - 1) * Bb; q.cp_ld = ld; q.cp_bs = 1; }
+                    if (keep) { q.gates = e->gates[l]; q.tc = e->tcb[l]; q.hprev_out = e->hprev_buf[l]; q.cprev_out = e->cprev_buf[l]; q.keep_ld = B; q.keep_c0 = 0; }
+                };
+                seq(e->p_on, e->gx_on[l], e->act_on[l], e->cst_on[l], ncon, 0, true);
+                if (e->hp.double_q) seq(e->p_on, e->gx_on[l], e->act_on[l], e->cst_on[l], ncon, B, false);
+                seq(e->p_tg, e->gx_tg[l], e->act_tg[l], e->cst_tg[l], B, 0, false);
+                a.nseq = ns;
+                e->prog.push_back({pname(e, "lstm_step", L.kind, l), [=](dqn_engine* en) { launch_lstm_step_t(en->stream, a, t); }});
+            }
+        }
     }
     // ---------------- dueling reduce + argmax + Bellman target + TD + Huber + dL/dQ + priority update
     {
@@ -508,7 +576,13 @@ static int build_program(dqn_engine* e) {
         t.on_adv = head[lq][0]; t.tg_adv = head[lq][1]; t.d_adv = e->dact[lq];
         if (e->hp.dueling) { t.on_val = head[e->last_val][0]; t.tg_val = head[e->last_val][1]; t.d_val = e->dact[e->last_val]; }
         t.w_is = e->w_is; t.td = e->td; t.q_on_s = e->q_on_s; t.q_on_sp = e->q_on_sp; t.q_tg_sp = e->q_tg_sp; t.ytarget = e->ytarget; t.best = e->best; t.st = e->state;
-        e->prog.push_back({"td_huber", [=](dqn_engine* en) { TdArgs a = t; a.bump_sample_ctr = en->step_sampled ? 1 : 0; launch_td(en->stream, a); }});
+        if (!rec) e->prog.push_back({"td_huber", [=](dqn_engine* en) { TdArgs a = t; a.bump_sample_ctr = en->step_sampled ? 1 : 0; launch_td(en->stream, a); }});
+        else {
+            TdDrqnArgs d; memset(&d, 0, sizeof d); d.B = Bb; d.T = T; d.nA = e->nA; d.ncon = ncon; d.dueling = e->hp.dueling; d.double_q = e->hp.double_q; d.gamma = e->hp.gamma;
+            d.on_val = t.on_val; d.on_adv = t.on_adv; d.tg_val = t.tg_val; d.tg_adv = t.tg_adv; d.d_val = t.d_val; d.d_adv = t.d_adv;
+            d.a = e->r_a; d.r = e->r_r; d.done = e->r_done; d.mask = e->r_mask; d.td = e->td; d.st = e->state;
+            e->prog.push_back({"td_huber_drqn", [=](dqn_engine* en) { launch_td_drqn(en->stream, d); }});
+        }
     }
     // ---------------- backward of the online net on the s columns (Zygote through src/solver.jl:219-225)
     std::vector<RSeg> final_segs;   // dW split-K slabs: nothing reads the gradient before Adam, so ONE reduce launch at the end
@@ -521,6 +595,40 @@ static int build_program(dqn_engine* e) {
             const int l = lv[k]; const LayerDev L = e->L[l];
             const float* X = L.src < 0 ? e->x0 : e->act_on[L.src]; const int ldx = L.src < 0 ? ld0 : ncon;
             float* dpre = e->dact[l];
+            if (L.kind == DQN_LAYER_LSTM) {
+                // BPTT over the s-sequence: T single-workgroup steps produce dG (gate pre-activation gradients) for all columns,
+                // then Wi|b, Wh and the input gradient are ordinary dense contractions over the T*B columns.
+                float* grad = e->grad;
+                for (int t = T - 1; t >= 0; t--) {
+                    LstmBwdArgs a; a.t = t; a.T = T; a.H = L.H; a.B = Bb; a.TB = B; a.gates = e->gates[l]; a.tc = e->tcb[l]; a.cprev = e->cprev_buf[l]; a.Wh = e->p_on + L.wh_off;
+                    a.dH = dpre; a.dG = e->dG[l]; a.dhn = e->dhn[l]; a.dcn = e->dcn[l]; a.g_h0 = grad + L.h0_off; a.g_c0 = grad + L.c0_off;
+                    e->prog.push_back({pname(e, "lstm_bwd", L.kind, l), [=](dqn_engine* en) { launch_lstm_bwd_step(en->stream, a); }});
+                }
+                LayerDev Vi = L; Vi.kind = DQN_LAYER_DENSE; Vi.out_feat = L.N; Vi.act = DQN_ACT_IDENTITY;                    // Wi | b  : (K+1) x 4H
+                LayerDev Vh = Vi; Vh.K = L.H; Vh.in_feat = L.H; Vh.w_off = L.wh_off; Vh.b_off = L.wh_off + (size_t)L.H * L.N;  // Wh | junk
+                const float* dG = e->dG[l];
+                auto emit_dw1 = [&](const LayerDev V, const float* Xv, int ldv, const char* nm) {
+                    const int S = dqn_nchunks(B, V.dw_kc);
+                    float* part = S > 1 ? palloc(e, (size_t)S * (V.K + 1) * V.N) : nullptr; float* dst = S > 1 ? part : grad + V.w_off;
+                    if (mf && gemm_dw_eligible(V, B, ldv)) { struct A { const float* X[1]; const float* d[1]; float* o[1]; } a; a.X[0] = Xv; a.d[0] = dG; a.o[0] = dst;
+                        e->prog.push_back({nm, [=](dqn_engine* en) { launch_gemm_dw(en->stream, V, 1, a.X, ldv, a.d, B, a.o); }}); }
+                    else if (mf && mfma_dw_ok(V, B)) e->prog.push_back({nm, [=](dqn_engine* en) { launch_mfma_dw(en->stream, V, Xv, ldv, dG, B, grad, part, false); }});
+                    else { VTask t; memset(&t, 0, sizeof t); t.kind = 1; t.L = V; t.X = Xv; t.ldx = ldv; t.dpre = dG; t.B = B; t.S = S; t.kc = dqn_chunk_len(B, V.dw_kc); t.out = dst; add_valu(e, pend, t); }
+                    if (S > 1) { RSeg r; memset(&r, 0, sizeof r); r.part = part; r.S = S; r.elems = (unsigned long long)(V.K + 1) * V.N; r.mode = 2; r.out = grad + V.w_off; final_segs.push_back(r); }
+                };
+                emit_dw1(Vh, e->hprev_buf[l], B, pname(e, "dw_wh", L.kind, l));      // first: its junk bias row is then overwritten by nothing that matters
+                emit_dw1(Vi, X, ldx, pname(e, "dw_wi", L.kind, l));
+                if (L.src >= 0) {
+                    const int src = L.src; const int act_src = e->L[src].act; float* out = e->dact[src]; const float* ysrc = e->act_on[src]; const float* P = e->p_on;
+                    const int S = dqn_nchunks(Vi.N, Vi.dx_kc); float* part = S > 1 ? palloc(e, (size_t)S * Vi.in_feat * B) : nullptr;
+                    if (mf && gemm_dx_eligible(Vi, B, ncon)) { struct A1 { const float* W[1]; const float* d[1]; } a; a.W[0] = P + Vi.w_off; a.d[0] = dG; float* dst = S > 1 ? part : out; const float* ys = S > 1 ? nullptr : ysrc;
+                        e->prog.push_back({pname(e, "dx", L.kind, l), [=](dqn_engine* en) { launch_gemm_dx(en->stream, Vi, 1, a.W, a.d, B, dst, ys, ncon, act_src); }}); }
+                    else if (mf && mfma_dx_ok(Vi, B, ncon)) e->prog.push_back({pname(e, "dx", L.kind, l), [=](dqn_engine* en) { launch_mfma_dx(en->stream, Vi, P, dG, B, out, part, nullptr, ysrc, ncon, act_src, false); }});
+                    else { VTask t; memset(&t, 0, sizeof t); t.kind = 2; t.L = Vi; t.P = P; t.dpre = dG; t.B = B; t.S = S; t.kc = dqn_chunk_len(Vi.N, Vi.dx_kc); t.out = S > 1 ? part : out; t.ysrc = ysrc; t.ldy = ncon; t.act_src = act_src; add_valu(e, pend, t); }
+                    if (S > 1) { flush_valu(e, pend, pname(e, "bwd_valu", L.kind, l)); std::vector<RSeg> one; RSeg r; memset(&r, 0, sizeof r); r.part = part; r.S = S; r.elems = (unsigned long long)Vi.in_feat * B; r.mode = 1; r.act = act_src; r.ysrc = ysrc; r.B = B; r.ldy = ncon; r.out = out; one.push_back(r); emit_reduce(e, one, pname(e, "dx_reduce", L.kind, l)); }
+                }
+                continue;
+            }
             {   // dW / db
                 const int S = dqn_nchunks(L.npos * B, L.dw_kc);
                 float* part = S > 1 ? palloc(e, (size_t)S * (L.K + 1) * L.N) : nullptr;
@@ -582,7 +690,7 @@ static int build_program(dqn_engine* e) {
     emit_reduce(e, final_segs, "dw_reduce_all");
     e->prog_post_begin = e->prog.size();
     e->prog.push_back({"adam", [](dqn_engine* en) {
-        PrioArgs pa; pa.n = en->hp.prioritized_replay ? en->B : 0; pa.cap2 = en->cap2; pa.idx = en->idx; pa.td = en->td; pa.eps = en->hp.prio_eps; pa.alpha = en->hp.prio_alpha; pa.tree = en->tree;
+        PrioArgs pa; pa.n = (en->hp.prioritized_replay && !en->hp.recurrence) ? en->B : 0; pa.cap2 = en->cap2; pa.idx = en->idx; pa.td = en->td; pa.eps = en->hp.prio_eps; pa.alpha = en->hp.prio_alpha; pa.tree = en->tree;
         launch_adam(en->stream, en->Pint, en->p_on, en->m, en->v, en->grad, en->state, en->gmax_part, en->hp.adam_f64_scalars, en->hp.learning_rate,
                     en->hp.adam_beta1, en->hp.adam_beta2, en->hp.adam_eps, en->world > 1 ? 1.0f / (float)en->world : 1.0f, pa); }});
     e->prog_built = true;
@@ -591,6 +699,11 @@ static int build_program(dqn_engine* e) {
 static void enqueue_step(dqn_engine* e, bool sample, int phase) {
     e->step_sampled = sample;
     if (phase != PH_POST) {
+        if (e->hp.recurrence) {
+            EpGatherArgs g; g.ep_s = e->ep_s; g.ep_sp = e->ep_sp; g.ep_a = e->ep_a; g.ep_r = e->ep_r; g.ep_done = e->ep_done; g.ep_len = e->ep_len; g.ep_idx = e->ep_idx; g.ep_start = e->ep_start;
+            g.E = e->E; g.B = e->B; g.T = e->T; g.x0 = e->x0; g.a_out = e->r_a; g.r_out = e->r_r; g.done_out = e->r_done; g.mask_out = e->r_mask;
+            RUN(e, "gather_episodes", launch_gather_episodes(e->stream, g));
+        } else
         RUN(e, sample ? "sample_gather" : "gather", launch_gather_fb(e->stream, e->s_rows, e->sp_rows, e->hp.obs_dtype == DQN_OBS_U8, e->E, e->B, e->idx, e->x0,
                                                                    sample ? 1 : 0, e->cap2, e->tree, e->hp.seed, e->state));
         for (size_t i = 0; i < e->prog_post_begin; i++) RUN(e, e->prog[i].name, e->prog[i].fn(e));
@@ -640,6 +753,7 @@ static int fetch_scalars(dqn_engine* e, float* loss, float* gn) {
 }
 extern "C" int dqn_train_step(dqn_engine_t* e, const int64_t* idx, float* loss, float* grad_norm, float* td_out) {
     HIPCHK(hipSetDevice(e->device));
+    if (e->hp.recurrence) return fail("recurrence = true: use dqn_train_step_drqn (src/solver.jl:239-287)");
     if (e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
     if (idx) { if (check_idx(e, idx, e->B)) return -1; HIPCHK(hipMemcpyAsync(e->idx, idx, (size_t)e->B * 8, hipMemcpyHostToDevice, e->stream)); }
     if (run_step(e, idx == nullptr)) return -1;
@@ -649,6 +763,7 @@ extern "C" int dqn_train_step(dqn_engine_t* e, const int64_t* idx, float* loss, 
 }
 extern "C" int dqn_train_steps(dqn_engine_t* e, int n, float* loss, float* grad_norm) {
     HIPCHK(hipSetDevice(e->device));
+    if (e->hp.recurrence) { for (int i = 0; i < n; i++) if (dqn_train_step_drqn(e, nullptr, nullptr, i + 1 == n ? loss : nullptr, i + 1 == n ? grad_norm : nullptr)) return -1; return 0; }
     if (e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
     for (int i = 0; i < n; i++) if (run_step(e, true)) return -1;
     if (loss || grad_norm) return fetch_scalars(e, loss, grad_norm);
@@ -680,15 +795,47 @@ static int policy_ws(dqn_engine* e, int n) {
     for (int i = 0; i < e->nl; i++) DM(e->pol_act[i], (size_t)e->L[i].out_feat * n);
     e->pol_n = n; return 0;
 }
+static int policy_state(dqn_engine* e, int n, bool force_reset) {
+    // Recur state of the policy network: one (h, c) column per observation stream; reset = state0 of the ONLINE net (policy.jl:32-34)
+    if (!e->hp.recurrence) return 0;
+    if (n != e->pol_state_n) {
+        for (int i = 0; i < e->nl; i++) if (e->L[i].kind == DQN_LAYER_LSTM) {
+            for (int k = 0; k < 2; k++) { hipFree(e->pol_h[i][k]); hipFree(e->pol_c[i][k]); e->pol_h[i][k] = e->pol_c[i][k] = nullptr; DM(e->pol_h[i][k], (size_t)e->L[i].H * n); DM(e->pol_c[i][k], (size_t)e->L[i].H * n); }
+            hipFree(e->pol_gx[i]); e->pol_gx[i] = nullptr; DM(e->pol_gx[i], (size_t)e->L[i].N * n);
+        }
+        e->pol_state_n = n; force_reset = true;
+    }
+    if (force_reset) {
+        for (int i = 0; i < e->nl; i++) if (e->L[i].kind == DQN_LAYER_LSTM) {
+            launch_bcast_state(e->stream, e->p_on + e->L[i].h0_off, e->L[i].H, n, e->pol_h[i][e->pol_flip]);
+            launch_bcast_state(e->stream, e->p_on + e->L[i].c0_off, e->L[i].H, n, e->pol_c[i][e->pol_flip]);
+        }
+    }
+    return 0;
+}
 static int policy_forward(dqn_engine* e, int which, const float* obs, int n) {
     if (n < 1) return fail("n must be >= 1");
     HIPCHK(hipSetDevice(e->device));
     if (policy_ws(e, n)) return -1;
+    if (policy_state(e, n, false)) return -1;
     HIPCHK(hipMemcpyAsync(e->pol_obs, obs, (size_t)n * e->E * 4, hipMemcpyHostToDevice, e->stream));
     launch_transpose_obs(e->stream, e->pol_obs, e->E, n, e->pol_x);
     const float* P = which == DQN_NET_TARGET ? e->p_tg : e->p_on;
     // the policy workspace has leading dimension n (not pol_n): layers are dense in the batch column
-    for (int i = 0; i < e->nl; i++) { const LayerDev& l = e->L[i]; fwd_layer(e, l, P, l.src < 0 ? e->pol_x : e->pol_act[l.src], n, 0, n, e->pol_act[i], "policy_fwd"); }
+    const int fl = e->pol_flip;
+    for (int i = 0; i < e->nl; i++) {
+        const LayerDev& l = e->L[i]; const float* X = l.src < 0 ? e->pol_x : e->pol_act[l.src];
+        if (l.kind == DQN_LAYER_LSTM) {      // one Recur step: Gx = Wi*x (bias-free view), then the cell with the carried (h, c)
+            LayerDev V = l; V.kind = DQN_LAYER_DENSE; V.out_feat = l.N; V.b_off = l.z_off; V.act = DQN_ACT_IDENTITY;
+            fwd_layer(e, V, P, X, n, 0, n, e->pol_gx[i], "policy_fwd");
+            LstmStepArgs a; memset(&a, 0, sizeof a); a.H = l.H; a.B = n; a.nseq = 1;
+            LstmSeq& q = a.s[0]; q.Gx = e->pol_gx[i]; q.Hout = e->pol_act[i]; q.Cst = e->pol_c[i][fl ^ 1]; q.ld = n; q.c0 = 0; q.Wh = P + l.wh_off; q.bias = P + l.b_off;
+            q.hprev = e->pol_h[i][fl]; q.hp_ld = n; q.hp_bs = 1; q.cprev = e->pol_c[i][fl]; q.cp_ld = n; q.cp_bs = 1;
+            launch_lstm_step_t(e->stream, a, 0);
+            HIPCHK(hipMemcpyAsync(e->pol_h[i][fl ^ 1], e->pol_act[i], (size_t)l.H * n * 4, hipMemcpyDeviceToDevice, e->stream));
+        } else fwd_layer(e, l, P, X, n, 0, n, e->pol_act[i], "policy_fwd");
+    }
+    if (e->hp.recurrence) e->pol_flip ^= 1;
     const int lq = e->hp.dueling ? e->last_adv : e->last_base;
     launch_q_columns(e->stream, n, e->nA, e->hp.dueling, e->hp.dueling ? e->pol_act[e->last_val] : nullptr, e->pol_act[lq], e->pol_q, e->pol_a);
     return 0;
@@ -700,6 +847,114 @@ extern "C" int dqn_forward(dqn_engine_t* e, int which, const float* obs, int n, 
 extern "C" int dqn_greedy_action(dqn_engine_t* e, const float* obs, int n, int32_t* a_out) {
     if (policy_forward(e, DQN_NET_ONLINE, obs, n)) return -1;
     HIPCHK(hipMemcpyAsync(a_out, e->pol_a, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); return 0;
+}
+
+// ---------------------------------------------------------------- DRQN: EpisodeReplayBuffer + recurrent batch_train!
+#define NEED_REC(e) do { if (!(e)->hp.recurrence) return fail("this engine was created with recurrence = false"); } while (0)
+extern "C" int dqn_episode_commit(dqn_engine_t* e) {          // add_episode! (src/episode_replay.jl:54-60)
+    NEED_REC(e); HIPCHK(hipSetDevice(e->device));
+    const int len = (int)e->ep_cur_len;
+    e->ep_len_host[(size_t)e->ep_widx] = len;
+    HIPCHK(hipMemcpyAsync(e->ep_len + e->ep_widx, &e->ep_len_host[(size_t)e->ep_widx], 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->ep_widx = (e->ep_widx + 1) % e->ep_cap; if (e->ep_size < e->ep_cap) e->ep_size++;
+    e->ep_cur_len = 0; return 0;
+}
+extern "C" int dqn_episode_add(dqn_engine_t* e, const void* s, const int32_t* a, const float* r, const void* sp, const uint8_t* done, int n) {
+    NEED_REC(e); HIPCHK(hipSetDevice(e->device));
+    const size_t row = (size_t)e->E * 4;
+    for (int i = 0; i < n; i++) {                              // add_exp! (:46-52): push; the episode is stored when done
+        if (a[i] < 0 || a[i] >= e->nA) return fail("action index %d out of range 0..%d", a[i], e->nA - 1);
+        if (e->ep_cur_len < e->T) {                            // only the first trace_length transitions can ever be sampled (:82-92)
+            const size_t slot = (size_t)e->ep_widx * e->T + (size_t)e->ep_cur_len;
+            HIPCHK(hipMemcpyAsync((char*)e->ep_s + slot * row, (const char*)s + (size_t)i * row, row, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync((char*)e->ep_sp + slot * row, (const char*)sp + (size_t)i * row, row, hipMemcpyHostToDevice, e->stream));
+            const unsigned char d8 = done[i] ? 1 : 0;
+            HIPCHK(hipMemcpyAsync(e->ep_a + slot, a + i, 4, hipMemcpyHostToDevice, e->stream)); HIPCHK(hipMemcpyAsync(e->ep_r + slot, r + i, 4, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync(e->ep_done + slot, &d8, 1, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
+        }
+        e->ep_cur_len++;
+        if (done[i] && dqn_episode_commit(e)) return -1;
+    }
+    return 0;
+}
+extern "C" int dqn_episode_count(dqn_engine_t* e, int64_t* cur, int64_t* cap) { NEED_REC(e); if (cur) *cur = e->ep_size; if (cap) *cap = e->ep_cap; return 0; }
+static int drqn_check(dqn_engine* e, const int64_t* ep_idx, const int32_t* ep_start) {
+    if (e->ep_size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
+    for (int b = 0; b < e->B; b++) {
+        if (ep_idx[b] < 0 || ep_idx[b] >= e->ep_size) return fail("BoundsError: episode index %lld outside 0..%lld", (long long)ep_idx[b], (long long)e->ep_size - 1);
+        const int len = e->ep_len_host[(size_t)ep_idx[b]];
+        if (len > 0 && (ep_start[b] < 0 || ep_start[b] >= len)) return fail("episode start %d outside 0..%d", ep_start[b], len - 1);
+    }
+    return 0;
+}
+static int drqn_upload_draws(dqn_engine* e, const int64_t* ep_idx, const int32_t* ep_start) {
+    HIPCHK(hipMemcpyAsync(e->ep_idx, ep_idx, (size_t)e->B * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->ep_start, ep_start, (size_t)e->B * 4, hipMemcpyHostToDevice, e->stream));
+    return 0;
+}
+extern "C" int dqn_episode_get_batch(dqn_engine_t* e, const int64_t* ep_idx, const int32_t* ep_start, float* s, int32_t* a, float* r, float* sp, float* done, int32_t* mask) {
+    NEED_REC(e); HIPCHK(hipSetDevice(e->device));
+    if (drqn_check(e, ep_idx, ep_start) || drqn_upload_draws(e, ep_idx, ep_start)) return -1;
+    EpGatherArgs g; g.ep_s = e->ep_s; g.ep_sp = e->ep_sp; g.ep_a = e->ep_a; g.ep_r = e->ep_r; g.ep_done = e->ep_done; g.ep_len = e->ep_len; g.ep_idx = e->ep_idx; g.ep_start = e->ep_start;
+    g.E = e->E; g.B = e->B; g.T = e->T; g.x0 = e->x0; g.a_out = e->r_a; g.r_out = e->r_r; g.done_out = e->r_done; g.mask_out = e->r_mask;
+    launch_gather_episodes(e->stream, g);
+    const int TB = e->Bc, E = e->E;
+    std::vector<float> x((size_t)E * 2 * TB), rr(TB), dd(TB), mm(TB); std::vector<int> aa(TB);
+    HIPCHK(hipMemcpyAsync(x.data(), e->x0, x.size() * 4, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipMemcpyAsync(aa.data(), e->r_a, TB * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(rr.data(), e->r_r, TB * 4, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipMemcpyAsync(dd.data(), e->r_done, TB * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(mm.data(), e->r_mask, TB * 4, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream));
+    for (int k = 0; k < TB; k++) {      // device arena is [feature][column]; the seam returns [T][B][obs]
+        if (s) for (int f = 0; f < E; f++) s[(size_t)k * E + f] = x[(size_t)f * 2 * TB + k];
+        if (sp) for (int f = 0; f < E; f++) sp[(size_t)k * E + f] = x[(size_t)f * 2 * TB + TB + k];
+        if (a) a[k] = aa[k]; if (r) r[k] = rr[k]; if (done) done[k] = dd[k]; if (mask) mask[k] = (int32_t)mm[k];
+    }
+    return 0;
+}
+extern "C" int dqn_train_step_drqn(dqn_engine_t* e, const int64_t* ep_idx, const int32_t* ep_start, float* loss, float* grad_norm) {
+    NEED_REC(e); HIPCHK(hipSetDevice(e->device));
+    std::vector<int64_t> di; std::vector<int32_t> ds;
+    if (!ep_idx) {   // sample(rng, 1:n, B, replace=false); ep_start = rand(rng, 1:length(ep))  (src/episode_replay.jl:75,81) -- host-side SplitMix draws
+        if (e->ep_size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
+        auto next = [&]() { uint64_t z = (e->drqn_draws += 0x9E3779B97F4A7C15ull) ^ e->hp.seed; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+        std::vector<int64_t> perm((size_t)e->ep_size); for (size_t i = 0; i < perm.size(); i++) perm[i] = (int64_t)i;
+        for (int b = 0; b < e->B; b++) { const size_t j = b + (size_t)(next() % (perm.size() - b)); std::swap(perm[b], perm[j]); }
+        di.assign(perm.begin(), perm.begin() + e->B); ds.resize(e->B);
+        for (int b = 0; b < e->B; b++) { const int len = e->ep_len_host[(size_t)di[b]]; ds[b] = len > 0 ? (int32_t)(next() % (uint64_t)len) : 0; }
+        ep_idx = di.data(); ep_start = ds.data();
+    }
+    if (drqn_check(e, ep_idx, ep_start) || drqn_upload_draws(e, ep_idx, ep_start)) return -1;
+    if (build_program(e)) return -1;
+    if (e->hp.use_graph && !e->profiling && e->world == 1) {
+        if (!e->g_drqn && capture(e, false, PH_ALL, &e->g_drqn)) return -1;
+        HIPCHK(hipGraphLaunch(e->g_drqn, e->stream));
+    } else { enqueue_step(e, false, PH_PRE); if (e->world > 1 && allreduce_grads(e)) return -1; enqueue_step(e, false, PH_POST); }
+    if (loss || grad_norm) return fetch_scalars(e, loss, grad_norm);
+    return 0;
+}
+extern "C" int dqn_reset_state(dqn_engine_t* e) {             // resetstate!(policy) (src/policy.jl:32-34)
+    HIPCHK(hipSetDevice(e->device));
+    if (!e->hp.recurrence) return 0;
+    return policy_state(e, e->pol_state_n > 0 ? e->pol_state_n : 1, true);
+}
+extern "C" int dqn_get_hidden(dqn_engine_t* e, float* hc, size_t n) {   // hiddenstates(m) (src/helpers.jl:61-63): per LSTM layer h then c, [out][streams]
+    HIPCHK(hipSetDevice(e->device)); size_t off = 0;
+    for (int i = 0; i < e->nl; i++) if (e->L[i].kind == DQN_LAYER_LSTM) {
+        const size_t m = (size_t)e->L[i].H * e->pol_state_n; if (off + 2 * m > n) return fail("get_hidden: buffer too small");
+        HIPCHK(hipMemcpyAsync(hc + off, e->pol_h[i][e->pol_flip], m * 4, hipMemcpyDeviceToHost, e->stream)); off += m;
+        HIPCHK(hipMemcpyAsync(hc + off, e->pol_c[i][e->pol_flip], m * 4, hipMemcpyDeviceToHost, e->stream)); off += m;
+    }
+    HIPCHK(hipStreamSynchronize(e->stream)); return 0;
+}
+extern "C" int dqn_set_hidden(dqn_engine_t* e, const float* hc, size_t n) {   // sethiddenstates!(m, hs) (src/helpers.jl:71-79)
+    HIPCHK(hipSetDevice(e->device)); size_t off = 0;
+    for (int i = 0; i < e->nl; i++) if (e->L[i].kind == DQN_LAYER_LSTM) {
+        const size_t m = (size_t)e->L[i].H * e->pol_state_n; if (off + 2 * m > n) return fail("set_hidden: buffer too small");
+        HIPCHK(hipMemcpyAsync(e->pol_h[i][e->pol_flip], hc + off, m * 4, hipMemcpyHostToDevice, e->stream)); off += m;
+        HIPCHK(hipMemcpyAsync(e->pol_c[i][e->pol_flip], hc + off, m * 4, hipMemcpyHostToDevice, e->stream)); off += m;
+    }
+    HIPCHK(hipStreamSynchronize(e->stream)); return 0;
 }
 
 // ---------------------------------------------------------------- data-parallel replicas

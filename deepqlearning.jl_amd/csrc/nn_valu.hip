@@ -421,6 +421,11 @@ __global__ void k_convert_params(const LayerDev* __restrict__ layers, int nl, co
             j = L.w_off + e; break;
         }
         if (i >= L.eb_off && i < L.eb_off + (size_t)L.N) { j = L.b_off + (i - L.eb_off); break; }
+        if (L.kind == DQN_LAYER_LSTM) {          // Flux.params order Wi, Wh, b, h0, c0 -> internal [Wi][b][Wh][junk][h0][c0][zeros]
+            if (i >= L.ewh_off && i < L.ewh_off + (size_t)L.H * L.N) { j = L.wh_off + (i - L.ewh_off); break; }
+            if (i >= L.eh0_off && i < L.eh0_off + (size_t)L.H) { j = L.h0_off + (i - L.eh0_off); break; }
+            if (i >= L.ec0_off && i < L.ec0_off + (size_t)L.H) { j = L.c0_off + (i - L.ec0_off); break; }
+        }
     }
     if (to_internal) dst[j] = src[i]; else dst[i] = src[j];
 }

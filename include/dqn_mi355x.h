@@ -38,7 +38,7 @@ extern "C" {
 
 typedef struct dqn_engine dqn_engine_t;
 
-enum { DQN_LAYER_DENSE = 0, DQN_LAYER_CONV = 1 };
+enum { DQN_LAYER_DENSE = 0, DQN_LAYER_CONV = 1, DQN_LAYER_LSTM = 2 };
 enum { DQN_ACT_IDENTITY = 0, DQN_ACT_RELU = 1, DQN_ACT_TANH = 2, DQN_ACT_SIGMOID = 3 };
 enum { DQN_STREAM_BASE = 0, DQN_STREAM_VAL = 1, DQN_STREAM_ADV = 2 };
 enum { DQN_OBS_F32 = 0, DQN_OBS_U8 = 1 }; /* u8: stored byte, consumed as (float)byte/255f0 (test/test_env.jl:59) */
@@ -52,7 +52,7 @@ typedef struct {
     int32_t kind;   /* DQN_LAYER_* */
     int32_t act;    /* DQN_ACT_* */
     int32_t stream; /* DQN_STREAM_*; all BASE when dueling == 0 */
-    int32_t n_in, n_out;               /* Dense(in,out) */
+    int32_t n_in, n_out;               /* Dense(in,out); LSTM(in,out) = Flux Recur(LSTMCell): params Wi (4out,in), Wh (4out,out), b (4out), state0 h0, c0 */
     int32_t cin, cout, kh, kw, sh, sw; /* Conv((kh,kw), cin=>cout; stride=(sh,sw)), pad 0 */
 } dqn_layer_desc;
 
@@ -87,7 +87,9 @@ typedef struct {
     uint64_t seed;             /* sampler key (Philox4x32-10 counter RNG) */
     int32_t use_graph;         /* 1: replay the train step from a captured hipGraph */
     int32_t use_mfma;          /* 1: fp32 MFMA kernels where shapes allow (bit-identical to the VALU path) */
-    int32_t reserved[6];
+    int32_t recurrence;        /* solver.recurrence: DRQN on an EpisodeReplayBuffer (src/solver.jl:12,182-183,239-287) */
+    int32_t trace_length;      /* solver.trace_length (40) */
+    int32_t reserved[4];
 } dqn_hparams;
 
 const char* dqn_last_error(void);
@@ -153,6 +155,28 @@ int dqn_get_last_q(dqn_engine_t* e, float* q_on_s, float* q_on_sp, float* q_tg_s
                    int32_t* best_a /* B */, float* q_targets /* B */);
 int dqn_get_last_indices(dqn_engine_t* e, int64_t* idx /* B */);
 int dqn_get_grads(dqn_engine_t* e, float* flat, size_t n); /* Flux.params order/layout */
+
+/* ---- DRQN (solver.recurrence = true): EpisodeReplayBuffer (src/episode_replay.jl) and batch_train!(..., ::EpisodeReplayBuffer)
+ * (src/solver.jl:239-287).  buffer_size counts EPISODES.  Only the first trace_length transitions of an episode are ever
+ * read by the reference's sampler (episode_replay.jl:82-92 copies the episode PREFIX), so only those are kept. */
+/* add_exp!(r::EpisodeReplayBuffer, exp) (:46-52): append n transitions to the open episode; an episode is stored when done. */
+int dqn_episode_add(dqn_engine_t* e, const void* s, const int32_t* a, const float* r, const void* sp, const uint8_t* done, int n);
+/* add_episode!(r, ep) (:54-60) for populate_replay_buffer!/generate_episode (:97-130): store the open episode now. */
+int dqn_episode_commit(dqn_engine_t* e);
+int dqn_episode_count(dqn_engine_t* e, int64_t* cur, int64_t* cap);
+/* sample(r::EpisodeReplayBuffer) (:71-95) for GIVEN draws: ep_idx[B] distinct episodes (0-based), ep_start[B] in [0,len).
+ * Outputs (all optional): s, sp: float[T][B][C][H][W]; a: int32[T][B] (0-based); r, done: float[T][B]; mask: int32[T][B]. */
+int dqn_episode_get_batch(dqn_engine_t* e, const int64_t* ep_idx, const int32_t* ep_start, float* s, int32_t* a, float* r,
+                          float* sp, float* done, int32_t* mask);
+/* recurrent batch_train! (src/solver.jl:239-287): targets with hidden state carried over sp[1..T] for both nets, BPTT over
+ * s[1..T] of the masked Huber loss / B / T, max-abs grad norm, Adam; no IS weights, no priority update.
+ * ep_idx/ep_start NULL => the engine draws them (uniform without replacement; start uniform in [0,len)). */
+int dqn_train_step_drqn(dqn_engine_t* e, const int64_t* ep_idx, const int32_t* ep_start, float* loss, float* grad_norm);
+/* Recur state of the POLICY network (src/policy.jl:32-34 resetstate!, src/helpers.jl:61-79 hiddenstates/sethiddenstates!):
+ * dqn_forward / dqn_greedy_action advance it for recurrent networks (n streams, one per observation row). */
+int dqn_reset_state(dqn_engine_t* e);
+int dqn_get_hidden(dqn_engine_t* e, float* hc, size_t n /* sum over LSTM layers of 2*out*streams */);
+int dqn_set_hidden(dqn_engine_t* e, const float* hc, size_t n);
 
 /* NNPolicy: actionvalues / action / value (src/policy.jl:38-64) for n observations
  * (n = 1 in the reference; n > 1 serves vectorised envs).  obs: float[n][C][H][W]. */

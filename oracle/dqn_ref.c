@@ -49,6 +49,7 @@ typedef struct {
     int in_feat, out_feat;
     int src;                  /* producing layer index, -1 = observation */
     size_t w_off, b_off;      /* offsets in the flat parameter vector */
+    size_t wh_off, h0_off, c0_off; int H; /* LSTM: Flux.params order Wi (w_off), Wh, b (b_off), h0, c0 */
     dqn_layer_plan plan;
 } RLayer;
 
@@ -70,6 +71,13 @@ typedef struct ref_engine {
     float *w_is, *rew, *donef, *td, *qon_s, *qon_sp, *qtg_sp, *ytarget; int32_t *abatch, *best;
     float loss, gnorm;
     int nthreads;
+    /* DRQN: EpisodeReplayBuffer (src/episode_replay.jl) -- only the first T transitions of an episode are ever sampled */
+    int T; int64_t ep_cap, ep_size, ep_widx, ep_cur_len;
+    float *ep_s, *ep_sp; int32_t* ep_a; float* ep_r; uint8_t* ep_done; int32_t* ep_len;
+    float *rx0, *racc_on[MAXL], *racc_tg[MAXL], *rdact[MAXL];            /* [feat][2TB] / [feat][TB] */
+    float *gx_on[MAXL], *gx_tg[MAXL], *gates[MAXL], *cst[MAXL], *hprev[MAXL], *dgates[MAXL]; /* LSTM workspaces (online s-sequence keeps gates) */
+    float *r_a_f, *r_r, *r_done, *r_mask; int32_t* r_a; uint64_t drqn_ctr;
+    float* pol_h[MAXL]; float* pol_c[MAXL]; int pol_n;
 } ref_engine;
 
 static char g_err[512];
@@ -126,12 +134,12 @@ int ref_plan_default(const dqn_layer_desc* d, int n, const dqn_hparams* hp, dqn_
             K = d[i].cin * d[i].kh * d[i].kw; c = d[i].cout; h = oh; w = ow; posB = 1;
         } else { K = d[i].n_in; c = d[i].n_out; h = 1; w = 1; posB = 0; }
         if (d[i].stream == DQN_STREAM_BASE) { bc = c; bh = h; bw = w; }
-        int B = hp->batch_size;
+        int B = hp->batch_size; const int nout = d[i].kind == DQN_LAYER_LSTM ? 4 * d[i].n_out : d[i].n_out;
         out[i].fwd_kc = 0;
         if (K > 1024) { int s = (K + 511) / 512; int kc = (K + s - 1) / s; kc = (kc + 3) / 4 * 4; out[i].fwd_kc = kc; }
         else if (d[i].kind == DQN_LAYER_DENSE && d[i].n_out < 16 && K >= 128) out[i].fwd_kc = 32;
         out[i].dx_kc = 0;
-        if (d[i].kind == DQN_LAYER_DENSE && d[i].n_out > 512) out[i].dx_kc = 256;
+        if (d[i].kind != DQN_LAYER_CONV && nout > 512) out[i].dx_kc = 256;
         out[i].dw_kc = 0;
         if (posB) { int mrows = (K + 63) / 64; int st = (512 + mrows - 1) / mrows; int ppc = (h * w) / st; if (ppc < 1) ppc = 1; out[i].dw_kc = ppc * B; }
     }
@@ -159,18 +167,26 @@ int ref_create(const dqn_layer_desc* d, int n, const dqn_hparams* hp, const dqn_
         int c, h, w;
         if (prev < 0) { c = hp->obs_c; h = hp->obs_h; w = hp->obs_w; }
         else if (e->L[prev].kind == DQN_LAYER_CONV) { c = e->L[prev].cout; h = e->L[prev].oh; w = e->L[prev].ow; }
-        else { c = e->L[prev].N; h = 1; w = 1; }
+        else { c = e->L[prev].out_feat; h = 1; w = 1; }
         L->in_feat = c * h * w;
         if (L->kind == DQN_LAYER_CONV) {
             L->cin = d[i].cin; L->cout = d[i].cout; L->kh = d[i].kh; L->kw = d[i].kw; L->sh = d[i].sh; L->sw = d[i].sw;
             if (L->cin != c) { free(e); FAIL("layer %d: conv cin %d != incoming channels %d", i, L->cin, c); }
             L->ih = h; L->iw = w; L->oh = (h - L->kh) / L->sh + 1; L->ow = (w - L->kw) / L->sw + 1;
             L->K = L->cin * L->kh * L->kw; L->N = L->cout; L->out_feat = L->cout * L->oh * L->ow;
+        } else if (L->kind == DQN_LAYER_LSTM) {
+            if (d[i].n_in != L->in_feat) { free(e); FAIL("layer %d: LSTM n_in %d != incoming features %d", i, d[i].n_in, L->in_feat); }
+            if (!hp->recurrence) { free(e); FAIL("DeepQLearningError: you passed in a recurrent model but recurrence is set to false"); }
+            if (d[i].stream != DQN_STREAM_BASE) { free(e); FAIL("LSTM layers are supported in the base chain only"); }
+            L->H = d[i].n_out; L->K = d[i].n_in; L->N = 4 * L->H; L->out_feat = L->H; L->act = DQN_ACT_IDENTITY;
         } else {
             if (d[i].n_in != L->in_feat) { free(e); FAIL("layer %d: dense n_in %d != incoming features %d", i, d[i].n_in, L->in_feat); }
             L->K = d[i].n_in; L->N = d[i].n_out; L->out_feat = L->N;
         }
-        L->w_off = off; off += (size_t)L->K * L->N; L->b_off = off; off += L->N;
+        if (L->kind == DQN_LAYER_LSTM) {   /* Flux.params order: Wi, Wh, b, h0, c0 */
+            L->w_off = off; off += (size_t)L->K * L->N; L->wh_off = off; off += (size_t)L->H * L->N; L->b_off = off; off += L->N;
+            L->h0_off = off; off += L->H; L->c0_off = off; off += L->H;
+        } else { L->w_off = off; off += (size_t)L->K * L->N; L->b_off = off; off += L->N; }
         if (d[i].stream == DQN_STREAM_BASE) e->last_base = i;
         else if (d[i].stream == DQN_STREAM_VAL) e->last_val = i; else e->last_adv = i;
     }
@@ -197,6 +213,24 @@ int ref_create(const dqn_layer_desc* d, int n, const dqn_hparams* hp, const dqn_
     e->qon_s = calloc((size_t)B * e->nA, 4); e->qon_sp = calloc((size_t)B * e->nA, 4); e->qtg_sp = calloc((size_t)B * e->nA, 4);
     e->ytarget = calloc(B, 4); e->abatch = calloc(B, 4); e->best = calloc(B, 4);
     e->nthreads = 1;
+    if (hp->recurrence) {
+        const int T = hp->trace_length, TB = T * B; e->T = T; e->ep_cap = hp->buffer_size;
+        if (T < 1) { FAIL("trace_length must be >= 1"); }
+        e->ep_s = calloc((size_t)e->ep_cap * T * e->obs_elems, 4); e->ep_sp = calloc((size_t)e->ep_cap * T * e->obs_elems, 4);
+        e->ep_a = calloc((size_t)e->ep_cap * T, 4); e->ep_r = calloc((size_t)e->ep_cap * T, 4); e->ep_done = calloc((size_t)e->ep_cap * T, 1); e->ep_len = calloc(e->ep_cap, 4);
+        e->rx0 = calloc((size_t)e->obs_elems * 2 * TB, 4);
+        for (int i = 0; i < n; i++) {
+            const RLayer* L = &e->L[i];
+            e->racc_on[i] = calloc((size_t)L->out_feat * 2 * TB, 4); e->racc_tg[i] = calloc((size_t)L->out_feat * TB, 4); e->rdact[i] = calloc((size_t)L->out_feat * TB, 4);
+            if (L->kind == DQN_LAYER_LSTM) {
+                e->gx_on[i] = calloc((size_t)L->N * 2 * TB, 4); e->gx_tg[i] = calloc((size_t)L->N * TB, 4);
+                e->gates[i] = calloc((size_t)L->N * TB, 4); e->cst[i] = calloc((size_t)L->H * TB * 2, 4);   /* c and tanh(c) */
+                e->hprev[i] = calloc((size_t)L->H * TB * 2, 4);                                           /* h_{t-1} and c_{t-1} */
+                e->dgates[i] = calloc((size_t)L->N * TB, 4);
+            }
+        }
+        e->r_a = calloc(TB, 4); e->r_r = calloc(TB, 4); e->r_done = calloc(TB, 4); e->r_mask = calloc(TB, 4);
+    }
     *out = e; return 0;
 }
 int ref_set_threads(ref_engine* e, int n) {
@@ -222,6 +256,7 @@ int ref_get_plan(ref_engine* e, dqn_layer_plan* p) { for (int i = 0; i < e->nl; 
 static void convert_params(const ref_engine* e, const float* src, float* dst, int to_internal) {
     for (int i = 0; i < e->nl; i++) {
         const RLayer* L = &e->L[i];
+        if (L->kind == DQN_LAYER_LSTM) { memcpy(dst + L->w_off, src + L->w_off, ((size_t)L->K * L->N + (size_t)L->H * L->N + L->N + 2 * L->H) * 4); continue; }
         if (L->kind == DQN_LAYER_DENSE) memcpy(dst + L->w_off, src + L->w_off, (size_t)L->K * L->N * 4);
         else for (int co = 0; co < L->cout; co++) for (int ci = 0; ci < L->cin; ci++)
             for (int ky = 0; ky < L->kh; ky++) for (int kx = 0; kx < L->kw; kx++) {
@@ -581,4 +616,247 @@ int ref_greedy_action(ref_engine* e, const float* obs, int n, int32_t* a_out) {
     float* q = (float*)malloc((size_t)n * e->nA * 4); ref_forward(e, DQN_NET_ONLINE, obs, n, q);
     for (int b = 0; b < n; b++) a_out[b] = argmax_first(q + (size_t)b * e->nA, e->nA);
     free(q); return 0;
+}
+
+/* ================================================================= DRQN
+ * EpisodeReplayBuffer  src/episode_replay.jl:3-95      batch_train! (recurrent)  src/solver.jl:239-287
+ * Flux LSTM (third-party; recalled): g = Wi*x .+ Wh*h .+ b, gates input/forget/cell/output,
+ * c' = sigm(f).*c .+ sigm(i).*tanh(g), h' = sigm(o).*tanh(c'), trainable state0 = (h0, c0).
+ * Column of timestep t, sample b: t*B + b.  Canonical order: gate pre-activation
+ * = ((chain_k Wi x) + (chain_j Wh h)) + b; sigm/tanh evaluated in double and rounded once. */
+static inline float sigm_f(float x) { return (float)(1.0 / (1.0 + exp(-(double)x))); }
+static inline float tanh_f(float x) { return (float)tanh((double)x); }
+
+int ref_episode_count(ref_engine* e, int64_t* cur, int64_t* cap) { if (cur) *cur = e->ep_size; if (cap) *cap = e->ep_cap; return 0; }
+int ref_episode_commit(ref_engine* e) {          /* add_episode! (:54-60) */
+    if (!e->hp.recurrence) FAIL("engine was created with recurrence = false");
+    e->ep_len[e->ep_widx] = (int32_t)e->ep_cur_len;
+    e->ep_widx = (e->ep_widx + 1) % e->ep_cap; if (e->ep_size < e->ep_cap) e->ep_size++;
+    e->ep_cur_len = 0; return 0;
+}
+int ref_episode_add(ref_engine* e, const void* s, const int32_t* a, const float* r, const void* sp, const uint8_t* done, int n) {
+    if (!e->hp.recurrence) FAIL("engine was created with recurrence = false");
+    const int E = e->obs_elems, T = e->T;
+    for (int i = 0; i < n; i++) {                 /* add_exp! (:46-52): push, store the episode when done */
+        if (a[i] < 0 || a[i] >= e->nA) FAIL("action index %d out of range", a[i]);
+        const int64_t t = e->ep_cur_len;
+        if (t < T) {
+            const size_t slot = (size_t)e->ep_widx * T + t;
+            memcpy(e->ep_s + slot * E, (const float*)s + (size_t)i * E, (size_t)E * 4); memcpy(e->ep_sp + slot * E, (const float*)sp + (size_t)i * E, (size_t)E * 4);
+            e->ep_a[slot] = a[i]; e->ep_r[slot] = r[i]; e->ep_done[slot] = done[i] ? 1 : 0;
+        }
+        e->ep_cur_len++;
+        if (done[i]) ref_episode_commit(e);
+    }
+    return 0;
+}
+static int drqn_check(ref_engine* e, const int64_t* ep_idx, const int32_t* ep_start) {
+    if (e->ep_size < e->B) FAIL("AssertionError: r._curr_size >= r.batch_size");
+    for (int b = 0; b < e->B; b++) {
+        if (ep_idx[b] < 0 || ep_idx[b] >= e->ep_size) FAIL("BoundsError: episode index %lld outside 0..%lld", (long long)ep_idx[b], (long long)e->ep_size - 1);
+        const int len = e->ep_len[ep_idx[b]];
+        if (len > 0 && (ep_start[b] < 0 || ep_start[b] >= len)) FAIL("episode start %d outside 0..%d", ep_start[b], len - 1);
+    }
+    return 0;
+}
+/* number of transitions copied for sample b: the reference's `for j = ep_start:min(len,T)` with t counting from 1 copies
+ * the episode PREFIX of length max(0, min(len,T) - ep_start) (0-based start), episode_replay.jl:82-92 */
+static inline int prefix_len(const ref_engine* e, int64_t ep, int start) { int len = e->ep_len[ep]; int m = len < e->T ? len : e->T; int n = m - start; return n < 0 ? 0 : n; }
+int ref_episode_get_batch(ref_engine* e, const int64_t* ep_idx, const int32_t* ep_start, float* s, int32_t* a, float* r, float* sp, float* done, int32_t* mask) {
+    if (drqn_check(e, ep_idx, ep_start)) return -1;
+    const int T = e->T, B = e->B, E = e->obs_elems;
+    for (int t = 0; t < T; t++) for (int b = 0; b < B; b++) {
+        const int ok = t < prefix_len(e, ep_idx[b], ep_start[b]); const size_t slot = (size_t)ep_idx[b] * T + t; const size_t o = (size_t)t * B + b;
+        if (s) for (int f = 0; f < E; f++) s[o * E + f] = ok ? e->ep_s[slot * E + f] : 0.0f;
+        if (sp) for (int f = 0; f < E; f++) sp[o * E + f] = ok ? e->ep_sp[slot * E + f] : 0.0f;
+        if (a) a[o] = ok ? e->ep_a[slot] : 0;      /* CartesianIndex(1,1) for masked rows (:29,:64): harmless, mask multiplies inside huber */
+        if (r) r[o] = ok ? e->ep_r[slot] : 0.0f; if (done) done[o] = ok ? (float)e->ep_done[slot] : 0.0f; if (mask) mask[o] = ok;
+    }
+    return 0;
+}
+/* a dense view of (part of) an LSTM parameter block, so that the feed-forward routines above can be reused */
+static RLayer dense_view(const RLayer* L, int K, int N, size_t w_off, size_t b_off) {
+    RLayer v; memset(&v, 0, sizeof v); v.kind = DQN_LAYER_DENSE; v.act = DQN_ACT_IDENTITY; v.K = K; v.N = N; v.in_feat = K; v.out_feat = N; v.oh = v.ow = v.ih = v.iw = 1;
+    v.w_off = w_off; v.b_off = b_off; v.plan = L->plan; v.src = L->src; return v;
+}
+/* Gx[n][col] = chain_k X[k][col] Wi[k][n]  (no bias: it is added inside the recurrence, after the Wh*h chain) */
+static void lstm_input_proj(const RLayer* L, const float* P, const float* X, int ldx, int col0, int ncols, float* Gx) {
+    RLayer v = dense_view(L, L->K, L->N, L->w_off, L->b_off);
+    float* zero = (float*)calloc(L->N, 4);
+    /* layer_forward adds P[b_off + n]: run it against a parameter image whose bias is zero */
+    const size_t span = (size_t)L->K * L->N;
+    float* img = (float*)malloc((span + L->N) * 4); memcpy(img, P + L->w_off, span * 4); memcpy(img + span, zero, (size_t)L->N * 4);
+    v.w_off = 0; v.b_off = span; layer_forward(&v, img, X, ldx, col0, ncols, Gx);
+    free(img); free(zero);
+}
+/* one sequence of T steps on B columns starting at column c0 of arrays with leading dimension ld.
+ * keep != 0: store gates (i,f,g,o post-activation), c, tanh(c), h_{t-1}, c_{t-1} for BPTT (online s-sequence). */
+static void lstm_recurrence(ref_engine* e, int li, const float* P, const float* Gx, int ld, int c0, float* Hout, int keep) {
+    const RLayer* L = &e->L[li]; const int H = L->H, B = e->B, T = e->T, TB = T * B;
+    const float *Wh = P + L->wh_off, *bias = P + L->b_off, *h0 = P + L->h0_off, *c0p = P + L->c0_off;
+    float* hp = (float*)malloc((size_t)H * B * 4); float* cp = (float*)malloc((size_t)H * B * 4); float* hn = (float*)malloc((size_t)H * B * 4); float* cn = (float*)malloc((size_t)H * B * 4);
+    for (int u = 0; u < H; u++) for (int b = 0; b < B; b++) { hp[u * B + b] = h0[u]; cp[u * B + b] = c0p[u]; }
+    for (int t = 0; t < T; t++) {
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int u = 0; u < H; u++) for (int b = 0; b < B; b++) {
+            const int col = c0 + t * B + b; float g[4];
+            for (int q = 0; q < 4; q++) {
+                const int n = q * H + u; float ch = 0.0f;
+                for (int j = 0; j < H; j++) ch = fmaf(hp[j * B + b], Wh[(size_t)j * L->N + n], ch);
+                g[q] = (Gx[(size_t)n * ld + col] + ch) + bias[n];
+            }
+            const float ig = sigm_f(g[0]), fg = sigm_f(g[1]), gg = tanh_f(g[2]), og = sigm_f(g[3]);
+            const float t1 = fg * cp[u * B + b]; const float t2 = ig * gg; const float c = t1 + t2; const float tc = tanh_f(c); const float h = og * tc;
+            cn[u * B + b] = c; hn[u * B + b] = h; Hout[(size_t)u * ld + col] = h;
+            if (keep) {
+                const int k = t * B + b;
+                e->gates[li][(size_t)(0 * H + u) * TB + k] = ig; e->gates[li][(size_t)(1 * H + u) * TB + k] = fg;
+                e->gates[li][(size_t)(2 * H + u) * TB + k] = gg; e->gates[li][(size_t)(3 * H + u) * TB + k] = og;
+                e->cst[li][(size_t)u * TB + k] = c; e->cst[li][(size_t)(H + u) * TB + k] = tc;
+                e->hprev[li][(size_t)u * TB + k] = hp[u * B + b]; e->hprev[li][(size_t)(H + u) * TB + k] = cp[u * B + b];
+            }
+        }
+        float* x = hp; hp = hn; hn = x; x = cp; cp = cn; cn = x;
+    }
+    free(hp); free(cp); free(hn); free(cn);
+}
+static void seq_forward(ref_engine* e, const float* P, float** act, float** gx, const float* X0, int ld0, int col0, int ncols, int nseq) {
+    /* ncols = nseq * T * B columns; each group of T*B columns is an independent sequence from the reset state */
+    for (int i = 0; i < e->nl; i++) {
+        const RLayer* L = &e->L[i];
+        const float* X = L->src < 0 ? X0 : act[L->src]; const int ldx = L->src < 0 ? ld0 : ncols; const int c0 = L->src < 0 ? col0 : 0;
+        if (L->kind == DQN_LAYER_LSTM) {
+            lstm_input_proj(L, P, X, ldx, c0, ncols, gx[i]);
+            for (int q = 0; q < nseq; q++) lstm_recurrence(e, i, P, gx[i], ncols, q * e->T * e->B, act[i], (act == e->racc_on && q == 0));
+        } else layer_forward(L, P, X, ldx, c0, ncols, act[i]);
+    }
+}
+int ref_train_step_drqn(ref_engine* e, const int64_t* ep_idx_in, const int32_t* ep_start_in, float* loss_out, float* gnorm_out) {
+    if (!e->hp.recurrence) FAIL("engine was created with recurrence = false");
+    const int B = e->B, T = e->T, TB = T * B, nA = e->nA, E = e->obs_elems, ld0 = 2 * TB;
+    int64_t ep_idx[1024]; int32_t ep_start[1024];
+    if (!ep_idx_in) FAIL("the twin needs explicit episode draws");
+    memcpy(ep_idx, ep_idx_in, (size_t)B * 8); memcpy(ep_start, ep_start_in, (size_t)B * 4);
+    if (drqn_check(e, ep_idx, ep_start)) return -1;
+    /* sample(r) (:71-95) into the batch-innermost arena: columns t*B+b = s, TB + t*B+b = sp */
+    for (int t = 0; t < T; t++) for (int b = 0; b < B; b++) {
+        const int ok = t < prefix_len(e, ep_idx[b], ep_start[b]); const size_t slot = (size_t)ep_idx[b] * T + t; const int k = t * B + b;
+        for (int f = 0; f < E; f++) { e->rx0[(size_t)f * ld0 + k] = ok ? e->ep_s[slot * E + f] : 0.0f; e->rx0[(size_t)f * ld0 + TB + k] = ok ? e->ep_sp[slot * E + f] : 0.0f; }
+        e->r_a[k] = ok ? e->ep_a[slot] : 0; e->r_r[k] = ok ? e->ep_r[slot] : 0.0f; e->r_done[k] = ok ? (float)e->ep_done[slot] : 0.0f; e->r_mask[k] = (float)ok;
+    }
+    /* online net: the s sequence (loss) and, for double-Q, the sp sequence; target net: the sp sequence (:249-271) */
+    const int nseq_on = e->hp.double_q ? 2 : 1;
+    seq_forward(e, e->p_on, e->racc_on, e->gx_on, e->rx0, ld0, 0, nseq_on * TB, nseq_on);
+    seq_forward(e, e->p_tg, e->racc_tg, e->gx_tg, e->rx0, ld0, TB, TB, 1);
+    const int ncon = nseq_on * TB;
+    const float gamma = e->hp.gamma, invT = 1.0f / (float)T; float q[64], qt[64];
+    const int lastv = e->last_val, lasta = e->hp.dueling ? e->last_adv : e->last_base;
+    float loss = 0.0f;
+    for (int t = 0; t < T; t++) {
+        float lsum = 0.0f;
+        for (int b = 0; b < B; b++) {
+            const int k = t * B + b;
+            q_column(e, e->racc_tg, TB, k, qt);
+            int best; float qsp;
+            if (e->hp.double_q) { q_column(e, e->racc_on, ncon, TB + k, q); best = argmax_first(q, nA); qsp = qt[best]; } else { best = argmax_first(qt, nA); qsp = qt[best]; }
+            const float t1 = 1.0f - e->r_done[k]; const float t2 = t1 * gamma; const float t3 = t2 * qsp; const float y = e->r_r[k] + t3;    /* :268 */
+            q_column(e, e->racc_on, ncon, k, q);
+            const float td = q[e->r_a[k]] - y; const float m = e->r_mask[k];
+            const float x = m * td; const float ab = fabsf(x); const float qd = ab < 1.0f ? ab : 1.0f; const float lin = ab - qd;
+            lsum = lsum + ((0.5f * qd) * qd + lin);
+            const float cl = x < -1.0f ? -1.0f : (x > 1.0f ? 1.0f : x);
+            const float g = ((invT / (float)B) * cl) * m;
+            if (e->hp.dueling) {
+                e->rdact[lastv][k] = g; const float gm = g / (float)nA;
+                for (int a = 0; a < nA; a++) e->rdact[lasta][(size_t)a * TB + k] = (a == e->r_a[k] ? g : 0.0f) - gm;
+            } else for (int a = 0; a < nA; a++) e->rdact[lasta][(size_t)a * TB + k] = (a == e->r_a[k] ? g : 0.0f);
+        }
+        loss = loss + lsum / (float)B;                                                       /* :279 */
+    }
+    e->loss = loss / (float)T;                                                               /* :281 */
+    /* backward over the s-sequence columns 0..TB-1 */
+    memset(e->grad, 0, e->P * 4);
+    int joined = 0;
+    for (int i = e->nl - 1; i >= 0; i--) {
+        const RLayer* L = &e->L[i];
+        float* d = e->rdact[i]; const float* y = e->racc_on[i];
+        const float* X = L->src < 0 ? e->rx0 : e->racc_on[L->src]; const int ldx = L->src < 0 ? ld0 : ncon;
+        float* dxout = NULL; RLayer xv; const float* dpre_for_dx = d;
+        if (L->kind == DQN_LAYER_LSTM) {
+            const int H = L->H; const float* Wh = e->p_on + L->wh_off;
+            float* dG = e->dgates[i]; const float* G = e->gates[i]; const float* C = e->cst[i]; const float* HP = e->hprev[i];
+            float* dhn = (float*)calloc((size_t)H * B, 4); float* dcn = (float*)calloc((size_t)H * B, 4);
+            for (int t = T - 1; t >= 0; t--) {
+                for (int u = 0; u < H; u++) for (int b = 0; b < B; b++) {
+                    const int k = t * B + b;
+                    const float ig = G[(size_t)u * TB + k], fg = G[(size_t)(H + u) * TB + k], gg = G[(size_t)(2 * H + u) * TB + k], og = G[(size_t)(3 * H + u) * TB + k];
+                    const float tc = C[(size_t)(H + u) * TB + k], cprev = HP[(size_t)(H + u) * TB + k];
+                    const float dh = d[(size_t)u * TB + k] + dhn[u * B + b];
+                    const float dov = dh * tc; const float t1 = dh * og; const float t2 = tc * tc; const float t3 = 1.0f - t2; const float t4 = t1 * t3; const float dc = dcn[u * B + b] + t4;
+                    const float di = dc * gg, df = dc * cprev, dgc = dc * ig; dcn[u * B + b] = dc * fg;
+                    const float a1 = di * ig, a2 = 1.0f - ig; dG[(size_t)u * TB + k] = a1 * a2;
+                    const float b1 = df * fg, b2 = 1.0f - fg; dG[(size_t)(H + u) * TB + k] = b1 * b2;
+                    const float c1 = gg * gg, c2 = 1.0f - c1; dG[(size_t)(2 * H + u) * TB + k] = dgc * c2;
+                    const float d1 = dov * og, d2 = 1.0f - og; dG[(size_t)(3 * H + u) * TB + k] = d1 * d2;
+                }
+                for (int j = 0; j < H; j++) for (int b = 0; b < B; b++) {       /* dh_{t-1} = Wh * dG_t : n ascending over 4H */
+                    float acc = 0.0f; const int k = t * B + b;
+                    for (int n = 0; n < L->N; n++) acc = fmaf(dG[(size_t)n * TB + k], Wh[(size_t)j * L->N + n], acc);
+                    dhn[j * B + b] = acc;
+                }
+            }
+            for (int u = 0; u < H; u++) {                                          /* trainable initial state: sum over the batch, ascending b */
+                float sh = 0.0f, sc = 0.0f; for (int b = 0; b < B; b++) { sh = sh + dhn[u * B + b]; sc = sc + dcn[u * B + b]; }
+                e->grad[L->h0_off + u] = sh; e->grad[L->c0_off + u] = sc;
+            }
+            free(dhn); free(dcn);
+            RLayer wi = dense_view(L, L->K, L->N, L->w_off, L->b_off);             /* dWi and db over all T*B columns (t-major, b-minor) */
+            /* layer_backward_w writes db right after dW: stage into a scratch (K+1) x N block */
+            float* scratch = (float*)calloc(((size_t)(L->K > H ? L->K : H) + 1) * L->N, 4);
+            wi.w_off = 0; wi.b_off = (size_t)L->K * L->N; layer_backward_w(&wi, X, ldx, dG, TB, scratch);
+            memcpy(e->grad + L->w_off, scratch, (size_t)L->K * L->N * 4); memcpy(e->grad + L->b_off, scratch + (size_t)L->K * L->N, (size_t)L->N * 4);
+            RLayer wh = dense_view(L, H, L->N, 0, (size_t)H * L->N);               /* dWh: X = h_{t-1} (h0 broadcast at t = 0) */
+            layer_backward_w(&wh, HP, TB, dG, TB, scratch);
+            memcpy(e->grad + L->wh_off, scratch, (size_t)H * L->N * 4);
+            free(scratch);
+            xv = dense_view(L, L->K, L->N, L->w_off, L->b_off); dpre_for_dx = dG;
+        } else {
+            for (size_t t = 0; t < (size_t)L->out_feat; t++) for (int k = 0; k < TB; k++) d[t * TB + k] = dact_f(d[t * TB + k], y[t * ncon + k], L->act);
+            layer_backward_w(L, X, ldx, d, TB, e->grad);
+            xv = *L;
+        }
+        if (L->src >= 0) {
+            const int src = L->src; const size_t n = (size_t)e->L[src].out_feat * TB;
+            const int is_join = e->hp.dueling && src == e->last_base && L->stream != DQN_STREAM_BASE;
+            if (!is_join) layer_backward_x(&xv, e->p_on, dpre_for_dx, TB, e->rdact[src]);
+            else {
+                float* tmp = (float*)malloc(n * 4); layer_backward_x(&xv, e->p_on, dpre_for_dx, TB, tmp);
+                if (!joined) { memcpy(e->rdact[src], tmp, n * 4); joined = 1; } else for (size_t t = 0; t < n; t++) e->rdact[src][t] = tmp[t] + e->rdact[src][t];
+                free(tmp);
+            }
+        }
+        (void)dxout;
+    }
+    float gn = 0.0f; for (size_t i = 0; i < e->P; i++) { float a = fabsf(e->grad[i]); if (a > gn) gn = a; }
+    e->gnorm = gn;
+    {   /* Flux Adam, Float64-scalar form (same arithmetic as the feed-forward step) */
+        const double b1 = e->hp.adam_beta1, b2 = e->hp.adam_beta2, eps = e->hp.adam_eps, eta = (double)e->hp.learning_rate;
+        const double omb1 = 1.0 - b1, omb2 = 1.0 - b2, c1 = 1.0 - e->bp1, c2 = 1.0 - e->bp2;
+        for (size_t i = 0; i < e->P; i++) {
+            if (e->hp.adam_f64_scalars) {
+                double g = (double)e->grad[i]; double t1 = b1 * (double)e->m[i]; double t2 = omb1 * g; float mn = (float)(t1 + t2);
+                double u1 = b2 * (double)e->v[i]; double u2 = omb2 * g; double u3 = u2 * g; float vn = (float)(u1 + u3);
+                double mh = (double)mn / c1; double vh = (double)vn / c2; double den = sqrt(vh) + eps; double q1 = mh / den; float dl = (float)(q1 * eta);
+                e->m[i] = mn; e->v[i] = vn; e->p_on[i] = e->p_on[i] - dl;
+            } else {
+                const float fb1 = (float)b1, fb2 = (float)b2; float g = e->grad[i];
+                float t1 = fb1 * e->m[i]; float t2 = (1.0f - fb1) * g; float mn = t1 + t2; float u1 = fb2 * e->v[i]; float u2 = (1.0f - fb2) * g; float u3 = u2 * g; float vn = u1 + u3;
+                float mh = mn / (1.0f - (float)e->bp1); float vh = vn / (1.0f - (float)e->bp2); float den = sqrtf(vh) + (float)eps; float q1 = mh / den; float dl = q1 * e->hp.learning_rate;
+                e->m[i] = mn; e->v[i] = vn; e->p_on[i] = e->p_on[i] - dl;
+            }
+        }
+        e->bp1 *= b1; e->bp2 *= b2;
+    }
+    if (loss_out) *loss_out = e->loss; if (gnorm_out) *gnorm_out = e->gnorm;
+    return 0;
 }

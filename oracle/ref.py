@@ -55,6 +55,8 @@ def layers_from_network(net):
             d.act, d.stream = l.act, stream
             if l.kind == "dense":
                 d.kind, d.n_in, d.n_out = abi.LAYER_DENSE, l.n_in, l.n_out
+            elif l.kind == "lstm":
+                d.kind, d.n_in, d.n_out = abi.LAYER_LSTM, l.n_in, l.n_out
             else:
                 d.kind = abi.LAYER_CONV
                 d.cin, d.cout, d.kh, d.kw, d.sh, d.sw = l.cin, l.cout, l.kh, l.kw, l.sh, l.sw

@@ -1,0 +1,83 @@
+"""GPU: DRQN (EpisodeReplayBuffer + recurrent batch_train!, src/episode_replay.jl, src/solver.jl:239-287) through the C ABI:
+bit-exact vs the CPU twin over several steps, fp32 round-off vs the fp64 oracle, recurrent policy forward vs the oracle."""
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+import dqn_oracle as O
+import ref
+from drqn_common import check_against_oracle, draws, drqn_nets, feed, make_episodes, make_handle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = ge.load_package(); p.lib(); return p
+
+
+def setup(pkg, name, mfma=1, graph=1):
+    net, B, T, kw = drqn_nets()[name]
+    rng = np.random.default_rng(5)
+    cap = max(12, B + 4)
+    gpu, hp, layers = make_handle(pkg.Engine, net, B, T, dict(kw, use_mfma=mfma, use_graph=graph), cap=cap)
+    cpu = ref.Twin(layers, hp, plan=gpu.plan(), threads=4)
+    eps = make_episodes(net, cap + 3, T, rng)
+    feed(gpu, eps); feed(cpu, eps)
+    ring = [None] * cap
+    for i, ep in enumerate(eps):
+        ring[i % cap] = ep
+    p_on = (O.Network.flatten(O.init_params_recurrent(net, 3)) + 0.05 * rng.standard_normal(net.n_params())).astype(np.float32)
+    p_tg = (O.Network.flatten(O.init_params_recurrent(net, 4)) + 0.05 * rng.standard_normal(net.n_params())).astype(np.float32)
+    for h in (gpu, cpu):
+        h.set_params(p_on, 0); h.set_params(p_tg, 1)
+    np.testing.assert_array_equal(gpu.get_params(0), p_on)      # LSTM block layout round trip (Wi, Wh, b, h0, c0)
+    return net, B, T, kw, rng, gpu, cpu, ring, (p_on, p_tg)
+
+
+@pytest.mark.parametrize("mfma", [0, 1])
+@pytest.mark.parametrize("name", list(drqn_nets()))
+def test_drqn_bit_exact_vs_twin_and_oracle(pkg, name, mfma):
+    net, B, T, kw, rng, gpu, cpu, ring, params = setup(pkg, name, mfma=mfma)
+    assert gpu.episode_count() == cpu.episode_count()
+    idx, start = draws(ring, B, np.random.default_rng(9))
+    for a, b in zip(gpu.episode_get_batch(idx, start), cpu.episode_get_batch(idx, start)):
+        np.testing.assert_array_equal(a, b)
+    check_against_oracle(gpu, net, ring, B, T, kw, np.random.default_rng(11), params)     # also advances the engine by one step
+    cpu.train_step_drqn(*draws(ring, B, np.random.default_rng(11)))                       # same draws -> same state
+    for step in range(4):
+        idx, start = draws(ring, B, rng)
+        lg, gg = gpu.train_step_drqn(idx, start); lc, gc = cpu.train_step_drqn(idx, start)
+        assert lg == lc and gg == gc, (step, lg, lc, gg, gc)
+        if step == 1:
+            gpu.sync_target(); cpu.sync_target()
+    np.testing.assert_array_equal(gpu.get_grads(), cpu.get_grads())
+    np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+    mg, vg, bg = gpu.get_adam_state(); mc, vc, bc = cpu.get_adam_state()
+    np.testing.assert_array_equal(mg, mc); np.testing.assert_array_equal(vg, vc); np.testing.assert_array_equal(bg, bc)
+    gpu.close(); cpu.close()
+
+
+def test_recurrent_policy_forward_carries_state(pkg):
+    net, B, T, kw, rng, gpu, cpu, ring, (p_on, p_tg) = setup(pkg, "dense_lstm_dueling")
+    xs = [rng.random((1,) + net.obs_shape).astype(np.float32) for _ in range(6)]
+    qs64, _ = O._seq_forward(net, [p.astype(np.float64) for p in net.unflatten(p_on)], [x.astype(np.float64) for x in xs])
+    gpu.reset_state()
+    for t, x in enumerate(xs):                     # Flux Recur: the hidden state persists between calls (src/policy.jl:38-46)
+        np.testing.assert_allclose(gpu.forward(x), qs64[t], atol=1e-5, rtol=1e-5)
+    gpu.reset_state()                              # resetstate!(policy): back to state0
+    np.testing.assert_allclose(gpu.forward(xs[0]), qs64[0], atol=1e-5, rtol=1e-5)
+    assert gpu.greedy_action(xs[1])[0] == int(np.argmax(qs64[1][0]))
+    # the sampled-draws path (engine draws episodes itself) runs and keeps training finite
+    l, g = gpu.train_step_drqn()
+    assert np.isfinite(l) and g >= 0
+    with pytest.raises(pkg.DQNError, match="use dqn_train_step_drqn"):
+        gpu.train_step()
+    gpu.close(); cpu.close()
+
+
+def test_lstm_without_recurrence_flag_is_rejected(pkg):
+    net, B, T, kw = drqn_nets()["lstm_single_q"]
+    hp = ref.hparams_for(net, batch_size=B, buffer_size=8, recurrence=0)
+    with pytest.raises(pkg.DQNError, match="recurrent model but recurrence is set to false"):   # src/solver.jl:45-47
+        pkg.Engine(ref.layers_from_network(net), hp)
