@@ -47,6 +47,18 @@ class Conv:
         return self.kh * self.kw * self.cin, self.kh * self.kw * self.cout
 
 
+class LSTM:
+    """Flux LSTM(in, out) = Recur(LSTMCell): params Wi (4out,in), Wh (4out,out), b (4out, forget gate bias 1), state0 (h0, c0)."""
+    kind = "lstm"
+
+    def __init__(self, n_in, n_out):
+        self.n_in, self.n_out, self.act = int(n_in), int(n_out), identity
+
+    def shapes(self):   # Julia memory order: Wi (4out,in) == C (in,4out), Wh (4out,out) == C (out,4out), b, h0, c0
+        h = self.n_out
+        return [(self.n_in, 4 * h), (h, 4 * h), (4 * h,), (h,), (h,)]
+
+
 class Chain:
     def __init__(self, *layers):
         self.layers = [l for l in layers if getattr(l, "kind", None) != "flatten" and l is not flattenbatch]
@@ -96,6 +108,8 @@ def lower(net):
             d.act, d.stream = l.act, stream
             if l.kind == "dense":
                 d.kind, d.n_in, d.n_out = _abi.LAYER_DENSE, l.n_in, l.n_out
+            elif l.kind == "lstm":
+                d.kind, d.n_in, d.n_out = _abi.LAYER_LSTM, l.n_in, l.n_out
             elif l.kind == "conv":
                 d.kind = _abi.LAYER_CONV
                 d.cin, d.cout, d.kh, d.kw, d.sh, d.sw = l.cin, l.cout, l.kh, l.kw, l.sh, l.sw
@@ -112,6 +126,11 @@ def lower(net):
     return out, False
 
 
+def isrecurrent(m):
+    """src/helpers.jl:25-32."""
+    return any(getattr(l, "kind", None) == "lstm" for l in all_layers(m))
+
+
 def all_layers(net):
     return list(net.base) + list(net.val) + list(net.adv) if isinstance(net, DuelingNetwork) else list(net)
 
@@ -122,6 +141,14 @@ def glorot_params(net, seed=1):
     rng = np.random.default_rng(seed)
     parts = []
     for l in all_layers(net):
+        if l.kind == "lstm":
+            h = l.n_out
+            for shp, fi, fo in (((l.n_in, 4 * h), l.n_in, 4 * h), ((h, 4 * h), h, 4 * h)):
+                parts.append(((rng.random(shp, dtype=np.float32) - np.float32(0.5)) * np.sqrt(np.float32(24.0) / np.float32(fi + fo))).astype(np.float32).reshape(-1))
+            b = np.zeros(4 * h, np.float32)
+            b[h:2 * h] = 1.0        # Flux LSTMCell: forget-gate bias initialised to 1
+            parts += [b, np.zeros(h, np.float32), np.zeros(h, np.float32)]
+            continue
         wshape, bshape = l.shapes()
         fi, fo = l.fans()
         parts.append(((rng.random(wshape, dtype=np.float32) - np.float32(0.5)) * np.sqrt(np.float32(24.0) / np.float32(fi + fo))).astype(np.float32).reshape(-1))

@@ -91,6 +91,58 @@ class HIPReplayBuffer:
         return s, a, r, sp, done, idx, w
 
 
+class HIPEpisodeReplayBuffer:
+    """EpisodeReplayBuffer (src/episode_replay.jl:3-95) whose episode storage lives in HBM (engine-owned)."""
+
+    def __init__(self, engine):
+        self.e = engine
+
+    @property
+    def batch_size(self):
+        return self.e.B
+
+    def max_size(self):
+        return self.e.episode_count()[1]
+
+    def is_full(self):
+        cur, cap = self.e.episode_count()
+        return cur == cap
+
+    def add_exp(self, s, a, r, sp, done, td_err=None):
+        """add_exp!(r::EpisodeReplayBuffer, exp) (:46-52): the episode is stored when done (truncated ones keep growing)."""
+        self.e.episode_add(s, a, r, sp, done)
+
+    def add_episode(self):
+        self.e.episode_commit()
+
+
+def generate_episode(replay, env, max_steps=100, rng=None):
+    """src/episode_replay.jl:109-130: one random rollout (n=1 stream), stored whether or not it terminated."""
+    rng = rng if rng is not None else np.random.default_rng(0)
+    env.reset()
+    o = env.observe()
+    done, step = False, 1
+    while not done and step < max_steps:
+        a = rng.integers(0, env.n_actions, env.n)
+        rew = env.act(a)
+        op = env.observe()
+        done = bool(env.terminated()[0])
+        replay.e.episode_add(o[:1], a[:1].astype(np.int32), rew[:1], op[:1], np.array([done], np.uint8))   # done => the engine stores the episode (add_exp!)
+        o = op
+        step += 1
+    if not done:
+        replay.add_episode()       # add_episode!(r, ep) for a rollout cut at max_steps (:100-101)
+
+
+def populate_episode_replay(replay, env, max_pop=None, max_steps=100, rng=None):
+    """src/episode_replay.jl:97-107."""
+    max_pop = replay.max_size() if max_pop is None else max_pop
+    for _ in range(max_pop - replay.e.episode_count()[0]):
+        generate_episode(replay, env, max_steps=max_steps, rng=rng)
+    if replay.e.episode_count()[0] < replay.batch_size:
+        raise DQNError("AssertionError: r._curr_size >= r.batch_size")
+
+
 def populate_replay_buffer(replay: HIPReplayBuffer, env, max_pop=None, max_steps=100, rng=None):
     """...replay.jl:106-134: random policy, priority = |r|, episodes cut at max_steps."""
     rng = rng if rng is not None else np.random.default_rng(0)
@@ -133,7 +185,7 @@ class NNPolicy(AbstractNNPolicy):
         return self.engine.get_params(_abi.NET_ONLINE)
 
     def resetstate(self):
-        pass  # feed-forward networks carry no hidden state (Flux.reset! is a no-op for them)
+        self.engine.reset_state()      # Flux.reset!(qnetwork): Recur state <- state0 (no-op for feed-forward networks)
 
     def actionmap(self):
         return self.action_map
@@ -226,6 +278,10 @@ class DeepQLearningSolver:
 
 def initialize_replay_buffer(solver, env, engine):
     """src/solver.jl:180-189: buffer defaults alpha=0.6 beta=0.4 eps=1e-3 are used whatever the solver says."""
+    if solver.recurrence:
+        replay = HIPEpisodeReplayBuffer(engine)                      # EpisodeReplayBuffer(env, buffer_size, batch_size, trace_length), :183
+        populate_episode_replay(replay, env, max_pop=solver.train_start, rng=solver.rng)
+        return replay
     replay = HIPReplayBuffer(engine)
     populate_replay_buffer(replay, env, max_pop=solver.train_start, rng=solver.rng)
     return replay
@@ -238,7 +294,7 @@ def make_engine(pkg_engine_cls, solver, env, net, discount):
     hp = _abi.default_hparams(batch_size=solver.batch_size, n_actions=env.n_actions, obs_c=c, obs_h=h, obs_w=w,
                               obs_dtype=solver.obs_dtype, learning_rate=solver.learning_rate, gamma=float(discount),
                               double_q=int(solver.double_q), dueling=int(dueling), prioritized_replay=int(solver.prioritized_replay),
-                              buffer_size=solver.buffer_size, seed=solver.seed)
+                              buffer_size=solver.buffer_size, seed=solver.seed, recurrence=int(solver.recurrence), trace_length=solver.trace_length)
     return pkg_engine_cls(layers, hp, device=solver.device)
 
 
@@ -246,8 +302,8 @@ def solve(solver: DeepQLearningSolver, env, engine_cls=None, init_seed=1):
     """POMDPs.solve(solver, env) (src/solver.jl:40-57)."""
     if engine_cls is None:
         from . import Engine as engine_cls
-    if solver.recurrence:
-        raise DQNError("DeepQLearningError: recurrence=true (DRQN, src/solver.jl:239-287) is not built in this round")
+    if nn.isrecurrent(solver.qnetwork) and not solver.recurrence:
+        raise DQNError("DeepQLearningError: you passed in a recurrent model but recurrence is set to false")   # src/solver.jl:45-47
     action_map = list(range(env.n_actions))
     net = nn.create_dueling_network(solver.qnetwork) if solver.dueling else solver.qnetwork
     engine = make_engine(engine_cls, solver, env, net, getattr(env, "discount", 1.0))
@@ -261,6 +317,8 @@ def solve(solver: DeepQLearningSolver, env, engine_cls=None, init_seed=1):
 def batch_train(solver, env, policy, optimizer, target_q, replay, discount=None):
     """batch_train!(solver, env, policy, optimizer, target_q, replay) -> (loss_val, grad_norm) (src/solver.jl:191-236).
     optimizer / target_q live inside the engine; the arguments are kept for signature parity."""
+    if isinstance(replay, HIPEpisodeReplayBuffer):                    # dispatch on the replay type, src/solver.jl:239-246
+        return policy.engine.train_step_drqn()
     loss, gn = policy.engine.train_step(want_td=False)
     return loss, gn
 
@@ -301,8 +359,11 @@ def dqn_train(solver, env, policy, replay):
         rew = env.act(act)
         op = env.observe()
         done = env.terminated()
-        td0 = np.abs(rew) if solver.prioritized_replay else np.zeros_like(rew)          # :91-94
-        replay.add_exp(obs, act.astype(np.int32), rew, op, done.astype(np.uint8), td0)
+        if solver.recurrence:
+            replay.add_exp(obs, act.astype(np.int32), rew, op, done.astype(np.uint8))     # :89-90
+        else:
+            td0 = np.abs(rew) if solver.prioritized_replay else np.zeros_like(rew)      # :91-94
+            replay.add_exp(obs, act.astype(np.int32), rew, op, done.astype(np.uint8), td0)
         obs = op
         step += 1
         cur += rew

@@ -64,3 +64,39 @@ def test_gridworld_config1_runs(mods):
     assert policy.actionvalues(np.array([1.0, 1.0], np.float32)).shape == (4,)
     assert policy.action(np.array([9.0, 2.0], np.float32)) in range(4)
     policy.engine.close()
+
+
+def test_testmdp_drqn(mods):
+    """test/runtests.jl:115-129: TestMDP((5,5),1,6), Chain(flattenbatch, LSTM(25,8), Dense(8,4)), recurrence=true, double_q; return >= 0."""
+    pkg, nn, envs, S = mods
+    env = envs.TestMDP((5, 5), 1, 6, n=1, seed=7)
+    model = nn.Chain(nn.flattenbatch, nn.LSTM(25, 8), nn.Dense(8, env.n_actions))
+    max_steps = 4000
+    expl = S.EpsGreedyPolicy(env, S.LinearDecaySchedule(start=1.0, stop=0.01, steps=max_steps / 2), rng=np.random.default_rng(1))
+    solver = S.DeepQLearningSolver(qnetwork=model, max_steps=max_steps, learning_rate=0.005, exploration_policy=expl, eval_freq=2000, num_ep_eval=20,
+                                   log_freq=500, double_q=True, dueling=False, recurrence=True, verbose=False, logdir=None)
+    policy = S.solve(solver, env)
+    tot = 0.0
+    for _ in range(50):
+        env.reset(); policy.resetstate()
+        r, step = 0.0, 0
+        while not env.terminated()[0] and step < 100:
+            r += float(env.act(np.array([policy.action(env.observe()[0])]))[0]); step += 1
+        tot += r
+    assert tot / 50 >= 0.0
+    policy.engine.close()
+
+
+def test_gridworld_ddrqn_dueling(mods):
+    """test/runtests.jl:131-147: SimpleGridWorld, LSTM(2,32) -> Dense(32,4), trace_length 10, dueling + double-Q DRQN runs end to end."""
+    pkg, nn, envs, S = mods
+    env = envs.SimpleGridWorld(n=1, seed=3)
+    model = nn.Chain(nn.flattenbatch, nn.LSTM(2, 32), nn.Dense(32, env.n_actions))
+    expl = S.EpsGreedyPolicy(env, S.LinearDecaySchedule(start=1.0, stop=0.01, steps=1000), rng=np.random.default_rng(2))
+    solver = S.DeepQLearningSolver(qnetwork=model, prioritized_replay=False, max_steps=2000, exploration_policy=expl, learning_rate=0.001, log_freq=500,
+                                   recurrence=True, trace_length=10, double_q=True, dueling=True, verbose=False, logdir=None)
+    policy = S.solve(solver, env)
+    assert policy.actionvalues(np.array([3.0, 4.0], np.float32)).shape == (4,)
+    with pytest.raises(pkg.DQNError, match="recurrent model but recurrence is set to false"):
+        S.solve(S.DeepQLearningSolver(qnetwork=model, exploration_policy=expl, recurrence=False, verbose=False, logdir=None), env)
+    policy.engine.close()
