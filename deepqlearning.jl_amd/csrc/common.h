@@ -205,6 +205,9 @@ bool gemm_dx_eligible(const LayerDev& L, int B, int ldy);
 void launch_gemm_dx(hipStream_t st, const LayerDev& L, int nsrc, const float* const* W, const float* const* dpre, int B, float* out /* dact or partial slabs */,
                     const float* ysrc, int ldy, int act_src);
 
+void launch_gemm_dwdx(hipStream_t st, const LayerDev& Lw, int nprob, const float* const* X, int ldx, const float* const* dpre_w, int B, float* const* out_w,
+                      const LayerDev& Lx, int nsrc, const float* const* W, const float* const* dpre_x, float* out_x, const float* ysrc, int ldy, int act_src);
+
 // (reduce == false leaves split-K partial slabs in `partials` for the caller's batched k_reduce_multi)
 bool mfma_fwd_ok(const LayerDev& L, int ncols);
 bool mfma_dw_ok(const LayerDev& L, int B);

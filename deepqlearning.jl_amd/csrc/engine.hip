@@ -591,6 +591,10 @@ static int build_program(dqn_engine* e) {
         const auto& lv = levels[li];
         std::vector<VTask> pend;
         bool dw_done_sibling = false;   // the level's two sibling layers got their dW from one fused launch
+        struct DwL { bool on = false; LayerDev L; int nprob = 0; const float* X[2]; int ldx = 0; const float* d[2]; float* o[2]; const char* name = ""; } dwl;
+        struct DxL { bool on = false; LayerDev L; int nsrc = 0; const float* W[2]; const float* d[2]; float* out = nullptr; const float* ys = nullptr; int act_src = 0; const char* name = ""; } dxl;
+        auto flush_dw = [&]() { if (!dwl.on) return; const DwL a = dwl; e->prog.push_back({a.name, [=](dqn_engine* en) { launch_gemm_dw(en->stream, a.L, a.nprob, a.X, a.ldx, a.d, B, a.o); }}); dwl.on = false; };
+        auto flush_dx = [&]() { if (!dxl.on) return; const DxL a = dxl; e->prog.push_back({a.name, [=](dqn_engine* en) { launch_gemm_dx(en->stream, a.L, a.nsrc, a.W, a.d, B, a.out, a.ys, ncon, a.act_src); }}); dxl.on = false; };
         for (int k = (int)lv.size() - 1; k >= 0; k--) {
             const int l = lv[k]; const LayerDev L = e->L[l];
             const float* X = L.src < 0 ? e->x0 : e->act_on[L.src]; const int ldx = L.src < 0 ? ld0 : ncon;
@@ -639,14 +643,13 @@ static int build_program(dqn_engine* e) {
                     if (k == (int)lv.size() - 1 && lv.size() == 2 && same_geo(e->L[lv[0]], e->L[lv[1]]) && e->L[lv[0]].dw_kc == e->L[lv[1]].dw_kc) {
                         const LayerDev L0 = e->L[lv[0]]; const int S0 = S;
                         float* part0 = S0 > 1 ? palloc(e, (size_t)S0 * (L0.K + 1) * L0.N) : nullptr;
-                        struct A { const float* X[2]; const float* d[2]; float* o[2]; } a;
-                        a.X[0] = X; a.d[0] = dpre; a.o[0] = dst; a.X[1] = X; a.d[1] = e->dact[lv[0]]; a.o[1] = S0 > 1 ? part0 : grad + L0.w_off;
-                        e->prog.push_back({pname(e, "dw2", L.kind, l), [=](dqn_engine* en) { launch_gemm_dw(en->stream, L, 2, a.X, ldx, a.d, B, a.o); }});
+                        flush_dw(); dwl.on = true; dwl.L = L; dwl.nprob = 2; dwl.ldx = ldx; dwl.name = pname(e, "dw2", L.kind, l);
+                        dwl.X[0] = X; dwl.d[0] = dpre; dwl.o[0] = dst; dwl.X[1] = X; dwl.d[1] = e->dact[lv[0]]; dwl.o[1] = S0 > 1 ? part0 : grad + L0.w_off;
                         if (S0 > 1) { RSeg r; memset(&r, 0, sizeof r); r.part = part0; r.S = S0; r.elems = (unsigned long long)(L0.K + 1) * L0.N; r.mode = 2; r.out = grad + L0.w_off; final_segs.push_back(r); }
                         dw_done_sibling = true;
                     } else if (!(dw_done_sibling && k == 0 && lv.size() == 2)) {
-                        struct A { const float* X[1]; const float* d[1]; float* o[1]; } a; a.X[0] = X; a.d[0] = dpre; a.o[0] = dst;
-                        e->prog.push_back({pname(e, "dw", L.kind, l), [=](dqn_engine* en) { launch_gemm_dw(en->stream, L, 1, a.X, ldx, a.d, B, a.o); }});
+                        flush_dw(); dwl.on = true; dwl.L = L; dwl.nprob = 1; dwl.ldx = ldx; dwl.name = pname(e, "dw", L.kind, l);
+                        dwl.X[0] = dwl.X[1] = X; dwl.d[0] = dwl.d[1] = dpre; dwl.o[0] = dwl.o[1] = dst;
                     }
                 }
                 else if (mf && mfma_dw_ok(L, B)) e->prog.push_back({pname(e, "dw", L.kind, l), [=](dqn_engine* en) { launch_mfma_dw(en->stream, L, X, ldx, dpre, B, grad, part, false); }});
@@ -662,9 +665,8 @@ static int build_program(dqn_engine* e) {
                 // both streams in ONE launch: the kernel accumulates dX_val and dX_adv separately and adds them (val first)
                 if (k == (int)lv.size() - 1) {
                     const LayerDev Lv = e->L[lv[0]], La = e->L[lv[1]];
-                    struct A2 { const float* W[2]; const float* d[2]; } a; a.W[0] = P + Lv.w_off; a.d[0] = e->dact[lv[0]]; a.W[1] = P + La.w_off; a.d[1] = e->dact[lv[1]];
-                    float* out = e->dact[src]; const float* ysrc = e->act_on[src];
-                    e->prog.push_back({pname(e, "dx_join", L.kind, l), [=](dqn_engine* en) { launch_gemm_dx(en->stream, Lv, 2, a.W, a.d, B, out, ysrc, ncon, act_src); }});
+                    flush_dx(); dxl.on = true; dxl.L = Lv; dxl.nsrc = 2; dxl.W[0] = P + Lv.w_off; dxl.d[0] = e->dact[lv[0]]; dxl.W[1] = P + La.w_off; dxl.d[1] = e->dact[lv[1]];
+                    dxl.out = e->dact[src]; dxl.ys = e->act_on[src]; dxl.act_src = act_src; dxl.name = pname(e, "dx_join", L.kind, l);
                 }
                 continue;
             }
@@ -673,11 +675,11 @@ static int build_program(dqn_engine* e) {
             else if (is_join) { addend = e->join_tmp; flush_valu(e, pend, pname(e, "bwd_valu", L.kind, l)); }   // depends on the first stream's dX
             float* part = S > 1 ? palloc(e, (size_t)S * L.in_feat * B) : nullptr;
             if (mf && !addend && gemm_dx_eligible(L, B, ncon)) {
-                struct A1 { const float* W[1]; const float* d[1]; } a; a.W[0] = P + L.w_off; a.d[0] = dpre;
-                float* dst = S > 1 ? part : out; const float* ys = S > 1 ? nullptr : ysrc;
-                e->prog.push_back({pname(e, "dx", L.kind, l), [=](dqn_engine* en) { launch_gemm_dx(en->stream, L, 1, a.W, a.d, B, dst, ys, ncon, act_src); }});
+                flush_dx(); dxl.on = true; dxl.L = L; dxl.nsrc = 1; dxl.W[0] = dxl.W[1] = P + L.w_off; dxl.d[0] = dxl.d[1] = dpre;
+                dxl.out = S > 1 ? part : out; dxl.ys = S > 1 ? nullptr : ysrc; dxl.act_src = act_src; dxl.name = pname(e, "dx", L.kind, l);
+                if (S > 1) flush_dx();   // its partial slabs are reduced right below
             }
-            else if (mf && mfma_dx_ok(L, B, ncon)) e->prog.push_back({pname(e, "dx", L.kind, l), [=](dqn_engine* en) { launch_mfma_dx(en->stream, L, P, dpre, B, out, part, addend, ysrc, ncon, act_src, false); }});
+            else if (mf && L.N >= 16 && mfma_dx_ok(L, B, ncon)) e->prog.push_back({pname(e, "dx", L.kind, l), [=](dqn_engine* en) { launch_mfma_dx(en->stream, L, P, dpre, B, out, part, addend, ysrc, ncon, act_src, false); }});
             else { VTask t; memset(&t, 0, sizeof t); t.kind = 2; t.L = L; t.P = P; t.dpre = dpre; t.B = B; t.S = S; t.kc = dqn_chunk_len(L.N, L.dx_kc); t.out = S > 1 ? part : out; t.addend = addend; t.ysrc = ysrc; t.ldy = ncon; t.act_src = act_src; add_valu(e, pend, t); }
             if (S > 1) {
                 flush_valu(e, pend, pname(e, "bwd_valu", L.kind, l));
@@ -686,6 +688,12 @@ static int build_program(dqn_engine* e) {
             }
         }
         flush_valu(e, pend, pname(e, "bwd_valu", e->L[lv[0]].kind, lv[0]));
+        if (dwl.on && dxl.on) {      // dW and dX of this level in ONE launch
+            const DwL a = dwl; const DxL x = dxl; dwl.on = dxl.on = false;
+            char nm[48]; snprintf(nm, sizeof nm, "%s+%s", a.name, x.name); e->prog_names.push_back(nm); const char* name = e->prog_names.back().c_str();
+            e->prog.push_back({name, [=](dqn_engine* en) { launch_gemm_dwdx(en->stream, a.L, a.nprob, a.X, a.ldx, a.d, B, a.o, x.L, x.nsrc, x.W, x.d, x.out, x.ys, ncon, x.act_src); }});
+        }
+        flush_dw(); flush_dx();
     }
     emit_reduce(e, final_segs, "dw_reduce_all");
     e->prog_post_begin = e->prog.size();

@@ -207,7 +207,7 @@ struct GDwProbs { GDwProb p[2]; };
 constexpr int W_ST = 36;     // LDS row stride (32 samples + 4 pad): 16-B aligned rows, fragment reads at most 2-way conflicted
 
 template <int NT>
-__global__ __launch_bounds__(256) void k_dw_lds(LayerDev L, GDwProbs pr, int nprob, int ldx, int B, int S, int kc) {
+__device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& pr, int nprob, int ldx, int B, int S, int kc, int bid, int nblocks) {
     constexpr int NW = 16 * NT;
     constexpr int BQ = (NW * 8 + 255) / 256;          // float4 per thread for the B tile (1 or 2)
     extern __shared__ float lds[];
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void k_dw_lds(LayerDev L, GDwProbs pr, int npr
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const bool conv = L.kind == DQN_LAYER_CONV;
     const int mrows = (L.K + 63) / 64, ngroups = L.N / NW;
-    int w = xcd_remap(blockIdx.x, gridDim.x);
+    int w = xcd_remap(bid, nblocks);
     const int pi = w % nprob; w /= nprob;
     const int ng = w % ngroups; w /= ngroups;
     const int mr = w % mrows; const int s = w / mrows;
@@ -311,6 +311,10 @@ __global__ __launch_bounds__(256) void k_dw_lds(LayerDev L, GDwProbs pr, int npr
     }
     if (do_bias) out[(size_t)L.K * L.N + n0 + tid] = dbacc;
 }
+template <int NT>
+__global__ __launch_bounds__(256) void k_dw_lds(LayerDev L, GDwProbs pr, int nprob, int ldx, int B, int S, int kc) {
+    dw_lds_body<NT>(L, pr, nprob, ldx, B, S, kc, blockIdx.x, gridDim.x);
+}
 bool gemm_dw_eligible(const LayerDev& L, int B, int ldx) {
     const int KK = L.npos * B, S = dqn_nchunks(KK, L.dw_kc), kc = dqn_chunk_len(KK, L.dw_kc);
     return !(L.N % 16 || B % 32 || ldx % 4 || L.K < 16 || (S > 1 && kc % B));
@@ -342,7 +346,7 @@ struct GDxArgs { GDxSrc src[2]; int nsrc; float* out; const float* ysrc; int ldy
 constexpr int X_SA = 48;     // A tile row stride (32 samples + 16 pad): fragment reads hit banks 16*kq + i
 constexpr int X_SB = 36;     // B tile row stride (32 k + 4 pad)
 
-__global__ __launch_bounds__(256) void k_dx_lds(LayerDev L, GDxArgs A, int B, int S, int kc) {
+__device__ __forceinline__ void dx_lds_body(const LayerDev& L, const GDxArgs& A, int B, int S, int kc, int bid, int nblocks, int by) {
     extern __shared__ float lds[];
     float* As = lds;                                  // [2][32][X_SA]
     float* Bs = lds + 2 * 32 * X_SA;                  // [2][32][X_SB]
@@ -350,8 +354,8 @@ __global__ __launch_bounds__(256) void k_dx_lds(LayerDev L, GDxArgs A, int B, in
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const bool dense = L.kind == DQN_LAYER_DENSE;
     const int ft = wave & 1, mt = wave >> 1;
-    const int b0 = blockIdx.y * 32;
-    int w = xcd_remap(blockIdx.x, gridDim.x);
+    const int b0 = by * 32;
+    int w = xcd_remap(bid, nblocks);
     int f0, s = 0, ip = 0;                            // f0: first feature row (dense) / first input channel (conv)
     const int nfeat = dense ? L.K : L.cin;
     if (dense) { const int ftiles = (L.K + 31) / 32; f0 = (w % ftiles) * 32; s = w / ftiles; }
@@ -443,6 +447,17 @@ __global__ __launch_bounds__(256) void k_dx_lds(LayerDev L, GDxArgs A, int B, in
     }
     *reinterpret_cast<f32x4*>(A.out + (size_t)s * per_s + feat * B + bcol) = v;
 }
+__global__ __launch_bounds__(256) void k_dx_lds(LayerDev L, GDxArgs A, int B, int S, int kc) {
+    dx_lds_body(L, A, B, S, kc, blockIdx.x, gridDim.x, blockIdx.y);
+}
+// dW and dX of one layer are independent given dpre: ONE launch runs both (blocks [0, dw_blocks) do dW, the rest dX), which
+// saves a dispatch and lets the latency-bound dX workgroups share the machine with the dW ones.
+template <int NT>
+__global__ __launch_bounds__(256) void k_dwdx_lds(LayerDev Lw, GDwProbs pr, int nprob, int ldx, int B, int Sw, int kcw, int dw_blocks,
+                                                  LayerDev Lx, GDxArgs A, int Sx, int kcx, int dx_gx) {
+    if ((int)blockIdx.x < dw_blocks) dw_lds_body<NT>(Lw, pr, nprob, ldx, B, Sw, kcw, blockIdx.x, dw_blocks);
+    else { const int r = blockIdx.x - dw_blocks; dx_lds_body(Lx, A, B, Sx, kcx, r % dx_gx, dx_gx, r / dx_gx); }
+}
 bool gemm_dx_eligible(const LayerDev& L, int B, int ldy) {
     const bool dense = L.kind == DQN_LAYER_DENSE;
     const int S = dense ? dqn_nchunks(L.N, L.dx_kc) : 1, kc = dqn_chunk_len(L.N, L.dx_kc);
@@ -460,4 +475,24 @@ void launch_gemm_dx(hipStream_t st, const LayerDev& L, int nsrc, const float* co
     const int gx = dense ? ((L.K + 31) / 32) * S : (L.cin / 32) * L.ih * L.iw;
     const size_t lds = (size_t)(2 * 32 * X_SA + 2 * 32 * X_SB) * 4 + 256 * 4;
     hipLaunchKernelGGL(k_dx_lds, dim3(gx, B / 32), dim3(256), lds, st, L, a, B, S, kc);
+}
+
+void launch_gemm_dwdx(hipStream_t st, const LayerDev& Lw, int nprob, const float* const* X, int ldx, const float* const* dpre_w, int B, float* const* out_w,
+                      const LayerDev& Lx, int nsrc, const float* const* W, const float* const* dpre_x, float* out_x, const float* ysrc, int ldy, int act_src) {
+    const int KK = Lw.npos * B, Sw = dqn_nchunks(KK, Lw.dw_kc), kcw = dqn_chunk_len(KK, Lw.dw_kc);
+    GDwProbs pr;
+    for (int i = 0; i < 2; i++) { const int j = i < nprob ? i : 0; pr.p[i].X = X[j]; pr.p[i].dpre = dpre_w[j]; pr.p[i].out = out_w[j]; }
+    const int NT = Lw.N % 64 == 0 ? 4 : (Lw.N % 32 == 0 ? 2 : 1);
+    const int dw_blocks = ((Lw.K + 63) / 64) * (Lw.N / (16 * NT)) * Sw * nprob;
+    const bool dense = Lx.kind == DQN_LAYER_DENSE;
+    const int Sx = dense ? dqn_nchunks(Lx.N, Lx.dx_kc) : 1, kcx = dqn_chunk_len(Lx.N, Lx.dx_kc);
+    GDxArgs a; a.nsrc = nsrc; a.out = out_x; a.ysrc = ysrc; a.ldy = ldy; a.act_src = act_src;
+    for (int i = 0; i < 2; i++) { const int j = i < nsrc ? i : 0; a.src[i].W = W[j]; a.src[i].dpre = dpre_x[j]; }
+    const int gx = dense ? ((Lx.K + 31) / 32) * Sx : (Lx.cin / 32) * Lx.ih * Lx.iw;
+    const size_t lds_w = (size_t)(2 * 64 * W_ST + 2 * 16 * NT * W_ST) * 4, lds_x = (size_t)(2 * 32 * X_SA + 2 * 32 * X_SB) * 4 + 256 * 4;
+    const size_t lds = lds_w > lds_x ? lds_w : lds_x;
+    const int grid = dw_blocks + gx * (B / 32);
+    if (NT == 4) hipLaunchKernelGGL((k_dwdx_lds<4>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx);
+    else if (NT == 2) hipLaunchKernelGGL((k_dwdx_lds<2>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx);
+    else hipLaunchKernelGGL((k_dwdx_lds<1>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx);
 }

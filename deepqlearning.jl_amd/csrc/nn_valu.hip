@@ -128,6 +128,25 @@ __device__ __forceinline__ void valu_dw_body(const LayerDev& L, const float* __r
     if (L.kind == DQN_LAYER_CONV && k < L.K) { const int khw = L.kh * L.kw; const int ci = k / khw, ky = (k / L.kw) % L.kh, kx = k % L.kw; koff = (ci * L.ih + ky) * L.iw + kx; }
     float acc = 0.0f;
     int pos = j0 / B, b = j0 % B;
+    if (L.kind != DQN_LAYER_CONV) {      // dense: one "position"; operands are two contiguous rows -> 16 loads in flight, chain order unchanged
+        const float* dr = dpre + (size_t)n * B; const float* xr = k < L.K ? X + (size_t)k * ldx : nullptr;
+        int j = j0;
+        for (; j + 8 <= j1; j += 8) {
+            float dv[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { dv[u] = dr[j + u]; xv[u] = xr ? xr[j + u] : 1.0f; }
+            if (xr) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc = fmaf(xv[u], dv[u], acc);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc = acc + dv[u];
+            }
+        }
+        for (; j < j1; j++) { if (xr) acc = fmaf(xr[j], dr[j], acc); else acc = acc + dr[j]; }
+        out[(size_t)s * per_s + e] = acc;
+        return;
+    }
     for (int j = j0; j < j1; j++) {
         const float d = dpre[((size_t)n * L.npos + pos) * B + b];
         if (k < L.K) {
@@ -252,15 +271,26 @@ __device__ __forceinline__ void q_column_h(int nA, int dueling, const HeadSrc& v
     const float mean = sum / (float)nA;
     for (int a = 0; a < nA; a++) q[a] = (v + araw[a]) - mean;
 }
-__device__ __forceinline__ void q_from_lds(int nA, int dueling, const float* v, const float* a, int ld, int col, float* q, float* vout, float* araw) {
-    for (int i = 0; i < nA; i++) araw[i] = a[i * ld + col];
-    if (!dueling) { for (int i = 0; i < nA; i++) q[i] = araw[i]; *vout = 0.0f; return; }
+// NMAX is a compile-time bound on n_actions so that the per-lane Q arrays live in registers (runtime-bounded loops over a
+// local array put it in scratch: 784 B/lane and ~8 us of this single-workgroup kernel before the change)
+template <int NMAX>
+__device__ __forceinline__ void q_from_lds(int nA, int dueling, const float* v, const float* a, int ld, int col, float (&q)[NMAX], float* vout, float (&araw)[NMAX]) {
+#pragma unroll
+    for (int i = 0; i < NMAX; i++) araw[i] = i < nA ? a[i * ld + col] : 0.0f;
+    if (!dueling) {
+#pragma unroll
+        for (int i = 0; i < NMAX; i++) q[i] = araw[i];
+        *vout = 0.0f; return;
+    }
     const float vv = v[col]; *vout = vv;
     float sum = araw[0];
-    for (int i = 1; i < nA; i++) sum = sum + araw[i];
+#pragma unroll
+    for (int i = 1; i < NMAX; i++) if (i < nA) sum = sum + araw[i];
     const float mean = sum / (float)nA;
-    for (int i = 0; i < nA; i++) q[i] = (vv + araw[i]) - mean;
+#pragma unroll
+    for (int i = 0; i < NMAX; i++) q[i] = (vv + araw[i]) - mean;
 }
+template <int NMAX>
 __global__ __launch_bounds__(1024) void k_td(TdArgs A) {
     extern __shared__ float hl[];   // [B] Huber terms | [B] long long indices | head outputs: on_val[ncon] on_adv[nA][ncon] tg_val[B] tg_adv[nA][B]
     const int B = A.B, nA = A.nA, ncon = A.ncon;
@@ -288,25 +318,35 @@ __global__ __launch_bounds__(1024) void k_td(TdArgs A) {
         const float p = A.tree[A.cap2 + j] / total; const float xw = (float)size * p;
         const float w = (float)pow((double)xw, -(double)A.prio_beta);     // IS weight, ...replay.jl:101-102
         A.w_is[b] = w;
-        float q[DQN_MAX_ACTIONS], qt[DQN_MAX_ACTIONS], araw[DQN_MAX_ACTIONS], vraw;
-        q_from_lds(nA, A.dueling, hv_tg_val, hv_tg_adv, B, b, qt, &vraw, araw);
-        for (int a = 0; a < nA; a++) A.q_tg_sp[(size_t)b * nA + a] = qt[a];
+        float q[NMAX], qt[NMAX], araw[NMAX], vraw;
+        q_from_lds<NMAX>(nA, A.dueling, hv_tg_val, hv_tg_adv, B, b, qt, &vraw, araw);
+#pragma unroll
+        for (int a = 0; a < NMAX; a++) if (a < nA) A.q_tg_sp[(size_t)b * nA + a] = qt[a];
         int best = 0; float qsp;
         if (A.double_q) {
-            q_from_lds(nA, A.dueling, hv_on_val, hv_on_adv, ncon, B + b, q, &vraw, araw);
-            for (int a = 0; a < nA; a++) A.q_on_sp[(size_t)b * nA + a] = q[a];
-            for (int a = 1; a < nA; a++) if (q[a] > q[best]) best = a;
+            q_from_lds<NMAX>(nA, A.dueling, hv_on_val, hv_on_adv, ncon, B + b, q, &vraw, araw);
+#pragma unroll
+            for (int a = 0; a < NMAX; a++) if (a < nA) A.q_on_sp[(size_t)b * nA + a] = q[a];
+            float bq = q[0];
+#pragma unroll
+            for (int a = 1; a < NMAX; a++) if (a < nA && q[a] > bq) { bq = q[a]; best = a; }
         } else {
-            for (int a = 0; a < nA; a++) A.q_on_sp[(size_t)b * nA + a] = qt[a];
-            for (int a = 1; a < nA; a++) if (qt[a] > qt[best]) best = a;
+#pragma unroll
+            for (int a = 0; a < NMAX; a++) if (a < nA) A.q_on_sp[(size_t)b * nA + a] = qt[a];
+            float bq = qt[0];
+#pragma unroll
+            for (int a = 1; a < NMAX; a++) if (a < nA && qt[a] > bq) { bq = qt[a]; best = a; }
         }
-        qsp = qt[0]; for (int a = 1; a < nA; a++) if (a == best) qsp = qt[a];
+        qsp = qt[0];
+#pragma unroll
+        for (int a = 1; a < NMAX; a++) if (a == best) qsp = qt[a];
         A.best[b] = best;
         const float t1 = 1.0f - dn; const float t2 = t1 * A.gamma; const float t3 = t2 * qsp; const float y = rew + t3;
         A.ytarget[b] = y;
-        q_from_lds(nA, A.dueling, hv_on_val, hv_on_adv, ncon, b, q, &vraw, araw);
+        q_from_lds<NMAX>(nA, A.dueling, hv_on_val, hv_on_adv, ncon, b, q, &vraw, araw);
         float qsa = q[0];
-        for (int a = 0; a < nA; a++) { A.q_on_s[(size_t)b * nA + a] = q[a]; if (a == act) qsa = q[a]; }
+#pragma unroll
+        for (int a = 0; a < NMAX; a++) if (a < nA) { A.q_on_s[(size_t)b * nA + a] = q[a]; if (a == act) qsa = q[a]; }
         const float td = qsa - y; A.td[b] = td;
         const float x = w * td; const float ab = fabsf(x); const float qd = ab < 1.0f ? ab : 1.0f; const float lin = ab - qd;
         hl[b] = (0.5f * qd) * qd + lin;
@@ -315,9 +355,12 @@ __global__ __launch_bounds__(1024) void k_td(TdArgs A) {
         if (A.dueling) {
             A.d_val[b] = dact_f(g, vraw, A.on_val.act);
             const float gm = g / (float)nA;
-            for (int a = 0; a < nA; a++) A.d_adv[(size_t)a * B + b] = dact_f((a == act ? g : 0.0f) - gm, araw[a], A.on_adv.act);
-        } else
-            for (int a = 0; a < nA; a++) A.d_adv[(size_t)a * B + b] = dact_f(a == act ? g : 0.0f, araw[a], A.on_adv.act);
+#pragma unroll
+            for (int a = 0; a < NMAX; a++) if (a < nA) A.d_adv[(size_t)a * B + b] = dact_f((a == act ? g : 0.0f) - gm, araw[a], A.on_adv.act);
+        } else {
+#pragma unroll
+            for (int a = 0; a < NMAX; a++) if (a < nA) A.d_adv[(size_t)a * B + b] = dact_f(a == act ? g : 0.0f, araw[a], A.on_adv.act);
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -332,7 +375,9 @@ __global__ __launch_bounds__(1024) void k_td(TdArgs A) {
 void launch_td(hipStream_t st, const TdArgs& a) {
     int bs = ((a.B + 63) / 64) * 64; if (bs < 512) bs = 512; if (bs > 1024) bs = 1024;
     const size_t lds = (size_t)a.B * sizeof(float) + (size_t)(1 + a.nA) * (a.ncon + a.B) * sizeof(float);
-    hipLaunchKernelGGL(k_td, dim3(1), dim3(bs), lds, st, a);
+    if (a.nA <= 8) hipLaunchKernelGGL((k_td<8>), dim3(1), dim3(bs), lds, st, a);
+    else if (a.nA <= 32) hipLaunchKernelGGL((k_td<32>), dim3(1), dim3(bs), lds, st, a);
+    else hipLaunchKernelGGL((k_td<DQN_MAX_ACTIONS>), dim3(1), dim3(bs), lds, st, a);
 }
 
 // Q columns for the policy path (src/policy.jl:38-64): q_out[n][nA], argmax (first max)
@@ -371,26 +416,33 @@ __global__ __launch_bounds__(256) void k_adam(size_t P, float* __restrict__ p, f
     if (bid == 0 && threadIdx.x == 0) { state->bp[slot ^ 1][0] = bp1 * b1; state->bp[slot ^ 1][1] = bp2 * b2; }
     const double c1 = 1.0 - bp1, c2 = 1.0 - bp2;
     float gmax = 0.0f;
-    for (size_t i = (size_t)bid * blockDim.x + threadIdx.x; i < P; i += (size_t)nblk * blockDim.x) {
-        float gi = g[i];
+    auto upd = [&](float gi, float& mi, float& vi, float& pi) {
         if (gscale != 1.0f) gi = gi * gscale;
         gmax = fmaxf(gmax, fabsf(gi));
         float mn, vn, dl;
         if (f64mode) {
             const double gd = (double)gi;
-            const double t1 = b1 * (double)m[i]; const double t2 = (1.0 - b1) * gd; mn = (float)(t1 + t2);
-            const double u1 = b2 * (double)v[i]; const double u2 = (1.0 - b2) * gd; const double u3 = u2 * gd; vn = (float)(u1 + u3);
+            const double t1 = b1 * (double)mi; const double t2 = (1.0 - b1) * gd; mn = (float)(t1 + t2);
+            const double u1 = b2 * (double)vi; const double u2 = (1.0 - b2) * gd; const double u3 = u2 * gd; vn = (float)(u1 + u3);
             const double mh = (double)mn / c1; const double vh = (double)vn / c2; const double den = sqrt(vh) + eps; const double q1 = mh / den;
             dl = (float)(q1 * (double)lr);
         } else {
             const float fb1 = (float)b1, fb2 = (float)b2;
-            const float t1 = fb1 * m[i]; const float t2 = (1.0f - fb1) * gi; mn = t1 + t2;
-            const float u1 = fb2 * v[i]; const float u2 = (1.0f - fb2) * gi; const float u3 = u2 * gi; vn = u1 + u3;
+            const float t1 = fb1 * mi; const float t2 = (1.0f - fb1) * gi; mn = t1 + t2;
+            const float u1 = fb2 * vi; const float u2 = (1.0f - fb2) * gi; const float u3 = u2 * gi; vn = u1 + u3;
             const float mh = mn / (1.0f - (float)bp1); const float vh = vn / (1.0f - (float)bp2); const float den = sqrtf(vh) + (float)eps; const float q1 = mh / den;
             dl = q1 * lr;
         }
-        m[i] = mn; v[i] = vn; p[i] = p[i] - dl;
+        mi = mn; vi = vn; pi = pi - dl;
+    };
+    // 16-B accesses: P is a multiple of 4 and every array is 16-B aligned (internal parameter layout)
+    const size_t P4 = P / 4;
+    for (size_t i = (size_t)bid * blockDim.x + threadIdx.x; i < P4; i += (size_t)nblk * blockDim.x) {
+        const float4 g4 = reinterpret_cast<const float4*>(g)[i]; float4 m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i], p4 = reinterpret_cast<float4*>(p)[i];
+        upd(g4.x, m4.x, v4.x, p4.x); upd(g4.y, m4.y, v4.y, p4.y); upd(g4.z, m4.z, v4.z, p4.z); upd(g4.w, m4.w, v4.w, p4.w);
+        reinterpret_cast<float4*>(m)[i] = m4; reinterpret_cast<float4*>(v)[i] = v4; reinterpret_cast<float4*>(p)[i] = p4;
     }
+    for (size_t i = P4 * 4 + (size_t)bid * blockDim.x + threadIdx.x; i < P; i += (size_t)nblk * blockDim.x) upd(g[i], m[i], v[i], p[i]);
     // wave max (64 lanes) then one value per block; max is order-independent, so this is exact
     for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off));
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = gmax;
