@@ -129,7 +129,10 @@ def main():
     pkg.nn = importlib.import_module(pkg.__name__ + ".nn")
     pkg.envs = importlib.import_module(pkg.__name__ + ".envs")
     par = importlib.import_module(pkg.__name__ + ".parallel")
-    group = par.Group(backend="nccl", device=torch.device("cuda", local_rank))   # "nccl" IS RCCL on ROCm
+    # control plane (rendezvous, 128-byte id broadcast, barriers, max-over-ranks timer) over gloo on the loopback interface;
+    # the DATA path -- the per-step gradient all-reduce -- is RCCL over xGMI inside the engine (dqn_comm_init), on its stream.
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    group = par.Group(backend="gloo")
 
     eng, layers, hp, net, params, env = build_workload(pkg, args, rank, local_rank)
     group.attach_engine(pkg, eng)          # RCCL communicator inside the engine (gradient all-reduce on its stream)

@@ -4,6 +4,7 @@
 // C ABI: include/dqn_mi355x.h.  No CPU fallback exists: every entry point that computes needs the HIP device.
 #include <dlfcn.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -73,7 +74,7 @@ struct dqn_engine {
     // graphs: [0] = step with sampling, [1] = step on given indices; with a communicator the step is cut in two
     hipGraphExec_t g_full[2] = {nullptr, nullptr}, g_pre[2] = {nullptr, nullptr}, g_post = nullptr;
     // comm
-    void* comm = nullptr; int rank = 0, world = 1;
+    void* comm = nullptr; int rank = 0, world = 1; bool force_comm = false;   // force_comm: run the all-reduce path even at world == 1 (tests)
     // DRQN (recurrence = true): column count per sequence set Bc = T*B (B otherwise); EpisodeReplayBuffer storage; LSTM workspaces
     int Bc = 0, T = 1; long long ep_cap = 0, ep_size = 0, ep_widx = 0, ep_cur_len = 0; std::vector<int> ep_len_host;
     float *ep_s = nullptr, *ep_sp = nullptr, *ep_r = nullptr; int* ep_a = nullptr; unsigned char* ep_done = nullptr; int* ep_len = nullptr;
@@ -734,7 +735,7 @@ static int allreduce_grads(dqn_engine* e) {
 static int run_step(dqn_engine* e, bool sample) {
     if (build_program(e)) return -1;
     const int gi = sample ? 0 : 1;
-    if (e->world > 1) {
+    if (e->world > 1 || (e->comm && e->force_comm)) {
         if (e->hp.use_graph && !e->profiling) {
             if (!e->g_pre[gi] && capture(e, sample, PH_PRE, &e->g_pre[gi])) return -1;
             if (!e->g_post && capture(e, sample, PH_POST, &e->g_post)) return -1;
@@ -973,7 +974,7 @@ extern "C" int dqn_comm_init(dqn_engine_t* e, const void* id128, int rank, int w
     Id128 id; memcpy(id.b, id128, 128);
     const int rc = g_rccl.CommInitRank(&e->comm, world, id, rank);
     if (rc) return fail("ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
-    e->rank = rank; e->world = world; drop_graphs(e); return 0;
+    e->rank = rank; e->world = world; e->force_comm = getenv("DQN_FORCE_ALLREDUCE") != nullptr; drop_graphs(e); return 0;
 }
 
 // ---------------------------------------------------------------- misc

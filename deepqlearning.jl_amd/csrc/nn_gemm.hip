@@ -107,12 +107,19 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     auto compute = [&](int buf) {
         const float* Ab = As + buf * F_KT * F_SA + 16 * wave + l15;
         const float* Bb = Bs + buf * F_KT * SB + l15;
+        // all fragments of the K tile are read first (one LDS latency per tile instead of one per MFMA pair), then the
+        // 8*NT MFMAs issue back to back; chain order per accumulator is still st = 0..7
+        float af[F_KT / 4], bf[F_KT / 4][NT];
 #pragma unroll
         for (int st = 0; st < F_KT / 4; st++) {
-            const float a = Ab[(4 * st + kq) * F_SA];
+            af[st] = Ab[(4 * st + kq) * F_SA];
 #pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = MFMA(a, Bb[(4 * st + kq) * SB + 16 * t], acc[t]);
+            for (int t = 0; t < NT; t++) bf[st][t] = Bb[(4 * st + kq) * SB + 16 * t];
         }
+#pragma unroll
+        for (int st = 0; st < F_KT / 4; st++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = MFMA(af[st], bf[st][t], acc[t]);
     };
     // prefetch distance 2: tile kt computes from LDS while tile kt+1 lands in one register stage and tile kt+2's loads
     // are issued into the other; one barrier per K tile.
@@ -269,12 +276,17 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
     auto compute = [&](int buf) {
         const float* Ab = As + (buf * 64 + 16 * wave + l15) * W_ST + kq;
         const float* Bb = Bs + (buf * NW + l15) * W_ST + kq;
+        float af[8], bf[8][NT];
 #pragma unroll
         for (int st = 0; st < 8; st++) {
-            const float a = Ab[4 * st];
+            af[st] = Ab[4 * st];
 #pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = MFMA(a, Bb[16 * t * W_ST + 4 * st], acc[t]);
+            for (int t = 0; t < NT; t++) bf[st][t] = Bb[16 * t * W_ST + 4 * st];
         }
+#pragma unroll
+        for (int st = 0; st < 8; st++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = MFMA(af[st], bf[st][t], acc[t]);
         if (do_bias) {
             const float* br = Bs + (buf * NW + tid) * W_ST;
 #pragma unroll
@@ -408,12 +420,15 @@ __device__ __forceinline__ void dx_lds_body(const LayerDev& L, const GDxArgs& A,
     auto compute = [&](int buf, bool second) {
         const float* Ab = As + buf * 32 * X_SA + 16 * mt + l15;
         const float* Bb = Bs + (buf * 32 + 16 * ft + l15) * X_SB + kq;
+        float af[8], bf[8];
+#pragma unroll
+        for (int st = 0; st < 8; st++) { af[st] = Ab[(4 * st + kq) * X_SA]; bf[st] = Bb[4 * st]; }
         if (!second) {
 #pragma unroll
-            for (int st = 0; st < 8; st++) acc0 = MFMA(Ab[(4 * st + kq) * X_SA], Bb[4 * st], acc0);
+            for (int st = 0; st < 8; st++) acc0 = MFMA(af[st], bf[st], acc0);
         } else {
 #pragma unroll
-            for (int st = 0; st < 8; st++) acc1 = MFMA(Ab[(4 * st + kq) * X_SA], Bb[4 * st], acc1);
+            for (int st = 0; st < 8; st++) acc1 = MFMA(af[st], bf[st], acc1);
         }
     };
     if (total > 0) {

@@ -6,8 +6,9 @@ all-reduced (SUM) over RCCL inside the engine (dqn_comm_init / ncclAllReduce on 
 single-GPU step on the concatenated batch of B*world with the loss averaged (tests/test_parallel_cpu.py checks that
 equivalence with the CPU twin over gloo).  The reference has no distributed code at all.
 
-This module is the host-side plumbing only (torch.distributed is used for rendezvous, the 128-byte RCCL id broadcast,
-barriers and the max-over-ranks timer); the data path collective never touches torch.
+This module is the host-side plumbing only (torch.distributed -- gloo by default, so that the engine's communicator is
+the only RCCL instance in the process -- is used for rendezvous, the 128-byte RCCL id broadcast, barriers and the
+max-over-ranks timer); the data path collective never touches torch.
 """
 from __future__ import annotations
 

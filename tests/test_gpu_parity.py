@@ -194,3 +194,20 @@ def test_errors_are_loud(pkg):
         gpu.train_step()
     with pytest.raises(pkg.DQNError):
         gpu.set_params(np.zeros(3, np.float32))
+
+
+def test_rccl_path_world1_matches_plain(pkg, monkeypatch):
+    """The data-parallel code path (dlopen'ed RCCL communicator, step graph cut in two around ncclAllReduce on the engine
+    stream) forced on at world_size 1: an all-reduce over one rank is the identity, so results must equal the plain path."""
+    monkeypatch.setenv("DQN_FORCE_ALLREDUCE", "1")
+    net = small_conv_dueling()
+    a, cpu, _ = make_pair(pkg, net, 16)
+    b, _, _ = make_pair(pkg, net, 16)
+    fill((a, b, cpu), net, 64); set_same_params((a, b, cpu), net)
+    a.comm_init(pkg.comm_unique_id(), 0, 1)
+    for _ in range(4):
+        ra, rb, rc = a.train_step(), b.train_step(), cpu.train_step()
+        assert ra[0] == rb[0] == rc[0] and ra[1] == rb[1]
+        np.testing.assert_array_equal(ra[2], rb[2])
+    np.testing.assert_array_equal(a.get_params(0), b.get_params(0))
+    np.testing.assert_array_equal(a.get_params(0), cpu.get_params(0))
