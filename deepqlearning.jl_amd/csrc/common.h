@@ -109,6 +109,9 @@ __device__ __forceinline__ void prio_update_block(int n, long long cap2, const l
     }
 }
 struct PrioArgs { int n; long long cap2; const long long* idx; const float* td; float eps, alpha; float* tree; };
+// deferred dW split-K slabs reduced INSIDE the Adam launch by dedicated blocks (single-GPU path): element ranges [beg, end) of the
+// gradient vector, each the ascending sum of S slabs
+struct AdamSegs { int n; unsigned long long beg[8], end[8]; const float* part[8]; int S[8]; unsigned blocks; };
 
 // ---- kernel launchers (defined in the .hip files; all enqueue on `st` and never synchronise)
 // a head tensor as seen by k_td: finished activation (S <= 1) or split-K partial slabs to be reduced on the fly
@@ -160,7 +163,7 @@ void launch_valu_dx(hipStream_t st, const LayerDev& L, const float* P, const flo
 void launch_td(hipStream_t st, const TdArgs& a);
 int adam_blocks(size_t P);
 void launch_adam(hipStream_t st, size_t P, float* p, float* m, float* v, const float* g, StepState* state, float* gmax_part, int f64mode,
-                 float lr, double b1, double b2, double eps, float gscale, const PrioArgs& prio);
+                 float lr, double b1, double b2, double eps, float gscale, const PrioArgs& prio, const AdamSegs& segs, float* g_out);
 void launch_q_columns(hipStream_t st, int n, int nA, int dueling, const float* val, const float* adv, float* q_out /*[n][nA]*/, int* argmax_out);
 void launch_convert_params(hipStream_t st, const LayerDev* layers_dev, int nl, const float* src, float* dst, int to_internal, size_t P_ext);
 

@@ -86,6 +86,7 @@ struct dqn_engine {
     // static launch program
     struct Step { const char* name; std::function<void(dqn_engine*)> fn; };
     std::vector<Step> prog; size_t prog_post_begin = 0; bool prog_built = false, step_sampled = true;
+    AdamSegs adam_segs; long final_reduce_step = -1;   // deferred dW slabs: reduced inside k_adam unless a communicator needs the materialised gradient
     std::vector<void*> prog_allocs; std::vector<std::string> prog_names;
     // profiling
     bool profiling = false; std::vector<ProfEntry> prof;
@@ -251,7 +252,7 @@ extern "C" int dqn_engine_create(const dqn_layer_desc* layers, int n_layers, con
         DM(e->ep_idx, B); DM(e->ep_start, B); DM(e->r_a, Bc); DM(e->r_r, Bc); DM(e->r_done, Bc); DM(e->r_mask, Bc);
     }
     e->partials_elems = pmax; DM(e->partials, 2 * pmax);   // second half: the target net's split-K partials (fused on+tg launches)
-    DM(e->join_tmp, jmax); DM(e->gmax_part, adam_blocks(e->Pint));
+    DM(e->join_tmp, jmax); DM(e->gmax_part, adam_blocks(e->Pint) + 4096); HIPCHK(hipMemset(e->gmax_part, 0, (adam_blocks(e->Pint) + 4096) * 4));
     DM(e->w_is, B); DM(e->td, Bc); DM(e->q_on_s, (size_t)B * e->nA); DM(e->q_on_sp, (size_t)B * e->nA); DM(e->q_tg_sp, (size_t)B * e->nA);
     DM(e->ytarget, B); DM(e->best, B);
     DM(e->gb_rows, (size_t)B * e->E); DM(e->gb_r, B); DM(e->gb_done, B); DM(e->gb_w, B); DM(e->gb_a, B); DM(e->gb_idx, B);
@@ -696,12 +697,24 @@ static int build_program(dqn_engine* e) {
         }
         flush_dw(); flush_dx();
     }
+    memset(&e->adam_segs, 0, sizeof e->adam_segs);
+    {
+        bool ok = !final_segs.empty() && final_segs.size() <= 8; unsigned long long tot = 0;
+        for (auto& r : final_segs) { const unsigned long long beg = (unsigned long long)(r.out - e->grad); ok = ok && beg % 4 == 0 && r.elems % 4 == 0 && r.S2 == 0; }
+        if (ok) {
+            for (auto& r : final_segs) { const int q = e->adam_segs.n++; e->adam_segs.beg[q] = (unsigned long long)(r.out - e->grad); e->adam_segs.end[q] = e->adam_segs.beg[q] + r.elems; e->adam_segs.part[q] = r.part; e->adam_segs.S[q] = r.S; tot += r.elems; }
+            e->adam_segs.blocks = (unsigned)((tot + 255) / 256);
+        }
+        if (!final_segs.empty()) e->final_reduce_step = (long)e->prog.size();
+    }
     emit_reduce(e, final_segs, "dw_reduce_all");
     e->prog_post_begin = e->prog.size();
     e->prog.push_back({"adam", [](dqn_engine* en) {
         PrioArgs pa; pa.n = (en->hp.prioritized_replay && !en->hp.recurrence) ? en->B : 0; pa.cap2 = en->cap2; pa.idx = en->idx; pa.td = en->td; pa.eps = en->hp.prio_eps; pa.alpha = en->hp.prio_alpha; pa.tree = en->tree;
+        AdamSegs none; memset(&none, 0, sizeof none);
+        const bool fold = en->adam_segs.n > 0 && !en->comm;     // with a communicator the gradient must be materialised before the all-reduce
         launch_adam(en->stream, en->Pint, en->p_on, en->m, en->v, en->grad, en->state, en->gmax_part, en->hp.adam_f64_scalars, en->hp.learning_rate,
-                    en->hp.adam_beta1, en->hp.adam_beta2, en->hp.adam_eps, en->world > 1 ? 1.0f / (float)en->world : 1.0f, pa); }});
+                    en->hp.adam_beta1, en->hp.adam_beta2, en->hp.adam_eps, en->world > 1 ? 1.0f / (float)en->world : 1.0f, pa, fold ? en->adam_segs : none, en->grad); }});
     e->prog_built = true;
     return 0;
 }
@@ -715,7 +728,10 @@ static void enqueue_step(dqn_engine* e, bool sample, int phase) {
         } else
         RUN(e, sample ? "sample_gather" : "gather", launch_gather_fb(e->stream, e->s_rows, e->sp_rows, e->hp.obs_dtype == DQN_OBS_U8, e->E, e->B, e->idx, e->x0,
                                                                    sample ? 1 : 0, e->cap2, e->tree, e->hp.seed, e->state));
-        for (size_t i = 0; i < e->prog_post_begin; i++) RUN(e, e->prog[i].name, e->prog[i].fn(e));
+        for (size_t i = 0; i < e->prog_post_begin; i++) {
+            if ((long)i == e->final_reduce_step && e->adam_segs.n > 0 && !e->comm) continue;   // folded into k_adam
+            RUN(e, e->prog[i].name, e->prog[i].fn(e));
+        }
     }
     if (phase != PH_PRE) for (size_t i = e->prog_post_begin; i < e->prog.size(); i++) RUN(e, e->prog[i].name, e->prog[i].fn(e));
 }
@@ -753,7 +769,7 @@ static int run_step(dqn_engine* e, bool sample) {
 }
 static int fetch_scalars(dqn_engine* e, float* loss, float* gn) {
     // globalnorm (helpers.jl:38-46): fold the Adam kernel's per-block maxima only when the host asks for the scalar
-    if (gn) launch_update_priorities(e->stream, 0, e->cap2, e->idx, e->td, e->hp.prio_eps, e->hp.prio_alpha, e->tree, e->state, 1, 1.0, 1.0, e->gmax_part, adam_blocks(e->Pint));
+    if (gn) launch_update_priorities(e->stream, 0, e->cap2, e->idx, e->td, e->hp.prio_eps, e->hp.prio_alpha, e->tree, e->state, 1, 1.0, 1.0, e->gmax_part, adam_blocks(e->Pint) + 4096);
     StepState s; HIPCHK(hipMemcpyAsync(&s, e->state, sizeof s, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream));
     if (s.err == 2) return fail("AssertionError: all(new_priorities .> 0f0)");
     if (loss) *loss = s.loss;

@@ -470,8 +470,11 @@ __global__ __launch_bounds__(256) void k_dx_lds(LayerDev L, GDxArgs A, int B, in
 template <int NT>
 __global__ __launch_bounds__(256) void k_dwdx_lds(LayerDev Lw, GDwProbs pr, int nprob, int ldx, int B, int Sw, int kcw, int dw_blocks,
                                                   LayerDev Lx, GDxArgs A, int Sx, int kcx, int dx_gx) {
-    if ((int)blockIdx.x < dw_blocks) dw_lds_body<NT>(Lw, pr, nprob, ldx, B, Sw, kcw, blockIdx.x, dw_blocks);
-    else { const int r = blockIdx.x - dw_blocks; dx_lds_body(Lx, A, B, Sx, kcx, r % dx_gx, dx_gx, r / dx_gx); }
+    // the few, long-latency dX workgroups are dispatched FIRST so that they run for the whole kernel while the many short dW
+    // workgroups fill the remaining CUs (dispatch order is blockIdx order)
+    const int dx_blocks = (int)gridDim.x - dw_blocks;
+    if ((int)blockIdx.x < dx_blocks) dx_lds_body(Lx, A, B, Sx, kcx, blockIdx.x % dx_gx, dx_gx, blockIdx.x / dx_gx);
+    else dw_lds_body<NT>(Lw, pr, nprob, ldx, B, Sw, kcw, blockIdx.x - dx_blocks, dw_blocks);
 }
 bool gemm_dx_eligible(const LayerDev& L, int B, int ldy) {
     const bool dense = L.kind == DQN_LAYER_DENSE;
