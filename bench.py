@@ -36,7 +36,10 @@ def build_workload(pkg, args, rank, device):
     hp = pkg.default_hparams(batch_size=args.batch, n_actions=4, obs_c=4, obs_h=84, obs_w=84, obs_dtype=pkg.OBS_U8 if args.u8 else pkg.OBS_F32,
                              learning_rate=1e-4, gamma=0.99, double_q=1, dueling=1, prioritized_replay=1, buffer_size=args.replay,
                              seed=1234 + rank, use_graph=0 if args.no_graph else 1, use_mfma=0 if args.no_mfma else 1)
-    eng = pkg.Engine(layers, hp, device=device)
+    plan = None
+    if args.fc_kc:      # experiment knob: forward split-K chunk of the 3136-wide dense layers (the plan only fixes rounding order)
+        plan = [(args.fc_kc if (d.kind == pkg._abi.LAYER_DENSE and d.n_in > 1024) else p[0], p[1], p[2]) for d, p in zip(layers, pkg.default_plan(layers, hp))]
+    eng = pkg.Engine(layers, hp, plan=plan, device=device)
     params = nn.glorot_params(net, seed=1)           # identical replicas on every rank
     eng.set_params(params, pkg.NET_ONLINE)
     eng.set_params(params, pkg.NET_TARGET)
@@ -57,6 +60,9 @@ def build_workload(pkg, args, rank, device):
     return eng, layers, hp, net, params, env
 
 
+ADAM_EXTRA_BYTES = [0.0]
+
+
 def op_cost(name, eng_layers, B, ncon, E, P):
     """algorithmic (flops, bytes) of one profiled launch by its program name.
     fwd_<l>      forward of layer l AND its sibling (val/adv) for the online net on [s;sp] and the target net on sp
@@ -65,7 +71,7 @@ def op_cost(name, eng_layers, B, ncon, E, P):
     if name in ("gather", "sample_gather"):
         return 0.0, 2.0 * B * E * 4 * 2          # rows read + batch arena written
     if name == "adam":
-        return 0.0, P * 28.0                      # p,m,v,g read + p,m,v written
+        return 0.0, P * 28.0 + ADAM_EXTRA_BYTES[0]   # p,m,v,g read + p,m,v written (+ the conv dW split-K slabs it reduces on a single GPU)
     digits = "".join(ch for ch in parts[-1] if ch.isdigit())
     if not digits or parts[0] not in ("fwd", "dw", "dw2", "dx"):
         return 0.0, 0.0
@@ -107,6 +113,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--fc-kc", type=int, default=0, help="experiment: override fwd_kc of the wide dense layers")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -172,6 +179,12 @@ def main():
                 h, w = (h - d.kh) // d.sh + 1, (w - d.kw) // d.sw + 1
                 npos = h * w
             g2.append((K, N, npos))
+        # single-GPU path: k_adam also reduces the conv layers' dW split-K slabs (S slabs of (K+1) x N floats, read once, grad written)
+        if world == 1:
+            for (K, N, npos), (_, _, dw_kc) in zip(g2, eng.plan()):
+                S = -(-npos * B // dw_kc) if dw_kc and dw_kc < npos * B else 1
+                if S > 1:
+                    ADAM_EXTRA_BYTES[0] += (S + 1) * (K + 1) * N * 4.0
         acc = {}
         for _ in range(args.profile_steps):
             for name, ms in eng.profile_step():

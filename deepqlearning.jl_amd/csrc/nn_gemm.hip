@@ -9,6 +9,8 @@
 // ds_read_b32.  Tiles are double-buffered in LDS; the next tile's global loads are in flight while the current
 // tile's 8 MFMA steps issue, one barrier per 32-deep K tile.  ~40 KB LDS per workgroup => 4 workgroups (16 waves)
 // per CU hide the rest of the latency.
+#include <type_traits>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -25,7 +27,10 @@ void launch_reduce_pub(hipStream_t st, const float* part, int S, size_t elems, i
 struct GFwdProb { const float* W; const float* bias; const float* X; int ldx, col0, ncols; float* out; int mtiles, mgroups; };
 struct GFwdProbs { GFwdProb p[4]; int wg_end[4]; };   // up to 4 problems of one geometry per launch: {val,adv} x {online,target}
 
-constexpr int F_KT = 32;        // K tile depth
+#ifndef DQN_F_KT
+#define DQN_F_KT 32
+#endif
+constexpr int F_KT = DQN_F_KT;  // K tile depth (32 or 64)
 constexpr int F_SA = 80;        // A tile row stride (64 columns + 16 pad): ds_read_b32 of lanes (i, kq) hits banks 16*kq + i
 template <int NT> struct FwdCfg { static constexpr int NW = 16 * NT; static constexpr int SB = (NW % 32 == 0) ? NW + 16 : NW + 32; };
 
@@ -76,31 +81,43 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     // So the staging loads are inline asm (invisible to that pass), ALWAYS issued (tile index clamped, so the number of
     // loads in flight is a compile-time constant) and retired with explicit s_waitcnt vmcnt(N) naming their registers
     // (cdna_hip_programming.md section 5.7 form (ii)).
-    constexpr int LPS = 2 + BQ;                        // loads per stage
-    struct Stage { f32x4 a0, a1, b0, b1; };
-    const int bq0 = tid < F_KT * BF4 ? tid : F_KT * BF4 - 1;          // clamped B slots (threads beyond the tile re-load the last one)
-    const int bq1 = tid + 256 < F_KT * BF4 ? tid + 256 : F_KT * BF4 - 1;
-    const float* Wb0 = Wp + (unsigned)(bq0 / BF4) * (unsigned)L.N + 4 * (bq0 % BF4);
-    const float* Wb1 = Wp + (unsigned)(bq1 / BF4) * (unsigned)L.N + 4 * (bq1 % BF4);
+    constexpr int AQ = F_KT / 16;                      // A float4 per thread
+    constexpr int LPS = AQ + BQ;                       // loads per stage
+    struct Stage { f32x4 a[AQ]; f32x4 b[BQ]; };
+    const float* Wb[BQ]; bool bok[BQ]; int brow[BQ], bc4[BQ];
+#pragma unroll
+    for (int i = 0; i < BQ; i++) {                                   // clamped B slots (threads beyond the tile re-load the last one)
+        const int q = tid + 256 * i; bok[i] = q < F_KT * BF4; const int qc = bok[i] ? q : F_KT * BF4 - 1;
+        brow[i] = qc / BF4; bc4[i] = qc % BF4; Wb[i] = Wp + (unsigned)brow[i] * (unsigned)L.N + 4 * bc4[i];
+    }
     auto gld = [](const float* ptr) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory"); return v; };
     auto gload = [&](int kt, Stage& r) {
         kt = min(kt, nkt - 1);
         const int kb = k0 + kt * F_KT;
-        const int ka = kb + arow;
-        const int ko0 = conv ? koff_lds[ka] : ka, ko1 = conv ? koff_lds[ka + 16] : ka + 16;
-        r.a0 = gld(Xa + (unsigned)(a_xb + ko0) * ldx);
-        r.a1 = gld(Xa + (unsigned)(a_xb + ko1) * ldx);
-        r.b0 = gld(Wb0 + (unsigned)kb * (unsigned)L.N);
-        if (BQ > 1) r.b1 = gld(Wb1 + (unsigned)kb * (unsigned)L.N);
+#pragma unroll
+        for (int q = 0; q < AQ; q++) {
+            const int ka = kb + arow + 16 * q;
+            const int ko = conv ? koff_lds[ka] : ka;
+            r.a[q] = gld(Xa + (unsigned)(a_xb + ko) * ldx);
+        }
+#pragma unroll
+        for (int i = 0; i < BQ; i++) r.b[i] = gld(Wb[i] + (unsigned)kb * (unsigned)L.N);
     };
     auto lstore = [&](int buf, const Stage& r) {
-        *reinterpret_cast<f32x4*>(As + (buf * F_KT + arow) * F_SA + (tid & 15) * 4) = r.a0;
-        *reinterpret_cast<f32x4*>(As + (buf * F_KT + arow + 16) * F_SA + (tid & 15) * 4) = r.a1;
-        if (tid < F_KT * BF4) *reinterpret_cast<f32x4*>(Bs + (buf * F_KT + tid / BF4) * SB + 4 * (tid % BF4)) = r.b0;
-        if (BQ > 1) *reinterpret_cast<f32x4*>(Bs + (buf * F_KT + (tid + 256) / BF4) * SB + 4 * ((tid + 256) % BF4)) = r.b1;
+#pragma unroll
+        for (int q = 0; q < AQ; q++) *reinterpret_cast<f32x4*>(As + (buf * F_KT + arow + 16 * q) * F_SA + (tid & 15) * 4) = r.a[q];
+#pragma unroll
+        for (int i = 0; i < BQ; i++) if (bok[i]) *reinterpret_cast<f32x4*>(Bs + (buf * F_KT + brow[i]) * SB + 4 * bc4[i]) = r.b[i];
     };
-#define STAGE_WAIT(N, r) do { if (BQ > 1) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r.a0), "+v"(r.a1), "+v"(r.b0), "+v"(r.b1) : "n"(N) : "memory"); \
-                              else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r.a0), "+v"(r.a1), "+v"(r.b0) : "n"(N) : "memory"); } while (0)
+    auto stage_wait = [&](auto N, Stage& r) {
+        constexpr int n = decltype(N)::value;
+        if constexpr (AQ == 2 && BQ == 1) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.b[0]) : "n"(n) : "memory");
+        else if constexpr (AQ == 2 && BQ == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.b[0]), "+v"(r.b[1]) : "n"(n) : "memory");
+        else if constexpr (AQ == 4 && BQ == 1) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.b[0]) : "n"(n) : "memory");
+        else if constexpr (AQ == 4 && BQ == 2) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.b[0]), "+v"(r.b[1]) : "n"(n) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.b[0]), "+v"(r.b[1]), "+v"(r.b[2]), "+v"(r.b[3]) : "n"(n) : "memory");
+    };
+#define STAGE_WAIT(N, r) stage_wait(std::integral_constant<int, N>{}, r)
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -124,7 +141,6 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     // prefetch distance 2: tile kt computes from LDS while tile kt+1 lands in one register stage and tile kt+2's loads
     // are issued into the other; one barrier per K tile.
     Stage r0, r1;
-    r0.b1 = r1.b1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     gload(0, r0); STAGE_WAIT(0, r0); lstore(0, r0); __syncthreads();
     gload(1, r0);
     for (int kt = 0; kt < nkt; kt += 2) {
