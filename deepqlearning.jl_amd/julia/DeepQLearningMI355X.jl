@@ -37,7 +37,8 @@ mutable struct HParams
     prio_alpha::Float32; prio_beta::Float32; prio_eps::Float32
     seed::UInt64
     use_graph::Int32; use_mfma::Int32
-    reserved::NTuple{6,Int32}
+    recurrence::Int32; trace_length::Int32
+    reserved::NTuple{4,Int32}
     HParams() = new()
 end
 
@@ -53,7 +54,10 @@ function lower_layer(l, stream)::LayerDesc
         all(==(0), l.pad) || throw("DeepQLearningError: the MI355X engine supports Conv with pad=0 only")
         return LayerDesc(1, ACT[l.σ], stream, 0, 0, cin, cout, kh, kw, l.stride[2], l.stride[1])
     end
-    throw("DeepQLearningError: unsupported layer $(typeof(l)) (Conv / Dense / flattenbatch only)")
+    elseif l isa Flux.Recur && l.cell isa Flux.LSTMCell     # Flux.params order Wi, Wh, b, state0 (h0, c0) == the ABI's LSTM block
+        return LayerDesc(2, 0, stream, size(l.cell.Wi, 2), size(l.cell.Wh, 2), 0, 0, 0, 0, 0, 0)
+    end
+    throw("DeepQLearningError: unsupported layer $(typeof(l)) (Conv / Dense / LSTM / flattenbatch only)")
 end
 is_glue(l) = l === identity || l === flattenbatch || l isa Function
 function lower(q)
@@ -83,6 +87,7 @@ function Engine(solver::DeepQLearningSolver, env::AbstractEnv, q; device=0, obs_
     hp.learning_rate = solver.learning_rate; hp.gamma = Float32(DeepQLearning.default_discount(env))
     hp.double_q = solver.double_q; hp.dueling = q isa DeepQLearning.DuelingNetwork; hp.prioritized_replay = solver.prioritized_replay
     hp.buffer_size = solver.buffer_size
+    hp.recurrence = solver.recurrence; hp.trace_length = solver.trace_length
     descs = lower(q); out = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:dqn_engine_create, LIB), Cint, (Ptr{LayerDesc}, Cint, Ref{HParams}, Ptr{Cvoid}, Cint, Ref{Ptr{Cvoid}}),
                 descs, length(descs), hp, C_NULL, device, out))
@@ -133,6 +138,23 @@ function batch_train!(solver::DeepQLearningSolver, env::AbstractEnv, policy::Abs
     return loss[], gn[]
 end
 
+# ---- DRQN: EpisodeReplayBuffer protocol (src/episode_replay.jl) and the recurrent batch_train! (src/solver.jl:239-287)
+mutable struct HIPEpisodeReplayBuffer
+    e::Engine
+    rng::AbstractRNG
+end
+function add_exp!(r::HIPEpisodeReplayBuffer, expe::DQExperience)                      # :46-52 (the engine stores the episode when done)
+    check(ccall((:dqn_episode_add, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int32}, Ref{Float32}, Ptr{Cvoid}, Ref{UInt8}, Cint),
+                r.e.h, Float32.(vec(expe.s)), Int32(expe.a - 1), Float32(expe.r), Float32.(vec(expe.sp)), UInt8(expe.done), 1))
+end
+add_episode!(r::HIPEpisodeReplayBuffer) = check(ccall((:dqn_episode_commit, LIB), Cint, (Ptr{Cvoid},), r.e.h))   # :54-60, after generate_episode
+function batch_train!(solver::DeepQLearningSolver, env::AbstractEnv, policy::AbstractNNPolicy, optimizer, target_q,
+                      replay::HIPEpisodeReplayBuffer; discount=DeepQLearning.default_discount(env))
+    loss = Ref{Float32}(0); gn = Ref{Float32}(0)
+    check(ccall((:dqn_train_step_drqn, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int32}, Ref{Float32}, Ref{Float32}), replay.e.h, C_NULL, C_NULL, loss, gn))
+    return loss[], gn[]
+end
+
 # ---- policy (src/policy.jl)
 struct HIPNNPolicy{P,A} <: AbstractNNPolicy
     problem::P
@@ -147,7 +169,7 @@ function getnetwork(p::HIPNNPolicy)                    # Flux.params(active_q) <
     off = 0; for w in ps; copyto!(w, reshape(flat[off+1:off+length(w)], size(w))); off += length(w); end
     p.qnetwork
 end
-resetstate!(p::HIPNNPolicy) = nothing
+resetstate!(p::HIPNNPolicy) = check(ccall((:dqn_reset_state, LIB), Cint, (Ptr{Cvoid},), p.e.h))   # Flux.reset!: Recur state <- state0
 actionmap(p::HIPNNPolicy) = p.action_map
 function _q(p::HIPNNPolicy, o)
     ndims(o) == p.n_input_dims || throw("NNPolicyError: was expecting an array with $(p.n_input_dims) dimensions, got $(ndims(o))")
