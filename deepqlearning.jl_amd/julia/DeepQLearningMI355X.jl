@@ -53,7 +53,6 @@ function lower_layer(l, stream)::LayerDesc
         kw, kh, cin, cout = size(l.weight)
         all(==(0), l.pad) || throw("DeepQLearningError: the MI355X engine supports Conv with pad=0 only")
         return LayerDesc(1, ACT[l.σ], stream, 0, 0, cin, cout, kh, kw, l.stride[2], l.stride[1])
-    end
     elseif l isa Flux.Recur && l.cell isa Flux.LSTMCell     # Flux.params order Wi, Wh, b, state0 (h0, c0) == the ABI's LSTM block
         return LayerDesc(2, 0, stream, size(l.cell.Wi, 2), size(l.cell.Wh, 2), 0, 0, 0, 0, 0, 0)
     end
