@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--env-steps", type=int, default=200, help="vector steps of the device-resident env loop timed after the main metric (0 = skip)")
     ap.add_argument("--fc-kc", type=int, default=0, help="experiment: override fwd_kc of the wide dense layers")
     args = ap.parse_args()
 
@@ -160,6 +161,27 @@ def main():
     group.barrier()
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps / elapsed            # whole-job train steps/s (each rank runs its own B=32 step)
+
+    # ---- secondary: the device-resident env loop of config 3 (envs_per_rank copies of the image MDP per rank, eps-greedy + add_exp! in HBM)
+    env_loop = None
+    if args.env_steps > 0:
+        eng.envs_create(env, n_envs=args.envs_per_rank, max_episode_length=100, seed=1234 + rank)
+        eng.rollout(20, t0=1, train_freq=0, target_update_freq=0, stats=False)
+        eng.sync()
+        ta = time.perf_counter()
+        eng.rollout(args.env_steps, t0=21, train_freq=0, target_update_freq=0, stats=False)      # acting only: no collective, safe on every rank
+        eng.sync()
+        tb = time.perf_counter()
+        act_s = group.max_over_ranks(tb - ta)
+        env_loop = {"envs_per_rank": args.envs_per_rank, "vector_steps": args.env_steps, "act_only_env_steps_per_s": world * args.envs_per_rank * args.env_steps / act_s,
+                    "act_only_ms_per_vector_step": act_s / args.env_steps * 1e3}
+        if world == 1:
+            ta = time.perf_counter()
+            st = eng.rollout(args.env_steps, t0=21 + args.env_steps, train_freq=4, target_update_freq=500)
+            tb = time.perf_counter()
+            env_loop.update({"train_freq": 4, "loop_env_steps_per_s": args.envs_per_rank * args.env_steps / (tb - ta),
+                             "loop_train_steps_per_s": st["train_steps"] / (tb - ta), "loop_ms_per_vector_step": (tb - ta) / args.env_steps * 1e3})
+        group.barrier()
 
     out = None
     if rank == 0:
@@ -218,7 +240,7 @@ def main():
                        "parallelism": f"dp{world} (per-rank replay, RCCL grad all-reduce)" if world > 1 else "single GPU",
                        "hip_graph": not args.no_graph, "mfma": not args.no_mfma, "last_loss": loss, "last_grad_norm": gnorm},
             "samples_per_s": value * args.batch,
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "env_loop": env_loop,
         }
         print(json.dumps(out))
     group.barrier()

@@ -68,6 +68,26 @@ def default_hparams(**kw) -> HParams:
     return hp
 
 
+class EnvSpec(C.Structure):
+    """dqn_env_spec (include/dqn_mi355x.h): n lock-stepped device environments."""
+    _fields_ = [("kind", C.c_int32), ("n_envs", C.c_int32), ("max_episode_length", C.c_int32), ("seed", C.c_uint64),
+                ("o_stack", C.c_int32), ("max_time", C.c_int32), ("images", C.c_void_p),
+                ("size_x", C.c_int32), ("size_y", C.c_int32), ("tprob", C.c_float), ("n_reward_cells", C.c_int32),
+                ("reward_xy", (C.c_int32 * 2) * 8), ("reward_val", C.c_float * 8)]
+
+
+class RolloutCfg(C.Structure):
+    _fields_ = [("train_freq", C.c_int32), ("target_update_freq", C.c_int32),
+                ("eps_start", C.c_float), ("eps_stop", C.c_float), ("eps_steps", C.c_float), ("t0", C.c_int64)]
+
+
+class RolloutStats(C.Structure):
+    _fields_ = [("episodes", C.c_int64), ("reward_sum", C.c_double), ("train_steps", C.c_int64),
+                ("last_loss", C.c_float), ("last_grad_norm", C.c_float)]
+
+
+ENV_TESTMDP, ENV_GRIDWORLD = 0, 1
+
 _P = C.POINTER
 _f32p, _i32p, _i64p, _u8p, _f64p = _P(C.c_float), _P(C.c_int32), _P(C.c_int64), _P(C.c_uint8), _P(C.c_double)
 _vp, _sz = C.c_void_p, C.c_size_t
@@ -111,6 +131,10 @@ PROTOS = {
     "reset_state": [_vp],
     "get_hidden": [_vp, _f32p, _sz],
     "set_hidden": [_vp, _f32p, _sz],
+    "envs_create": [_vp, _P(EnvSpec)],
+    "envs_reset": [_vp],
+    "rollout": [_vp, C.c_int, _P(RolloutCfg), _P(RolloutStats)],
+    "envs_peek": [_vp, _f32p, _i32p, _f32p, _u8p],
 }
 # twin spellings that differ from the product's
 _TWIN_ALIASES = {"engine_create": "create", "engine_destroy": "destroy", "engine_get_plan": "get_plan"}
@@ -335,6 +359,40 @@ class Handle:
 
     def reset_state(self):
         self._check(self.f["reset_state"](self._h))
+
+    # ---- vectorised environments on the device
+    def envs_create(self, env, n_envs=None, max_episode_length=100, seed=0):
+        """`env` is an envs.TestMDP / envs.SimpleGridWorld instance used as the SPEC (images, sizes, rewards); its own state is not used."""
+        sp = EnvSpec()
+        sp.n_envs = int(n_envs if n_envs is not None else env.n)
+        sp.max_episode_length, sp.seed = int(max_episode_length), int(seed)
+        if hasattr(env, "images"):
+            sp.kind, sp.o_stack, sp.max_time = ENV_TESTMDP, env.o_stack, env.max_time
+            self._env_images = np.ascontiguousarray(env.images, np.uint8)
+            sp.images = self._env_images.ctypes.data
+        else:
+            sp.kind, sp.size_x, sp.size_y, sp.tprob = ENV_GRIDWORLD, env.size[0], env.size[1], env.tprob
+            sp.n_reward_cells = len(env.reward_cells)
+            for k, ((x, y), v) in enumerate(env.reward_cells.items()):
+                sp.reward_xy[k][0], sp.reward_xy[k][1], sp.reward_val[k] = x, y, v
+        self._check(self.f["envs_create"](self._h, C.byref(sp)))
+        self.n_envs = sp.n_envs
+
+    def envs_reset(self):
+        self._check(self.f["envs_reset"](self._h))
+
+    def rollout(self, n_steps, t0=1, train_freq=4, target_update_freq=500, eps=(1.0, 0.01, 5000.0), stats=True):
+        cfg = RolloutCfg(int(train_freq), int(target_update_freq), float(eps[0]), float(eps[1]), float(eps[2]), int(t0))
+        st = RolloutStats()
+        self._check(self.f["rollout"](self._h, int(n_steps), C.byref(cfg), C.byref(st) if stats else None))
+        return dict(episodes=st.episodes, reward_sum=st.reward_sum, train_steps=st.train_steps, loss=st.last_loss, grad_norm=st.last_grad_norm) if stats else None
+
+    def envs_peek(self):
+        n = self.n_envs
+        obs = np.empty((n,) + self.obs_shape, np.float32)
+        a, r, d = np.empty(n, np.int32), np.empty(n, np.float32), np.empty(n, np.uint8)
+        self._check(self.f["envs_peek"](self._h, _ptr(obs, _f32p), _ptr(a, _i32p), _ptr(r, _f32p), _ptr(d, _u8p)))
+        return obs, a, r, d
 
     # ---- misc (product only)
     def sync(self):

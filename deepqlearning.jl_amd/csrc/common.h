@@ -199,6 +199,53 @@ struct TdDrqnArgs {
 void launch_td_drqn(hipStream_t st, const TdDrqnArgs& a);
 void launch_bcast_state(hipStream_t st, const float* src, int H, int n, float* dst);
 
+#ifdef __HIPCC__
+// head output (n, col): either the finished activation, or -- when the head's forward ran split-K and its reduction is
+// folded into this kernel -- act(sum_s partial + bias)
+__device__ __forceinline__ float head_val(const HeadSrc& h, int n, int col) {
+    const size_t e = (size_t)n * h.ld + col;
+    if (h.S <= 1) return h.p[e];
+    float tot = h.p[e];
+    int s = 1;
+    for (; s + 8 <= h.S; s += 8) {      // 8 independent slab loads in flight, adds in ascending order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = h.p[(size_t)(s + u) * h.per_s + e];
+#pragma unroll
+        for (int u = 0; u < 8; u++) tot = tot + v[u];
+    }
+    for (; s < h.S; s++) tot = tot + h.p[(size_t)s * h.per_s + e];
+    return act_f(tot + h.bias[n], h.act);
+}
+__device__ __forceinline__ void q_column_h(int nA, int dueling, const HeadSrc& val, const HeadSrc& adv, int col, float* q, float* vout, float* araw) {
+    for (int a = 0; a < nA; a++) araw[a] = head_val(adv, a, col);
+    if (!dueling) { for (int a = 0; a < nA; a++) q[a] = araw[a]; *vout = 0.0f; return; }
+    const float v = head_val(val, 0, col); *vout = v;
+    float sum = araw[0];
+    for (int a = 1; a < nA; a++) sum = sum + araw[a];
+    const float mean = sum / (float)nA;
+    for (int a = 0; a < nA; a++) q[a] = (v + araw[a]) - mean;
+}
+#endif
+
+// ---- vectorised environments on the device (envs.hip)
+struct EnvDev {
+    int kind, n, E, H, W, nA, max_episode_length, prioritized; unsigned long long seed;
+    // TestMDP
+    const unsigned char* images; signed char *tm_s, *tm_prev; int* tm_t; int max_time;
+    // SimpleGridWorld
+    int *gw_pos, *gw_prev; int size_x, size_y, n_reward; float tprob; int reward_xy[8][2]; float reward_val[8];
+    // per-env loop state / outputs
+    int* actions; float* rewards; unsigned char* dones; unsigned char* pending; float* ep_reward; int* ep_step; long long* fin_eps; double* fin_reward;
+};
+struct RolloutDev { long long t, widx; float eps_start, eps_stop, eps_steps; int pad; };     // t, widx: values of the LAST completed vector step
+struct ReplayMeta { long long cap, cap2; int* a; float* r; unsigned char* done; float* tree; StepState* state; float eps, alpha; };
+void launch_env_observe(hipStream_t st, const EnvDev& V, void* rows, int rows_u8, float* x);
+struct ActHeads { HeadSrc val, adv; int dueling; float* q_out; int* amax; };     // last-layer outputs of the acting forward (adv doubles as the plain Q head)
+void launch_env_step(hipStream_t st, const EnvDev& V, RolloutDev* rs, const ActHeads& Hd, const ReplayMeta& R);
+void launch_env_observe2(hipStream_t st, const EnvDev& V, const RolloutDev* rs, int rows_u8, void* s_rows, void* sp_rows, long long cap, float* x);
+void launch_env_reset_pending(hipStream_t st, const EnvDev& V, const RolloutDev* rs, int force_all);
+
 // MFMA path (nn_mfma.hip): returns false if the shape is not eligible (caller falls back to the VALU kernel,
 // which computes bit-identical values)
 bool gemm_dw_eligible(const LayerDev& L, int B, int ldx);

@@ -70,6 +70,7 @@ struct dqn_engine {
     // get_batch seam workspace
     float *gb_rows = nullptr, *gb_r = nullptr, *gb_done = nullptr, *gb_w = nullptr; int* gb_a = nullptr; long long* gb_idx = nullptr;
     // policy workspace
+    EnvDev env{}; bool has_envs = false; unsigned char* env_images = nullptr;
     int pol_n = 0; float *pol_obs = nullptr, *pol_x = nullptr, *pol_act[DQN_MAX_LAYERS] = {}, *pol_q = nullptr; int* pol_a = nullptr;
     // graphs: [0] = step with sampling, [1] = step on given indices; with a communicator the step is cut in two
     hipGraphExec_t g_full[2] = {nullptr, nullptr}, g_pre[2] = {nullptr, nullptr}, g_post = nullptr;
@@ -85,6 +86,7 @@ struct dqn_engine {
     hipGraphExec_t g_drqn = nullptr;
     // static launch program
     struct Step { const char* name; std::function<void(dqn_engine*)> fn; };
+    std::vector<Step> act_prog; std::vector<Step>* sink = nullptr; int act_prog_n = 0; hipGraphExec_t g_act = nullptr; RolloutDev* roll = nullptr;
     std::vector<Step> prog; size_t prog_post_begin = 0; bool prog_built = false, step_sampled = true;
     AdamSegs adam_segs; long final_reduce_step = -1;   // deferred dW slabs: reduced inside k_adam unless a communicator needs the materialised gradient
     std::vector<void*> prog_allocs; std::vector<std::string> prog_names;
@@ -266,7 +268,9 @@ static void drop_graphs(dqn_engine* e) {
         if (e->g_pre[i]) { hipGraphExecDestroy(e->g_pre[i]); e->g_pre[i] = nullptr; }
     }
     if (e->g_post) { hipGraphExecDestroy(e->g_post); e->g_post = nullptr; }
+    if (e->g_act) { hipGraphExecDestroy(e->g_act); e->g_act = nullptr; }
 }
+static void free_envs(dqn_engine* e);
 static void free_policy_ws(dqn_engine* e) {
     hipFree(e->pol_obs); hipFree(e->pol_x); hipFree(e->pol_q); hipFree(e->pol_a);
     for (int i = 0; i < e->nl; i++) { hipFree(e->pol_act[i]); e->pol_act[i] = nullptr; }
@@ -284,7 +288,7 @@ extern "C" int dqn_engine_destroy(dqn_engine_t* e) {
     for (int i = 0; i < e->nl; i++) { hipFree(e->act_on[i]); hipFree(e->act_tg[i]); hipFree(e->dact[i]); }
     hipFree(e->join_tmp); hipFree(e->partials); hipFree(e->gmax_part); hipFree(e->w_is); hipFree(e->td); hipFree(e->q_on_s); hipFree(e->q_on_sp); hipFree(e->q_tg_sp);
     hipFree(e->ytarget); hipFree(e->best); hipFree(e->gb_rows); hipFree(e->gb_r); hipFree(e->gb_done); hipFree(e->gb_w); hipFree(e->gb_a); hipFree(e->gb_idx);
-    free_policy_ws(e);
+    free_policy_ws(e); free_envs(e);
     for (void* p : e->prog_allocs) hipFree(p);
     hipFree(e->ep_s); hipFree(e->ep_sp); hipFree(e->ep_a); hipFree(e->ep_r); hipFree(e->ep_done); hipFree(e->ep_len); hipFree(e->ep_idx); hipFree(e->ep_start);
     hipFree(e->r_a); hipFree(e->r_r); hipFree(e->r_done); hipFree(e->r_mask);
@@ -438,11 +442,6 @@ static void fwd_layer(dqn_engine* e, const LayerDev& l, const float* P, const fl
         launch_valu_fwd(e->stream, l, P, X, ldx, col0, ncols, Y, e->partials);
     prof_end(e);
 }
-static const char* lname(dqn_engine* e, const char* op, int kind, int i) {
-    if (!e->profiling) return "";
-    static char buf[DQN_MAX_LAYERS * 8][24]; static int slot = 0;
-    char* b = buf[(slot++) % (DQN_MAX_LAYERS * 8)]; snprintf(b, 24, "%s_%s%d", op, kind == DQN_LAYER_CONV ? "conv" : "dense", i); return b;
-}
 enum { PH_ALL = 0, PH_PRE = 1, PH_POST = 2 };
 
 // ---------------------------------------------------------------- static launch program
@@ -464,7 +463,7 @@ static void flush_valu(dqn_engine* e, std::vector<VTask>& pend, const char* name
     unsigned blocks = 0;
     for (auto& t : pend) { t.first_block = blocks; blocks += valu_task_blocks(t); }
     VTask* dev = upload(e, pend); const int n = (int)pend.size();
-    e->prog.push_back({name, [=](dqn_engine* en) { launch_valu_multi(en->stream, dev, n, blocks); }});
+    (e->sink ? *e->sink : e->prog).push_back({name, [=](dqn_engine* en) { launch_valu_multi(en->stream, dev, n, blocks); }});
     pend.clear();
 }
 static void emit_reduce(dqn_engine* e, std::vector<RSeg>& segs, const char* name) {
@@ -472,7 +471,7 @@ static void emit_reduce(dqn_engine* e, std::vector<RSeg>& segs, const char* name
     unsigned blocks = 0;
     for (auto& r : segs) { r.first_block = blocks; blocks += (unsigned)((r.elems + 255) / 256); }
     RSeg* dev = upload(e, segs); const int n = (int)segs.size();
-    e->prog.push_back({name, [=](dqn_engine* en) { launch_reduce_multi(en->stream, dev, n, blocks); }});
+    (e->sink ? *e->sink : e->prog).push_back({name, [=](dqn_engine* en) { launch_reduce_multi(en->stream, dev, n, blocks); }});
     segs.clear();
 }
 static const char* pname(dqn_engine* e, const char* op, int kind, int i) {
@@ -812,7 +811,7 @@ extern "C" int dqn_get_last_indices(dqn_engine_t* e, int64_t* idx) {
 // ---------------------------------------------------------------- policy (src/policy.jl:38-64)
 static int policy_ws(dqn_engine* e, int n) {
     if (n <= e->pol_n) return 0;
-    HIPCHK(hipStreamSynchronize(e->stream)); free_policy_ws(e);
+    HIPCHK(hipStreamSynchronize(e->stream)); free_policy_ws(e); e->act_prog_n = 0; e->act_prog.clear(); if (e->g_act) { hipGraphExecDestroy(e->g_act); e->g_act = nullptr; }
     size_t need = 1;   // split-K partials of the widest forward at n columns
     for (int i = 0; i < e->nl; i++) { const size_t sf = dqn_nchunks(e->L[i].K, e->L[i].fwd_kc); if (sf > 1) need = std::max(need, sf * (size_t)e->L[i].out_feat * n); }
     if (need > e->partials_elems) { drop_graphs(e); hipFree(e->partials); e->partials = nullptr; DM(e->partials, 2 * need); e->partials_elems = need; }
@@ -843,8 +842,10 @@ static int policy_forward(dqn_engine* e, int which, const float* obs, int n) {
     HIPCHK(hipSetDevice(e->device));
     if (policy_ws(e, n)) return -1;
     if (policy_state(e, n, false)) return -1;
-    HIPCHK(hipMemcpyAsync(e->pol_obs, obs, (size_t)n * e->E * 4, hipMemcpyHostToDevice, e->stream));
-    launch_transpose_obs(e->stream, e->pol_obs, e->E, n, e->pol_x);
+    if (obs) {      // obs == nullptr: pol_x was filled on the device (vectorised envs)
+        HIPCHK(hipMemcpyAsync(e->pol_obs, obs, (size_t)n * e->E * 4, hipMemcpyHostToDevice, e->stream));
+        launch_transpose_obs(e->stream, e->pol_obs, e->E, n, e->pol_x);
+    }
     const float* P = which == DQN_NET_TARGET ? e->p_tg : e->p_on;
     // the policy workspace has leading dimension n (not pol_n): layers are dense in the batch column
     const int fl = e->pol_flip;
@@ -866,10 +867,12 @@ static int policy_forward(dqn_engine* e, int which, const float* obs, int n) {
     return 0;
 }
 extern "C" int dqn_forward(dqn_engine_t* e, int which, const float* obs, int n, float* q_out) {
+    if (!obs) return fail("obs is null");
     if (policy_forward(e, which, obs, n)) return -1;
     HIPCHK(hipMemcpyAsync(q_out, e->pol_q, (size_t)n * e->nA * 4, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); return 0;
 }
 extern "C" int dqn_greedy_action(dqn_engine_t* e, const float* obs, int n, int32_t* a_out) {
+    if (!obs) return fail("obs is null");
     if (policy_forward(e, DQN_NET_ONLINE, obs, n)) return -1;
     HIPCHK(hipMemcpyAsync(a_out, e->pol_a, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); return 0;
 }
@@ -980,6 +983,174 @@ extern "C" int dqn_set_hidden(dqn_engine_t* e, const float* hc, size_t n) {   //
         HIPCHK(hipMemcpyAsync(e->pol_c[i][e->pol_flip], hc + off, m * 4, hipMemcpyHostToDevice, e->stream)); off += m;
     }
     HIPCHK(hipStreamSynchronize(e->stream)); return 0;
+}
+
+// ---------------------------------------------------------------- vectorised environments on the device
+static void free_envs(dqn_engine* e) {
+    EnvDev& V = e->env;
+    hipFree(e->env_images); hipFree(V.tm_s); hipFree(V.tm_prev); hipFree(V.tm_t); hipFree(V.gw_pos); hipFree(V.gw_prev); hipFree(e->roll);
+    hipFree(V.actions); hipFree(V.rewards); hipFree(V.dones); hipFree(V.pending); hipFree(V.ep_reward); hipFree(V.ep_step); hipFree(V.fin_eps); hipFree(V.fin_reward);
+    e->env_images = nullptr; e->roll = nullptr; memset(&V, 0, sizeof V); e->has_envs = false;
+    e->act_prog.clear(); e->act_prog_n = 0; if (e->g_act) { hipGraphExecDestroy(e->g_act); e->g_act = nullptr; }
+}
+extern "C" int dqn_envs_create(dqn_engine_t* e, const dqn_env_spec* sp) {
+    HIPCHK(hipSetDevice(e->device));
+    if (e->hp.recurrence) return fail("device environments drive the feed-forward path (recurrence = false)");
+    if (sp->n_envs < 1 || sp->n_envs > std::min<long long>(1024, e->cap)) return fail("n_envs must be in 1..min(1024, replay capacity)");
+    if (sp->max_episode_length < 1) return fail("max_episode_length must be >= 1");
+    HIPCHK(hipStreamSynchronize(e->stream)); free_envs(e);
+    EnvDev& V = e->env; const int n = sp->n_envs;
+    V.kind = sp->kind; V.n = n; V.E = e->E; V.nA = e->nA; V.max_episode_length = sp->max_episode_length; V.seed = sp->seed; V.prioritized = e->hp.prioritized_replay ? 1 : 0;
+    const bool u8 = e->hp.obs_dtype == DQN_OBS_U8;
+    if (sp->kind == DQN_ENV_TESTMDP) {
+        if (!sp->images) return fail("TestMDP needs its three images");
+        if (sp->o_stack < 1 || sp->o_stack > 4 || sp->o_stack != e->hp.obs_c) return fail("TestMDP: o_stack (%d) must equal obs_c (%d) and be <= 4", sp->o_stack, e->hp.obs_c);
+        if (e->nA != 4) return fail("TestMDP has 4 actions, the network has %d outputs", e->nA);
+        V.H = e->hp.obs_h; V.W = e->hp.obs_w; V.max_time = sp->max_time;
+        const size_t ib = (size_t)3 * V.H * V.W;
+        DM(e->env_images, ib); HIPCHK(hipMemcpy(e->env_images, sp->images, ib, hipMemcpyHostToDevice)); V.images = e->env_images;
+        DM(V.tm_s, (size_t)n * 4); DM(V.tm_prev, (size_t)n * 4); DM(V.tm_t, n);
+    } else if (sp->kind == DQN_ENV_GRIDWORLD) {
+        if (u8) return fail("SimpleGridWorld observations are Float32[x, y]: use obs_dtype f32");
+        if (e->E != 2 || e->nA != 4) return fail("SimpleGridWorld: observation has 2 elements and there are 4 actions (network: %d in, %d out)", e->E, e->nA);
+        if (sp->n_reward_cells < 0 || sp->n_reward_cells > 8) return fail("at most 8 reward cells");
+        V.size_x = sp->size_x; V.size_y = sp->size_y; V.tprob = sp->tprob; V.n_reward = sp->n_reward_cells;
+        for (int k = 0; k < V.n_reward; k++) { V.reward_xy[k][0] = sp->reward_xy[k][0]; V.reward_xy[k][1] = sp->reward_xy[k][1]; V.reward_val[k] = sp->reward_val[k]; }
+        DM(V.gw_pos, (size_t)n * 2); DM(V.gw_prev, (size_t)n * 2);
+    } else return fail("unknown environment kind %d", sp->kind);
+    DM(V.actions, n); DM(V.rewards, n); DM(V.dones, n); DM(V.pending, n); DM(V.ep_reward, n); DM(V.ep_step, n); DM(V.fin_eps, n); DM(V.fin_reward, n); DM(e->roll, 1);
+    HIPCHK(hipMemsetAsync(V.fin_eps, 0, (size_t)n * 8, e->stream)); HIPCHK(hipMemsetAsync(V.fin_reward, 0, (size_t)n * 8, e->stream));
+    HIPCHK(hipMemsetAsync(V.actions, 0, (size_t)n * 4, e->stream)); HIPCHK(hipMemsetAsync(V.rewards, 0, (size_t)n * 4, e->stream));
+    HIPCHK(hipMemsetAsync(e->roll, 0, sizeof(RolloutDev), e->stream));
+    e->has_envs = true;
+    return dqn_envs_reset(e);
+}
+extern "C" int dqn_envs_reset(dqn_engine_t* e) {
+    HIPCHK(hipSetDevice(e->device));
+    if (!e->has_envs) return fail("no device environments: call dqn_envs_create");
+    launch_env_reset_pending(e->stream, e->env, e->roll, 1);
+    return 0;
+}
+// the acting program: online net forward on the n columns of pol_x (batch-innermost), then Q columns + first-max argmax
+// (action(policy, obs), src/policy.jl:38-64) -- the same tiled kernels and the same plan as the train step, compiled once per n
+static int build_act_program(dqn_engine* e, int n) {
+    if (e->act_prog_n == n) return 0;
+    if (policy_ws(e, n)) return -1;
+    e->act_prog.clear(); if (e->g_act) { hipGraphExecDestroy(e->g_act); e->g_act = nullptr; }
+    e->prog_names.reserve(512);
+    e->sink = &e->act_prog;
+    const bool mf = e->hp.use_mfma != 0;
+    std::vector<std::vector<int>> levels; std::vector<int> val, adv;
+    for (int i = 0; i < e->nl; i++) { if (e->L[i].stream == DQN_STREAM_BASE) levels.push_back({i}); else if (e->L[i].stream == DQN_STREAM_VAL) val.push_back(i); else adv.push_back(i); }
+    for (size_t j = 0; j < std::max(val.size(), adv.size()); j++) { std::vector<int> lv; if (j < val.size()) lv.push_back(val[j]); if (j < adv.size()) lv.push_back(adv[j]); levels.push_back(lv); }
+    const float* P = e->p_on;
+    HeadSrc head[DQN_MAX_LAYERS];
+    for (size_t li = 0; li < levels.size(); li++) {
+        const auto& lv = levels[li]; const bool last = li + 1 == levels.size();
+        struct Prob { int l; const float* X; float *Y, *part; int S; };
+        std::vector<Prob> pr;
+        for (int l : lv) { const LayerDev& L = e->L[l]; Prob q; q.l = l; q.X = L.src < 0 ? e->pol_x : e->pol_act[L.src]; q.Y = e->pol_act[l]; q.S = dqn_nchunks(L.K, L.fwd_kc);
+                           q.part = q.S > 1 ? palloc(e, (size_t)q.S * L.out_feat * n) : nullptr; pr.push_back(q); }
+        bool geo = true; for (int l : lv) geo = geo && same_geo(e->L[lv[0]], e->L[l]);
+        std::vector<bool> done(pr.size(), false);
+        auto emit_gemm = [&](const std::vector<int>& ids, const char* name) {
+            const LayerDev L = e->L[pr[ids[0]].l]; const int np = (int)ids.size();
+            struct A { const float *W[4], *bias[4], *X[4]; int ldx[4], col0[4], ncols[4]; float* out[4]; } a;
+            for (int i = 0; i < np; i++) { const Prob& q = pr[ids[i]]; const LayerDev& Lq = e->L[q.l]; a.W[i] = P + Lq.w_off; a.bias[i] = P + Lq.b_off; a.X[i] = q.X; a.ldx[i] = n; a.col0[i] = 0; a.ncols[i] = n; a.out[i] = q.S > 1 ? q.part : q.Y; }
+            e->act_prog.push_back({name, [=](dqn_engine* en) { launch_gemm_fwd(en->stream, L, np, a.W, a.bias, a.X, a.ldx, a.col0, a.ncols, a.out); }});
+            for (int id : ids) done[id] = true;
+        };
+        if (mf && pr.size() <= 4) {
+            int ldx[4], c0[4], nc[4]; std::vector<int> all;
+            for (size_t i = 0; i < pr.size(); i++) { all.push_back((int)i); ldx[i] = n; c0[i] = 0; nc[i] = n; }
+            if (geo && gemm_fwd_eligible(e->L[lv[0]], (int)pr.size(), ldx, c0, nc)) emit_gemm(all, pname(e, "act_fwd", e->L[lv[0]].kind, lv[0]));
+            else for (size_t i = 0; i < pr.size(); i++) if (gemm_fwd_eligible(e->L[pr[i].l], 1, ldx, c0, nc)) emit_gemm({(int)i}, pname(e, "act_fwd", e->L[pr[i].l].kind, pr[i].l));
+        }
+        std::vector<VTask> pend;
+        for (size_t i = 0; i < pr.size(); i++) {
+            if (done[i]) continue;
+            const Prob q = pr[i]; const LayerDev L = e->L[q.l];
+            if (mf && mfma_fwd_ok(L, n)) e->act_prog.push_back({pname(e, "act_fwd", L.kind, q.l), [=](dqn_engine* en) { launch_mfma_fwd(en->stream, L, P, q.X, n, 0, n, q.Y, q.part, false); }});
+            else { VTask t; memset(&t, 0, sizeof t); t.kind = 0; t.L = L; t.P = P; t.X = q.X; t.ldx = n; t.col0 = 0; t.ncols = n; t.S = q.S; t.kc = dqn_chunk_len(L.K, L.fwd_kc); t.out = q.S > 1 ? q.part : q.Y; add_valu(e, pend, t); }
+        }
+        flush_valu(e, pend, pname(e, "act_fwd_valu", e->L[lv[0]].kind, lv[0]));
+        std::vector<RSeg> segs;
+        for (const Prob& q : pr) {
+            const LayerDev& L = e->L[q.l];
+            HeadSrc h; h.p = q.Y; h.ld = n; h.S = 1; h.per_s = 0; h.bias = P + L.b_off; h.act = L.act;
+            if (q.S > 1) {
+                if (last) { h.p = q.part; h.S = q.S; h.per_s = (unsigned long long)L.out_feat * n; }      // reduced on the fly by k_env_step
+                else { RSeg r; memset(&r, 0, sizeof r); r.part = q.part; r.S = q.S; r.elems = (unsigned long long)L.out_feat * n; r.mode = 0; r.bias = P + L.b_off; r.per_n = L.npos * n; r.act = L.act; r.out = q.Y; segs.push_back(r); }
+            }
+            head[q.l] = h;
+        }
+        emit_reduce(e, segs, pname(e, "act_reduce", e->L[lv[0]].kind, lv[0]));
+    }
+    e->sink = nullptr;
+    const int lq = e->hp.dueling ? e->last_adv : e->last_base;
+    ActHeads Hd; memset(&Hd, 0, sizeof Hd); Hd.adv = head[lq]; if (e->hp.dueling) Hd.val = head[e->last_val]; Hd.dueling = e->hp.dueling; Hd.q_out = e->pol_q; Hd.amax = e->pol_a;
+    // act!, add_exp!, observe, episode bookkeeping
+    const EnvDev V = e->env; RolloutDev* rs = e->roll; const bool u8 = e->hp.obs_dtype == DQN_OBS_U8;
+    ReplayMeta R; R.cap = e->cap; R.cap2 = e->cap2; R.a = e->ra; R.r = e->rr; R.done = e->rdone; R.tree = e->tree; R.state = e->state; R.eps = e->hp.prio_eps; R.alpha = e->hp.prio_alpha;
+    void *srows = e->s_rows, *sprows = e->sp_rows; float* px = e->pol_x; const long long cap = e->cap;
+    e->act_prog.push_back({"env_step_commit", [=](dqn_engine* en) { launch_env_step(en->stream, V, rs, Hd, R); }});
+    e->act_prog.push_back({"env_observe", [=](dqn_engine* en) { launch_env_observe2(en->stream, V, rs, u8, srows, sprows, cap, px); }});
+    e->act_prog_n = n; return 0;
+}
+extern "C" int dqn_rollout(dqn_engine_t* e, int n_steps, const dqn_rollout_cfg* cfg, dqn_rollout_stats* out) {
+    HIPCHK(hipSetDevice(e->device));
+    if (!e->has_envs) return fail("no device environments: call dqn_envs_create");
+    if (cfg->t0 < 1) return fail("t0 counts from 1 (src/solver.jl:82)");
+    EnvDev& V = e->env; const int n = V.n;
+    if (build_act_program(e, n)) return -1;
+    if (cfg->train_freq > 0 && build_program(e)) return -1;       // may reallocate split-K workspaces: before any capture
+    RolloutDev h; h.t = cfg->t0 - 1; h.widx = ((e->widx - n) % e->cap + e->cap) % e->cap; h.eps_start = cfg->eps_start; h.eps_stop = cfg->eps_stop; h.eps_steps = cfg->eps_steps; h.pad = 0;
+    HIPCHK(hipMemcpyAsync(e->roll, &h, sizeof h, hipMemcpyHostToDevice, e->stream)); HIPCHK(hipStreamSynchronize(e->stream));   // h lives on this stack frame
+    launch_env_observe(e->stream, V, nullptr, 0, e->pol_x);
+    const bool graph = e->hp.use_graph && !e->profiling;
+    if (graph && !e->g_act) {
+        hipGraph_t g;
+        HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+        for (auto& s : e->act_prog) s.fn(e);
+        HIPCHK(hipStreamEndCapture(e->stream, &g));
+        HIPCHK(hipGraphInstantiate(&e->g_act, g, nullptr, nullptr, 0)); HIPCHK(hipGraphDestroy(g));
+    }
+    long long trained = 0;
+    for (int k = 0; k < n_steps; k++) {
+        const long long t = cfg->t0 + k;
+        if (graph) HIPCHK(hipGraphLaunch(e->g_act, e->stream));
+        else for (auto& s : e->act_prog) { prof_begin(e, s.name); s.fn(e); prof_end(e); }
+        e->widx = (e->widx + n) % e->cap; e->size = std::min(e->cap, e->size + n);
+        if (cfg->train_freq > 0 && t % cfg->train_freq == 0 && e->size >= e->B) { if (run_step(e, true)) return -1; trained++; }     // :134-139
+        if (cfg->target_update_freq > 0 && t % cfg->target_update_freq == 0) { if (dqn_sync_target(e)) return -1; }                // :142-145
+    }
+    launch_env_reset_pending(e->stream, V, e->roll, 0);      // episode bookkeeping of the last step (src/solver.jl:99-132)
+    if (out) {
+        std::vector<long long> fe(n); std::vector<double> fr(n);
+        HIPCHK(hipMemcpyAsync(fe.data(), V.fin_eps, (size_t)n * 8, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(fr.data(), V.fin_reward, (size_t)n * 8, hipMemcpyDeviceToHost, e->stream));
+        out->last_loss = out->last_grad_norm = 0.0f;
+        if (trained) { if (fetch_scalars(e, &out->last_loss, &out->last_grad_norm)) return -1; } else HIPCHK(hipStreamSynchronize(e->stream));
+        out->episodes = 0; out->reward_sum = 0.0; out->train_steps = trained;
+        for (int i = 0; i < n; i++) { out->episodes += fe[i]; out->reward_sum += fr[i]; }
+    }
+    return 0;
+}
+extern "C" int dqn_envs_peek(dqn_engine_t* e, float* obs, int32_t* actions, float* rewards, uint8_t* dones) {
+    HIPCHK(hipSetDevice(e->device));
+    if (!e->has_envs) return fail("no device environments: call dqn_envs_create");
+    EnvDev& V = e->env; const int n = V.n;
+    if (obs) {
+        if (policy_ws(e, n)) return -1;
+        launch_env_observe(e->stream, V, nullptr, 0, e->pol_x);
+        std::vector<float> x((size_t)e->E * n); HIPCHK(hipMemcpyAsync(x.data(), e->pol_x, x.size() * 4, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream));
+        for (int i = 0; i < n; i++) for (int f = 0; f < e->E; f++) obs[(size_t)i * e->E + f] = x[(size_t)f * n + i];
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (actions) HIPCHK(hipMemcpy(actions, V.actions, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (rewards) HIPCHK(hipMemcpy(rewards, V.rewards, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (dones) HIPCHK(hipMemcpy(dones, V.dones, (size_t)n, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 // ---------------------------------------------------------------- data-parallel replicas

@@ -12,6 +12,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -173,15 +174,16 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
 }
 
 static int fwd_pick_nt(const LayerDev& L, long mgroups_total, int S) {
-    // widest N tile (most reuse of the im2col'd A tile) that still yields >= ~400 workgroups; tiny-M problems (dense
-    // layers at B=32) take the widest tile regardless and get their parallelism from split-K
+    // widest N tile (most reuse of the im2col'd A tile) that still yields >= ~400 workgroups.  Dense layers at B=32 stream
+    // their weights once whatever the tile, so they too prefer more, narrower workgroups (measured: FC1 forward 19.2 -> 16.3 us
+    // at NT=2 in the train step, 15.6 -> ~10 us at NT=1 for the 32-column acting forward)
     const int cands[3] = {4, 2, 1};
     int best = 1; long best_wgs = -1;
     for (int c = 0; c < 3; c++) {
         const int nt = cands[c];
         if (L.N % (16 * nt)) continue;
         const long wgs = mgroups_total * (L.N / (16 * nt)) * S;
-        if (wgs >= 400 || mgroups_total <= 8) return nt;
+        if (wgs >= 400) return nt;
         if (wgs > best_wgs) { best_wgs = wgs; best = nt; }
     }
     return best;

@@ -245,32 +245,6 @@ __device__ __forceinline__ void q_column(int nA, int dueling, const float* val, 
     const float mean = sum / (float)nA;
     for (int a = 0; a < nA; a++) q[a] = (v + adv[(size_t)a * ld + col]) - mean;
 }
-// head output (n, col): either the finished activation, or -- when the head's forward ran split-K and its reduction is
-// folded into this kernel -- act(sum_s partial + bias)
-__device__ __forceinline__ float head_val(const HeadSrc& h, int n, int col) {
-    const size_t e = (size_t)n * h.ld + col;
-    if (h.S <= 1) return h.p[e];
-    float tot = h.p[e];
-    int s = 1;
-    for (; s + 8 <= h.S; s += 8) {      // 8 independent slab loads in flight, adds in ascending order
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = h.p[(size_t)(s + u) * h.per_s + e];
-#pragma unroll
-        for (int u = 0; u < 8; u++) tot = tot + v[u];
-    }
-    for (; s < h.S; s++) tot = tot + h.p[(size_t)s * h.per_s + e];
-    return act_f(tot + h.bias[n], h.act);
-}
-__device__ __forceinline__ void q_column_h(int nA, int dueling, const HeadSrc& val, const HeadSrc& adv, int col, float* q, float* vout, float* araw) {
-    for (int a = 0; a < nA; a++) araw[a] = head_val(adv, a, col);
-    if (!dueling) { for (int a = 0; a < nA; a++) q[a] = araw[a]; *vout = 0.0f; return; }
-    const float v = head_val(val, 0, col); *vout = v;
-    float sum = araw[0];
-    for (int a = 1; a < nA; a++) sum = sum + araw[a];
-    const float mean = sum / (float)nA;
-    for (int a = 0; a < nA; a++) q[a] = (v + araw[a]) - mean;
-}
 // NMAX is a compile-time bound on n_actions so that the per-lane Q arrays live in registers (runtime-bounded loops over a
 // local array put it in scratch: 784 B/lane and ~8 us of this single-workgroup kernel before the change)
 template <int NMAX>

@@ -42,6 +42,7 @@ class LinearDecaySchedule:
 class EpsGreedyPolicy:
     def __init__(self, env, eps, rng=None):
         self.n_actions = env.n_actions
+        self.schedule = eps
         self.eps = eps if callable(eps) else (lambda t, e=eps: e)
         self.rng = rng if rng is not None else np.random.default_rng(1)
 
@@ -274,6 +275,7 @@ class DeepQLearningSolver:
     device: int = 0
     obs_dtype: int = _abi.OBS_F32
     seed: int = 0
+    device_envs: bool = False                  # step env.n copies of the MDP on the GPU (dqn_envs_create / dqn_rollout)
 
 
 def initialize_replay_buffer(solver, env, engine):
@@ -341,8 +343,48 @@ def restore_best_model(solver, policy):
     return policy
 
 
+def dqn_train_device(solver, env, policy, replay):
+    """dqn_train! (src/solver.jl:59-178) with the env loop on the device: `env` is only the SPEC (images, grid, rewards) of the
+    env.n copies that dqn_envs_create builds in HBM; exploration uses the engine's Philox eps-greedy with the solver's
+    LinearDecaySchedule.  Differences from the host loop: evaluation runs right at t % eval_freq == 0 (not at the next
+    episode end), on the host copy of the environment."""
+    e = policy.engine
+    e.sync_target()
+    sch = getattr(solver.exploration_policy, "schedule", None)
+    if isinstance(sch, LinearDecaySchedule):
+        eps = (sch.start, sch.stop, sch.steps)
+    else:
+        v = float(solver.exploration_policy.eps(1))
+        eps = (v, v, 1.0)
+    e.envs_create(env, n_envs=env.n, max_episode_length=solver.max_episode_length, seed=solver.seed)
+    saved_mean_reward, scores_eval, model_saved = -np.inf, -np.inf, False
+    marks = sorted({solver.eval_freq, solver.log_freq, solver.save_freq})
+    t, episodes, reward_sum = 1, 0, 0.0
+    while t <= solver.max_steps:
+        nxt = min(min((t + m - 1) // m * m for m in marks), solver.max_steps)      # run up to the next eval/log/save boundary
+        st = e.rollout(nxt - t + 1, t0=t, train_freq=solver.train_freq, target_update_freq=solver.target_update_freq, eps=eps)
+        t = nxt + 1
+        d_eps, d_rew = st["episodes"] - episodes, st["reward_sum"] - reward_sum
+        episodes, reward_sum = st["episodes"], st["reward_sum"]
+        if nxt % solver.eval_freq == 0:
+            scores_eval, _, _ = solver.evaluation_policy(policy, env, solver.num_ep_eval, solver.max_episode_length, solver.verbose)
+            if nxt % solver.save_freq == 0 and solver.logdir is not None:
+                model_saved, saved_mean_reward = save_model(solver, policy, scores_eval, saved_mean_reward, model_saved)
+        if nxt % solver.log_freq == 0 and solver.verbose:
+            avg = d_rew / d_eps if d_eps else float("nan")
+            print(f"{nxt:5d} / {solver.max_steps:5d} eps {max(eps[1], eps[0] - nxt * (eps[0] - eps[1]) / eps[2]):0.3f} |  avgR {avg:1.3f} | "
+                  f"Loss {st['loss']:2.3e} | Grad {st['grad_norm']:2.3e} | EvalR {scores_eval:1.3f}")
+    if model_saved and solver.verbose:
+        restore_best_model(solver, policy)
+    return policy
+
+
 def dqn_train(solver, env, policy, replay):
     """src/solver.jl:59-178.  `env` holds env.n lock-stepped copies (the reference: 1); t counts vector steps."""
+    if solver.device_envs:
+        if solver.recurrence:
+            raise DQNError("device_envs drives the feed-forward path (recurrence = false)")
+        return dqn_train_device(solver, env, policy, replay)
     e = policy.engine
     e.sync_target()                                   # target_q = deepcopy(active_q), :65
     policy.resetstate()

@@ -183,6 +183,39 @@ int dqn_set_hidden(dqn_engine_t* e, const float* hc, size_t n);
 int dqn_forward(dqn_engine_t* e, int which, const float* obs, int n, float* q_out /* [n][nA] */);
 int dqn_greedy_action(dqn_engine_t* e, const float* obs, int n, int32_t* a_out /* first-max tie rule */);
 
+/* ---- vectorised environments on the device (north star: "vectorised parallel environments (SimpleGridWorld /
+ * image-obs MDPs)").  n lock-stepped copies of a built-in MDP live in HBM; one vector step is one iteration of the dqn_train!
+ * loop (src/solver.jl:82-145) for all copies: eps-greedy action from the online net (POMDPTools EpsGreedyPolicy:
+ * rand < eps ? random action : greedy), act!, observe, add_exp!(replay, exp, |r|) straight into the replay ring, episode
+ * bookkeeping (reset on done or max_episode_length), every train_freq vector steps one batch_train!, every
+ * target_update_freq a target sync.  No observation crosses PCIe.  Randomness: Philox4x32-10 keyed by seed, counter =
+ * (global vector step, env, purpose), so the CPU twin reproduces every trajectory bit for bit. */
+enum { DQN_ENV_TESTMDP = 0, DQN_ENV_GRIDWORLD = 1 };
+typedef struct {
+    int32_t kind;               /* DQN_ENV_* */
+    int32_t n_envs;
+    int32_t max_episode_length; /* solver.max_episode_length (100) */
+    uint64_t seed;
+    /* TestMDP (test/test_env.jl:10-87): obs = stack of o_stack of three fixed H x W integer images / 255, chosen by the last
+     * actions; rewards [-0.1, 0, 0.1][sp[end]] x (-10 if s[end] == 2); terminal at t >= max_time; 4 actions */
+    int32_t o_stack, max_time;
+    const uint8_t* images;      /* uint8[3][H*W]: bad, normal, good; H, W from hparams.obs_h/obs_w; obs_c == o_stack */
+    /* SimpleGridWorld (POMDPModels defaults, third-party; recalled): size_x x size_y grid, 4 actions up/down/left/right,
+     * reward cells are terminal, intended move with probability tprob, obs = Float32[x, y] */
+    int32_t size_x, size_y; float tprob; int32_t n_reward_cells; int32_t reward_xy[8][2]; float reward_val[8];
+} dqn_env_spec;
+typedef struct {
+    int32_t train_freq, target_update_freq;     /* solver.train_freq (4), solver.target_update_freq (500); 0 = never */
+    float eps_start, eps_stop, eps_steps;       /* LinearDecaySchedule(start, stop, steps) of the exploration policy */
+    int64_t t0;                                 /* global index of the first vector step of this call (t counts from 1) */
+} dqn_rollout_cfg;
+typedef struct { int64_t episodes; double reward_sum; int64_t train_steps; float last_loss, last_grad_norm; } dqn_rollout_stats;
+int dqn_envs_create(dqn_engine_t* e, const dqn_env_spec* spec);
+int dqn_envs_reset(dqn_engine_t* e);
+int dqn_rollout(dqn_engine_t* e, int n_vector_steps, const dqn_rollout_cfg* cfg, dqn_rollout_stats* stats_or_null);
+/* inspection (parity tests): current observations float[n][C][H][W], last actions int32[n], last rewards float[n], last dones uint8[n] */
+int dqn_envs_peek(dqn_engine_t* e, float* obs, int32_t* actions, float* rewards, uint8_t* dones);
+
 /* data-parallel replicas: all-reduce (SUM over ranks, then * 1/world) of the flat
  * gradient between backward and Adam, over RCCL (dlopen'ed librccl; no reference
  * equivalent).  unique_id: 128 bytes from dqn_comm_unique_id on rank 0. */

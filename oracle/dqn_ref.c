@@ -78,6 +78,7 @@ typedef struct ref_engine {
     float *gx_on[MAXL], *gx_tg[MAXL], *gates[MAXL], *cst[MAXL], *hprev[MAXL], *dgates[MAXL]; /* LSTM workspaces (online s-sequence keeps gates) */
     float *r_a_f, *r_r, *r_done, *r_mask; int32_t* r_a; uint64_t drqn_ctr;
     float* pol_h[MAXL]; float* pol_c[MAXL]; int pol_n;
+    struct ref_envs* envs;
 } ref_engine;
 
 static char g_err[512];
@@ -240,8 +241,10 @@ int ref_set_threads(ref_engine* e, int n) {
 #endif
     return 0;
 }
+static void envs_free(struct ref_envs* v);
 int ref_destroy(ref_engine* e) {
     if (!e) return 0;
+    envs_free(e->envs);
     free(e->p_on); free(e->p_tg); free(e->grad); free(e->m); free(e->v);
     free(e->s_f32); free(e->sp_f32); free(e->s_u8); free(e->sp_u8); free(e->a); free(e->r); free(e->done); free(e->tree);
     free(e->idx); free(e->x0);
@@ -858,5 +861,126 @@ int ref_train_step_drqn(ref_engine* e, const int64_t* ep_idx_in, const int32_t* 
         e->bp1 *= b1; e->bp2 *= b2;
     }
     if (loss_out) *loss_out = e->loss; if (gnorm_out) *gnorm_out = e->gnorm;
+    return 0;
+}
+
+/* ================================================================= vectorised environments
+ * The env loop of dqn_train! (src/solver.jl:82-145) for n lock-stepped copies of TestMDP (test/test_env.jl:10-87) or
+ * SimpleGridWorld (POMDPModels defaults; third-party, recalled).  Randomness: Philox4x32-10, key = seed, counter =
+ * (vector step lo, hi, env, purpose) -- the same draws as deepqlearning.jl_amd/csrc/envs.hip. */
+typedef struct ref_envs {
+    dqn_env_spec sp; int n, E, H, W; uint8_t* images;
+    int8_t* tm_s; int32_t* tm_t; int32_t* gw_pos;
+    int32_t* actions; float* rewards; uint8_t* dones; float* ep_reward; int32_t* ep_step; int64_t* fin_eps; double* fin_reward;
+} ref_envs;
+static uint32_t env_rand(uint64_t seed, uint64_t t, int env, uint32_t purpose) {
+    uint32_t c[4] = {(uint32_t)t, (uint32_t)(t >> 32), (uint32_t)env, purpose};
+    philox((uint32_t)seed, (uint32_t)(seed >> 32), c); return c[0];
+}
+static float u01(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+static void envs_free(struct ref_envs* v) {
+    if (!v) return;
+    free(v->images); free(v->tm_s); free(v->tm_t); free(v->gw_pos); free(v->actions); free(v->rewards); free(v->dones); free(v->ep_reward); free(v->ep_step);
+    free(v->fin_eps); free(v->fin_reward); free(v);
+}
+static void envs_reset_one(ref_envs* v, int i, uint64_t t) {
+    v->ep_reward[i] = 0.0f; v->ep_step[i] = 0;      /* dones[] keeps the flags of the last act! (inspection) */
+    if (v->sp.kind == DQN_ENV_TESTMDP) { for (int k = 0; k < 4; k++) v->tm_s[i * 4 + k] = 1; v->tm_t[i] = 1; }                 /* initialstate, :46-52 */
+    else { v->gw_pos[i * 2] = 1 + (int)(env_rand(v->sp.seed, t, i, 5u) % (uint32_t)v->sp.size_x); v->gw_pos[i * 2 + 1] = 1 + (int)(env_rand(v->sp.seed, t, i, 6u) % (uint32_t)v->sp.size_y); }
+}
+/* observation of env i as float and (TestMDP) as the raw byte */
+static void envs_observe(ref_envs* v, int i, float* of, uint8_t* ob) {
+    if (v->sp.kind == DQN_ENV_TESTMDP) {
+        int hw = v->H * v->W;
+        for (int f = 0; f < v->E; f++) {                                   /* obs[.., c] = observations[s[end - c]], :56-58 */
+            int c = f / hw, px = f % hw; uint8_t b = v->images[(v->tm_s[i * 4 + (3 - c)] - 1) * hw + px];
+            if (of) of[f] = (float)b / 255.0f; if (ob) ob[f] = b;
+        }
+    } else for (int f = 0; f < 2; f++) { if (of) of[f] = (float)v->gw_pos[i * 2 + f]; }
+}
+int ref_envs_reset(ref_engine* e) {
+    if (!e->envs) FAIL("no environments");
+    for (int i = 0; i < e->envs->n; i++) envs_reset_one(e->envs, i, 0);
+    return 0;
+}
+int ref_envs_create(ref_engine* e, const dqn_env_spec* sp) {
+    if (e->hp.recurrence) FAIL("feed-forward only");
+    envs_free(e->envs); e->envs = NULL;
+    ref_envs* v = (ref_envs*)calloc(1, sizeof *v); v->sp = *sp; v->sp.images = NULL; v->n = sp->n_envs; v->E = e->obs_elems; v->H = e->hp.obs_h; v->W = e->hp.obs_w;
+    int n = v->n;
+    if (sp->kind == DQN_ENV_TESTMDP) {
+        if (!sp->images || sp->o_stack != e->hp.obs_c || e->nA != 4) { envs_free(v); FAIL("TestMDP spec does not match the network"); }
+        size_t ib = (size_t)3 * v->H * v->W; v->images = (uint8_t*)malloc(ib); memcpy(v->images, sp->images, ib);
+        v->tm_s = (int8_t*)calloc((size_t)n * 4, 1); v->tm_t = (int32_t*)calloc(n, 4);
+    } else if (sp->kind == DQN_ENV_GRIDWORLD) {
+        if (e->obs_elems != 2 || e->nA != 4 || e->hp.obs_dtype == DQN_OBS_U8) { envs_free(v); FAIL("SimpleGridWorld spec does not match the network"); }
+        v->gw_pos = (int32_t*)calloc((size_t)n * 2, 4);
+    } else { envs_free(v); FAIL("unknown environment kind"); }
+    v->actions = (int32_t*)calloc(n, 4); v->rewards = (float*)calloc(n, 4); v->dones = (uint8_t*)calloc(n, 1); v->ep_reward = (float*)calloc(n, 4);
+    v->ep_step = (int32_t*)calloc(n, 4); v->fin_eps = (int64_t*)calloc(n, 8); v->fin_reward = (double*)calloc(n, 8);
+    e->envs = v;
+    return ref_envs_reset(e);
+}
+static void envs_act(ref_envs* v, int i, int a, uint64_t t) {
+    float r; uint8_t done;
+    if (v->sp.kind == DQN_ENV_TESTMDP) {
+        int8_t* s = v->tm_s + i * 4;
+        int was_second = s[3] == 2;                                       /* :62-64 */
+        int8_t s0 = s[1], s1 = s[2], s2 = s[3], last = a < 3 ? (int8_t)(a + 1) : s2;    /* circshift(s, -1); a < 4 ? a : s_new[end-1], :69-74 */
+        s[0] = s0; s[1] = s1; s[2] = s2; s[3] = last;
+        r = (last == 1 ? -0.1f : (last == 2 ? 0.0f : 0.1f));
+        if (was_second) r = r * -10.0f;                                   /* :77-83 */
+        v->tm_t[i] += 1; done = v->tm_t[i] >= v->sp.max_time;             /* :85-87 */
+    } else {
+        int32_t* p = v->gw_pos + i * 2; float rv = 0.0f;
+        for (int k = 0; k < v->sp.n_reward_cells; k++) if (p[0] == v->sp.reward_xy[k][0] && p[1] == v->sp.reward_xy[k][1]) rv = v->sp.reward_val[k];
+        int at_reward = rv != 0.0f;
+        int intended = u01(env_rand(v->sp.seed, t, i, 3u)) < v->sp.tprob;
+        int other = (int)(env_rand(v->sp.seed, t, i, 4u) % 3u);
+        int eff = intended ? a : (a + 1 + other) % 4;
+        int dx = eff == 2 ? -1 : (eff == 3 ? 1 : 0), dy = eff == 0 ? 1 : (eff == 1 ? -1 : 0);
+        int nx = p[0] + dx, ny = p[1] + dy;
+        if (!at_reward && nx >= 1 && nx <= v->sp.size_x && ny >= 1 && ny <= v->sp.size_y) { p[0] = nx; p[1] = ny; }
+        r = rv; done = (uint8_t)at_reward;
+    }
+    v->actions[i] = a; v->rewards[i] = r; v->dones[i] = done; v->ep_reward[i] += r; v->ep_step[i] += 1;
+}
+int ref_rollout(ref_engine* e, int n_steps, const dqn_rollout_cfg* cfg, dqn_rollout_stats* out) {
+    ref_envs* v = e->envs; if (!v) FAIL("no environments");
+    if (cfg->t0 < 1) FAIL("t0 counts from 1");
+    int n = v->n, E = v->E, u8 = e->hp.obs_dtype == DQN_OBS_U8; int64_t trained = 0; float loss = 0.0f, gn = 0.0f;
+    float* obs = (float*)malloc((size_t)n * E * 4); int32_t* greedy = (int32_t*)malloc((size_t)n * 4); float* td0 = (float*)malloc((size_t)n * 4);
+    size_t rowb = (size_t)E * (u8 ? 1 : 4); uint8_t* srow = (uint8_t*)malloc(rowb * n); uint8_t* sprow = (uint8_t*)malloc(rowb * n);
+    for (int k = 0; k < n_steps; k++) {
+        int64_t t = cfg->t0 + k;
+        float eps = cfg->eps_start - (float)t * ((cfg->eps_start - cfg->eps_stop) / cfg->eps_steps);
+        if (!(cfg->eps_steps > 0.0f) || eps < cfg->eps_stop) eps = cfg->eps_stop;
+        for (int i = 0; i < n; i++) envs_observe(v, i, obs + (size_t)i * E, u8 ? srow + i * rowb : NULL);
+        if (!u8) memcpy(srow, obs, rowb * n);
+        ref_greedy_action(e, obs, n, greedy);
+        for (int i = 0; i < n; i++) {
+            int a = greedy[i];
+            if (u01(env_rand(v->sp.seed, (uint64_t)t, i, 1u)) < eps) a = (int)(env_rand(v->sp.seed, (uint64_t)t, i, 2u) % (uint32_t)e->nA);
+            envs_act(v, i, a, (uint64_t)t);
+            td0[i] = e->hp.prioritized_replay ? fabsf(v->rewards[i]) : 0.0f;
+            if (u8) envs_observe(v, i, NULL, sprow + i * rowb); else envs_observe(v, i, (float*)(sprow + i * rowb), NULL);
+        }
+        if (ref_replay_add(e, srow, v->actions, v->rewards, sprow, v->dones, td0, n)) return -1;
+        for (int i = 0; i < n; i++) if (v->dones[i] || v->ep_step[i] >= v->sp.max_episode_length) {
+            v->fin_eps[i] += 1; v->fin_reward[i] += (double)v->ep_reward[i]; envs_reset_one(v, i, (uint64_t)t);
+        }
+        if (cfg->train_freq > 0 && t % cfg->train_freq == 0 && e->size >= e->B) { if (ref_train_step(e, NULL, &loss, &gn, NULL)) return -1; trained++; }
+        if (cfg->target_update_freq > 0 && t % cfg->target_update_freq == 0) ref_sync_target(e);
+    }
+    if (out) { out->episodes = 0; out->reward_sum = 0.0; out->train_steps = trained; out->last_loss = loss; out->last_grad_norm = gn;
+               for (int i = 0; i < n; i++) { out->episodes += v->fin_eps[i]; out->reward_sum += v->fin_reward[i]; } }
+    free(obs); free(greedy); free(td0); free(srow); free(sprow); return 0;
+}
+int ref_envs_peek(ref_engine* e, float* obs, int32_t* actions, float* rewards, uint8_t* dones) {
+    ref_envs* v = e->envs; if (!v) FAIL("no environments");
+    if (obs) for (int i = 0; i < v->n; i++) envs_observe(v, i, obs + (size_t)i * v->E, NULL);
+    if (actions) memcpy(actions, v->actions, (size_t)v->n * 4);
+    if (rewards) memcpy(rewards, v->rewards, (size_t)v->n * 4);
+    if (dones) memcpy(dones, v->dones, (size_t)v->n);
     return 0;
 }

@@ -1,0 +1,97 @@
+"""GPU (-m gpu): the device-resident env loop (dqn_envs_create / dqn_rollout) against the CPU twin's
+restatement -- BIT-EXACT trajectories (observations, eps-greedy actions, rewards, terminals), replay contents and
+priorities, episode statistics, and the parameters after interleaved training (src/solver.jl:82-145)."""
+import importlib
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+import envs_common as EC
+import ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = ge.load_package()
+    p.lib()
+    return p
+
+
+@pytest.fixture(scope="module")
+def envs(pkg):
+    return importlib.import_module(pkg.__name__ + ".envs")
+
+
+def make_pair(pkg, net, B, cap, **kw):
+    hp = ref.hparams_for(net, batch_size=B, buffer_size=cap, **kw)
+    layers = ref.layers_from_network(net)
+    plan = pkg.default_plan(layers, hp)
+    return pkg.Engine(layers, hp, plan=plan), ref.Twin(layers, hp, plan=plan, threads=8), hp
+
+
+def compare_state(g, t):
+    for x, y in zip(g.envs_peek(), t.envs_peek()):
+        np.testing.assert_array_equal(x, y)
+    assert g.replay_size() == t.replay_size()
+    np.testing.assert_array_equal(g.replay_priorities(), t.replay_priorities())
+
+
+@pytest.mark.parametrize("u8,mfma", [(False, 1), (True, 1), (False, 0)])
+def test_testmdp_rollout_bit_exact(pkg, envs, u8, mfma):
+    net = EC.testmdp_conv_dueling()
+    g, t, hp = make_pair(pkg, net, B=8, cap=96, obs_dtype=1 if u8 else 0, use_mfma=mfma)
+    EC.same_params([g, t], net)
+    spec = envs.TestMDP((14, 12), 4, 6, n=6, seed=3)
+    for h in (g, t):
+        h.envs_create(spec, max_episode_length=100, seed=17)
+    compare_state(g, t)
+    t0 = 1
+    for chunk in (1, 3, 7, 12, 9):          # 32 vector steps: the 96-slot ring wraps, episodes end every 5 steps
+        sg = g.rollout(chunk, t0=t0, train_freq=2, target_update_freq=5, eps=(1.0, 0.1, 20.0))
+        st = t.rollout(chunk, t0=t0, train_freq=2, target_update_freq=5, eps=(1.0, 0.1, 20.0))
+        t0 += chunk
+        assert sg == st, (sg, st)
+        compare_state(g, t)
+        np.testing.assert_array_equal(g.get_params(0), t.get_params(0))
+        np.testing.assert_array_equal(g.get_params(1), t.get_params(1))
+    assert sg["episodes"] > 0 or st["train_steps"] > 0
+    idx = np.arange(8, dtype=np.int64) * 11
+    for x, y in zip(g.get_batch(idx), t.get_batch(idx)):
+        np.testing.assert_array_equal(x, y)
+
+
+def test_gridworld_rollout_bit_exact(pkg, envs):
+    net = EC.gridworld_mlp_dueling()
+    g, t, hp = make_pair(pkg, net, B=32, cap=1024)
+    EC.same_params([g, t], net)
+    spec = envs.SimpleGridWorld(n=64)
+    for h in (g, t):
+        h.envs_create(spec, max_episode_length=20, seed=5)
+    t0 = 1
+    tot_eps = 0
+    for chunk in (5, 40, 55):
+        sg = g.rollout(chunk, t0=t0, train_freq=4, target_update_freq=25, eps=(1.0, 0.05, 60.0))
+        st = t.rollout(chunk, t0=t0, train_freq=4, target_update_freq=25, eps=(1.0, 0.05, 60.0))
+        t0 += chunk
+        assert sg == st, (sg, st)
+        compare_state(g, t)
+        np.testing.assert_array_equal(g.get_params(0), t.get_params(0))
+        tot_eps = sg["episodes"]
+    assert tot_eps >= 64 * 4          # max_episode_length 20 over 100 steps
+
+
+def test_rollout_errors(pkg, envs):
+    net = EC.gridworld_mlp_dueling()
+    g, t, hp = make_pair(pkg, net, B=8, cap=64)
+    with pytest.raises(pkg.DQNError, match="dqn_envs_create"):
+        g.rollout(1)
+    with pytest.raises(pkg.DQNError, match="TestMDP"):
+        g.envs_create(envs.TestMDP((14, 12), 4, 6, n=2))
+    with pytest.raises(pkg.DQNError, match="n_envs"):
+        g.envs_create(envs.SimpleGridWorld(n=65))           # more envs than replay slots
+    g.envs_create(envs.SimpleGridWorld(n=4))
+    with pytest.raises(pkg.DQNError, match="t0"):
+        g.rollout(1, t0=0)

@@ -100,3 +100,26 @@ def test_gridworld_ddrqn_dueling(mods):
     with pytest.raises(pkg.DQNError, match="recurrent model but recurrence is set to false"):
         S.solve(S.DeepQLearningSolver(qnetwork=model, exploration_policy=expl, recurrence=False, verbose=False, logdir=None), env)
     policy.engine.close()
+
+
+def test_testmdp_device_envs(mods):
+    """The reference's TestMDP end-to-end test (test/runtests.jl:45-57: return >= 1.5 of the optimal 2.1) with the env loop on the device:
+    16 lock-stepped copies, eps-greedy and add_exp! in HBM (dqn_rollout), same solver settings."""
+    pkg, nn, envs, S = mods
+    env = envs.TestMDP((5, 5), 4, 6, n=16, seed=7)
+    model = nn.Chain(nn.flattenbatch, nn.Dense(100, 8, nn.tanh), nn.Dense(8, env.n_actions))
+    expl = S.EpsGreedyPolicy(env, S.LinearDecaySchedule(start=1.0, stop=0.01, steps=1000 / 2))
+    solver = S.DeepQLearningSolver(qnetwork=model, max_steps=1000, learning_rate=0.005, exploration_policy=expl, eval_freq=500, num_ep_eval=16, train_freq=1,
+                                   log_freq=500, double_q=False, dueling=False, prioritized_replay=True, verbose=False, logdir=None, device_envs=True,
+                                   buffer_size=4096, train_start=64)
+    policy = S.solve(solver, env)
+    ev = envs.TestMDP((5, 5), 4, 6, n=1, seed=7)
+    tot = 0.0
+    for _ in range(20):
+        ev.reset()
+        r = 0.0
+        while not ev.terminated()[0]:
+            r += float(ev.act(np.array([policy.action(ev.observe()[0])]))[0])
+        tot += r
+    assert tot / 20 >= 1.5
+    policy.engine.close()
