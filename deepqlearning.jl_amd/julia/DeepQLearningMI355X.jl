@@ -181,4 +181,38 @@ POMDPTools.actionvalues(p::HIPNNPolicy, o::AbstractArray) = _q(p, o)
 POMDPs.value(p::HIPNNPolicy, o::AbstractArray) = maximum(_q(p, o))
 sync_target!(p::HIPNNPolicy) = check(ccall((:dqn_sync_target, LIB), Cint, (Ptr{Cvoid},), p.e.h))   # replaces Flux.loadparams! at src/solver.jl:142-145
 
+# ---- device-resident vectorised environments (dqn_env_spec / dqn_rollout_cfg / dqn_rollout_stats, include/dqn_mi355x.h)
+# the env loop of dqn_train! (src/solver.jl:82-145) for n copies of a built-in MDP without observations crossing PCIe
+struct EnvSpec
+    kind::Int32; n_envs::Int32; max_episode_length::Int32; seed::UInt64
+    o_stack::Int32; max_time::Int32; images::Ptr{UInt8}                       # TestMDP: UInt8[H*W, 3] (bad, normal, good)
+    size_x::Int32; size_y::Int32; tprob::Float32; n_reward_cells::Int32
+    reward_xy::NTuple{16,Int32}; reward_val::NTuple{8,Float32}                # SimpleGridWorld reward cells (x1,y1,x2,y2,...)
+end
+struct RolloutCfg
+    train_freq::Int32; target_update_freq::Int32; eps_start::Float32; eps_stop::Float32; eps_steps::Float32; t0::Int64
+end
+mutable struct RolloutStats
+    episodes::Int64; reward_sum::Float64; train_steps::Int64; last_loss::Float32; last_grad_norm::Float32
+    RolloutStats() = new(0, 0.0, 0, 0f0, 0f0)
+end
+function envs_create_gridworld!(e::Engine, mdp; n_envs, max_episode_length = 100, seed = 0)      # mdp::POMDPModels.SimpleGridWorld
+    cells = collect(mdp.rewards); xy = zeros(Int32, 16); rv = zeros(Float32, 8)
+    for (k, (pos, r)) in enumerate(cells); xy[2k-1] = pos[1]; xy[2k] = pos[2]; rv[k] = r; end
+    spec = EnvSpec(1, n_envs, max_episode_length, seed, 0, 0, C_NULL, mdp.size[1], mdp.size[2], mdp.tprob, length(cells), Tuple(xy), Tuple(rv))
+    check(ccall((:dqn_envs_create, LIB), Cint, (Ptr{Cvoid}, Ref{EnvSpec}), e.h, spec))
+end
+function envs_create_testmdp!(e::Engine, images::Matrix{UInt8}, o_stack, max_time; n_envs, max_episode_length = 100, seed = 0)
+    GC.@preserve images begin
+        spec = EnvSpec(0, n_envs, max_episode_length, seed, o_stack, max_time, pointer(images), 0, 0, 0f0, 0, ntuple(_ -> Int32(0), 16), ntuple(_ -> 0f0, 8))
+        check(ccall((:dqn_envs_create, LIB), Cint, (Ptr{Cvoid}, Ref{EnvSpec}), e.h, spec))
+    end
+end
+function rollout!(e::Engine, n_steps; t0 = 1, train_freq = 4, target_update_freq = 500, eps = (1f0, 0.01f0, 5000f0))
+    st = RolloutStats()
+    check(ccall((:dqn_rollout, LIB), Cint, (Ptr{Cvoid}, Cint, Ref{RolloutCfg}, Ref{RolloutStats}), e.h, n_steps,
+                RolloutCfg(train_freq, target_update_freq, eps[1], eps[2], eps[3], t0), st))
+    st
+end
+
 end # module
