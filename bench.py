@@ -48,6 +48,12 @@ def build_workload(pkg, args, rank, device):
     env.rng = np.random.default_rng(1000 + rank)
     filled = 0
     o = env.observe()
+    if args.device_fill:
+        n_fill = min(1024, args.replay)
+        eng.envs_create(env, n_envs=n_fill, max_episode_length=100, seed=1000 + rank)
+        eng.rollout(-(-args.replay // n_fill), t0=1, train_freq=0, target_update_freq=0, eps=(1.0, 1.0, 1.0), stats=False)   # eps = 1: uniform-random actions
+        eng.sync()
+        filled = args.replay
     while filled < args.replay:
         a = env.rng.integers(0, 4, env.n)
         r = env.act(a)
@@ -63,13 +69,13 @@ def build_workload(pkg, args, rank, device):
 ADAM_EXTRA_BYTES = [0.0]
 
 
-def op_cost(name, eng_layers, B, ncon, E, P):
+def op_cost(name, eng_layers, B, ncon, E, P, obs_bytes=4):
     """algorithmic (flops, bytes) of one profiled launch by its program name.
     fwd_<l>      forward of layer l AND its sibling (val/adv) for the online net on [s;sp] and the target net on sp
     dw_<l>/dw2_<l>  dW+db of layer l (dw2: both sibling layers);  dx_<l>/dx_join_<l>  dX of layer l (join: both streams)"""
     parts = name.split("_")
     if name in ("gather", "sample_gather"):
-        return 0.0, 2.0 * B * E * 4 * 2          # rows read + batch arena written
+        return 0.0, 2.0 * B * E * (obs_bytes + 4)   # rows read (u8 or f32) + fp32 batch arena written
     if name == "adam":
         return 0.0, P * 28.0 + ADAM_EXTRA_BYTES[0]   # p,m,v,g read + p,m,v written (+ the conv dW split-K slabs it reduces on a single GPU)
     digits = "".join(ch for ch in parts[-1] if ch.isdigit())
@@ -113,6 +119,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--device-fill", action="store_true", help="fill the replay with the device-resident env loop (uniform-random policy, eps = 1) instead of host rollouts + PCIe; needed for config 5's 1e6-transition replay")
     ap.add_argument("--env-steps", type=int, default=200, help="vector steps of the device-resident env loop timed after the main metric (0 = skip)")
     ap.add_argument("--fc-kc", type=int, default=0, help="experiment: override fwd_kc of the wide dense layers")
     args = ap.parse_args()
@@ -215,7 +222,7 @@ def main():
                 a[1] += 1
         kern = {k: v[0] / v[1] for k, v in acc.items()}
         dom = max(kern, key=kern.get)
-        fl, by = op_cost(dom, g2, B, ncon, E, P)
+        fl, by = op_cost(dom, g2, B, ncon, E, P, 1 if args.u8 else 4)
         if fl > 0:
             roof = dict(kernel=dom, bound="mfma", achieved=fl / (kern[dom] * 1e-3) / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", traffic=None)
         else:
@@ -226,6 +233,10 @@ def main():
         roof["step_flops"] = step_flops
         roof["step_mfma_frac"] = (value / world) * step_flops / (PEAK_F32_MFMA_TFLOPS * 1e12)
         roof["eager_kernel_ms"] = {k: round(v, 5) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])[:12]}
+        gname = "sample_gather" if "sample_gather" in kern else "gather"
+        gbytes = op_cost(gname, g2, B, ncon, E, P, 1 if args.u8 else 4)[1]
+        roof["gather"] = {"avg_launch_ms": kern[gname], "algorithmic_bytes": gbytes, "achieved_GBs": gbytes / (kern[gname] * 1e-3) / 1e9,
+                          "frac_of_hbm_peak": gbytes / (kern[gname] * 1e-3) / 1e9 / PEAK_HBM_GBS}
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

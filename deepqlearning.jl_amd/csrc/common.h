@@ -104,7 +104,14 @@ __device__ __forceinline__ void prio_update_block(int n, long long cap2, const l
     for (int i = threadIdx.x; i < n; i += blockDim.x) sidx[i] = (cap2 + sidx[i]) >> 1;
     __syncthreads();
     for (long long width = cap2; width > 1; width >>= 1) {
-        for (int i = threadIdx.x; i < n; i += blockDim.x) { const long long node = sidx[i]; tree[node] = tree[2 * node] + tree[2 * node + 1]; sidx[i] = node >> 1; }
+        // up to 4 nodes per thread (n <= 1024 at 256 threads): all child loads are issued before any store, so a level costs one
+        // memory round trip however many nodes a thread owns
+        long long nd[4]; float vs[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int i = threadIdx.x + u * blockDim.x; nd[u] = -1; if (i < n) { nd[u] = sidx[i]; vs[u] = tree[2 * nd[u]] + tree[2 * nd[u] + 1]; } }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int i = threadIdx.x + u * blockDim.x; if (nd[u] >= 0) { tree[nd[u]] = vs[u]; sidx[i] = nd[u] >> 1; } }
+        for (int i = threadIdx.x + 4 * blockDim.x; i < n; i += blockDim.x) { const long long node = sidx[i]; tree[node] = tree[2 * node] + tree[2 * node + 1]; sidx[i] = node >> 1; }
         __syncthreads();
     }
 }
@@ -149,7 +156,7 @@ void launch_transpose_obs(hipStream_t st, const float* obs /*[n][E]*/, int E, in
 void launch_replay_commit(hipStream_t st, int n, long long start, long long cap, long long cap2, const int* a_in, const float* r_in,
                           const unsigned char* done_in, const float* td_in, float eps, float alpha, int* a, float* r,
                           unsigned char* done, float* tree, StepState* state);
-void launch_sample(hipStream_t st, int B, long long cap2, const float* tree, unsigned long long seed, long long* idx, StepState* state);
+void launch_sample(hipStream_t st, int B, long long cap2, const float* tree, unsigned long long seed, long long* idx, StepState* state, int bump);
 void launch_batch_meta(hipStream_t st, int B, long long cap2, const long long* idx, const int* a, const float* r,
                        const unsigned char* done, const float* tree, float beta, const StepState* state,
                        int* a_out, float* r_out, float* done_out, float* w_out);

@@ -398,7 +398,7 @@ static int check_idx(dqn_engine* e, const int64_t* idx, int n) {
 extern "C" int dqn_replay_sample(dqn_engine_t* e, int64_t* idx_out) {
     if (e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");   // ...replay.jl:83
     HIPCHK(hipSetDevice(e->device));
-    launch_sample(e->stream, e->B, e->cap2, e->tree, e->hp.seed, e->idx, e->state);
+    launch_sample(e->stream, e->B, e->cap2, e->tree, e->hp.seed, e->idx, e->state, 1);
     if (idx_out) { HIPCHK(hipMemcpyAsync(idx_out, e->idx, (size_t)e->B * 8, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); }
     return 0;
 }
@@ -496,7 +496,9 @@ static int build_program(dqn_engine* e) {
     HeadSrc head[DQN_MAX_LAYERS][2];   // per (layer, net): where k_td finds the layer's output
     // ---------------- forward: online net on [s ; sp] (src/solver.jl:210,220), target net on sp (:211)
     for (size_t li = 0; li < levels.size(); li++) {
-        const auto& lv = levels[li]; const bool last = li + 1 == levels.size() && !rec;
+        // the head layers' split-K slabs are reduced inside the single-workgroup TD kernel only while that is cheaper than a reduce
+        // launch (small batches); at B = 512 the 7680 head values x 16 slabs belong on many workgroups
+        const auto& lv = levels[li]; const bool last = li + 1 == levels.size() && !rec && e->B <= 64;
         struct Prob { int l, net; const float *P, *X; int ldx, col0, ncols; float *Y, *part; int S; };
         std::vector<Prob> pr;
         for (int l : lv) for (int net = 0; net < 2; net++) {
@@ -724,9 +726,14 @@ static void enqueue_step(dqn_engine* e, bool sample, int phase) {
             EpGatherArgs g; g.ep_s = e->ep_s; g.ep_sp = e->ep_sp; g.ep_a = e->ep_a; g.ep_r = e->ep_r; g.ep_done = e->ep_done; g.ep_len = e->ep_len; g.ep_idx = e->ep_idx; g.ep_start = e->ep_start;
             g.E = e->E; g.B = e->B; g.T = e->T; g.x0 = e->x0; g.a_out = e->r_a; g.r_out = e->r_r; g.done_out = e->r_done; g.mask_out = e->r_mask;
             RUN(e, "gather_episodes", launch_gather_episodes(e->stream, g));
-        } else
-        RUN(e, sample ? "sample_gather" : "gather", launch_gather_fb(e->stream, e->s_rows, e->sp_rows, e->hp.obs_dtype == DQN_OBS_U8, e->E, e->B, e->idx, e->x0,
-                                                                   sample ? 1 : 0, e->cap2, e->tree, e->hp.seed, e->state));
+        } else {
+            // the descent is fused into the gather (every workgroup repeats it) while that is cheaper than a launch of its own:
+            // small batches.  At B = 512 / 1e6 leaves the repeats cost more than the ~5 us launch, so sample once, then gather.
+            const bool fused = sample && e->B <= 64;
+            if (sample && !fused) RUN(e, "sample", launch_sample(e->stream, e->B, e->cap2, e->tree, e->hp.seed, e->idx, e->state, 0));    // k_td bumps the Philox counter
+            RUN(e, fused ? "sample_gather" : "gather", launch_gather_fb(e->stream, e->s_rows, e->sp_rows, e->hp.obs_dtype == DQN_OBS_U8, e->E, e->B, e->idx, e->x0,
+                                                                        fused ? 1 : 0, e->cap2, e->tree, e->hp.seed, e->state));
+        }
         for (size_t i = 0; i < e->prog_post_begin; i++) {
             if ((long)i == e->final_reduce_step && e->adam_segs.n > 0 && !e->comm) continue;   // folded into k_adam
             RUN(e, e->prog[i].name, e->prog[i].fn(e));

@@ -85,8 +85,58 @@ __global__ __launch_bounds__(256) void k_gather_fb(const void* __restrict__ s_ro
         if (f < E && c < ld) x0[(size_t)f * ld + c] = tile[lane][fl];
     }
 }
+// u8 rows (config 5: 1e6 transitions, 28 224 B each): 256 features x 64 columns per workgroup so that every sampled row is
+// read in 256-B segments (one uchar4 per lane, 16 independent loads in flight per thread); 4x fewer workgroups than the f32
+// tiling also means 4x fewer repeats of the descent when it is fused.
+__global__ __launch_bounds__(256) void k_gather_fb_u8(const unsigned char* __restrict__ s_rows, const unsigned char* __restrict__ sp_rows, int E, int B,
+                                                      long long* __restrict__ idx, float* __restrict__ x0, int do_sample, long long cap2,
+                                                      const float* __restrict__ tree, unsigned long long seed, const StepState* __restrict__ state) {
+    extern __shared__ float tile8[];                     // [64][257]
+    __shared__ long long rows[64];
+    const int f0 = blockIdx.x * 256, c0 = blockIdx.y * 64, ld = 2 * B;
+    if (threadIdx.x < 64) {
+        const int c = c0 + threadIdx.x;
+        long long r = 0;
+        if (c < ld) {
+            const int i = c < B ? c : c - B;
+            if (do_sample) {
+                r = tree_descend(tree, cap2, state->size, seed, state->sample_ctr, i, tree[1] / (float)B);
+                if (blockIdx.x == 0 && c < B) idx[i] = r;
+            } else r = idx[i];
+        }
+        rows[threadIdx.x] = r;
+    }
+    __syncthreads();
+    uint32_t v[16];
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+        const int q = threadIdx.x + 256 * p, cl = q >> 6, c = c0 + cl, f = f0 + 4 * (q & 63);
+        v[p] = 0;
+        if (c < ld && f < E) v[p] = *reinterpret_cast<const uint32_t*>((c < B ? s_rows : sp_rows) + rows[cl] * E + f);      // E % 4 == 0
+    }
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+        const int q = threadIdx.x + 256 * p, cl = q >> 6, fl = 4 * (q & 63);
+        float* t = tile8 + cl * 257 + fl;
+        t[0] = (float)(v[p] & 0xffu) / 255.0f; t[1] = (float)((v[p] >> 8) & 0xffu) / 255.0f;       // test/test_env.jl:59
+        t[2] = (float)((v[p] >> 16) & 0xffu) / 255.0f; t[3] = (float)(v[p] >> 24) / 255.0f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int p = 0; p < 64; p++) {
+        const int fl = p * 4 + w, f = f0 + fl, c = c0 + lane;
+        if (f < E && c < ld) x0[(size_t)f * ld + c] = tile8[lane * 257 + fl];
+    }
+}
 void launch_gather_fb(hipStream_t st, const void* s_rows, const void* sp_rows, int obs_u8, int E, int B, long long* idx, float* x0, int do_sample,
                       long long cap2, const float* tree, unsigned long long seed, const StepState* state) {
+    if (obs_u8 && (E & 3) == 0) {
+        dim3 grid((E + 255) / 256, (2 * B + 63) / 64);
+        hipLaunchKernelGGL(k_gather_fb_u8, grid, dim3(256), 64 * 257 * sizeof(float), st, (const unsigned char*)s_rows, (const unsigned char*)sp_rows, E, B, idx, x0,
+                           do_sample, cap2, tree, seed, state);
+        return;
+    }
     dim3 grid((E + 63) / 64, (2 * B + 63) / 64);
     hipLaunchKernelGGL(k_gather_fb, grid, dim3(256), 0, st, s_rows, sp_rows, obs_u8, E, B, idx, x0, do_sample, cap2, tree, seed, state);
 }
@@ -153,17 +203,17 @@ void launch_replay_commit(hipStream_t st, int n, long long start, long long cap,
 
 // ------------------------------------------------------------------ sample
 __global__ __launch_bounds__(1024) void k_sample(int B, long long cap2, const float* __restrict__ tree, unsigned long long seed,
-                                                 long long* __restrict__ idx, StepState* state) {
+                                                 long long* __restrict__ idx, StepState* state, int bump) {
     const unsigned long long ctr = state->sample_ctr;
     const long long size = state->size;
     const float total = tree[1], seg = total / (float)B;
     for (int i = threadIdx.x; i < B; i += blockDim.x) idx[i] = tree_descend(tree, cap2, size, seed, ctr, i, seg);
     __syncthreads();
-    if (threadIdx.x == 0) state->sample_ctr = ctr + 1;
+    if (threadIdx.x == 0 && bump) state->sample_ctr = ctr + 1;
 }
-void launch_sample(hipStream_t st, int B, long long cap2, const float* tree, unsigned long long seed, long long* idx, StepState* state) {
+void launch_sample(hipStream_t st, int B, long long cap2, const float* tree, unsigned long long seed, long long* idx, StepState* state, int bump) {
     int bs = ((B + 63) / 64) * 64; if (bs > 1024) bs = 1024;
-    hipLaunchKernelGGL(k_sample, dim3(1), dim3(bs), 0, st, B, cap2, tree, seed, idx, state);
+    hipLaunchKernelGGL(k_sample, dim3(1), dim3(bs), 0, st, B, cap2, tree, seed, idx, state, bump);
 }
 
 // ------------------------------------------------------------------ get_batch scalars + IS weights (parity seam)

@@ -156,6 +156,21 @@ def test_u8_replay_bit_exact(pkg):
         assert_step_bit_exact(gpu, cpu)
 
 
+@pytest.mark.parametrize("u8", [False, True])
+def test_large_batch_paths_bit_exact(pkg, u8):
+    """B > 64 switches the step program to its large-batch shape (config 5 runs B = 512): the sampler is a launch of its own instead of
+    being repeated inside every gather workgroup, the head split-K slabs go through the multi-workgroup reduce instead of the TD kernel,
+    u8 rows use the 256-byte-segment gather, and the priority block of the Adam launch owns several tree nodes per thread."""
+    net = small_conv_dueling()
+    gpu, cpu, _ = make_pair(pkg, net, 320, cap=2048, obs_dtype=1 if u8 else 0, learning_rate=1e-3, gamma=0.99)
+    fill((gpu, cpu), net, 1500, u8=u8)
+    set_same_params((gpu, cpu), net)
+    for _ in range(4):
+        assert_step_bit_exact(gpu, cpu)
+    np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+    np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
+
+
 def test_policy_forward_and_greedy(pkg):
     net = small_conv_dueling()
     gpu, cpu, _ = make_pair(pkg, net, 16)
