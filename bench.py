@@ -284,13 +284,15 @@ def cpu_baseline(pkg, layers, hp, params, env, args):
         o = env.observe()
     tw.train_step()
     # OpenMP scaling of the twin is poor past a few dozen threads (short loops): take the fastest of a few counts
-    best, cores = None, 1
+    best, cores, single = None, 1, None
     for th in sorted({1, min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu)}):
         tw.set_threads(th)
         tw.train_step()
         t0 = time.perf_counter()
         tw.train_step()
         dt1 = time.perf_counter() - t0
+        if th == 1:
+            single = 1.0 / dt1
         if best is None or dt1 < best:
             best, cores = dt1, th
     tw.set_threads(cores)
@@ -301,10 +303,58 @@ def cpu_baseline(pkg, layers, hp, params, env, args):
         tw.train_step()
     dt = time.perf_counter() - t0
     tw.close()
-    return {"value": k / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+    return {"value": k / dt, "unit": "steps/s", "cores": cores, "kind": "port", "nproc": ncpu, "single_thread_value": single,
+            "torch_cpu": torch_cpu_line(hp, min(5.0, args.cpu_seconds)),
             "sample": f"{k} train steps of the same config (B={hp.batch_size}, Nature-DQN dueling) on a 512-transition replay, "
                       f"oracle/dqn_ref.c with OpenMP over {cores} threads (best of 1/8/16/32/64 on a {ncpu}-CPU host); the Julia/Flux reference cannot run in this image"}
 
 
 if __name__ == "__main__":
     main()
+
+
+def torch_cpu_line(hp, seconds):
+    """A "well-optimised CPU library" sanity line next to the twin: the same train step -- Nature-DQN dueling, double-Q
+    target, IS-weighted Huber, backward, Adam -- in eager PyTorch on the host cores (oneDNN convolutions).  A proxy for the Flux CPU
+    path, not a parity reference: random weights and batch, no replay."""
+    import torch
+    import torch.nn.functional as F
+    B, nA = hp.batch_size, hp.n_actions
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1, self.c2, self.c3 = torch.nn.Conv2d(4, 32, 8, 4), torch.nn.Conv2d(32, 64, 4, 2), torch.nn.Conv2d(64, 64, 3, 1)
+            self.v1, self.v2 = torch.nn.Linear(3136, 512), torch.nn.Linear(512, 1)
+            self.a1, self.a2 = torch.nn.Linear(3136, 512), torch.nn.Linear(512, nA)
+
+        def forward(self, x):
+            x = F.relu(self.c3(F.relu(self.c2(F.relu(self.c1(x)))))).flatten(1)
+            v, a = self.v2(F.relu(self.v1(x))), self.a2(F.relu(self.a1(x)))
+            return v + a - a.mean(1, keepdim=True)
+
+    torch.manual_seed(0)
+    on, tg = Net(), Net()
+    opt = torch.optim.Adam(on.parameters(), lr=1e-4)
+    s, sp = torch.rand(B, 4, 84, 84), torch.rand(B, 4, 84, 84)
+    a, r, d, w = torch.randint(0, nA, (B,)), torch.randn(B), (torch.rand(B) < 0.2).float(), torch.rand(B) + 0.5
+
+    def step():
+        with torch.no_grad():
+            best = on(sp).argmax(1)
+            y = r + (1 - d) * hp.gamma * tg(sp).gather(1, best[:, None])[:, 0]
+        td = on(s).gather(1, a[:, None])[:, 0] - y
+        x = (w * td).abs()
+        m = torch.clamp(x, max=1.0)
+        loss = (0.5 * m * m + (x - m)).sum() / B
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    step()
+    t0 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t0 < seconds:
+        step()
+        k += 1
+    return {"value": k / (time.perf_counter() - t0), "unit": "steps/s", "threads": torch.get_num_threads(), "kind": "eager PyTorch CPU (oneDNN), proxy"}

@@ -135,6 +135,7 @@ PROTOS = {
     "envs_reset": [_vp],
     "rollout": [_vp, C.c_int, _P(RolloutCfg), _P(RolloutStats)],
     "envs_peek": [_vp, _f32p, _i32p, _f32p, _u8p],
+    "evaluate": [_vp, C.c_int, C.c_int, C.c_uint64, _f64p, _f64p],
 }
 # twin spellings that differ from the product's
 _TWIN_ALIASES = {"engine_create": "create", "engine_destroy": "destroy", "engine_get_plan": "get_plan"}
@@ -386,6 +387,12 @@ class Handle:
         st = RolloutStats()
         self._check(self.f["rollout"](self._h, int(n_steps), C.byref(cfg), C.byref(st) if stats else None))
         return dict(episodes=st.episodes, reward_sum=st.reward_sum, train_steps=st.train_steps, loss=st.last_loss, grad_norm=st.last_grad_norm) if stats else None
+
+    def evaluate(self, n_eval, max_episode_length=100, seed=0):
+        """basic_evaluation on the device: (average return, average steps) of n_eval greedy episodes."""
+        r, st = C.c_double(), C.c_double()
+        self._check(self.f["evaluate"](self._h, int(n_eval), int(max_episode_length), int(seed), C.byref(r), C.byref(st)))
+        return r.value, st.value
 
     def envs_peek(self):
         n = self.n_envs

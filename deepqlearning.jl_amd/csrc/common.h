@@ -237,7 +237,7 @@ __device__ __forceinline__ void q_column_h(int nA, int dueling, const HeadSrc& v
 
 // ---- vectorised environments on the device (envs.hip)
 struct EnvDev {
-    int kind, n, E, H, W, nA, max_episode_length, prioritized; unsigned long long seed;
+    int kind, n, E, H, W, nA, max_episode_length, prioritized, eval_mode; unsigned long long seed;
     // TestMDP
     const unsigned char* images; signed char *tm_s, *tm_prev; int* tm_t; int max_time;
     // SimpleGridWorld

@@ -86,7 +86,10 @@ struct dqn_engine {
     hipGraphExec_t g_drqn = nullptr;
     // static launch program
     struct Step { const char* name; std::function<void(dqn_engine*)> fn; };
-    std::vector<Step> act_prog; std::vector<Step>* sink = nullptr; int act_prog_n = 0; hipGraphExec_t g_act = nullptr; RolloutDev* roll = nullptr;
+    // acting programs (forward on n columns + env kernels), one for the training envs and one for the evaluation envs
+    struct ActProg { std::vector<Step> steps; int n = 0; hipGraphExec_t graph = nullptr; std::vector<void*> allocs; };
+    ActProg act, evalp; std::vector<Step>* sink = nullptr; std::vector<void*>* alloc_sink = nullptr; RolloutDev *roll = nullptr, *eval_roll = nullptr;
+    EnvDev eval_env{}; int eval_n = 0;
     std::vector<Step> prog; size_t prog_post_begin = 0; bool prog_built = false, step_sampled = true;
     AdamSegs adam_segs; long final_reduce_step = -1;   // deferred dW slabs: reduced inside k_adam unless a communicator needs the materialised gradient
     std::vector<void*> prog_allocs; std::vector<std::string> prog_names;
@@ -268,9 +271,15 @@ static void drop_graphs(dqn_engine* e) {
         if (e->g_pre[i]) { hipGraphExecDestroy(e->g_pre[i]); e->g_pre[i] = nullptr; }
     }
     if (e->g_post) { hipGraphExecDestroy(e->g_post); e->g_post = nullptr; }
-    if (e->g_act) { hipGraphExecDestroy(e->g_act); e->g_act = nullptr; }
+    for (dqn_engine::ActProg* a : {&e->act, &e->evalp}) if (a->graph) { hipGraphExecDestroy(a->graph); a->graph = nullptr; }
 }
 static void free_envs(dqn_engine* e);
+static void drop_act(dqn_engine* e, dqn_engine::ActProg& a) {
+    if (a.graph) { hipGraphExecDestroy(a.graph); a.graph = nullptr; }
+    if (!a.allocs.empty()) hipStreamSynchronize(e->stream);
+    for (void* p : a.allocs) hipFree(p);
+    a.allocs.clear(); a.steps.clear(); a.n = 0;
+}
 static void free_policy_ws(dqn_engine* e) {
     hipFree(e->pol_obs); hipFree(e->pol_x); hipFree(e->pol_q); hipFree(e->pol_a);
     for (int i = 0; i < e->nl; i++) { hipFree(e->pol_act[i]); e->pol_act[i] = nullptr; }
@@ -450,9 +459,9 @@ enum { PH_ALL = 0, PH_PRE = 1, PH_POST = 2 };
 // launch per network level, one k_reduce_multi per level, head reductions folded into k_td.
 template <class T> static T* upload(dqn_engine* e, const std::vector<T>& v) {
     T* d = nullptr; hipMalloc((void**)&d, sizeof(T) * v.size()); hipMemcpy(d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice);
-    e->prog_allocs.push_back(d); return d;
+    (e->alloc_sink ? *e->alloc_sink : e->prog_allocs).push_back(d); return d;
 }
-static float* palloc(dqn_engine* e, size_t n) { float* d = nullptr; hipMalloc((void**)&d, n * 4); e->prog_allocs.push_back(d); return d; }
+static float* palloc(dqn_engine* e, size_t n) { float* d = nullptr; hipMalloc((void**)&d, n * 4); (e->alloc_sink ? *e->alloc_sink : e->prog_allocs).push_back(d); return d; }
 static bool same_geo(const LayerDev& a, const LayerDev& b) {
     return a.kind == b.kind && a.act == b.act && a.K == b.K && a.N == b.N && a.npos == b.npos && a.cin == b.cin && a.kh == b.kh && a.kw == b.kw &&
            a.sh == b.sh && a.sw == b.sw && a.ih == b.ih && a.iw == b.iw && a.fwd_kc == b.fwd_kc && a.src == b.src;
@@ -818,7 +827,7 @@ extern "C" int dqn_get_last_indices(dqn_engine_t* e, int64_t* idx) {
 // ---------------------------------------------------------------- policy (src/policy.jl:38-64)
 static int policy_ws(dqn_engine* e, int n) {
     if (n <= e->pol_n) return 0;
-    HIPCHK(hipStreamSynchronize(e->stream)); free_policy_ws(e); e->act_prog_n = 0; e->act_prog.clear(); if (e->g_act) { hipGraphExecDestroy(e->g_act); e->g_act = nullptr; }
+    HIPCHK(hipStreamSynchronize(e->stream)); free_policy_ws(e); drop_act(e, e->act); drop_act(e, e->evalp);
     size_t need = 1;   // split-K partials of the widest forward at n columns
     for (int i = 0; i < e->nl; i++) { const size_t sf = dqn_nchunks(e->L[i].K, e->L[i].fwd_kc); if (sf > 1) need = std::max(need, sf * (size_t)e->L[i].out_feat * n); }
     if (need > e->partials_elems) { drop_graphs(e); hipFree(e->partials); e->partials = nullptr; DM(e->partials, 2 * need); e->partials_elems = need; }
@@ -993,12 +1002,18 @@ extern "C" int dqn_set_hidden(dqn_engine_t* e, const float* hc, size_t n) {   //
 }
 
 // ---------------------------------------------------------------- vectorised environments on the device
+static void free_env_arrays(EnvDev& V) {      // the per-copy arrays of an evaluation env set (images and spec are shared with the training set)
+    hipFree(V.tm_s); hipFree(V.tm_prev); hipFree(V.tm_t); hipFree(V.gw_pos); hipFree(V.gw_prev);
+    hipFree(V.actions); hipFree(V.rewards); hipFree(V.dones); hipFree(V.pending); hipFree(V.ep_reward); hipFree(V.ep_step); hipFree(V.fin_eps); hipFree(V.fin_reward);
+    memset(&V, 0, sizeof V);
+}
 static void free_envs(dqn_engine* e) {
     EnvDev& V = e->env;
     hipFree(e->env_images); hipFree(V.tm_s); hipFree(V.tm_prev); hipFree(V.tm_t); hipFree(V.gw_pos); hipFree(V.gw_prev); hipFree(e->roll);
     hipFree(V.actions); hipFree(V.rewards); hipFree(V.dones); hipFree(V.pending); hipFree(V.ep_reward); hipFree(V.ep_step); hipFree(V.fin_eps); hipFree(V.fin_reward);
     e->env_images = nullptr; e->roll = nullptr; memset(&V, 0, sizeof V); e->has_envs = false;
-    e->act_prog.clear(); e->act_prog_n = 0; if (e->g_act) { hipGraphExecDestroy(e->g_act); e->g_act = nullptr; }
+    free_env_arrays(e->eval_env); hipFree(e->eval_roll); e->eval_roll = nullptr; e->eval_n = 0;
+    drop_act(e, e->act); drop_act(e, e->evalp);
 }
 extern "C" int dqn_envs_create(dqn_engine_t* e, const dqn_env_spec* sp) {
     HIPCHK(hipSetDevice(e->device));
@@ -1040,12 +1055,13 @@ extern "C" int dqn_envs_reset(dqn_engine_t* e) {
 }
 // the acting program: online net forward on the n columns of pol_x (batch-innermost), then Q columns + first-max argmax
 // (action(policy, obs), src/policy.jl:38-64) -- the same tiled kernels and the same plan as the train step, compiled once per n
-static int build_act_program(dqn_engine* e, int n) {
-    if (e->act_prog_n == n) return 0;
-    if (policy_ws(e, n)) return -1;
-    e->act_prog.clear(); if (e->g_act) { hipGraphExecDestroy(e->g_act); e->g_act = nullptr; }
+static int build_act_program(dqn_engine* e, dqn_engine::ActProg& ap, const EnvDev& V, RolloutDev* rs) {
+    const int n = V.n;
+    if (ap.n == n) return 0;
+    if (policy_ws(e, std::max(n, std::max(e->env.n, e->eval_n)))) return -1;      // one workspace serves both env sets (no realloc when they alternate)
+    drop_act(e, ap);
     e->prog_names.reserve(512);
-    e->sink = &e->act_prog;
+    e->sink = &ap.steps; e->alloc_sink = &ap.allocs;
     const bool mf = e->hp.use_mfma != 0;
     std::vector<std::vector<int>> levels; std::vector<int> val, adv;
     for (int i = 0; i < e->nl; i++) { if (e->L[i].stream == DQN_STREAM_BASE) levels.push_back({i}); else if (e->L[i].stream == DQN_STREAM_VAL) val.push_back(i); else adv.push_back(i); }
@@ -1064,7 +1080,7 @@ static int build_act_program(dqn_engine* e, int n) {
             const LayerDev L = e->L[pr[ids[0]].l]; const int np = (int)ids.size();
             struct A { const float *W[4], *bias[4], *X[4]; int ldx[4], col0[4], ncols[4]; float* out[4]; } a;
             for (int i = 0; i < np; i++) { const Prob& q = pr[ids[i]]; const LayerDev& Lq = e->L[q.l]; a.W[i] = P + Lq.w_off; a.bias[i] = P + Lq.b_off; a.X[i] = q.X; a.ldx[i] = n; a.col0[i] = 0; a.ncols[i] = n; a.out[i] = q.S > 1 ? q.part : q.Y; }
-            e->act_prog.push_back({name, [=](dqn_engine* en) { launch_gemm_fwd(en->stream, L, np, a.W, a.bias, a.X, a.ldx, a.col0, a.ncols, a.out); }});
+            ap.steps.push_back({name, [=](dqn_engine* en) { launch_gemm_fwd(en->stream, L, np, a.W, a.bias, a.X, a.ldx, a.col0, a.ncols, a.out); }});
             for (int id : ids) done[id] = true;
         };
         if (mf && pr.size() <= 4) {
@@ -1077,7 +1093,7 @@ static int build_act_program(dqn_engine* e, int n) {
         for (size_t i = 0; i < pr.size(); i++) {
             if (done[i]) continue;
             const Prob q = pr[i]; const LayerDev L = e->L[q.l];
-            if (mf && mfma_fwd_ok(L, n)) e->act_prog.push_back({pname(e, "act_fwd", L.kind, q.l), [=](dqn_engine* en) { launch_mfma_fwd(en->stream, L, P, q.X, n, 0, n, q.Y, q.part, false); }});
+            if (mf && mfma_fwd_ok(L, n)) ap.steps.push_back({pname(e, "act_fwd", L.kind, q.l), [=](dqn_engine* en) { launch_mfma_fwd(en->stream, L, P, q.X, n, 0, n, q.Y, q.part, false); }});
             else { VTask t; memset(&t, 0, sizeof t); t.kind = 0; t.L = L; t.P = P; t.X = q.X; t.ldx = n; t.col0 = 0; t.ncols = n; t.S = q.S; t.kc = dqn_chunk_len(L.K, L.fwd_kc); t.out = q.S > 1 ? q.part : q.Y; add_valu(e, pend, t); }
         }
         flush_valu(e, pend, pname(e, "act_fwd_valu", e->L[lv[0]].kind, lv[0]));
@@ -1093,40 +1109,42 @@ static int build_act_program(dqn_engine* e, int n) {
         }
         emit_reduce(e, segs, pname(e, "act_reduce", e->L[lv[0]].kind, lv[0]));
     }
-    e->sink = nullptr;
+    e->sink = nullptr; e->alloc_sink = nullptr;
     const int lq = e->hp.dueling ? e->last_adv : e->last_base;
     ActHeads Hd; memset(&Hd, 0, sizeof Hd); Hd.adv = head[lq]; if (e->hp.dueling) Hd.val = head[e->last_val]; Hd.dueling = e->hp.dueling; Hd.q_out = e->pol_q; Hd.amax = e->pol_a;
     // act!, add_exp!, observe, episode bookkeeping
-    const EnvDev V = e->env; RolloutDev* rs = e->roll; const bool u8 = e->hp.obs_dtype == DQN_OBS_U8;
+    const bool u8 = e->hp.obs_dtype == DQN_OBS_U8;
     ReplayMeta R; R.cap = e->cap; R.cap2 = e->cap2; R.a = e->ra; R.r = e->rr; R.done = e->rdone; R.tree = e->tree; R.state = e->state; R.eps = e->hp.prio_eps; R.alpha = e->hp.prio_alpha;
-    void *srows = e->s_rows, *sprows = e->sp_rows; float* px = e->pol_x; const long long cap = e->cap;
-    e->act_prog.push_back({"env_step_commit", [=](dqn_engine* en) { launch_env_step(en->stream, V, rs, Hd, R); }});
-    e->act_prog.push_back({"env_observe", [=](dqn_engine* en) { launch_env_observe2(en->stream, V, rs, u8, srows, sprows, cap, px); }});
-    e->act_prog_n = n; return 0;
+    void *srows = e->s_rows, *sprows = e->sp_rows; float* px = e->pol_x; const long long cap = e->cap; const EnvDev Vc = V;
+    ap.steps.push_back({"env_step_commit", [=](dqn_engine* en) { launch_env_step(en->stream, Vc, rs, Hd, R); }});
+    ap.steps.push_back({"env_observe", [=](dqn_engine* en) { launch_env_observe2(en->stream, Vc, rs, u8, srows, sprows, cap, px); }});
+    ap.n = n; return 0;
+}
+static int act_graph(dqn_engine* e, dqn_engine::ActProg& ap) {
+    if (ap.graph) return 0;
+    hipGraph_t g;
+    HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+    for (auto& s : ap.steps) s.fn(e);
+    HIPCHK(hipStreamEndCapture(e->stream, &g));
+    HIPCHK(hipGraphInstantiate(&ap.graph, g, nullptr, nullptr, 0)); HIPCHK(hipGraphDestroy(g)); return 0;
 }
 extern "C" int dqn_rollout(dqn_engine_t* e, int n_steps, const dqn_rollout_cfg* cfg, dqn_rollout_stats* out) {
     HIPCHK(hipSetDevice(e->device));
     if (!e->has_envs) return fail("no device environments: call dqn_envs_create");
     if (cfg->t0 < 1) return fail("t0 counts from 1 (src/solver.jl:82)");
     EnvDev& V = e->env; const int n = V.n;
-    if (build_act_program(e, n)) return -1;
+    if (build_act_program(e, e->act, V, e->roll)) return -1;
     if (cfg->train_freq > 0 && build_program(e)) return -1;       // may reallocate split-K workspaces: before any capture
     RolloutDev h; h.t = cfg->t0 - 1; h.widx = ((e->widx - n) % e->cap + e->cap) % e->cap; h.eps_start = cfg->eps_start; h.eps_stop = cfg->eps_stop; h.eps_steps = cfg->eps_steps; h.pad = 0;
     HIPCHK(hipMemcpyAsync(e->roll, &h, sizeof h, hipMemcpyHostToDevice, e->stream)); HIPCHK(hipStreamSynchronize(e->stream));   // h lives on this stack frame
     launch_env_observe(e->stream, V, nullptr, 0, e->pol_x);
     const bool graph = e->hp.use_graph && !e->profiling;
-    if (graph && !e->g_act) {
-        hipGraph_t g;
-        HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-        for (auto& s : e->act_prog) s.fn(e);
-        HIPCHK(hipStreamEndCapture(e->stream, &g));
-        HIPCHK(hipGraphInstantiate(&e->g_act, g, nullptr, nullptr, 0)); HIPCHK(hipGraphDestroy(g));
-    }
+    if (graph && act_graph(e, e->act)) return -1;
     long long trained = 0;
     for (int k = 0; k < n_steps; k++) {
         const long long t = cfg->t0 + k;
-        if (graph) HIPCHK(hipGraphLaunch(e->g_act, e->stream));
-        else for (auto& s : e->act_prog) { prof_begin(e, s.name); s.fn(e); prof_end(e); }
+        if (graph) HIPCHK(hipGraphLaunch(e->act.graph, e->stream));
+        else for (auto& s : e->act.steps) { prof_begin(e, s.name); s.fn(e); prof_end(e); }
         e->widx = (e->widx + n) % e->cap; e->size = std::min(e->cap, e->size + n);
         if (cfg->train_freq > 0 && t % cfg->train_freq == 0 && e->size >= e->B) { if (run_step(e, true)) return -1; trained++; }     // :134-139
         if (cfg->target_update_freq > 0 && t % cfg->target_update_freq == 0) { if (dqn_sync_target(e)) return -1; }                // :142-145
@@ -1141,6 +1159,53 @@ extern "C" int dqn_rollout(dqn_engine_t* e, int n_steps, const dqn_rollout_cfg* 
         out->episodes = 0; out->reward_sum = 0.0; out->train_steps = trained;
         for (int i = 0; i < n; i++) { out->episodes += fe[i]; out->reward_sum += fr[i]; }
     }
+    return 0;
+}
+// basic_evaluation (src/evaluation_policy.jl:17-42) on the device: n_eval copies of the training MDP run one greedy episode each
+// (while !done && step <= max_episode_length), rewards summed in Float64 like the reference's r_tot; returns the averages.
+extern "C" int dqn_evaluate(dqn_engine_t* e, int n_eval, int max_episode_length, uint64_t seed, double* avg_reward, double* avg_steps) {
+    HIPCHK(hipSetDevice(e->device));
+    if (!e->has_envs) return fail("no device environments: call dqn_envs_create (the evaluation copies share its MDP)");
+    if (n_eval < 1 || n_eval > 1024) return fail("n_eval must be in 1..1024");
+    if (max_episode_length < 1) return fail("max_episode_length must be >= 1");
+    EnvDev& W = e->eval_env;
+    if (e->eval_n != n_eval) {
+        HIPCHK(hipStreamSynchronize(e->stream)); drop_act(e, e->evalp); free_env_arrays(W); hipFree(e->eval_roll); e->eval_roll = nullptr; e->eval_n = 0;
+        W = e->env; W.n = n_eval; W.eval_mode = 1;
+        W.tm_s = W.tm_prev = nullptr; W.tm_t = nullptr; W.gw_pos = W.gw_prev = nullptr; W.actions = nullptr; W.rewards = nullptr; W.dones = W.pending = nullptr;
+        W.ep_reward = nullptr; W.ep_step = nullptr; W.fin_eps = nullptr; W.fin_reward = nullptr;
+        if (W.kind == DQN_ENV_TESTMDP) { DM(W.tm_s, (size_t)n_eval * 4); DM(W.tm_prev, (size_t)n_eval * 4); DM(W.tm_t, n_eval); }
+        else { DM(W.gw_pos, (size_t)n_eval * 2); DM(W.gw_prev, (size_t)n_eval * 2); }
+        DM(W.actions, n_eval); DM(W.rewards, n_eval); DM(W.dones, n_eval); DM(W.pending, n_eval); DM(W.ep_reward, n_eval); DM(W.ep_step, n_eval); DM(W.fin_eps, n_eval); DM(W.fin_reward, n_eval);
+        DM(e->eval_roll, 1);
+        e->eval_n = n_eval;
+    }
+    if (W.seed != seed || W.max_episode_length != max_episode_length) { W.seed = seed; W.max_episode_length = max_episode_length; drop_act(e, e->evalp); }   // baked into the program
+    if (build_act_program(e, e->evalp, W, e->eval_roll)) return -1;
+    RolloutDev h; memset(&h, 0, sizeof h);                                   // t = 0; eps schedule (0, 0, 1): always greedy
+    h.eps_steps = 1.0f;
+    HIPCHK(hipMemcpyAsync(e->eval_roll, &h, sizeof h, hipMemcpyHostToDevice, e->stream)); HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemsetAsync(W.fin_reward, 0, (size_t)n_eval * 8, e->stream));
+    launch_env_reset_pending(e->stream, W, e->eval_roll, 1);                   // reset!(env), resetstate!(policy)
+    launch_env_observe(e->stream, W, nullptr, 0, e->pol_x);
+    const bool graph = e->hp.use_graph && !e->profiling;
+    if (graph && act_graph(e, e->evalp)) return -1;
+    std::vector<unsigned char> pend(n_eval);
+    for (int k = 0; k <= max_episode_length; k++) {
+        if (graph) HIPCHK(hipGraphLaunch(e->evalp.graph, e->stream)); else for (auto& s : e->evalp.steps) s.fn(e);
+        if ((k & 7) == 7) {     // every 8 vector steps: stop early once every episode is over
+            HIPCHK(hipMemcpyAsync(pend.data(), W.pending, n_eval, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream));
+            bool alive = false; for (int i = 0; i < n_eval; i++) alive = alive || !pend[i];
+            if (!alive) break;
+        }
+    }
+    std::vector<double> fr(n_eval); std::vector<int> st(n_eval);
+    HIPCHK(hipMemcpyAsync(fr.data(), W.fin_reward, (size_t)n_eval * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(st.data(), W.ep_step, (size_t)n_eval * 4, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream));
+    double r = 0.0, s = 0.0;
+    for (int i = 0; i < n_eval; i++) { r += fr[i]; s += (double)st[i]; }      // avg_r += r_tot; avg_steps += step, episode order
+    if (avg_reward) *avg_reward = r / n_eval;
+    if (avg_steps) *avg_steps = s / n_eval;
     return 0;
 }
 extern "C" int dqn_envs_peek(dqn_engine_t* e, float* obs, int32_t* actions, float* rewards, uint8_t* dones) {

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(1024) void k_env_step(EnvDev V, RolloutDev* rs, Act
     }
     if (threadIdx.x == 0) { rs->t = (long long)t; rs->widx = start; }
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        if (V.eval_mode && V.pending[i]) continue;              // evaluation: one episode per copy, finished copies idle
         if (V.pending[i]) {
             V.fin_eps[i] += 1; V.fin_reward[i] += (double)V.ep_reward[i]; V.ep_reward[i] = 0.0f; V.ep_step[i] = 0; V.pending[i] = 0;
             store_reset(V, i, t_prev);
@@ -170,6 +171,9 @@ __global__ __launch_bounds__(1024) void k_env_step(EnvDev V, RolloutDev* rs, Act
             r = rv; done = at_reward;
         }
         V.actions[i] = a; V.rewards[i] = r; V.dones[i] = done; V.ep_reward[i] += r; V.ep_step[i] += 1;
+        if (V.eval_mode) {      // basic_evaluation: r_tot += rew in Float64; while !done && step <= max_episode_length (src/evaluation_policy.jl:27-34)
+            V.fin_reward[i] += (double)r; V.pending[i] = (done || V.ep_step[i] > V.max_episode_length) ? 1 : 0; continue;
+        }
         V.pending[i] = (done || V.ep_step[i] >= V.max_episode_length) ? 1 : 0;
         const long long slot = (start + i) % R.cap;
         R.a[slot] = a; R.r[slot] = r; R.done[slot] = done ? 1 : 0;
@@ -178,6 +182,7 @@ __global__ __launch_bounds__(1024) void k_env_step(EnvDev V, RolloutDev* rs, Act
         const float pr = prio_f(td, R.eps, R.alpha);
         R.tree[R.cap2 + slot] = pr; lvl[0][i] = pr;
     }
+    if (V.eval_mode) return;                                    // no add_exp! (uniform branch: eval_mode is a kernel argument)
     const long long s0 = start % R.cap, e0 = (start + n - 1) % R.cap;
     const bool wrap = n >= R.cap || e0 < s0;
     if (!wrap) {
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(256) void k_env_observe2(EnvDev V, const RolloutDev
 #pragma unroll
         for (int u = 0; u < VEC; u++) {
             uint32_t sw; int px, py, tm = 0; load_state(V, (int)(i0 + u), &sw, &px, &py);
-            if (V.pending[i0 + u]) reset_state(V, (int)(i0 + u), t, &sw, &tm, &px, &py);
+            if (V.pending[i0 + u] && !V.eval_mode) reset_state(V, (int)(i0 + u), t, &sw, &tm, &px, &py);
             unsigned char b; nx[u] = obs_elem(V, sw, px, py, (int)f, &b);
         }
         *(FloatV*)(x + (size_t)f * n + i0) = *(const FloatV*)nx;
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(256) void k_env_observe2(EnvDev V, const RolloutDev
 }
 void launch_env_observe2(hipStream_t st, const EnvDev& V, const RolloutDev* rs, int rows_u8, void* s_rows, void* sp_rows, long long cap, float* x) {
     const bool v4 = V.E % 4 == 0 && V.n % 4 == 0; const unsigned vec = v4 ? 4 : 1;
-    const unsigned bx = (V.E / vec + 255) / 256, rows_blocks = bx * V.n, x_blocks = (unsigned)(((size_t)V.n / vec * V.E + 255) / 256);
+    const unsigned bx = (V.E / vec + 255) / 256, rows_blocks = V.eval_mode ? 0 : bx * V.n, x_blocks = (unsigned)(((size_t)V.n / vec * V.E + 255) / 256);
     const dim3 g(rows_blocks + x_blocks), b(256);
     if (rows_u8) { if (v4) hipLaunchKernelGGL((k_env_observe2<unsigned char, 4>), g, b, 0, st, V, rs, (unsigned char*)s_rows, (unsigned char*)sp_rows, cap, x, bx, rows_blocks);
                    else hipLaunchKernelGGL((k_env_observe2<unsigned char, 1>), g, b, 0, st, V, rs, (unsigned char*)s_rows, (unsigned char*)sp_rows, cap, x, bx, rows_blocks); }

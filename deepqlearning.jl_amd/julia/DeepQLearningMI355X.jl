@@ -208,6 +208,11 @@ function envs_create_testmdp!(e::Engine, images::Matrix{UInt8}, o_stack, max_tim
         check(ccall((:dqn_envs_create, LIB), Cint, (Ptr{Cvoid}, Ref{EnvSpec}), e.h, spec))
     end
 end
+function evaluate(e::Engine, n_eval, max_episode_length; seed = 0)                   # basic_evaluation (src/evaluation_policy.jl:17-42) on the device
+    r = Ref{Float64}(0); st = Ref{Float64}(0)
+    check(ccall((:dqn_evaluate, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, UInt64, Ref{Float64}, Ref{Float64}), e.h, n_eval, max_episode_length, seed, r, st))
+    r[], st[]
+end
 function rollout!(e::Engine, n_steps; t0 = 1, train_freq = 4, target_update_freq = 500, eps = (1f0, 0.01f0, 5000f0))
     st = RolloutStats()
     check(ccall((:dqn_rollout, LIB), Cint, (Ptr{Cvoid}, Cint, Ref{RolloutCfg}, Ref{RolloutStats}), e.h, n_steps,

@@ -347,7 +347,7 @@ def dqn_train_device(solver, env, policy, replay):
     """dqn_train! (src/solver.jl:59-178) with the env loop on the device: `env` is only the SPEC (images, grid, rewards) of the
     env.n copies that dqn_envs_create builds in HBM; exploration uses the engine's Philox eps-greedy with the solver's
     LinearDecaySchedule.  Differences from the host loop: evaluation runs right at t % eval_freq == 0 (not at the next
-    episode end), on the host copy of the environment."""
+    episode end); the default basic_evaluation runs on the device too (dqn_evaluate), a user-supplied one on the host copy."""
     e = policy.engine
     e.sync_target()
     sch = getattr(solver.exploration_policy, "schedule", None)
@@ -367,7 +367,12 @@ def dqn_train_device(solver, env, policy, replay):
         d_eps, d_rew = st["episodes"] - episodes, st["reward_sum"] - reward_sum
         episodes, reward_sum = st["episodes"], st["reward_sum"]
         if nxt % solver.eval_freq == 0:
-            scores_eval, _, _ = solver.evaluation_policy(policy, env, solver.num_ep_eval, solver.max_episode_length, solver.verbose)
+            if solver.evaluation_policy is basic_evaluation:        # the default rollout evaluation also runs on the device
+                scores_eval, steps_eval = e.evaluate(min(solver.num_ep_eval, 1024), solver.max_episode_length, seed=solver.seed + nxt)
+                if solver.verbose:
+                    print(f"Evaluation ... Avg Reward {scores_eval:2.2f} | Avg Step {steps_eval:2.2f}")
+            else:
+                scores_eval, _, _ = solver.evaluation_policy(policy, env, solver.num_ep_eval, solver.max_episode_length, solver.verbose)
             if nxt % solver.save_freq == 0 and solver.logdir is not None:
                 model_saved, saved_mean_reward = save_model(solver, policy, scores_eval, saved_mean_reward, model_saved)
         if nxt % solver.log_freq == 0 and solver.verbose:

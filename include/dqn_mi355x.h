@@ -213,6 +213,10 @@ typedef struct { int64_t episodes; double reward_sum; int64_t train_steps; float
 int dqn_envs_create(dqn_engine_t* e, const dqn_env_spec* spec);
 int dqn_envs_reset(dqn_engine_t* e);
 int dqn_rollout(dqn_engine_t* e, int n_vector_steps, const dqn_rollout_cfg* cfg, dqn_rollout_stats* stats_or_null);
+/* basic_evaluation (src/evaluation_policy.jl:17-42; cadence src/solver.jl:101-122) batched on the device: n_eval
+ * further copies of the MDP given to dqn_envs_create each run ONE greedy episode (while !done && step <= max_episode_length); returns
+ * the average undiscounted return (Float64 sum of the Float32 rewards, as r_tot) and the average step count. */
+int dqn_evaluate(dqn_engine_t* e, int n_eval, int max_episode_length, uint64_t seed, double* avg_reward, double* avg_steps);
 /* inspection (parity tests): current observations float[n][C][H][W], last actions int32[n], last rewards float[n], last dones uint8[n] */
 int dqn_envs_peek(dqn_engine_t* e, float* obs, int32_t* actions, float* rewards, uint8_t* dones);
 

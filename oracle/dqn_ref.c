@@ -984,3 +984,36 @@ int ref_envs_peek(ref_engine* e, float* obs, int32_t* actions, float* rewards, u
     if (dones) memcpy(dones, v->dones, (size_t)v->n);
     return 0;
 }
+
+/* basic_evaluation (src/evaluation_policy.jl:17-42): n_eval fresh copies of the MDP of ref_envs_create, one greedy episode each,
+ * while !done && step <= max_episode_length; r_tot accumulates in Float64.  Same Philox draws as dqn_evaluate (seed, t from 1). */
+int ref_evaluate(ref_engine* e, int n_eval, int max_episode_length, uint64_t seed, double* avg_reward, double* avg_steps) {
+    ref_envs* tr = e->envs; if (!tr) FAIL("no environments");
+    ref_envs v = *tr; int n = n_eval, E = tr->E;
+    v.n = n; v.sp.seed = seed;
+    v.tm_s = (int8_t*)calloc((size_t)n * 4, 1); v.tm_t = (int32_t*)calloc(n, 4); v.gw_pos = (int32_t*)calloc((size_t)n * 2, 4);
+    v.actions = (int32_t*)calloc(n, 4); v.rewards = (float*)calloc(n, 4); v.dones = (uint8_t*)calloc(n, 1); v.ep_reward = (float*)calloc(n, 4);
+    v.ep_step = (int32_t*)calloc(n, 4); v.fin_eps = NULL; v.fin_reward = NULL;
+    float* obs = (float*)malloc((size_t)n * E * 4); int32_t* greedy = (int32_t*)malloc((size_t)n * 4);
+    uint8_t* over = (uint8_t*)calloc(n, 1); double* rtot = (double*)calloc(n, 8);
+    for (int i = 0; i < n; i++) envs_reset_one(&v, i, 0);
+    for (int k = 0; k <= max_episode_length; k++) {
+        uint64_t t = (uint64_t)k + 1;
+        for (int i = 0; i < n; i++) envs_observe(&v, i, obs + (size_t)i * E, NULL);
+        ref_greedy_action(e, obs, n, greedy);
+        int alive = 0;
+        for (int i = 0; i < n; i++) {
+            if (over[i]) continue;
+            envs_act(&v, i, greedy[i], t);
+            rtot[i] += (double)v.rewards[i];
+            over[i] = v.dones[i] || v.ep_step[i] > max_episode_length;
+            alive |= !over[i];
+        }
+        if (!alive) break;
+    }
+    double r = 0.0, st = 0.0;
+    for (int i = 0; i < n; i++) { r += rtot[i]; st += (double)v.ep_step[i]; }
+    if (avg_reward) *avg_reward = r / n; if (avg_steps) *avg_steps = st / n;
+    free(v.tm_s); free(v.tm_t); free(v.gw_pos); free(v.actions); free(v.rewards); free(v.dones); free(v.ep_reward); free(v.ep_step);
+    free(obs); free(greedy); free(over); free(rtot); return 0;
+}

@@ -129,6 +129,26 @@ def test_training_cadence_and_target_sync():
     assert not np.array_equal(tw.get_params(0), p0)
 
 
+def test_evaluate_matches_host_rollout():
+    """ref_evaluate = basic_evaluation (src/evaluation_policy.jl:17-42): greedy episodes, undiscounted Float64 return, step count;
+    `while !done && step <= max_episode_length` runs max_episode_length + 1 steps when the episode does not end."""
+    net = EC.testmdp_conv_dueling()
+    tw, hp = make_twin(net)
+    EC.same_params([tw], net)
+    tw.envs_create(envs.TestMDP((14, 12), 4, 6, n=4, seed=3), seed=1)
+    host = envs.TestMDP((14, 12), 4, 6, n=1, seed=3)
+    r, st = 0.0, 0
+    while not host.terminated()[0] and st <= 100:
+        r += float(host.act(tw.greedy_action(host.observe()))[0]); st += 1
+    assert tw.evaluate(7, 100, seed=9) == (r, float(st))          # deterministic MDP: every copy runs the same episode
+    assert tw.evaluate(3, 2, seed=9)[1] == 3.0                     # truncated at max_episode_length + 1 steps
+    # the training envs are untouched by an evaluation
+    before = tw.envs_peek()
+    tw.evaluate(5, 10)
+    for x, y in zip(before, tw.envs_peek()):
+        np.testing.assert_array_equal(x, y)
+
+
 def test_errors():
     net = EC.gridworld_mlp_dueling()
     tw, hp = make_twin(net)

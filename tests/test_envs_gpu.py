@@ -83,6 +83,31 @@ def test_gridworld_rollout_bit_exact(pkg, envs):
     assert tot_eps >= 64 * 4          # max_episode_length 20 over 100 steps
 
 
+@pytest.mark.parametrize("kind", ["testmdp", "testmdp_u8", "gridworld"])
+def test_evaluate_bit_exact_and_isolated(pkg, envs, kind):
+    """dqn_evaluate (device basic_evaluation) == the twin's: average return (Float64) and steps identical; the training envs, the
+    replay and the rollout that follows are not disturbed by an evaluation in between."""
+    if kind == "gridworld":
+        net, spec, n, mel = EC.gridworld_mlp_dueling(), envs.SimpleGridWorld(n=8), 8, 30
+        g, t, hp = make_pair(pkg, net, B=8, cap=256)
+    else:
+        net, spec, n, mel = EC.testmdp_conv_dueling(), envs.TestMDP((14, 12), 4, 6, n=8, seed=3), 8, 100
+        g, t, hp = make_pair(pkg, net, B=8, cap=256, obs_dtype=1 if kind.endswith("u8") else 0)
+    EC.same_params([g, t], net)
+    for h in (g, t):
+        h.envs_create(spec, max_episode_length=mel, seed=2)
+        h.rollout(6, t0=1, train_freq=2, target_update_freq=0, eps=(0.5, 0.5, 1.0))
+    for n_eval, mx, seed in ((16, mel, 7), (16, mel, 8), (5, 3, 7), (40, mel, 1)):
+        assert g.evaluate(n_eval, mx, seed) == t.evaluate(n_eval, mx, seed)
+    compare_state(g, t)
+    sg = g.rollout(9, t0=7, train_freq=2, target_update_freq=4, eps=(0.5, 0.5, 1.0))
+    st = t.rollout(9, t0=7, train_freq=2, target_update_freq=4, eps=(0.5, 0.5, 1.0))
+    assert sg == st
+    compare_state(g, t)
+    np.testing.assert_array_equal(g.get_params(0), t.get_params(0))
+    assert g.evaluate(16, mel, 7) == t.evaluate(16, mel, 7)
+
+
 def test_rollout_errors(pkg, envs):
     net = EC.gridworld_mlp_dueling()
     g, t, hp = make_pair(pkg, net, B=8, cap=64)
