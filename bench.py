@@ -37,6 +37,8 @@ def build_workload(pkg, args, rank, device):
                              learning_rate=1e-4, gamma=0.99, double_q=1, dueling=1, prioritized_replay=1, buffer_size=args.replay,
                              seed=1234 + rank, use_graph=0 if args.no_graph else 1, use_mfma=0 if args.no_mfma else 1)
     plan = None
+    if args.conv_kc:
+        plan = [(args.conv_kc if (d.kind == pkg._abi.LAYER_CONV and d.cin * d.kh * d.kw > args.conv_kc) else p[0], p[1], p[2]) for d, p in zip(layers, pkg.default_plan(layers, hp))]
     if args.fc_kc:      # experiment knob: forward split-K chunk of the 3136-wide dense layers (the plan only fixes rounding order)
         plan = [(args.fc_kc if (d.kind == pkg._abi.LAYER_DENSE and d.n_in > 1024) else p[0], p[1], p[2]) for d, p in zip(layers, pkg.default_plan(layers, hp))]
     eng = pkg.Engine(layers, hp, plan=plan, device=device)
@@ -121,6 +123,7 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--device-fill", action="store_true", help="fill the replay with the device-resident env loop (uniform-random policy, eps = 1) instead of host rollouts + PCIe; needed for config 5's 1e6-transition replay")
     ap.add_argument("--env-steps", type=int, default=200, help="vector steps of the device-resident env loop timed after the main metric (0 = skip)")
+    ap.add_argument("--conv-kc", type=int, default=0, help="experiment: forward split-K chunk of the conv layers")
     ap.add_argument("--fc-kc", type=int, default=0, help="experiment: override fwd_kc of the wide dense layers")
     args = ap.parse_args()
 

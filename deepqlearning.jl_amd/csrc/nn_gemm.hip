@@ -122,6 +122,11 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the epilogue's bias values are requested now: their latency (a cold line, ~1-2 us) rides under the K loop instead of
+    // stalling every workgroup at its end.  (An older outstanding load only makes the counted vmcnt waits conservative.)
+    float bias_r[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) bias_r[t] = S == 1 ? p.bias[n0 + 16 * t + l15] : 0.0f;
     auto compute = [&](int buf) {
         const float* Ab = As + buf * F_KT * F_SA + 16 * wave + l15;
         const float* Bb = Bs + buf * F_KT * SB + l15;
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
         const int n = n0 + 16 * t + l15;
         f32x4 v = acc[t];
         if (S == 1) {
-            const float bias = p.bias[n];
+            const float bias = bias_r[t];
             v.x = act_f(v.x + bias, L.act); v.y = act_f(v.y + bias, L.act); v.z = act_f(v.z + bias, L.act); v.w = act_f(v.w + bias, L.act);
         }
         *reinterpret_cast<f32x4*>(p.out + (size_t)s * per_s + ((size_t)n * L.npos + pos) * p.ncols + ct * 16 + 4 * kq) = v;
@@ -394,16 +399,20 @@ __device__ __forceinline__ void dx_lds_body(const LayerDev& L, const GDxArgs& A,
     const int khw = L.kh * L.kw;
     if (dense) { const int n0 = s * kc, n1 = min(L.N, n0 + kc); nkt = (n1 - n0) / 32; }
     else {
-        if (tid == 0) {
-            const int iy = ip / L.iw, ix = ip % L.iw; int c = 0;
-            for (int ky = 0; ky < L.kh; ky++) {
-                const int ty = iy - ky; if (ty < 0 || ty % L.sh) continue; const int oy = ty / L.sh; if (oy >= L.oh) continue;
-                for (int kx = 0; kx < L.kw; kx++) {
-                    const int tx = ix - kx; if (tx < 0 || tx % L.sw) continue; const int ox = tx / L.sw; if (ox >= L.ow) continue;
-                    taps[c++] = ((ky * L.kw + kx) << 16) | (oy * L.ow + ox);
+        // taps of input position ip: kernel offsets (ky, kx) whose output position exists; lane (ky*kw + kx) of wave 0 tests its own
+        // tap and a ballot prefix compacts them in (ky, kx)-ascending order -- the canonical contraction order
+        if (tid < 64) {
+            const int iy = ip / L.iw, ix = ip % L.iw; bool ok = false; int val = 0;
+            if (tid < L.kh * L.kw) {
+                const int ky = tid / L.kw, kx = tid % L.kw, ty = iy - ky, tx = ix - kx;
+                if (ty >= 0 && tx >= 0 && ty % L.sh == 0 && tx % L.sw == 0) {
+                    const int oy = ty / L.sh, ox = tx / L.sw;
+                    if (oy < L.oh && ox < L.ow) { ok = true; val = (tid << 16) | (oy * L.ow + ox); }
                 }
             }
-            taps[255] = c;
+            const unsigned long long m = __ballot(ok);
+            if (ok) taps[__popcll(m & ((1ull << tid) - 1ull))] = val;
+            if (tid == 0) taps[255] = __popcll(m);
         }
         __syncthreads();
         nkt = taps[255] * (L.N / 32);
@@ -435,6 +444,11 @@ __device__ __forceinline__ void dx_lds_body(const LayerDev& L, const GDxArgs& A,
     };
 #define STAGE_WAIT(N, r) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.a), "+v"(r.b) : "n"(N) : "memory")
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // epilogue operands requested up front (see k_fwd_lds): the producer's activation for the fused act' multiply
+    const int fl_e = f0 + 16 * ft + l15;
+    const size_t feat_e = dense ? (size_t)min(fl_e, nfeat - 1) : (size_t)min(fl_e, nfeat - 1) * L.ih * L.iw + ip;
+    f32x4 y_e = {0.f, 0.f, 0.f, 0.f};
+    if (S == 1 && A.ysrc) y_e = *reinterpret_cast<const f32x4*>(A.ysrc + feat_e * A.ldy + b0 + 16 * mt + 4 * kq);
     auto compute = [&](int buf, bool second) {
         const float* Ab = As + buf * 32 * X_SA + 16 * mt + l15;
         const float* Bb = Bs + (buf * 32 + 16 * ft + l15) * X_SB + kq;
@@ -475,7 +489,7 @@ __device__ __forceinline__ void dx_lds_body(const LayerDev& L, const GDxArgs& A,
     if (A.nsrc > 1) { v.x = v.x + acc1.x; v.y = v.y + acc1.y; v.z = v.z + acc1.z; v.w = v.w + acc1.w; }
     const size_t per_s = (size_t)L.in_feat * B;
     if (S == 1 && A.ysrc) {
-        const f32x4 y = *reinterpret_cast<const f32x4*>(A.ysrc + feat * A.ldy + bcol);
+        const f32x4 y = y_e;
         v.x = dact_f(v.x, y.x, A.act_src); v.y = dact_f(v.y, y.y, A.act_src); v.z = dact_f(v.z, y.z, A.act_src); v.w = dact_f(v.w, y.w, A.act_src);
     }
     *reinterpret_cast<f32x4*>(A.out + (size_t)s * per_s + feat * B + bcol) = v;
@@ -498,7 +512,7 @@ bool gemm_dx_eligible(const LayerDev& L, int B, int ldy) {
     const bool dense = L.kind == DQN_LAYER_DENSE;
     const int S = dense ? dqn_nchunks(L.N, L.dx_kc) : 1, kc = dqn_chunk_len(L.N, L.dx_kc);
     if (B % 32 || ldy % 4 || L.N % 32 || (S > 1 && kc % 32) || L.w_off % 4) return false;
-    if (!dense && (L.cin % 32 || L.kh * L.kw > 255 || L.npos > 65535)) return false;
+    if (!dense && (L.cin % 32 || L.kh * L.kw > 64 || L.npos > 65535)) return false;
     return true;
 }
 // nsrc == 2: the two dueling streams (identical geometry, S == 1), out = dact(dX_src0 + dX_src1)
