@@ -312,8 +312,6 @@ def cpu_baseline(pkg, layers, hp, params, env, args):
                       f"oracle/dqn_ref.c with OpenMP over {cores} threads (best of 1/8/16/32/64 on a {ncpu}-CPU host); the Julia/Flux reference cannot run in this image"}
 
 
-if __name__ == "__main__":
-    main()
 
 
 def torch_cpu_line(hp, seconds):
@@ -361,3 +359,6 @@ def torch_cpu_line(hp, seconds):
         step()
         k += 1
     return {"value": k / (time.perf_counter() - t0), "unit": "steps/s", "threads": torch.get_num_threads(), "kind": "eager PyTorch CPU (oneDNN), proxy"}
+
+if __name__ == "__main__":
+    main()
