@@ -123,3 +123,108 @@ def test_testmdp_device_envs(mods):
         tot += r
     assert tot / 20 >= 1.5
     policy.engine.close()
+
+
+class _UserEnv:
+    """Minimal user-defined environment in the envs.py protocol (n lock-stepped copies): what CommonRLInterface / POMDPs.jl
+    adapters give the reference's solve()."""
+    n_actions, obs_shape, discount = 2, (1,), 0.95
+
+    def __init__(self, n=1):
+        self.n = n
+        self.reset()
+
+    def reset(self, mask=None):
+        if mask is None:
+            self.s = np.ones(self.n, np.int64)
+        else:
+            self.s[mask] = 1
+
+    def observe(self):
+        return self.s.astype(np.float32)[:, None]
+
+    def terminated(self):
+        return self.s >= 3
+
+
+class SimpleEnv(_UserEnv):
+    """test/runtests.jl:199-216: actions [-1, +1]; act! returns the state BEFORE the move; s = max(1, s + a); terminal at s >= 3."""
+
+    def act(self, a):
+        r = self.s.astype(np.float32)
+        self.s = np.maximum(1, self.s + np.where(np.asarray(a) == 0, -1, 1))
+        return r
+
+
+class StaticArrayMDP(_UserEnv):
+    """test/runtests.jl:165-181: state SVector(1); actions [0, 1]; sp = s + a; r = m.state[1]^2 == 1; terminal at s >= 3."""
+
+    def act(self, a):
+        self.s = self.s + np.asarray(a)
+        return np.ones(self.n, np.float32)
+
+
+@pytest.mark.parametrize("cls", [SimpleEnv, StaticArrayMDP], ids=["common_rl_env", "static_array_env"])
+def test_user_defined_env_ten_steps(mods, cls):
+    """test/runtests.jl:165-234: solve() on a user-defined env with a 1-element observation, Chain(Dense(1,32), Dense(32,2)), max_steps = 10,
+    double_q + dueling + prioritized; the rolled-out return is > 1.0."""
+    pkg, nn, envs, S = mods
+    env = cls()
+    model = nn.Chain(nn.Dense(1, 32), nn.Dense(32, env.n_actions))
+    expl = S.EpsGreedyPolicy(env, S.LinearDecaySchedule(start=1.0, stop=0.01, steps=5), rng=np.random.default_rng(1))
+    solver = S.DeepQLearningSolver(qnetwork=model, max_steps=10, exploration_policy=expl, learning_rate=0.005, log_freq=500,
+                                   recurrence=False, double_q=True, dueling=True, prioritized_replay=True, verbose=False, logdir=None)
+    policy = S.solve(solver, env)
+    assert evaluate(env, policy, n_ep=1, max_steps=50) > 1.0
+    assert policy.actionvalues(np.array([1.0], np.float32)).shape == (2,)
+    policy.engine.close()
+
+
+class TigerPOMDP:
+    """POMDPModels.TigerPOMDP(r_listen, r_findtiger, r_escapetiger, p_listen_correctly, discount) (third-party; recalled) as the env the
+    reference's POMDP path produces: observation = convert_o(Vector, o) = [tiger heard on the left?]; actions listen / open-left / open-right;
+    opening a door ends the episode."""
+    n_actions, obs_shape = 3, (1,)
+
+    def __init__(self, r_listen=0.01, r_find=-1.0, r_escape=0.1, p_correct=0.8, discount=0.95, n=1, seed=0):
+        self.r_listen, self.r_find, self.r_escape, self.p_correct, self.discount, self.n = r_listen, r_find, r_escape, p_correct, discount, n
+        self.rng = np.random.default_rng(seed)
+        self.reset()
+
+    def reset(self, mask=None):
+        new = self.rng.integers(0, 2, self.n)
+        if mask is None:
+            self.tiger, self.done, self.o = new, np.zeros(self.n, bool), np.zeros(self.n, np.float32)
+        else:
+            self.tiger[mask], self.done[mask], self.o[mask] = new[mask], False, 0.0
+
+    def observe(self):
+        return self.o[:, None].copy()
+
+    def terminated(self):
+        return self.done
+
+    def act(self, a):
+        a = np.asarray(a)
+        correct = self.rng.random(self.n) < self.p_correct
+        heard = np.where(correct, self.tiger, 1 - self.tiger)
+        self.o = np.where(a == 0, heard, self.rng.integers(0, 2, self.n)).astype(np.float32)
+        opened_tiger = (a - 1) == self.tiger
+        r = np.where(a == 0, self.r_listen, np.where(opened_tiger, self.r_find, self.r_escape)).astype(np.float32)
+        self.done = a != 0
+        return r
+
+
+def test_tiger_pomdp_ddrqn_shape(mods):
+    """test/runtests.jl:149-163: POMDP path, Chain(flattenbatch, LSTM(input_dims, 4), Dense(4, 3)), recurrence, trace_length 10, dueling + double-Q,
+    target_update_freq 1000; asserts only size(actionvalues(policy, o)) == (n_actions,).  (2000 of the reference's 10 000 steps.)"""
+    pkg, nn, envs, S = mods
+    env = TigerPOMDP(0.01, -1.0, 0.1, 0.8, 0.95)
+    model = nn.Chain(nn.flattenbatch, nn.LSTM(1, 4), nn.Dense(4, env.n_actions))
+    expl = S.EpsGreedyPolicy(env, S.LinearDecaySchedule(start=1.0, stop=0.01, steps=1000), rng=np.random.default_rng(1))
+    solver = S.DeepQLearningSolver(qnetwork=model, prioritized_replay=False, max_steps=2000, learning_rate=0.0001, exploration_policy=expl, log_freq=500,
+                                   target_update_freq=1000, recurrence=True, trace_length=10, double_q=True, dueling=True, max_episode_length=100,
+                                   verbose=False, logdir=None)
+    policy = S.solve(solver, env)
+    assert policy.actionvalues(np.array([1.0], np.float32)).shape == (env.n_actions,)
+    policy.engine.close()
