@@ -193,6 +193,16 @@ struct LstmBwdArgs {
     int t, T, H, B, TB; const float *gates, *tc, *cprev, *Wh; const float* dH; float* dG; float *dhn, *dcn; float *g_h0, *g_c0;
 };
 void launch_lstm_bwd_step(hipStream_t st, const LstmBwdArgs& a);
+// whole-sequence variants (small LSTMs: Wh and one step's state in LDS)
+struct LstmSeqF {
+    const float* Gx; float* Hout; float* Cst; int ld, c0;
+    const float *Wh, *bias, *h0, *c0v;
+    float *gates, *tc, *hprev_out, *cprev_out; int keep_ld, keep_c0;
+};
+struct LstmSeqArgs { LstmSeqF s[3]; int nseq, H, B, T; };
+bool lstm_seq_fits(int H, int B);
+void launch_lstm_seq(hipStream_t st, const LstmSeqArgs& a);
+void launch_lstm_bwd_seq(hipStream_t st, const LstmBwdArgs& a);   // a.t ignored
 struct EpGatherArgs {
     const float *ep_s, *ep_sp; const int* ep_a; const float* ep_r; const unsigned char* ep_done; const int* ep_len;
     const long long* ep_idx; const int* ep_start; int E, B, T; float* x0; int* a_out; float *r_out, *done_out, *mask_out;

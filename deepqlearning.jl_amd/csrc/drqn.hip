@@ -106,6 +106,138 @@ void launch_lstm_bwd_step(hipStream_t st, const LstmBwdArgs& a) {
     hipLaunchKernelGGL(k_lstm_bwd_step, dim3(1), dim3(bs), 0, st, a);
 }
 
+// ------------------------------------------------------------------ whole-sequence kernels for small LSTMs (config 4: H = 32, B = 32, T = 8)
+// The per-step launches above cost a dispatch and a cold walk over Wh per time step.  When Wh (H x 4H) and one step's state fit in
+// LDS, ONE launch runs the whole recurrence: workgroup s owns sequence set s (online s, online sp, target sp), keeps Wh, the bias
+// and the (h, c) state in LDS and walks t = 0..T-1; the arithmetic per output -- and therefore every bit -- is that of k_lstm_step.
+// Batch columns are independent in the recurrence, so a sequence set is further split into groups of CB columns (one workgroup
+// each, its own LDS copy of Wh): H*CB ~ 256 outputs per step keeps one wave per SIMD busy and the double-precision sigm/tanh
+// (most of a step's instructions) spread over 4x more CUs.
+static int lstm_cb(int H, int B) { int cb = 256 / H; if (cb < 1) cb = 1; if (cb > B) cb = B; while (B % cb) cb--; return cb; }
+bool lstm_seq_fits(int H, int B) {     // both kernels within 64 KB of dynamic LDS
+    const int cb = lstm_cb(H, B);
+    const size_t fwd = (size_t)H * 4 * H + 4 * H + 3 * (size_t)H * cb, bwd = (size_t)H * 4 * H + 6 * (size_t)H * cb;
+    return fwd <= 16384 && bwd <= 16384;
+}
+
+__global__ __launch_bounds__(1024) void k_lstm_seq(LstmSeqArgs A, int CB) {
+    extern __shared__ float lds[];
+    const int H = A.H, B = A.B, N = 4 * H, per = H * CB, T = A.T, nsplit = B / CB;
+    float* Wh_s = lds;                 // [H][4H]
+    float* bias_s = Wh_s + H * N;      // [4H]
+    float* h_s = bias_s + N;           // [2][H*CB]
+    float* c_s = h_s + 2 * per;        // [H*CB]
+    const LstmSeqF& S = A.s[blockIdx.x / nsplit];
+    const int b0 = (blockIdx.x % nsplit) * CB;
+    for (int i = threadIdx.x; i < H * N; i += blockDim.x) Wh_s[i] = S.Wh[i];
+    for (int i = threadIdx.x; i < N; i += blockDim.x) bias_s[i] = S.bias[i];
+    for (int e = threadIdx.x; e < per; e += blockDim.x) { const int u = e / CB; h_s[e] = S.h0[u]; c_s[e] = S.c0v[u]; }      // Flux.reset!: state0 broadcast over the batch
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < T; t++) {
+        const float* hp = h_s + cur * per; float* hn = h_s + (cur ^ 1) * per;
+        for (int e = threadIdx.x; e < per; e += blockDim.x) {
+            const int u = e / CB, bl = e - u * CB, b = b0 + bl;
+            const int col = S.c0 + t * B + b;
+            float gx[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) gx[q] = S.Gx[(size_t)(q * H + u) * S.ld + col];       // requested before the chains: their latency rides under them
+            // the four gate chains advance together: one h read per j and four independent fma chains (each still j-ascending)
+            float ch[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 8
+            for (int j = 0; j < H; j++) {
+                const float hv = hp[j * CB + bl]; const float* wr = Wh_s + j * N + u;
+                ch[0] = fmaf(hv, wr[0], ch[0]); ch[1] = fmaf(hv, wr[H], ch[1]); ch[2] = fmaf(hv, wr[2 * H], ch[2]); ch[3] = fmaf(hv, wr[3 * H], ch[3]);
+            }
+            float g[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) g[q] = (gx[q] + ch[q]) + bias_s[q * H + u];
+            const float ig = sigm_f(g[0]), fg = sigm_f(g[1]), gg = tanh_f(g[2]), og = sigm_f(g[3]);
+            const float cp = c_s[e];
+            const float t1 = fg * cp; const float t2 = ig * gg; const float c = t1 + t2; const float tc = tanh_f(c); const float h = og * tc;
+            S.Hout[(size_t)u * S.ld + col] = h; S.Cst[(size_t)u * S.ld + col] = c;
+            if (S.gates) {
+                const size_t k = (size_t)S.keep_c0 + t * B + b; const size_t kl = S.keep_ld;
+                S.gates[(size_t)(0 * H + u) * kl + k] = ig; S.gates[(size_t)(1 * H + u) * kl + k] = fg; S.gates[(size_t)(2 * H + u) * kl + k] = gg; S.gates[(size_t)(3 * H + u) * kl + k] = og;
+                S.tc[(size_t)u * kl + k] = tc; S.hprev_out[(size_t)u * kl + k] = hp[e]; S.cprev_out[(size_t)u * kl + k] = cp;
+            }
+            hn[e] = h; c_s[e] = c;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+void launch_lstm_seq(hipStream_t st, const LstmSeqArgs& a) {
+    const int cb = lstm_cb(a.H, a.B);
+    const size_t lds = ((size_t)a.H * 4 * a.H + 4 * a.H + 3 * (size_t)a.H * cb) * sizeof(float);
+    int bs = ((a.H * cb + 63) / 64) * 64; if (bs > 1024) bs = 1024;
+    hipLaunchKernelGGL(k_lstm_seq, dim3(a.nseq * (a.B / cb)), dim3(bs), lds, st, a, cb);
+}
+
+// BPTT over the whole s-sequence, one workgroup per group of CB columns (same arithmetic as T calls of k_lstm_bwd_step); the
+// trainable state0's gradient (a sum over ALL columns, ascending b) is folded by k_state0_grad afterwards.
+__global__ __launch_bounds__(1024) void k_lstm_bwd_seq(LstmBwdArgs A, int CB) {
+    extern __shared__ float lds[];
+    const int H = A.H, B = A.B, TB = A.TB, N = 4 * H, per = H * CB, b0 = blockIdx.x * CB;
+    float* Wh_s = lds;                 // [H][4H]
+    float* dG_s = Wh_s + H * N;        // [4H][CB]
+    float* dhn_s = dG_s + N * CB;      // [H*CB]
+    float* dcn_s = dhn_s + per;        // [H*CB]
+    for (int i = threadIdx.x; i < H * N; i += blockDim.x) Wh_s[i] = A.Wh[i];
+    for (int e = threadIdx.x; e < per; e += blockDim.x) { dhn_s[e] = 0.0f; dcn_s[e] = 0.0f; }
+    __syncthreads();
+    // one (u, column) element per thread (per <= blockDim by construction); the seven stashed values of step t-1 are requested
+    // while step t's dh chain runs, so their latency is off the serial path
+    const int e = threadIdx.x; const bool on = e < per;
+    const int u = on ? e / CB : 0, bl = on ? e - u * CB : 0;
+    struct St { float ig, fg, gg, og, tc, cprev, dH; };
+    auto fetch = [&](int t) { St s; const size_t k = (size_t)t * B + b0 + bl;
+        s.ig = A.gates[(size_t)u * TB + k]; s.fg = A.gates[(size_t)(H + u) * TB + k]; s.gg = A.gates[(size_t)(2 * H + u) * TB + k]; s.og = A.gates[(size_t)(3 * H + u) * TB + k];
+        s.tc = A.tc[(size_t)u * TB + k]; s.cprev = A.cprev[(size_t)u * TB + k]; s.dH = A.dH[(size_t)u * TB + k]; return s; };
+    St nx = fetch(A.T - 1);
+    for (int t = A.T - 1; t >= 0; t--) {
+        const St c = nx;
+        if (on) {
+            const size_t k = (size_t)t * B + b0 + bl;
+            const float ig = c.ig, fg = c.fg, gg = c.gg, og = c.og, tc = c.tc, cprev = c.cprev;
+            const float dhn = t == A.T - 1 ? 0.0f : dhn_s[e], dcn = t == A.T - 1 ? 0.0f : dcn_s[e];
+            const float dh = c.dH + dhn;
+            const float dov = dh * tc; const float t1 = dh * og; const float t2 = tc * tc; const float t3 = 1.0f - t2; const float t4 = t1 * t3; const float dc = dcn + t4;
+            const float di = dc * gg, df = dc * cprev, dgc = dc * ig; dcn_s[e] = dc * fg;
+            const float a1 = di * ig, a2 = 1.0f - ig, v0 = a1 * a2;
+            const float b1 = df * fg, b2 = 1.0f - fg, v1 = b1 * b2;
+            const float c1 = gg * gg, c2 = 1.0f - c1, v2 = dgc * c2;
+            const float d1 = dov * og, d2 = 1.0f - og, v3 = d1 * d2;
+            A.dG[(size_t)u * TB + k] = v0; A.dG[(size_t)(H + u) * TB + k] = v1; A.dG[(size_t)(2 * H + u) * TB + k] = v2; A.dG[(size_t)(3 * H + u) * TB + k] = v3;
+            dG_s[u * CB + bl] = v0; dG_s[(H + u) * CB + bl] = v1; dG_s[(2 * H + u) * CB + bl] = v2; dG_s[(3 * H + u) * CB + bl] = v3;
+        }
+        if (t > 0) nx = fetch(t - 1);
+        __syncthreads();
+        if (on) {                                                  // dh_{t-1}[j][b] = sum_n dG[n][t,b] Wh[j][n], n ascending  (j == u)
+            float acc = 0.0f;
+#pragma unroll 8
+            for (int n = 0; n < N; n++) acc = fmaf(dG_s[n * CB + bl], Wh_s[u * N + n], acc);
+            dhn_s[e] = acc;
+        }
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < per; e += blockDim.x) { const int u = e / CB, bl = e - u * CB; A.dhn[u * B + b0 + bl] = dhn_s[e]; A.dcn[u * B + b0 + bl] = dcn_s[e]; }
+}
+__global__ void k_state0_grad(int H, int B, const float* __restrict__ dhn, const float* __restrict__ dcn, float* __restrict__ g_h0, float* __restrict__ g_c0) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= H) return;
+    float sh = 0.0f, sc = 0.0f;
+    for (int b = 0; b < B; b++) { sh = sh + dhn[u * B + b]; sc = sc + dcn[u * B + b]; }      // ascending b
+    g_h0[u] = sh; g_c0[u] = sc;
+}
+void launch_lstm_bwd_seq(hipStream_t st, const LstmBwdArgs& a) {
+    const int cb = lstm_cb(a.H, a.B);
+    const size_t lds = ((size_t)a.H * 4 * a.H + 6 * (size_t)a.H * cb) * sizeof(float);
+    int bs = ((a.H * cb + 63) / 64) * 64; if (bs > 1024) bs = 1024;
+    hipLaunchKernelGGL(k_lstm_bwd_seq, dim3(a.B / cb), dim3(bs), lds, st, a, cb);
+    hipLaunchKernelGGL(k_state0_grad, dim3((a.H + 63) / 64), dim3(64), 0, st, a.H, a.B, a.dhn, a.dcn, a.g_h0, a.g_c0);
+}
+
 // ------------------------------------------------------------------ recurrent TD: targets, masked Huber / B / T, dL/dQ  (src/solver.jl:259-282)
 __device__ __forceinline__ float head_at(const HeadSrc& h, int n, int col) { return h.p[(size_t)n * h.ld + col]; }
 __device__ __forceinline__ void q_col(int nA, int dueling, const HeadSrc& val, const HeadSrc& adv, int col, float* q, float* vout, float* araw) {

@@ -77,7 +77,7 @@ struct dqn_engine {
     // comm
     void* comm = nullptr; int rank = 0, world = 1; bool force_comm = false;   // force_comm: run the all-reduce path even at world == 1 (tests)
     // DRQN (recurrence = true): column count per sequence set Bc = T*B (B otherwise); EpisodeReplayBuffer storage; LSTM workspaces
-    int Bc = 0, T = 1; long long ep_cap = 0, ep_size = 0, ep_widx = 0, ep_cur_len = 0; std::vector<int> ep_len_host;
+    int Bc = 0, T = 1; long long ep_cap = 0, ep_size = 0, ep_widx = 0, ep_cur_len = 0; std::vector<int> ep_len_host; std::vector<int64_t> ep_perm;
     float *ep_s = nullptr, *ep_sp = nullptr, *ep_r = nullptr; int* ep_a = nullptr; unsigned char* ep_done = nullptr; int* ep_len = nullptr;
     long long* ep_idx = nullptr; int* ep_start = nullptr; int* r_a = nullptr; float *r_r = nullptr, *r_done = nullptr, *r_mask = nullptr;
     float *gx_on[DQN_MAX_LAYERS] = {}, *gx_tg[DQN_MAX_LAYERS] = {}, *cst_on[DQN_MAX_LAYERS] = {}, *cst_tg[DQN_MAX_LAYERS] = {}, *gates[DQN_MAX_LAYERS] = {}, *tcb[DQN_MAX_LAYERS] = {},
@@ -562,6 +562,18 @@ static int build_program(dqn_engine* e) {
             // the recurrence: T launches, each advancing the online s-sequence, the online sp-sequence (double-Q) and the target
             // sp-sequence by one step from the reset state (Flux.reset!, src/solver.jl:249-250,271)
             const int l = lv[0]; const LayerDev L = e->L[l]; const int H = L.H;
+            if (lstm_seq_fits(H, Bb)) {        // small LSTM: the whole recurrence of the three sequence sets in ONE launch
+                LstmSeqArgs a; memset(&a, 0, sizeof a); a.H = H; a.B = Bb; a.T = T; int ns = 0;
+                auto seq = [&](const float* P, const float* gx, float* hout, float* cst, int ld, int c0, bool keep) {
+                    LstmSeqF& q = a.s[ns++]; q.Gx = gx; q.Hout = hout; q.Cst = cst; q.ld = ld; q.c0 = c0; q.Wh = P + L.wh_off; q.bias = P + L.b_off; q.h0 = P + L.h0_off; q.c0v = P + L.c0_off;
+                    if (keep) { q.gates = e->gates[l]; q.tc = e->tcb[l]; q.hprev_out = e->hprev_buf[l]; q.cprev_out = e->cprev_buf[l]; q.keep_ld = B; q.keep_c0 = 0; }
+                };
+                seq(e->p_on, e->gx_on[l], e->act_on[l], e->cst_on[l], ncon, 0, true);
+                if (e->hp.double_q) seq(e->p_on, e->gx_on[l], e->act_on[l], e->cst_on[l], ncon, B, false);
+                seq(e->p_tg, e->gx_tg[l], e->act_tg[l], e->cst_tg[l], B, 0, false);
+                a.nseq = ns;
+                e->prog.push_back({pname(e, "lstm_seq", L.kind, l), [=](dqn_engine* en) { launch_lstm_seq(en->stream, a); }});
+            } else
             for (int t = 0; t < T; t++) {
                 LstmStepArgs a; memset(&a, 0, sizeof a); a.H = H; a.B = Bb; int ns = 0;
                 auto seq = [&](const float* P, const float* gx, float* hout, float* cst, int ld, int c0, bool keep) {
@@ -615,6 +627,11 @@ static int build_program(dqn_engine* e) {
                 // BPTT over the s-sequence: T single-workgroup steps produce dG (gate pre-activation gradients) for all columns,
                 // then Wi|b, Wh and the input gradient are ordinary dense contractions over the T*B columns.
                 float* grad = e->grad;
+                if (lstm_seq_fits(L.H, Bb)) {
+                    LstmBwdArgs a; a.t = 0; a.T = T; a.H = L.H; a.B = Bb; a.TB = B; a.gates = e->gates[l]; a.tc = e->tcb[l]; a.cprev = e->cprev_buf[l]; a.Wh = e->p_on + L.wh_off;
+                    a.dH = dpre; a.dG = e->dG[l]; a.dhn = e->dhn[l]; a.dcn = e->dcn[l]; a.g_h0 = grad + L.h0_off; a.g_c0 = grad + L.c0_off;
+                    e->prog.push_back({pname(e, "lstm_bwd_seq", L.kind, l), [=](dqn_engine* en) { launch_lstm_bwd_seq(en->stream, a); }});
+                } else
                 for (int t = T - 1; t >= 0; t--) {
                     LstmBwdArgs a; a.t = t; a.T = T; a.H = L.H; a.B = Bb; a.TB = B; a.gates = e->gates[l]; a.tc = e->tcb[l]; a.cprev = e->cprev_buf[l]; a.Wh = e->p_on + L.wh_off;
                     a.dH = dpre; a.dG = e->dG[l]; a.dhn = e->dhn[l]; a.dcn = e->dcn[l]; a.g_h0 = grad + L.h0_off; a.g_c0 = grad + L.c0_off;
@@ -962,9 +979,14 @@ extern "C" int dqn_train_step_drqn(dqn_engine_t* e, const int64_t* ep_idx, const
     if (!ep_idx) {   // sample(rng, 1:n, B, replace=false); ep_start = rand(rng, 1:length(ep))  (src/episode_replay.jl:75,81) -- host-side SplitMix draws
         if (e->ep_size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
         auto next = [&]() { uint64_t z = (e->drqn_draws += 0x9E3779B97F4A7C15ull) ^ e->hp.seed; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
-        std::vector<int64_t> perm((size_t)e->ep_size); for (size_t i = 0; i < perm.size(); i++) perm[i] = (int64_t)i;
-        for (int b = 0; b < e->B; b++) { const size_t j = b + (size_t)(next() % (perm.size() - b)); std::swap(perm[b], perm[j]); }
+        // partial Fisher-Yates on a persistent identity permutation: B swaps, read the prefix, undo the swaps (O(B) per step, same
+        // draws as shuffling a fresh 0..n-1 vector)
+        std::vector<int64_t>& perm = e->ep_perm;
+        if ((long long)perm.size() != e->ep_size) { perm.resize((size_t)e->ep_size); for (size_t i = 0; i < perm.size(); i++) perm[i] = (int64_t)i; }
+        std::vector<size_t> js((size_t)e->B);
+        for (int b = 0; b < e->B; b++) { js[b] = b + (size_t)(next() % (perm.size() - b)); std::swap(perm[b], perm[js[b]]); }
         di.assign(perm.begin(), perm.begin() + e->B); ds.resize(e->B);
+        for (int b = e->B - 1; b >= 0; b--) std::swap(perm[b], perm[js[b]]);
         for (int b = 0; b < e->B; b++) { const int len = e->ep_len_host[(size_t)di[b]]; ds[b] = len > 0 ? (int32_t)(next() % (uint64_t)len) : 0; }
         ep_idx = di.data(); ep_start = ds.data();
     }
@@ -1246,14 +1268,15 @@ __global__ void k_gate(volatile int* flag) {
 }
 extern "C" int dqn_profile_step(dqn_engine_t* e, int max_entries, const char** names, float* ms, int* n_entries) {
     HIPCHK(hipSetDevice(e->device));
-    if (e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
+    if (!e->hp.recurrence && e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
+    if (e->hp.recurrence && e->ep_size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
     HIPCHK(hipStreamSynchronize(e->stream));
     static int* gate = nullptr;
     if (!gate) HIPCHK(hipHostMalloc((void**)&gate, sizeof(int), hipHostMallocMapped));
     *gate = 0;
     hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, e->stream, (volatile int*)gate);
     e->profiling = true; e->prof.clear();
-    const int rc = run_step(e, true);
+    const int rc = e->hp.recurrence ? dqn_train_step_drqn(e, nullptr, nullptr, nullptr, nullptr) : run_step(e, true);
     e->profiling = false;
     __atomic_store_n(gate, 1, __ATOMIC_SEQ_CST);
     if (rc) return -1;
