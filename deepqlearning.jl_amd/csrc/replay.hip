@@ -23,6 +23,22 @@ __device__ __forceinline__ long long tree_descend(const float* __restrict__ tree
     const float u = (float)(c[0] >> 8) * (1.0f / 16777216.0f);
     float t = ((float)i + u) * seg;
     long long node = 1;
+    // three levels per memory round trip: the 2 children, 4 grandchildren and 8 great-grandchildren of a heap node are three
+    // contiguous runs (2n.., 4n.., 8n..), fetched with independent 8/16-byte loads; the three left/right decisions then use exactly
+    // the values (and the comparisons) of the one-level walk below, so the chosen leaf is identical.
+    while (8 * node < 2 * cap2) {
+        const float2 c = *reinterpret_cast<const float2*>(tree + 2 * node);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(tree + 4 * node);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(tree + 8 * node), h1 = *reinterpret_cast<const f32x4*>(tree + 8 * node + 4);
+        int b1 = 0, b2 = 0, b3 = 0;
+        if (!(t < c.x || !(c.y > 0.0f))) { t -= c.x; b1 = 1; }
+        const float gl = b1 ? g.z : g.x, gr = b1 ? g.w : g.y;
+        if (!(t < gl || !(gr > 0.0f))) { t -= gl; b2 = 1; }
+        const f32x4 hh = b1 ? h1 : h0;
+        const float hl = b2 ? hh.z : hh.x, hr = b2 ? hh.w : hh.y;
+        if (!(t < hl || !(hr > 0.0f))) { t -= hl; b3 = 1; }
+        node = 8 * node + 4 * b1 + 2 * b2 + b3;
+    }
     while (node < cap2) {
         const float l = tree[2 * node], rg = tree[2 * node + 1];
         if (t < l || !(rg > 0.0f)) node = 2 * node; else { t -= l; node = 2 * node + 1; }
