@@ -1,0 +1,106 @@
+// engine.h -- internal header of libdqn_mi355x.so's host side: the engine record, error/alloc helpers and the functions the
+// translation units engine.hip (ABI core, graphs, policy), engine_program.hip (static launch program of the train step),
+// engine_drqn.hip (EpisodeReplayBuffer + recurrent step) and engine_envs.hip (device-resident environments) share.
+#pragma once
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <functional>
+#include <string>
+#include <vector>
+#include "common.h"
+
+int fail(const char* fmt, ...);      // records the message for dqn_last_error(), returns -1
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail("HIP error %s at %s:%d (%s)", hipGetErrorString(_e), __FILE__, __LINE__, #x); } while (0)
+
+// ---------------------------------------------------------------- engine
+struct ProfEntry { const char* name; hipEvent_t a, b; };
+
+struct dqn_engine {
+    int device = 0; hipStream_t stream = nullptr, stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int nl = 0; LayerDev L[DQN_MAX_LAYERS]; LayerDev* L_dev = nullptr;
+    dqn_hparams hp; int B = 0, nA = 0, E = 0, ncon = 0;
+    int last_base = -1, last_val = -1, last_adv = -1;
+    size_t P = 0, Pint = 0;   // external (Flux.params) and internal (16-B aligned arrays) parameter counts
+    float *p_on = nullptr, *p_tg = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr, *io_tmp = nullptr;
+    StepState* state = nullptr;
+    // replay
+    long long cap = 0, cap2 = 1, widx = 0, size = 0;
+    void *s_rows = nullptr, *sp_rows = nullptr; int* ra = nullptr; float* rr = nullptr; unsigned char* rdone = nullptr; float* tree = nullptr;
+    static const int ADD_CHUNK = 1024;
+    int* st_a = nullptr; float* st_r = nullptr; unsigned char* st_done = nullptr; float* st_td = nullptr;
+    // step workspace
+    long long* idx = nullptr; float* x0 = nullptr;
+    float *act_on[DQN_MAX_LAYERS] = {}, *act_tg[DQN_MAX_LAYERS] = {}, *dact[DQN_MAX_LAYERS] = {};
+    float *join_tmp = nullptr, *partials = nullptr, *gmax_part = nullptr; size_t partials_elems = 0;
+    float *w_is = nullptr, *td = nullptr, *q_on_s = nullptr, *q_on_sp = nullptr, *q_tg_sp = nullptr, *ytarget = nullptr; int* best = nullptr;
+    // get_batch seam workspace
+    float *gb_rows = nullptr, *gb_r = nullptr, *gb_done = nullptr, *gb_w = nullptr; int* gb_a = nullptr; long long* gb_idx = nullptr;
+    // policy workspace
+    EnvDev env{}; bool has_envs = false; unsigned char* env_images = nullptr;
+    int pol_n = 0; float *pol_obs = nullptr, *pol_x = nullptr, *pol_act[DQN_MAX_LAYERS] = {}, *pol_q = nullptr; int* pol_a = nullptr;
+    // graphs: [0] = step with sampling, [1] = step on given indices; with a communicator the step is cut in two
+    hipGraphExec_t g_full[2] = {nullptr, nullptr}, g_pre[2] = {nullptr, nullptr}, g_post = nullptr;
+    // comm
+    void* comm = nullptr; int rank = 0, world = 1; bool force_comm = false;   // force_comm: run the all-reduce path even at world == 1 (tests)
+    // DRQN (recurrence = true): column count per sequence set Bc = T*B (B otherwise); EpisodeReplayBuffer storage; LSTM workspaces
+    int Bc = 0, T = 1; long long ep_cap = 0, ep_size = 0, ep_widx = 0, ep_cur_len = 0; std::vector<int> ep_len_host; std::vector<int64_t> ep_perm;
+    float *ep_s = nullptr, *ep_sp = nullptr, *ep_r = nullptr; int* ep_a = nullptr; unsigned char* ep_done = nullptr; int* ep_len = nullptr;
+    long long* ep_idx = nullptr; int* ep_start = nullptr; int* r_a = nullptr; float *r_r = nullptr, *r_done = nullptr, *r_mask = nullptr;
+    float *gx_on[DQN_MAX_LAYERS] = {}, *gx_tg[DQN_MAX_LAYERS] = {}, *cst_on[DQN_MAX_LAYERS] = {}, *cst_tg[DQN_MAX_LAYERS] = {}, *gates[DQN_MAX_LAYERS] = {}, *tcb[DQN_MAX_LAYERS] = {},
+          *hprev_buf[DQN_MAX_LAYERS] = {}, *cprev_buf[DQN_MAX_LAYERS] = {}, *dG[DQN_MAX_LAYERS] = {}, *dhn[DQN_MAX_LAYERS] = {}, *dcn[DQN_MAX_LAYERS] = {};
+    float *pol_h[DQN_MAX_LAYERS][2] = {}, *pol_c[DQN_MAX_LAYERS][2] = {}, *pol_gx[DQN_MAX_LAYERS] = {}; int pol_flip = 0, pol_state_n = 0; uint64_t drqn_draws = 0;
+    hipGraphExec_t g_drqn = nullptr;
+    // static launch program
+    struct Step { const char* name; std::function<void(dqn_engine*)> fn; };
+    // acting programs (forward on n columns + env kernels), one for the training envs and one for the evaluation envs
+    struct ActProg { std::vector<Step> steps; int n = 0; hipGraphExec_t graph = nullptr; std::vector<void*> allocs; };
+    ActProg act, evalp; std::vector<Step>* sink = nullptr; std::vector<void*>* alloc_sink = nullptr; RolloutDev *roll = nullptr, *eval_roll = nullptr;
+    EnvDev eval_env{}; int eval_n = 0;
+    std::vector<Step> prog; size_t prog_post_begin = 0; bool prog_built = false, step_sampled = true;
+    AdamSegs adam_segs; long final_reduce_step = -1;   // deferred dW slabs: reduced inside k_adam unless a communicator needs the materialised gradient
+    std::vector<void*> prog_allocs; std::vector<std::string> prog_names;
+    // profiling
+    bool profiling = false; std::vector<ProfEntry> prof;
+};
+
+void prof_begin(dqn_engine* e, const char* name);
+void prof_end(dqn_engine* e);
+#define RUN(e, name, call) do { prof_begin(e, name); call; prof_end(e); } while (0)
+enum { PH_ALL = 0, PH_PRE = 1, PH_POST = 2 };
+template <class T> static int dmalloc(T** p, size_t n) {
+    hipError_t e = hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T));
+    if (e != hipSuccess) return fail("hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
+    return 0;
+}
+#define DM(p, n) do { if (dmalloc(&(p), (n))) return -1; } while (0)
+#define NEED_REC(e) do { if (!(e)->hp.recurrence) return fail("this engine was created with recurrence = false"); } while (0)
+
+// engine.hip
+void drop_graphs(dqn_engine* e);
+void drop_act(dqn_engine* e, dqn_engine::ActProg& a);
+void fwd_layer(dqn_engine* e, const LayerDev& l, const float* P, const float* X, int ldx, int col0, int ncols, float* Y, const char* name);
+void enqueue_step(dqn_engine* e, bool sample, int phase);
+int capture(dqn_engine* e, bool sample, int phase, hipGraphExec_t* out);
+int allreduce_grads(dqn_engine* e);
+int run_step(dqn_engine* e, bool sample);
+int fetch_scalars(dqn_engine* e, float* loss, float* gn);
+int policy_ws(dqn_engine* e, int n);
+int policy_state(dqn_engine* e, int n, bool force_reset);
+// engine_program.hip
+template <class T> static T* upload(dqn_engine* e, const std::vector<T>& v) {
+    T* d = nullptr; hipMalloc((void**)&d, sizeof(T) * v.size()); hipMemcpy(d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice);
+    (e->alloc_sink ? *e->alloc_sink : e->prog_allocs).push_back(d); return d;
+}
+float* palloc(dqn_engine* e, size_t n);
+bool same_geo(const LayerDev& a, const LayerDev& b);
+void add_valu(dqn_engine* e, std::vector<VTask>& pend, const VTask& t);
+void flush_valu(dqn_engine* e, std::vector<VTask>& pend, const char* name);
+void emit_reduce(dqn_engine* e, std::vector<RSeg>& segs, const char* name);
+const char* pname(dqn_engine* e, const char* op, int kind, int i);
+int build_program(dqn_engine* e);
+// engine_envs.hip
+void free_envs(dqn_engine* e);

@@ -1,0 +1,116 @@
+// engine_drqn.hip -- C ABI of the recurrent path: EpisodeReplayBuffer (src/episode_replay.jl:3-95) and the DRQN train step
+// (src/solver.jl:239-287); the launch program itself is built by engine_program.hip.
+#include "engine.h"
+
+// ---------------------------------------------------------------- DRQN: EpisodeReplayBuffer + recurrent batch_train!
+extern "C" int dqn_episode_commit(dqn_engine_t* e) {          // add_episode! (src/episode_replay.jl:54-60)
+    NEED_REC(e); HIPCHK(hipSetDevice(e->device));
+    const int len = (int)e->ep_cur_len;
+    e->ep_len_host[(size_t)e->ep_widx] = len;
+    HIPCHK(hipMemcpyAsync(e->ep_len + e->ep_widx, &e->ep_len_host[(size_t)e->ep_widx], 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->ep_widx = (e->ep_widx + 1) % e->ep_cap; if (e->ep_size < e->ep_cap) e->ep_size++;
+    e->ep_cur_len = 0; return 0;
+}
+extern "C" int dqn_episode_add(dqn_engine_t* e, const void* s, const int32_t* a, const float* r, const void* sp, const uint8_t* done, int n) {
+    NEED_REC(e); HIPCHK(hipSetDevice(e->device));
+    const size_t row = (size_t)e->E * 4;
+    for (int i = 0; i < n; i++) {                              // add_exp! (:46-52): push; the episode is stored when done
+        if (a[i] < 0 || a[i] >= e->nA) return fail("action index %d out of range 0..%d", a[i], e->nA - 1);
+        if (e->ep_cur_len < e->T) {                            // only the first trace_length transitions can ever be sampled (:82-92)
+            const size_t slot = (size_t)e->ep_widx * e->T + (size_t)e->ep_cur_len;
+            HIPCHK(hipMemcpyAsync((char*)e->ep_s + slot * row, (const char*)s + (size_t)i * row, row, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync((char*)e->ep_sp + slot * row, (const char*)sp + (size_t)i * row, row, hipMemcpyHostToDevice, e->stream));
+            const unsigned char d8 = done[i] ? 1 : 0;
+            HIPCHK(hipMemcpyAsync(e->ep_a + slot, a + i, 4, hipMemcpyHostToDevice, e->stream)); HIPCHK(hipMemcpyAsync(e->ep_r + slot, r + i, 4, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync(e->ep_done + slot, &d8, 1, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
+        }
+        e->ep_cur_len++;
+        if (done[i] && dqn_episode_commit(e)) return -1;
+    }
+    return 0;
+}
+extern "C" int dqn_episode_count(dqn_engine_t* e, int64_t* cur, int64_t* cap) { NEED_REC(e); if (cur) *cur = e->ep_size; if (cap) *cap = e->ep_cap; return 0; }
+static int drqn_check(dqn_engine* e, const int64_t* ep_idx, const int32_t* ep_start) {
+    if (e->ep_size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
+    for (int b = 0; b < e->B; b++) {
+        if (ep_idx[b] < 0 || ep_idx[b] >= e->ep_size) return fail("BoundsError: episode index %lld outside 0..%lld", (long long)ep_idx[b], (long long)e->ep_size - 1);
+        const int len = e->ep_len_host[(size_t)ep_idx[b]];
+        if (len > 0 && (ep_start[b] < 0 || ep_start[b] >= len)) return fail("episode start %d outside 0..%d", ep_start[b], len - 1);
+    }
+    return 0;
+}
+static int drqn_upload_draws(dqn_engine* e, const int64_t* ep_idx, const int32_t* ep_start) {
+    HIPCHK(hipMemcpyAsync(e->ep_idx, ep_idx, (size_t)e->B * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->ep_start, ep_start, (size_t)e->B * 4, hipMemcpyHostToDevice, e->stream));
+    return 0;
+}
+extern "C" int dqn_episode_get_batch(dqn_engine_t* e, const int64_t* ep_idx, const int32_t* ep_start, float* s, int32_t* a, float* r, float* sp, float* done, int32_t* mask) {
+    NEED_REC(e); HIPCHK(hipSetDevice(e->device));
+    if (drqn_check(e, ep_idx, ep_start) || drqn_upload_draws(e, ep_idx, ep_start)) return -1;
+    EpGatherArgs g; g.ep_s = e->ep_s; g.ep_sp = e->ep_sp; g.ep_a = e->ep_a; g.ep_r = e->ep_r; g.ep_done = e->ep_done; g.ep_len = e->ep_len; g.ep_idx = e->ep_idx; g.ep_start = e->ep_start;
+    g.E = e->E; g.B = e->B; g.T = e->T; g.x0 = e->x0; g.a_out = e->r_a; g.r_out = e->r_r; g.done_out = e->r_done; g.mask_out = e->r_mask;
+    launch_gather_episodes(e->stream, g);
+    const int TB = e->Bc, E = e->E;
+    std::vector<float> x((size_t)E * 2 * TB), rr(TB), dd(TB), mm(TB); std::vector<int> aa(TB);
+    HIPCHK(hipMemcpyAsync(x.data(), e->x0, x.size() * 4, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipMemcpyAsync(aa.data(), e->r_a, TB * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(rr.data(), e->r_r, TB * 4, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipMemcpyAsync(dd.data(), e->r_done, TB * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(mm.data(), e->r_mask, TB * 4, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream));
+    for (int k = 0; k < TB; k++) {      // device arena is [feature][column]; the seam returns [T][B][obs]
+        if (s) for (int f = 0; f < E; f++) s[(size_t)k * E + f] = x[(size_t)f * 2 * TB + k];
+        if (sp) for (int f = 0; f < E; f++) sp[(size_t)k * E + f] = x[(size_t)f * 2 * TB + TB + k];
+        if (a) a[k] = aa[k]; if (r) r[k] = rr[k]; if (done) done[k] = dd[k]; if (mask) mask[k] = (int32_t)mm[k];
+    }
+    return 0;
+}
+extern "C" int dqn_train_step_drqn(dqn_engine_t* e, const int64_t* ep_idx, const int32_t* ep_start, float* loss, float* grad_norm) {
+    NEED_REC(e); HIPCHK(hipSetDevice(e->device));
+    std::vector<int64_t> di; std::vector<int32_t> ds;
+    if (!ep_idx) {   // sample(rng, 1:n, B, replace=false); ep_start = rand(rng, 1:length(ep))  (src/episode_replay.jl:75,81) -- host-side SplitMix draws
+        if (e->ep_size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
+        auto next = [&]() { uint64_t z = (e->drqn_draws += 0x9E3779B97F4A7C15ull) ^ e->hp.seed; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+        // partial Fisher-Yates on a persistent identity permutation: B swaps, read the prefix, undo the swaps (O(B) per step, same
+        // draws as shuffling a fresh 0..n-1 vector)
+        std::vector<int64_t>& perm = e->ep_perm;
+        if ((long long)perm.size() != e->ep_size) { perm.resize((size_t)e->ep_size); for (size_t i = 0; i < perm.size(); i++) perm[i] = (int64_t)i; }
+        std::vector<size_t> js((size_t)e->B);
+        for (int b = 0; b < e->B; b++) { js[b] = b + (size_t)(next() % (perm.size() - b)); std::swap(perm[b], perm[js[b]]); }
+        di.assign(perm.begin(), perm.begin() + e->B); ds.resize(e->B);
+        for (int b = e->B - 1; b >= 0; b--) std::swap(perm[b], perm[js[b]]);
+        for (int b = 0; b < e->B; b++) { const int len = e->ep_len_host[(size_t)di[b]]; ds[b] = len > 0 ? (int32_t)(next() % (uint64_t)len) : 0; }
+        ep_idx = di.data(); ep_start = ds.data();
+    }
+    if (drqn_check(e, ep_idx, ep_start) || drqn_upload_draws(e, ep_idx, ep_start)) return -1;
+    if (build_program(e)) return -1;
+    if (e->hp.use_graph && !e->profiling && e->world == 1) {
+        if (!e->g_drqn && capture(e, false, PH_ALL, &e->g_drqn)) return -1;
+        HIPCHK(hipGraphLaunch(e->g_drqn, e->stream));
+    } else { enqueue_step(e, false, PH_PRE); if (e->world > 1 && allreduce_grads(e)) return -1; enqueue_step(e, false, PH_POST); }
+    if (loss || grad_norm) return fetch_scalars(e, loss, grad_norm);
+    return 0;
+}
+extern "C" int dqn_reset_state(dqn_engine_t* e) {             // resetstate!(policy) (src/policy.jl:32-34)
+    HIPCHK(hipSetDevice(e->device));
+    if (!e->hp.recurrence) return 0;
+    return policy_state(e, e->pol_state_n > 0 ? e->pol_state_n : 1, true);
+}
+extern "C" int dqn_get_hidden(dqn_engine_t* e, float* hc, size_t n) {   // hiddenstates(m) (src/helpers.jl:61-63): per LSTM layer h then c, [out][streams]
+    HIPCHK(hipSetDevice(e->device)); size_t off = 0;
+    for (int i = 0; i < e->nl; i++) if (e->L[i].kind == DQN_LAYER_LSTM) {
+        const size_t m = (size_t)e->L[i].H * e->pol_state_n; if (off + 2 * m > n) return fail("get_hidden: buffer too small");
+        HIPCHK(hipMemcpyAsync(hc + off, e->pol_h[i][e->pol_flip], m * 4, hipMemcpyDeviceToHost, e->stream)); off += m;
+        HIPCHK(hipMemcpyAsync(hc + off, e->pol_c[i][e->pol_flip], m * 4, hipMemcpyDeviceToHost, e->stream)); off += m;
+    }
+    HIPCHK(hipStreamSynchronize(e->stream)); return 0;
+}
+extern "C" int dqn_set_hidden(dqn_engine_t* e, const float* hc, size_t n) {   // sethiddenstates!(m, hs) (src/helpers.jl:71-79)
+    HIPCHK(hipSetDevice(e->device)); size_t off = 0;
+    for (int i = 0; i < e->nl; i++) if (e->L[i].kind == DQN_LAYER_LSTM) {
+        const size_t m = (size_t)e->L[i].H * e->pol_state_n; if (off + 2 * m > n) return fail("set_hidden: buffer too small");
+        HIPCHK(hipMemcpyAsync(e->pol_h[i][e->pol_flip], hc + off, m * 4, hipMemcpyHostToDevice, e->stream)); off += m;
+        HIPCHK(hipMemcpyAsync(e->pol_c[i][e->pol_flip], hc + off, m * 4, hipMemcpyHostToDevice, e->stream)); off += m;
+    }
+    HIPCHK(hipStreamSynchronize(e->stream)); return 0;
+}
+

@@ -1,0 +1,292 @@
+// engine_program.hip -- the static launch program of the train step (batch_train!, src/solver.jl:191-236 and :239-287): every pointer,
+// shape and plan is fixed at engine creation, so the step is compiled ONCE into a list of launches and replayed (hipGraph).
+#include "engine.h"
+
+// ---------------------------------------------------------------- static launch program
+// Every pointer, shape and plan is fixed at engine creation, so the train step is compiled ONCE into a list of launches
+// (closures) and merely replayed (and captured into a hipGraph).  Small independent kernels are batched: one k_valu_multi
+// launch per network level, one k_reduce_multi per level, head reductions folded into k_td.
+float* palloc(dqn_engine* e, size_t n) { float* d = nullptr; hipMalloc((void**)&d, n * 4); (e->alloc_sink ? *e->alloc_sink : e->prog_allocs).push_back(d); return d; }
+bool same_geo(const LayerDev& a, const LayerDev& b) {
+    return a.kind == b.kind && a.act == b.act && a.K == b.K && a.N == b.N && a.npos == b.npos && a.cin == b.cin && a.kh == b.kh && a.kw == b.kw &&
+           a.sh == b.sh && a.sw == b.sw && a.ih == b.ih && a.iw == b.iw && a.fwd_kc == b.fwd_kc && a.src == b.src;
+}
+void add_valu(dqn_engine* e, std::vector<VTask>& pend, const VTask& t) { pend.push_back(t); }
+void flush_valu(dqn_engine* e, std::vector<VTask>& pend, const char* name) {
+    if (pend.empty()) return;
+    unsigned blocks = 0;
+    for (auto& t : pend) { t.first_block = blocks; blocks += valu_task_blocks(t); }
+    VTask* dev = upload(e, pend); const int n = (int)pend.size();
+    (e->sink ? *e->sink : e->prog).push_back({name, [=](dqn_engine* en) { launch_valu_multi(en->stream, dev, n, blocks); }});
+    pend.clear();
+}
+void emit_reduce(dqn_engine* e, std::vector<RSeg>& segs, const char* name) {
+    if (segs.empty()) return;
+    unsigned blocks = 0;
+    for (auto& r : segs) { r.first_block = blocks; blocks += (unsigned)((r.elems + 255) / 256); }
+    RSeg* dev = upload(e, segs); const int n = (int)segs.size();
+    (e->sink ? *e->sink : e->prog).push_back({name, [=](dqn_engine* en) { launch_reduce_multi(en->stream, dev, n, blocks); }});
+    segs.clear();
+}
+const char* pname(dqn_engine* e, const char* op, int kind, int i) {
+    char b[32]; snprintf(b, sizeof b, "%s_%s%d", op, kind == DQN_LAYER_CONV ? "conv" : "dense", i); e->prog_names.push_back(b); return e->prog_names.back().c_str();
+}
+int build_program(dqn_engine* e) {
+    if (e->prog_built) return 0;
+    HIPCHK(hipSetDevice(e->device));
+    e->prog_names.reserve(512);
+    const int B = e->Bc /* columns of one sequence set: batch_size, or T*batch_size for DRQN */, ncon = e->ncon, ld0 = 2 * B, Bb = e->B, T = e->T;
+    const bool mf = e->hp.use_mfma != 0, rec = e->hp.recurrence != 0;
+    // forward views: an LSTM layer's batched part is its bias-free input projection Gx = Wi*x over ALL columns (a dense layer
+    // K = n_in, N = 4H writing gx_*); the recurrence then runs as T small launches.
+    LayerDev LV[DQN_MAX_LAYERS]; float *fwd_on[DQN_MAX_LAYERS], *fwd_tg[DQN_MAX_LAYERS];
+    for (int i = 0; i < e->nl; i++) {
+        LV[i] = e->L[i]; fwd_on[i] = e->act_on[i]; fwd_tg[i] = e->act_tg[i];
+        if (e->L[i].kind == DQN_LAYER_LSTM) { LV[i].kind = DQN_LAYER_DENSE; LV[i].out_feat = LV[i].N; LV[i].b_off = LV[i].z_off; LV[i].act = DQN_ACT_IDENTITY; fwd_on[i] = e->gx_on[i]; fwd_tg[i] = e->gx_tg[i]; }
+    }
+    std::vector<std::vector<int>> levels; std::vector<int> val, adv;
+    for (int i = 0; i < e->nl; i++) { if (e->L[i].stream == DQN_STREAM_BASE) levels.push_back({i}); else if (e->L[i].stream == DQN_STREAM_VAL) val.push_back(i); else adv.push_back(i); }
+    for (size_t j = 0; j < std::max(val.size(), adv.size()); j++) { std::vector<int> lv; if (j < val.size()) lv.push_back(val[j]); if (j < adv.size()) lv.push_back(adv[j]); levels.push_back(lv); }
+    HeadSrc head[DQN_MAX_LAYERS][2];   // per (layer, net): where k_td finds the layer's output
+    // ---------------- forward: online net on [s ; sp] (src/solver.jl:210,220), target net on sp (:211)
+    for (size_t li = 0; li < levels.size(); li++) {
+        // the head layers' split-K slabs are reduced inside the single-workgroup TD kernel only while that is cheaper than a reduce
+        // launch (small batches); at B = 512 the 7680 head values x 16 slabs belong on many workgroups
+        const auto& lv = levels[li]; const bool last = li + 1 == levels.size() && !rec && e->B <= 64;
+        struct Prob { int l, net; const float *P, *X; int ldx, col0, ncols; float *Y, *part; int S; };
+        std::vector<Prob> pr;
+        for (int l : lv) for (int net = 0; net < 2; net++) {
+            const LayerDev& L = LV[l]; Prob q; q.l = l; q.net = net; q.P = net ? e->p_tg : e->p_on;
+            float** act = net ? e->act_tg : e->act_on;
+            q.X = L.src < 0 ? e->x0 : act[L.src]; q.ldx = L.src < 0 ? ld0 : (net ? B : ncon); q.col0 = (L.src < 0 && net) ? B : 0; q.ncols = net ? B : ncon;
+            q.Y = net ? fwd_tg[l] : fwd_on[l]; q.S = dqn_nchunks(L.K, L.fwd_kc); q.part = q.S > 1 ? palloc(e, (size_t)q.S * L.out_feat * q.ncols) : nullptr;
+            pr.push_back(q);
+        }
+        bool geo = true; for (int l : lv) geo = geo && same_geo(LV[lv[0]], LV[l]);
+        std::vector<bool> done(pr.size(), false);
+        auto emit_gemm = [&](const std::vector<int>& ids, const char* name) {
+            const LayerDev L = LV[pr[ids[0]].l]; const int n = (int)ids.size();
+            struct A { const float *W[4], *bias[4], *X[4]; int ldx[4], col0[4], ncols[4]; float* out[4]; } a;
+            for (int i = 0; i < n; i++) { const Prob& q = pr[ids[i]]; const LayerDev& Lq = LV[q.l]; a.W[i] = q.P + Lq.w_off; a.bias[i] = q.P + Lq.b_off; a.X[i] = q.X; a.ldx[i] = q.ldx; a.col0[i] = q.col0; a.ncols[i] = q.ncols; a.out[i] = q.S > 1 ? q.part : q.Y; }
+            e->prog.push_back({name, [=](dqn_engine* en) { launch_gemm_fwd(en->stream, L, n, a.W, a.bias, a.X, a.ldx, a.col0, a.ncols, a.out); }});
+            for (int id : ids) done[id] = true;
+        };
+        if (mf) {
+            std::vector<int> all; int ldx[4], c0[4], nc[4];
+            for (size_t i = 0; i < pr.size() && i < 4; i++) { all.push_back((int)i); ldx[i] = pr[i].ldx; c0[i] = pr[i].col0; nc[i] = pr[i].ncols; }
+            if (geo && pr.size() <= 4 && gemm_fwd_eligible(LV[lv[0]], (int)pr.size(), ldx, c0, nc)) emit_gemm(all, pname(e, "fwd", e->L[lv[0]].kind, lv[0]));
+            else for (size_t i = 0; i + 1 < pr.size(); i += 2) {
+                int l2[2] = {pr[i].ldx, pr[i + 1].ldx}, c2[2] = {pr[i].col0, pr[i + 1].col0}, n2[2] = {pr[i].ncols, pr[i + 1].ncols};
+                if (gemm_fwd_eligible(LV[pr[i].l], 2, l2, c2, n2)) emit_gemm({(int)i, (int)i + 1}, pname(e, "fwd", e->L[pr[i].l].kind, pr[i].l));
+            }
+        }
+        std::vector<VTask> pend;
+        for (size_t i = 0; i < pr.size(); i++) {
+            if (done[i]) continue;
+            const Prob q = pr[i]; const LayerDev L = LV[q.l];
+            if (mf && mfma_fwd_ok(L, q.ncols)) {
+                e->prog.push_back({pname(e, q.net ? "fwd_tg" : "fwd_on", L.kind, q.l), [=](dqn_engine* en) { launch_mfma_fwd(en->stream, L, q.P, q.X, q.ldx, q.col0, q.ncols, q.Y, q.part, false); }});
+            } else {
+                VTask t; memset(&t, 0, sizeof t); t.kind = 0; t.L = L; t.P = q.P; t.X = q.X; t.ldx = q.ldx; t.col0 = q.col0; t.ncols = q.ncols; t.S = q.S; t.kc = dqn_chunk_len(L.K, L.fwd_kc);
+                t.out = q.S > 1 ? q.part : q.Y; add_valu(e, pend, t);
+            }
+        }
+        flush_valu(e, pend, pname(e, "fwd_valu", e->L[lv[0]].kind, lv[0]));
+        std::vector<RSeg> segs;
+        for (const Prob& q : pr) {
+            const LayerDev& L = LV[q.l];
+            HeadSrc h; h.p = q.Y; h.ld = q.ncols; h.S = 1; h.per_s = 0; h.bias = q.P + L.b_off; h.act = L.act;
+            if (q.S > 1) {
+                if (last) { h.p = q.part; h.S = q.S; h.per_s = (unsigned long long)L.out_feat * q.ncols; }   // reduced on the fly by k_td
+                else { RSeg r; memset(&r, 0, sizeof r); r.part = q.part; r.S = q.S; r.elems = (unsigned long long)L.out_feat * q.ncols; r.mode = 0; r.bias = q.P + L.b_off; r.per_n = L.npos * q.ncols; r.act = L.act; r.out = q.Y; segs.push_back(r); }
+            }
+            head[q.l][q.net] = h;
+        }
+        emit_reduce(e, segs, pname(e, "fwd_reduce", e->L[lv[0]].kind, lv[0]));
+        if (e->L[lv[0]].kind == DQN_LAYER_LSTM) {
+            // the recurrence: T launches, each advancing the online s-sequence, the online sp-sequence (double-Q) and the target
+            // sp-sequence by one step from the reset state (Flux.reset!, src/solver.jl:249-250,271)
+            const int l = lv[0]; const LayerDev L = e->L[l]; const int H = L.H;
+            if (lstm_seq_fits(H, Bb)) {        // small LSTM: the whole recurrence of the three sequence sets in ONE launch
+                LstmSeqArgs a; memset(&a, 0, sizeof a); a.H = H; a.B = Bb; a.T = T; int ns = 0;
+                auto seq = [&](const float* P, const float* gx, float* hout, float* cst, int ld, int c0, bool keep) {
+                    LstmSeqF& q = a.s[ns++]; q.Gx = gx; q.Hout = hout; q.Cst = cst; q.ld = ld; q.c0 = c0; q.Wh = P + L.wh_off; q.bias = P + L.b_off; q.h0 = P + L.h0_off; q.c0v = P + L.c0_off;
+                    if (keep) { q.gates = e->gates[l]; q.tc = e->tcb[l]; q.hprev_out = e->hprev_buf[l]; q.cprev_out = e->cprev_buf[l]; q.keep_ld = B; q.keep_c0 = 0; }
+                };
+                seq(e->p_on, e->gx_on[l], e->act_on[l], e->cst_on[l], ncon, 0, true);
+                if (e->hp.double_q) seq(e->p_on, e->gx_on[l], e->act_on[l], e->cst_on[l], ncon, B, false);
+                seq(e->p_tg, e->gx_tg[l], e->act_tg[l], e->cst_tg[l], B, 0, false);
+                a.nseq = ns;
+                e->prog.push_back({pname(e, "lstm_seq", L.kind, l), [=](dqn_engine* en) { launch_lstm_seq(en->stream, a); }});
+            } else
+            for (int t = 0; t < T; t++) {
+                LstmStepArgs a; memset(&a, 0, sizeof a); a.H = H; a.B = Bb; int ns = 0;
+                auto seq = [&](const float* P, const float* gx, float* hout, float* cst, int ld, int c0, bool keep) {
+                    LstmSeq& q = a.s[ns++]; q.Gx = gx; q.Hout = hout; q.Cst = cst; q.ld = ld; q.c0 = c0; q.Wh = P + L.wh_off; q.bias = P + L.b_off;
+                    if (t == 0) { q.hprev = P + L.h0_off; q.hp_ld = 1; q.hp_bs = 0; q.cprev = P + L.c0_off; q.cp_ld = 1; q.cp_bs = 0; }
+                    else { q.hprev = hout + c0 + (t - 1) * Bb; q.hp_ld = ld; q.hp_bs = 1; q.cprev = cst + c0 + (t - 1) * Bb; q.cp_ld = ld; q.cp_bs = 1; }
+                    if (keep) { q.gates = e->gates[l]; q.tc = e->tcb[l]; q.hprev_out = e->hprev_buf[l]; q.cprev_out = e->cprev_buf[l]; q.keep_ld = B; q.keep_c0 = 0; }
+                };
+                seq(e->p_on, e->gx_on[l], e->act_on[l], e->cst_on[l], ncon, 0, true);
+                if (e->hp.double_q) seq(e->p_on, e->gx_on[l], e->act_on[l], e->cst_on[l], ncon, B, false);
+                seq(e->p_tg, e->gx_tg[l], e->act_tg[l], e->cst_tg[l], B, 0, false);
+                a.nseq = ns;
+                e->prog.push_back({pname(e, "lstm_step", L.kind, l), [=](dqn_engine* en) { launch_lstm_step_t(en->stream, a, t); }});
+            }
+        }
+    }
+    // ---------------- dueling reduce + argmax + Bellman target + TD + Huber + dL/dQ + priority update
+    {
+        TdArgs t; memset(&t, 0, sizeof t);
+        t.B = B; t.nA = e->nA; t.ncon = ncon; t.dueling = e->hp.dueling; t.double_q = e->hp.double_q; t.prioritized = e->hp.prioritized_replay;
+        t.gamma = e->hp.gamma; t.prio_beta = e->hp.prio_beta; t.prio_eps = e->hp.prio_eps; t.prio_alpha = e->hp.prio_alpha; t.cap2 = e->cap2;
+        t.idx = e->idx; t.a = e->ra; t.r = e->rr; t.done = e->rdone; t.tree = e->tree;
+        const int lq = e->hp.dueling ? e->last_adv : e->last_base;
+        t.on_adv = head[lq][0]; t.tg_adv = head[lq][1]; t.d_adv = e->dact[lq];
+        if (e->hp.dueling) { t.on_val = head[e->last_val][0]; t.tg_val = head[e->last_val][1]; t.d_val = e->dact[e->last_val]; }
+        t.w_is = e->w_is; t.td = e->td; t.q_on_s = e->q_on_s; t.q_on_sp = e->q_on_sp; t.q_tg_sp = e->q_tg_sp; t.ytarget = e->ytarget; t.best = e->best; t.st = e->state;
+        if (!rec) e->prog.push_back({"td_huber", [=](dqn_engine* en) { TdArgs a = t; a.bump_sample_ctr = en->step_sampled ? 1 : 0; launch_td(en->stream, a); }});
+        else {
+            TdDrqnArgs d; memset(&d, 0, sizeof d); d.B = Bb; d.T = T; d.nA = e->nA; d.ncon = ncon; d.dueling = e->hp.dueling; d.double_q = e->hp.double_q; d.gamma = e->hp.gamma;
+            d.on_val = t.on_val; d.on_adv = t.on_adv; d.tg_val = t.tg_val; d.tg_adv = t.tg_adv; d.d_val = t.d_val; d.d_adv = t.d_adv;
+            d.a = e->r_a; d.r = e->r_r; d.done = e->r_done; d.mask = e->r_mask; d.td = e->td; d.st = e->state;
+            e->prog.push_back({"td_huber_drqn", [=](dqn_engine* en) { launch_td_drqn(en->stream, d); }});
+        }
+    }
+    // ---------------- backward of the online net on the s columns (Zygote through src/solver.jl:219-225)
+    std::vector<RSeg> final_segs;   // dW split-K slabs: nothing reads the gradient before Adam, so ONE reduce launch at the end
+    bool joined = false;
+    for (int li = (int)levels.size() - 1; li >= 0; li--) {
+        const auto& lv = levels[li];
+        std::vector<VTask> pend;
+        bool dw_done_sibling = false;   // the level's two sibling layers got their dW from one fused launch
+        struct DwL { bool on = false; LayerDev L; int nprob = 0; const float* X[2]; int ldx = 0; const float* d[2]; float* o[2]; const char* name = ""; } dwl;
+        struct DxL { bool on = false; LayerDev L; int nsrc = 0; const float* W[2]; const float* d[2]; float* out = nullptr; const float* ys = nullptr; int act_src = 0; const char* name = ""; } dxl;
+        auto flush_dw = [&]() { if (!dwl.on) return; const DwL a = dwl; e->prog.push_back({a.name, [=](dqn_engine* en) { launch_gemm_dw(en->stream, a.L, a.nprob, a.X, a.ldx, a.d, B, a.o); }}); dwl.on = false; };
+        auto flush_dx = [&]() { if (!dxl.on) return; const DxL a = dxl; e->prog.push_back({a.name, [=](dqn_engine* en) { launch_gemm_dx(en->stream, a.L, a.nsrc, a.W, a.d, B, a.out, a.ys, ncon, a.act_src); }}); dxl.on = false; };
+        for (int k = (int)lv.size() - 1; k >= 0; k--) {
+            const int l = lv[k]; const LayerDev L = e->L[l];
+            const float* X = L.src < 0 ? e->x0 : e->act_on[L.src]; const int ldx = L.src < 0 ? ld0 : ncon;
+            float* dpre = e->dact[l];
+            if (L.kind == DQN_LAYER_LSTM) {
+                // BPTT over the s-sequence: T single-workgroup steps produce dG (gate pre-activation gradients) for all columns,
+                // then Wi|b, Wh and the input gradient are ordinary dense contractions over the T*B columns.
+                float* grad = e->grad;
+                if (lstm_seq_fits(L.H, Bb)) {
+                    LstmBwdArgs a; a.t = 0; a.T = T; a.H = L.H; a.B = Bb; a.TB = B; a.gates = e->gates[l]; a.tc = e->tcb[l]; a.cprev = e->cprev_buf[l]; a.Wh = e->p_on + L.wh_off;
+                    a.dH = dpre; a.dG = e->dG[l]; a.dhn = e->dhn[l]; a.dcn = e->dcn[l]; a.g_h0 = grad + L.h0_off; a.g_c0 = grad + L.c0_off;
+                    e->prog.push_back({pname(e, "lstm_bwd_seq", L.kind, l), [=](dqn_engine* en) { launch_lstm_bwd_seq(en->stream, a); }});
+                } else
+                for (int t = T - 1; t >= 0; t--) {
+                    LstmBwdArgs a; a.t = t; a.T = T; a.H = L.H; a.B = Bb; a.TB = B; a.gates = e->gates[l]; a.tc = e->tcb[l]; a.cprev = e->cprev_buf[l]; a.Wh = e->p_on + L.wh_off;
+                    a.dH = dpre; a.dG = e->dG[l]; a.dhn = e->dhn[l]; a.dcn = e->dcn[l]; a.g_h0 = grad + L.h0_off; a.g_c0 = grad + L.c0_off;
+                    e->prog.push_back({pname(e, "lstm_bwd", L.kind, l), [=](dqn_engine* en) { launch_lstm_bwd_step(en->stream, a); }});
+                }
+                LayerDev Vi = L; Vi.kind = DQN_LAYER_DENSE; Vi.out_feat = L.N; Vi.act = DQN_ACT_IDENTITY;                    // Wi | b  : (K+1) x 4H
+                LayerDev Vh = Vi; Vh.K = L.H; Vh.in_feat = L.H; Vh.w_off = L.wh_off; Vh.b_off = L.wh_off + (size_t)L.H * L.N;  // Wh | junk
+                const float* dG = e->dG[l];
+                auto emit_dw1 = [&](const LayerDev V, const float* Xv, int ldv, const char* nm) {
+                    const int S = dqn_nchunks(B, V.dw_kc);
+                    float* part = S > 1 ? palloc(e, (size_t)S * (V.K + 1) * V.N) : nullptr; float* dst = S > 1 ? part : grad + V.w_off;
+                    if (mf && gemm_dw_eligible(V, B, ldv)) { struct A { const float* X[1]; const float* d[1]; float* o[1]; } a; a.X[0] = Xv; a.d[0] = dG; a.o[0] = dst;
+                        e->prog.push_back({nm, [=](dqn_engine* en) { launch_gemm_dw(en->stream, V, 1, a.X, ldv, a.d, B, a.o); }}); }
+                    else if (mf && mfma_dw_ok(V, B)) e->prog.push_back({nm, [=](dqn_engine* en) { launch_mfma_dw(en->stream, V, Xv, ldv, dG, B, grad, part, false); }});
+                    else { VTask t; memset(&t, 0, sizeof t); t.kind = 1; t.L = V; t.X = Xv; t.ldx = ldv; t.dpre = dG; t.B = B; t.S = S; t.kc = dqn_chunk_len(B, V.dw_kc); t.out = dst; add_valu(e, pend, t); }
+                    if (S > 1) { RSeg r; memset(&r, 0, sizeof r); r.part = part; r.S = S; r.elems = (unsigned long long)(V.K + 1) * V.N; r.mode = 2; r.out = grad + V.w_off; final_segs.push_back(r); }
+                };
+                emit_dw1(Vh, e->hprev_buf[l], B, pname(e, "dw_wh", L.kind, l));      // first: its junk bias row is then overwritten by nothing that matters
+                emit_dw1(Vi, X, ldx, pname(e, "dw_wi", L.kind, l));
+                if (L.src >= 0) {
+                    const int src = L.src; const int act_src = e->L[src].act; float* out = e->dact[src]; const float* ysrc = e->act_on[src]; const float* P = e->p_on;
+                    const int S = dqn_nchunks(Vi.N, Vi.dx_kc); float* part = S > 1 ? palloc(e, (size_t)S * Vi.in_feat * B) : nullptr;
+                    if (mf && gemm_dx_eligible(Vi, B, ncon)) { struct A1 { const float* W[1]; const float* d[1]; } a; a.W[0] = P + Vi.w_off; a.d[0] = dG; float* dst = S > 1 ? part : out; const float* ys = S > 1 ? nullptr : ysrc;
+                        e->prog.push_back({pname(e, "dx", L.kind, l), [=](dqn_engine* en) { launch_gemm_dx(en->stream, Vi, 1, a.W, a.d, B, dst, ys, ncon, act_src); }}); }
+                    else if (mf && mfma_dx_ok(Vi, B, ncon)) e->prog.push_back({pname(e, "dx", L.kind, l), [=](dqn_engine* en) { launch_mfma_dx(en->stream, Vi, P, dG, B, out, part, nullptr, ysrc, ncon, act_src, false); }});
+                    else { VTask t; memset(&t, 0, sizeof t); t.kind = 2; t.L = Vi; t.P = P; t.dpre = dG; t.B = B; t.S = S; t.kc = dqn_chunk_len(Vi.N, Vi.dx_kc); t.out = S > 1 ? part : out; t.ysrc = ysrc; t.ldy = ncon; t.act_src = act_src; add_valu(e, pend, t); }
+                    if (S > 1) { flush_valu(e, pend, pname(e, "bwd_valu", L.kind, l)); std::vector<RSeg> one; RSeg r; memset(&r, 0, sizeof r); r.part = part; r.S = S; r.elems = (unsigned long long)Vi.in_feat * B; r.mode = 1; r.act = act_src; r.ysrc = ysrc; r.B = B; r.ldy = ncon; r.out = out; one.push_back(r); emit_reduce(e, one, pname(e, "dx_reduce", L.kind, l)); }
+                }
+                continue;
+            }
+            {   // dW / db
+                const int S = dqn_nchunks(L.npos * B, L.dw_kc);
+                float* part = S > 1 ? palloc(e, (size_t)S * (L.K + 1) * L.N) : nullptr;
+                float* grad = e->grad;
+                float* dst = S > 1 ? part : grad + L.w_off;
+                if (mf && gemm_dw_eligible(L, B, ldx)) {
+                    // sibling layers of this level with identical geometry and the same input share ONE launch
+                    if (k == (int)lv.size() - 1 && lv.size() == 2 && same_geo(e->L[lv[0]], e->L[lv[1]]) && e->L[lv[0]].dw_kc == e->L[lv[1]].dw_kc) {
+                        const LayerDev L0 = e->L[lv[0]]; const int S0 = S;
+                        float* part0 = S0 > 1 ? palloc(e, (size_t)S0 * (L0.K + 1) * L0.N) : nullptr;
+                        flush_dw(); dwl.on = true; dwl.L = L; dwl.nprob = 2; dwl.ldx = ldx; dwl.name = pname(e, "dw2", L.kind, l);
+                        dwl.X[0] = X; dwl.d[0] = dpre; dwl.o[0] = dst; dwl.X[1] = X; dwl.d[1] = e->dact[lv[0]]; dwl.o[1] = S0 > 1 ? part0 : grad + L0.w_off;
+                        if (S0 > 1) { RSeg r; memset(&r, 0, sizeof r); r.part = part0; r.S = S0; r.elems = (unsigned long long)(L0.K + 1) * L0.N; r.mode = 2; r.out = grad + L0.w_off; final_segs.push_back(r); }
+                        dw_done_sibling = true;
+                    } else if (!(dw_done_sibling && k == 0 && lv.size() == 2)) {
+                        flush_dw(); dwl.on = true; dwl.L = L; dwl.nprob = 1; dwl.ldx = ldx; dwl.name = pname(e, "dw", L.kind, l);
+                        dwl.X[0] = dwl.X[1] = X; dwl.d[0] = dwl.d[1] = dpre; dwl.o[0] = dwl.o[1] = dst;
+                    }
+                }
+                else if (mf && mfma_dw_ok(L, B)) e->prog.push_back({pname(e, "dw", L.kind, l), [=](dqn_engine* en) { launch_mfma_dw(en->stream, L, X, ldx, dpre, B, grad, part, false); }});
+                else { VTask t; memset(&t, 0, sizeof t); t.kind = 1; t.L = L; t.X = X; t.ldx = ldx; t.dpre = dpre; t.B = B; t.S = S; t.kc = dqn_chunk_len(L.npos * B, L.dw_kc); t.out = dst; add_valu(e, pend, t); }
+                if (S > 1 && !(dw_done_sibling && k == 0 && lv.size() == 2)) { RSeg r; memset(&r, 0, sizeof r); r.part = part; r.S = S; r.elems = (unsigned long long)(L.K + 1) * L.N; r.mode = 2; r.out = grad + L.w_off; final_segs.push_back(r); }
+            }
+            if (L.src < 0) continue;
+            // dX, then act' of the producing layer; the two streams of a dueling net meet at the base output (dX_val + dX_adv)
+            const int src = L.src; const bool is_join = e->hp.dueling && src == e->last_base && L.stream != DQN_STREAM_BASE;
+            const bool dense = L.kind == DQN_LAYER_DENSE; const int S = dense ? dqn_nchunks(L.N, L.dx_kc) : 1;
+            const float* P = e->p_on; const int act_src = e->L[src].act;
+            if (is_join && lv.size() == 2 && S == 1 && mf && same_geo(e->L[lv[0]], e->L[lv[1]]) && gemm_dx_eligible(L, B, ncon)) {
+                // both streams in ONE launch: the kernel accumulates dX_val and dX_adv separately and adds them (val first)
+                if (k == (int)lv.size() - 1) {
+                    const LayerDev Lv = e->L[lv[0]], La = e->L[lv[1]];
+                    flush_dx(); dxl.on = true; dxl.L = Lv; dxl.nsrc = 2; dxl.W[0] = P + Lv.w_off; dxl.d[0] = e->dact[lv[0]]; dxl.W[1] = P + La.w_off; dxl.d[1] = e->dact[lv[1]];
+                    dxl.out = e->dact[src]; dxl.ys = e->act_on[src]; dxl.act_src = act_src; dxl.name = pname(e, "dx_join", L.kind, l);
+                }
+                continue;
+            }
+            float* out = e->dact[src]; const float *addend = nullptr, *ysrc = e->act_on[src];
+            if (is_join && !joined) { out = e->join_tmp; ysrc = nullptr; joined = true; }
+            else if (is_join) { addend = e->join_tmp; flush_valu(e, pend, pname(e, "bwd_valu", L.kind, l)); }   // depends on the first stream's dX
+            float* part = S > 1 ? palloc(e, (size_t)S * L.in_feat * B) : nullptr;
+            if (mf && !addend && gemm_dx_eligible(L, B, ncon)) {
+                flush_dx(); dxl.on = true; dxl.L = L; dxl.nsrc = 1; dxl.W[0] = dxl.W[1] = P + L.w_off; dxl.d[0] = dxl.d[1] = dpre;
+                dxl.out = S > 1 ? part : out; dxl.ys = S > 1 ? nullptr : ysrc; dxl.act_src = act_src; dxl.name = pname(e, "dx", L.kind, l);
+                if (S > 1) flush_dx();   // its partial slabs are reduced right below
+            }
+            else if (mf && L.N >= 16 && mfma_dx_ok(L, B, ncon)) e->prog.push_back({pname(e, "dx", L.kind, l), [=](dqn_engine* en) { launch_mfma_dx(en->stream, L, P, dpre, B, out, part, addend, ysrc, ncon, act_src, false); }});
+            else { VTask t; memset(&t, 0, sizeof t); t.kind = 2; t.L = L; t.P = P; t.dpre = dpre; t.B = B; t.S = S; t.kc = dqn_chunk_len(L.N, L.dx_kc); t.out = S > 1 ? part : out; t.addend = addend; t.ysrc = ysrc; t.ldy = ncon; t.act_src = act_src; add_valu(e, pend, t); }
+            if (S > 1) {
+                flush_valu(e, pend, pname(e, "bwd_valu", L.kind, l));
+                std::vector<RSeg> one; RSeg r; memset(&r, 0, sizeof r); r.part = part; r.S = S; r.elems = (unsigned long long)L.in_feat * B; r.mode = 1; r.act = act_src; r.addend = addend; r.ysrc = ysrc; r.B = B; r.ldy = ncon; r.out = out; one.push_back(r);
+                emit_reduce(e, one, pname(e, "dx_reduce", L.kind, l));
+            }
+        }
+        flush_valu(e, pend, pname(e, "bwd_valu", e->L[lv[0]].kind, lv[0]));
+        if (dwl.on && dxl.on) {      // dW and dX of this level in ONE launch
+            const DwL a = dwl; const DxL x = dxl; dwl.on = dxl.on = false;
+            char nm[48]; snprintf(nm, sizeof nm, "%s+%s", a.name, x.name); e->prog_names.push_back(nm); const char* name = e->prog_names.back().c_str();
+            e->prog.push_back({name, [=](dqn_engine* en) { launch_gemm_dwdx(en->stream, a.L, a.nprob, a.X, a.ldx, a.d, B, a.o, x.L, x.nsrc, x.W, x.d, x.out, x.ys, ncon, x.act_src); }});
+        }
+        flush_dw(); flush_dx();
+    }
+    memset(&e->adam_segs, 0, sizeof e->adam_segs);
+    {
+        bool ok = !final_segs.empty() && final_segs.size() <= 8; unsigned long long tot = 0;
+        for (auto& r : final_segs) { const unsigned long long beg = (unsigned long long)(r.out - e->grad); ok = ok && beg % 4 == 0 && r.elems % 4 == 0 && r.S2 == 0; }
+        if (ok) {
+            for (auto& r : final_segs) { const int q = e->adam_segs.n++; e->adam_segs.beg[q] = (unsigned long long)(r.out - e->grad); e->adam_segs.end[q] = e->adam_segs.beg[q] + r.elems; e->adam_segs.part[q] = r.part; e->adam_segs.S[q] = r.S; tot += r.elems; }
+            e->adam_segs.blocks = (unsigned)((tot + 255) / 256);
+        }
+        if (!final_segs.empty()) e->final_reduce_step = (long)e->prog.size();
+    }
+    emit_reduce(e, final_segs, "dw_reduce_all");
+    e->prog_post_begin = e->prog.size();
+    e->prog.push_back({"adam", [](dqn_engine* en) {
+        PrioArgs pa; pa.n = (en->hp.prioritized_replay && !en->hp.recurrence) ? en->B : 0; pa.cap2 = en->cap2; pa.idx = en->idx; pa.td = en->td; pa.eps = en->hp.prio_eps; pa.alpha = en->hp.prio_alpha; pa.tree = en->tree;
+        AdamSegs none; memset(&none, 0, sizeof none);
+        const bool fold = en->adam_segs.n > 0 && !en->comm;     // with a communicator the gradient must be materialised before the all-reduce
+        launch_adam(en->stream, en->Pint, en->p_on, en->m, en->v, en->grad, en->state, en->gmax_part, en->hp.adam_f64_scalars, en->hp.learning_rate,
+                    en->hp.adam_beta1, en->hp.adam_beta2, en->hp.adam_eps, en->world > 1 ? 1.0f / (float)en->world : 1.0f, pa, fold ? en->adam_segs : none, en->grad); }});
+    e->prog_built = true;
+    return 0;
+}

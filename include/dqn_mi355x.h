@@ -35,6 +35,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: only these entry points are exported */
+#endif
 
 typedef struct dqn_engine dqn_engine_t;
 
@@ -233,6 +236,9 @@ int dqn_stream_handle(dqn_engine_t* e, void** hip_stream);
  * milliseconds measured with HIP events on the engine stream. */
 int dqn_profile_step(dqn_engine_t* e, int max_entries, const char** names, float* ms, int* n_entries);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif
