@@ -231,6 +231,7 @@ def main():
         else:
             roof = dict(kernel=dom, bound="hbm", achieved=by / (kern[dom] * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", traffic=None)
         roof["frac"] = roof["achieved"] / roof["peak"]
+        roof.update(pmc_traffic(dom))
         roof["avg_launch_ms"] = kern[dom]
         step_flops = step_flops_analytic(g2, B, ncon)
         roof["step_flops"] = step_flops
@@ -312,6 +313,31 @@ def cpu_baseline(pkg, layers, hp, params, env, args):
                       f"oracle/dqn_ref.c with OpenMP over {cores} threads (best of 1/8/16/32/64 on a {ncpu}-CPU host); the Julia/Flux reference cannot run in this image"}
 
 
+
+
+def pmc_traffic(op):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_fetch.txt / *_pmc_write.txt: separate
+    --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this bench, values in KB; gfx950 reports half of wide reads, hence x2 on FETCH_SIZE as the
+    MI355X guide prescribes).  bench.py cannot run the profiler itself; the newest committed pass is quoted, or null."""
+    import glob
+    kname = {"adam": "k_adam", "sample_gather": "k_gather_fb", "gather": "k_gather_fb"}.get(op)
+    if kname is None:
+        return {}
+    def last(pattern):
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+            if "cfg5" in path:
+                continue
+            for line in open(path):
+                f = line.split()
+                if f and f[0] == kname and len(f) >= 3:
+                    return float(f[-1]), os.path.basename(path)
+        return None, None
+    fetch, pf = last("*_pmc_fetch.txt")
+    write, pw = last("*_pmc_write.txt")
+    if fetch is None or write is None:
+        return {}
+    return {"traffic": (2.0 * fetch + write) * 1024.0, "traffic_unit": "bytes/launch",
+            "traffic_source": f"profiles/{pf} (FETCH_SIZE x2) + profiles/{pw} (WRITE_SIZE), separate rocprofv3 --pmc passes of this bench"}
 
 
 def torch_cpu_line(hp, seconds):
