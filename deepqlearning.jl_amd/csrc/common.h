@@ -263,10 +263,20 @@ void launch_env_step(hipStream_t st, const EnvDev& V, RolloutDev* rs, const ActH
 void launch_env_observe2(hipStream_t st, const EnvDev& V, const RolloutDev* rs, int rows_u8, void* s_rows, void* sp_rows, long long cap, float* x);
 void launch_env_reset_pending(hipStream_t st, const EnvDev& V, const RolloutDev* rs, int force_all);
 
+// ---- data-parallel exchange (dp.hip)
+#define DP_MAX_REGIONS 48
+struct DpRegion { const float* src; unsigned long long dst, n; int B, ld; };
+struct DpPackArgs { int n; DpRegion r[DP_MAX_REGIONS]; float* send; };
+struct DpRange { unsigned long long src, dst, n; };
+struct DpSumArgs { int n; DpRange r[DP_MAX_REGIONS]; const float* recv; unsigned long long stride; int world; float* grad; };
+void launch_dp_pack(hipStream_t st, const DpPackArgs& a);
+void launch_dp_unpack_sum(hipStream_t st, const DpSumArgs& a);
+
 // MFMA path (nn_mfma.hip): returns false if the shape is not eligible (caller falls back to the VALU kernel,
 // which computes bit-identical values)
 bool gemm_dw_eligible(const LayerDev& L, int B, int ldx);
-void launch_gemm_dw(hipStream_t st, const LayerDev& L, int nprob, const float* const* X, int ldx, const float* const* dpre, int B, float* const* out);
+void launch_gemm_dw(hipStream_t st, const LayerDev& L, int nprob, const float* const* X, int ldx, const float* const* dpre, int B, float* const* out,
+                    int ldd = 0, int tpr = 0, int rstride = 0);   // 0 = plain layout; else gathered rank blocks (see DwStride in nn_gemm.hip)
 
 bool gemm_dx_eligible(const LayerDev& L, int B, int ldy);
 void launch_gemm_dx(hipStream_t st, const LayerDev& L, int nsrc, const float* const* W, const float* const* dpre, int B, float* out /* dact or partial slabs */,

@@ -45,7 +45,10 @@ struct dqn_engine {
     // graphs: [0] = step with sampling, [1] = step on given indices; with a communicator the step is cut in two
     hipGraphExec_t g_full[2] = {nullptr, nullptr}, g_pre[2] = {nullptr, nullptr}, g_post = nullptr;
     // comm
-    void* comm = nullptr; int rank = 0, world = 1; bool force_comm = false;   // force_comm: run the all-reduce path even at world == 1 (tests)
+    void* comm = nullptr; int rank = 0, world = 1; bool force_comm = false;
+    // exchange mode of the replicas: gather = all-gather of the wide dense layers' operands + small gradients (dp.hip); else all-reduce of the gradient.
+    // sim_world = k (env DQN_SIM_WORLD, tests): one process plays k identical ranks, the collective is k local copies.
+    bool dp_gather = false; int sim_world = 0; float *dp_send = nullptr, *dp_recv = nullptr; size_t dp_count = 0;   // force_comm: run the all-reduce path even at world == 1 (tests)
     // DRQN (recurrence = true): column count per sequence set Bc = T*B (B otherwise); EpisodeReplayBuffer storage; LSTM workspaces
     int Bc = 0, T = 1; long long ep_cap = 0, ep_size = 0, ep_widx = 0, ep_cur_len = 0; std::vector<int> ep_len_host; std::vector<int64_t> ep_perm;
     float *ep_s = nullptr, *ep_sp = nullptr, *ep_r = nullptr; int* ep_a = nullptr; unsigned char* ep_done = nullptr; int* ep_len = nullptr;
@@ -85,7 +88,7 @@ void drop_act(dqn_engine* e, dqn_engine::ActProg& a);
 void fwd_layer(dqn_engine* e, const LayerDev& l, const float* P, const float* X, int ldx, int col0, int ncols, float* Y, const char* name);
 void enqueue_step(dqn_engine* e, bool sample, int phase);
 int capture(dqn_engine* e, bool sample, int phase, hipGraphExec_t* out);
-int allreduce_grads(dqn_engine* e);
+int exchange_grads(dqn_engine* e);      // the one collective of a data-parallel step (all-gather or all-reduce)
 int run_step(dqn_engine* e, bool sample);
 int fetch_scalars(dqn_engine* e, float* loss, float* gn);
 int policy_ws(dqn_engine* e, int n);

@@ -19,6 +19,7 @@ struct Rccl {
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, Id128, int) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
@@ -31,9 +32,10 @@ static int rccl_load() {
     g_rccl.GetUniqueId = (int (*)(void*))dlsym(g_rccl.lib, "ncclGetUniqueId");
     g_rccl.CommInitRank = (int (*)(void**, int, Id128, int))dlsym(g_rccl.lib, "ncclCommInitRank");
     g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(g_rccl.lib, "ncclAllReduce");
+    g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(g_rccl.lib, "ncclAllGather");
     g_rccl.CommDestroy = (int (*)(void*))dlsym(g_rccl.lib, "ncclCommDestroy");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce) return fail("librccl is missing nccl symbols");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather) return fail("librccl is missing nccl symbols");
     return 0;
 }
 
@@ -140,6 +142,7 @@ extern "C" int dqn_engine_create(const dqn_layer_desc* layers, int n_layers, con
     e->device = device; e->hp = *hp; e->B = hp->batch_size; e->nA = hp->n_actions; e->E = hp->obs_c * hp->obs_h * hp->obs_w;
     if (build_layers(layers, n_layers, hp, e->L, &e->last_base, &e->last_val, &e->last_adv, &e->P, &e->Pint)) { delete e; return -1; }
     e->nl = n_layers;
+    if (const char* sw = getenv("DQN_SIM_WORLD")) { const int k = atoi(sw); if (k >= 1 && !hp->recurrence) { e->sim_world = k; e->world = k; } }   // tests: one process plays k identical ranks
     dqn_layer_plan defp[DQN_MAX_LAYERS];
     if (!plan) { default_plan(e->L, e->nl, e->B, defp); plan = defp; }
     for (int i = 0; i < e->nl; i++) {
@@ -230,7 +233,7 @@ extern "C" int dqn_engine_destroy(dqn_engine_t* e) {
     for (int i = 0; i < e->nl; i++) { hipFree(e->act_on[i]); hipFree(e->act_tg[i]); hipFree(e->dact[i]); }
     hipFree(e->join_tmp); hipFree(e->partials); hipFree(e->gmax_part); hipFree(e->w_is); hipFree(e->td); hipFree(e->q_on_s); hipFree(e->q_on_sp); hipFree(e->q_tg_sp);
     hipFree(e->ytarget); hipFree(e->best); hipFree(e->gb_rows); hipFree(e->gb_r); hipFree(e->gb_done); hipFree(e->gb_w); hipFree(e->gb_a); hipFree(e->gb_idx);
-    free_policy_ws(e); free_envs(e);
+    free_policy_ws(e); free_envs(e); hipFree(e->dp_send); hipFree(e->dp_recv);
     for (void* p : e->prog_allocs) hipFree(p);
     hipFree(e->ep_s); hipFree(e->ep_sp); hipFree(e->ep_a); hipFree(e->ep_r); hipFree(e->ep_done); hipFree(e->ep_len); hipFree(e->ep_idx); hipFree(e->ep_start);
     hipFree(e->r_a); hipFree(e->r_r); hipFree(e->r_done); hipFree(e->r_mask);
@@ -401,7 +404,7 @@ void enqueue_step(dqn_engine* e, bool sample, int phase) {
                                                                         fused ? 1 : 0, e->cap2, e->tree, e->hp.seed, e->state));
         }
         for (size_t i = 0; i < e->prog_post_begin; i++) {
-            if ((long)i == e->final_reduce_step && e->adam_segs.n > 0 && !e->comm) continue;   // folded into k_adam
+            if ((long)i == e->final_reduce_step && e->adam_segs.n > 0 && !e->comm && !e->sim_world) continue;   // folded into k_adam
             RUN(e, e->prog[i].name, e->prog[i].fn(e));
         }
     }
@@ -415,7 +418,17 @@ int capture(dqn_engine* e, bool sample, int phase, hipGraphExec_t* out) {
     HIPCHK(hipGraphInstantiate(out, g, nullptr, nullptr, 0));
     HIPCHK(hipGraphDestroy(g)); return 0;
 }
-int allreduce_grads(dqn_engine* e) {
+int exchange_grads(dqn_engine* e) {
+    if (e->dp_gather) {      // every rank's packed block -> all ranks (rank-major), on the engine stream between the two halves of the step
+        if (e->sim_world) {
+            for (int r = 0; r < e->sim_world; r++) HIPCHK(hipMemcpyAsync(e->dp_recv + (size_t)r * e->dp_count, e->dp_send, e->dp_count * 4, hipMemcpyDeviceToDevice, e->stream));
+            return 0;
+        }
+        const int rc = g_rccl.AllGather(e->dp_send, e->dp_recv, e->dp_count, /*ncclFloat*/ 7, e->comm, e->stream);
+        if (rc) return fail("ncclAllGather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+        return 0;
+    }
+    if (e->sim_world) return fail("DQN_SIM_WORLD needs the gather exchange (no wide dense layer in this network, or DQN_DP_ALLREDUCE is set)");
     const int rc = g_rccl.AllReduce(e->grad, e->grad, e->Pint, /*ncclFloat*/ 7, /*ncclSum*/ 0, e->comm, e->stream);
     if (rc) return fail("ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
     return 0;
@@ -423,14 +436,14 @@ int allreduce_grads(dqn_engine* e) {
 int run_step(dqn_engine* e, bool sample) {
     if (build_program(e)) return -1;
     const int gi = sample ? 0 : 1;
-    if (e->world > 1 || (e->comm && e->force_comm)) {
+    if (e->world > 1 || (e->comm && e->force_comm)) {      // data-parallel replicas (also DQN_SIM_WORLD: world = k without a communicator)
         if (e->hp.use_graph && !e->profiling) {
             if (!e->g_pre[gi] && capture(e, sample, PH_PRE, &e->g_pre[gi])) return -1;
             if (!e->g_post && capture(e, sample, PH_POST, &e->g_post)) return -1;
             HIPCHK(hipGraphLaunch(e->g_pre[gi], e->stream));
-            if (allreduce_grads(e)) return -1;
+            if (exchange_grads(e)) return -1;
             HIPCHK(hipGraphLaunch(e->g_post, e->stream));
-        } else { enqueue_step(e, sample, PH_PRE); if (allreduce_grads(e)) return -1; enqueue_step(e, sample, PH_POST); }
+        } else { enqueue_step(e, sample, PH_PRE); if (exchange_grads(e)) return -1; enqueue_step(e, sample, PH_POST); }
         return 0;
     }
     if (e->hp.use_graph && !e->profiling) {
@@ -558,7 +571,13 @@ extern "C" int dqn_comm_init(dqn_engine_t* e, const void* id128, int rank, int w
     Id128 id; memcpy(id.b, id128, 128);
     const int rc = g_rccl.CommInitRank(&e->comm, world, id, rank);
     if (rc) return fail("ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
-    e->rank = rank; e->world = world; e->force_comm = getenv("DQN_FORCE_ALLREDUCE") != nullptr; drop_graphs(e); return 0;
+    e->rank = rank; e->world = world; e->sim_world = 0; e->force_comm = getenv("DQN_FORCE_ALLREDUCE") != nullptr;
+    // the launch program depends on the exchange mode and the world size: rebuild it on the next step
+    drop_graphs(e); HIPCHK(hipStreamSynchronize(e->stream));
+    for (void* p : e->prog_allocs) hipFree(p);
+    e->prog_allocs.clear(); e->prog.clear(); e->prog_built = false; e->prog_post_begin = 0; e->final_reduce_step = -1; memset(&e->adam_segs, 0, sizeof e->adam_segs);
+    hipFree(e->dp_send); hipFree(e->dp_recv); e->dp_send = e->dp_recv = nullptr; e->dp_gather = false; e->dp_count = 0;
+    return 0;
 }
 
 // ---------------------------------------------------------------- misc

@@ -86,7 +86,7 @@ extern "C" int dqn_train_step_drqn(dqn_engine_t* e, const int64_t* ep_idx, const
     if (e->hp.use_graph && !e->profiling && e->world == 1) {
         if (!e->g_drqn && capture(e, false, PH_ALL, &e->g_drqn)) return -1;
         HIPCHK(hipGraphLaunch(e->g_drqn, e->stream));
-    } else { enqueue_step(e, false, PH_PRE); if (e->world > 1 && allreduce_grads(e)) return -1; enqueue_step(e, false, PH_POST); }
+    } else { enqueue_step(e, false, PH_PRE); if (e->world > 1 && exchange_grads(e)) return -1; enqueue_step(e, false, PH_POST); }
     if (loss || grad_norm) return fetch_scalars(e, loss, grad_norm);
     return 0;
 }

@@ -153,6 +153,15 @@ int build_program(dqn_engine* e) {
             e->prog.push_back({"td_huber_drqn", [=](dqn_engine* en) { launch_td_drqn(en->stream, d); }});
         }
     }
+    // ---------------- data-parallel replicas: which layers' dW is computed AFTER the exchange from gathered operands (dp.hip)
+    const int W = e->sim_world ? e->sim_world : e->world;
+    const bool dp_on = (e->comm || e->sim_world) && !rec && getenv("DQN_DP_ALLREDUCE") == nullptr;
+    bool dp_layer[DQN_MAX_LAYERS] = {}; int n_dp = 0;
+    if (dp_on) for (int i = 0; i < e->nl; i++) {
+        const LayerDev& L = e->L[i];
+        // a wide dense layer whose operands (X: K x B, dpre: N x B per rank) are smaller than its gradient, one chain over all W*B samples
+        if (L.kind == DQN_LAYER_DENSE && mf && (size_t)(L.K + 1) * L.N > (size_t)4 * (L.K + L.N) * B && L.dw_kc == 0 && B % 32 == 0 && gemm_dw_eligible(L, W * B, B) && n_dp < 8) { dp_layer[i] = true; n_dp++; }
+    }
     // ---------------- backward of the online net on the s columns (Zygote through src/solver.jl:219-225)
     std::vector<RSeg> final_segs;   // dW split-K slabs: nothing reads the gradient before Adam, so ONE reduce launch at the end
     bool joined = false;
@@ -207,7 +216,7 @@ int build_program(dqn_engine* e) {
                 }
                 continue;
             }
-            {   // dW / db
+            if (!dp_layer[l]) {   // dW / db  (layers flagged for the gather exchange get theirs after the collective)
                 const int S = dqn_nchunks(L.npos * B, L.dw_kc);
                 float* part = S > 1 ? palloc(e, (size_t)S * (L.K + 1) * L.N) : nullptr;
                 float* grad = e->grad;
@@ -280,11 +289,59 @@ int build_program(dqn_engine* e) {
         if (!final_segs.empty()) e->final_reduce_step = (long)e->prog.size();
     }
     emit_reduce(e, final_segs, "dw_reduce_all");
+    e->dp_gather = false;
+    DpSumArgs dsum; memset(&dsum, 0, sizeof dsum);
+    struct DpDw { LayerDev L; const float* X; unsigned long long x_off, d_off; };
+    std::vector<DpDw> dpdw;
+    if (n_dp > 0) {
+        // per-rank block: [X of each distinct producer: K x B][dpre of each flagged layer: N x B][every other gradient range]
+        DpPackArgs pk; memset(&pk, 0, sizeof pk); unsigned long long off = 0;
+        std::vector<std::pair<const float*, unsigned long long>> xs;
+        for (int l = 0; l < e->nl; l++) if (dp_layer[l]) {
+            const LayerDev& L = e->L[l]; const float* X = L.src < 0 ? e->x0 : e->act_on[L.src]; const int ldx = L.src < 0 ? ld0 : ncon;
+            unsigned long long xo = ~0ull; for (auto& q : xs) if (q.first == X) xo = q.second;
+            if (xo == ~0ull) { xo = off; xs.push_back({X, xo}); DpRegion r; r.src = X; r.dst = off; r.n = (unsigned long long)L.K * B; r.B = B; r.ld = ldx; pk.r[pk.n++] = r; off += r.n; }
+            DpRegion d; d.src = e->dact[l]; d.dst = off; d.n = (unsigned long long)L.N * B; d.B = 1; d.ld = 1; pk.r[pk.n++] = d;
+            dpdw.push_back({L, X, xo, off}); off += d.n;
+        }
+        // the complement of the flagged layers' (K+1) x N blocks inside the internal gradient vector
+        std::vector<std::pair<unsigned long long, unsigned long long>> holes;
+        for (int l = 0; l < e->nl; l++) if (dp_layer[l]) holes.push_back({e->L[l].w_off, e->L[l].w_off + (unsigned long long)(e->L[l].K + 1) * e->L[l].N});
+        std::sort(holes.begin(), holes.end());
+        unsigned long long cur = 0;
+        auto small = [&](unsigned long long a, unsigned long long b) {
+            if (b <= a) return;
+            DpRegion r; r.src = e->grad + a; r.dst = off; r.n = b - a; r.B = 1; r.ld = 1; pk.r[pk.n++] = r;
+            DpRange q; q.src = off; q.dst = a; q.n = b - a; dsum.r[dsum.n++] = q; off += b - a;
+        };
+        for (auto& h : holes) { small(cur, h.first); cur = h.second; }
+        small(cur, e->Pint);
+        off = (off + 3) / 4 * 4;
+        if (e->dp_count != off) { hipFree(e->dp_send); hipFree(e->dp_recv); e->dp_send = e->dp_recv = nullptr; HIPCHK(hipMalloc((void**)&e->dp_send, off * 4)); HIPCHK(hipMalloc((void**)&e->dp_recv, off * 4 * W)); e->dp_count = off; }
+        pk.send = e->dp_send; dsum.recv = e->dp_recv; dsum.stride = off; dsum.world = W; dsum.grad = e->grad;
+        e->prog.push_back({"dp_pack", [=](dqn_engine* en) { launch_dp_pack(en->stream, pk); }});
+        e->dp_gather = true;
+    }
     e->prog_post_begin = e->prog.size();
+    if (e->dp_gather) {
+        // big dense dW over the W*B gathered samples (rank-major = the concatenated batch); siblings with the same X and geometry share a launch
+        const float* recv = e->dp_recv; const int cnt = (int)e->dp_count; float* grad = e->grad;
+        std::vector<bool> used(dpdw.size(), false);
+        for (size_t i = 0; i < dpdw.size(); i++) {
+            if (used[i]) continue; used[i] = true;
+            size_t j = i + 1; for (; j < dpdw.size(); j++) if (!used[j] && dpdw[j].x_off == dpdw[i].x_off && same_geo(dpdw[i].L, dpdw[j].L)) break;
+            const bool pair = j < dpdw.size(); if (pair) used[j] = true;
+            const DpDw a = dpdw[i], b = pair ? dpdw[j] : dpdw[i]; const int np = pair ? 2 : 1;
+            e->prog.push_back({pname(e, "dp_dw", a.L.kind, (int)i), [=](dqn_engine* en) {
+                const float* X[2] = {recv + a.x_off, recv + b.x_off}; const float* d[2] = {recv + a.d_off, recv + b.d_off}; float* o[2] = {grad + a.L.w_off, grad + b.L.w_off};
+                launch_gemm_dw(en->stream, a.L, np, X, B, d, W * B, o, /*ldd*/ B, /*tiles per rank*/ B / 32, /*rank stride*/ cnt); }});
+        }
+        e->prog.push_back({"dp_sum_ranks", [=](dqn_engine* en) { launch_dp_unpack_sum(en->stream, dsum); }});
+    }
     e->prog.push_back({"adam", [](dqn_engine* en) {
         PrioArgs pa; pa.n = (en->hp.prioritized_replay && !en->hp.recurrence) ? en->B : 0; pa.cap2 = en->cap2; pa.idx = en->idx; pa.td = en->td; pa.eps = en->hp.prio_eps; pa.alpha = en->hp.prio_alpha; pa.tree = en->tree;
         AdamSegs none; memset(&none, 0, sizeof none);
-        const bool fold = en->adam_segs.n > 0 && !en->comm;     // with a communicator the gradient must be materialised before the all-reduce
+        const bool fold = en->adam_segs.n > 0 && !en->comm && !en->sim_world;     // with a communicator the gradient must be materialised before the all-reduce
         launch_adam(en->stream, en->Pint, en->p_on, en->m, en->v, en->grad, en->state, en->gmax_part, en->hp.adam_f64_scalars, en->hp.learning_rate,
                     en->hp.adam_beta1, en->hp.adam_beta2, en->hp.adam_eps, en->world > 1 ? 1.0f / (float)en->world : 1.0f, pa, fold ? en->adam_segs : none, en->grad); }});
     e->prog_built = true;

@@ -234,10 +234,13 @@ void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* 
 // =====================================================================================================================
 struct GDwProb { const float* X; const float* dpre; float* out; };   // out: G + w_off (S == 1) or the partial slab base
 struct GDwProbs { GDwProb p[2]; };
+// operand layout: ldd = row stride of dpre ([n][pos][b]: npos*B).  The sample axis of a position is either one plain run (tpr = 0) or the
+// concatenation of gathered per-rank blocks (dp.hip): tpr 32-sample tiles per rank, consecutive ranks rstride floats apart (X and dpre alike)
+struct DwStride { int ldd, tpr, rstride; };
 constexpr int W_ST = 36;     // LDS row stride (32 samples + 4 pad): 16-B aligned rows, fragment reads at most 2-way conflicted
 
 template <int NT>
-__device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& pr, int nprob, int ldx, int B, int S, int kc, int bid, int nblocks) {
+__device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& pr, int nprob, int ldx, int B, int S, int kc, int bid, int nblocks, DwStride ds) {
     constexpr int NW = 16 * NT;
     constexpr int BQ = (NW * 8 + 255) / 256;          // float4 per thread for the B tile (1 or 2)
     extern __shared__ float lds[];
@@ -268,20 +271,22 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
     const float* Xa = p.X + 4 * f4;
     // ---- B tile slice: channel rows q>>3 (clamped), float4 (q & 7)
     const int bq0 = tid < NW * 8 ? tid : NW * 8 - 1, bq1 = tid + 256 < NW * 8 ? tid + 256 : NW * 8 - 1;
-    const float* Db0 = p.dpre + (size_t)(n0 + (bq0 >> 3)) * L.npos * B + 4 * (bq0 & 7);
-    const float* Db1 = p.dpre + (size_t)(n0 + (bq1 >> 3)) * L.npos * B + 4 * (bq1 & 7);
+    const float* Db0 = p.dpre + (size_t)(n0 + (bq0 >> 3)) * ds.ldd + 4 * (bq0 & 7);
+    const float* Db1 = p.dpre + (size_t)(n0 + (bq1 >> 3)) * ds.ldd + 4 * (bq1 & 7);
     constexpr int LPS = 2 + BQ;
     struct Stage { f32x4 a0, a1, b0, b1; };
     auto gld = [](const float* ptr) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory"); return v; };
     auto gload = [&](int kt, Stage& r) {
         kt = min(kt, nkt - 1);
-        const int pos = pos0 + kt / nsub, bo = (kt % nsub) * 32;
+        const int pos = pos0 + kt / nsub, sub = kt % nsub;          // 32-sample block `sub` of position `pos`
+        const unsigned so = ds.tpr > 0 ? (unsigned)(sub / ds.tpr) * (unsigned)ds.rstride + (unsigned)(sub % ds.tpr) * 32u : (unsigned)sub * 32u;
+        const unsigned ao = so, bo = (unsigned)pos * (unsigned)B + so;
         int xb = 0;
         if (conv) { const int oy = pos / L.ow, ox = pos % L.ow; xb = oy * L.sh * L.iw + ox * L.sw; }
-        r.a0 = gld(Xa + (unsigned)(xb + koff0) * (unsigned)ldx + bo);
-        r.a1 = gld(Xa + (unsigned)(xb + koff1) * (unsigned)ldx + bo);
-        r.b0 = gld(Db0 + (unsigned)pos * (unsigned)B + bo);
-        if (BQ > 1) r.b1 = gld(Db1 + (unsigned)pos * (unsigned)B + bo);
+        r.a0 = gld(Xa + (unsigned)(xb + koff0) * (unsigned)ldx + ao);
+        r.a1 = gld(Xa + (unsigned)(xb + koff1) * (unsigned)ldx + ao);
+        r.b0 = gld(Db0 + bo);
+        if (BQ > 1) r.b1 = gld(Db1 + bo);
     };
     auto lstore = [&](int buf, const Stage& r) {
         *reinterpret_cast<f32x4*>(As + (buf * 64 + (tid >> 3)) * W_ST + 4 * f4) = r.a0;
@@ -347,24 +352,25 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
     if (do_bias) out[(size_t)L.K * L.N + n0 + tid] = dbacc;
 }
 template <int NT>
-__global__ __launch_bounds__(256) void k_dw_lds(LayerDev L, GDwProbs pr, int nprob, int ldx, int B, int S, int kc) {
-    dw_lds_body<NT>(L, pr, nprob, ldx, B, S, kc, blockIdx.x, gridDim.x);
+__global__ __launch_bounds__(256) void k_dw_lds(LayerDev L, GDwProbs pr, int nprob, int ldx, int B, int S, int kc, DwStride ds) {
+    dw_lds_body<NT>(L, pr, nprob, ldx, B, S, kc, blockIdx.x, gridDim.x, ds);
 }
 bool gemm_dw_eligible(const LayerDev& L, int B, int ldx) {
     const int KK = L.npos * B, S = dqn_nchunks(KK, L.dw_kc), kc = dqn_chunk_len(KK, L.dw_kc);
     return !(L.N % 16 || B % 32 || ldx % 4 || L.K < 16 || (S > 1 && kc % B));
 }
 // nprob (<= 2) sibling layers of identical geometry in one launch; out[i] = gradient base (S == 1) or partial slab base
-void launch_gemm_dw(hipStream_t st, const LayerDev& L, int nprob, const float* const* X, int ldx, const float* const* dpre, int B, float* const* out) {
+void launch_gemm_dw(hipStream_t st, const LayerDev& L, int nprob, const float* const* X, int ldx, const float* const* dpre, int B, float* const* out, int ldd, int tpr, int rstride) {
     const int KK = L.npos * B, S = dqn_nchunks(KK, L.dw_kc), kc = dqn_chunk_len(KK, L.dw_kc);
+    const DwStride ds = {ldd > 0 ? ldd : L.npos * B, tpr, rstride};
     GDwProbs pr;
     for (int i = 0; i < 2; i++) { const int j = i < nprob ? i : 0; pr.p[i].X = X[j]; pr.p[i].dpre = dpre[j]; pr.p[i].out = out[j]; }
     const int NT = L.N % 64 == 0 ? 4 : (L.N % 32 == 0 ? 2 : 1);
     const int grid = ((L.K + 63) / 64) * (L.N / (16 * NT)) * S * nprob;
     const size_t lds = (size_t)(2 * 64 * W_ST + 2 * 16 * NT * W_ST) * 4;
-    if (NT == 4) hipLaunchKernelGGL((k_dw_lds<4>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc);
-    else if (NT == 2) hipLaunchKernelGGL((k_dw_lds<2>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc);
-    else hipLaunchKernelGGL((k_dw_lds<1>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc);
+    if (NT == 4) hipLaunchKernelGGL((k_dw_lds<4>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds);
+    else if (NT == 2) hipLaunchKernelGGL((k_dw_lds<2>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds);
+    else hipLaunchKernelGGL((k_dw_lds<1>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds);
 }
 
 // =====================================================================================================================
@@ -506,7 +512,7 @@ __global__ __launch_bounds__(256) void k_dwdx_lds(LayerDev Lw, GDwProbs pr, int 
     // workgroups fill the remaining CUs (dispatch order is blockIdx order)
     const int dx_blocks = (int)gridDim.x - dw_blocks;
     if ((int)blockIdx.x < dx_blocks) dx_lds_body(Lx, A, B, Sx, kcx, blockIdx.x % dx_gx, dx_gx, blockIdx.x / dx_gx);
-    else dw_lds_body<NT>(Lw, pr, nprob, ldx, B, Sw, kcw, blockIdx.x - dx_blocks, dw_blocks);
+    else dw_lds_body<NT>(Lw, pr, nprob, ldx, B, Sw, kcw, blockIdx.x - dx_blocks, dw_blocks, DwStride{Lw.npos * B, 0, 0});
 }
 bool gemm_dx_eligible(const LayerDev& L, int B, int ldy) {
     const bool dense = L.kind == DQN_LAYER_DENSE;

@@ -1,0 +1,90 @@
+"""GPU (-m gpu): the data-parallel exchange of DESIGN.md section 8 -- ONE all-gather of the wide dense layers' operands (X, dpre) and of the
+small gradients instead of an all-reduce of the whole gradient -- checked on one GPU:
+  * DQN_SIM_WORLD=k: one process plays k identical ranks (the collective is k local copies); the step must equal the CPU twin's single-device
+    step on the CONCATENATED batch of k*B samples (SURVEY.md 8e's definition of multi-GPU parity) -- bit for bit on the wide dense layers
+    (rank-major contraction order == the concatenated batch's column order), to round-off on the layers summed over ranks;
+  * the real RCCL ncclAllGather (dlopen'ed communicator on the engine stream between the two step graphs) forced on at world_size 1 must
+    reproduce the plain single-GPU path exactly."""
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+import dqn_oracle as O
+import ref
+
+pytestmark = pytest.mark.gpu
+R, I = O.ACT_RELU, O.ACT_IDENTITY
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = ge.load_package()
+    p.lib()
+    return p
+
+
+def wide_dense_dueling():
+    """conv trunk + Dense(192, 512) dueling streams: (K+1)*N = 98 816 floats of gradient per stream against 4*(K+N)*B = 90 112 of operands."""
+    b, v, a = O.create_dueling_network([O.Conv(4, 3, 8, R, 2), O.Conv(3, 8, 16, R, 1), O.Dense(16 * 3 * 4, 512, R), O.Dense(512, 5, I)])
+    return O.Network((3, 12, 14), b, v, a)
+
+
+def setup(pkg, net, B, Bt, cap=256, n_fill=200, seed=0):
+    layers = ref.layers_from_network(net)
+    hp_g = ref.hparams_for(net, batch_size=B, buffer_size=cap, learning_rate=1e-3, gamma=0.99)
+    hp_t = ref.hparams_for(net, batch_size=Bt, buffer_size=cap, learning_rate=1e-3, gamma=0.99)
+    g = pkg.Engine(layers, hp_g, plan=pkg.default_plan(layers, hp_g))
+    t = ref.Twin(layers, hp_t, plan=pkg.default_plan(layers, hp_t), threads=8)
+    rng = np.random.default_rng(seed)
+    s = rng.random((n_fill,) + net.obs_shape, dtype=np.float32); sp = rng.random((n_fill,) + net.obs_shape, dtype=np.float32)
+    a = rng.integers(0, net.n_actions, n_fill).astype(np.int32); r = (rng.standard_normal(n_fill) * 2).astype(np.float32); d = (rng.random(n_fill) < 0.2).astype(np.uint8)
+    p = O.Network.flatten(O.init_params(net, seed=5))
+    p = (p + 0.01 * rng.standard_normal(p.shape)).astype(np.float32)
+    for h in (g, t):
+        h.replay_add(s, a, r, sp, d); h.set_params(p, 0); h.set_params(p, 1)
+    return g, t, rng
+
+
+def wide_blocks(net, flat):
+    blocks = [w for w in net.unflatten(flat) if w.ndim == 2 and 512 in w.shape and 192 in w.shape]      # the two Dense(192, 512) weight matrices
+    assert len(blocks) == 2
+    return blocks
+
+
+@pytest.mark.parametrize("k", [2, 4, 8])
+def test_simulated_ranks_equal_concatenated_batch(pkg, monkeypatch, k):
+    net = wide_dense_dueling()
+    monkeypatch.setenv("DQN_SIM_WORLD", str(k))
+    g, t, rng = setup(pkg, net, 32, 32 * k)
+    monkeypatch.delenv("DQN_SIM_WORLD")
+    for step in range(3):
+        idx = rng.choice(200, 32, replace=False).astype(np.int64)
+        lg, gg, tdg = g.train_step(idx)
+        lt, gt, tdt = t.train_step(np.tile(idx, k))
+        np.testing.assert_array_equal(tdg, tdt[:32])                       # same per-sample TD errors
+        np.testing.assert_allclose(lg, lt, rtol=1e-6)                      # mean over 32 vs over k copies of them
+        Gg, Gt = g.get_grads() / np.float32(k), t.get_grads()              # sum over ranks, scaled by 1/world (exact power of two)
+        for x, y in zip(wide_blocks(net, Gg), wide_blocks(net, Gt)):
+            np.testing.assert_array_equal(x, y)                             # gathered contraction == the concatenated batch's, bit for bit
+        np.testing.assert_allclose(Gg, Gt, rtol=1e-4, atol=1e-7)            # conv / head gradients: summed over ranks vs one long chain
+        assert abs(gg - gt) <= 1e-6 * max(1.0, abs(gt))
+        Pg, Pt = g.get_params(0), t.get_params(0)
+        assert np.abs(Pg - Pt).max() <= 2.1e-3                              # Adam at |g| ~ eps moves up to lr
+        assert (np.abs(Pg - Pt) > 2e-6).mean() < 1e-3
+        np.testing.assert_array_equal(g.replay_priorities(), t.replay_priorities())
+        t.set_params(Pg, 0)                                                 # keep the two trajectories on the same parameters
+
+
+def test_rccl_allgather_world1_matches_plain(pkg, monkeypatch):
+    net = wide_dense_dueling()
+    a, cpu, rng = setup(pkg, net, 32, 32, seed=1)
+    b, _, _ = setup(pkg, net, 32, 32, seed=1)
+    monkeypatch.setenv("DQN_FORCE_ALLREDUCE", "1")                         # run the communicator path although world_size == 1
+    a.comm_init(pkg.comm_unique_id(), 0, 1)
+    for _ in range(4):
+        ra, rb, rc = a.train_step(), b.train_step(), cpu.train_step()
+        assert ra[0] == rb[0] == rc[0] and ra[1] == rb[1]
+        np.testing.assert_array_equal(ra[2], rb[2])
+    np.testing.assert_array_equal(a.get_params(0), b.get_params(0))
+    np.testing.assert_array_equal(a.get_params(0), cpu.get_params(0))
+    np.testing.assert_array_equal(a.get_grads(), b.get_grads())
