@@ -148,12 +148,13 @@ def main():
     pkg.envs = importlib.import_module(pkg.__name__ + ".envs")
     par = importlib.import_module(pkg.__name__ + ".parallel")
     # control plane (rendezvous, 128-byte id broadcast, barriers, max-over-ranks timer) over gloo on the loopback interface;
-    # the DATA path -- the per-step gradient all-reduce -- is RCCL over xGMI inside the engine (dqn_comm_init), on its stream.
+    # the DATA path -- the one collective of a step (all-gather of the wide dense layers' operands + small gradients) -- is RCCL
+    # over xGMI inside the engine (dqn_comm_init), on its stream.
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     group = par.Group(backend="gloo")
 
     eng, layers, hp, net, params, env = build_workload(pkg, args, rank, local_rank)
-    group.attach_engine(pkg, eng)          # RCCL communicator inside the engine (gradient all-reduce on its stream)
+    group.attach_engine(pkg, eng)          # RCCL communicator inside the engine (the step's collective runs on its stream)
 
     def barrier():
         group.barrier()
@@ -252,7 +253,7 @@ def main():
             "config": {"workload": "configs[1]: TestMDP((84,84),4,6) image MDP, Nature-DQN 3-conv+2-dense dueling, double-Q, prioritized replay",
                        "batch_per_rank": args.batch, "global_batch": args.batch * world, "replay_per_rank": args.replay,
                        "replay_dtype": "u8" if args.u8 else "f32", "envs_per_rank": args.envs_per_rank, "n_params": int(P),
-                       "parallelism": f"dp{world} (per-rank replay, RCCL grad all-reduce)" if world > 1 else "single GPU",
+                       "parallelism": f"dp{world} (per-rank envs + replay; one RCCL all-gather per step: wide-dense operands + small gradients)" if world > 1 else "single GPU",
                        "hip_graph": not args.no_graph, "mfma": not args.no_mfma, "last_loss": loss, "last_grad_norm": gnorm},
             "samples_per_s": value * args.batch,
             "roofline": roof, "cpu_baseline": cpu, "env_loop": env_loop,
