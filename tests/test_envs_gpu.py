@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import __graft_entry__ as ge
+import dqn_oracle as O
 import envs_common as EC
 import ref
 
@@ -120,3 +121,24 @@ def test_rollout_errors(pkg, envs):
     g.envs_create(envs.SimpleGridWorld(n=4))
     with pytest.raises(pkg.DQNError, match="t0"):
         g.rollout(1, t0=0)
+
+
+def test_odd_shapes_recreate_and_zero_steps(pkg, envs):
+    """Shapes off the vectorised paths (E = 25 and n = 3 are not multiples of 4 -> scalar observe kernel; u8 rows), re-creating the env set with
+    another size on the same engine, a zero-step rollout and single-copy evaluation -- all still identical to the twin."""
+    net = O.Network((1, 5, 5), [O.Dense(25, 16, O.ACT_RELU), O.Dense(16, 4, O.ACT_IDENTITY)])
+    for u8 in (0, 1):
+        g, t, hp = make_pair(pkg, net, B=4, cap=40, obs_dtype=u8, dueling=0)
+        EC.same_params([g, t], net)
+        for n in (3, 7):
+            spec = envs.TestMDP((5, 5), 1, 6, n=n, seed=4)
+            for h in (g, t):
+                h.envs_create(spec, max_episode_length=4, seed=11 + n)
+                assert h.rollout(0, t0=1)["train_steps"] == 0
+            compare_state(g, t)
+            sg = g.rollout(13, t0=1, train_freq=3, target_update_freq=6, eps=(0.9, 0.2, 10.0))
+            st = t.rollout(13, t0=1, train_freq=3, target_update_freq=6, eps=(0.9, 0.2, 10.0))
+            assert sg == st
+            compare_state(g, t)
+            np.testing.assert_array_equal(g.get_params(0), t.get_params(0))
+            assert g.evaluate(1, 3, seed=2) == t.evaluate(1, 3, seed=2)
