@@ -228,3 +228,20 @@ def test_tiger_pomdp_ddrqn_shape(mods):
     policy = S.solve(solver, env)
     assert policy.actionvalues(np.array([1.0], np.float32)).shape == (env.n_actions,)
     policy.engine.close()
+
+
+def test_headline_config_end_to_end_on_device(mods):
+    """BASELINE configs 2/3 end to end: TestMDP((84,84),4,6) (84x84x4 observations), Nature-DQN 3-conv + 2-dense dueling, double-Q, prioritized replay,
+    B = 32, 32 device-resident env copies, the dqn_train! loop on the device (dqn_rollout + dqn_evaluate).  Known answer of the MDP: optimal return 2.1
+    (test/test_env.jl:7-8); the reference's own threshold on its small-image variant is 1.5 (test/runtests.jl:110)."""
+    pkg, nn, envs, S = mods
+    env = envs.TestMDP((84, 84), 4, 6, n=32, seed=7)
+    steps = 3000
+    expl = S.EpsGreedyPolicy(env, S.LinearDecaySchedule(start=1.0, stop=0.01, steps=steps / 2))
+    solver = S.DeepQLearningSolver(qnetwork=nn.nature_dqn(n_actions=4, in_channels=4), max_steps=steps, learning_rate=1e-4, exploration_policy=expl,
+                                   train_freq=4, target_update_freq=500, eval_freq=1000, num_ep_eval=32, log_freq=1000, double_q=True, dueling=True,
+                                   prioritized_replay=True, buffer_size=20000, train_start=640, verbose=False, logdir=None, device_envs=True)
+    policy = S.solve(solver, env)
+    r, st = policy.engine.evaluate(64, 100, seed=99)
+    assert r >= 1.5 and st == 5.0, (r, st)
+    policy.engine.close()
