@@ -194,6 +194,16 @@ def main():
                              "loop_train_steps_per_s": st["train_steps"] / (tb - ta), "loop_ms_per_vector_step": (tb - ta) / args.env_steps * 1e3})
         group.barrier()
 
+    # per-launch durations (HIP events on the engine stream, eager launches).  A profiled step is a full train step -- with its collective when
+    # world > 1 -- so EVERY rank runs the same number of them; only rank 0 uses the numbers.
+    prof_acc = {}
+    for _ in range(args.profile_steps):
+        for name, ms in eng.profile_step():
+            a = prof_acc.setdefault(name, [0.0, 0])
+            a[0] += ms
+            a[1] += 1
+    group.barrier()
+
     out = None
     if rank == 0:
         B, ncon, E, P = args.batch, 2 * args.batch, 4 * 84 * 84, eng.P
@@ -218,13 +228,7 @@ def main():
                 S = -(-npos * B // dw_kc) if dw_kc and dw_kc < npos * B else 1
                 if S > 1:
                     ADAM_EXTRA_BYTES[0] += (S + 1) * (K + 1) * N * 4.0
-        acc = {}
-        for _ in range(args.profile_steps):
-            for name, ms in eng.profile_step():
-                a = acc.setdefault(name, [0.0, 0])
-                a[0] += ms
-                a[1] += 1
-        kern = {k: v[0] / v[1] for k, v in acc.items()}
+        kern = {k: v[0] / v[1] for k, v in prof_acc.items()}
         dom = max(kern, key=kern.get)
         fl, by = op_cost(dom, g2, B, ncon, E, P, 1 if args.u8 else 4)
         if fl > 0:

@@ -118,7 +118,7 @@ __device__ __forceinline__ void prio_update_block(int n, long long cap2, const l
 struct PrioArgs { int n; long long cap2; const long long* idx; const float* td; float eps, alpha; float* tree; };
 // deferred dW split-K slabs reduced INSIDE the Adam launch by dedicated blocks (single-GPU path): element ranges [beg, end) of the
 // gradient vector, each the ascending sum of S slabs
-struct AdamSegs { int n; unsigned long long beg[8], end[8]; const float* part[8]; int S[8]; unsigned blocks; };
+struct AdamSegs { int n; unsigned long long beg[8], end[8]; const float* part[8]; int S[8]; unsigned blocks; unsigned long long stride[8]; };   // stride 0: slabs `len` apart
 
 // ---- kernel launchers (defined in the .hip files; all enqueue on `st` and never synchronise)
 // a head tensor as seen by k_td: finished activation (S <= 1) or split-K partial slabs to be reduced on the fly
@@ -265,7 +265,7 @@ void launch_env_reset_pending(hipStream_t st, const EnvDev& V, const RolloutDev*
 
 // ---- data-parallel exchange (dp.hip)
 #define DP_MAX_REGIONS 48
-struct DpRegion { const float* src; unsigned long long dst, n; int B, ld; };
+struct DpRegion { const float* src; unsigned long long dst, n; int B, ld; int S; unsigned long long per_s; };   // S > 1: the value is the ascending sum of S split-K slabs
 struct DpPackArgs { int n; DpRegion r[DP_MAX_REGIONS]; float* send; };
 struct DpRange { unsigned long long src, dst, n; };
 struct DpSumArgs { int n; DpRange r[DP_MAX_REGIONS]; const float* recv; unsigned long long stride; int world; float* grad; };

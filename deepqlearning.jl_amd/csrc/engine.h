@@ -48,7 +48,7 @@ struct dqn_engine {
     void* comm = nullptr; int rank = 0, world = 1; bool force_comm = false;
     // exchange mode of the replicas: gather = all-gather of the wide dense layers' operands + small gradients (dp.hip); else all-reduce of the gradient.
     // sim_world = k (env DQN_SIM_WORLD, tests): one process plays k identical ranks, the collective is k local copies.
-    bool dp_gather = false; int sim_world = 0; float *dp_send = nullptr, *dp_recv = nullptr; size_t dp_count = 0;   // force_comm: run the all-reduce path even at world == 1 (tests)
+    bool dp_gather = false, dp_pack_folds = false, dp_adam_folds = false; AdamSegs dp_adam_segs; int sim_world = 0; float *dp_send = nullptr, *dp_recv = nullptr; size_t dp_count = 0;   // force_comm: run the all-reduce path even at world == 1 (tests)
     // DRQN (recurrence = true): column count per sequence set Bc = T*B (B otherwise); EpisodeReplayBuffer storage; LSTM workspaces
     int Bc = 0, T = 1; long long ep_cap = 0, ep_size = 0, ep_widx = 0, ep_cur_len = 0; std::vector<int> ep_len_host; std::vector<int64_t> ep_perm;
     float *ep_s = nullptr, *ep_sp = nullptr, *ep_r = nullptr; int* ep_a = nullptr; unsigned char* ep_done = nullptr; int* ep_len = nullptr;

@@ -404,7 +404,7 @@ void enqueue_step(dqn_engine* e, bool sample, int phase) {
                                                                         fused ? 1 : 0, e->cap2, e->tree, e->hp.seed, e->state));
         }
         for (size_t i = 0; i < e->prog_post_begin; i++) {
-            if ((long)i == e->final_reduce_step && e->adam_segs.n > 0 && !e->comm && !e->sim_world) continue;   // folded into k_adam
+            if ((long)i == e->final_reduce_step && ((e->adam_segs.n > 0 && !e->comm && !e->sim_world) || (e->dp_gather && e->dp_pack_folds))) continue;   // folded into k_adam / k_dp_pack   // folded into k_adam
             RUN(e, e->prog[i].name, e->prog[i].fn(e));
         }
     }
@@ -576,7 +576,7 @@ extern "C" int dqn_comm_init(dqn_engine_t* e, const void* id128, int rank, int w
     drop_graphs(e); HIPCHK(hipStreamSynchronize(e->stream));
     for (void* p : e->prog_allocs) hipFree(p);
     e->prog_allocs.clear(); e->prog.clear(); e->prog_built = false; e->prog_post_begin = 0; e->final_reduce_step = -1; memset(&e->adam_segs, 0, sizeof e->adam_segs);
-    hipFree(e->dp_send); hipFree(e->dp_recv); e->dp_send = e->dp_recv = nullptr; e->dp_gather = false; e->dp_count = 0;
+    hipFree(e->dp_send); hipFree(e->dp_recv); e->dp_send = e->dp_recv = nullptr; e->dp_gather = e->dp_pack_folds = e->dp_adam_folds = false; e->dp_count = 0;
     return 0;
 }
 

@@ -288,6 +288,7 @@ int build_program(dqn_engine* e) {
         }
         if (!final_segs.empty()) e->final_reduce_step = (long)e->prog.size();
     }
+    const std::vector<RSeg> slab_segs(final_segs);      // emit_reduce consumes the list
     emit_reduce(e, final_segs, "dw_reduce_all");
     e->dp_gather = false;
     DpSumArgs dsum; memset(&dsum, 0, sizeof dsum);
@@ -300,8 +301,8 @@ int build_program(dqn_engine* e) {
         for (int l = 0; l < e->nl; l++) if (dp_layer[l]) {
             const LayerDev& L = e->L[l]; const float* X = L.src < 0 ? e->x0 : e->act_on[L.src]; const int ldx = L.src < 0 ? ld0 : ncon;
             unsigned long long xo = ~0ull; for (auto& q : xs) if (q.first == X) xo = q.second;
-            if (xo == ~0ull) { xo = off; xs.push_back({X, xo}); DpRegion r; r.src = X; r.dst = off; r.n = (unsigned long long)L.K * B; r.B = B; r.ld = ldx; pk.r[pk.n++] = r; off += r.n; }
-            DpRegion d; d.src = e->dact[l]; d.dst = off; d.n = (unsigned long long)L.N * B; d.B = 1; d.ld = 1; pk.r[pk.n++] = d;
+            if (xo == ~0ull) { xo = off; xs.push_back({X, xo}); DpRegion r; memset(&r, 0, sizeof r); r.S = 1; r.src = X; r.dst = off; r.n = (unsigned long long)L.K * B; r.B = B; r.ld = ldx; pk.r[pk.n++] = r; off += r.n; }
+            DpRegion d; memset(&d, 0, sizeof d); d.S = 1; d.src = e->dact[l]; d.dst = off; d.n = (unsigned long long)L.N * B; d.B = 1; d.ld = 1; pk.r[pk.n++] = d;
             dpdw.push_back({L, X, xo, off}); off += d.n;
         }
         // the complement of the flagged layers' (K+1) x N blocks inside the internal gradient vector
@@ -309,10 +310,24 @@ int build_program(dqn_engine* e) {
         for (int l = 0; l < e->nl; l++) if (dp_layer[l]) holes.push_back({e->L[l].w_off, e->L[l].w_off + (unsigned long long)(e->L[l].K + 1) * e->L[l].N});
         std::sort(holes.begin(), holes.end());
         unsigned long long cur = 0;
+        // sub-ranges whose gradient still sits in split-K slabs (conv dW) are reduced by the pack kernel itself
+        std::vector<RSeg> slabs(slab_segs); std::sort(slabs.begin(), slabs.end(), [](const RSeg& x, const RSeg& y) { return x.out < y.out; });
+        bool pack_folds = !slabs.empty();
+        for (auto& r : slabs) pack_folds = pack_folds && r.S2 == 0 && r.mode == 2;
         auto small = [&](unsigned long long a, unsigned long long b) {
             if (b <= a) return;
-            DpRegion r; r.src = e->grad + a; r.dst = off; r.n = b - a; r.B = 1; r.ld = 1; pk.r[pk.n++] = r;
-            DpRange q; q.src = off; q.dst = a; q.n = b - a; dsum.r[dsum.n++] = q; off += b - a;
+            DpRange q; q.src = off; q.dst = a; q.n = b - a; dsum.r[dsum.n++] = q;
+            unsigned long long cur2 = a;
+            auto plain = [&](unsigned long long x, unsigned long long y) { if (y <= x) return; DpRegion r; memset(&r, 0, sizeof r); r.src = e->grad + x; r.dst = off + (x - a); r.n = y - x; r.B = 1; r.ld = 1; r.S = 1; pk.r[pk.n++] = r; };
+            if (pack_folds) for (auto& sg : slabs) {
+                const unsigned long long sb = (unsigned long long)(sg.out - e->grad), se = sb + sg.elems;
+                if (sb < a || se > b) continue;
+                plain(cur2, sb);
+                DpRegion r; memset(&r, 0, sizeof r); r.src = sg.part; r.dst = off + (sb - a); r.n = sg.elems; r.B = 1; r.ld = 1; r.S = sg.S; r.per_s = sg.elems; pk.r[pk.n++] = r;
+                cur2 = se;
+            }
+            plain(cur2, b);
+            off += b - a;
         };
         for (auto& h : holes) { small(cur, h.first); cur = h.second; }
         small(cur, e->Pint);
@@ -320,7 +335,14 @@ int build_program(dqn_engine* e) {
         if (e->dp_count != off) { hipFree(e->dp_send); hipFree(e->dp_recv); e->dp_send = e->dp_recv = nullptr; HIPCHK(hipMalloc((void**)&e->dp_send, off * 4)); HIPCHK(hipMalloc((void**)&e->dp_recv, off * 4 * W)); e->dp_count = off; }
         pk.send = e->dp_send; dsum.recv = e->dp_recv; dsum.stride = off; dsum.world = W; dsum.grad = e->grad;
         e->prog.push_back({"dp_pack", [=](dqn_engine* en) { launch_dp_pack(en->stream, pk); }});
-        e->dp_gather = true;
+        e->dp_gather = true; e->dp_pack_folds = pack_folds;
+        // the ascending sum over ranks of the small gradient ranges rides inside k_adam (its slab-reduce blocks) when the ranges allow it
+        memset(&e->dp_adam_segs, 0, sizeof e->dp_adam_segs);
+        bool af = dsum.n > 0 && dsum.n <= 8; unsigned long long tot = 0;
+        for (int i = 0; i < dsum.n; i++) af = af && dsum.r[i].dst % 4 == 0 && dsum.r[i].n % 4 == 0;
+        if (af) for (int i = 0; i < dsum.n; i++) { AdamSegs& A = e->dp_adam_segs; const int q = A.n++; A.beg[q] = dsum.r[i].dst; A.end[q] = dsum.r[i].dst + dsum.r[i].n; A.part[q] = e->dp_recv + dsum.r[i].src; A.S[q] = W; A.stride[q] = off; tot += dsum.r[i].n; }
+        e->dp_adam_segs.blocks = (unsigned)((tot + 255) / 256);
+        e->dp_adam_folds = af;
     }
     e->prog_post_begin = e->prog.size();
     if (e->dp_gather) {
@@ -336,14 +358,14 @@ int build_program(dqn_engine* e) {
                 const float* X[2] = {recv + a.x_off, recv + b.x_off}; const float* d[2] = {recv + a.d_off, recv + b.d_off}; float* o[2] = {grad + a.L.w_off, grad + b.L.w_off};
                 launch_gemm_dw(en->stream, a.L, np, X, B, d, W * B, o, /*ldd*/ B, /*tiles per rank*/ B / 32, /*rank stride*/ cnt); }});
         }
-        e->prog.push_back({"dp_sum_ranks", [=](dqn_engine* en) { launch_dp_unpack_sum(en->stream, dsum); }});
+        if (!e->dp_adam_folds) e->prog.push_back({"dp_sum_ranks", [=](dqn_engine* en) { launch_dp_unpack_sum(en->stream, dsum); }});
     }
     e->prog.push_back({"adam", [](dqn_engine* en) {
         PrioArgs pa; pa.n = (en->hp.prioritized_replay && !en->hp.recurrence) ? en->B : 0; pa.cap2 = en->cap2; pa.idx = en->idx; pa.td = en->td; pa.eps = en->hp.prio_eps; pa.alpha = en->hp.prio_alpha; pa.tree = en->tree;
         AdamSegs none; memset(&none, 0, sizeof none);
         const bool fold = en->adam_segs.n > 0 && !en->comm && !en->sim_world;     // with a communicator the gradient must be materialised before the all-reduce
         launch_adam(en->stream, en->Pint, en->p_on, en->m, en->v, en->grad, en->state, en->gmax_part, en->hp.adam_f64_scalars, en->hp.learning_rate,
-                    en->hp.adam_beta1, en->hp.adam_beta2, en->hp.adam_eps, en->world > 1 ? 1.0f / (float)en->world : 1.0f, pa, fold ? en->adam_segs : none, en->grad); }});
+                    en->hp.adam_beta1, en->hp.adam_beta2, en->hp.adam_eps, en->world > 1 ? 1.0f / (float)en->world : 1.0f, pa, (en->dp_gather && en->dp_adam_folds) ? en->dp_adam_segs : (fold ? en->adam_segs : none), en->grad); }});
     e->prog_built = true;
     return 0;
 }

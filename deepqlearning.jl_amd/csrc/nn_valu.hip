@@ -419,15 +419,15 @@ __global__ __launch_bounds__(256) void k_adam(size_t P, float* __restrict__ p, f
         for (int q = 0; q < segs.n; q++) {
             const size_t len = segs.end[q] - segs.beg[q];
             if (e < len) {
-                const float* pp = segs.part[q] + e; float tot = pp[0]; int sI = 1;
+                const float* pp = segs.part[q] + e; float tot = pp[0]; int sI = 1; const size_t sst = segs.stride[q] ? (size_t)segs.stride[q] : len;
                 for (; sI + 8 <= segs.S[q]; sI += 8) {
                     float vv[8];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) vv[u] = pp[(size_t)(sI + u) * len];
+                    for (int u = 0; u < 8; u++) vv[u] = pp[(size_t)(sI + u) * sst];
 #pragma unroll
                     for (int u = 0; u < 8; u++) tot = tot + vv[u];
                 }
-                for (; sI < segs.S[q]; sI++) tot = tot + pp[(size_t)sI * len];
+                for (; sI < segs.S[q]; sI++) tot = tot + pp[(size_t)sI * sst];
                 const size_t i = segs.beg[q] + e;
                 g_out[i] = tot;                                       // the materialised gradient (dqn_get_grads, parity tests)
                 upd(tot, m[i], v[i], p[i]);

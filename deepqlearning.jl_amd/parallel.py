@@ -1,10 +1,11 @@
 """
 Data-parallel replicas (BASELINE config 3): one process per GPU, per-rank vectorised envs + per-rank replay and
-sum-tree (no cross-rank sampling), identical parameter replicas, ONE exchange per train step: the flat gradient is
-all-reduced (SUM) over RCCL inside the engine (dqn_comm_init / ncclAllReduce on the engine's stream) and scaled by
-1/world in the Adam kernel, so every rank applies the same update and replicas stay bit-identical.  Equivalent to a
-single-GPU step on the concatenated batch of B*world with the loss averaged (tests/test_parallel_cpu.py checks that
-equivalence with the CPU twin over gloo).  The reference has no distributed code at all.
+sum-tree (no cross-rank sampling), identical parameter replicas, ONE exchange per train step over RCCL inside the engine
+(dqn_comm_init; on the engine's stream): an all-gather of the wide dense layers' operands and of the small gradients
+(csrc/dp.hip), or an all-reduce of the flat gradient as the fallback; Adam scales by 1/world, so every
+rank applies the same update and replicas stay bit-identical.  Equivalent to a single-GPU step on the concatenated batch of
+B*world with the loss averaged (tests/test_dp_gpu.py: simulated ranks against the CPU twin; tests/test_parallel_cpu.py: the
+same equivalence and this module's plumbing over gloo).  The reference has no distributed code at all.
 
 This module is the host-side plumbing only (torch.distributed -- gloo by default, so that the engine's communicator is
 the only RCCL instance in the process -- is used for rendezvous, the 128-byte RCCL id broadcast, barriers and the
