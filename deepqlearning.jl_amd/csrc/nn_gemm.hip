@@ -500,18 +500,101 @@ __device__ __forceinline__ void dx_lds_body(const LayerDev& L, const GDxArgs& A,
     }
     *reinterpret_cast<f32x4*>(A.out + (size_t)s * per_s + feat * B + bcol) = v;
 }
-__global__ __launch_bounds__(256) void k_dx_lds(LayerDev L, GDxArgs A, int B, int S, int kc) {
-    dx_lds_body(L, A, B, S, kc, blockIdx.x, gridDim.x, blockIdx.y);
+// Dense dueling join with the two sources advancing CONCURRENTLY: waves 0-1 contract source 0 (val), waves 2-3 source 1 (adv), each
+// wave owning one 16-feature tile and both 16-sample tiles, so the serial chain of a workgroup is N/32 K tiles instead of 2*N/32;
+// the accumulators meet through LDS at the end as (val + adv) -- the same per-source chains and the same final addition as the
+// sequential body above, hence identical bits.  (FC-pair backward of config 2: 32 -> 16 K tiles on the critical path.)
+__device__ __forceinline__ void dx_lds_body_pj(const LayerDev& L, const GDxArgs& A, int B, int bid, int nblocks, int by) {
+    extern __shared__ float lds[];
+    float* As = lds;                                  // [2 buf][2 src][32][X_SA]
+    float* Bs = lds + 2 * 2 * 32 * X_SA;              // [2 buf][2 src][32][X_SB]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int ft = wave & 1, src = wave >> 1;
+    const int b0 = by * 32;
+    const int w = xcd_remap(bid, nblocks);
+    const int ftiles = (L.K + 31) / 32, f0 = (w % ftiles) * 32, nfeat = L.K;
+    const int nkt = L.N / 32;
+    const int row = tid >> 3, f4 = tid & 7;
+    const int frow = min(f0 + row, nfeat - 1);
+    struct Stage { f32x4 a0, b0, a1, b1; };
+    auto gld = [](const float* ptr) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory"); return v; };
+    auto gload = [&](int kt, Stage& r) {
+        kt = min(kt, nkt - 1);
+        const int nb = kt * 32;
+        r.a0 = gld(A.src[0].dpre + (size_t)(nb + row) * B + b0 + 4 * f4);
+        r.b0 = gld(A.src[0].W + (size_t)frow * L.N + nb + 4 * f4);
+        r.a1 = gld(A.src[1].dpre + (size_t)(nb + row) * B + b0 + 4 * f4);
+        r.b1 = gld(A.src[1].W + (size_t)frow * L.N + nb + 4 * f4);
+    };
+    auto lstore = [&](int buf, const Stage& r) {
+        *reinterpret_cast<f32x4*>(As + ((buf * 2 + 0) * 32 + row) * X_SA + 4 * f4) = r.a0;
+        *reinterpret_cast<f32x4*>(Bs + ((buf * 2 + 0) * 32 + row) * X_SB + 4 * f4) = r.b0;
+        *reinterpret_cast<f32x4*>(As + ((buf * 2 + 1) * 32 + row) * X_SA + 4 * f4) = r.a1;
+        *reinterpret_cast<f32x4*>(Bs + ((buf * 2 + 1) * 32 + row) * X_SB + 4 * f4) = r.b1;
+    };
+#define STAGE_WAIT4(N, r) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r.a0), "+v"(r.b0), "+v"(r.a1), "+v"(r.b1) : "n"(N) : "memory")
+    f32x4 accm0 = {0.f, 0.f, 0.f, 0.f}, accm1 = {0.f, 0.f, 0.f, 0.f};      // sample tiles 0 and 1 of this wave's (source, feature tile)
+    // epilogue operands of the source-0 waves, requested up front
+    const int fl = f0 + 16 * ft + l15;
+    const size_t feat = (size_t)min(fl, nfeat - 1);
+    f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = {0.f, 0.f, 0.f, 0.f};
+    if (src == 0 && A.ysrc) { y0 = *reinterpret_cast<const f32x4*>(A.ysrc + feat * A.ldy + b0 + 4 * kq); y1 = *reinterpret_cast<const f32x4*>(A.ysrc + feat * A.ldy + b0 + 16 + 4 * kq); }
+    auto compute = [&](int buf) {
+        const float* Ab = As + (buf * 2 + src) * 32 * X_SA + l15;
+        const float* Bb = Bs + ((buf * 2 + src) * 32 + 16 * ft + l15) * X_SB + kq;
+        float a0f[8], a1f[8], bf[8];
+#pragma unroll
+        for (int st = 0; st < 8; st++) { a0f[st] = Ab[(4 * st + kq) * X_SA]; a1f[st] = Ab[(4 * st + kq) * X_SA + 16]; bf[st] = Bb[4 * st]; }
+#pragma unroll
+        for (int st = 0; st < 8; st++) { accm0 = MFMA(a0f[st], bf[st], accm0); accm1 = MFMA(a1f[st], bf[st], accm1); }
+    };
+    Stage r0, r1;
+    gload(0, r0); STAGE_WAIT4(0, r0); lstore(0, r0); __syncthreads();
+    gload(1, r0);
+    for (int kt = 0; kt < nkt; kt += 2) {
+        gload(kt + 2, r1);
+        compute(0);
+        STAGE_WAIT4(4, r0); lstore(1, r0);
+        __syncthreads();
+        gload(kt + 3, r0);
+        if (kt + 1 < nkt) compute(1);
+        STAGE_WAIT4(4, r1); lstore(0, r1);
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef STAGE_WAIT4
+    // ---- join: the source-1 waves hand their accumulators over through LDS (the tiles are dead after the last barrier)
+    f32x4* xch = reinterpret_cast<f32x4*>(lds);       // [2 ft][2 mt][64 lanes]
+    if (src == 1) { xch[(ft * 2 + 0) * 64 + lane] = accm0; xch[(ft * 2 + 1) * 64 + lane] = accm1; }
+    __syncthreads();
+    if (src == 1 || fl >= nfeat) return;
+    const f32x4 o0 = xch[(ft * 2 + 0) * 64 + lane], o1 = xch[(ft * 2 + 1) * 64 + lane];
+    f32x4 v0 = accm0, v1 = accm1;
+    v0.x = v0.x + o0.x; v0.y = v0.y + o0.y; v0.z = v0.z + o0.z; v0.w = v0.w + o0.w;
+    v1.x = v1.x + o1.x; v1.y = v1.y + o1.y; v1.z = v1.z + o1.z; v1.w = v1.w + o1.w;
+    if (A.ysrc) {
+        v0.x = dact_f(v0.x, y0.x, A.act_src); v0.y = dact_f(v0.y, y0.y, A.act_src); v0.z = dact_f(v0.z, y0.z, A.act_src); v0.w = dact_f(v0.w, y0.w, A.act_src);
+        v1.x = dact_f(v1.x, y1.x, A.act_src); v1.y = dact_f(v1.y, y1.y, A.act_src); v1.z = dact_f(v1.z, y1.z, A.act_src); v1.w = dact_f(v1.w, y1.w, A.act_src);
+    }
+    *reinterpret_cast<f32x4*>(A.out + (size_t)fl * B + b0 + 4 * kq) = v0;
+    *reinterpret_cast<f32x4*>(A.out + (size_t)fl * B + b0 + 16 + 4 * kq) = v1;
+}
+static bool dx_parallel_join(const LayerDev& L, int nsrc, int S) { return nsrc == 2 && S == 1 && L.kind == DQN_LAYER_DENSE && (L.N / 32) % 2 == 0; }
+static size_t dx_lds_bytes(bool pj) { return pj ? (size_t)(2 * 2 * 32 * X_SA + 2 * 2 * 32 * X_SB) * 4 : (size_t)(2 * 32 * X_SA + 2 * 32 * X_SB) * 4 + 256 * 4; }
+
+__global__ __launch_bounds__(256) void k_dx_lds(LayerDev L, GDxArgs A, int B, int S, int kc, int pj) {
+    if (pj) dx_lds_body_pj(L, A, B, blockIdx.x, gridDim.x, blockIdx.y);
+    else dx_lds_body(L, A, B, S, kc, blockIdx.x, gridDim.x, blockIdx.y);
 }
 // dW and dX of one layer are independent given dpre: ONE launch runs both (blocks [0, dw_blocks) do dW, the rest dX), which
 // saves a dispatch and lets the latency-bound dX workgroups share the machine with the dW ones.
 template <int NT>
 __global__ __launch_bounds__(256) void k_dwdx_lds(LayerDev Lw, GDwProbs pr, int nprob, int ldx, int B, int Sw, int kcw, int dw_blocks,
-                                                  LayerDev Lx, GDxArgs A, int Sx, int kcx, int dx_gx) {
+                                                  LayerDev Lx, GDxArgs A, int Sx, int kcx, int dx_gx, int pj) {
     // the few, long-latency dX workgroups are dispatched FIRST so that they run for the whole kernel while the many short dW
     // workgroups fill the remaining CUs (dispatch order is blockIdx order)
     const int dx_blocks = (int)gridDim.x - dw_blocks;
-    if ((int)blockIdx.x < dx_blocks) dx_lds_body(Lx, A, B, Sx, kcx, blockIdx.x % dx_gx, dx_gx, blockIdx.x / dx_gx);
+    if ((int)blockIdx.x < dx_blocks) { if (pj) dx_lds_body_pj(Lx, A, B, blockIdx.x % dx_gx, dx_gx, blockIdx.x / dx_gx); else dx_lds_body(Lx, A, B, Sx, kcx, blockIdx.x % dx_gx, dx_gx, blockIdx.x / dx_gx); }
     else dw_lds_body<NT>(Lw, pr, nprob, ldx, B, Sw, kcw, blockIdx.x - dx_blocks, dw_blocks, DwStride{Lw.npos * B, 0, 0});
 }
 bool gemm_dx_eligible(const LayerDev& L, int B, int ldy) {
@@ -529,8 +612,8 @@ void launch_gemm_dx(hipStream_t st, const LayerDev& L, int nsrc, const float* co
     GDxArgs a; a.nsrc = nsrc; a.out = out; a.ysrc = ysrc; a.ldy = ldy; a.act_src = act_src;
     for (int i = 0; i < 2; i++) { const int j = i < nsrc ? i : 0; a.src[i].W = W[j]; a.src[i].dpre = dpre[j]; }
     const int gx = dense ? ((L.K + 31) / 32) * S : (L.cin / 32) * L.ih * L.iw;
-    const size_t lds = (size_t)(2 * 32 * X_SA + 2 * 32 * X_SB) * 4 + 256 * 4;
-    hipLaunchKernelGGL(k_dx_lds, dim3(gx, B / 32), dim3(256), lds, st, L, a, B, S, kc);
+    const bool pj = dx_parallel_join(L, nsrc, S);
+    hipLaunchKernelGGL(k_dx_lds, dim3(gx, B / 32), dim3(256), dx_lds_bytes(pj), st, L, a, B, S, kc, pj ? 1 : 0);
 }
 
 void launch_gemm_dwdx(hipStream_t st, const LayerDev& Lw, int nprob, const float* const* X, int ldx, const float* const* dpre_w, int B, float* const* out_w,
@@ -545,10 +628,11 @@ void launch_gemm_dwdx(hipStream_t st, const LayerDev& Lw, int nprob, const float
     GDxArgs a; a.nsrc = nsrc; a.out = out_x; a.ysrc = ysrc; a.ldy = ldy; a.act_src = act_src;
     for (int i = 0; i < 2; i++) { const int j = i < nsrc ? i : 0; a.src[i].W = W[j]; a.src[i].dpre = dpre_x[j]; }
     const int gx = dense ? ((Lx.K + 31) / 32) * Sx : (Lx.cin / 32) * Lx.ih * Lx.iw;
-    const size_t lds_w = (size_t)(2 * 64 * W_ST + 2 * 16 * NT * W_ST) * 4, lds_x = (size_t)(2 * 32 * X_SA + 2 * 32 * X_SB) * 4 + 256 * 4;
+    const bool pj = dx_parallel_join(Lx, nsrc, Sx);
+    const size_t lds_w = (size_t)(2 * 64 * W_ST + 2 * 16 * NT * W_ST) * 4, lds_x = dx_lds_bytes(pj);
     const size_t lds = lds_w > lds_x ? lds_w : lds_x;
     const int grid = dw_blocks + gx * (B / 32);
-    if (NT == 4) hipLaunchKernelGGL((k_dwdx_lds<4>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx);
-    else if (NT == 2) hipLaunchKernelGGL((k_dwdx_lds<2>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx);
-    else hipLaunchKernelGGL((k_dwdx_lds<1>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx);
+    if (NT == 4) hipLaunchKernelGGL((k_dwdx_lds<4>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, pj ? 1 : 0);
+    else if (NT == 2) hipLaunchKernelGGL((k_dwdx_lds<2>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, pj ? 1 : 0);
+    else hipLaunchKernelGGL((k_dwdx_lds<1>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, pj ? 1 : 0);
 }
