@@ -272,6 +272,16 @@ __global__ __launch_bounds__(1024) void k_td(TdArgs A) {
     float* hv_on_adv = hv_on_val + ncon;
     float* hv_tg_val = hv_on_adv + nA * ncon;
     float* hv_tg_adv = hv_tg_val + B;
+    // the batch metadata of this thread's column (blockDim >= B: one column per thread) is requested FIRST -- two dependent round trips
+    // (idx -> a, r, done, priority) and the double-precision pow of the IS weight ride under the head reduction below
+    const int b_ = threadIdx.x; const bool hasb = b_ < B;
+    long long j_ = 0; int act_ = 0; float rew_ = 0.0f, dn_ = 0.0f, w_ = 0.0f;
+    if (hasb) {
+        const float total = A.tree[1]; const long long size = A.st->size;
+        j_ = A.idx[b_]; act_ = A.a[j_]; rew_ = A.r[j_]; dn_ = (float)A.done[j_];
+        const float p = A.tree[A.cap2 + j_] / total; const float xw = (float)size * p;
+        w_ = (float)pow((double)xw, -(double)A.prio_beta);               // IS weight, ...replay.jl:101-102
+    }
     // phase 1: every lane of the workgroup finishes head outputs (split-K slabs of the head layers are reduced here)
     {
         const int n_on = (A.dueling ? 1 : 0) * ncon, n_oa = nA * ncon, n_tv = (A.dueling ? 1 : 0) * B, n_ta = nA * B;
@@ -284,13 +294,8 @@ __global__ __launch_bounds__(1024) void k_td(TdArgs A) {
     }
     __syncthreads();
     const float invB = 1.0f / (float)B;
-    const float total = A.tree[1];
-    const long long size = A.st->size;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        const long long j = A.idx[b];
-        const int act = A.a[j]; const float rew = A.r[j]; const float dn = (float)A.done[j];
-        const float p = A.tree[A.cap2 + j] / total; const float xw = (float)size * p;
-        const float w = (float)pow((double)xw, -(double)A.prio_beta);     // IS weight, ...replay.jl:101-102
+    if (hasb) {
+        const int b = b_; const int act = act_; const float rew = rew_, dn = dn_, w = w_;
         A.w_is[b] = w;
         float q[NMAX], qt[NMAX], araw[NMAX], vraw;
         q_from_lds<NMAX>(nA, A.dueling, hv_tg_val, hv_tg_adv, B, b, qt, &vraw, araw);
