@@ -153,6 +153,18 @@ int build_program(dqn_engine* e) {
             e->prog.push_back({"td_huber_drqn", [=](dqn_engine* en) { launch_td_drqn(en->stream, d); }});
         }
     }
+    {
+        // update_priorities! (src/solver.jl:231-233) needs only idx and td.  For small batches it rides as a dedicated block of the Adam launch; at
+        // B > 64 its B leaf paths x log2(cap) levels (~70 us at B = 512, 1e6 leaves) would be that launch's tail, so it runs on a side stream
+        // concurrently with the whole backward pass and is joined before the optimizer (a graph fork/join costs ~15 us -- only worth it here).
+        if (!rec && e->hp.prioritized_replay && Bb > 64) {
+            e->prio_forked = true;
+            e->prog.push_back({"prio_fork", [](dqn_engine* en) {
+                hipEventRecord(en->ev_fork, en->stream); hipStreamWaitEvent(en->stream2, en->ev_fork, 0);
+                launch_update_priorities(en->stream2, en->B, en->cap2, en->idx, en->td, en->hp.prio_eps, en->hp.prio_alpha, en->tree, en->state, 0, 1.0, 1.0, nullptr, 0);
+                hipEventRecord(en->ev_join, en->stream2); }});
+        } else e->prio_forked = false;
+    }
     // ---------------- data-parallel replicas: which layers' dW is computed AFTER the exchange from gathered operands (dp.hip)
     const int W = e->sim_world ? e->sim_world : e->world;
     const bool dp_on = (e->comm || e->sim_world) && !rec && getenv("DQN_DP_ALLREDUCE") == nullptr;
@@ -278,6 +290,7 @@ int build_program(dqn_engine* e) {
         }
         flush_dw(); flush_dx();
     }
+    if (e->prio_forked) e->prog.push_back({"prio_join", [](dqn_engine* en) { hipStreamWaitEvent(en->stream, en->ev_join, 0); }});
     memset(&e->adam_segs, 0, sizeof e->adam_segs);
     {
         bool ok = !final_segs.empty() && final_segs.size() <= 8; unsigned long long tot = 0;
@@ -361,7 +374,7 @@ int build_program(dqn_engine* e) {
         if (!e->dp_adam_folds) e->prog.push_back({"dp_sum_ranks", [=](dqn_engine* en) { launch_dp_unpack_sum(en->stream, dsum); }});
     }
     e->prog.push_back({"adam", [](dqn_engine* en) {
-        PrioArgs pa; pa.n = (en->hp.prioritized_replay && !en->hp.recurrence) ? en->B : 0; pa.cap2 = en->cap2; pa.idx = en->idx; pa.td = en->td; pa.eps = en->hp.prio_eps; pa.alpha = en->hp.prio_alpha; pa.tree = en->tree;
+        PrioArgs pa; pa.n = (en->hp.prioritized_replay && !en->hp.recurrence && !en->prio_forked) ? en->B : 0; pa.cap2 = en->cap2; pa.idx = en->idx; pa.td = en->td; pa.eps = en->hp.prio_eps; pa.alpha = en->hp.prio_alpha; pa.tree = en->tree;
         AdamSegs none; memset(&none, 0, sizeof none);
         const bool fold = en->adam_segs.n > 0 && !en->comm && !en->sim_world;     // with a communicator the gradient must be materialised before the all-reduce
         launch_adam(en->stream, en->Pint, en->p_on, en->m, en->v, en->grad, en->state, en->gmax_part, en->hp.adam_f64_scalars, en->hp.learning_rate,
