@@ -251,7 +251,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(pkg, layers, hp, params, env, args)
         out = {
-            "metric": "train steps/sec (batch=32, 84x84x4 obs)", "value": value, "unit": "steps/s", "n_gpus": world,
+            "metric": f"train steps/sec (batch={args.batch}, 84x84x4 obs)", "value": value, "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: TestMDP((84,84),4,6) image MDP, Nature-DQN 3-conv+2-dense dueling, double-Q, prioritized replay",
