@@ -324,6 +324,11 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
     Stage r0, r1;
     r0.b1 = r1.b1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     gload(0, r0); STAGE_WAIT(0, r0); lstore(0, r0); __syncthreads();
+    if (nkt == 1) {
+        // a chunk of a single K tile (conv layers at B = 32: one position x 32 samples; the wide dense layers): nothing to pipeline, and
+        // the clamped prefetches below would only add three serialized round trips before the workgroup may exit
+        compute(0);
+    } else {
     gload(1, r0);
     for (int kt = 0; kt < nkt; kt += 2) {
         gload(kt + 2, r1);
@@ -336,6 +341,7 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
         __syncthreads();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 #undef STAGE_WAIT
     const size_t per_s = (size_t)(L.K + 1) * L.N;
     float* out = p.out + (size_t)s * per_s;
