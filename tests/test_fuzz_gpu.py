@@ -163,3 +163,41 @@ def test_random_device_env_loop_bit_exact(pkg, seed):
         np.testing.assert_array_equal(g.get_params(0), t.get_params(0))
     ne = int(rng.choice([1, 4, 9])); assert g.evaluate(ne, mel, seed=3) == t.evaluate(ne, mel, seed=3)
     g.close(); t.close()
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_simulated_ranks_equal_concatenated_batch(pkg, monkeypatch, seed):
+    """random wide-dense networks (first layer or after a conv trunk, dueling or not) under DQN_SIM_WORLD=k: the gather exchange must equal the twin's
+    single-device step on the concatenated k*B batch (wide layers bit for bit, everything else to round-off)."""
+    rng = np.random.default_rng(4000 + seed)
+    k = int(rng.choice([2, 3, 4])); B = 32
+    wide = int(rng.choice([256, 512]))
+    if rng.random() < 0.5:
+        obs = (3, 12, 14); trunk = [O.Conv(3, 3, 8, O.ACT_RELU, 1), O.Conv(4, 8, 16, O.ACT_RELU, 2)]; feat = 16 * 4 * 5
+    else:
+        obs = (320,); trunk = []; feat = 320
+    layers_ = trunk + [O.Dense(feat, wide, O.ACT_RELU), O.Dense(wide, 4, O.ACT_IDENTITY)]
+    net = O.Network(obs, *O.create_dueling_network(layers_)) if rng.random() < 0.6 else O.Network(obs, layers_)
+    layers = ref.layers_from_network(net)
+    hp_g = ref.hparams_for(net, batch_size=B, buffer_size=200, learning_rate=1e-3, gamma=0.99, double_q=int(rng.random() < 0.7))
+    hp_t = ref.hparams_for(net, batch_size=B * k, buffer_size=200, learning_rate=1e-3, gamma=0.99, double_q=hp_g.double_q)
+    monkeypatch.setenv("DQN_SIM_WORLD", str(k))
+    g = pkg.Engine(layers, hp_g, plan=pkg.default_plan(layers, hp_g))
+    monkeypatch.delenv("DQN_SIM_WORLD")
+    t = ref.Twin(layers, hp_t, plan=pkg.default_plan(layers, hp_t), threads=8)
+    n = 150
+    s = rng.random((n,) + obs, dtype=np.float32); sp = rng.random((n,) + obs, dtype=np.float32)
+    a = rng.integers(0, 4, n).astype(np.int32); r = (2 * rng.standard_normal(n)).astype(np.float32); d = (rng.random(n) < 0.2).astype(np.uint8)
+    p = O.Network.flatten(O.init_params(net, seed=seed)); p = (p + 0.01 * rng.standard_normal(p.shape)).astype(np.float32)
+    for h in (g, t):
+        h.replay_add(s, a, r, sp, d); h.set_params(p, 0); h.set_params(p, 1)
+    idx = rng.choice(n, B, replace=False).astype(np.int64)
+    lg, gg, tdg = g.train_step(idx); lt, gt, tdt = t.train_step(np.tile(idx, k))
+    np.testing.assert_array_equal(tdg, tdt[:B])
+    Gg, Gt = g.get_grads() / np.float32(k), t.get_grads()
+    np.testing.assert_allclose(Gg, Gt, rtol=2e-4, atol=2e-7)
+    if k in (2, 4):     # 1/k exact: the wide blocks are then bit-identical
+        for x, y in zip(net.unflatten(Gg), net.unflatten(Gt)):
+            if x.ndim == 2 and wide in x.shape and feat in x.shape:
+                np.testing.assert_array_equal(x, y)
+    g.close(); t.close()
