@@ -86,6 +86,10 @@ class RolloutStats(C.Structure):
                 ("last_loss", C.c_float), ("last_grad_norm", C.c_float)]
 
 
+class Counters(C.Structure):
+    _fields_ = [("size", C.c_int64), ("widx", C.c_int64), ("sample_ctr", C.c_uint64), ("train_steps", C.c_uint64)]
+
+
 ENV_TESTMDP, ENV_GRIDWORLD = 0, 1
 
 _P = C.POINTER
@@ -136,6 +140,10 @@ PROTOS = {
     "rollout": [_vp, C.c_int, _P(RolloutCfg), _P(RolloutStats)],
     "envs_peek": [_vp, _f32p, _i32p, _f32p, _u8p],
     "evaluate": [_vp, C.c_int, C.c_int, C.c_uint64, _f64p, _f64p],
+    "replay_export": [_vp, C.c_int64, C.c_int64, _vp, _vp, _i32p, _f32p, _u8p, _f32p],
+    "replay_import": [_vp, C.c_int64, _vp, _vp, _i32p, _f32p, _u8p, _f32p],
+    "get_counters": [_vp, _P(Counters)],
+    "set_counters": [_vp, _P(Counters)],
 }
 # twin spellings that differ from the product's
 _TWIN_ALIASES = {"engine_create": "create", "engine_destroy": "destroy", "engine_get_plan": "get_plan"}
@@ -239,6 +247,10 @@ class Handle:
         m, v, bp = np.empty(self.P, np.float32), np.empty(self.P, np.float32), np.empty(2, np.float64)
         self._check(self.f["get_adam_state"](self._h, _ptr(m, _f32p), _ptr(v, _f32p), _ptr(bp, _f64p), self.P))
         return m, v, bp
+
+    def set_adam_state(self, m, v, bp):
+        m, v, bp = _as(m, np.float32), _as(v, np.float32), _as(bp, np.float64)
+        self._check(self.f["set_adam_state"](self._h, _ptr(m, _f32p), _ptr(v, _f32p), _ptr(bp, _f64p), self.P))
 
     def sync_target(self):
         self._check(self.f["sync_target"](self._h))
@@ -400,6 +412,43 @@ class Handle:
         a, r, d = np.empty(n, np.int32), np.empty(n, np.float32), np.empty(n, np.uint8)
         self._check(self.f["envs_peek"](self._h, _ptr(obs, _f32p), _ptr(a, _i32p), _ptr(r, _f32p), _ptr(d, _u8p)))
         return obs, a, r, d
+
+    # ---- checkpoint / resume (product only)
+    def replay_export(self, first=0, n=None):
+        n = self.replay_size()[0] - first if n is None else n
+        s = np.empty((n,) + self.obs_shape, self.obs_np); sp = np.empty_like(s)
+        a, r, d, pr = np.empty(n, np.int32), np.empty(n, np.float32), np.empty(n, np.uint8), np.empty(n, np.float32)
+        self._check(self.f["replay_export"](self._h, first, n, s.ctypes.data_as(_vp), sp.ctypes.data_as(_vp), _ptr(a, _i32p), _ptr(r, _f32p), _ptr(d, _u8p), _ptr(pr, _f32p)))
+        return s, sp, a, r, d, pr
+
+    def replay_import(self, s, sp, a, r, done, priorities):
+        s = _as(s, self.obs_np).reshape(-1, self.obs_elems); sp = _as(sp, self.obs_np).reshape(-1, self.obs_elems)
+        a, r, done, priorities = _as(a, np.int32), _as(r, np.float32), _as(done, np.uint8), _as(priorities, np.float32)
+        self._check(self.f["replay_import"](self._h, s.shape[0], s.ctypes.data_as(_vp), sp.ctypes.data_as(_vp), _ptr(a, _i32p), _ptr(r, _f32p), _ptr(done, _u8p), _ptr(priorities, _f32p)))
+
+    def get_counters(self):
+        c = Counters()
+        self._check(self.f["get_counters"](self._h, C.byref(c)))
+        return dict(size=c.size, widx=c.widx, sample_ctr=c.sample_ctr, train_steps=c.train_steps)
+
+    def set_counters(self, size, widx, sample_ctr, train_steps):
+        c = Counters(int(size), int(widx), int(sample_ctr), int(train_steps))
+        self._check(self.f["set_counters"](self._h, C.byref(c)))
+
+    def checkpoint(self):
+        """everything a bit-exact resume of the train loop needs, as a dict of NumPy arrays (np.savez-able)."""
+        s, sp, a, r, d, pr = self.replay_export()
+        m, v, bp = self.get_adam_state()
+        c = self.get_counters()
+        return dict(p_on=self.get_params(NET_ONLINE), p_tg=self.get_params(NET_TARGET), adam_m=m, adam_v=v, adam_bp=np.asarray(bp, np.float64),
+                    s=s, sp=sp, a=a, r=r, done=d, priorities=pr, counters=np.array([c["size"], c["widx"], c["sample_ctr"], c["train_steps"]], np.int64))
+
+    def restore(self, ck):
+        self.set_params(ck["p_on"], NET_ONLINE); self.set_params(ck["p_tg"], NET_TARGET)
+        self.replay_import(ck["s"], ck["sp"], ck["a"], ck["r"], ck["done"], ck["priorities"])
+        size, widx, sctr, steps = (int(x) for x in ck["counters"])
+        self.set_counters(size, widx, sctr, steps)
+        self.set_adam_state(ck["adam_m"], ck["adam_v"], ck["adam_bp"])
 
     # ---- misc (product only)
     def sync(self):

@@ -156,6 +156,7 @@ void launch_transpose_obs(hipStream_t st, const float* obs /*[n][E]*/, int E, in
 void launch_replay_commit(hipStream_t st, int n, long long start, long long cap, long long cap2, const int* a_in, const float* r_in,
                           const unsigned char* done_in, const float* td_in, float eps, float alpha, int* a, float* r,
                           unsigned char* done, float* tree, StepState* state);
+void launch_tree_rebuild(hipStream_t st, float* tree, long long cap2);
 void launch_sample(hipStream_t st, int B, long long cap2, const float* tree, unsigned long long seed, long long* idx, StepState* state, int bump);
 void launch_batch_meta(hipStream_t st, int B, long long cap2, const long long* idx, const int* a, const float* r,
                        const unsigned char* done, const float* tree, float beta, const StepState* state,

@@ -336,6 +336,59 @@ extern "C" int dqn_replay_get_priorities(dqn_engine_t* e, float* prio, int64_t n
     HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(prio, e->tree + e->cap2, (size_t)n * 4, hipMemcpyDeviceToHost)); return 0;
 }
+// ---------------------------------------------------------------- checkpoint / resume
+extern "C" int dqn_replay_export(dqn_engine_t* e, int64_t first, int64_t n, void* s, void* sp, int32_t* a, float* r, uint8_t* done, float* prio) {
+    HIPCHK(hipSetDevice(e->device));
+    if (e->hp.recurrence) return fail("recurrence = true: the episode replay has no export yet");
+    if (first < 0 || n < 0 || first + n > e->size) return fail("BoundsError: rows %lld..%lld outside 0..%lld", (long long)first, (long long)(first + n - 1), (long long)e->size - 1);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const size_t row = (size_t)e->E * (e->hp.obs_dtype == DQN_OBS_U8 ? 1 : 4);
+    if (s) HIPCHK(hipMemcpy(s, (const char*)e->s_rows + (size_t)first * row, (size_t)n * row, hipMemcpyDeviceToHost));
+    if (sp) HIPCHK(hipMemcpy(sp, (const char*)e->sp_rows + (size_t)first * row, (size_t)n * row, hipMemcpyDeviceToHost));
+    if (a) HIPCHK(hipMemcpy(a, e->ra + first, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (r) HIPCHK(hipMemcpy(r, e->rr + first, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (done) HIPCHK(hipMemcpy(done, e->rdone + first, (size_t)n, hipMemcpyDeviceToHost));
+    if (prio) HIPCHK(hipMemcpy(prio, e->tree + e->cap2 + first, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int dqn_replay_import(dqn_engine_t* e, int64_t n, const void* s, const void* sp, const int32_t* a, const float* r, const uint8_t* done, const float* prio) {
+    HIPCHK(hipSetDevice(e->device));
+    if (e->hp.recurrence) return fail("recurrence = true: the episode replay has no import yet");
+    if (n < 0 || n > e->cap) return fail("import of %lld transitions into a replay of capacity %lld", (long long)n, (long long)e->cap);
+    for (int64_t i = 0; i < n; i++) {
+        if (a[i] < 0 || a[i] >= e->nA) return fail("action index %d out of range 0..%d", a[i], e->nA - 1);
+        if (!(prio[i] > 0.0f)) return fail("AssertionError: all(new_priorities .> 0f0)");
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const size_t row = (size_t)e->E * (e->hp.obs_dtype == DQN_OBS_U8 ? 1 : 4);
+    HIPCHK(hipMemcpy(e->s_rows, s, (size_t)n * row, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(e->sp_rows, sp, (size_t)n * row, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->ra, a, (size_t)n * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(e->rr, r, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->rdone, done, (size_t)n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(e->tree, 0, 2 * (size_t)e->cap2 * 4));
+    HIPCHK(hipMemcpy(e->tree + e->cap2, prio, (size_t)n * 4, hipMemcpyHostToDevice));
+    launch_tree_rebuild(e->stream, e->tree, e->cap2);
+    StepState st; HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipMemcpy(&st, e->state, sizeof st, hipMemcpyDeviceToHost));
+    st.size = n; HIPCHK(hipMemcpy(e->state, &st, sizeof st, hipMemcpyHostToDevice));
+    e->size = n; e->widx = n % e->cap;
+    return 0;
+}
+extern "C" int dqn_get_counters(dqn_engine_t* e, dqn_counters* out) {
+    HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream));
+    StepState st; HIPCHK(hipMemcpy(&st, e->state, sizeof st, hipMemcpyDeviceToHost));
+    out->size = e->size; out->widx = e->widx; out->sample_ctr = st.sample_ctr; out->train_steps = st.step; return 0;
+}
+extern "C" int dqn_set_counters(dqn_engine_t* e, const dqn_counters* in) {
+    HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream));
+    if (in->size != e->size) return fail("counters.size (%lld) differs from the replay's (%lld): import the replay first", (long long)in->size, (long long)e->size);
+    if (in->widx < 0 || in->widx >= e->cap) return fail("counters.widx out of range");
+    StepState st; HIPCHK(hipMemcpy(&st, e->state, sizeof st, hipMemcpyDeviceToHost));
+    // the Adam beta powers are double-buffered by step parity: keep the live pair where the new parity expects it
+    const int old_slot = (int)(st.step & 1ull), new_slot = (int)(in->train_steps & 1ull);
+    if (old_slot != new_slot) { const double b0 = st.bp[old_slot][0], b1 = st.bp[old_slot][1]; st.bp[new_slot][0] = b0; st.bp[new_slot][1] = b1; }
+    st.sample_ctr = in->sample_ctr; st.step = in->train_steps;
+    HIPCHK(hipMemcpy(e->state, &st, sizeof st, hipMemcpyHostToDevice));
+    e->widx = in->widx; return 0;
+}
 static int check_idx(dqn_engine* e, const int64_t* idx, int n) {
     for (int i = 0; i < n; i++) if (idx[i] < 0 || idx[i] >= e->size) return fail("BoundsError: index %lld outside 0..%lld", (long long)idx[i], (long long)e->size - 1);
     return 0;

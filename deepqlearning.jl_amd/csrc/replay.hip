@@ -271,3 +271,13 @@ void launch_update_priorities(hipStream_t st, int n, long long cap2, const long 
     if (tick_adam && bs < 256) bs = 256;
     hipLaunchKernelGGL(k_update_priorities, dim3(1), dim3(bs), 0, st, n, cap2, idx, td, eps, alpha, tree, state, tick_adam, beta1, beta2, gmax_part, n_gmax);
 }
+
+// ------------------------------------------------------------------ checkpoint import: rebuild every internal node of the sum-tree from the leaves
+__global__ void k_tree_level(float* tree, long long width) {      // width = number of nodes on the PARENT level
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < width) { const long long node = width + i; tree[node] = tree[2 * node] + tree[2 * node + 1]; }
+}
+void launch_tree_rebuild(hipStream_t st, float* tree, long long cap2) {
+    for (long long width = cap2 >> 1; width >= 1; width >>= 1)
+        hipLaunchKernelGGL(k_tree_level, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, st, tree, width);
+}

@@ -223,6 +223,16 @@ int dqn_evaluate(dqn_engine_t* e, int n_eval, int max_episode_length, uint64_t s
 /* inspection (parity tests): current observations float[n][C][H][W], last actions int32[n], last rewards float[n], last dones uint8[n] */
 int dqn_envs_peek(dqn_engine_t* e, float* obs, int32_t* actions, float* rewards, uint8_t* dones);
 
+/* ---- checkpoint / resume (absent in the reference, which only saves the best network: src/solver.jl:290-318).
+ * Together with dqn_get/set_params, dqn_get/set_adam_state these make a run resumable bit for bit: the replay in its storage type
+ * (rows `first .. first+n-1` of the ring, slot order), stored priorities, ring cursor, and the sampler / optimizer counters. */
+typedef struct { int64_t size, widx; uint64_t sample_ctr, train_steps; } dqn_counters;
+int dqn_replay_export(dqn_engine_t* e, int64_t first, int64_t n, void* s, void* sp, int32_t* a, float* r, uint8_t* done, float* priorities);
+/* replaces the whole replay: n <= capacity transitions go to slots 0..n-1 with the given priorities (NOT td errors); the sum-tree is rebuilt */
+int dqn_replay_import(dqn_engine_t* e, int64_t n, const void* s, const void* sp, const int32_t* a, const float* r, const uint8_t* done, const float* priorities);
+int dqn_get_counters(dqn_engine_t* e, dqn_counters* out);
+int dqn_set_counters(dqn_engine_t* e, const dqn_counters* in);   /* size must equal the imported n; widx < capacity */
+
 /* data-parallel replicas: all-reduce (SUM over ranks, then * 1/world) of the flat
  * gradient between backward and Adam, over RCCL (dlopen'ed librccl; no reference
  * equivalent).  unique_id: 128 bytes from dqn_comm_unique_id on rank 0. */

@@ -226,3 +226,34 @@ def test_rccl_path_world1_matches_plain(pkg, monkeypatch):
         np.testing.assert_array_equal(ra[2], rb[2])
     np.testing.assert_array_equal(a.get_params(0), b.get_params(0))
     np.testing.assert_array_equal(a.get_params(0), cpu.get_params(0))
+
+
+@pytest.mark.parametrize("u8", [False, True])
+def test_checkpoint_resume_is_bit_exact(pkg, u8, tmp_path):
+    """dqn_replay_export/import + counters + parameters + Adam state (the reference only saves the best network, src/solver.jl:290-318):
+    a run continued from a checkpoint in a NEW engine reproduces the uninterrupted run bit for bit (sampled indices, TD errors, loss, parameters)."""
+    net = small_conv_dueling()
+    a, cpu, hp = make_pair(pkg, net, 16, cap=100, obs_dtype=1 if u8 else 0, learning_rate=1e-3)
+    fill((a, cpu), net, 137, u8=u8); set_same_params((a, cpu), net)
+    for _ in range(5):
+        a.train_step()
+    ck = a.checkpoint()
+    np.savez(tmp_path / "ck.npz", **ck)
+    ref_run = [a.train_step() for _ in range(4)]
+    b, _, _ = make_pair(pkg, net, 16, cap=100, obs_dtype=1 if u8 else 0, learning_rate=1e-3)
+    b.restore(dict(np.load(tmp_path / "ck.npz")))
+    assert b.get_counters() == {k: int(v) for k, v in zip(("size", "widx", "sample_ctr", "train_steps"), ck["counters"])}
+    for want in ref_run:
+        got = b.train_step()
+        assert got[0] == want[0] and got[1] == want[1]
+        np.testing.assert_array_equal(got[2], want[2])
+    np.testing.assert_array_equal(a.get_params(0), b.get_params(0)); np.testing.assert_array_equal(a.get_params(1), b.get_params(1))
+    np.testing.assert_array_equal(a.replay_priorities(), b.replay_priorities())
+    ma, va, ba = a.get_adam_state(); mb, vb, bb = b.get_adam_state()
+    np.testing.assert_array_equal(ma, mb); np.testing.assert_array_equal(va, vb); np.testing.assert_array_equal(ba, bb)
+    # the ring cursor survives: the next add lands in the same slot
+    s1, a1, r1, sp1, d1 = fill((a, b), net, 3, seed=9, u8=u8)
+    np.testing.assert_array_equal(a.replay_priorities(), b.replay_priorities())
+    z = np.zeros((101,) + net.obs_shape, b.obs_np)
+    with pytest.raises(pkg.DQNError, match="capacity"):
+        b.replay_import(z, z, np.zeros(101, np.int32), np.zeros(101, np.float32), np.zeros(101, np.uint8), np.ones(101, np.float32))
