@@ -425,6 +425,13 @@ __global__ __launch_bounds__(256) void k_adam(size_t P, float* __restrict__ p, f
             const size_t len = segs.end[q] - segs.beg[q];
             if (e < len) {
                 const float* pp = segs.part[q] + e; float tot = pp[0]; int sI = 1; const size_t sst = segs.stride[q] ? (size_t)segs.stride[q] : len;
+                for (; sI + 32 <= segs.S[q]; sI += 32) {      // conv1 has 134 slabs: 32 loads in flight per thread, adds still in ascending order
+                    float vv[32];
+#pragma unroll
+                    for (int u = 0; u < 32; u++) vv[u] = pp[(size_t)(sI + u) * sst];
+#pragma unroll
+                    for (int u = 0; u < 32; u++) tot = tot + vv[u];
+                }
                 for (; sI + 8 <= segs.S[q]; sI += 8) {
                     float vv[8];
 #pragma unroll
