@@ -92,6 +92,13 @@ __device__ __forceinline__ void valu_fwd_body(const LayerDev& L, const float* __
     } else {
         const float* xp = X + col0 + col; const float* wp = W + n;
         int k = k0;
+        for (; k + 32 <= k1; k += 32) {   // a whole 32-deep head chunk in one round of 64 independent loads; the fma chain stays k-ascending
+            float xv[32], wv[32];
+#pragma unroll
+            for (int u = 0; u < 32; u++) { xv[u] = xp[(size_t)(k + u) * ldx]; wv[u] = wp[(size_t)(k + u) * L.N]; }
+#pragma unroll
+            for (int u = 0; u < 32; u++) acc = fmaf(xv[u], wv[u], acc);
+        }
         for (; k + 8 <= k1; k += 8) {     // 16 independent loads in flight; the fma chain stays k-ascending
             float xv[8], wv[8];
 #pragma unroll
@@ -131,6 +138,19 @@ __device__ __forceinline__ void valu_dw_body(const LayerDev& L, const float* __r
     if (L.kind != DQN_LAYER_CONV) {      // dense: one "position"; operands are two contiguous rows -> 16 loads in flight, chain order unchanged
         const float* dr = dpre + (size_t)n * B; const float* xr = k < L.K ? X + (size_t)k * ldx : nullptr;
         int j = j0;
+        if (j1 - j0 == 32) {                 // B = 32: the whole sample axis in one round of loads
+            float dv[32], xv[32];
+#pragma unroll
+            for (int u = 0; u < 32; u++) { dv[u] = dr[j0 + u]; xv[u] = xr ? xr[j0 + u] : 1.0f; }
+            if (xr) {
+#pragma unroll
+                for (int u = 0; u < 32; u++) acc = fmaf(xv[u], dv[u], acc);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 32; u++) acc = acc + dv[u];
+            }
+            j = j1;
+        }
         for (; j + 8 <= j1; j += 8) {
             float dv[8], xv[8];
 #pragma unroll
