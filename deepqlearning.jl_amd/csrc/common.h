@@ -220,19 +220,32 @@ void launch_bcast_state(hipStream_t st, const float* src, int H, int n, float* d
 #ifdef __HIPCC__
 // head output (n, col): either the finished activation, or -- when the head's forward ran split-K and its reduction is
 // folded into this kernel -- act(sum_s partial + bias)
+// ascending sum of S split-K slabs p[0], p[stride], ..., p[(S-1)*stride]: loads go out in rounds of up to 32 (then 8) INDEPENDENT requests,
+// the last round predicated instead of a one-load-at-a-time tail; the additions stay strictly in slab order (the canonical chunk order)
+__device__ __forceinline__ float slab_sum(const float* __restrict__ p, size_t stride, int S) {
+    float tot = p[0];
+    int s = 1;
+    for (; s + 32 <= S; s += 32) {
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; u++) v[u] = p[(size_t)(s + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 32; u++) tot = tot + v[u];
+    }
+    for (; s < S; s += 8) {
+        const int m = S - s < 8 ? S - s : 8;
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = u < m ? p[(size_t)(s + u) * stride] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (u < m) tot = tot + v[u];
+    }
+    return tot;
+}
 __device__ __forceinline__ float head_val(const HeadSrc& h, int n, int col) {
     const size_t e = (size_t)n * h.ld + col;
     if (h.S <= 1) return h.p[e];
-    float tot = h.p[e];
-    int s = 1;
-    for (; s + 8 <= h.S; s += 8) {      // 8 independent slab loads in flight, adds in ascending order
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = h.p[(size_t)(s + u) * h.per_s + e];
-#pragma unroll
-        for (int u = 0; u < 8; u++) tot = tot + v[u];
-    }
-    for (; s < h.S; s++) tot = tot + h.p[(size_t)s * h.per_s + e];
+    const float tot = slab_sum(h.p + e, (size_t)h.per_s, h.S);
     return act_f(tot + h.bias[n], h.act);
 }
 __device__ __forceinline__ void q_column_h(int nA, int dueling, const HeadSrc& val, const HeadSrc& adv, int col, float* q, float* vout, float* araw) {

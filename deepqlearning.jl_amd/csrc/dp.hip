@@ -14,15 +14,7 @@ __global__ void k_dp_pack(DpPackArgs A) {
         const unsigned long long row = R.B > 1 ? i / (unsigned)R.B : i; const unsigned col = R.B > 1 ? (unsigned)(i - row * (unsigned)R.B) : 0u;
         float v;
         if (R.S > 1) {          // a conv layer's split-K dW slabs: reduced here (ascending) instead of by a launch of their own
-            v = R.src[i]; int s = 1;
-            for (; s + 8 <= R.S; s += 8) {
-                float t[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) t[u] = R.src[(unsigned long long)(s + u) * R.per_s + i];
-#pragma unroll
-                for (int u = 0; u < 8; u++) v = v + t[u];
-            }
-            for (; s < R.S; s++) v = v + R.src[(unsigned long long)s * R.per_s + i];
+            v = slab_sum(R.src + i, (size_t)R.per_s, R.S);
         } else v = R.B > 1 ? R.src[row * (unsigned)R.ld + col] : R.src[i];
         A.send[R.dst + i] = v;
     }

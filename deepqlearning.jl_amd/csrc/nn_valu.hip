@@ -14,8 +14,7 @@ __global__ void k_reduce(const float* __restrict__ part, int S, size_t elems, in
                          const float* __restrict__ addend, const float* __restrict__ ysrc, int B, int ldy, float* __restrict__ out) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= elems) return;
-    float tot = part[e];
-    for (int s = 1; s < S; s++) tot = tot + part[(size_t)s * elems + e];
+    float tot = slab_sum(part + e, elems, S);
     if (mode == 0) tot = act_f(tot + bias[e / per_n], act);
     else if (mode == 1) {
         if (addend) tot = addend[e] + tot;
@@ -31,22 +30,9 @@ __global__ __launch_bounds__(256) void k_reduce_multi(const RSeg* __restrict__ s
     const RSeg& R = segs[si];
     const size_t e = (size_t)(blockIdx.x - R.first_block) * 256 + threadIdx.x;
     if (e >= R.elems) return;
-    float tot = R.part[e];
-    {   // slab loads are issued 8 at a time (independent), the adds stay in ascending slab order
-        const float* pp = R.part + e; const size_t st = R.elems;
-        int s = 1;
-        for (; s + 8 <= R.S; s += 8) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = pp[(size_t)(s + u) * st];
-#pragma unroll
-            for (int u = 0; u < 8; u++) tot = tot + v[u];
-        }
-        for (; s < R.S; s++) tot = tot + pp[(size_t)s * st];
-    }
+    float tot = slab_sum(R.part + e, (size_t)R.elems, R.S);
     if (R.S2 > 0) {
-        float t2 = R.part[(size_t)R.S * R.elems + e];
-        for (int s = 1; s < R.S2; s++) t2 = t2 + R.part[(size_t)(R.S + s) * R.elems + e];
+        const float t2 = slab_sum(R.part + (size_t)R.S * R.elems + e, (size_t)R.elems, R.S2);
         tot = tot + t2;
     }
     if (R.mode == 0) tot = act_f(tot + R.bias[e / R.per_n], R.act);
@@ -444,22 +430,7 @@ __global__ __launch_bounds__(256) void k_adam(size_t P, float* __restrict__ p, f
         for (int q = 0; q < segs.n; q++) {
             const size_t len = segs.end[q] - segs.beg[q];
             if (e < len) {
-                const float* pp = segs.part[q] + e; float tot = pp[0]; int sI = 1; const size_t sst = segs.stride[q] ? (size_t)segs.stride[q] : len;
-                for (; sI + 32 <= segs.S[q]; sI += 32) {      // conv1 has 134 slabs: 32 loads in flight per thread, adds still in ascending order
-                    float vv[32];
-#pragma unroll
-                    for (int u = 0; u < 32; u++) vv[u] = pp[(size_t)(sI + u) * sst];
-#pragma unroll
-                    for (int u = 0; u < 32; u++) tot = tot + vv[u];
-                }
-                for (; sI + 8 <= segs.S[q]; sI += 8) {
-                    float vv[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) vv[u] = pp[(size_t)(sI + u) * sst];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) tot = tot + vv[u];
-                }
-                for (; sI < segs.S[q]; sI++) tot = tot + pp[(size_t)sI * sst];
+                const float tot = slab_sum(segs.part[q] + e, segs.stride[q] ? (size_t)segs.stride[q] : len, segs.S[q]);
                 const size_t i = segs.beg[q] + e;
                 g_out[i] = tot;                                       // the materialised gradient (dqn_get_grads, parity tests)
                 upd(tot, m[i], v[i], p[i]);
