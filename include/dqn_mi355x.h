@@ -233,9 +233,11 @@ int dqn_replay_import(dqn_engine_t* e, int64_t n, const void* s, const void* sp,
 int dqn_get_counters(dqn_engine_t* e, dqn_counters* out);
 int dqn_set_counters(dqn_engine_t* e, const dqn_counters* in);   /* size must equal the imported n; widx < capacity */
 
-/* data-parallel replicas: all-reduce (SUM over ranks, then * 1/world) of the flat
- * gradient between backward and Adam, over RCCL (dlopen'ed librccl; no reference
- * equivalent).  unique_id: 128 bytes from dqn_comm_unique_id on rank 0. */
+/* data-parallel replicas (no reference equivalent): after dqn_comm_init every train step exchanges gradients between backward and Adam
+ * with ONE collective over RCCL (dlopen'ed librccl) on the engine's stream -- an all-gather of the wide dense layers' operands and of the
+ * small gradients, or an all-reduce of the flat gradient (no qualifying layer, recurrent engines, DQN_DP_ALLREDUCE=1);
+ * Adam then applies the sum * 1/world, identically on every rank.  unique_id: 128 bytes from dqn_comm_unique_id on rank 0.
+ * Every rank must issue the same sequence of train steps. */
 int dqn_comm_unique_id(void* id128);
 int dqn_comm_init(dqn_engine_t* e, const void* id128, int rank, int world);
 
