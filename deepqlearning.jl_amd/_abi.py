@@ -202,7 +202,7 @@ class Handle:
             rc = fns["engine_create"](self.layers, self.n_layers, C.byref(hp), parr, C.byref(h))
         else:
             rc = fns["engine_create"](self.layers, self.n_layers, C.byref(hp), parr, device, C.byref(h))
-        self._h = h
+        self._handle = h
         self._check(rc)
         n = C.c_size_t()
         self._check(fns["n_params"](h, C.byref(n)))
@@ -212,10 +212,18 @@ class Handle:
         if rc != 0:
             raise DQNError(self.f["last_error"]().decode())
 
+    @property
+    def _h(self):
+        h = getattr(self, "_handle", None)
+        if h is None or not h.value:
+            raise DQNError("the engine has been closed (or was never created)")
+        return h
+
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
-            self.f["engine_destroy"](self._h)
-            self._h = C.c_void_p()
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            self.f["engine_destroy"](h)
+            self._handle = C.c_void_p()
 
     def __del__(self):
         try:

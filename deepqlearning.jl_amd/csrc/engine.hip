@@ -422,6 +422,9 @@ static int check_state_err(dqn_engine* e) {
 }
 extern "C" int dqn_update_priorities(dqn_engine_t* e, const int64_t* idx, const float* td, int n) {
     if (check_idx(e, idx, n)) return -1;
+    // the reference asserts BEFORE it assigns (...replay.jl:77-79), so a bad TD error must leave the priorities untouched; with eps > 0
+    // (|td| + eps)^alpha fails to be > 0 only for NaN
+    for (int i = 0; i < n; i++) if (td[i] != td[i]) return fail("AssertionError: all(new_priorities .> 0f0)");
     HIPCHK(hipSetDevice(e->device));
     for (int o = 0; o < n; o += e->B) {   // the device buffers hold B entries
         const int c = std::min(e->B, n - o);

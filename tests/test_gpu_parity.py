@@ -209,6 +209,22 @@ def test_errors_are_loud(pkg):
         gpu.train_step()
     with pytest.raises(pkg.DQNError):
         gpu.set_params(np.zeros(3, np.float32))
+    # update_priorities! asserts before it assigns (...replay.jl:77-79): a NaN TD error is refused and the priorities stay as they were
+    fill((gpu,), net, 40)
+    before = gpu.replay_priorities()
+    idx = np.arange(32, dtype=np.int64)
+    with pytest.raises(pkg.DQNError, match="new_priorities"):
+        gpu.update_priorities(idx, np.full(32, np.nan, np.float32))
+    np.testing.assert_array_equal(gpu.replay_priorities(), before)
+    gpu.train_step()                                        # and the engine keeps working
+    # zero-length and degenerate calls
+    gpu.replay_add(np.zeros((0, 2), np.float32), np.zeros(0, np.int32), np.zeros(0, np.float32), np.zeros((0, 2), np.float32), np.zeros(0, np.uint8))
+    with pytest.raises(pkg.DQNError, match="n must be >= 1"):
+        gpu.forward(np.zeros((0, 2), np.float32))
+    gpu.close()
+    with pytest.raises(pkg.DQNError, match="closed"):      # not a crash
+        gpu.train_step()
+    gpu.close()                                            # idempotent
 
 
 def test_rccl_path_world1_matches_plain(pkg, monkeypatch):
