@@ -246,10 +246,10 @@ extern "C" int dqn_engine_destroy(dqn_engine_t* e) {
     if (e->ev_join) hipEventDestroy(e->ev_join);
     delete e; return 0;
 }
-extern "C" int dqn_engine_get_plan(dqn_engine_t* e, dqn_layer_plan* p) {
+extern "C" int dqn_engine_get_plan(dqn_engine_t* e, dqn_layer_plan* p) { if (!e) return fail("null engine handle");
     for (int i = 0; i < e->nl; i++) { p[i].fwd_kc = e->L[i].fwd_kc; p[i].dx_kc = e->L[i].dx_kc; p[i].dw_kc = e->L[i].dw_kc; } return 0;
 }
-extern "C" int dqn_n_params(dqn_engine_t* e, size_t* n) { *n = e->P; return 0; }
+extern "C" int dqn_n_params(dqn_engine_t* e, size_t* n) { if (!e) return fail("null engine handle"); *n = e->P; return 0; }
 
 // ---------------------------------------------------------------- parameters
 static int put_vec(dqn_engine* e, const float* host, float* dev) {   // external layout -> internal
@@ -264,29 +264,29 @@ static int get_vec(dqn_engine* e, const float* dev, float* host) {
     HIPCHK(hipMemcpyAsync(host, e->io_tmp, e->P * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream)); return 0;
 }
-extern "C" int dqn_set_params(dqn_engine_t* e, int which, const float* flat, size_t n) {
+extern "C" int dqn_set_params(dqn_engine_t* e, int which, const float* flat, size_t n) { if (!e) return fail("null engine handle");
     if (n != e->P) return fail("set_params: got %zu values, the network has %zu parameters", n, e->P);
     return put_vec(e, flat, which == DQN_NET_TARGET ? e->p_tg : e->p_on);
 }
-extern "C" int dqn_get_params(dqn_engine_t* e, int which, float* flat, size_t n) {
+extern "C" int dqn_get_params(dqn_engine_t* e, int which, float* flat, size_t n) { if (!e) return fail("null engine handle");
     if (n != e->P) return fail("get_params: size mismatch (%zu vs %zu)", n, e->P);
     return get_vec(e, which == DQN_NET_TARGET ? e->p_tg : e->p_on, flat);
 }
-extern "C" int dqn_get_grads(dqn_engine_t* e, float* flat, size_t n) {
+extern "C" int dqn_get_grads(dqn_engine_t* e, float* flat, size_t n) { if (!e) return fail("null engine handle");
     if (n != e->P) return fail("get_grads: size mismatch"); return get_vec(e, e->grad, flat);
 }
-extern "C" int dqn_sync_target(dqn_engine_t* e) {   // Flux.loadparams!(target_q, params(active_q)), src/solver.jl:142-145
+extern "C" int dqn_sync_target(dqn_engine_t* e) { if (!e) return fail("null engine handle");   // Flux.loadparams!(target_q, params(active_q)), src/solver.jl:142-145
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpyAsync(e->p_tg, e->p_on, e->Pint * 4, hipMemcpyDeviceToDevice, e->stream)); return 0;
 }
-extern "C" int dqn_get_adam_state(dqn_engine_t* e, float* m, float* v, double* bp, size_t n) {
+extern "C" int dqn_get_adam_state(dqn_engine_t* e, float* m, float* v, double* bp, size_t n) { if (!e) return fail("null engine handle");
     if (n != e->P) return fail("size mismatch");
     if (m && get_vec(e, e->m, m)) return -1;
     if (v && get_vec(e, e->v, v)) return -1;
     if (bp) { StepState s; HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipMemcpy(&s, e->state, sizeof s, hipMemcpyDeviceToHost)); const int sl = (int)((s.step + 1) & 1); bp[0] = s.bp[sl][0]; bp[1] = s.bp[sl][1]; }
     return 0;
 }
-extern "C" int dqn_set_adam_state(dqn_engine_t* e, const float* m, const float* v, const double* bp, size_t n) {
+extern "C" int dqn_set_adam_state(dqn_engine_t* e, const float* m, const float* v, const double* bp, size_t n) { if (!e) return fail("null engine handle");
     if (n != e->P) return fail("size mismatch");
     if (m && put_vec(e, m, e->m)) return -1;
     if (v && put_vec(e, v, e->v)) return -1;
@@ -299,7 +299,7 @@ extern "C" int dqn_set_adam_state(dqn_engine_t* e, const float* m, const float* 
 
 // ---------------------------------------------------------------- replay
 extern "C" int dqn_replay_add(dqn_engine_t* e, const void* s, const int32_t* a, const float* r, const void* sp, const uint8_t* done,
-                              const float* td_err, int n) {
+                              const float* td_err, int n) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device));
     if (e->hp.recurrence) return fail("recurrence = true: use dqn_episode_add (EpisodeReplayBuffer, src/episode_replay.jl)");
     const size_t row = (size_t)e->E * (e->hp.obs_dtype == DQN_OBS_U8 ? 1 : 4);
@@ -331,13 +331,13 @@ extern "C" int dqn_replay_add(dqn_engine_t* e, const void* s, const int32_t* a, 
     }
     return 0;
 }
-extern "C" int dqn_replay_size(dqn_engine_t* e, int64_t* cur, int64_t* cap) { if (cur) *cur = e->size; if (cap) *cap = e->cap; return 0; }
-extern "C" int dqn_replay_get_priorities(dqn_engine_t* e, float* prio, int64_t n) {
+extern "C" int dqn_replay_size(dqn_engine_t* e, int64_t* cur, int64_t* cap) { if (!e) return fail("null engine handle"); if (cur) *cur = e->size; if (cap) *cap = e->cap; return 0; }
+extern "C" int dqn_replay_get_priorities(dqn_engine_t* e, float* prio, int64_t n) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(prio, e->tree + e->cap2, (size_t)n * 4, hipMemcpyDeviceToHost)); return 0;
 }
 // ---------------------------------------------------------------- checkpoint / resume
-extern "C" int dqn_replay_export(dqn_engine_t* e, int64_t first, int64_t n, void* s, void* sp, int32_t* a, float* r, uint8_t* done, float* prio) {
+extern "C" int dqn_replay_export(dqn_engine_t* e, int64_t first, int64_t n, void* s, void* sp, int32_t* a, float* r, uint8_t* done, float* prio) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device));
     if (e->hp.recurrence) return fail("recurrence = true: the episode replay has no export yet");
     if (first < 0 || n < 0 || first + n > e->size) return fail("BoundsError: rows %lld..%lld outside 0..%lld", (long long)first, (long long)(first + n - 1), (long long)e->size - 1);
@@ -351,7 +351,7 @@ extern "C" int dqn_replay_export(dqn_engine_t* e, int64_t first, int64_t n, void
     if (prio) HIPCHK(hipMemcpy(prio, e->tree + e->cap2 + first, (size_t)n * 4, hipMemcpyDeviceToHost));
     return 0;
 }
-extern "C" int dqn_replay_import(dqn_engine_t* e, int64_t n, const void* s, const void* sp, const int32_t* a, const float* r, const uint8_t* done, const float* prio) {
+extern "C" int dqn_replay_import(dqn_engine_t* e, int64_t n, const void* s, const void* sp, const int32_t* a, const float* r, const uint8_t* done, const float* prio) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device));
     if (e->hp.recurrence) return fail("recurrence = true: the episode replay has no import yet");
     if (n < 0 || n > e->cap) return fail("import of %lld transitions into a replay of capacity %lld", (long long)n, (long long)e->cap);
@@ -372,12 +372,12 @@ extern "C" int dqn_replay_import(dqn_engine_t* e, int64_t n, const void* s, cons
     e->size = n; e->widx = n % e->cap;
     return 0;
 }
-extern "C" int dqn_get_counters(dqn_engine_t* e, dqn_counters* out) {
+extern "C" int dqn_get_counters(dqn_engine_t* e, dqn_counters* out) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream));
     StepState st; HIPCHK(hipMemcpy(&st, e->state, sizeof st, hipMemcpyDeviceToHost));
     out->size = e->size; out->widx = e->widx; out->sample_ctr = st.sample_ctr; out->train_steps = st.step; return 0;
 }
-extern "C" int dqn_set_counters(dqn_engine_t* e, const dqn_counters* in) {
+extern "C" int dqn_set_counters(dqn_engine_t* e, const dqn_counters* in) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream));
     if (in->size != e->size) return fail("counters.size (%lld) differs from the replay's (%lld): import the replay first", (long long)in->size, (long long)e->size);
     if (in->widx < 0 || in->widx >= e->cap) return fail("counters.widx out of range");
@@ -393,14 +393,14 @@ static int check_idx(dqn_engine* e, const int64_t* idx, int n) {
     for (int i = 0; i < n; i++) if (idx[i] < 0 || idx[i] >= e->size) return fail("BoundsError: index %lld outside 0..%lld", (long long)idx[i], (long long)e->size - 1);
     return 0;
 }
-extern "C" int dqn_replay_sample(dqn_engine_t* e, int64_t* idx_out) {
+extern "C" int dqn_replay_sample(dqn_engine_t* e, int64_t* idx_out) { if (!e) return fail("null engine handle");
     if (e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");   // ...replay.jl:83
     HIPCHK(hipSetDevice(e->device));
     launch_sample(e->stream, e->B, e->cap2, e->tree, e->hp.seed, e->idx, e->state, 1);
     if (idx_out) { HIPCHK(hipMemcpyAsync(idx_out, e->idx, (size_t)e->B * 8, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); }
     return 0;
 }
-extern "C" int dqn_replay_get_batch(dqn_engine_t* e, const int64_t* idx, float* s, int32_t* a, float* r, float* sp, float* done, float* w) {
+extern "C" int dqn_replay_get_batch(dqn_engine_t* e, const int64_t* idx, float* s, int32_t* a, float* r, float* sp, float* done, float* w) { if (!e) return fail("null engine handle");
     if (check_idx(e, idx, e->B)) return -1;
     HIPCHK(hipSetDevice(e->device));
     const int B = e->B; const size_t rb = (size_t)B * e->E * 4; const int u8 = e->hp.obs_dtype == DQN_OBS_U8;
@@ -420,7 +420,7 @@ static int check_state_err(dqn_engine* e) {
     if (s.err == 2) return fail("AssertionError: all(new_priorities .> 0f0)");
     return 0;
 }
-extern "C" int dqn_update_priorities(dqn_engine_t* e, const int64_t* idx, const float* td, int n) {
+extern "C" int dqn_update_priorities(dqn_engine_t* e, const int64_t* idx, const float* td, int n) { if (!e) return fail("null engine handle");
     if (check_idx(e, idx, n)) return -1;
     // the reference asserts BEFORE it assigns (...replay.jl:77-79), so a bad TD error must leave the priorities untouched; with eps > 0
     // (|td| + eps)^alpha fails to be > 0 only for NaN
@@ -517,7 +517,7 @@ int fetch_scalars(dqn_engine* e, float* loss, float* gn) {
     if (gn) { float g; memcpy(&g, &s.gnorm_bits, 4); *gn = g; }
     return 0;
 }
-extern "C" int dqn_train_step(dqn_engine_t* e, const int64_t* idx, float* loss, float* grad_norm, float* td_out) {
+extern "C" int dqn_train_step(dqn_engine_t* e, const int64_t* idx, float* loss, float* grad_norm, float* td_out) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device));
     if (e->hp.recurrence) return fail("recurrence = true: use dqn_train_step_drqn (src/solver.jl:239-287)");
     if (e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
@@ -527,7 +527,7 @@ extern "C" int dqn_train_step(dqn_engine_t* e, const int64_t* idx, float* loss, 
     if (loss || grad_norm || td_out) return fetch_scalars(e, loss, grad_norm);
     return 0;
 }
-extern "C" int dqn_train_steps(dqn_engine_t* e, int n, float* loss, float* grad_norm) {
+extern "C" int dqn_train_steps(dqn_engine_t* e, int n, float* loss, float* grad_norm) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device));
     if (e->hp.recurrence) { for (int i = 0; i < n; i++) if (dqn_train_step_drqn(e, nullptr, nullptr, i + 1 == n ? loss : nullptr, i + 1 == n ? grad_norm : nullptr)) return -1; return 0; }
     if (e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
@@ -535,7 +535,7 @@ extern "C" int dqn_train_steps(dqn_engine_t* e, int n, float* loss, float* grad_
     if (loss || grad_norm) return fetch_scalars(e, loss, grad_norm);
     return 0;
 }
-extern "C" int dqn_get_last_q(dqn_engine_t* e, float* qs, float* qsp, float* qt, int32_t* best, float* y) {
+extern "C" int dqn_get_last_q(dqn_engine_t* e, float* qs, float* qsp, float* qt, int32_t* best, float* y) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream));
     const size_t n = (size_t)e->B * e->nA * 4;
     if (qs) HIPCHK(hipMemcpy(qs, e->q_on_s, n, hipMemcpyDeviceToHost));
@@ -545,7 +545,7 @@ extern "C" int dqn_get_last_q(dqn_engine_t* e, float* qs, float* qsp, float* qt,
     if (y) HIPCHK(hipMemcpy(y, e->ytarget, (size_t)e->B * 4, hipMemcpyDeviceToHost));
     return 0;
 }
-extern "C" int dqn_get_last_indices(dqn_engine_t* e, int64_t* idx) {
+extern "C" int dqn_get_last_indices(dqn_engine_t* e, int64_t* idx) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(idx, e->idx, (size_t)e->B * 8, hipMemcpyDeviceToHost)); return 0;
 }
@@ -608,12 +608,12 @@ static int policy_forward(dqn_engine* e, int which, const float* obs, int n) {
     launch_q_columns(e->stream, n, e->nA, e->hp.dueling, e->hp.dueling ? e->pol_act[e->last_val] : nullptr, e->pol_act[lq], e->pol_q, e->pol_a);
     return 0;
 }
-extern "C" int dqn_forward(dqn_engine_t* e, int which, const float* obs, int n, float* q_out) {
+extern "C" int dqn_forward(dqn_engine_t* e, int which, const float* obs, int n, float* q_out) { if (!e) return fail("null engine handle");
     if (!obs) return fail("obs is null");
     if (policy_forward(e, which, obs, n)) return -1;
     HIPCHK(hipMemcpyAsync(q_out, e->pol_q, (size_t)n * e->nA * 4, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); return 0;
 }
-extern "C" int dqn_greedy_action(dqn_engine_t* e, const float* obs, int n, int32_t* a_out) {
+extern "C" int dqn_greedy_action(dqn_engine_t* e, const float* obs, int n, int32_t* a_out) { if (!e) return fail("null engine handle");
     if (!obs) return fail("obs is null");
     if (policy_forward(e, DQN_NET_ONLINE, obs, n)) return -1;
     HIPCHK(hipMemcpyAsync(a_out, e->pol_a, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); return 0;
@@ -621,7 +621,7 @@ extern "C" int dqn_greedy_action(dqn_engine_t* e, const float* obs, int n, int32
 
 // ---------------------------------------------------------------- data-parallel replicas
 extern "C" int dqn_comm_unique_id(void* id128) { if (rccl_load()) return -1; const int rc = g_rccl.GetUniqueId(id128); return rc ? fail("ncclGetUniqueId failed (%d)", rc) : 0; }
-extern "C" int dqn_comm_init(dqn_engine_t* e, const void* id128, int rank, int world) {
+extern "C" int dqn_comm_init(dqn_engine_t* e, const void* id128, int rank, int world) { if (!e) return fail("null engine handle");
     if (rccl_load()) return -1;
     HIPCHK(hipSetDevice(e->device));
     Id128 id; memcpy(id.b, id128, 128);
@@ -637,14 +637,14 @@ extern "C" int dqn_comm_init(dqn_engine_t* e, const void* id128, int rank, int w
 }
 
 // ---------------------------------------------------------------- misc
-extern "C" int dqn_stream_sync(dqn_engine_t* e) { HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream)); return 0; }
-extern "C" int dqn_stream_handle(dqn_engine_t* e, void** s) { *s = (void*)e->stream; return 0; }
+extern "C" int dqn_stream_sync(dqn_engine_t* e) { if (!e) return fail("null engine handle"); HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream)); return 0; }
+extern "C" int dqn_stream_handle(dqn_engine_t* e, void** s) { if (!e) return fail("null engine handle"); *s = (void*)e->stream; return 0; }
 // Holds the stream until the host has enqueued the whole profiled step, so that the HIP events around each kernel time
 // the kernel and not the host's launch latency.  Bounded spin (~0.2 s) so a dead host can never hang the GPU.
 __global__ void k_gate(volatile int* flag) {
     for (long i = 0; i < 2000000 && *flag == 0; i++) __builtin_amdgcn_s_sleep(32);
 }
-extern "C" int dqn_profile_step(dqn_engine_t* e, int max_entries, const char** names, float* ms, int* n_entries) {
+extern "C" int dqn_profile_step(dqn_engine_t* e, int max_entries, const char** names, float* ms, int* n_entries) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device));
     if (!e->hp.recurrence && e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
     if (e->hp.recurrence && e->ep_size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");

@@ -3,7 +3,7 @@
 #include "engine.h"
 
 // ---------------------------------------------------------------- DRQN: EpisodeReplayBuffer + recurrent batch_train!
-extern "C" int dqn_episode_commit(dqn_engine_t* e) {          // add_episode! (src/episode_replay.jl:54-60)
+extern "C" int dqn_episode_commit(dqn_engine_t* e) { if (!e) return fail("null engine handle");          // add_episode! (src/episode_replay.jl:54-60)
     NEED_REC(e); HIPCHK(hipSetDevice(e->device));
     const int len = (int)e->ep_cur_len;
     e->ep_len_host[(size_t)e->ep_widx] = len;
@@ -12,7 +12,7 @@ extern "C" int dqn_episode_commit(dqn_engine_t* e) {          // add_episode! (s
     e->ep_widx = (e->ep_widx + 1) % e->ep_cap; if (e->ep_size < e->ep_cap) e->ep_size++;
     e->ep_cur_len = 0; return 0;
 }
-extern "C" int dqn_episode_add(dqn_engine_t* e, const void* s, const int32_t* a, const float* r, const void* sp, const uint8_t* done, int n) {
+extern "C" int dqn_episode_add(dqn_engine_t* e, const void* s, const int32_t* a, const float* r, const void* sp, const uint8_t* done, int n) { if (!e) return fail("null engine handle");
     NEED_REC(e); HIPCHK(hipSetDevice(e->device));
     const size_t row = (size_t)e->E * 4;
     for (int i = 0; i < n; i++) {                              // add_exp! (:46-52): push; the episode is stored when done
@@ -31,7 +31,7 @@ extern "C" int dqn_episode_add(dqn_engine_t* e, const void* s, const int32_t* a,
     }
     return 0;
 }
-extern "C" int dqn_episode_count(dqn_engine_t* e, int64_t* cur, int64_t* cap) { NEED_REC(e); if (cur) *cur = e->ep_size; if (cap) *cap = e->ep_cap; return 0; }
+extern "C" int dqn_episode_count(dqn_engine_t* e, int64_t* cur, int64_t* cap) { if (!e) return fail("null engine handle"); NEED_REC(e); if (cur) *cur = e->ep_size; if (cap) *cap = e->ep_cap; return 0; }
 static int drqn_check(dqn_engine* e, const int64_t* ep_idx, const int32_t* ep_start) {
     if (e->ep_size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
     for (int b = 0; b < e->B; b++) {
@@ -46,7 +46,7 @@ static int drqn_upload_draws(dqn_engine* e, const int64_t* ep_idx, const int32_t
     HIPCHK(hipMemcpyAsync(e->ep_start, ep_start, (size_t)e->B * 4, hipMemcpyHostToDevice, e->stream));
     return 0;
 }
-extern "C" int dqn_episode_get_batch(dqn_engine_t* e, const int64_t* ep_idx, const int32_t* ep_start, float* s, int32_t* a, float* r, float* sp, float* done, int32_t* mask) {
+extern "C" int dqn_episode_get_batch(dqn_engine_t* e, const int64_t* ep_idx, const int32_t* ep_start, float* s, int32_t* a, float* r, float* sp, float* done, int32_t* mask) { if (!e) return fail("null engine handle");
     NEED_REC(e); HIPCHK(hipSetDevice(e->device));
     if (drqn_check(e, ep_idx, ep_start) || drqn_upload_draws(e, ep_idx, ep_start)) return -1;
     EpGatherArgs g; g.ep_s = e->ep_s; g.ep_sp = e->ep_sp; g.ep_a = e->ep_a; g.ep_r = e->ep_r; g.ep_done = e->ep_done; g.ep_len = e->ep_len; g.ep_idx = e->ep_idx; g.ep_start = e->ep_start;
@@ -64,7 +64,7 @@ extern "C" int dqn_episode_get_batch(dqn_engine_t* e, const int64_t* ep_idx, con
     }
     return 0;
 }
-extern "C" int dqn_train_step_drqn(dqn_engine_t* e, const int64_t* ep_idx, const int32_t* ep_start, float* loss, float* grad_norm) {
+extern "C" int dqn_train_step_drqn(dqn_engine_t* e, const int64_t* ep_idx, const int32_t* ep_start, float* loss, float* grad_norm) { if (!e) return fail("null engine handle");
     NEED_REC(e); HIPCHK(hipSetDevice(e->device));
     std::vector<int64_t> di; std::vector<int32_t> ds;
     if (!ep_idx) {   // sample(rng, 1:n, B, replace=false); ep_start = rand(rng, 1:length(ep))  (src/episode_replay.jl:75,81) -- host-side SplitMix draws
@@ -90,12 +90,12 @@ extern "C" int dqn_train_step_drqn(dqn_engine_t* e, const int64_t* ep_idx, const
     if (loss || grad_norm) return fetch_scalars(e, loss, grad_norm);
     return 0;
 }
-extern "C" int dqn_reset_state(dqn_engine_t* e) {             // resetstate!(policy) (src/policy.jl:32-34)
+extern "C" int dqn_reset_state(dqn_engine_t* e) { if (!e) return fail("null engine handle");             // resetstate!(policy) (src/policy.jl:32-34)
     HIPCHK(hipSetDevice(e->device));
     if (!e->hp.recurrence) return 0;
     return policy_state(e, e->pol_state_n > 0 ? e->pol_state_n : 1, true);
 }
-extern "C" int dqn_get_hidden(dqn_engine_t* e, float* hc, size_t n) {   // hiddenstates(m) (src/helpers.jl:61-63): per LSTM layer h then c, [out][streams]
+extern "C" int dqn_get_hidden(dqn_engine_t* e, float* hc, size_t n) { if (!e) return fail("null engine handle");   // hiddenstates(m) (src/helpers.jl:61-63): per LSTM layer h then c, [out][streams]
     HIPCHK(hipSetDevice(e->device)); size_t off = 0;
     for (int i = 0; i < e->nl; i++) if (e->L[i].kind == DQN_LAYER_LSTM) {
         const size_t m = (size_t)e->L[i].H * e->pol_state_n; if (off + 2 * m > n) return fail("get_hidden: buffer too small");
@@ -104,7 +104,7 @@ extern "C" int dqn_get_hidden(dqn_engine_t* e, float* hc, size_t n) {   // hidde
     }
     HIPCHK(hipStreamSynchronize(e->stream)); return 0;
 }
-extern "C" int dqn_set_hidden(dqn_engine_t* e, const float* hc, size_t n) {   // sethiddenstates!(m, hs) (src/helpers.jl:71-79)
+extern "C" int dqn_set_hidden(dqn_engine_t* e, const float* hc, size_t n) { if (!e) return fail("null engine handle");   // sethiddenstates!(m, hs) (src/helpers.jl:71-79)
     HIPCHK(hipSetDevice(e->device)); size_t off = 0;
     for (int i = 0; i < e->nl; i++) if (e->L[i].kind == DQN_LAYER_LSTM) {
         const size_t m = (size_t)e->L[i].H * e->pol_state_n; if (off + 2 * m > n) return fail("set_hidden: buffer too small");

@@ -16,7 +16,7 @@ void free_envs(dqn_engine* e) {
     free_env_arrays(e->eval_env); hipFree(e->eval_roll); e->eval_roll = nullptr; e->eval_n = 0;
     drop_act(e, e->act); drop_act(e, e->evalp);
 }
-extern "C" int dqn_envs_create(dqn_engine_t* e, const dqn_env_spec* sp) {
+extern "C" int dqn_envs_create(dqn_engine_t* e, const dqn_env_spec* sp) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device));
     if (e->hp.recurrence) return fail("device environments drive the feed-forward path (recurrence = false)");
     if (sp->n_envs < 1 || sp->n_envs > std::min<long long>(1024, e->cap)) return fail("n_envs must be in 1..min(1024, replay capacity)");
@@ -48,7 +48,7 @@ extern "C" int dqn_envs_create(dqn_engine_t* e, const dqn_env_spec* sp) {
     e->has_envs = true;
     return dqn_envs_reset(e);
 }
-extern "C" int dqn_envs_reset(dqn_engine_t* e) {
+extern "C" int dqn_envs_reset(dqn_engine_t* e) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device));
     if (!e->has_envs) return fail("no device environments: call dqn_envs_create");
     launch_env_reset_pending(e->stream, e->env, e->roll, 1);
@@ -129,7 +129,7 @@ static int act_graph(dqn_engine* e, dqn_engine::ActProg& ap) {
     HIPCHK(hipStreamEndCapture(e->stream, &g));
     HIPCHK(hipGraphInstantiate(&ap.graph, g, nullptr, nullptr, 0)); HIPCHK(hipGraphDestroy(g)); return 0;
 }
-extern "C" int dqn_rollout(dqn_engine_t* e, int n_steps, const dqn_rollout_cfg* cfg, dqn_rollout_stats* out) {
+extern "C" int dqn_rollout(dqn_engine_t* e, int n_steps, const dqn_rollout_cfg* cfg, dqn_rollout_stats* out) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device));
     if (!e->has_envs) return fail("no device environments: call dqn_envs_create");
     if (cfg->t0 < 1) return fail("t0 counts from 1 (src/solver.jl:82)");
@@ -164,7 +164,7 @@ extern "C" int dqn_rollout(dqn_engine_t* e, int n_steps, const dqn_rollout_cfg* 
 }
 // basic_evaluation (src/evaluation_policy.jl:17-42) on the device: n_eval copies of the training MDP run one greedy episode each
 // (while !done && step <= max_episode_length), rewards summed in Float64 like the reference's r_tot; returns the averages.
-extern "C" int dqn_evaluate(dqn_engine_t* e, int n_eval, int max_episode_length, uint64_t seed, double* avg_reward, double* avg_steps) {
+extern "C" int dqn_evaluate(dqn_engine_t* e, int n_eval, int max_episode_length, uint64_t seed, double* avg_reward, double* avg_steps) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device));
     if (!e->has_envs) return fail("no device environments: call dqn_envs_create (the evaluation copies share its MDP)");
     if (n_eval < 1 || n_eval > 1024) return fail("n_eval must be in 1..1024");
@@ -209,7 +209,7 @@ extern "C" int dqn_evaluate(dqn_engine_t* e, int n_eval, int max_episode_length,
     if (avg_steps) *avg_steps = s / n_eval;
     return 0;
 }
-extern "C" int dqn_envs_peek(dqn_engine_t* e, float* obs, int32_t* actions, float* rewards, uint8_t* dones) {
+extern "C" int dqn_envs_peek(dqn_engine_t* e, float* obs, int32_t* actions, float* rewards, uint8_t* dones) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device));
     if (!e->has_envs) return fail("no device environments: call dqn_envs_create");
     EnvDev& V = e->env; const int n = V.n;

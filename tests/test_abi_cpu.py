@@ -71,3 +71,16 @@ def test_no_gpu_means_loud_failure_not_fallback(pkg):
     net = nature_dueling()
     with pytest.raises(pkg.DQNError, match="no CPU fallback"):
         pkg.Engine(ref.layers_from_network(net), ref.hparams_for(net, batch_size=32))
+
+
+def test_null_handle_is_an_error_not_a_crash():
+    """every entry point taking an engine checks the handle (C callers): rc = -1 and a message, no dereference"""
+    import ctypes as C
+    pkg = ge.load_package()
+    lib = pkg.lib()
+    lib.dqn_last_error.restype = C.c_char_p
+    for name in ("dqn_sync_target", "dqn_stream_sync", "dqn_envs_reset", "dqn_reset_state", "dqn_episode_commit"):
+        f = getattr(lib, name); f.argtypes = [C.c_void_p]; f.restype = C.c_int
+        assert f(None) == -1 and b"null engine handle" in lib.dqn_last_error()
+    lib.dqn_engine_destroy.argtypes = [C.c_void_p]; lib.dqn_engine_destroy.restype = C.c_int
+    assert lib.dqn_engine_destroy(None) == 0
