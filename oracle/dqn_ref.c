@@ -606,12 +606,54 @@ int ref_get_last_q(ref_engine* e, float* qs, float* qsp, float* qt, int32_t* bes
 int ref_get_last_indices(ref_engine* e, int64_t* idx) { memcpy(idx, e->idx, (size_t)e->B * 8); return 0; }
 
 /* ---------------------------------------------------------------- policy (policy.jl:38-64) */
+static void lstm_input_proj(const RLayer* L, const float* P, const float* X, int ldx, int col0, int ncols, float* Gx);
+static inline float sigm_f(float x); static inline float tanh_f(float x);
+/* Recur state of the policy network: one (h, c) column per observation stream; reset = state0 of the ONLINE net (policy.jl:32-34) */
+static void policy_state(ref_engine* e, int n, int force_reset) {
+    if (!e->hp.recurrence) return;
+    if (n != e->pol_n) {
+        for (int i = 0; i < e->nl; i++) if (e->L[i].kind == DQN_LAYER_LSTM) {
+            free(e->pol_h[i]); free(e->pol_c[i]);
+            e->pol_h[i] = (float*)malloc((size_t)e->L[i].H * n * 4); e->pol_c[i] = (float*)malloc((size_t)e->L[i].H * n * 4);
+        }
+        e->pol_n = n; force_reset = 1;
+    }
+    if (force_reset) for (int i = 0; i < e->nl; i++) if (e->L[i].kind == DQN_LAYER_LSTM) {
+        const RLayer* L = &e->L[i];
+        for (int u = 0; u < L->H; u++) for (int b = 0; b < n; b++) { e->pol_h[i][u * n + b] = e->p_on[L->h0_off + u]; e->pol_c[i][u * n + b] = e->p_on[L->c0_off + u]; }
+    }
+}
+int ref_reset_state(ref_engine* e) { policy_state(e, e->pol_n > 0 ? e->pol_n : 1, 1); return 0; }      /* resetstate!(policy) */
 int ref_forward(ref_engine* e, int which, const float* obs, int n, float* q_out) {
     const float* P = which == DQN_NET_TARGET ? e->p_tg : e->p_on; int E = e->obs_elems;
     float* x = (float*)malloc((size_t)E * n * 4); float* act[MAXL];
     for (int f = 0; f < E; f++) for (int b = 0; b < n; b++) x[(size_t)f * n + b] = obs[(size_t)b * E + f];
     for (int i = 0; i < e->nl; i++) act[i] = (float*)malloc((size_t)e->L[i].out_feat * n * 4);
-    net_forward(e, P, act, x, n, 0, n);
+    if (!e->hp.recurrence) net_forward(e, P, act, x, n, 0, n);
+    else {      /* one Recur step per call: the hidden state persists between calls (policy.jl:38-46) */
+        policy_state(e, n, 0);
+        for (int i = 0; i < e->nl; i++) {
+            const RLayer* L = &e->L[i]; const float* X = L->src < 0 ? x : act[L->src];
+            if (L->kind != DQN_LAYER_LSTM) { layer_forward(L, P, X, n, 0, n, act[i]); continue; }
+            const int H = L->H; float* gx = (float*)malloc((size_t)L->N * n * 4);
+            lstm_input_proj(L, P, X, n, 0, n, gx);
+            const float *Wh = P + L->wh_off, *bias = P + L->b_off;
+            float* hn = (float*)malloc((size_t)H * n * 4); float* cn = (float*)malloc((size_t)H * n * 4);
+            for (int u = 0; u < H; u++) for (int b = 0; b < n; b++) {
+                float g[4];
+                for (int q = 0; q < 4; q++) {
+                    const int nn = q * H + u; float ch = 0.0f;
+                    for (int j = 0; j < H; j++) ch = fmaf(e->pol_h[i][j * n + b], Wh[(size_t)j * L->N + nn], ch);
+                    g[q] = (gx[(size_t)nn * n + b] + ch) + bias[nn];
+                }
+                const float ig = sigm_f(g[0]), fg = sigm_f(g[1]), gg = tanh_f(g[2]), og = sigm_f(g[3]);
+                const float t1 = fg * e->pol_c[i][u * n + b]; const float t2 = ig * gg; const float c = t1 + t2; const float tc = tanh_f(c);
+                cn[u * n + b] = c; hn[u * n + b] = og * tc;
+            }
+            memcpy(e->pol_h[i], hn, (size_t)H * n * 4); memcpy(e->pol_c[i], cn, (size_t)H * n * 4); memcpy(act[i], hn, (size_t)H * n * 4);
+            free(hn); free(cn); free(gx);
+        }
+    }
     for (int b = 0; b < n; b++) q_column(e, act, n, b, q_out + (size_t)b * e->nA);
     for (int i = 0; i < e->nl; i++) free(act[i]); free(x); return 0;
 }
@@ -738,8 +780,21 @@ int ref_train_step_drqn(ref_engine* e, const int64_t* ep_idx_in, const int32_t* 
     if (!e->hp.recurrence) FAIL("engine was created with recurrence = false");
     const int B = e->B, T = e->T, TB = T * B, nA = e->nA, E = e->obs_elems, ld0 = 2 * TB;
     int64_t ep_idx[1024]; int32_t ep_start[1024];
-    if (!ep_idx_in) FAIL("the twin needs explicit episode draws");
-    memcpy(ep_idx, ep_idx_in, (size_t)B * 8); memcpy(ep_start, ep_start_in, (size_t)B * 4);
+    if (!ep_idx_in) {      /* sample(rng, 1:n, B, replace=false); ep_start = rand(rng, 1:length(ep)) (src/episode_replay.jl:75,81): the engine's SplitMix64 draws */
+        if (e->ep_size < B) FAIL("AssertionError: r._curr_size >= r.batch_size");
+        int64_t* perm = (int64_t*)malloc((size_t)e->ep_size * 8);
+        for (int64_t i = 0; i < e->ep_size; i++) perm[i] = i;
+        for (int b = 0; b < B; b++) {
+            uint64_t z = (e->drqn_ctr += 0x9E3779B97F4A7C15ull) ^ e->hp.seed; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z = z ^ (z >> 31);
+            const int64_t j = b + (int64_t)(z % (uint64_t)(e->ep_size - b)); const int64_t tmp = perm[b]; perm[b] = perm[j]; perm[j] = tmp;
+        }
+        for (int b = 0; b < B; b++) ep_idx[b] = perm[b];
+        free(perm);
+        for (int b = 0; b < B; b++) {
+            uint64_t z = (e->drqn_ctr += 0x9E3779B97F4A7C15ull) ^ e->hp.seed; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z = z ^ (z >> 31);
+            const int len = e->ep_len[ep_idx[b]]; ep_start[b] = len > 0 ? (int32_t)(z % (uint64_t)len) : 0;
+        }
+    } else { memcpy(ep_idx, ep_idx_in, (size_t)B * 8); memcpy(ep_start, ep_start_in, (size_t)B * 4); }
     if (drqn_check(e, ep_idx, ep_start)) return -1;
     /* sample(r) (:71-95) into the batch-innermost arena: columns t*B+b = s, TB + t*B+b = sp */
     for (int t = 0; t < T; t++) for (int b = 0; b < B; b++) {

@@ -81,3 +81,22 @@ def test_lstm_without_recurrence_flag_is_rejected(pkg):
     hp = ref.hparams_for(net, batch_size=B, buffer_size=8, recurrence=0)
     with pytest.raises(pkg.DQNError, match="recurrent model but recurrence is set to false"):   # src/solver.jl:45-47
         pkg.Engine(ref.layers_from_network(net), hp)
+
+
+@pytest.mark.parametrize("name", list(drqn_nets()))
+def test_recurrent_policy_and_sampled_draws_bit_exact_vs_twin(pkg, name):
+    """The Recur state carried by the policy path (action / actionvalues between resetstate! calls, src/policy.jl:32-46) and the engine's own
+    episode draws (sample without replacement + random start, src/episode_replay.jl:75,81 -- SplitMix64 stream) against the twin's restatement."""
+    net, B, T, kw, rng, gpu, cpu, ring, (p_on, p_tg) = setup(pkg, name)
+    for n in (1, 3):
+        xs = [rng.random((n,) + net.obs_shape).astype(np.float32) for _ in range(5)]
+        gpu.reset_state(); cpu.reset_state()
+        for x in xs:
+            np.testing.assert_array_equal(gpu.forward(x), cpu.forward(x))
+        np.testing.assert_array_equal(gpu.greedy_action(xs[0]), cpu.greedy_action(xs[0]))       # state advanced identically on both
+        gpu.reset_state(); cpu.reset_state()
+        np.testing.assert_array_equal(gpu.forward(xs[0], which=1), cpu.forward(xs[0], which=1))    # target weights, shared carried state
+    for step in range(4):                                   # no draws given: both sides sample the same episodes and start offsets
+        assert gpu.train_step_drqn() == cpu.train_step_drqn()
+    np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+    gpu.close(); cpu.close()
