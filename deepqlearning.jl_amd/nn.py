@@ -84,7 +84,7 @@ def create_dueling_network(m: Chain) -> DuelingNetwork:
     n = len(layers)
     duel_layer = -1
     for i in range(1, n + 1):
-        if layers[n - i].kind != "dense":
+        if getattr(layers[n - i], "kind", None) != "dense":
             duel_layer = n - i + 1
             break
         elif i == n:
@@ -92,6 +92,8 @@ def create_dueling_network(m: Chain) -> DuelingNetwork:
     if duel_layer == -1:
         raise _abi.DQNError("DeepQLearningError: the qnetwork provided is incompatible with dueling")
     trailing = layers[duel_layer:]
+    if not trailing:      # the chain does not end in a Dense layer: nothing to split into value / advantage streams
+        raise _abi.DQNError("DeepQLearningError: the qnetwork provided is incompatible with dueling")
     last = trailing[-1]
     val = Chain(*[Dense(l.n_in, l.n_out, l.act) for l in trailing[:-1]], Dense(last.n_in, 1))
     adv = Chain(*[Dense(l.n_in, l.n_out, l.act) for l in trailing])
@@ -105,16 +107,16 @@ def lower(net):
     def add(chain, stream):
         for l in chain:
             d = _abi.LayerDesc()
+            if getattr(l, "kind", None) not in ("dense", "lstm", "conv"):
+                raise _abi.DQNError(f"DeepQLearningError: unsupported layer {l!r} (Conv / Dense / LSTM / flattenbatch only)")
             d.act, d.stream = l.act, stream
             if l.kind == "dense":
                 d.kind, d.n_in, d.n_out = _abi.LAYER_DENSE, l.n_in, l.n_out
             elif l.kind == "lstm":
                 d.kind, d.n_in, d.n_out = _abi.LAYER_LSTM, l.n_in, l.n_out
-            elif l.kind == "conv":
+            else:
                 d.kind = _abi.LAYER_CONV
                 d.cin, d.cout, d.kh, d.kw, d.sh, d.sw = l.cin, l.cout, l.kh, l.kw, l.sh, l.sw
-            else:
-                raise _abi.DQNError(f"DeepQLearningError: unsupported layer {l!r} (Conv / Dense / flattenbatch only)")
             out.append(d)
 
     if isinstance(net, DuelingNetwork):
