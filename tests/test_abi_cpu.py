@@ -26,14 +26,19 @@ def test_every_declared_symbol_is_exported(pkg):
 
 
 def test_ctypes_structs_match_the_header_sizes(pkg):
-    # sizeof via a tiny C program compiled against the header
+    # sizeof and the offset of one late field per struct, via a tiny C program compiled against the header
     import subprocess, tempfile
-    src = '#include <stdio.h>\n#include "dqn_mi355x.h"\nint main(){printf("%zu %zu %zu\\n", sizeof(dqn_layer_desc), sizeof(dqn_layer_plan), sizeof(dqn_hparams));}'
+    abi = pkg._abi
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "dqn_mi355x.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu  %zu %zu %zu %zu\\n", '
+           'sizeof(dqn_layer_desc), sizeof(dqn_layer_plan), sizeof(dqn_hparams), sizeof(dqn_env_spec), sizeof(dqn_rollout_cfg), sizeof(dqn_rollout_stats), sizeof(dqn_counters), '
+           'offsetof(dqn_hparams, trace_length), offsetof(dqn_env_spec, images), offsetof(dqn_env_spec, reward_val), offsetof(dqn_rollout_cfg, t0));}')
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.run(["gcc", "-I", os.path.join(ge.ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")], check=True)
-        a, b, c = map(int, subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split())
-    assert (a, b, c) == (ctypes.sizeof(pkg.LayerDesc), ctypes.sizeof(pkg.LayerPlan), ctypes.sizeof(pkg.HParams))
+        got = list(map(int, subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()))
+    want = [ctypes.sizeof(x) for x in (pkg.LayerDesc, pkg.LayerPlan, pkg.HParams, abi.EnvSpec, abi.RolloutCfg, abi.RolloutStats, abi.Counters)]
+    want += [pkg.HParams.trace_length.offset, abi.EnvSpec.images.offset, abi.EnvSpec.reward_val.offset, abi.RolloutCfg.t0.offset]
+    assert got == want, (got, want)
 
 
 @pytest.mark.parametrize("name", list(GOLDEN_CASES))
