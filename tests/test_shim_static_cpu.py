@@ -1,0 +1,111 @@
+"""CPU: static checks of the Julia ccall shim (deepqlearning.jl_amd/julia/DeepQLearningMI355X.jl), which cannot be executed here (no julia binary):
+  * the isbits structs it passes by reference have the C layout of the header's structs (field order, sizes, natural alignment -- Julia lays
+    out isbits structs exactly like C), checked against ctypes mirrors that test_abi_cpu.py ties to the header with a compiled C program;
+  * every C entry point it ccalls exists in the header, with the same number of arguments."""
+import ctypes
+import os
+import re
+
+import __graft_entry__ as ge
+
+pkg = ge.load_package()
+abi = pkg._abi
+SHIM = os.path.join(ge.ROOT, "deepqlearning.jl_amd", "julia", "DeepQLearningMI355X.jl")
+HEADER = os.path.join(ge.ROOT, "include", "dqn_mi355x.h")
+
+SCALARS = {"Int32": (4, 4), "UInt32": (4, 4), "Cint": (4, 4), "Float32": (4, 4), "Int64": (8, 8), "UInt64": (8, 8), "Float64": (8, 8), "Csize_t": (8, 8),
+           "UInt8": (1, 1), "Bool": (1, 1)}
+
+
+def type_layout(t):
+    t = t.strip()
+    if t in SCALARS:
+        return SCALARS[t]
+    if t.startswith("Ptr{"):
+        return 8, 8
+    m = re.fullmatch(r"NTuple\{(\d+),\s*(\w+)\}", t)
+    if m:
+        sz, al = SCALARS[m.group(2)]
+        return int(m.group(1)) * sz, al
+    raise KeyError(t)
+
+
+def julia_struct_layout(src, name):
+    m = re.search(r"(?:mutable\s+)?struct\s+" + name + r"\b(.*?)\nend", src, re.S)
+    assert m, name
+    body = re.sub(r"#.*", "", m.group(1))
+    fields = re.findall(r"(\w+)::([\w{}, ]+?)(?=;|\n|$)", body)
+    off, maxal, offsets = 0, 1, {}
+    for fname, ftype in fields:
+        sz, al = type_layout(ftype)
+        off = (off + al - 1) // al * al
+        offsets[fname] = off
+        off += sz
+        maxal = max(maxal, al)
+    return (off + maxal - 1) // maxal * maxal, offsets
+
+
+def test_shim_structs_have_the_c_layout():
+    src = open(SHIM).read()
+    for jl, ct in (("LayerDesc", pkg.LayerDesc), ("HParams", pkg.HParams), ("EnvSpec", abi.EnvSpec), ("RolloutCfg", abi.RolloutCfg), ("RolloutStats", abi.RolloutStats)):
+        size, offsets = julia_struct_layout(src, jl)
+        assert size == ctypes.sizeof(ct), (jl, size, ctypes.sizeof(ct))
+        cfields = [f[0] for f in ct._fields_]
+        assert list(offsets) == cfields, (jl, list(offsets), cfields)             # same names in the same order
+        for f in cfields:
+            assert offsets[f] == getattr(ct, f).offset, (jl, f)
+
+
+def test_every_ccall_names_a_declared_entry_point_with_the_right_arity():
+    src = open(SHIM).read()
+    header = open(HEADER).read()
+    protos = {m.group(1): m.group(2) for m in re.finditer(r"\b(?:int|const char\*)\s+(dqn_\w+)\s*\(([^;{]*?)\)\s*;", header, re.S)}
+    def ccalls(text):
+        """(name, [argument types]) of every ccall((:name, LIB), ret, (types...), args...) -- a small balanced-parenthesis scan"""
+        out = []
+        for m in re.finditer(r"ccall\(\(:(dqn_\w+),\s*LIB\),\s*\w+,\s*\(", text):
+            i, depth, cur, items = m.end(), 1, "", []
+            while depth:
+                ch = text[i]; i += 1
+                if ch in "({":
+                    depth += 1
+                elif ch in ")}":
+                    depth -= 1
+                    if depth == 0:
+                        break
+                if ch == "," and depth == 1:
+                    items.append(cur.strip()); cur = ""
+                else:
+                    cur += ch
+            if cur.strip():
+                items.append(cur.strip())
+            out.append((m.group(1), items))
+        return out
+
+    calls = ccalls(src)
+    assert len(calls) >= 20 and ("dqn_last_error", []) in calls
+    for name, argtypes in calls:
+        assert name in protos, name
+        want = 0 if protos[name].strip() in ("", "void") else protos[name].count(",") + 1
+        assert len(argtypes) == want, (name, argtypes, protos[name])
+    # argument categories: pointer vs 32-bit int vs 64-bit int vs float, position by position
+    def c_cat(param):
+        param = param.strip()
+        if "*" in param:
+            return "ptr"
+        t = param.rsplit(" ", 1)[0].replace("const ", "").strip()
+        return {"int": "i32", "int32_t": "i32", "int64_t": "i64", "uint64_t": "u64", "size_t": "u64", "float": "f32", "double": "f64"}[t]
+
+    def jl_cat(t):
+        if t.startswith(("Ptr{", "Ref{")) or t == "Cstring":
+            return "ptr"
+        return {"Cint": "i32", "Int32": "i32", "Int64": "i64", "UInt64": "u64", "Csize_t": "u64", "Float32": "f32", "Float64": "f64"}[t]
+
+    for name, argtypes in calls:
+        cparams = [x for x in protos[name].split(",") if x.strip() and x.strip() != "void"]
+        assert [jl_cat(t) for t in argtypes] == [c_cat(x) for x in cparams], (name, argtypes, cparams)
+    # and the data-path entry points are all bound
+    bound = {n for n, _ in calls}
+    for must in ("dqn_engine_create", "dqn_train_step", "dqn_replay_add", "dqn_replay_get_batch", "dqn_update_priorities", "dqn_forward", "dqn_sync_target",
+                 "dqn_get_params", "dqn_set_params", "dqn_train_step_drqn", "dqn_episode_add", "dqn_reset_state", "dqn_envs_create", "dqn_rollout", "dqn_evaluate"):
+        assert must in bound, must
