@@ -107,8 +107,13 @@ __global__ __launch_bounds__(256) void k_gather_fb(const void* __restrict__ s_ro
 __global__ __launch_bounds__(256) void k_gather_fb_u8(const unsigned char* __restrict__ s_rows, const unsigned char* __restrict__ sp_rows, int E, int B,
                                                       long long* __restrict__ idx, float* __restrict__ x0, int do_sample, long long cap2,
                                                       const float* __restrict__ tree, unsigned long long seed, const StepState* __restrict__ state) {
-    extern __shared__ float tile8[];                     // [64][257]
+    // the tile stays PACKED in LDS (64 columns x 64 words of 4 features = 16.6 KB instead of 66 KB of floats): several workgroups per CU keep the
+    // random 256-B row reads in flight; bytes are unpacked and converted (256-entry table: one IEEE division per value of b, not per element)
+    // on the way out
+    __shared__ uint32_t tile32[64 * 65];
     __shared__ long long rows[64];
+    __shared__ float lut[256];
+    lut[threadIdx.x] = (float)threadIdx.x / 255.0f;      // test/test_env.jl:59
     const int f0 = blockIdx.x * 256, c0 = blockIdx.y * 64, ld = 2 * B;
     if (threadIdx.x < 64) {
         const int c = c0 + threadIdx.x;
@@ -131,25 +136,26 @@ __global__ __launch_bounds__(256) void k_gather_fb_u8(const unsigned char* __res
         if (c < ld && f < E) v[p] = *reinterpret_cast<const uint32_t*>((c < B ? s_rows : sp_rows) + rows[cl] * E + f);      // E % 4 == 0
     }
 #pragma unroll
-    for (int p = 0; p < 16; p++) {
-        const int q = threadIdx.x + 256 * p, cl = q >> 6, fl = 4 * (q & 63);
-        float* t = tile8 + cl * 257 + fl;
-        t[0] = (float)(v[p] & 0xffu) / 255.0f; t[1] = (float)((v[p] >> 8) & 0xffu) / 255.0f;       // test/test_env.jl:59
-        t[2] = (float)((v[p] >> 16) & 0xffu) / 255.0f; t[3] = (float)(v[p] >> 24) / 255.0f;
-    }
+    for (int p = 0; p < 16; p++) { const int q = threadIdx.x + 256 * p; tile32[(q >> 6) * 65 + (q & 63)] = v[p]; }     // consecutive lanes, consecutive words
     __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // 16 lanes x float4 = one 256-B row segment of the arena (64 consecutive columns of one feature); a wave writes 4 feature rows per instruction
+    const int l16 = threadIdx.x & 15, r16 = threadIdx.x >> 4;
 #pragma unroll 4
-    for (int p = 0; p < 64; p++) {
-        const int fl = p * 4 + w, f = f0 + fl, c = c0 + lane;
-        if (f < E && c < ld) x0[(size_t)f * ld + c] = tile8[lane * 257 + fl];
+    for (int p = 0; p < 16; p++) {
+        const int fl = p * 16 + r16, f = f0 + fl, c = c0 + 4 * l16, sh = 8 * (fl & 3);
+        if (f >= E) continue;
+        float o[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) o[u] = lut[(tile32[(4 * l16 + u) * 65 + (fl >> 2)] >> sh) & 0xffu];
+        if (c + 3 < ld) *reinterpret_cast<f32x4*>(x0 + (size_t)f * ld + c) = (f32x4){o[0], o[1], o[2], o[3]};
+        else for (int u = 0; u < 4; u++) if (c + u < ld) x0[(size_t)f * ld + c + u] = o[u];
     }
 }
 void launch_gather_fb(hipStream_t st, const void* s_rows, const void* sp_rows, int obs_u8, int E, int B, long long* idx, float* x0, int do_sample,
                       long long cap2, const float* tree, unsigned long long seed, const StepState* state) {
     if (obs_u8 && (E & 3) == 0) {
         dim3 grid((E + 255) / 256, (2 * B + 63) / 64);
-        hipLaunchKernelGGL(k_gather_fb_u8, grid, dim3(256), 64 * 257 * sizeof(float), st, (const unsigned char*)s_rows, (const unsigned char*)sp_rows, E, B, idx, x0,
+        hipLaunchKernelGGL(k_gather_fb_u8, grid, dim3(256), 0, st, (const unsigned char*)s_rows, (const unsigned char*)sp_rows, E, B, idx, x0,
                            do_sample, cap2, tree, seed, state);
         return;
     }
