@@ -116,6 +116,7 @@ static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out) {
         else if (L[i].kind == DQN_LAYER_DENSE && L[i].N < 16 && L[i].K >= 128) out[i].fwd_kc = 32;   // heads: 16+ short chains instead of one long one
         out[i].dx_kc = (L[i].kind != DQN_LAYER_CONV && L[i].N > 512) ? 256 : 0;
         out[i].dw_kc = 0;
+        if (L[i].kind == DQN_LAYER_DENSE && L[i].N < 16 && B >= 128) out[i].dw_kc = 64;   // head layers at large batches: 64-sample chains on 8x more threads instead of one B-long chain per output
         if (L[i].kind == DQN_LAYER_CONV) {   // positions per chunk so that (K/64 row tiles) x chunks >= ~512 workgroups
             const int st = (512 + (L[i].K + 63) / 64 - 1) / ((L[i].K + 63) / 64); int ppc = L[i].npos / st; if (ppc < 1) ppc = 1; out[i].dw_kc = ppc * B;
         }

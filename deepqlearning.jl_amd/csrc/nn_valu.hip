@@ -5,6 +5,7 @@
 // Threads are laid out with the batch column fastest, so activation loads are coalesced 256-B lines and the
 // weight is a wave-uniform (scalar) load.
 #include "common.h"
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------ split-K reduction epilogues
 // mode 0: forward      Y = act(sum_s part + bias[n])             (n = e / per_n)
@@ -124,6 +125,19 @@ __device__ __forceinline__ void valu_dw_body(const LayerDev& L, const float* __r
     if (L.kind != DQN_LAYER_CONV) {      // dense: one "position"; operands are two contiguous rows -> 16 loads in flight, chain order unchanged
         const float* dr = dpre + (size_t)n * B; const float* xr = k < L.K ? X + (size_t)k * ldx : nullptr;
         int j = j0;
+        if (j1 - j0 == 64) {                 // a 64-sample chunk (head layers at large batches): one round of 32 float4 loads
+            f32x4v dq[16], xq[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) { dq[u] = *reinterpret_cast<const f32x4v*>(dr + j0 + 4 * u); xq[u] = xr ? *reinterpret_cast<const f32x4v*>(xr + j0 + 4 * u) : (f32x4v){1.f, 1.f, 1.f, 1.f}; }
+            if (xr) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) { acc = fmaf(xq[u].x, dq[u].x, acc); acc = fmaf(xq[u].y, dq[u].y, acc); acc = fmaf(xq[u].z, dq[u].z, acc); acc = fmaf(xq[u].w, dq[u].w, acc); }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 16; u++) { acc = acc + dq[u].x; acc = acc + dq[u].y; acc = acc + dq[u].z; acc = acc + dq[u].w; }
+            }
+            j = j1;
+        }
         if (j1 - j0 == 32) {                 // B = 32: the whole sample axis in one round of loads
             float dv[32], xv[32];
 #pragma unroll

@@ -142,6 +142,7 @@ int ref_plan_default(const dqn_layer_desc* d, int n, const dqn_hparams* hp, dqn_
         out[i].dx_kc = 0;
         if (d[i].kind != DQN_LAYER_CONV && nout > 512) out[i].dx_kc = 256;
         out[i].dw_kc = 0;
+        if (d[i].kind == DQN_LAYER_DENSE && d[i].n_out < 16 && B >= 128) out[i].dw_kc = 64;
         if (posB) { int mrows = (K + 63) / 64; int st = (512 + mrows - 1) / mrows; int ppc = (h * w) / st; if (ppc < 1) ppc = 1; out[i].dw_kc = ppc * B; }
     }
     return 0;
