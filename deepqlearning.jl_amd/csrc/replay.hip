@@ -95,10 +95,14 @@ __global__ __launch_bounds__(256) void k_gather_fb(const void* __restrict__ s_ro
         }
     }
     __syncthreads();
-#pragma unroll 4
-    for (int p = 0; p < 16; p++) {
-        const int fl = p * 4 + w, f = f0 + fl, c = c0 + lane;
-        if (f < E && c < ld) x0[(size_t)f * ld + c] = tile[lane][fl];
+    // 16 lanes x float4 = one 256-B row segment of the arena (64 consecutive columns of one feature); a wave writes 4 feature rows per instruction
+    const int l16 = threadIdx.x & 15, r16 = threadIdx.x >> 4;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int fl = p * 16 + r16, f = f0 + fl, c = c0 + 4 * l16;
+        if (f >= E) continue;
+        if (c + 3 < ld) *reinterpret_cast<f32x4*>(x0 + (size_t)f * ld + c) = (f32x4){tile[4 * l16][fl], tile[4 * l16 + 1][fl], tile[4 * l16 + 2][fl], tile[4 * l16 + 3][fl]};
+        else for (int u = 0; u < 4; u++) if (c + u < ld) x0[(size_t)f * ld + c + u] = tile[4 * l16 + u][fl];
     }
 }
 // u8 rows (config 5: 1e6 transitions, 28 224 B each): 256 features x 64 columns per workgroup so that every sampled row is
