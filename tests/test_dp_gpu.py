@@ -88,3 +88,23 @@ def test_rccl_allgather_world1_matches_plain(pkg, monkeypatch):
     np.testing.assert_array_equal(a.get_params(0), b.get_params(0))
     np.testing.assert_array_equal(a.get_params(0), cpu.get_params(0))
     np.testing.assert_array_equal(a.get_grads(), b.get_grads())
+
+
+def test_simulated_ranks_with_two_tiles_per_rank(pkg, monkeypatch):
+    """B = 64 per rank: each rank block of the gathered sample axis spans two 32-sample K tiles (the dW kernel's tiles-per-rank stride path);
+    the wide layer here is the network's FIRST layer, so its X operand is packed out of the observation arena (leading dimension 2B)."""
+    net = O.Network((768,), *O.create_dueling_network([O.Dense(768, 1024, R), O.Dense(1024, 5, I)]))
+    k = 2
+    monkeypatch.setenv("DQN_SIM_WORLD", str(k))
+    g, t, rng = setup(pkg, net, 64, 64 * k)
+    monkeypatch.delenv("DQN_SIM_WORLD")
+    idx = rng.choice(200, 64, replace=False).astype(np.int64)
+    lg, gg, tdg = g.train_step(idx)
+    lt, gt, tdt = t.train_step(np.tile(idx, k))
+    np.testing.assert_array_equal(tdg, tdt[:64])
+    Gg, Gt = g.get_grads() / np.float32(k), t.get_grads()
+    wide = [(x, y) for x, y in zip(net.unflatten(Gg), net.unflatten(Gt)) if x.ndim == 2 and 768 in x.shape]
+    assert len(wide) == 2
+    for x, y in wide:
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_allclose(Gg, Gt, rtol=1e-4, atol=1e-7)
