@@ -68,18 +68,22 @@ def build_workload(pkg, args, rank, device):
     return eng, layers, hp, net, params, env
 
 
-ADAM_EXTRA_BYTES = [0.0]
+ADAM_SLAB_BYTES = [0.0]     # the engine's OWN overhead inside k_adam (conv dW split-K slabs it reduces): reported beside, never inside, the 8(d) floor
 
 
 def op_cost(name, eng_layers, B, ncon, E, P, obs_bytes=4):
-    """algorithmic (flops, bytes) of one profiled launch by its program name.
+    """algorithmic (flops, bytes) of one profiled launch by its program name; names joined by '+' are one launch doing both.
     fwd_<l>      forward of layer l AND its sibling (val/adv) for the online net on [s;sp] and the target net on sp
-    dw_<l>/dw2_<l>  dW+db of layer l (dw2: both sibling layers);  dx_<l>/dx_join_<l>  dX of layer l (join: both streams)"""
+    dw_<l>/dw2_<l>  dW+db of layer l (dw2: both sibling layers);  dx_<l>/dx_join_<l>  dX of layer l (join: both streams)
+    adam         SURVEY 8(d)'s parameter-traffic floor: 28 B per parameter (p, m, v, g read; p, m, v written) -- 92 199 436 B at config 2"""
+    if "+" in name:
+        parts = [op_cost(n, eng_layers, B, ncon, E, P, obs_bytes) for n in name.split("+")]
+        return sum(p[0] for p in parts), sum(p[1] for p in parts)
     parts = name.split("_")
     if name in ("gather", "sample_gather"):
         return 0.0, 2.0 * B * E * (obs_bytes + 4)   # rows read (u8 or f32) + fp32 batch arena written
-    if name == "adam":
-        return 0.0, P * 28.0 + ADAM_EXTRA_BYTES[0]   # p,m,v,g read + p,m,v written (+ the conv dW split-K slabs it reduces on a single GPU)
+    if name.startswith("adam"):
+        return 0.0, P * 28.0
     digits = "".join(ch for ch in parts[-1] if ch.isdigit())
     if not digits or parts[0] not in ("fwd", "dw", "dw2", "dx"):
         return 0.0, 0.0
@@ -90,8 +94,8 @@ def op_cost(name, eng_layers, B, ncon, E, P, obs_bytes=4):
     if parts[0] == "fwd":
         if len(parts) == 3 and parts[1] in ("on", "tg"):
             return f1 * (ncon if parts[1] == "on" else B), 0.0
-        if len(parts) == 3:                       # fwd_valu_<l>: the whole level (both heads, both nets)
-            return 0.0, 0.0                       # heads are accounted by their own geometry below (negligible)
+        if len(parts) == 3:                       # fwd_valu_<l> / fwd_reduce_<l>: head forwards / split-K folds (negligible flops)
+            return 0.0, 0.0
         return f1 * (ncon + B) * nsib, 0.0
     if parts[0] == "dw2" or (parts[0] == "dx" and len(parts) == 3 and parts[1] == "join"):
         return f1 * B * 2, 0.0
@@ -105,6 +109,19 @@ def step_flops_analytic(eng_layers, B, ncon):
         f1 = 2.0 * K * N * npos
         tot += f1 * (ncon + B) + f1 * B + (f1 * B if i > 0 else 0.0)
     return tot
+
+
+def workload_name(args, world):
+    """which BASELINE.json config the flags describe (configs[] is 0-based: [1] = B=32 on one GPU, [2] = the same sharded over ranks,
+    [4] = the B=512 / 1e6-transition u8 stress run); anything else is named by its parameters"""
+    base = "TestMDP((84,84),4,6) image MDP, Nature-DQN 3-conv+2-dense dueling, double-Q, prioritized replay"
+    if args.batch == 512 and args.u8 and args.replay >= 1_000_000:
+        return f"configs[4]: large-batch stress, batch_size=512, replay {args.replay} u8 transitions; {base}"
+    if args.batch == 32 and not args.u8:
+        if world > 1:
+            return f"configs[2]: {args.envs_per_rank * world} envs sharded {world}-way, per-rank replay, one RCCL exchange per step; {base}"
+        return f"configs[1]: {base}"
+    return f"non-BASELINE variant (batch={args.batch}, replay={args.replay}, {'u8' if args.u8 else 'f32'}): {base}"
 
 
 def main():
@@ -224,30 +241,53 @@ def main():
                 h, w = (h - d.kh) // d.sh + 1, (w - d.kw) // d.sw + 1
                 npos = h * w
             g2.append((K, N, npos))
-        # single-GPU path: k_adam also reduces the conv layers' dW split-K slabs (S slabs of (K+1) x N floats, read once, grad written)
+        # single-GPU path: k_adam also reduces the conv layers' dW split-K slabs (S slabs of (K+1) x N floats read once, gradient written) --
+        # the engine's own overhead on top of the 8(d) floor
         if world == 1:
             for (K, N, npos), (_, _, dw_kc) in zip(g2, eng.plan()):
                 S = -(-npos * B // dw_kc) if dw_kc and dw_kc < npos * B else 1
                 if S > 1:
-                    ADAM_EXTRA_BYTES[0] += (S + 1) * (K + 1) * N * 4.0
+                    ADAM_SLAB_BYTES[0] += (S + 1) * (K + 1) * N * 4.0
         kern = {k: v[0] / v[1] for k, v in prof_acc.items()}
-        dom = max(kern, key=kern.get)
-        fl, by = op_cost(dom, g2, B, ncon, E, P, 1 if args.u8 else 4)
-        if fl > 0:
-            roof = dict(kernel=dom, bound="mfma", achieved=fl / (kern[dom] * 1e-3) / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", traffic=None)
-        else:
-            roof = dict(kernel=dom, bound="hbm", achieved=by / (kern[dom] * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", traffic=None)
-        roof["frac"] = roof["achieved"] / roof["peak"]
-        roof.update(pmc_traffic(dom))
-        roof["avg_launch_ms"] = kern[dom]
+        obs_b = 1 if args.u8 else 4
         step_flops = step_flops_analytic(g2, B, ncon)
-        roof["step_flops"] = step_flops
-        roof["step_mfma_frac"] = (value / world) * step_flops / (PEAK_F32_MFMA_TFLOPS * 1e12)
-        roof["eager_kernel_ms"] = {k: round(v, 5) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])[:12]}
-        gname = "sample_gather" if "sample_gather" in kern else "gather"
-        gbytes = op_cost(gname, g2, B, ncon, E, P, 1 if args.u8 else 4)[1]
-        roof["gather"] = {"avg_launch_ms": kern[gname], "algorithmic_bytes": gbytes, "achieved_GBs": gbytes / (kern[gname] * 1e-3) / 1e9,
-                          "frac_of_hbm_peak": gbytes / (kern[gname] * 1e-3) / 1e9 / PEAK_HBM_GBS}
+        # ---- headline: the train step is a dense contraction => bound by the fp32 MFMA peak;
+        #      achieved = steps/s x algorithmic FLOP per step (adv stream once, no conv1 dX), on the TIMED (graph-replay) rate
+        ach = (value / world) * step_flops / 1e12
+        roof = dict(bound="mfma", achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=None,
+                    definition="steps/s x step_flops / fp32-MFMA peak (SURVEY.md 8d); step_flops = fwd 2KN*npos x (2B online + B target) columns + dW x B + dX x B (no conv1 dX)",
+                    step_flops=step_flops, step_gflop=step_flops / 1e9)
+        # ---- per-launch table: algorithmic MFLOP or MB, HIP-event duration (eager launches, engine stream), fraction of the bound that applies
+        table = []
+        for name, ms in sorted(kern.items(), key=lambda kv: -kv[1]):
+            fl, by = op_cost(name, g2, B, ncon, E, P, obs_b)
+            row = {"launch": name, "avg_us": round(ms * 1e3, 2)}
+            if fl > 0:
+                row.update(bound="mfma", mflop=round(fl / 1e6, 1), tflops=round(fl / (ms * 1e-3) / 1e12, 2), frac=round(fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
+            elif by > 0:
+                row.update(bound="hbm", mbytes=round(by / 1e6, 2), gbs=round(by / (ms * 1e-3) / 1e9, 1), frac=round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+                if name.startswith("adam") and ADAM_SLAB_BYTES[0] > 0:
+                    row["overhead_mbytes"] = round(ADAM_SLAB_BYTES[0] / 1e6, 2)      # conv dW slabs: engine overhead, not in `mbytes`
+                row.update(pmc_traffic(name))
+            else:
+                row.update(bound="latency")
+            table.append(row)
+        roof["launches"] = table
+        roof["eager_step_us"] = round(sum(kern.values()) * 1e3, 1)
+        gemm = [r for r in table if r.get("bound") == "mfma"]
+        if gemm:
+            roof["gemm_launches_frac"] = round(sum(r["mflop"] for r in gemm) * 1e6 / (sum(r["avg_us"] for r in gemm) * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+            dom = max(gemm, key=lambda r: r["avg_us"])
+            roof["dominant_kernel"] = dict(dom)          # the longest GEMM launch, per-launch roofline: algorithmic FLOP / HIP-event duration
+        gname = "sample_gather" if "sample_gather" in kern else ("gather" if "gather" in kern else None)
+        if gname:
+            gbytes = op_cost(gname, g2, B, ncon, E, P, obs_b)[1]
+            roof["gather"] = {"avg_launch_ms": kern[gname], "algorithmic_bytes": gbytes, "achieved_GBs": gbytes / (kern[gname] * 1e-3) / 1e9,
+                              "frac_of_hbm_peak": gbytes / (kern[gname] * 1e-3) / 1e9 / PEAK_HBM_GBS}
+            roof["gather"].update(pmc_traffic(gname))
+        adam_rows = [r for r in table if r["launch"].startswith("adam") and "traffic" in r]
+        if adam_rows:
+            roof["traffic"] = adam_rows[0]["traffic"]; roof["traffic_note"] = "HBM bytes per launch of the Adam kernel (the step's HBM-bound launch); " + adam_rows[0].get("traffic_source", "")
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -256,7 +296,7 @@ def main():
             "metric": f"train steps/sec (batch={args.batch}, 84x84x4 obs)", "value": value, "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: TestMDP((84,84),4,6) image MDP, Nature-DQN 3-conv+2-dense dueling, double-Q, prioritized replay",
+            "config": {"workload": workload_name(args, world),
                        "batch_per_rank": args.batch, "global_batch": args.batch * world, "replay_per_rank": args.replay,
                        "replay_dtype": "u8" if args.u8 else "f32", "envs_per_rank": args.envs_per_rank, "n_params": int(P),
                        "parallelism": f"dp{world} (per-rank envs + replay; one RCCL all-gather per step: wide-dense operands + small gradients)" if world > 1 else "single GPU",
@@ -307,17 +347,24 @@ def cpu_baseline(pkg, layers, hp, params, env, args):
         if best is None or dt1 < best:
             best, cores = dt1, th
     tw.set_threads(cores)
-    one = best
-    k = int(max(3, min(200, args.cpu_seconds / max(one, 1e-3))))
-    t0 = time.perf_counter()
-    for _ in range(k):
+    # SURVEY 8(d) protocol: 10 warm-up steps, then >= 30 individually timed steps (bounded by --cpu-seconds): median, p10, p90
+    for _ in range(10):
         tw.train_step()
-    dt = time.perf_counter() - t0
+    k = int(max(30, min(400, args.cpu_seconds / max(best, 1e-3))))
+    dts = []
+    for _ in range(k):
+        t0 = time.perf_counter()
+        tw.train_step()
+        dts.append(time.perf_counter() - t0)
     tw.close()
-    return {"value": k / dt, "unit": "steps/s", "cores": cores, "kind": "port", "nproc": ncpu, "single_thread_value": single,
+    dts = np.sort(np.array(dts))
+    med, p10, p90 = float(np.median(dts)), float(dts[int(0.1 * (k - 1))]), float(dts[int(0.9 * (k - 1))])
+    return {"value": 1.0 / med, "unit": "steps/s", "cores": cores, "kind": "port", "nproc": ncpu, "single_thread_value": single,
+            "median_ms": med * 1e3, "p10_ms": p10 * 1e3, "p90_ms": p90 * 1e3, "timed_steps": k,
             "torch_cpu": torch_cpu_line(hp, min(5.0, args.cpu_seconds)),
-            "sample": f"{k} train steps of the same config (B={hp.batch_size}, Nature-DQN dueling) on a 512-transition replay, "
-                      f"oracle/dqn_ref.c with OpenMP over {cores} threads (best of 1/8/16/32/64 on a {ncpu}-CPU host); the Julia/Flux reference cannot run in this image"}
+            "sample": f"median of {k} individually timed train steps after 10 warm-up steps, same config (B={hp.batch_size}, Nature-DQN dueling, same step) on a "
+                      f"512-transition replay, oracle/dqn_ref.c with OpenMP over {cores} threads (fastest of 1/8/16/32/64 on a {ncpu}-CPU host); "
+                      "a PORT of the reference's algorithm: the Julia/Flux reference itself cannot run in this image"}
 
 
 

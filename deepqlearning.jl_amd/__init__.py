@@ -42,7 +42,7 @@ class Engine(_abi.Handle):
     """One engine per GPU: replay + sum-tree + networks + Adam state + a HIP stream."""
 
     def __init__(self, layers, hp, plan=None, device=0):
-        super().__init__(fns(), layers, hp, plan=plan, device=device, is_twin=False)
+        super().__init__(fns(), layers, hp, plan=plan, device=device)
 
 
 def default_plan(layers, hp):

@@ -1,8 +1,9 @@
 """
 ctypes view of include/dqn_mi355x.h: struct layouts, function prototypes and a
-thin handle class.  Standalone (no package-relative imports) so that the test
-infrastructure can bind the CPU twin (oracle/_ref/libdqn_ref.so, prefix "ref_")
-with the very same struct layouts as the product library (prefix "dqn_").
+thin handle class over libdqn_mi355x.so.  Standalone (no package-relative
+imports); `bind` and `Handle` are generic in the symbol prefix and in how a
+handle is created, so other libraries with the same struct layouts can reuse
+them (the test infrastructure under oracle/ does; nothing about it lives here).
 """
 from __future__ import annotations
 
@@ -123,6 +124,7 @@ PROTOS = {
     "greedy_action": [_vp, _f32p, C.c_int, _i32p],
     "comm_unique_id": [_vp],
     "comm_init": [_vp, _vp, C.c_int, C.c_int],
+    "sim_ranks_step": [_vp, _i64p, _f32p, _f32p, _f32p],
     "stream_sync": [_vp],
     "stream_handle": [_vp, _P(_vp)],
     "profile_step": [_vp, C.c_int, _P(C.c_char_p), _f32p, _P(C.c_int)],
@@ -145,28 +147,20 @@ PROTOS = {
     "get_counters": [_vp, _P(Counters)],
     "set_counters": [_vp, _P(Counters)],
 }
-# twin spellings that differ from the product's
-_TWIN_ALIASES = {"engine_create": "create", "engine_destroy": "destroy", "engine_get_plan": "get_plan"}
-
 
 class DQNError(RuntimeError):
     """Mirrors the reference's thrown Strings / AssertionErrors."""
 
 
-def bind(lib: C.CDLL, prefix: str):
-    """Attach prototypes; returns {name: callable} for every symbol the library exports."""
+def bind(lib: C.CDLL, prefix: str, aliases=None, argtypes=None):
+    """Attach prototypes; returns {name: callable} for every symbol the library exports.
+    aliases: {name: spelling} for symbols spelled differently; argtypes: {name: [ctypes]} overriding PROTOS."""
     fns = {}
     for name, args in PROTOS.items():
-        sym = prefix + name
-        f = getattr(lib, sym, None)
-        if f is None and prefix == "ref_":
-            f = getattr(lib, prefix + _TWIN_ALIASES.get(name, name), None)
+        f = getattr(lib, prefix + (aliases or {}).get(name, name), None)
         if f is None:
             continue
-        if name == "engine_create" and prefix == "ref_":
-            f.argtypes = [_P(LayerDesc), C.c_int, _P(HParams), _P(LayerPlan), _P(_vp)]
-        else:
-            f.argtypes = args
+        f.argtypes = (argtypes or {}).get(name, args)
         f.restype = C.c_int
         fns[name] = f
     le = getattr(lib, prefix + "last_error")
@@ -184,10 +178,10 @@ def _as(a, dtype):
 
 
 class Handle:
-    """NumPy-friendly wrapper over one engine handle (product or twin)."""
+    """NumPy-friendly wrapper over one engine handle."""
 
-    def __init__(self, fns, layers, hp: HParams, plan=None, device=0, is_twin=False):
-        self.f, self.hp, self.is_twin = fns, hp, is_twin
+    def __init__(self, fns, layers, hp: HParams, plan=None, device=0):
+        self.f, self.hp = fns, hp
         self.layers = (LayerDesc * len(layers))(*layers)
         self.n_layers = len(layers)
         self.B, self.nA = hp.batch_size, hp.n_actions
@@ -198,15 +192,16 @@ class Handle:
         if plan is not None:
             parr = (LayerPlan * len(layers))(*[LayerPlan(*p) for p in plan])
         h = C.c_void_p()
-        if is_twin:
-            rc = fns["engine_create"](self.layers, self.n_layers, C.byref(hp), parr, C.byref(h))
-        else:
-            rc = fns["engine_create"](self.layers, self.n_layers, C.byref(hp), parr, device, C.byref(h))
+        rc = self._create(parr, device, h)
         self._handle = h
         self._check(rc)
         n = C.c_size_t()
         self._check(fns["n_params"](h, C.byref(n)))
         self.P = n.value
+
+    def _create(self, parr, device, h):
+        """dqn_engine_create; subclasses binding another library override this"""
+        return self.f["engine_create"](self.layers, self.n_layers, C.byref(self.hp), parr, device, C.byref(h))
 
     def _check(self, rc):
         if rc != 0:
@@ -263,10 +258,17 @@ class Handle:
     def sync_target(self):
         self._check(self.f["sync_target"](self._h))
 
+    def _obs_rows(self, x, what):
+        """observation rows in the replay's storage dtype.  A u8 replay stores BYTES that training reads back as byte / 255f0: a float
+        array would be silently truncated to 0/1 by a cast, so only uint8 input is accepted there."""
+        if self.obs_np is np.uint8 and np.asarray(x).dtype != np.uint8:
+            raise DQNError(f"{what}: this replay stores uint8 observations (obs_dtype = OBS_U8); got {np.asarray(x).dtype} -- pass the raw bytes")
+        return _as(x, self.obs_np).reshape(-1, self.obs_elems)
+
     # ---- replay
     def replay_add(self, s, a, r, sp, done, td_err=None):
-        s = _as(s, self.obs_np).reshape(-1, self.obs_elems)
-        sp = _as(sp, self.obs_np).reshape(-1, self.obs_elems)
+        s = self._obs_rows(s, "replay_add")
+        sp = self._obs_rows(sp, "replay_add")
         n = s.shape[0]
         a, r, done = _as(np.atleast_1d(a), np.int32), _as(np.atleast_1d(r), np.float32), _as(np.atleast_1d(done), np.uint8)
         td = None if td_err is None else _as(np.atleast_1d(td_err), np.float32)
@@ -348,8 +350,8 @@ class Handle:
 
     # ---- DRQN
     def episode_add(self, s, a, r, sp, done):
-        s = _as(s, self.obs_np).reshape(-1, self.obs_elems)
-        sp = _as(sp, self.obs_np).reshape(-1, self.obs_elems)
+        s = self._obs_rows(s, "episode_add")
+        sp = self._obs_rows(sp, "episode_add")
         n = s.shape[0]
         a, r, done = _as(np.atleast_1d(a), np.int32), _as(np.atleast_1d(r), np.float32), _as(np.atleast_1d(done), np.uint8)
         self._check(self.f["episode_add"](self._h, s.ctypes.data_as(_vp), _ptr(a, _i32p), _ptr(r, _f32p), sp.ctypes.data_as(_vp), _ptr(done, _u8p), n))
@@ -430,7 +432,7 @@ class Handle:
         return s, sp, a, r, d, pr
 
     def replay_import(self, s, sp, a, r, done, priorities):
-        s = _as(s, self.obs_np).reshape(-1, self.obs_elems); sp = _as(sp, self.obs_np).reshape(-1, self.obs_elems)
+        s = self._obs_rows(s, "replay_import"); sp = self._obs_rows(sp, "replay_import")
         a, r, done, priorities = _as(a, np.int32), _as(r, np.float32), _as(done, np.uint8), _as(priorities, np.float32)
         self._check(self.f["replay_import"](self._h, s.shape[0], s.ctypes.data_as(_vp), sp.ctypes.data_as(_vp), _ptr(a, _i32p), _ptr(r, _f32p), _ptr(done, _u8p), _ptr(priorities, _f32p)))
 
@@ -473,6 +475,14 @@ class Handle:
         n = C.c_int()
         self._check(self.f["profile_step"](self._h, max_entries, names, _ptr(ms, _f32p), C.byref(n)))
         return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+    def sim_ranks_step(self, idx):
+        """test hook (engine created under DQN_SIM_WORLD=k): one data-parallel step with k distinct batches idx[k][B] -> (loss[k], grad_norm, td[k][B])."""
+        idx = _as(idx, np.int64)
+        k = idx.size // self.B
+        loss, td, gn = np.empty(k, np.float32), np.empty((k, self.B), np.float32), C.c_float()
+        self._check(self.f["sim_ranks_step"](self._h, _ptr(idx, _i64p), _ptr(loss, _f32p), C.byref(gn), _ptr(td, _f32p)))
+        return loss, gn.value, td
 
     def comm_init(self, id128: bytes, rank: int, world: int):
         buf = C.create_string_buffer(id128, 128)

@@ -131,6 +131,7 @@ extern "C" int dqn_plan_default(const dqn_layer_desc* layers, int n_layers, cons
 
 extern "C" int dqn_engine_destroy(dqn_engine_t* e);
 
+static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers, const dqn_hparams* hp, const dqn_layer_plan* plan, int device);
 extern "C" int dqn_engine_create(const dqn_layer_desc* layers, int n_layers, const dqn_hparams* hp, const dqn_layer_plan* plan, int device,
                                  dqn_engine_t** out) {
     int ndev = 0;
@@ -140,17 +141,33 @@ extern "C" int dqn_engine_create(const dqn_layer_desc* layers, int n_layers, con
     if (hp->batch_size < 1 || hp->batch_size > 1024) return fail("batch_size %d unsupported (1..1024)", hp->batch_size);
     if (hp->buffer_size < hp->batch_size) return fail("AssertionError: r.max_size >= r.batch_size");   // ...replay.jl:84
     dqn_engine* e = new dqn_engine();
+    if (engine_init(e, layers, n_layers, hp, plan, device)) {   // every failure path releases what was allocated so far (the message survives: destroy never calls fail)
+        dqn_engine_destroy(e); return -1;
+    }
+    *out = e; return 0;
+}
+// dynamic LDS of the single-workgroup TD kernel (nn_valu.hip, launch_td) for this shape
+static size_t td_lds_bytes(int B, int nA, int ncon) { return (size_t)B * sizeof(float) + (size_t)(1 + nA) * (ncon + B) * sizeof(float); }
+static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers, const dqn_hparams* hp, const dqn_layer_plan* plan, int device) {
     e->device = device; e->hp = *hp; e->B = hp->batch_size; e->nA = hp->n_actions; e->E = hp->obs_c * hp->obs_h * hp->obs_w;
-    if (build_layers(layers, n_layers, hp, e->L, &e->last_base, &e->last_val, &e->last_adv, &e->P, &e->Pint)) { delete e; return -1; }
+    if (build_layers(layers, n_layers, hp, e->L, &e->last_base, &e->last_val, &e->last_adv, &e->P, &e->Pint)) return -1;
     e->nl = n_layers;
     if (const char* sw = getenv("DQN_SIM_WORLD")) { const int k = atoi(sw); if (k >= 1 && !hp->recurrence) { e->sim_world = k; e->world = k; } }   // tests: one process plays k identical ranks
     dqn_layer_plan defp[DQN_MAX_LAYERS];
     if (!plan) { default_plan(e->L, e->nl, e->B, defp); plan = defp; }
     for (int i = 0; i < e->nl; i++) {
         e->L[i].fwd_kc = plan[i].fwd_kc; e->L[i].dx_kc = plan[i].dx_kc; e->L[i].dw_kc = plan[i].dw_kc;
-        if (e->L[i].kind == DQN_LAYER_CONV && e->L[i].dw_kc > 0 && e->L[i].dw_kc % e->B) { delete e; return fail("plan: conv dw_kc must be a multiple of batch_size"); }
+        if (e->L[i].kind == DQN_LAYER_CONV && e->L[i].dw_kc > 0 && e->L[i].dw_kc % e->B) return fail("plan: conv dw_kc must be a multiple of batch_size");
     }
     HIPCHK(hipSetDevice(device));
+    if (!hp->recurrence) {
+        // the TD kernel keeps every head output of the step in LDS: (B + (1 + nA) * (ncon + B)) floats.  Shapes that do not fit the
+        // workgroup limit of this device are refused HERE with a message instead of failing at launch time (a failed launch would
+        // leave the step running backward and Adam on stale gradients).
+        hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device));
+        const size_t need = td_lds_bytes(e->B, e->nA, hp->double_q ? 2 * e->B : e->B), have = prop.sharedMemPerBlock;
+        if (need > have) return fail("batch_size %d x n_actions %d needs %zu bytes of LDS in the TD kernel, the device offers %zu per workgroup: lower batch_size or n_actions", e->B, e->nA, need, have);
+    }
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
@@ -200,7 +217,7 @@ extern "C" int dqn_engine_create(const dqn_layer_desc* layers, int n_layers, con
     DM(e->ytarget, B); DM(e->best, B);
     DM(e->gb_rows, (size_t)B * e->E); DM(e->gb_r, B); DM(e->gb_done, B); DM(e->gb_w, B); DM(e->gb_a, B); DM(e->gb_idx, B);
     HIPCHK(hipStreamSynchronize(e->stream));
-    *out = e; return 0;
+    return 0;
 }
 
 void drop_graphs(dqn_engine* e) {
@@ -383,9 +400,10 @@ extern "C" int dqn_set_counters(dqn_engine_t* e, const dqn_counters* in) { if (!
     if (in->size != e->size) return fail("counters.size (%lld) differs from the replay's (%lld): import the replay first", (long long)in->size, (long long)e->size);
     if (in->widx < 0 || in->widx >= e->cap) return fail("counters.widx out of range");
     StepState st; HIPCHK(hipMemcpy(&st, e->state, sizeof st, hipMemcpyDeviceToHost));
-    // the Adam beta powers are double-buffered by step parity: keep the live pair where the new parity expects it
-    const int old_slot = (int)(st.step & 1ull), new_slot = (int)(in->train_steps & 1ull);
-    if (old_slot != new_slot) { const double b0 = st.bp[old_slot][0], b1 = st.bp[old_slot][1]; st.bp[new_slot][0] = b0; st.bp[new_slot][1] = b1; }
+    // the Adam beta powers are double-buffered by step parity: after a step with counter S the LIVE pair (the one the next step reads) sits in
+    // slot (S + 1) & 1 -- the slot dqn_get_adam_state reports.  Whatever the new parity, make both slots hold the live pair.
+    const int live = (int)((st.step + 1ull) & 1ull);
+    st.bp[live ^ 1][0] = st.bp[live][0]; st.bp[live ^ 1][1] = st.bp[live][1];
     st.sample_ctr = in->sample_ctr; st.step = in->train_steps;
     HIPCHK(hipMemcpy(e->state, &st, sizeof st, hipMemcpyHostToDevice));
     e->widx = in->widx; return 0;
@@ -469,9 +487,12 @@ void enqueue_step(dqn_engine* e, bool sample, int phase) {
 }
 int capture(dqn_engine* e, bool sample, int phase, hipGraphExec_t* out) {
     hipGraph_t g;
+    (void)hipGetLastError();
     HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
     enqueue_step(e, sample, phase);
+    const hipError_t lerr = hipGetLastError();          // a launch refused during capture never becomes a graph node
     HIPCHK(hipStreamEndCapture(e->stream, &g));
+    if (lerr != hipSuccess) { hipGraphDestroy(g); return fail("HIP error %s while capturing the train step", hipGetErrorString(lerr)); }
     HIPCHK(hipGraphInstantiate(out, g, nullptr, nullptr, 0));
     HIPCHK(hipGraphDestroy(g)); return 0;
 }
@@ -500,13 +521,13 @@ int run_step(dqn_engine* e, bool sample) {
             HIPCHK(hipGraphLaunch(e->g_pre[gi], e->stream));
             if (exchange_grads(e)) return -1;
             HIPCHK(hipGraphLaunch(e->g_post, e->stream));
-        } else { enqueue_step(e, sample, PH_PRE); if (exchange_grads(e)) return -1; enqueue_step(e, sample, PH_POST); }
+        } else { enqueue_step(e, sample, PH_PRE); HIPCHK(hipGetLastError()); if (exchange_grads(e)) return -1; enqueue_step(e, sample, PH_POST); HIPCHK(hipGetLastError()); }
         return 0;
     }
     if (e->hp.use_graph && !e->profiling) {
         if (!e->g_full[gi] && capture(e, sample, PH_ALL, &e->g_full[gi])) return -1;
         HIPCHK(hipGraphLaunch(e->g_full[gi], e->stream));
-    } else enqueue_step(e, sample, PH_ALL);
+    } else { enqueue_step(e, sample, PH_ALL); HIPCHK(hipGetLastError()); }      // eager launches: a refused launch (bad LDS size, bad grid) is an error, not a silent no-op
     return 0;
 }
 int fetch_scalars(dqn_engine* e, float* loss, float* gn) {
@@ -527,6 +548,45 @@ extern "C" int dqn_train_step(dqn_engine_t* e, const int64_t* idx, float* loss, 
     if (td_out) HIPCHK(hipMemcpyAsync(td_out, e->td, (size_t)e->B * 4, hipMemcpyDeviceToHost, e->stream));
     if (loss || grad_norm || td_out) return fetch_scalars(e, loss, grad_norm);
     return 0;
+}
+// TEST HOOK (DQN_SIM_WORLD = k): one data-parallel step in which this process plays k ranks with k DISTINCT batches.  Each simulated rank runs
+// the first half of the step (gather .. backward .. dp_pack) on its own index list and its packed block lands in ITS slot of the gathered
+// buffer -- exactly what ncclAllGather delivers -- then the second half (wide dW over the k*B gathered samples, sum over ranks, Adam) runs once.
+// Equivalent single-device step: the concatenated batch of k*B samples, which is what tests/test_dp_gpu.py compares with.
+// Priority updates of ranks 0..k-2 are applied after the step (every rank's IS weights see the pre-step tree, as on k real ranks with one
+// shared replay).  idx: [k][B]; loss: [k] per-rank losses; td_out: [k][B].
+extern "C" int dqn_sim_ranks_step(dqn_engine_t* e, const int64_t* idx, float* loss, float* grad_norm, float* td_out) { if (!e) return fail("null engine handle");
+    HIPCHK(hipSetDevice(e->device));
+    if (!e->sim_world) return fail("dqn_sim_ranks_step needs an engine created under DQN_SIM_WORLD=k");
+    if (e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
+    const int k = e->sim_world, B = e->B;
+    if (check_idx(e, idx, k * B)) return -1;
+    if (build_program(e)) return -1;
+    if (!e->dp_gather) return fail("DQN_SIM_WORLD needs the gather exchange (no wide dense layer in this network, or DQN_DP_ALLREDUCE is set)");
+    long long* s_idx = nullptr; float* s_td = nullptr; DM(s_idx, (size_t)k * B); DM(s_td, (size_t)k * B);
+    int rc = 0;
+    for (int r = 0; r < k && !rc; r++) {
+        HIPCHK(hipMemcpyAsync(e->idx, idx + (size_t)r * B, (size_t)B * 8, hipMemcpyHostToDevice, e->stream));
+        if (e->hp.use_graph) { if (!e->g_pre[1] && capture(e, false, PH_PRE, &e->g_pre[1])) { rc = -1; break; } HIPCHK(hipGraphLaunch(e->g_pre[1], e->stream)); }
+        else enqueue_step(e, false, PH_PRE);
+        HIPCHK(hipMemcpyAsync(e->dp_recv + (size_t)r * e->dp_count, e->dp_send, e->dp_count * 4, hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(s_idx + (size_t)r * B, e->idx, (size_t)B * 8, hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(s_td + (size_t)r * B, e->td, (size_t)B * 4, hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        StepState st; HIPCHK(hipMemcpy(&st, e->state, sizeof st, hipMemcpyDeviceToHost));
+        if (loss) loss[r] = st.loss;
+        if (r + 1 < k) { st.step -= 1; HIPCHK(hipMemcpy(e->state, &st, sizeof st, hipMemcpyHostToDevice)); }   // k_td counts train steps: the k halves are ONE step
+    }
+    if (!rc) {
+        if (e->hp.use_graph) { if (!e->g_post && capture(e, false, PH_POST, &e->g_post)) rc = -1; else HIPCHK(hipGraphLaunch(e->g_post, e->stream)); }
+        else enqueue_step(e, false, PH_POST);
+    }
+    if (!rc && e->hp.prioritized_replay)
+        for (int r = 0; r + 1 < k; r++) launch_update_priorities(e->stream, B, e->cap2, s_idx + (size_t)r * B, s_td + (size_t)r * B, e->hp.prio_eps, e->hp.prio_alpha, e->tree, e->state, 0, 1.0, 1.0, nullptr, 0);
+    if (!rc && td_out) HIPCHK(hipMemcpyAsync(td_out, s_td, (size_t)k * B * 4, hipMemcpyDeviceToHost, e->stream));
+    if (!rc) rc = fetch_scalars(e, nullptr, grad_norm);
+    hipStreamSynchronize(e->stream); hipFree(s_idx); hipFree(s_td);
+    return rc;
 }
 extern "C" int dqn_train_steps(dqn_engine_t* e, int n, float* loss, float* grad_norm) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device));

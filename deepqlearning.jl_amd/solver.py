@@ -23,7 +23,7 @@ from typing import Any, Callable, Optional
 
 import numpy as np
 
-from . import _abi, nn
+from . import _abi, bson, nn
 from ._abi import DQNError
 
 
@@ -177,10 +177,11 @@ class AbstractNNPolicy:
 class NNPolicy(AbstractNNPolicy):
     """src/policy.jl:17-76.  The Q-network lives in the engine; getnetwork returns the flat Flux.params vector."""
 
-    def __init__(self, env, engine, action_map, n_input_dims):
+    def __init__(self, env, engine, action_map, n_input_dims, qnetwork=None):
         self.problem, self.engine = env, engine
         self.action_map = list(action_map)
         self.n_input_dims = n_input_dims
+        self.qnetwork = qnetwork           # the nn.Chain / nn.DuelingNetwork description (array shapes for qnetwork.bson)
 
     def getnetwork(self):
         return self.engine.get_params(_abi.NET_ONLINE)
@@ -192,7 +193,12 @@ class NNPolicy(AbstractNNPolicy):
         return self.action_map
 
     def _check(self, o):
-        o = np.asarray(o, np.float32)
+        o = np.asarray(o)
+        if self.engine.obs_np is np.uint8 and o.dtype == np.uint8:
+            # u8 replay storage: training consumes byte / 255f0 (test/test_env.jl:59), so the policy must see the same scale
+            o = o.astype(np.float32) / np.float32(255.0)
+        else:
+            o = np.asarray(o, np.float32)
         if o.ndim == self.n_input_dims:
             return o[None], True
         if o.ndim == self.n_input_dims + 1:
@@ -220,6 +226,7 @@ def basic_evaluation(policy, env, n_eval, max_episode_length, verbose=False):
     tot_r, tot_steps, done_eps = 0.0, 0.0, 0
     while done_eps < n_eval:
         env.reset()
+        policy.resetstate()                    # resetstate!(policy) before every evaluation episode (src/evaluation_policy.jl:26)
         obs = env.observe()
         alive = np.ones(env.n, bool)
         r_ep = np.zeros(env.n)
@@ -312,7 +319,7 @@ def solve(solver: DeepQLearningSolver, env, engine_cls=None, init_seed=1):
     params = nn.glorot_params(net, seed=init_seed)
     engine.set_params(params, _abi.NET_ONLINE)
     replay = initialize_replay_buffer(solver, env, engine)
-    policy = NNPolicy(env, engine, action_map, len(env.obs_shape))
+    policy = NNPolicy(env, engine, action_map, len(env.obs_shape), qnetwork=net)
     return dqn_train(solver, env, policy, replay)
 
 
@@ -326,10 +333,13 @@ def batch_train(solver, env, policy, optimizer, target_q, replay, discount=None)
 
 
 def save_model(solver, policy, scores_eval, saved_mean_reward, model_saved):
-    """src/solver.jl:290-300 (qnetwork.npz instead of qnetwork.bson: a vector of arrays in Flux.params order)."""
+    """src/solver.jl:290-300: bson(joinpath(logdir, "qnetwork.bson"), qnetwork=[w for w in Flux.params(active_q)]) when the evaluation
+    score did not get worse.  The file is written in BSON.jl's array lowering (bson.py; unverified against BSON.jl -- no Julia here)."""
     if scores_eval >= saved_mean_reward:
         os.makedirs(solver.logdir, exist_ok=True)
-        np.savez(os.path.join(solver.logdir, "qnetwork.npz"), qnetwork=policy.getnetwork())
+        if policy.qnetwork is None:
+            raise DQNError("save_model: the policy carries no network description (NNPolicy(..., qnetwork=net)); qnetwork.bson needs the array shapes")
+        bson.save_qnetwork(os.path.join(solver.logdir, "qnetwork.bson"), policy.getnetwork(), bson.julia_param_shapes(policy.qnetwork))
         if solver.verbose:
             print(f"Saving new model with eval reward {scores_eval:1.3f}")
         return True, scores_eval
@@ -337,8 +347,12 @@ def save_model(solver, policy, scores_eval, saved_mean_reward, model_saved):
 
 
 def restore_best_model(solver, policy):
-    """src/solver.jl:302-318."""
-    w = np.load(os.path.join(solver.logdir, "qnetwork.npz"))["qnetwork"]
+    """src/solver.jl:302-318: weights = BSON.load(logdir * "qnetwork.bson")[:qnetwork]; Flux.loadparams!(getnetwork(policy), weights)."""
+    w, sizes = bson.load_qnetwork(os.path.join(solver.logdir, "qnetwork.bson"))
+    if policy.qnetwork is not None:
+        want = [s for s, _ in bson.julia_param_shapes(policy.qnetwork)]
+        if sizes != want:
+            raise DQNError(f"restore_best_model: qnetwork.bson holds arrays of sizes {sizes}, the network expects {want}")   # loadparams! dimension check
     policy.engine.set_params(w, _abi.NET_ONLINE)
     return policy
 
@@ -360,12 +374,15 @@ def dqn_train_device(solver, env, policy, replay):
     saved_mean_reward, scores_eval, model_saved = -np.inf, -np.inf, False
     marks = sorted({solver.eval_freq, solver.log_freq, solver.save_freq})
     t, episodes, reward_sum = 1, 0, 0.0
+    save_next = False                                  # set at t % save_freq == 0, consumed at the next evaluation (src/solver.jl:109-113,150-152)
     while t <= solver.max_steps:
         nxt = min(min((t + m - 1) // m * m for m in marks), solver.max_steps)      # run up to the next eval/log/save boundary
         st = e.rollout(nxt - t + 1, t0=t, train_freq=solver.train_freq, target_update_freq=solver.target_update_freq, eps=eps)
         t = nxt + 1
         d_eps, d_rew = st["episodes"] - episodes, st["reward_sum"] - reward_sum
         episodes, reward_sum = st["episodes"], st["reward_sum"]
+        if nxt % solver.save_freq == 0:
+            save_next = True
         if nxt % solver.eval_freq == 0:
             if solver.evaluation_policy is basic_evaluation:        # the default rollout evaluation also runs on the device
                 scores_eval, steps_eval = e.evaluate(min(solver.num_ep_eval, 1024), solver.max_episode_length, seed=solver.seed + nxt)
@@ -373,8 +390,9 @@ def dqn_train_device(solver, env, policy, replay):
                     print(f"Evaluation ... Avg Reward {scores_eval:2.2f} | Avg Step {steps_eval:2.2f}")
             else:
                 scores_eval, _, _ = solver.evaluation_policy(policy, env, solver.num_ep_eval, solver.max_episode_length, solver.verbose)
-            if nxt % solver.save_freq == 0 and solver.logdir is not None:
+            if save_next and solver.logdir is not None:
                 model_saved, saved_mean_reward = save_model(solver, policy, scores_eval, saved_mean_reward, model_saved)
+                save_next = False
         if nxt % solver.log_freq == 0 and solver.verbose:
             avg = d_rew / d_eps if d_eps else float("nan")
             print(f"{nxt:5d} / {solver.max_steps:5d} eps {max(eps[1], eps[0] - nxt * (eps[0] - eps[1]) / eps[2]):0.3f} |  avgR {avg:1.3f} | "
@@ -391,6 +409,10 @@ def dqn_train(solver, env, policy, replay):
             raise DQNError("device_envs drives the feed-forward path (recurrence = false)")
         return dqn_train_device(solver, env, policy, replay)
     e = policy.engine
+    if solver.recurrence and env.n != 1:
+        # one EpisodeReplayBuffer episode and one Recur state are open at a time, as in the reference's single-env loop: n > 1 streams
+        # would interleave transitions of different environments in one episode
+        raise DQNError("recurrence = true drives ONE environment stream on the host loop (env.n == 1), like the reference's dqn_train!")
     e.sync_target()                                   # target_q = deepcopy(active_q), :65
     policy.resetstate()
     env.reset()

@@ -241,6 +241,11 @@ int dqn_set_counters(dqn_engine_t* e, const dqn_counters* in);   /* size must eq
 int dqn_comm_unique_id(void* id128);
 int dqn_comm_init(dqn_engine_t* e, const void* id128, int rank, int world);
 
+/* TEST HOOK for the exchange above on ONE GPU: an engine created with the environment variable DQN_SIM_WORLD=k plays k ranks; this call runs
+ * one data-parallel step with k DISTINCT batches idx[k][B] (rank r's packed block lands in slot r of the gathered buffer, as ncclAllGather
+ * would deliver it).  loss[k]: per-rank losses; td_out[k][B].  Equivalent single-device step: the concatenated batch of k*B samples. */
+int dqn_sim_ranks_step(dqn_engine_t* e, const int64_t* idx, float* loss, float* grad_norm, float* td_out);
+
 /* raw access for harnesses that time kernels on the engine's own stream. */
 int dqn_stream_sync(dqn_engine_t* e);
 int dqn_stream_handle(dqn_engine_t* e, void** hip_stream);

@@ -25,6 +25,11 @@ abi = _ge.load_package()._abi
 
 LIB_PATH = os.path.join(HERE, "_ref", "libdqn_ref.so")
 _fns = None
+# how the twin's C interface differs from the product's (this knowledge is test infrastructure and lives HERE, not in the product
+# package): symbols carry the prefix "ref_", three are spelled shorter, and ref_create takes no device argument
+PREFIX = "ref_"
+ALIASES = {"engine_create": "create", "engine_destroy": "destroy", "engine_get_plan": "get_plan"}
+ARGTYPES = {"engine_create": [C.POINTER(abi.LayerDesc), C.c_int, C.POINTER(abi.HParams), C.POINTER(abi.LayerPlan), C.POINTER(C.c_void_p)]}
 
 
 def build(force=False):
@@ -39,7 +44,7 @@ def fns():
         if not os.path.exists(LIB_PATH):
             build()
         lib = C.CDLL(LIB_PATH)
-        _fns = abi.bind(lib, "ref_")
+        _fns = abi.bind(lib, PREFIX, aliases=ALIASES, argtypes=ARGTYPES)
         lib.ref_set_threads.argtypes = [C.c_void_p, C.c_int]
         _fns["set_threads"] = lib.ref_set_threads
     return _fns
@@ -86,9 +91,14 @@ def default_plan(layers, hp):
 
 
 class Twin(abi.Handle):
+    is_twin = True
+
     def __init__(self, layers, hp, plan=None, threads=1):
-        super().__init__(fns(), layers, hp, plan=plan, is_twin=True)
+        super().__init__(fns(), layers, hp, plan=plan)
         self.f["set_threads"](self._h, threads)
+
+    def _create(self, parr, device, h):
+        return self.f["engine_create"](self.layers, self.n_layers, C.byref(self.hp), parr, C.byref(h))
 
     def set_threads(self, n):
         self.f["set_threads"](self._h, n)

@@ -1,0 +1,65 @@
+"""CPU: qnetwork.bson (src/solver.jl:290-318) written from a flat Flux.params vector by deepqlearning.jl_amd/bson.py:
+  * round trip through the module's independent reader (generic BSON decoder + BSON.jl-style raising): same values, same Julia sizes;
+  * byte-level structure against the BSON spec (bsonspec.org): total length prefix, element types, zero-based array keys, binary subtype 0,
+    int64 sizes, raw little-endian Float32 payload in Julia (column-major) memory order.
+UNVERIFIED against BSON.jl itself: no Julia runs in this image; the lowering ("tag" => "array" / "datatype") is restated from BSON.jl."""
+import importlib
+import struct
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+
+pkg = ge.load_package()
+nn = importlib.import_module(pkg.__name__ + ".nn")
+bson = importlib.import_module(pkg.__name__ + ".bson")
+
+
+def test_shapes_follow_flux_params_order():
+    net = nn.create_dueling_network(nn.nature_dqn(n_actions=4))
+    shapes = bson.julia_param_shapes(net)
+    assert [s for s, _ in shapes] == [(8, 8, 4, 32), (32,), (4, 4, 32, 64), (64,), (3, 3, 64, 64), (64,),      # base: Conv weight (kw, kh, cin, cout)
+                                      (512, 3136), (512,), (1, 512), (1,),                                      # val:  Dense weight (out, in), fresh Dense(512, 1)
+                                      (512, 3136), (512,), (4, 512), (4,)]                                      # adv
+    assert sum(n for _, n in shapes) == 3_292_837
+    rec = nn.Chain(nn.LSTM(25, 32), nn.Dense(32, 4))
+    assert [s for s, _ in bson.julia_param_shapes(rec)] == [(128, 25), (128, 32), (128,), (32, 1), (32, 1), (4, 32), (4,)]
+
+
+def test_round_trip_and_values(tmp_path):
+    net = nn.create_dueling_network(nn.Chain(nn.Conv(3, 2, 4, nn.relu, 1), nn.flattenbatch, nn.Dense(36, 8, nn.relu), nn.Dense(8, 3)))
+    shapes = bson.julia_param_shapes(net)
+    flat = np.random.default_rng(0).standard_normal(sum(n for _, n in shapes)).astype(np.float32)
+    path = tmp_path / "qnetwork.bson"
+    bson.save_qnetwork(path, flat, shapes)
+    got, sizes = bson.load_qnetwork(path)
+    np.testing.assert_array_equal(got, flat)
+    assert sizes == [s for s, _ in shapes]
+    with pytest.raises(AssertionError):
+        bson.dumps_qnetwork(flat[:-1], shapes)
+
+
+def test_bytes_follow_the_bson_spec():
+    shapes = [((2, 3), 6), ((2,), 2)]
+    flat = np.arange(8, dtype=np.float32)
+    data = bson.dumps_qnetwork(flat, shapes)
+    assert struct.unpack_from("<i", data, 0)[0] == len(data) and data[-1] == 0          # int32 total size, trailing 0x00
+    assert data[4] == 0x04 and data[5:14] == b"qnetwork\x00"                            # one element: array "qnetwork"
+    arr_len = struct.unpack_from("<i", data, 14)[0]
+    assert 14 + arr_len + 1 == len(data)
+    assert data[18] == 0x03 and data[19:21] == b"0\x00"                                  # first array element: embedded document keyed "0"
+    doc = bson.loads(data)                                                               # raised
+    (a0, s0), (a1, s1) = doc["qnetwork"]
+    assert s0 == (2, 3) and s1 == (2,)
+    np.testing.assert_array_equal(a0, flat[:6]); np.testing.assert_array_equal(a1, flat[6:])
+    raw, _ = bson._dec_doc(memoryview(data), 0)                                          # un-raised: the tagged documents themselves
+    e0 = raw["qnetwork"][0]
+    assert list(e0) == ["tag", "type", "size", "data"] and e0["tag"] == "array"
+    assert e0["type"] == {"tag": "datatype", "name": ["Core", "Float32"], "params": []}
+    assert e0["size"] == [2, 3] and e0["data"] == flat[:6].tobytes()
+    # sizes are int64 elements (0x12), the payload is binary subtype 0 with an int32 length
+    i = data.index(b"\x12" + b"0\x00" + struct.pack("<q", 2))
+    assert i > 0
+    j = data.index(b"\x05data\x00" + struct.pack("<i", 24) + b"\x00")
+    assert data[j + 11:j + 11 + 24] == flat[:6].tobytes()

@@ -75,6 +75,83 @@ def test_simulated_ranks_equal_concatenated_batch(pkg, monkeypatch, k):
         t.set_params(Pg, 0)                                                 # keep the two trajectories on the same parameters
 
 
+def _distinct_rank_step(g, t, net, k, B, idx, wide_shape, lr):
+    """one data-parallel step with k DISTINCT per-rank batches against the twin's single-device step on the true concatenated batch"""
+    pr_before = g.replay_priorities()
+    lossg, gg, tdg = g.sim_ranks_step(idx)
+    lt, gt, tdt = t.train_step(idx.reshape(-1))
+    np.testing.assert_array_equal(tdg.reshape(-1), tdt)                     # rank r's TD errors == columns r*B..(r+1)*B-1 of the big batch
+    assert np.unique(tdg, axis=0).shape[0] == k                              # the ranks really did different work
+    np.testing.assert_allclose(lossg.astype(np.float64).mean(), lt, rtol=2e-6)   # mean of per-rank means == mean over k*B
+    Gg, Gt = g.get_grads() / np.float32(k), t.get_grads()
+    wide = [(x, y) for x, y in zip(net.unflatten(Gg), net.unflatten(Gt)) if x.ndim == 2 and x.shape == wide_shape]
+    assert len(wide) == 2
+    for x, y in wide:
+        np.testing.assert_array_equal(x, y)                                  # gathered contraction, rank-major == the concatenated batch's, bit for bit
+    np.testing.assert_allclose(Gg, Gt, rtol=2e-4, atol=1e-6 * np.abs(Gt).max())   # conv / head gradients: per-rank chains summed over ranks vs one long chain
+    assert abs(gg - gt) <= 1e-5 * max(1.0, abs(gt))
+    Pg, Pt = g.get_params(0), t.get_params(0)
+    assert np.abs(Pg - Pt).max() <= 2.1 * lr                                 # Adam at |g| ~ eps moves up to lr
+    assert (np.abs(Pg - Pt) > 2e-6).mean() < 1e-3
+    np.testing.assert_array_equal(g.replay_priorities(), t.replay_priorities())   # every rank's update_priorities! landed
+    assert (g.replay_priorities() != pr_before).sum() >= k * B - 2
+    t.set_params(Pg, 0)
+
+
+@pytest.mark.parametrize("k", [2, 4, 8])
+def test_distinct_ranks_equal_concatenated_batch(pkg, monkeypatch, k):
+    """k simulated ranks with k DIFFERENT index lists (dqn_sim_ranks_step): a wrong rank offset anywhere in the exchange -- the pack layout,
+    the rank stride of the gathered dW operands (DwStride), the sum over ranks -- reads another rank's data and turns this red (with identical
+    ranks it could not)."""
+    net = wide_dense_dueling()
+    monkeypatch.setenv("DQN_SIM_WORLD", str(k))
+    g, t, rng = setup(pkg, net, 32, 32 * k, cap=512, n_fill=400)
+    monkeypatch.delenv("DQN_SIM_WORLD")
+    for step in range(2):
+        idx = rng.choice(400, (k, 32), replace=False).astype(np.int64)
+        _distinct_rank_step(g, t, net, k, 32, idx, (192, 512), 1e-3)
+
+
+def test_distinct_ranks_detects_a_wrong_rank_offset(pkg, monkeypatch):
+    """the test above CAN fail: feeding the twin the batch with two rank blocks swapped (what a wrong rank offset would compute) breaks it"""
+    net = wide_dense_dueling()
+    k = 4
+    monkeypatch.setenv("DQN_SIM_WORLD", str(k))
+    g, t, rng = setup(pkg, net, 32, 32 * k, cap=512, n_fill=400)
+    monkeypatch.delenv("DQN_SIM_WORLD")
+    idx = rng.choice(400, (k, 32), replace=False).astype(np.int64)
+    g.sim_ranks_step(idx)
+    t.train_step(idx[[1, 0, 2, 3]].reshape(-1))
+    Gg, Gt = g.get_grads() / np.float32(k), t.get_grads()
+    wide = [(x, y) for x, y in zip(net.unflatten(Gg), net.unflatten(Gt)) if x.ndim == 2 and x.shape == (192, 512)]
+    assert any(not np.array_equal(x, y) for x, y in wide)                    # same SET of samples, other ORDER: the bit-exact check notices
+
+
+def test_config3_nature_dqn_8_ranks_distinct_batches(pkg, monkeypatch):
+    """BASELINE config 3's exchange at FULL size on one GPU: Nature-DQN dueling (84x84x4), 8 ranks x B = 32 with distinct batches; the two
+    3136x512 dense layers go through the operand all-gather (0.86 MB per rank), everything else through the sum over ranks."""
+    from nets import nature_dueling
+    net = nature_dueling()
+    k, B = 8, 32
+    layers = ref.layers_from_network(net)
+    monkeypatch.setenv("DQN_SIM_WORLD", str(k))
+    hp_g = ref.hparams_for(net, batch_size=B, buffer_size=512, gamma=0.99)
+    g = pkg.Engine(layers, hp_g, plan=pkg.default_plan(layers, hp_g))
+    monkeypatch.delenv("DQN_SIM_WORLD")
+    hp_t = ref.hparams_for(net, batch_size=B * k, buffer_size=512, gamma=0.99)
+    t = ref.Twin(layers, hp_t, plan=pkg.default_plan(layers, hp_t), threads=64)
+    rng = np.random.default_rng(3)
+    n = 384
+    s = rng.random((n,) + net.obs_shape, dtype=np.float32); sp = rng.random((n,) + net.obs_shape, dtype=np.float32)
+    a = rng.integers(0, net.n_actions, n).astype(np.int32); r = (rng.standard_normal(n) * 2).astype(np.float32); d = (rng.random(n) < 0.2).astype(np.uint8)
+    p = O.Network.flatten(O.init_params(net, seed=5))
+    p = (p + 0.01 * rng.standard_normal(p.shape)).astype(np.float32)
+    for h in (g, t):
+        h.replay_add(s, a, r, sp, d); h.set_params(p, 0); h.set_params(p * np.float32(0.9), 1)
+    idx = rng.choice(n, (k, B), replace=False).astype(np.int64)
+    _distinct_rank_step(g, t, net, k, B, idx, (3136, 512), 1e-4)
+
+
 def test_rccl_allgather_world1_matches_plain(pkg, monkeypatch):
     net = wide_dense_dueling()
     a, cpu, rng = setup(pkg, net, 32, 32, seed=1)

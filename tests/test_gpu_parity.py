@@ -12,7 +12,8 @@ import dqn_oracle as O
 import ref
 from nets import GOLDEN_CASES, cfg1_mlp_dueling, nature_dueling, small_conv_dueling, small_conv_plain
 from nets import testmdp_mlp_tanh as mlp_tanh_net
-from test_twin_vs_oracle import run_case
+from parity_common import hand_derived_known_answer, sampler_distribution
+from test_twin_vs_oracle import check_priorities_after_step, run_case
 
 pytestmark = pytest.mark.gpu
 
@@ -74,6 +75,21 @@ def assert_step_bit_exact(gpu, cpu, idx=None):
 @pytest.mark.parametrize("name", list(GOLDEN_CASES))
 def test_engine_matches_fp64_oracle_and_golden(pkg, name, golden_dir):
     run_case(name, golden_dir, pkg.Engine)
+
+
+@pytest.mark.parametrize("name", ["cfg1_gridworld_mlp_dueling", "small_conv_dueling"])
+def test_prioritized_replay_off_leaves_priorities(pkg, name, golden_dir):
+    run_case(name, golden_dir, pkg.Engine, prioritized=0)      # src/solver.jl:231: no update_priorities! call
+
+
+def test_hand_derived_known_answer(pkg):
+    """every number of one batch_train! worked out by hand from the cited reference lines (tests/parity_common.py)"""
+    hand_derived_known_answer(pkg.Engine)
+
+
+def test_sampler_inclusion_frequencies(pkg):
+    """sum-tree sampler vs p / sum(p) (...replay.jl:85); the twin runs the same check on the CPU and the two samplers are bit-identical"""
+    sampler_distribution(pkg.Engine)
 
 
 @pytest.mark.parametrize("mfma", [0, 1])
@@ -188,7 +204,8 @@ def test_policy_forward_and_greedy(pkg):
 
 
 def test_nature_dqn_b32_full_size_bit_exact(pkg):
-    """BASELINE config 2 at full size: 84x84x4, Nature-DQN dueling, B=32, double-Q, prioritized."""
+    """BASELINE config 2 at full size: 84x84x4, Nature-DQN dueling, B=32, double-Q, prioritized: bit-exact vs the canonical-order twin,
+    then one more step on explicit indices against the NumPy fp64 oracle (north_star: Q-values within 1e-5, greedy indices equal)."""
     net = nature_dueling()
     gpu, cpu, hp = make_pair(pkg, net, 32, cap=256, gamma=0.99)
     fill((gpu, cpu), net, 256, seed=9)
@@ -196,10 +213,88 @@ def test_nature_dqn_b32_full_size_bit_exact(pkg):
     for step in range(3):
         loss, gn = assert_step_bit_exact(gpu, cpu)
     np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
-    # and against the fp64 oracle on the last batch's indices (Q within 1e-5)
-    idx = gpu.last_indices()
+    # ---- fp64 oracle at FULL size on the engine's own batch and current parameters
+    p_on, p_tg = gpu.get_params(0), gpu.get_params(1)
+    idx = np.random.default_rng(123).choice(256, 32, replace=False).astype(np.int64)
+    batch = gpu.get_batch(idx)
+    o = O.batch_train_step(net, net.unflatten(p_on), net.unflatten(p_tg), batch, gamma=float(np.float32(0.99)), double_q=True, adam=None)
+    pr_before = gpu.replay_priorities()
+    np.testing.assert_allclose(batch[5], O.is_weights(pr_before[idx], pr_before, hp.prio_beta, np.float64), rtol=2e-6)
+    loss, gn, td = gpu.train_step(idx)
     q = gpu.last_q()
-    assert np.isfinite(loss) and gn > 0
+    np.testing.assert_allclose(q["q_on_s"], o["q"], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(q["q_on_sp"], o["q_on_sp"], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(q["q_tg_sp"], o["q_tg_sp"], atol=1e-5, rtol=1e-5)
+    top2 = np.sort(o["q_on_sp"], axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-5                 # a greedy index can only differ where fp64 itself sees a near-tie
+    assert clear.sum() >= 24
+    np.testing.assert_array_equal(q["best_a"][clear], o["best_a"][clear])
+    np.testing.assert_allclose(q["y"], o["y"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(td, o["td"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(loss, o["loss"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(gn, o["grad_norm"], rtol=1e-4)
+    go = O.Network.flatten(o["grads"])
+    np.testing.assert_allclose(gpu.get_grads(), go, atol=2e-5 * np.abs(go).max(), rtol=1e-4)
+    check_priorities_after_step(gpu, hp, idx, pr_before, td, o["td"], batch[5])
+
+
+def test_config5_nature_b512_u8_bit_exact(pkg):
+    """BASELINE config 5's shape under pytest: Nature-DQN dueling, B = 512, u8 replay (4096 transitions here; the 1e6-transition property
+    run is test_config5_million_transition_properties): the large-batch program (own sampler launch, multi-workgroup head reduce, u8 gather,
+    side-stream priority update) bit-exact vs the twin for two sampled steps."""
+    net = nature_dueling()
+    gpu, cpu, hp = make_pair(pkg, net, 512, cap=4096, obs_dtype=1, gamma=0.99)
+    cpu.set_threads(64)
+    fill((gpu, cpu), net, 4096, seed=11, u8=True)
+    set_same_params((gpu, cpu), net, seed=2)
+    for _ in range(2):
+        assert_step_bit_exact(gpu, cpu)
+    np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+    np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
+
+
+def test_config5_million_transition_properties(pkg):
+    """BASELINE config 5 at FULL size: replay of 1 000 000 u8 transitions (56 GB of rows in HBM), filled by the device env loop; size-independent
+    properties: every sampled index in range and spread over the whole ring, finite loss, the sum-tree root equals the sum of the leaves, the
+    step touches exactly the sampled leaves, gathered rows equal the stored rows."""
+    import importlib
+    envs = importlib.import_module(pkg.__name__ + ".envs")
+    net = nature_dueling()
+    N, B = 1_000_000, 512
+    hp = ref.hparams_for(net, batch_size=B, buffer_size=N, obs_dtype=1, gamma=0.99, seed=3)
+    layers = ref.layers_from_network(net)
+    gpu = pkg.Engine(layers, hp)
+    p = O.Network.flatten(O.init_params(net, seed=1))
+    gpu.set_params(p, 0); gpu.set_params(p, 1)
+    env = envs.TestMDP((84, 84), 4, 6, n=32, seed=7, u8=True)
+    gpu.envs_create(env, n_envs=1000, max_episode_length=100, seed=5)
+    gpu.rollout(N // 1000, t0=1, train_freq=0, target_update_freq=0, eps=(1.0, 1.0, 1.0), stats=False)
+    assert gpu.replay_size() == (N, N)
+    pr = gpu.replay_priorities()
+    assert pr.shape == (N,) and np.all(pr > 0)
+    seen = np.zeros(N, bool)
+    for step in range(6):
+        before = pr
+        loss, gn, td = gpu.train_step()
+        idx = gpu.last_indices()
+        assert idx.min() >= 0 and idx.max() < N and np.isfinite(loss) and np.all(np.isfinite(td)) and gn > 0
+        seen[idx] = True
+        pr = gpu.replay_priorities()
+        changed = np.flatnonzero(pr != before)
+        assert np.isin(changed, idx).all()                                                   # only sampled leaves move
+        last = {int(i): k for k, i in enumerate(idx)}                                        # duplicates: last write wins
+        keep = np.array(sorted(last.values()))
+        np.testing.assert_allclose(pr[idx[keep]], O.priority_from_td(np.abs(td[keep]), hp.prio_eps, hp.prio_alpha), rtol=2e-7)
+    assert np.flatnonzero(seen).max() > N // 2 and np.flatnonzero(seen).min() < N // 2       # draws cover the ring, not a prefix
+    # IS weights carry the tree root: w = (n p / root)^-beta  =>  root recovered from one weight must equal the fp64 sum of the leaves
+    idx = np.arange(B, dtype=np.int64) * (N // B)
+    s_rows, a, r, sp_rows, done, w = gpu.get_batch(idx)
+    root = N * pr[idx].astype(np.float64) / w.astype(np.float64) ** (-1.0 / np.float64(np.float32(hp.prio_beta)))
+    np.testing.assert_allclose(root, pr.astype(np.float64).sum(), rtol=2e-5)
+    ex = gpu.replay_export(first=int(idx[5]), n=1)
+    np.testing.assert_array_equal(s_rows[5], ex[0][0].astype(np.float32) / np.float32(255))
+    np.testing.assert_array_equal(sp_rows[5], ex[1][0].astype(np.float32) / np.float32(255))
+    gpu.close()
 
 
 def test_errors_are_loud(pkg):

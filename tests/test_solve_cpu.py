@@ -88,7 +88,9 @@ def test_gridworld_config1_and_model_save_restore(tmp_path):
     policy = S.solve(solver, env, engine_cls=twin_engine)
     assert policy.actionvalues(np.array([1.0, 1.0], np.float32)).shape == (4,)
     assert policy.action(np.array([9.0, 2.0], np.float32)) in range(4)
-    saved = np.load(tmp_path / "qnetwork.npz")["qnetwork"]
+    bson = importlib.import_module(pkg.__name__ + ".bson")
+    saved, sizes = bson.load_qnetwork(tmp_path / "qnetwork.bson")  # joinpath(logdir, "qnetwork.bson"), src/solver.jl:292
+    assert sizes == [(32, 2), (32,), (1, 32), (1,), (32, 2), (32,), (4, 32), (4,)]    # Flux.params order base | val | adv, Julia sizes (out, in)
     assert saved.shape == policy.getnetwork().shape
     np.testing.assert_array_equal(saved, policy.getnetwork())      # verbose=True: the best model was restored at the end (src/solver.jl:170-176)
 

@@ -10,13 +10,32 @@ import ref
 from nets import GOLDEN_CASES, fill_replay_from_batch, golden_params
 
 
-def run_case(name, golden_dir, Engine, tol_q=1e-5, **engine_kw):
+def check_priorities_after_step(h, hp, idx, pr_before, td_engine, td_oracle, w):
+    """update_priorities!(replay, idx, td) (src/solver.jl:231-233, ...replay.jl:76-80): p[idx] = (|td| + eps)^alpha with the UNWEIGHTED td,
+    only when solver.prioritized_replay; every other priority is untouched.  idx must hold no duplicates."""
+    pr = h.replay_priorities()
+    if not hp.prioritized_replay:
+        np.testing.assert_array_equal(pr, pr_before)
+        return
+    eps, alpha = np.float32(hp.prio_eps), np.float32(hp.prio_alpha)
+    np.testing.assert_allclose(pr[idx], O.priority_from_td(np.abs(td_engine), eps, alpha), rtol=2e-7)   # the formula on the engine's own td: 1 ulp of pow
+    want = O.priority_from_td(np.abs(td_oracle), eps, alpha, np.float64)                                  # and on the fp64 oracle's td
+    slack = 0.6 * (np.abs(td_oracle) + float(eps)) ** (float(alpha) - 1.0) * 3e-5 + 1e-6 * want           # d p / d td  x  the td tolerance
+    assert np.all(np.abs(pr[idx] - want) <= slack), np.abs(pr[idx] - want).max()
+    rest = np.setdiff1d(np.arange(pr.size), idx)
+    np.testing.assert_array_equal(pr[rest], pr_before[rest])
+    # the misreading (priorities from the IS-WEIGHTED td) must be distinguishable on this batch, else the check above proves nothing
+    wrong = O.priority_from_td(np.abs(np.asarray(w, np.float64) * td_oracle), eps, alpha, np.float64)
+    assert np.any(np.abs(wrong - want) > 10 * slack), "batch cannot tell weighted from unweighted td"
+
+
+def run_case(name, golden_dir, Engine, tol_q=1e-5, prioritized=1, **engine_kw):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     net = GOLDEN_CASES[name]()
     B = int(g["B"])
     p_on, p_tg = golden_params(name, net, g)
     hp = ref.hparams_for(net, batch_size=B, gamma=float(g["gamma"]), double_q=int(g["double_q"]),
-                         learning_rate=float(g["lr"]), buffer_size=max(64, B))
+                         learning_rate=float(g["lr"]), buffer_size=max(64, B), prioritized_replay=prioritized)
     layers = ref.layers_from_network(net)
     h = Engine(layers, hp, **engine_kw)
     h.set_params(p_on, 0)
@@ -33,8 +52,10 @@ def run_case(name, golden_dir, Engine, tol_q=1e-5, **engine_kw):
                            gamma=float(np.float32(g["gamma"])), double_q=bool(g["double_q"]), adam=adam)
     w64 = O.is_weights(h.replay_priorities()[idx], h.replay_priorities(), hp.prio_beta, np.float64)
     np.testing.assert_allclose(w, w64, rtol=2e-6)
+    pr_before = h.replay_priorities()
     loss, gn, td = h.train_step(idx)
     q = h.last_q()
+    check_priorities_after_step(h, hp, idx, pr_before, td, o["td"], w)
     np.testing.assert_allclose(q["q_on_s"], o["q"], atol=tol_q, rtol=1e-5)
     np.testing.assert_allclose(q["q_tg_sp"], o["q_tg_sp"], atol=tol_q, rtol=1e-5)
     np.testing.assert_array_equal(q["best_a"], o["best_a"])
@@ -61,6 +82,11 @@ def run_case(name, golden_dir, Engine, tol_q=1e-5, **engine_kw):
 @pytest.mark.parametrize("name", list(GOLDEN_CASES))
 def test_twin_matches_fp64_oracle(name, golden_dir):
     run_case(name, golden_dir, ref.Twin, threads=8)
+
+
+@pytest.mark.parametrize("name", ["cfg1_gridworld_mlp_dueling", "small_conv_dueling"])
+def test_twin_prioritized_replay_off_leaves_priorities(name, golden_dir):
+    run_case(name, golden_dir, ref.Twin, prioritized=0, threads=4)     # src/solver.jl:231: no update_priorities! call
 
 
 def test_twin_thread_count_does_not_change_bits(golden_dir):
