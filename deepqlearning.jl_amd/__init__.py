@@ -16,7 +16,7 @@ from ._abi import (ACT_IDENTITY, ACT_RELU, ACT_SIGMOID, ACT_TANH, NET_ONLINE, NE
                    LayerDesc, LayerPlan, default_hparams)
 
 _HERE = _os.path.dirname(_os.path.abspath(__file__))
-LIB_PATH = _os.path.join(_HERE, "libdqn_mi355x.so")
+LIB_PATH = _os.environ.get("DQN_MI355X_LIB") or _os.path.join(_HERE, "libdqn_mi355x.so")   # same variable the Julia shim reads
 _lib = None
 _fns = None
 

@@ -6,16 +6,22 @@
 #   add_exp!, sample, get_batch, update_priorities!, populate_replay_buffer!            <- src/prioritized_experience_replay.jl:61-134
 #   AbstractNNPolicy interface: getnetwork, resetstate!, actionmap, action, actionvalues, value  <- src/policy.jl:1-76
 #
+#   solve(MI355XSolver(solver), mdp)  /  initialize_replay_buffer(solver, env, action_indices, engine)  /  dqn_train!(solver, env, ::HIPNNPolicy, replay)
+#                                                                                        <- src/solver.jl:30-57, :59-178, :180-189
+#
 # NOT EXECUTED IN THIS BUILD: neither the build container nor the GPU box has a `julia` binary (SURVEY.md), so this file
 # ships as reviewed source.  Every call below goes through exactly the C entry points that tests/ exercise from Python
 # (ctypes) with the same buffers, so its behaviour is pinned by the same fixtures.
 module DeepQLearningMI355X
 
-using DeepQLearning, Flux, POMDPs, POMDPTools, Random
+using DeepQLearning, Flux, POMDPs, POMDPTools, Random, Printf, Statistics, BSON
 import DeepQLearning: batch_train!, add_exp!, update_priorities!, get_batch, populate_replay_buffer!, is_full, max_size,
-                      getnetwork, resetstate!, actionmap, AbstractNNPolicy, DQExperience, DeepQLearningSolver
-import CommonRLInterface: AbstractEnv, observe, actions
+                      getnetwork, resetstate!, actionmap, initialize_replay_buffer, dqn_train!,
+                      AbstractNNPolicy, DQExperience, DeepQLearningSolver
+import CommonRLInterface: AbstractEnv, observe, actions, act!, reset!, terminated
+import TensorBoardLogger: TBLogger, log_value
 import StatsBase
+export MI355XSolver, HIPReplayBuffer, HIPEpisodeReplayBuffer, HIPNNPolicy
 
 const LIB = get(ENV, "DQN_MI355X_LIB", "libdqn_mi355x.so")
 
@@ -129,6 +135,26 @@ function StatsBase.sample(r::HIPReplayBuffer)                                   
     get_batch(r, idx .+ 1)
 end
 
+# populate_replay_buffer!(replay, env, action_indices; max_pop, max_steps, policy) (:106-134): the package's method is typed on
+# PrioritizedReplayBuffer and reads replay._curr_size, so the HIP replay gets its own: a random (or given) policy fills the ring with
+# priority |r|, episodes are cut at max_steps
+function populate_replay_buffer!(replay::HIPReplayBuffer, env::AbstractEnv, action_indices;
+                                 max_pop::Int64 = max_size(replay), max_steps::Int64 = 100,
+                                 policy::Policy = FunctionPolicy(o -> rand(actions(env))))
+    reset!(env); o = observe(env); step = 0
+    for _ in 1:(max_pop - cur_size(replay))
+        a = action(policy, o)
+        rew = Float32(act!(env, a)); op = observe(env); done = terminated(env)
+        add_exp!(replay, DQExperience(o, action_indices[a], rew, op, done), abs(rew))    # "assume initial td error is r" (:122)
+        o = op; step += 1
+        if done || step >= max_steps
+            reset!(env); o = observe(env); step = 0
+        end
+    end
+    cur_size(replay) >= replay.e.B || throw(AssertionError("replay._curr_size >= replay.batch_size"))    # :133
+    replay
+end
+
 # ---- the hot path: ONE ccall per batch_train!  (src/solver.jl:191-236)
 function batch_train!(solver::DeepQLearningSolver, env::AbstractEnv, policy::AbstractNNPolicy, optimizer, target_q,
                       replay::HIPReplayBuffer; discount=DeepQLearning.default_discount(env))
@@ -147,6 +173,24 @@ function add_exp!(r::HIPEpisodeReplayBuffer, expe::DQExperience)                
                 r.e.h, Float32.(vec(expe.s)), Int32(expe.a - 1), Float32(expe.r), Float32.(vec(expe.sp)), UInt8(expe.done), 1))
 end
 add_episode!(r::HIPEpisodeReplayBuffer) = check(ccall((:dqn_episode_commit, LIB), Cint, (Ptr{Cvoid},), r.e.h))   # :54-60, after generate_episode
+ep_count(r::HIPEpisodeReplayBuffer) = (cur = Ref{Int64}(); ccall((:dqn_episode_count, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}, Ptr{Int64}), r.e.h, cur, C_NULL); cur[])
+max_size(r::HIPEpisodeReplayBuffer) = (cap = Ref{Int64}(); ccall((:dqn_episode_count, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ref{Int64}), r.e.h, C_NULL, cap); cap[])
+is_full(r::HIPEpisodeReplayBuffer) = ep_count(r) == max_size(r)
+# populate_replay_buffer!(r::EpisodeReplayBuffer, env, action_indices; max_pop, max_steps) (src/episode_replay.jl:97-130): random rollouts of
+# fewer than max_steps steps, each stored as one episode whether or not it terminated
+function populate_replay_buffer!(r::HIPEpisodeReplayBuffer, env::AbstractEnv, action_indices; max_pop::Int64 = max_size(r), max_steps::Int64 = 100)
+    for _ in 1:(max_pop - ep_count(r))
+        reset!(env); o = observe(env); done = false; step = 1
+        while !done && step < max_steps
+            a = rand(actions(env)); rew = Float32(act!(env, a)); op = observe(env); done = terminated(env)
+            add_exp!(r, DQExperience(o, action_indices[a], rew, op, done))     # a terminal transition stores the episode (add_exp!, :46-52)
+            o = op; step += 1
+        end
+        done || add_episode!(r)                                                 # cut at max_steps: add_episode!(r, ep), :100-101
+    end
+    ep_count(r) >= r.e.B || throw(AssertionError("r._curr_size >= r.batch_size"))
+    r
+end
 function batch_train!(solver::DeepQLearningSolver, env::AbstractEnv, policy::AbstractNNPolicy, optimizer, target_q,
                       replay::HIPEpisodeReplayBuffer; discount=DeepQLearning.default_discount(env))
     loss = Ref{Float32}(0); gn = Ref{Float32}(0)
@@ -180,6 +224,109 @@ POMDPs.action(p::HIPNNPolicy, o::AbstractArray) = p.action_map[argmax(_q(p, o))]
 POMDPTools.actionvalues(p::HIPNNPolicy, o::AbstractArray) = _q(p, o)
 POMDPs.value(p::HIPNNPolicy, o::AbstractArray) = maximum(_q(p, o))
 sync_target!(p::HIPNNPolicy) = check(ccall((:dqn_sync_target, LIB), Cint, (Ptr{Cvoid},), p.e.h))   # replaces Flux.loadparams! at src/solver.jl:142-145
+function setnetwork!(p::HIPNNPolicy, weights)          # Flux.loadparams!(getnetwork(policy), weights) -> engine (restore_best_model, src/solver.jl:172-174,314-315)
+    Flux.loadparams!(p.qnetwork, weights)
+    flat = flatparams(p.qnetwork)
+    check(ccall((:dqn_set_params, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Float32}, Csize_t), p.e.h, 0, flat, length(flat)))
+    p
+end
+
+# ---- solve / initialize_replay_buffer / dqn_train! routes (src/solver.jl:30-57, :180-189, :59-178): ZERO edits to the package.
+# `solve(MI355XSolver(solver), mdp)` is the one-line change in user code; everything behind it dispatches on the HIP types.
+struct MI355XSolver <: POMDPs.Solver
+    solver::DeepQLearningSolver
+    device::Int
+    obs_u8::Bool
+end
+MI355XSolver(solver::DeepQLearningSolver; device = 0, obs_u8 = false) = MI355XSolver(solver, device, obs_u8)
+POMDPs.solve(s::MI355XSolver, problem::MDP) = solve(s, MDPCommonRLEnv{AbstractArray{Float32}}(problem))       # :30-33
+POMDPs.solve(s::MI355XSolver, problem::POMDP) = solve(s, POMDPCommonRLEnv{AbstractArray{Float32}}(problem))   # :35-38
+function POMDPs.solve(s::MI355XSolver, env::AbstractEnv)                                                       # :40-57
+    solver = s.solver
+    action_map = collect(actions(env))
+    action_indices = Dict(a => i for (i, a) in enumerate(action_map))
+    DeepQLearning.isrecurrent(solver.qnetwork) && !solver.recurrence &&
+        throw("DeepQLearningError: you passed in a recurrent model but recurrence is set to false")
+    active_q = solver.dueling ? DeepQLearning.create_dueling_network(solver.qnetwork) : solver.qnetwork
+    engine = Engine(solver, env, active_q; device = s.device, obs_u8 = s.obs_u8)
+    replay = initialize_replay_buffer(solver, env, action_indices, engine)
+    policy = HIPNNPolicy(env, engine, active_q, action_map, length(DeepQLearning.obs_dimensions(env)))
+    dqn_train!(solver, env, policy, replay)
+end
+HIPNNPolicy(env::MDPCommonRLEnv, e::Engine, q, action_map::Vector, n::Int) = HIPNNPolicy(convert(MDP, env), e, q, action_map, n)       # src/policy.jl:24
+HIPNNPolicy(env::POMDPCommonRLEnv, e::Engine, q, action_map::Vector, n::Int) = HIPNNPolicy(convert(POMDP, env), e, q, action_map, n)   # :25
+
+function initialize_replay_buffer(solver::DeepQLearningSolver, env::AbstractEnv, action_indices, engine::Engine)   # :180-189
+    replay = solver.recurrence ? HIPEpisodeReplayBuffer(engine, solver.rng) : HIPReplayBuffer(engine, solver.rng)
+    populate_replay_buffer!(replay, env, action_indices, max_pop = solver.train_start)
+    replay
+end
+
+# dqn_train! is dispatchable on the policy type (src/solver.jl:59).  The generic method would keep a Flux deepcopy as target network and
+# refresh THAT every target_update_freq steps (:65, :142-145) -- the engine's own target net would never be synced -- so the HIP policy
+# gets its own driver: same cadence (train / target / eval / save / log), same logged scalars, the optimizer, the target network and the
+# hidden-state save/restore around batch_train! (:137-139: the engine keeps the policy's Recur state apart from the train step) inside the engine.
+function dqn_train!(solver::DeepQLearningSolver, env::AbstractEnv, policy::HIPNNPolicy, replay)
+    logger = nothing
+    if solver.logdir !== nothing
+        logger = TBLogger(solver.logdir); solver.logdir = logger.logdir
+    end
+    sync_target!(policy)                                   # target_q = deepcopy(active_q), :65
+    resetstate!(policy); reset!(env); obs = observe(env)
+    action_indices = Dict(a => i for (i, a) in enumerate(actionmap(policy)))
+    ep_rewards = Float64[0.0]; ep_steps = Int64[]; step = 0
+    best_eval = -Inf; scores_eval = -Inf; model_saved = false; eval_next = false; save_next = false
+    loss_val = NaN32; grad_val = NaN32
+    for t in 1:solver.max_steps
+        act = action(solver.exploration_policy, policy, t, obs)
+        rew = act!(env, act); op = observe(env); done = terminated(env)
+        expe = DQExperience(obs, action_indices[act], Float32(rew), op, done)
+        if solver.recurrence
+            add_exp!(replay, expe)
+        else
+            add_exp!(replay, expe, solver.prioritized_replay ? abs(expe.r) : 0f0)     # :91-94
+        end
+        obs = op; step += 1; ep_rewards[end] += rew
+        if done || step >= solver.max_episode_length
+            if eval_next                                   # evaluation waits for the episode to end, :101-122
+                scores_eval, steps_eval, info_eval = DeepQLearning.evaluation(solver.evaluation_policy, policy, env, solver.num_ep_eval,
+                                                                              solver.max_episode_length, solver.verbose)
+                eval_next = false
+                if save_next                               # only right after an evaluation
+                    model_saved, best_eval = DeepQLearning.save_model(solver, getnetwork(policy), scores_eval, best_eval, model_saved)   # qnetwork.bson, :290-300
+                    save_next = false
+                end
+                if logger !== nothing
+                    log_value(logger, "eval_reward", scores_eval, step = t); log_value(logger, "eval_steps", steps_eval, step = t)
+                    for (k, v) in info_eval; log_value(logger, k, v, step = t); end
+                end
+            end
+            reset!(env); obs = observe(env); resetstate!(policy)
+            push!(ep_steps, step); push!(ep_rewards, 0.0); step = 0
+        end
+        if t % solver.train_freq == 0
+            loss_val, grad_val = batch_train!(solver, env, policy, nothing, nothing, replay)      # ONE ccall, :136-140
+        end
+        t % solver.target_update_freq == 0 && sync_target!(policy)                             # :142-145 inside the engine
+        t % solver.eval_freq == 0 && (eval_next = true)
+        t % solver.save_freq == 0 && (save_next = true)
+        if t % solver.log_freq == 0 && logger !== nothing
+            nt = POMDPTools.loginfo(solver.exploration_policy, t)
+            for (k, v) in pairs(nt); log_value(logger, String(k), v, step = t); end
+            avg100 = mean(ep_rewards[max(1, length(ep_rewards) - 101):end])
+            solver.verbose && @printf("%5d / %5d eps %0.3f |  avgR %1.3f | Loss %2.3e | Grad %2.3e | EvalR %1.3f \n",
+                                      t, solver.max_steps, nt[1], avg100, loss_val, grad_val, scores_eval)
+            log_value(logger, "avg_reward", avg100, step = t); log_value(logger, "loss", loss_val, step = t); log_value(logger, "grad_val", grad_val, step = t)
+        end
+    end
+    if model_saved && solver.verbose                       # quirk kept: the best weights come back only if verbose, :170-176
+        @printf("Restore model with eval reward %1.3f \n", best_eval)
+        setnetwork!(policy, BSON.load(joinpath(solver.logdir, "qnetwork.bson"))[:qnetwork])
+    else
+        getnetwork(policy)                                 # leave the Flux model in step with the engine for the caller
+    end
+    policy
+end
 
 # ---- device-resident vectorised environments (dqn_env_spec / dqn_rollout_cfg / dqn_rollout_stats, include/dqn_mi355x.h)
 # the env loop of dqn_train! (src/solver.jl:82-145) for n copies of a built-in MDP without observations crossing PCIe

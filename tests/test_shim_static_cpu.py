@@ -1,7 +1,10 @@
 """CPU: static checks of the Julia ccall shim (deepqlearning.jl_amd/julia/DeepQLearningMI355X.jl), which cannot be executed here (no julia binary):
   * the isbits structs it passes by reference have the C layout of the header's structs (field order, sizes, natural alignment -- Julia lays
     out isbits structs exactly like C), checked against ctypes mirrors that test_abi_cpu.py ties to the header with a compiled C program;
-  * every C entry point it ccalls exists in the header, with the same number of arguments."""
+  * every C entry point it ccalls exists in the header, with the same number of arguments;
+  * METHOD COVERAGE: every generic function the shim imports from DeepQLearning to extend has at least one method typed on a HIP type
+    (an imported-but-never-extended generic -- round 1's populate_replay_buffer! -- would fall through to the package's CPU method or
+    die with a MethodError), and the solve / dqn_train! / initialize_replay_buffer routes exist."""
 import ctypes
 import os
 import re
@@ -109,3 +112,57 @@ def test_every_ccall_names_a_declared_entry_point_with_the_right_arity():
     for must in ("dqn_engine_create", "dqn_train_step", "dqn_replay_add", "dqn_replay_get_batch", "dqn_update_priorities", "dqn_forward", "dqn_sync_target",
                  "dqn_get_params", "dqn_set_params", "dqn_train_step_drqn", "dqn_episode_add", "dqn_reset_state", "dqn_envs_create", "dqn_rollout", "dqn_evaluate"):
         assert must in bound, must
+
+
+def _imported_generics(src):
+    m = re.search(r"import DeepQLearning:(.*?)\n(?=import|export|using|\n)", src, re.S)
+    assert m
+    names = [x.strip() for x in m.group(1).replace("\n", " ").split(",") if x.strip()]
+    return [n for n in names if n[0].islower()]          # types (AbstractNNPolicy, DQExperience, DeepQLearningSolver) start upper-case
+
+
+def test_every_imported_generic_has_a_hip_typed_method():
+    src = re.sub(r"#.*", "", open(SHIM).read())
+    generics = _imported_generics(src)
+    assert {"batch_train!", "add_exp!", "update_priorities!", "get_batch", "populate_replay_buffer!", "is_full", "max_size", "getnetwork", "resetstate!",
+            "actionmap", "initialize_replay_buffer", "dqn_train!"} <= set(generics)
+    hip_types = ("HIPReplayBuffer", "HIPEpisodeReplayBuffer", "HIPNNPolicy", "Engine")
+    def signatures(g):
+        """argument lists of the method DEFINITIONS of g (`function g(...)` or `g(...) = ...` at the start of a line; may span lines)"""
+        out = []
+        for m in re.finditer(r"(?:^|\n)[ \t]*(?:function[ \t]+)?(?:\w+\.)?" + re.escape(g) + r"\(", src):
+            i, depth = m.end(), 1
+            while depth:
+                depth += {"(": 1, ")": -1}.get(src[i], 0); i += 1
+            if m.group(0).lstrip().startswith("function") or re.match(r"\s*(?:where[^=\n]*)?=(?!=)", src[i:]):
+                out.append(src[m.end():i - 1])
+        return out
+
+    for g in generics:
+        sigs = signatures(g)
+        assert any(any("::" + t in sig for t in hip_types) for sig in sigs), (g, sigs)
+    # replay protocol: BOTH replay types serve the whole protocol the driver loop uses (src/solver.jl:89-95,187)
+    for g in ("add_exp!", "populate_replay_buffer!", "is_full", "max_size", "batch_train!"):
+        for t in ("HIPReplayBuffer", "HIPEpisodeReplayBuffer"):
+            assert any("::" + t in sig for sig in signatures(g)), (g, t)
+    # policy protocol (src/policy.jl): action / actionvalues / value on the HIP policy
+    for g in ("POMDPs.action", "POMDPTools.actionvalues", "POMDPs.value"):
+        assert re.search(re.escape(g) + r"\(p::HIPNNPolicy", src), g
+    # routes: solve on the wrapper solver for MDP, POMDP and raw AbstractEnv (src/solver.jl:30-57); dqn_train! on the HIP policy (:59)
+    for t in ("MDP", "POMDP", "AbstractEnv"):
+        assert re.search(r"POMDPs\.solve\(s::MI355XSolver,\s*\w+::" + t + r"\)", src), t
+    assert re.search(r"function dqn_train!\(solver::DeepQLearningSolver, env::AbstractEnv, policy::HIPNNPolicy, replay\)", src)
+    assert "sync_target!(policy)" in src and "Flux.loadparams!(target_q" not in src     # the engine's target net is the one that is synced
+    assert re.search(r"function initialize_replay_buffer\(solver::DeepQLearningSolver, env::AbstractEnv, action_indices, engine::Engine\)", src)
+
+
+def test_julia_delimiters_balance():
+    """the shim cannot be parsed here; at least its (), [], {} and function/struct/for/if/while/begin ... end blocks balance"""
+    src = re.sub(r'"(?:[^"\\]|\\.)*"', '""', open(SHIM).read())
+    src = re.sub(r"#.*", "", src)
+    for a, b in ("()", "[]", "{}"):
+        assert src.count(a) == src.count(b), (a, src.count(a), src.count(b))
+    opens = len(re.findall(r"(?<![\w!.:])(?:function|struct|if|while|begin|module|do|let|try)\b(?!\s*=)", src))
+    opens += len(re.findall(r"(?:^|;|\n)[ \t]*for\b", src))       # statement-level `for` only: comprehensions / generators carry no `end`
+    ends = len(re.findall(r"(?<![\w!.:\[])end\b", src))
+    assert opens == ends, (opens, ends)
