@@ -134,23 +134,52 @@ struct TdArgs {
     StepState* st;
 };
 
+// ---- fused head kernel (small batches): head forwards of both nets + dueling reduce + argmax + Bellman target + TD + Huber + dL/dQ +
+// the head layers' dX, ONE workgroup per batch column (nn_valu.hip: k_head_td).  A head layer reads its input column(s) straight from the
+// producing layer's finished activations (or the observation arena): online net columns c0 + b (s) and c0 + B + b (sp), target net column c0 + b.
+struct HeadLayer {
+    int K, N, S, kc, act;                       // forward contraction K -> N in S chunks of kc (plan fwd_kc), head activation
+    const float *W[2], *bias[2];                // [net]: online, target
+    const float* X[2]; int ldx[2], c0[2];       // [net]
+    const float* XT[2];                         // [net] optional transposed copy [column][K] of X (see RSeg::outT); column index as for X
+    float* dpre;                                // [N][B]: dL/d(pre-activation) of the head (read by the head's dW task)
+    float* dsrc; const float* ysrc; int ldy, act_src;   // dX: dsrc[K][B] = dact(W * dpre, ysrc[k][b]); null when the head reads the observation
+};
+struct HeadTdArgs {
+    int B, nA, dueling, double_q, bump_sample_ctr, join;     // join: both heads read the SAME producer (dX_val + dX_adv, src/dueling.jl:10 backward)
+    int stage_w;                                             // the head weights of both nets are staged in LDS (they fit; K*N % 4 == 0)
+    int dbg;                                                 // timing experiments only (env DQN_HEAD_DBG): return after phase dbg (0 = run everything)
+    float gamma, prio_beta; long long cap2;
+    const int* bm_a; const float *bm_r, *bm_done, *bm_w;      // batch scalars of the B columns (written by the gather launch)
+    HeadLayer val, adv;                         // adv doubles as the plain Q head when !dueling
+    float *w_is, *td, *q_on_s, *q_on_sp, *q_tg_sp, *ytarget, *hl; int* best;
+    StepState* st;
+};
+size_t head_td_lds_bytes(const HeadTdArgs& a);
+void launch_head_td(hipStream_t st, const HeadTdArgs& a, const HeadTdArgs* a_dev, int bump_sample_ctr);   // a_dev: the same record in device memory
+
 // task / segment tables of the batched small kernels (device-resident, built once per engine)
 struct VTask {
-    int kind;                          // 0 forward, 1 dW/db, 2 dX
+    int kind;                          // 0 forward, 1 dW/db, 2 dX, 3 loss fold (dpre = B Huber terms, out = &state->loss)
     LayerDev L; const float* P; const float* X; int ldx, col0, ncols; const float* dpre; int B; float* out; int S, kc;
     const float* addend; const float* ysrc; int ldy, act_src; unsigned first_block;
 };
 struct RSeg {
     const float* part; int S, S2; unsigned long long elems; int mode; const float* bias; int per_n, act;
     const float* addend; const float* ysrc; int B, ldy; float* out; unsigned first_block;
+    float* outT; int ncolsT;           // mode 0, optional: a TRANSPOSED copy outT[col][feature] (feature contiguous) of the [feature][ncolsT] activation,
+                                       // so that the fused head kernel reads a batch column as one contiguous run instead of one 128-B line per element
 };
 unsigned valu_task_blocks(const VTask& T);
 void launch_valu_multi(hipStream_t st, const VTask* tasks_dev, int ntasks, unsigned total_blocks);
 void launch_reduce_multi(hipStream_t st, const RSeg* segs_dev, int nseg, unsigned total_blocks);
 
+// get_batch scalars of the sampled transitions (a, r, done, IS weight: ...replay.jl:93-102), written by ONE workgroup of the gather launch
+// for the fused head kernel (a_out == nullptr: not wanted)
+struct BatchMeta { const int* a; const float* r; const unsigned char* done; float beta; int* a_out; float* r_out; float* done_out; float* w_out; };
 void launch_gather_fb(hipStream_t st, const void* s_rows, const void* sp_rows, int obs_u8, int E, int B,
                       long long* idx, float* x0 /*[E][2B]*/, int do_sample, long long cap2, const float* tree, unsigned long long seed,
-                      const StepState* state);
+                      const StepState* state, const BatchMeta& meta);
 void launch_gather_rows(hipStream_t st, const void* rows, int obs_u8, int E, int n, const long long* idx, float* out /*[n][E]*/);
 void launch_transpose_obs(hipStream_t st, const float* obs /*[n][E]*/, int E, int n, float* x /*[E][n]*/);
 void launch_replay_commit(hipStream_t st, int n, long long start, long long cap, long long cap2, const int* a_in, const float* r_in,
@@ -289,15 +318,18 @@ void launch_dp_unpack_sum(hipStream_t st, const DpSumArgs& a);
 // MFMA path (nn_mfma.hip): returns false if the shape is not eligible (caller falls back to the VALU kernel,
 // which computes bit-identical values)
 bool gemm_dw_eligible(const LayerDev& L, int B, int ldx);
+// a TAIL of small independent VALU tasks (valu_tasks.h) riding in the last workgroups of an LDS-tiled launch
+struct GemmTail { const VTask* tasks; int n; unsigned blocks; };
 void launch_gemm_dw(hipStream_t st, const LayerDev& L, int nprob, const float* const* X, int ldx, const float* const* dpre, int B, float* const* out,
-                    int ldd = 0, int tpr = 0, int rstride = 0);   // 0 = plain layout; else gathered rank blocks (see DwStride in nn_gemm.hip)
+                    int ldd = 0, int tpr = 0, int rstride = 0, GemmTail tail = GemmTail{nullptr, 0, 0});   // ldd 0 = plain layout; else gathered rank blocks (see DwStride in nn_gemm.hip)
 
 bool gemm_dx_eligible(const LayerDev& L, int B, int ldy);
 void launch_gemm_dx(hipStream_t st, const LayerDev& L, int nsrc, const float* const* W, const float* const* dpre, int B, float* out /* dact or partial slabs */,
-                    const float* ysrc, int ldy, int act_src);
+                    const float* ysrc, int ldy, int act_src, GemmTail tail = GemmTail{nullptr, 0, 0});
 
 void launch_gemm_dwdx(hipStream_t st, const LayerDev& Lw, int nprob, const float* const* X, int ldx, const float* const* dpre_w, int B, float* const* out_w,
-                      const LayerDev& Lx, int nsrc, const float* const* W, const float* const* dpre_x, float* out_x, const float* ysrc, int ldy, int act_src);
+                      const LayerDev& Lx, int nsrc, const float* const* W, const float* const* dpre_x, float* out_x, const float* ysrc, int ldy, int act_src,
+                      GemmTail tail = GemmTail{nullptr, 0, 0});
 
 // (reduce == false leaves split-K partial slabs in `partials` for the caller's batched k_reduce_multi)
 bool mfma_fwd_ok(const LayerDev& L, int ncols);

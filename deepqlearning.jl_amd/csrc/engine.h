@@ -39,6 +39,8 @@ struct dqn_engine {
     float *w_is = nullptr, *td = nullptr, *q_on_s = nullptr, *q_on_sp = nullptr, *q_tg_sp = nullptr, *ytarget = nullptr; int* best = nullptr;
     // get_batch seam workspace
     float *gb_rows = nullptr, *gb_r = nullptr, *gb_done = nullptr, *gb_w = nullptr; int* gb_a = nullptr; long long* gb_idx = nullptr;
+    // train-step batch scalars (written by the gather launch, read by the fused head kernel)
+    float *gb_r2 = nullptr, *gb_done2 = nullptr, *gb_w2 = nullptr; int* gb_a2 = nullptr;
     // policy workspace
     EnvDev env{}; bool has_envs = false; unsigned char* env_images = nullptr;
     int pol_n = 0; float *pol_obs = nullptr, *pol_x = nullptr, *pol_act[DQN_MAX_LAYERS] = {}, *pol_q = nullptr; int* pol_a = nullptr;

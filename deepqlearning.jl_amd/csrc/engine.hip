@@ -216,6 +216,7 @@ static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers
     DM(e->w_is, B); DM(e->td, Bc); DM(e->q_on_s, (size_t)B * e->nA); DM(e->q_on_sp, (size_t)B * e->nA); DM(e->q_tg_sp, (size_t)B * e->nA);
     DM(e->ytarget, B); DM(e->best, B);
     DM(e->gb_rows, (size_t)B * e->E); DM(e->gb_r, B); DM(e->gb_done, B); DM(e->gb_w, B); DM(e->gb_a, B); DM(e->gb_idx, B);
+    DM(e->gb_r2, B); DM(e->gb_done2, B); DM(e->gb_w2, B); DM(e->gb_a2, B);
     HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
 }
@@ -251,6 +252,7 @@ extern "C" int dqn_engine_destroy(dqn_engine_t* e) {
     for (int i = 0; i < e->nl; i++) { hipFree(e->act_on[i]); hipFree(e->act_tg[i]); hipFree(e->dact[i]); }
     hipFree(e->join_tmp); hipFree(e->partials); hipFree(e->gmax_part); hipFree(e->w_is); hipFree(e->td); hipFree(e->q_on_s); hipFree(e->q_on_sp); hipFree(e->q_tg_sp);
     hipFree(e->ytarget); hipFree(e->best); hipFree(e->gb_rows); hipFree(e->gb_r); hipFree(e->gb_done); hipFree(e->gb_w); hipFree(e->gb_a); hipFree(e->gb_idx);
+    hipFree(e->gb_r2); hipFree(e->gb_done2); hipFree(e->gb_w2); hipFree(e->gb_a2);
     free_policy_ws(e); free_envs(e); hipFree(e->dp_send); hipFree(e->dp_recv);
     for (void* p : e->prog_allocs) hipFree(p);
     hipFree(e->ep_s); hipFree(e->ep_sp); hipFree(e->ep_a); hipFree(e->ep_r); hipFree(e->ep_done); hipFree(e->ep_len); hipFree(e->ep_idx); hipFree(e->ep_start);
@@ -475,8 +477,9 @@ void enqueue_step(dqn_engine* e, bool sample, int phase) {
             // small batches.  At B = 512 / 1e6 leaves the repeats cost more than the ~5 us launch, so sample once, then gather.
             const bool fused = sample && e->B <= 64;
             if (sample && !fused) RUN(e, "sample", launch_sample(e->stream, e->B, e->cap2, e->tree, e->hp.seed, e->idx, e->state, 0));    // k_td bumps the Philox counter
+            BatchMeta bm; bm.a = e->ra; bm.r = e->rr; bm.done = e->rdone; bm.beta = e->hp.prio_beta; bm.a_out = e->gb_a2; bm.r_out = e->gb_r2; bm.done_out = e->gb_done2; bm.w_out = e->gb_w2;
             RUN(e, fused ? "sample_gather" : "gather", launch_gather_fb(e->stream, e->s_rows, e->sp_rows, e->hp.obs_dtype == DQN_OBS_U8, e->E, e->B, e->idx, e->x0,
-                                                                        fused ? 1 : 0, e->cap2, e->tree, e->hp.seed, e->state));
+                                                                        fused ? 1 : 0, e->cap2, e->tree, e->hp.seed, e->state, bm));
         }
         for (size_t i = 0; i < e->prog_post_begin; i++) {
             if ((long)i == e->final_reduce_step && ((e->adam_segs.n > 0 && !e->comm && !e->sim_world) || (e->dp_gather && e->dp_pack_folds))) continue;   // folded into k_adam / k_dp_pack   // folded into k_adam

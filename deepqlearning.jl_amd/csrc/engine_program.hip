@@ -47,12 +47,34 @@ int build_program(dqn_engine* e) {
     std::vector<std::vector<int>> levels; std::vector<int> val, adv;
     for (int i = 0; i < e->nl; i++) { if (e->L[i].stream == DQN_STREAM_BASE) levels.push_back({i}); else if (e->L[i].stream == DQN_STREAM_VAL) val.push_back(i); else adv.push_back(i); }
     for (size_t j = 0; j < std::max(val.size(), adv.size()); j++) { std::vector<int> lv; if (j < val.size()) lv.push_back(val[j]); if (j < adv.size()) lv.push_back(adv[j]); levels.push_back(lv); }
+    // ---------------- small batches: the head level (forwards of both nets), the TD kernel and the head layers' dX run as ONE launch with a
+    // workgroup per batch column (k_head_td); the heads' dW/db and the loss fold ride as tail tasks of the next backward launch
+    int hv_l = -1, ha_l = -1; bool fuse_heads = false;
+    if (!rec && e->B <= 64 && getenv("DQN_NO_HEAD_FUSE") == nullptr) {
+        const auto& lv = levels.back();
+        if (e->hp.dueling && lv.size() == 2 && lv[0] == e->last_val && lv[1] == e->last_adv) { hv_l = lv[0]; ha_l = lv[1]; }
+        else if (!e->hp.dueling && lv.size() == 1 && lv[0] == e->last_base) ha_l = lv[0];
+        if (ha_l >= 0) {
+            fuse_heads = true; size_t lds = (size_t)(1 + e->nA) * 4;
+            for (int l : lv) {
+                const LayerDev& L = e->L[l];
+                fuse_heads = fuse_heads && L.kind == DQN_LAYER_DENSE && dqn_nchunks(B, L.dw_kc) == 1 && dqn_nchunks(L.N, L.dx_kc) == 1 && (L.src < 0 || e->L[L.src].kind != DQN_LAYER_LSTM);
+                lds += ((size_t)3 * L.K + (size_t)3 * L.N * dqn_nchunks(L.K, L.fwd_kc) + (size_t)3 * L.N) * 4;
+            }
+            fuse_heads = fuse_heads && lds <= 60 * 1024;
+        }
+    }
+    float* hl_buf = fuse_heads ? palloc(e, (size_t)B) : nullptr;      // per-column Huber terms (folded into the loss by a tail task)
+    float* actT[DQN_MAX_LAYERS][2] = {};                             // transposed copies [column][feature] of the head layers' inputs (written by the split-K reduce)
+    bool wantT[DQN_MAX_LAYERS] = {};
+    if (fuse_heads) for (int l : levels.back()) if (e->L[l].src >= 0) wantT[e->L[l].src] = true;
     HeadSrc head[DQN_MAX_LAYERS][2];   // per (layer, net): where k_td finds the layer's output
     // ---------------- forward: online net on [s ; sp] (src/solver.jl:210,220), target net on sp (:211)
     for (size_t li = 0; li < levels.size(); li++) {
         // the head layers' split-K slabs are reduced inside the single-workgroup TD kernel only while that is cheaper than a reduce
         // launch (small batches); at B = 512 the 7680 head values x 16 slabs belong on many workgroups
         const auto& lv = levels[li]; const bool last = li + 1 == levels.size() && !rec && e->B <= 64;
+        if (fuse_heads && li + 1 == levels.size()) continue;      // computed inside k_head_td
         struct Prob { int l, net; const float *P, *X; int ldx, col0, ncols; float *Y, *part; int S; };
         std::vector<Prob> pr;
         for (int l : lv) for (int net = 0; net < 2; net++) {
@@ -98,7 +120,9 @@ int build_program(dqn_engine* e) {
             HeadSrc h; h.p = q.Y; h.ld = q.ncols; h.S = 1; h.per_s = 0; h.bias = q.P + L.b_off; h.act = L.act;
             if (q.S > 1) {
                 if (last) { h.p = q.part; h.S = q.S; h.per_s = (unsigned long long)L.out_feat * q.ncols; }   // reduced on the fly by k_td
-                else { RSeg r; memset(&r, 0, sizeof r); r.part = q.part; r.S = q.S; r.elems = (unsigned long long)L.out_feat * q.ncols; r.mode = 0; r.bias = q.P + L.b_off; r.per_n = L.npos * q.ncols; r.act = L.act; r.out = q.Y; segs.push_back(r); }
+                else { RSeg r; memset(&r, 0, sizeof r); r.part = q.part; r.S = q.S; r.elems = (unsigned long long)L.out_feat * q.ncols; r.mode = 0; r.bias = q.P + L.b_off; r.per_n = L.npos * q.ncols; r.act = L.act; r.out = q.Y;
+                       if (wantT[q.l]) { r.outT = actT[q.l][q.net] = palloc(e, (size_t)L.out_feat * q.ncols); r.ncolsT = q.ncols; }
+                       segs.push_back(r); }
             }
             head[q.l][q.net] = h;
         }
@@ -145,7 +169,35 @@ int build_program(dqn_engine* e) {
         t.on_adv = head[lq][0]; t.tg_adv = head[lq][1]; t.d_adv = e->dact[lq];
         if (e->hp.dueling) { t.on_val = head[e->last_val][0]; t.tg_val = head[e->last_val][1]; t.d_val = e->dact[e->last_val]; }
         t.w_is = e->w_is; t.td = e->td; t.q_on_s = e->q_on_s; t.q_on_sp = e->q_on_sp; t.q_tg_sp = e->q_tg_sp; t.ytarget = e->ytarget; t.best = e->best; t.st = e->state;
-        if (!rec) e->prog.push_back({"td_huber", [=](dqn_engine* en) { TdArgs a = t; a.bump_sample_ctr = en->step_sampled ? 1 : 0; launch_td(en->stream, a); }});
+        if (fuse_heads) {
+            HeadTdArgs h; memset(&h, 0, sizeof h);
+            h.B = B; h.nA = e->nA; h.dueling = e->hp.dueling; h.double_q = e->hp.double_q; h.gamma = e->hp.gamma; h.prio_beta = e->hp.prio_beta; h.cap2 = e->cap2;
+            h.bm_a = e->gb_a2; h.bm_r = e->gb_r2; h.bm_done = e->gb_done2; h.bm_w = e->gb_w2;
+            h.w_is = e->w_is; h.td = e->td; h.q_on_s = e->q_on_s; h.q_on_sp = e->q_on_sp; h.q_tg_sp = e->q_tg_sp; h.ytarget = e->ytarget; h.best = e->best; h.st = e->state;
+            h.hl = hl_buf;
+            auto fill = [&](HeadLayer& H, int l) {
+                const LayerDev& L = e->L[l];
+                H.K = L.K; H.N = L.N; H.S = dqn_nchunks(L.K, L.fwd_kc); H.kc = dqn_chunk_len(L.K, L.fwd_kc); H.act = L.act;
+                H.W[0] = e->p_on + L.w_off; H.bias[0] = e->p_on + L.b_off; H.W[1] = e->p_tg + L.w_off; H.bias[1] = e->p_tg + L.b_off;
+                if (L.src < 0) { H.X[0] = H.X[1] = e->x0; H.ldx[0] = H.ldx[1] = ld0; H.c0[0] = 0; H.c0[1] = B; }
+                else { H.X[0] = e->act_on[L.src]; H.ldx[0] = ncon; H.c0[0] = 0; H.X[1] = e->act_tg[L.src]; H.ldx[1] = B; H.c0[1] = 0; H.XT[0] = actT[L.src][0]; H.XT[1] = actT[L.src][1]; }
+                H.dpre = e->dact[l];
+                if (L.src >= 0) { H.dsrc = e->dact[L.src]; H.ysrc = e->act_on[L.src]; H.ldy = ncon; H.act_src = e->L[L.src].act; }
+            };
+            fill(h.adv, ha_l);
+            if (hv_l >= 0) { fill(h.val, hv_l); h.join = (e->L[hv_l].src == e->L[ha_l].src && e->L[ha_l].src >= 0) ? 1 : 0; }
+            {   // stage the head weights in LDS when they fit beside the input columns
+                bool ok = true; size_t wb = 0;
+                for (int l : levels.back()) { const LayerDev& L = e->L[l]; ok = ok && ((size_t)L.K * L.N) % 4 == 0 && L.w_off % 4 == 0; wb += (size_t)2 * L.K * L.N * 4; }
+                h.stage_w = 0;
+                if (ok) { h.stage_w = 1; if (head_td_lds_bytes(h) > 60 * 1024) h.stage_w = 0; }
+                (void)wb;
+            }
+            if (const char* dv = getenv("DQN_HEAD_DBG")) h.dbg = atoi(dv);
+            const HeadTdArgs* h_dev = upload(e, std::vector<HeadTdArgs>(1, h));
+            e->prog.push_back({"head_td", [=](dqn_engine* en) { launch_head_td(en->stream, h, h_dev, en->step_sampled ? 1 : 0); }});
+        }
+        else if (!rec) e->prog.push_back({"td_huber", [=](dqn_engine* en) { TdArgs a = t; a.bump_sample_ctr = en->step_sampled ? 1 : 0; launch_td(en->stream, a); }});
         else {
             TdDrqnArgs d; memset(&d, 0, sizeof d); d.B = Bb; d.T = T; d.nA = e->nA; d.ncon = ncon; d.dueling = e->hp.dueling; d.double_q = e->hp.double_q; d.gamma = e->hp.gamma;
             d.on_val = t.on_val; d.on_adv = t.on_adv; d.tg_val = t.tg_val; d.tg_adv = t.tg_adv; d.d_val = t.d_val; d.d_adv = t.d_adv;
@@ -177,9 +229,28 @@ int build_program(dqn_engine* e) {
     // ---------------- backward of the online net on the s columns (Zygote through src/solver.jl:219-225)
     std::vector<RSeg> final_segs;   // dW split-K slabs: nothing reads the gradient before Adam, so ONE reduce launch at the end
     bool joined = false;
+    std::vector<VTask> tail_pend;    // small tasks waiting for a launch to ride on (fused heads: their dW/db and the loss fold)
+    auto make_tail = [&](std::vector<VTask>& v) {
+        GemmTail t{nullptr, 0, 0};
+        if (v.empty()) return t;
+        unsigned blocks = 0;
+        for (auto& q : v) { q.first_block = blocks; blocks += valu_task_blocks(q); }
+        t.tasks = upload(e, v); t.n = (int)v.size(); t.blocks = blocks; v.clear();
+        return t;
+    };
     for (int li = (int)levels.size() - 1; li >= 0; li--) {
         const auto& lv = levels[li];
         std::vector<VTask> pend;
+        if (fuse_heads && li + 1 == (int)levels.size()) {
+            // the head layers' dX already ran inside k_head_td; their dW/db (one B-long chain per weight) and the loss fold are tail tasks
+            for (int l : lv) {
+                const LayerDev L = e->L[l];
+                VTask t; memset(&t, 0, sizeof t); t.kind = 1; t.L = L; t.X = L.src < 0 ? e->x0 : e->act_on[L.src]; t.ldx = L.src < 0 ? ld0 : ncon; t.dpre = e->dact[l]; t.B = B; t.S = 1; t.kc = B;
+                t.out = e->grad + L.w_off; tail_pend.push_back(t);
+            }
+            VTask f; memset(&f, 0, sizeof f); f.kind = 3; f.dpre = hl_buf; f.B = B; f.out = &e->state->loss; tail_pend.push_back(f);
+            continue;
+        }
         bool dw_done_sibling = false;   // the level's two sibling layers got their dW from one fused launch
         struct DwL { bool on = false; LayerDev L; int nprob = 0; const float* X[2]; int ldx = 0; const float* d[2]; float* o[2]; const char* name = ""; } dwl;
         struct DxL { bool on = false; LayerDev L; int nsrc = 0; const float* W[2]; const float* d[2]; float* out = nullptr; const float* ys = nullptr; int act_src = 0; const char* name = ""; } dxl;
@@ -282,14 +353,22 @@ int build_program(dqn_engine* e) {
                 emit_reduce(e, one, pname(e, "dx_reduce", L.kind, l));
             }
         }
+        GemmTail tail{nullptr, 0, 0};
+        if (!tail_pend.empty()) {
+            if (dwl.on || dxl.on) tail = make_tail(tail_pend);                       // rides in the last workgroups of this level's LDS-tiled launch
+            else { for (auto& t : tail_pend) pend.push_back(t); tail_pend.clear(); } // or joins this level's VALU task table
+        }
         flush_valu(e, pend, pname(e, "bwd_valu", e->L[lv[0]].kind, lv[0]));
         if (dwl.on && dxl.on) {      // dW and dX of this level in ONE launch
             const DwL a = dwl; const DxL x = dxl; dwl.on = dxl.on = false;
             char nm[48]; snprintf(nm, sizeof nm, "%s+%s", a.name, x.name); e->prog_names.push_back(nm); const char* name = e->prog_names.back().c_str();
-            e->prog.push_back({name, [=](dqn_engine* en) { launch_gemm_dwdx(en->stream, a.L, a.nprob, a.X, a.ldx, a.d, B, a.o, x.L, x.nsrc, x.W, x.d, x.out, x.ys, ncon, x.act_src); }});
+            e->prog.push_back({name, [=](dqn_engine* en) { launch_gemm_dwdx(en->stream, a.L, a.nprob, a.X, a.ldx, a.d, B, a.o, x.L, x.nsrc, x.W, x.d, x.out, x.ys, ncon, x.act_src, tail); }});
         }
+        else if (dwl.on) { const DwL a = dwl; dwl.on = false; e->prog.push_back({a.name, [=](dqn_engine* en) { launch_gemm_dw(en->stream, a.L, a.nprob, a.X, a.ldx, a.d, B, a.o, 0, 0, 0, tail); }}); }
+        else if (dxl.on) { const DxL a = dxl; dxl.on = false; e->prog.push_back({a.name, [=](dqn_engine* en) { launch_gemm_dx(en->stream, a.L, a.nsrc, a.W, a.d, B, a.out, a.ys, ncon, a.act_src, tail); }}); }
         flush_dw(); flush_dx();
     }
+    if (!tail_pend.empty()) { std::vector<VTask> own(tail_pend); tail_pend.clear(); flush_valu(e, own, "head_dw"); }      // single-level network: nothing to ride on
     if (e->prio_forked) e->prog.push_back({"prio_join", [](dqn_engine* en) { hipStreamWaitEvent(en->stream, en->ev_join, 0); }});
     memset(&e->adam_segs, 0, sizeof e->adam_segs);
     {

@@ -12,6 +12,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "valu_tasks.h"
 #include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -358,25 +359,27 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
     if (do_bias) out[(size_t)L.K * L.N + n0 + tid] = dbacc;
 }
 template <int NT>
-__global__ __launch_bounds__(256) void k_dw_lds(LayerDev L, GDwProbs pr, int nprob, int ldx, int B, int S, int kc, DwStride ds) {
-    dw_lds_body<NT>(L, pr, nprob, ldx, B, S, kc, blockIdx.x, gridDim.x, ds);
+__global__ __launch_bounds__(256) void k_dw_lds(LayerDev L, GDwProbs pr, int nprob, int ldx, int B, int S, int kc, DwStride ds, GemmTail tail) {
+    const int main_blocks = (int)gridDim.x - (int)tail.blocks;
+    if ((int)blockIdx.x >= main_blocks) { valu_task_run(tail.tasks, tail.n, blockIdx.x - main_blocks); return; }
+    dw_lds_body<NT>(L, pr, nprob, ldx, B, S, kc, blockIdx.x, main_blocks, ds);
 }
 bool gemm_dw_eligible(const LayerDev& L, int B, int ldx) {
     const int KK = L.npos * B, S = dqn_nchunks(KK, L.dw_kc), kc = dqn_chunk_len(KK, L.dw_kc);
     return !(L.N % 16 || B % 32 || ldx % 4 || L.K < 16 || (S > 1 && kc % B));
 }
 // nprob (<= 2) sibling layers of identical geometry in one launch; out[i] = gradient base (S == 1) or partial slab base
-void launch_gemm_dw(hipStream_t st, const LayerDev& L, int nprob, const float* const* X, int ldx, const float* const* dpre, int B, float* const* out, int ldd, int tpr, int rstride) {
+void launch_gemm_dw(hipStream_t st, const LayerDev& L, int nprob, const float* const* X, int ldx, const float* const* dpre, int B, float* const* out, int ldd, int tpr, int rstride, GemmTail tail) {
     const int KK = L.npos * B, S = dqn_nchunks(KK, L.dw_kc), kc = dqn_chunk_len(KK, L.dw_kc);
     const DwStride ds = {ldd > 0 ? ldd : L.npos * B, tpr, rstride};
     GDwProbs pr;
     for (int i = 0; i < 2; i++) { const int j = i < nprob ? i : 0; pr.p[i].X = X[j]; pr.p[i].dpre = dpre[j]; pr.p[i].out = out[j]; }
     const int NT = L.N % 64 == 0 ? 4 : (L.N % 32 == 0 ? 2 : 1);
-    const int grid = ((L.K + 63) / 64) * (L.N / (16 * NT)) * S * nprob;
+    const int grid = ((L.K + 63) / 64) * (L.N / (16 * NT)) * S * nprob + (int)tail.blocks;
     const size_t lds = (size_t)(2 * 64 * W_ST + 2 * 16 * NT * W_ST) * 4;
-    if (NT == 4) hipLaunchKernelGGL((k_dw_lds<4>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds);
-    else if (NT == 2) hipLaunchKernelGGL((k_dw_lds<2>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds);
-    else hipLaunchKernelGGL((k_dw_lds<1>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds);
+    if (NT == 4) hipLaunchKernelGGL((k_dw_lds<4>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, tail);
+    else if (NT == 2) hipLaunchKernelGGL((k_dw_lds<2>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, tail);
+    else hipLaunchKernelGGL((k_dw_lds<1>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, tail);
 }
 
 // =====================================================================================================================
@@ -588,18 +591,22 @@ __device__ __forceinline__ void dx_lds_body_pj(const LayerDev& L, const GDxArgs&
 static bool dx_parallel_join(const LayerDev& L, int nsrc, int S) { return nsrc == 2 && S == 1 && L.kind == DQN_LAYER_DENSE && (L.N / 32) % 2 == 0; }
 static size_t dx_lds_bytes(bool pj) { return pj ? (size_t)(2 * 2 * 32 * X_SA + 2 * 2 * 32 * X_SB) * 4 : (size_t)(2 * 32 * X_SA + 2 * 32 * X_SB) * 4 + 256 * 4; }
 
-__global__ __launch_bounds__(256) void k_dx_lds(LayerDev L, GDxArgs A, int B, int S, int kc, int pj) {
-    if (pj) dx_lds_body_pj(L, A, B, blockIdx.x, gridDim.x, blockIdx.y);
-    else dx_lds_body(L, A, B, S, kc, blockIdx.x, gridDim.x, blockIdx.y);
+__global__ __launch_bounds__(256) void k_dx_lds(LayerDev L, GDxArgs A, int B, int S, int kc, int pj, int gx, GemmTail tail) {
+    const int main_blocks = (int)gridDim.x - (int)tail.blocks;
+    if ((int)blockIdx.x >= main_blocks) { valu_task_run(tail.tasks, tail.n, blockIdx.x - main_blocks); return; }
+    if (pj) dx_lds_body_pj(L, A, B, blockIdx.x % gx, gx, blockIdx.x / gx);
+    else dx_lds_body(L, A, B, S, kc, blockIdx.x % gx, gx, blockIdx.x / gx);
 }
 // dW and dX of one layer are independent given dpre: ONE launch runs both (blocks [0, dw_blocks) do dW, the rest dX), which
 // saves a dispatch and lets the latency-bound dX workgroups share the machine with the dW ones.
 template <int NT>
 __global__ __launch_bounds__(256) void k_dwdx_lds(LayerDev Lw, GDwProbs pr, int nprob, int ldx, int B, int Sw, int kcw, int dw_blocks,
-                                                  LayerDev Lx, GDxArgs A, int Sx, int kcx, int dx_gx, int pj) {
+                                                  LayerDev Lx, GDxArgs A, int Sx, int kcx, int dx_gx, int pj, GemmTail tail) {
     // the few, long-latency dX workgroups are dispatched FIRST so that they run for the whole kernel while the many short dW
-    // workgroups fill the remaining CUs (dispatch order is blockIdx order)
-    const int dx_blocks = (int)gridDim.x - dw_blocks;
+    // workgroups fill the remaining CUs (dispatch order is blockIdx order); a tail of small VALU tasks comes last
+    const int main_blocks = (int)gridDim.x - (int)tail.blocks;
+    if ((int)blockIdx.x >= main_blocks) { valu_task_run(tail.tasks, tail.n, blockIdx.x - main_blocks); return; }
+    const int dx_blocks = main_blocks - dw_blocks;
     if ((int)blockIdx.x < dx_blocks) { if (pj) dx_lds_body_pj(Lx, A, B, blockIdx.x % dx_gx, dx_gx, blockIdx.x / dx_gx); else dx_lds_body(Lx, A, B, Sx, kcx, blockIdx.x % dx_gx, dx_gx, blockIdx.x / dx_gx); }
     else dw_lds_body<NT>(Lw, pr, nprob, ldx, B, Sw, kcw, blockIdx.x - dx_blocks, dw_blocks, DwStride{Lw.npos * B, 0, 0});
 }
@@ -612,18 +619,18 @@ bool gemm_dx_eligible(const LayerDev& L, int B, int ldy) {
 }
 // nsrc == 2: the two dueling streams (identical geometry, S == 1), out = dact(dX_src0 + dX_src1)
 void launch_gemm_dx(hipStream_t st, const LayerDev& L, int nsrc, const float* const* W, const float* const* dpre, int B, float* out,
-                    const float* ysrc, int ldy, int act_src) {
+                    const float* ysrc, int ldy, int act_src, GemmTail tail) {
     const bool dense = L.kind == DQN_LAYER_DENSE;
     const int S = dense ? dqn_nchunks(L.N, L.dx_kc) : 1, kc = dqn_chunk_len(L.N, L.dx_kc);
     GDxArgs a; a.nsrc = nsrc; a.out = out; a.ysrc = ysrc; a.ldy = ldy; a.act_src = act_src;
     for (int i = 0; i < 2; i++) { const int j = i < nsrc ? i : 0; a.src[i].W = W[j]; a.src[i].dpre = dpre[j]; }
     const int gx = dense ? ((L.K + 31) / 32) * S : (L.cin / 32) * L.ih * L.iw;
     const bool pj = dx_parallel_join(L, nsrc, S);
-    hipLaunchKernelGGL(k_dx_lds, dim3(gx, B / 32), dim3(256), dx_lds_bytes(pj), st, L, a, B, S, kc, pj ? 1 : 0);
+    hipLaunchKernelGGL(k_dx_lds, dim3(gx * (B / 32) + tail.blocks), dim3(256), dx_lds_bytes(pj), st, L, a, B, S, kc, pj ? 1 : 0, gx, tail);
 }
 
 void launch_gemm_dwdx(hipStream_t st, const LayerDev& Lw, int nprob, const float* const* X, int ldx, const float* const* dpre_w, int B, float* const* out_w,
-                      const LayerDev& Lx, int nsrc, const float* const* W, const float* const* dpre_x, float* out_x, const float* ysrc, int ldy, int act_src) {
+                      const LayerDev& Lx, int nsrc, const float* const* W, const float* const* dpre_x, float* out_x, const float* ysrc, int ldy, int act_src, GemmTail tail) {
     const int KK = Lw.npos * B, Sw = dqn_nchunks(KK, Lw.dw_kc), kcw = dqn_chunk_len(KK, Lw.dw_kc);
     GDwProbs pr;
     for (int i = 0; i < 2; i++) { const int j = i < nprob ? i : 0; pr.p[i].X = X[j]; pr.p[i].dpre = dpre_w[j]; pr.p[i].out = out_w[j]; }
@@ -637,8 +644,8 @@ void launch_gemm_dwdx(hipStream_t st, const LayerDev& Lw, int nprob, const float
     const bool pj = dx_parallel_join(Lx, nsrc, Sx);
     const size_t lds_w = (size_t)(2 * 64 * W_ST + 2 * 16 * NT * W_ST) * 4, lds_x = dx_lds_bytes(pj);
     const size_t lds = lds_w > lds_x ? lds_w : lds_x;
-    const int grid = dw_blocks + gx * (B / 32);
-    if (NT == 4) hipLaunchKernelGGL((k_dwdx_lds<4>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, pj ? 1 : 0);
-    else if (NT == 2) hipLaunchKernelGGL((k_dwdx_lds<2>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, pj ? 1 : 0);
-    else hipLaunchKernelGGL((k_dwdx_lds<1>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, pj ? 1 : 0);
+    const int grid = dw_blocks + gx * (B / 32) + (int)tail.blocks;
+    if (NT == 4) hipLaunchKernelGGL((k_dwdx_lds<4>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, pj ? 1 : 0, tail);
+    else if (NT == 2) hipLaunchKernelGGL((k_dwdx_lds<2>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, pj ? 1 : 0, tail);
+    else hipLaunchKernelGGL((k_dwdx_lds<1>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, pj ? 1 : 0, tail);
 }

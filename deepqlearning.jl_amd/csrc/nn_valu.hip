@@ -5,7 +5,7 @@
 // Threads are laid out with the batch column fastest, so activation loads are coalesced 256-B lines and the
 // weight is a wave-uniform (scalar) load.
 #include "common.h"
-typedef float f32x4v __attribute__((ext_vector_type(4)));
+#include "valu_tasks.h"
 
 // ------------------------------------------------------------------ split-K reduction epilogues
 // mode 0: forward      Y = act(sum_s part + bias[n])             (n = e / per_n)
@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void k_reduce_multi(const RSeg* __restrict__ s
         if (R.ysrc) tot = dact_f(tot, R.ysrc[(e / R.B) * R.ldy + (e % R.B)], R.act);
     }
     R.out[e] = tot;
+    if (R.outT) { const size_t feat = e / R.ncolsT, col = e % R.ncolsT; R.outT[col * (R.elems / R.ncolsT) + feat] = tot; }
 }
 void launch_reduce_multi(hipStream_t st, const RSeg* segs_dev, int nseg, unsigned total_blocks) {
     hipLaunchKernelGGL(k_reduce_multi, dim3(total_blocks), dim3(256), 0, st, segs_dev, nseg);
@@ -56,48 +57,6 @@ void launch_reduce_pub(hipStream_t st, const float* part, int S, size_t elems, i
     launch_reduce(st, part, S, elems, mode, bias, per_n, act, addend, ysrc, B, ldy, out);
 }
 
-// ------------------------------------------------------------------ forward: Y[n][pos][col] = act(sum_k X[xb(pos)+koff(k)][col] W[k][n] + b[n])
-__device__ __forceinline__ void valu_fwd_body(const LayerDev& L, const float* __restrict__ P, const float* __restrict__ X, int ldx, int col0, int ncols,
-                                              int S, int kc, float* __restrict__ out, size_t t) {
-    const size_t per_s = (size_t)L.N * L.npos * ncols;
-    if (t >= per_s * S) return;
-    const int s = (int)(t / per_s); const size_t e = t % per_s;
-    const int col = (int)(e % ncols); const int pos = (int)((e / ncols) % L.npos); const int n = (int)(e / ((size_t)ncols * L.npos));
-    const float* W = P + L.w_off;
-    int xb = 0;
-    if (L.kind == DQN_LAYER_CONV) { const int oy = pos / L.ow, ox = pos % L.ow; xb = oy * L.sh * L.iw + ox * L.sw; }
-    const int k0 = s * kc, k1 = min(L.K, k0 + kc);
-    float acc = 0.0f;
-    if (L.kind == DQN_LAYER_CONV) {
-        const int khw = L.kh * L.kw;
-        int ci = k0 / khw, ky = (k0 / L.kw) % L.kh, kx = k0 % L.kw;
-        for (int k = k0; k < k1; k++) {
-            const int koff = (ci * L.ih + ky) * L.iw + kx;
-            acc = fmaf(X[(size_t)(xb + koff) * ldx + col0 + col], W[(size_t)k * L.N + n], acc);
-            if (++kx == L.kw) { kx = 0; if (++ky == L.kh) { ky = 0; ++ci; } }
-        }
-    } else {
-        const float* xp = X + col0 + col; const float* wp = W + n;
-        int k = k0;
-        for (; k + 32 <= k1; k += 32) {   // a whole 32-deep head chunk in one round of 64 independent loads; the fma chain stays k-ascending
-            float xv[32], wv[32];
-#pragma unroll
-            for (int u = 0; u < 32; u++) { xv[u] = xp[(size_t)(k + u) * ldx]; wv[u] = wp[(size_t)(k + u) * L.N]; }
-#pragma unroll
-            for (int u = 0; u < 32; u++) acc = fmaf(xv[u], wv[u], acc);
-        }
-        for (; k + 8 <= k1; k += 8) {     // 16 independent loads in flight; the fma chain stays k-ascending
-            float xv[8], wv[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { xv[u] = xp[(size_t)(k + u) * ldx]; wv[u] = wp[(size_t)(k + u) * L.N]; }
-#pragma unroll
-            for (int u = 0; u < 8; u++) acc = fmaf(xv[u], wv[u], acc);
-        }
-        for (; k < k1; k++) acc = fmaf(xp[(size_t)k * ldx], wp[(size_t)k * L.N], acc);
-    }
-    if (S == 1) out[e] = act_f(acc + P[L.b_off + n], L.act);
-    else out[(size_t)s * per_s + e] = acc;
-}
 __global__ void k_valu_fwd(LayerDev L, const float* __restrict__ P, const float* __restrict__ X, int ldx, int col0, int ncols, int S, int kc,
                            float* __restrict__ out) {
     valu_fwd_body(L, P, X, ldx, col0, ncols, S, kc, out, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
@@ -109,74 +68,6 @@ void launch_valu_fwd(hipStream_t st, const LayerDev& L, const float* P, const fl
     if (S > 1) launch_reduce(st, partials, S, per_s, 0, P + L.b_off, L.npos * ncols, L.act, nullptr, nullptr, 0, 0, Y);
 }
 
-// ------------------------------------------------------------------ dW[k][n] = sum_{(pos,b)} X[xb(pos)+koff(k)][b] dpre[n][pos][b];  db[n] = sum dpre
-// thread = (chunk, k, n) for k < K, plus a virtual row k == K that accumulates the bias gradient.
-__device__ __forceinline__ void valu_dw_body(const LayerDev& L, const float* __restrict__ X, int ldx, const float* __restrict__ dpre, int B, int S, int kc,
-                                             float* __restrict__ out, size_t t) {
-    const size_t per_s = (size_t)(L.K + 1) * L.N;
-    if (t >= per_s * S) return;
-    const int s = (int)(t / per_s); const size_t e = t % per_s;
-    const int n = (int)(e % L.N), k = (int)(e / L.N);
-    const int KK = L.npos * B, j0 = s * kc, j1 = min(KK, j0 + kc);
-    int koff = k;
-    if (L.kind == DQN_LAYER_CONV && k < L.K) { const int khw = L.kh * L.kw; const int ci = k / khw, ky = (k / L.kw) % L.kh, kx = k % L.kw; koff = (ci * L.ih + ky) * L.iw + kx; }
-    float acc = 0.0f;
-    int pos = j0 / B, b = j0 % B;
-    if (L.kind != DQN_LAYER_CONV) {      // dense: one "position"; operands are two contiguous rows -> 16 loads in flight, chain order unchanged
-        const float* dr = dpre + (size_t)n * B; const float* xr = k < L.K ? X + (size_t)k * ldx : nullptr;
-        int j = j0;
-        if (j1 - j0 == 64) {                 // a 64-sample chunk (head layers at large batches): one round of 32 float4 loads
-            f32x4v dq[16], xq[16];
-#pragma unroll
-            for (int u = 0; u < 16; u++) { dq[u] = *reinterpret_cast<const f32x4v*>(dr + j0 + 4 * u); xq[u] = xr ? *reinterpret_cast<const f32x4v*>(xr + j0 + 4 * u) : (f32x4v){1.f, 1.f, 1.f, 1.f}; }
-            if (xr) {
-#pragma unroll
-                for (int u = 0; u < 16; u++) { acc = fmaf(xq[u].x, dq[u].x, acc); acc = fmaf(xq[u].y, dq[u].y, acc); acc = fmaf(xq[u].z, dq[u].z, acc); acc = fmaf(xq[u].w, dq[u].w, acc); }
-            } else {
-#pragma unroll
-                for (int u = 0; u < 16; u++) { acc = acc + dq[u].x; acc = acc + dq[u].y; acc = acc + dq[u].z; acc = acc + dq[u].w; }
-            }
-            j = j1;
-        }
-        if (j1 - j0 == 32) {                 // B = 32: the whole sample axis in one round of loads
-            float dv[32], xv[32];
-#pragma unroll
-            for (int u = 0; u < 32; u++) { dv[u] = dr[j0 + u]; xv[u] = xr ? xr[j0 + u] : 1.0f; }
-            if (xr) {
-#pragma unroll
-                for (int u = 0; u < 32; u++) acc = fmaf(xv[u], dv[u], acc);
-            } else {
-#pragma unroll
-                for (int u = 0; u < 32; u++) acc = acc + dv[u];
-            }
-            j = j1;
-        }
-        for (; j + 8 <= j1; j += 8) {
-            float dv[8], xv[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { dv[u] = dr[j + u]; xv[u] = xr ? xr[j + u] : 1.0f; }
-            if (xr) {
-#pragma unroll
-                for (int u = 0; u < 8; u++) acc = fmaf(xv[u], dv[u], acc);
-            } else {
-#pragma unroll
-                for (int u = 0; u < 8; u++) acc = acc + dv[u];
-            }
-        }
-        for (; j < j1; j++) { if (xr) acc = fmaf(xr[j], dr[j], acc); else acc = acc + dr[j]; }
-        out[(size_t)s * per_s + e] = acc;
-        return;
-    }
-    for (int j = j0; j < j1; j++) {
-        const float d = dpre[((size_t)n * L.npos + pos) * B + b];
-        if (k < L.K) {
-            int xb = 0; if (L.kind == DQN_LAYER_CONV) { const int oy = pos / L.ow, ox = pos % L.ow; xb = oy * L.sh * L.iw + ox * L.sw; }
-            acc = fmaf(X[(size_t)(xb + koff) * ldx + b], d, acc);
-        } else acc = acc + d;
-        if (++b == B) { b = 0; ++pos; }
-    }
-    out[(size_t)s * per_s + e] = acc;
-}
 __global__ void k_valu_dw(LayerDev L, const float* __restrict__ X, int ldx, const float* __restrict__ dpre, int B, int S, int kc, float* __restrict__ out) {
     valu_dw_body(L, X, ldx, dpre, B, S, kc, out, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
@@ -189,35 +80,6 @@ void launch_valu_dw(hipStream_t st, const LayerDev& L, const float* X, int ldx, 
     if (S > 1) launch_reduce(st, partials, S, per_s, 2, nullptr, 1, 0, nullptr, nullptr, 0, 0, dst);
 }
 
-// ------------------------------------------------------------------ dX[feat][b]  (then dact of the producing layer, optionally + addend at the dueling join)
-__device__ __forceinline__ void valu_dx_body(const LayerDev& L, const float* __restrict__ P, const float* __restrict__ dpre, int B, int S, int kc,
-                                             float* __restrict__ out, const float* __restrict__ addend, const float* __restrict__ ysrc, int ldy, int act_src, size_t t) {
-    const size_t per_s = (size_t)L.in_feat * B;
-    if (t >= per_s * S) return;
-    const int s = (int)(t / per_s); const size_t e = t % per_s;
-    const int b = (int)(e % B); const int feat = (int)(e / B);
-    const float* W = P + L.w_off;
-    float acc = 0.0f;
-    if (L.kind == DQN_LAYER_DENSE) {
-        const int n0 = s * kc, n1 = min(L.N, n0 + kc);
-        for (int n = n0; n < n1; n++) acc = fmaf(dpre[(size_t)n * B + b], W[(size_t)feat * L.N + n], acc);
-    } else {
-        const int hw = L.ih * L.iw; const int ci = feat / hw, iy = (feat % hw) / L.iw, ix = feat % L.iw;
-        for (int ky = 0; ky < L.kh; ky++) {
-            const int ty = iy - ky; if (ty < 0 || ty % L.sh) continue; const int oy = ty / L.sh; if (oy >= L.oh) continue;
-            for (int kx = 0; kx < L.kw; kx++) {
-                const int tx = ix - kx; if (tx < 0 || tx % L.sw) continue; const int ox = tx / L.sw; if (ox >= L.ow) continue;
-                const float* wr = W + (size_t)((ci * L.kh + ky) * L.kw + kx) * L.N; const int pos = oy * L.ow + ox;
-                for (int co = 0; co < L.N; co++) acc = fmaf(dpre[((size_t)co * L.npos + pos) * B + b], wr[co], acc);
-            }
-        }
-    }
-    if (S == 1) {
-        if (addend) acc = addend[e] + acc;
-        if (ysrc) acc = dact_f(acc, ysrc[(size_t)feat * ldy + b], act_src);
-        out[e] = acc;
-    } else out[(size_t)s * per_s + e] = acc;
-}
 __global__ void k_valu_dx(LayerDev L, const float* __restrict__ P, const float* __restrict__ dpre, int B, int S, int kc, float* __restrict__ out,
                           const float* __restrict__ addend, const float* __restrict__ ysrc, int ldy, int act_src) {
     valu_dx_body(L, P, dpre, B, S, kc, out, addend, ysrc, ldy, act_src, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
@@ -225,19 +87,14 @@ __global__ void k_valu_dx(LayerDev L, const float* __restrict__ P, const float* 
 // One launch for a TABLE of independent small tasks (head forwards of both nets, head dW + dX, ...): the per-launch floor
 // (~4.6 us on MI355X) dominates these tiny kernels, so they are batched.  Tasks live in device memory (static schedule).
 __global__ __launch_bounds__(256) void k_valu_multi(const VTask* __restrict__ tasks, int ntasks) {
-    int ti = 0;
-    while (ti + 1 < ntasks && blockIdx.x >= tasks[ti + 1].first_block) ti++;
-    const VTask& T = tasks[ti];
-    const size_t t = (size_t)(blockIdx.x - T.first_block) * 256 + threadIdx.x;
-    if (T.kind == 0) valu_fwd_body(T.L, T.P, T.X, T.ldx, T.col0, T.ncols, T.S, T.kc, T.out, t);
-    else if (T.kind == 1) valu_dw_body(T.L, T.X, T.ldx, T.dpre, T.B, T.S, T.kc, T.out, t);
-    else valu_dx_body(T.L, T.P, T.dpre, T.B, T.S, T.kc, T.out, T.addend, T.ysrc, T.ldy, T.act_src, t);
+    valu_task_run(tasks, ntasks, blockIdx.x);
 }
 unsigned valu_task_blocks(const VTask& T) {
     size_t n;
     if (T.kind == 0) n = (size_t)T.L.N * T.L.npos * T.ncols * T.S;
     else if (T.kind == 1) n = (size_t)(T.L.K + 1) * T.L.N * T.S;
-    else n = (size_t)T.L.in_feat * T.B * T.S;
+    else if (T.kind == 2) n = (size_t)T.L.in_feat * T.B * T.S;
+    else n = 1;
     return (unsigned)((n + 255) / 256);
 }
 void launch_valu_multi(hipStream_t st, const VTask* tasks_dev, int ntasks, unsigned total_blocks) {
@@ -377,6 +234,235 @@ void launch_td(hipStream_t st, const TdArgs& a) {
     if (a.nA <= 8) hipLaunchKernelGGL((k_td<8>), dim3(1), dim3(bs), lds, st, a);
     else if (a.nA <= 32) hipLaunchKernelGGL((k_td<32>), dim3(1), dim3(bs), lds, st, a);
     else hipLaunchKernelGGL((k_td<DQN_MAX_ACTIONS>), dim3(1), dim3(bs), lds, st, a);
+}
+
+// ------------------------------------------------------------------ small batches: head forwards + TD + head dX in ONE launch, a workgroup per batch column
+// Replaces three dependent launches (head forwards of both nets as a task table, the single-workgroup k_td, the head dX tasks): 19.7 us -> one
+// launch at B = 32.  Every value follows the canonical order of the kernels it replaces:
+//   head forward   per plan chunk s: acc = +0; k ascending: acc = fma(x[k], W[k][n], acc); chunk sums added in ascending order; + bias; activation
+//   TD             exactly k_td's per-column arithmetic (dueling (v + a) - mean, first-max argmax, r + ((1 - done) * gamma) * q, Huber, dL/dQ)
+//   head dX        acc = +0; n ascending: acc = fma(dpre[n][b], W[k][n], acc); at a join dX_val + dX_adv; then act' of the producing layer
+// Workgroup b stages its three input columns (s_b, sp_b of the online net; sp_b of the target net) of each head in LDS, so the strided 4-byte
+// column reads happen once.  The loss is folded later from the per-column Huber terms (`hl`, valu_tasks.h kind 3); block 0 ticks the step counters.
+// LDS index padding: 4 floats per 32.  The lanes of phase 2 differ in the chunk index, i.e. by multiples of kc (32) elements -- unpadded
+// they would all hit one bank; with a 36-float pitch 16 lanes reading 16 bytes each cover all 64 banks once, and 32-chunks stay 16-byte aligned.
+#define PADI(i) ((i) + (((i) >> 5) << 2))
+// x / d for small non-negative ints through one multiply: floor((x + 0.5) * (1 / d)) is exact while x * 2^-23 << 0.5 / d (x < 2^16 here);
+// a runtime integer division costs ~40 instructions, and a lone wave pays every instruction in full
+__device__ __forceinline__ int qdiv(int x, float rcp) { return (int)(((float)x + 0.5f) * rcp); }
+// phase 1 of one head: request the three input columns (k = tid, tid + 256) and the first three weight float4s of this lane
+__device__ __forceinline__ void head_issue(const HeadLayer& L, int B, int b, int double_q, int stage_w, int tid, float (&xv)[6], f32x4v (&wv)[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int net = c == 2 ? 1 : 0, col = L.c0[net] + b + (c == 1 ? B : 0);
+        const bool on = !(c == 1 && !double_q);
+        const float* xt = L.XT[net];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int k = tid + 256 * j; xv[2 * c + j] = 0.0f;
+            if (on && k < L.K) xv[2 * c + j] = xt ? xt[(size_t)col * L.K + k] : L.X[net][(size_t)k * L.ldx[net] + col];
+        }
+    }
+    const int half = (L.K * L.N) >> 2;                     // float4s per net
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+        const int q = tid + 256 * u; wv[u] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        if (stage_w && q < 2 * half) { const int net = q >= half ? 1 : 0; wv[u] = reinterpret_cast<const f32x4v*>(L.W[net])[q - net * half]; }
+    }
+}
+// the weights are staged TRANSPOSED, wt[net][n][k] (k contiguous), so that a chain reads its 32 weights as eight 16-byte LDS loads
+__device__ __forceinline__ void head_put_w4(const HeadLayer& L, float rN, int q, int half, const f32x4v& w, float* wt) {
+    const int net = q >= half ? 1 : 0; const int e0 = 4 * (q - net * half);                      // first of 4 consecutive elements k * N + n
+    const float v[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int e = e0 + i, k = qdiv(e, rN), n = e - k * L.N; const int d = (net * L.N + n) * L.K + k; wt[PADI(d)] = v[i]; }
+}
+__device__ __forceinline__ void head_commit(const HeadLayer& L, int B, int b, int double_q, int stage_w, int tid, const float (&xv)[6], const f32x4v (&wv)[3], float* xs, float* wt) {
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) { const int k = tid + 256 * j; if (k < L.K) { const int i = c * L.K + k; xs[PADI(i)] = xv[2 * c + j]; } }
+    const int half = (L.K * L.N) >> 2; const float rN = 1.0f / (float)L.N;
+#pragma unroll
+    for (int u = 0; u < 3; u++) { const int q = tid + 256 * u; if (stage_w && q < 2 * half) head_put_w4(L, rN, q, half, wv[u], wt); }
+    // shapes beyond the straight-line slots (K > 512 or more than 768 weight float4s): plain rounds
+    for (int c = 0; c < 3; c++) {
+        if (c == 1 && !double_q) continue;
+        const int net = c == 2 ? 1 : 0, col = L.c0[net] + b + (c == 1 ? B : 0);
+        for (int k = tid + 512; k < L.K; k += 256) { const int i = c * L.K + k; xs[PADI(i)] = L.XT[net] ? L.XT[net][(size_t)col * L.K + k] : L.X[net][(size_t)k * L.ldx[net] + col]; }
+    }
+    if (stage_w) for (int q = tid + 768; q < 2 * half; q += 256) { const int net = q >= half ? 1 : 0; head_put_w4(L, rN, q, half, reinterpret_cast<const f32x4v*>(L.W[net])[q - net * half], wt); }
+}
+// The argument record lives in device memory (built once per engine): 350 bytes of kernel argument kept in SGPRs for the whole kernel
+// spilled ~700 lane moves; fields are fetched with scalar loads where they are used instead.  The kernel is written for a SHORT instruction
+// stream: its 32 workgroups are lone waves on cold instruction caches, so every instruction is paid in full -- the two heads share one copy of
+// each phase (per-lane selects instead of two inlined bodies), indices are decoded with multiplies, LDS is read 16 bytes at a time.
+__global__ __launch_bounds__(256) void k_head_td(const HeadTdArgs* __restrict__ Ap, int bump_sample_ctr) {
+    extern __shared__ float hs[];
+    const HeadTdArgs& A = *Ap;
+    const int B = A.B, nA = A.nA, b = blockIdx.x, tid = threadIdx.x;
+    const int double_q = A.double_q, stage_w = A.stage_w;
+    const bool has_val = A.dueling != 0;                   // plain network: only the `adv` record is populated
+    const int Kv = has_val ? A.val.K : 0, Nv = has_val ? A.val.N : 0, Sv = has_val ? A.val.S : 0, Ka = A.adv.K, Na = A.adv.N, Sa = A.adv.S;
+    // LDS carve-up (padded, see PADI): input columns | transposed weights of both nets | chunk sums | head outputs | Q columns | head gradients
+    float* p = hs;
+    float* const xs_v = p; p += PADI(3 * Kv);
+    float* const xs_a = p; p += PADI(3 * Ka);
+    float* const wt_v = p; p += stage_w ? PADI(2 * Kv * Nv) : 0;
+    float* const wt_a = p; p += stage_w ? PADI(2 * Ka * Na) : 0;
+    float* const part_v = p; p += 3 * Nv * Sv;
+    float* const part_a = p; p += 3 * Na * Sa;
+    float* const hv_v = p; p += 3 * Nv;
+    float* const hv_a = p; p += 3 * Na;
+    float* const qs = p; p += 3 * nA;                      // Q[slot][a]
+    float* const dq = p;                                   // [1 + nA]: head pre-activation gradients of this column (val first)
+    if (A.dbg == 9) return;
+    int act_ = 0; float rew_ = 0.0f, dn_ = 0.0f, w_ = 0.0f;
+    if (tid == 0) { act_ = A.bm_a[b]; rew_ = A.bm_r[b]; dn_ = A.bm_done[b]; w_ = A.bm_w[b]; }     // get_batch scalars + IS weight (gather launch)
+    // biases of the outputs this lane finishes (o = slot * N + n; adv outputs first, then val): requested now, consumed after phase 2
+    const int no_a = 3 * Na, no_v = 3 * Nv;
+    float bias_ = 0.0f;
+    if (tid < no_a) bias_ = A.adv.bias[tid >= 2 * Na ? 1 : 0][tid % Na];
+    else if (tid < no_a + no_v) { const int o = tid - no_a; bias_ = A.val.bias[o >= 2 * Nv ? 1 : 0][o % Nv]; }
+    // phase 1: input columns (slot c: 0 = online s_b, 1 = online sp_b, 2 = target sp_b; contiguous runs of the transposed copy when there is
+    // one) and the contiguous weights: every load of both heads is issued before the first LDS store -- one round trip at K <= 512
+    {
+        float xv[6], xa[6]; f32x4v wv[3], wa[3];
+        if (has_val) head_issue(A.val, B, b, double_q, stage_w, tid, xv, wv);
+        head_issue(A.adv, B, b, double_q, stage_w, tid, xa, wa);
+        if (has_val) head_commit(A.val, B, b, double_q, stage_w, tid, xv, wv, xs_v, wt_v);
+        head_commit(A.adv, B, b, double_q, stage_w, tid, xa, wa, xs_a, wt_a);
+    }
+    __syncthreads();
+    if (A.dbg == 1) return;
+    // phase 2: chunk chains, one (head, column slot c, output n, chunk s) per lane; adv items first: it = (c * N + n) * S + s
+    {
+        const int ia = 3 * Na * Sa, iv = 3 * Nv * Sv, kcv = has_val ? A.val.kc : 1, kca = A.adv.kc;
+        const float rSa = 1.0f / (float)Sa, rNa = 1.0f / (float)Na, rSv = has_val ? 1.0f / (float)Sv : 1.0f, rNv = has_val ? 1.0f / (float)Nv : 1.0f;
+        for (int it = tid; it < ia + iv; it += 256) {
+            const bool v = it >= ia; const int i2 = v ? it - ia : it;
+            const int K = v ? Kv : Ka, N = v ? Nv : Na, S = v ? Sv : Sa, kc = v ? kcv : kca;
+            const float* xs = v ? xs_v : xs_a; const float* wt = v ? wt_v : wt_a; float* part = v ? part_v : part_a;
+            const int cn = qdiv(i2, v ? rSv : rSa), s = i2 - cn * S, c = qdiv(cn, v ? rNv : rNa), n = cn - c * N;
+            if (c == 1 && !double_q) { part[i2] = 0.0f; continue; }
+            const int net = c == 2 ? 1 : 0;
+            const int k0 = s * kc, k1 = min(K, k0 + kc);
+            const int xi = c * K + k0, wi = (net * N + n) * K + k0;
+            float acc = 0.0f;
+            if (stage_w && k1 - k0 == 32 && ((xi | wi) & 31) == 0) {      // a whole aligned chunk: sixteen 16-byte LDS loads, then the k-ascending chain
+                const f32x4v* xp = reinterpret_cast<const f32x4v*>(xs + PADI(xi)); const f32x4v* wp = reinterpret_cast<const f32x4v*>(wt + PADI(wi));
+                f32x4v xq[8], wq[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { xq[u] = xp[u]; wq[u] = wp[u]; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) { acc = fmaf(xq[u].x, wq[u].x, acc); acc = fmaf(xq[u].y, wq[u].y, acc); acc = fmaf(xq[u].z, wq[u].z, acc); acc = fmaf(xq[u].w, wq[u].w, acc); }
+            } else if (stage_w) {
+                for (int k = 0; k < k1 - k0; k++) acc = fmaf(xs[PADI(xi + k)], wt[PADI(wi + k)], acc);
+            } else {
+                const float* W = (v ? A.val.W[net] : A.adv.W[net]) + n;
+                for (int k = k0; k < k1; k++) acc = fmaf(xs[PADI(c * K + k)], W[(size_t)k * N], acc);
+            }
+            part[i2] = acc;
+        }
+    }
+    __syncthreads();
+    // chunk sums added in ascending order, + bias, activation: output o = c * N + n (adv outputs first)
+    for (int o0 = tid; o0 < no_a + no_v; o0 += 256) {
+        const bool v = o0 >= no_a; const int o = v ? o0 - no_a : o0;
+        const int N = v ? Nv : Na, S = v ? Sv : Sa;
+        const float* pp = (v ? part_v : part_a) + o * S;
+        float tot = pp[0];
+        for (int s = 1; s < S; s++) tot = tot + pp[s];
+        float bias = bias_;
+        if (o0 >= 256) { const int c = o / N, n = o - c * N; bias = (v ? A.val.bias[c == 2 ? 1 : 0] : A.adv.bias[c == 2 ? 1 : 0])[n]; }
+        (v ? hv_v : hv_a)[o] = act_f(tot + bias, v ? A.val.act : A.adv.act);
+    }
+    __syncthreads();
+    if (A.dbg == 2) return;
+    // phase 3a: the three Q columns (slot c per lane): Q = (val .+ adv) .- mean(adv), src/dueling.jl:10; parity copies go out from here
+    if (tid < 3) {
+        const int c = tid; const float* ar = hv_a + c * Na;
+        float* qg = c == 0 ? A.q_on_s : (c == 1 ? A.q_on_sp : A.q_tg_sp);
+        if (c != 1 || double_q) {
+            if (!has_val) { for (int a = 0; a < nA; a++) { const float q = ar[a]; qs[c * nA + a] = q; qg[(size_t)b * nA + a] = q; if (c == 2 && !double_q) A.q_on_sp[(size_t)b * nA + a] = q; } }
+            else {
+                const float vv = hv_v[c];
+                float sum = ar[0];
+                for (int a = 1; a < nA; a++) sum = sum + ar[a];
+                const float mean = sum / (float)nA;
+                for (int a = 0; a < nA; a++) { const float q = (vv + ar[a]) - mean; qs[c * nA + a] = q; qg[(size_t)b * nA + a] = q; if (c == 2 && !double_q) A.q_on_sp[(size_t)b * nA + a] = q; }
+            }
+        }
+    }
+    __syncthreads();
+    // phase 3b: this column's TD (one lane; k_td's arithmetic)
+    if (tid == 0) {
+        const float invB = 1.0f / (float)B;
+        const int act = act_; const float rew = rew_, dn = dn_, w = w_;
+        A.w_is[b] = w;
+        const float* qsel = double_q ? qs + nA : qs + 2 * nA;          // argmax over the online net's Q(sp) (double-Q) or the target net's
+        int best = 0; float bq = qsel[0];
+        for (int a = 1; a < nA; a++) { const float q = qsel[a]; if (q > bq) { bq = q; best = a; } }      // first max (Julia argmax)
+        const float qsp = qs[2 * nA + best];
+        A.best[b] = best;
+        const float t1 = 1.0f - dn; const float t2 = t1 * A.gamma; const float t3 = t2 * qsp; const float y = rew + t3;
+        A.ytarget[b] = y;
+        const float qsa = qs[act];
+        const float td = qsa - y; A.td[b] = td;
+        const float x = w * td; const float ab = fabsf(x); const float qd = ab < 1.0f ? ab : 1.0f; const float lin = ab - qd;
+        A.hl[b] = (0.5f * qd) * qd + lin;
+        const float cl = x < -1.0f ? -1.0f : (x > 1.0f ? 1.0f : x);
+        const float g = (invB * cl) * w;
+        const int act_a = A.adv.act;
+        if (has_val) {
+            const float dv = dact_f(g, hv_v[0], A.val.act); dq[0] = dv; A.val.dpre[b] = dv;
+            const float gm = g / (float)nA;
+            for (int a = 0; a < nA; a++) { const float d = dact_f((a == act ? g : 0.0f) - gm, hv_a[a], act_a); dq[1 + a] = d; A.adv.dpre[(size_t)a * B + b] = d; }
+        } else {
+            for (int a = 0; a < nA; a++) { const float d = dact_f(a == act ? g : 0.0f, hv_a[a], act_a); dq[1 + a] = d; A.adv.dpre[(size_t)a * B + b] = d; }
+        }
+        if (b == 0) {
+            A.st->step = A.st->step + 1;                 // read by k_adam (beta-power slot) later in this step
+            if (bump_sample_ctr) A.st->sample_ctr = A.st->sample_ctr + 1;
+        }
+    }
+    __syncthreads();
+    if (A.dbg == 3) return;
+    // phase 4: dX of the head layers for column b (acc = +0; n ascending: acc = fma(dpre[n], W[k][n], acc)), the join (dX_val + dX_adv), then act'
+    // of the producing layer, whose activation y[k][b] is the staged input column of slot 0
+    if (A.join) {
+        const int act_src = A.adv.act_src; float* dsrc = A.adv.dsrc;
+        const float* Wv = A.val.W[0]; const float* Wa = A.adv.W[0];
+        for (int k = tid; k < Ka; k += 256) {
+            float xv = 0.0f, xa = 0.0f;
+            for (int n = 0; n < Nv; n++) xv = fmaf(dq[n], stage_w ? wt_v[PADI(n * Kv + k)] : Wv[(size_t)k * Nv + n], xv);
+            for (int n = 0; n < Na; n++) xa = fmaf(dq[1 + n], stage_w ? wt_a[PADI(n * Ka + k)] : Wa[(size_t)k * Na + n], xa);
+            const float v = xv + xa;
+            dsrc[(size_t)k * B + b] = dact_f(v, xs_a[PADI(k)], act_src);
+        }
+    } else {
+        float* dsa = A.adv.dsrc; float* dsv = has_val ? A.val.dsrc : nullptr;
+        const int na = dsa ? Ka : 0, nv = dsv ? Kv : 0;
+        for (int i = tid; i < na + nv; i += 256) {
+            const bool v = i >= na; const int k = v ? i - na : i;
+            const int K = v ? Kv : Ka, N = v ? Nv : Na;
+            const float* wt = v ? wt_v : wt_a; const float* d = v ? dq : dq + 1;
+            float acc = 0.0f;
+            if (stage_w) for (int n = 0; n < N; n++) acc = fmaf(d[n], wt[PADI(n * K + k)], acc);
+            else { const float* W = v ? A.val.W[0] : A.adv.W[0]; for (int n = 0; n < N; n++) acc = fmaf(d[n], W[(size_t)k * N + n], acc); }
+            (v ? dsv : dsa)[(size_t)k * B + b] = dact_f(acc, (v ? xs_v : xs_a)[PADI(k)], v ? A.val.act_src : A.adv.act_src);
+        }
+    }
+}
+size_t head_td_lds_bytes(const HeadTdArgs& a) {
+    size_t f = 0;
+    const HeadLayer* H[2] = {&a.val, &a.adv};
+    for (int h = a.dueling ? 0 : 1; h < 2; h++) f += PADI((size_t)3 * H[h]->K) + (a.stage_w ? PADI((size_t)2 * H[h]->K * H[h]->N) : 0) + (size_t)3 * H[h]->N * H[h]->S + (size_t)3 * H[h]->N;
+    return (f + 3 * a.nA + 1 + a.nA + 8) * sizeof(float);
+}
+void launch_head_td(hipStream_t st, const HeadTdArgs& a, const HeadTdArgs* a_dev, int bump_sample_ctr) {
+    const size_t lds = head_td_lds_bytes(a);
+    hipLaunchKernelGGL(k_head_td, dim3(a.B), dim3(256), lds, st, a_dev, bump_sample_ctr);
 }
 
 // Q columns for the policy path (src/policy.jl:38-64): q_out[n][nA], argmax (first max)

@@ -46,9 +46,22 @@ __device__ __forceinline__ long long tree_descend(const float* __restrict__ tree
     long long leaf = node - cap2; if (leaf >= size) leaf = size - 1;
     return leaf;
 }
+// batch scalars + IS weights of the B sampled transitions (k_batch_meta's arithmetic), by the first 64 lanes of ONE workgroup at the END of the
+// gather launch: its two dependent round trips and the double-precision pow overlap the other workgroups' row traffic
+__device__ __forceinline__ void gather_batch_meta(const BatchMeta& M, const long long* rows, int c0, int B, long long cap2, const float* __restrict__ tree,
+                                                  const StepState* __restrict__ state) {
+    if (!M.a_out || threadIdx.x >= 64) return;
+    const int c = c0 + threadIdx.x;
+    if (c >= B) return;
+    const long long j = rows[threadIdx.x];
+    M.a_out[c] = M.a[j]; M.r_out[c] = M.r[j]; M.done_out[c] = (float)M.done[j];
+    const float p = tree[cap2 + j] / tree[1];                   // p = prio ./ sum(prio[1:n]), :101
+    const float x = (float)state->size * p;                     // n .* p
+    M.w_out[c] = (float)pow((double)x, -(double)M.beta);        // .^ (-beta), :102
+}
 __global__ __launch_bounds__(256) void k_gather_fb(const void* __restrict__ s_rows, const void* __restrict__ sp_rows, int u8, int E, int B,
                                                    long long* __restrict__ idx, float* __restrict__ x0, int do_sample, long long cap2,
-                                                   const float* __restrict__ tree, unsigned long long seed, const StepState* __restrict__ state) {
+                                                   const float* __restrict__ tree, unsigned long long seed, const StepState* __restrict__ state, BatchMeta meta) {
     __shared__ float tile[64][65];
     __shared__ long long rows[64];
     const int f0 = blockIdx.x * 64, c0 = blockIdx.y * 64, lane = threadIdx.x & 63, w = threadIdx.x >> 6, ld = 2 * B;
@@ -104,13 +117,14 @@ __global__ __launch_bounds__(256) void k_gather_fb(const void* __restrict__ s_ro
         if (c + 3 < ld) *reinterpret_cast<f32x4*>(x0 + (size_t)f * ld + c) = (f32x4){tile[4 * l16][fl], tile[4 * l16 + 1][fl], tile[4 * l16 + 2][fl], tile[4 * l16 + 3][fl]};
         else for (int u = 0; u < 4; u++) if (c + u < ld) x0[(size_t)f * ld + c + u] = tile[4 * l16 + u][fl];
     }
+    if (blockIdx.x == 0) gather_batch_meta(meta, rows, c0, B, cap2, tree, state);
 }
 // u8 rows (config 5: 1e6 transitions, 28 224 B each): 256 features x 64 columns per workgroup so that every sampled row is
 // read in 256-B segments (one uchar4 per lane, 16 independent loads in flight per thread); 4x fewer workgroups than the f32
 // tiling also means 4x fewer repeats of the descent when it is fused.
 __global__ __launch_bounds__(256) void k_gather_fb_u8(const unsigned char* __restrict__ s_rows, const unsigned char* __restrict__ sp_rows, int E, int B,
                                                       long long* __restrict__ idx, float* __restrict__ x0, int do_sample, long long cap2,
-                                                      const float* __restrict__ tree, unsigned long long seed, const StepState* __restrict__ state) {
+                                                      const float* __restrict__ tree, unsigned long long seed, const StepState* __restrict__ state, BatchMeta meta) {
     // the tile stays PACKED in LDS (64 columns x 64 words of 4 features = 16.6 KB instead of 66 KB of floats): several workgroups per CU keep the
     // random 256-B row reads in flight; bytes are unpacked and converted (256-entry table: one IEEE division per value of b, not per element)
     // on the way out
@@ -154,17 +168,18 @@ __global__ __launch_bounds__(256) void k_gather_fb_u8(const unsigned char* __res
         if (c + 3 < ld) *reinterpret_cast<f32x4*>(x0 + (size_t)f * ld + c) = (f32x4){o[0], o[1], o[2], o[3]};
         else for (int u = 0; u < 4; u++) if (c + u < ld) x0[(size_t)f * ld + c + u] = o[u];
     }
+    if (blockIdx.x == 0) gather_batch_meta(meta, rows, c0, B, cap2, tree, state);
 }
 void launch_gather_fb(hipStream_t st, const void* s_rows, const void* sp_rows, int obs_u8, int E, int B, long long* idx, float* x0, int do_sample,
-                      long long cap2, const float* tree, unsigned long long seed, const StepState* state) {
+                      long long cap2, const float* tree, unsigned long long seed, const StepState* state, const BatchMeta& meta) {
     if (obs_u8 && (E & 3) == 0) {
         dim3 grid((E + 255) / 256, (2 * B + 63) / 64);
         hipLaunchKernelGGL(k_gather_fb_u8, grid, dim3(256), 0, st, (const unsigned char*)s_rows, (const unsigned char*)sp_rows, E, B, idx, x0,
-                           do_sample, cap2, tree, seed, state);
+                           do_sample, cap2, tree, seed, state, meta);
         return;
     }
     dim3 grid((E + 63) / 64, (2 * B + 63) / 64);
-    hipLaunchKernelGGL(k_gather_fb, grid, dim3(256), 0, st, s_rows, sp_rows, obs_u8, E, B, idx, x0, do_sample, cap2, tree, seed, state);
+    hipLaunchKernelGGL(k_gather_fb, grid, dim3(256), 0, st, s_rows, sp_rows, obs_u8, E, B, idx, x0, do_sample, cap2, tree, seed, state, meta);
 }
 
 __global__ void k_gather_rows(const void* __restrict__ rows, int u8, int E, const long long* __restrict__ idx, float* __restrict__ out) {
