@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/dqn_mi355x.h"
 
@@ -119,6 +120,15 @@ struct PrioArgs { int n; long long cap2; const long long* idx; const float* td; 
 // deferred dW split-K slabs reduced INSIDE the Adam launch by dedicated blocks (single-GPU path): element ranges [beg, end) of the
 // gradient vector, each the ascending sum of S slabs
 struct AdamSegs { int n; unsigned long long beg[8], end[8]; const float* part[8]; int S[8]; unsigned blocks; unsigned long long stride[8]; };   // stride 0: slabs `len` apart
+// one Adam job (adam_body.h): element ranges streamed 16 B at a time, slab ranges reduced on the fly, optionally the priority update and
+// the beta-power tick.  Run by k_adam or by tail workgroups of a backward launch.
+struct AdamJob {
+    float *p, *m, *v; const float* g; float* g_out; StepState* state; float* gmax_part; int slot0;
+    int f64mode; float lr; double b1, b2, eps; float gscale;
+    int nr; unsigned long long beg[4], end[4];
+    AdamSegs segs; PrioArgs prio; int tick; unsigned sblocks;
+};
+static inline __host__ __device__ unsigned adam_job_blocks(const AdamJob& j) { return (j.prio.n > 0 ? 1u : 0u) + j.segs.blocks + j.sblocks; }
 
 // ---- kernel launchers (defined in the .hip files; all enqueue on `st` and never synchronise)
 // a head tensor as seen by k_td: finished activation (S <= 1) or split-K partial slabs to be reduced on the fly
@@ -199,8 +209,8 @@ void launch_valu_dx(hipStream_t st, const LayerDev& L, const float* P, const flo
                     const float* addend, const float* ysrc, int ldy, int act_src);
 void launch_td(hipStream_t st, const TdArgs& a);
 int adam_blocks(size_t P);
-void launch_adam(hipStream_t st, size_t P, float* p, float* m, float* v, const float* g, StepState* state, float* gmax_part, int f64mode,
-                 float lr, double b1, double b2, double eps, float gscale, const PrioArgs& prio, const AdamSegs& segs, float* g_out);
+static inline int gmax_slots(size_t) { return 65536; }   // per-block max |g| of every Adam job of a step (each job owns a slot range)
+void launch_adam(hipStream_t st, const AdamJob& job);
 void launch_q_columns(hipStream_t st, int n, int nA, int dueling, const float* val, const float* adv, float* q_out /*[n][nA]*/, int* argmax_out);
 void launch_convert_params(hipStream_t st, const LayerDev* layers_dev, int nl, const float* src, float* dst, int to_internal, size_t P_ext);
 
@@ -318,18 +328,21 @@ void launch_dp_unpack_sum(hipStream_t st, const DpSumArgs& a);
 // MFMA path (nn_mfma.hip): returns false if the shape is not eligible (caller falls back to the VALU kernel,
 // which computes bit-identical values)
 bool gemm_dw_eligible(const LayerDev& L, int B, int ldx);
-// a TAIL of small independent VALU tasks (valu_tasks.h) riding in the last workgroups of an LDS-tiled launch
-struct GemmTail { const VTask* tasks; int n; unsigned blocks; };
+// a TAIL riding in the last workgroups of an LDS-tiled launch: small independent VALU tasks (valu_tasks.h), then (has_adam) an Adam job
+struct GemmTail { const VTask* tasks; int n; unsigned blocks; int has_adam; AdamJob adam; };
+static inline __host__ __device__ unsigned gemm_tail_blocks(const GemmTail& t) { return t.blocks + (t.has_adam ? adam_job_blocks(t.adam) : 0u); }
+static inline GemmTail gemm_no_tail() { GemmTail t; memset(&t, 0, sizeof t); return t; }
+
 void launch_gemm_dw(hipStream_t st, const LayerDev& L, int nprob, const float* const* X, int ldx, const float* const* dpre, int B, float* const* out,
-                    int ldd = 0, int tpr = 0, int rstride = 0, GemmTail tail = GemmTail{nullptr, 0, 0});   // ldd 0 = plain layout; else gathered rank blocks (see DwStride in nn_gemm.hip)
+                    int ldd = 0, int tpr = 0, int rstride = 0, GemmTail tail = gemm_no_tail());   // ldd 0 = plain layout; else gathered rank blocks (see DwStride in nn_gemm.hip)
 
 bool gemm_dx_eligible(const LayerDev& L, int B, int ldy);
 void launch_gemm_dx(hipStream_t st, const LayerDev& L, int nsrc, const float* const* W, const float* const* dpre, int B, float* out /* dact or partial slabs */,
-                    const float* ysrc, int ldy, int act_src, GemmTail tail = GemmTail{nullptr, 0, 0});
+                    const float* ysrc, int ldy, int act_src, GemmTail tail = gemm_no_tail());
 
 void launch_gemm_dwdx(hipStream_t st, const LayerDev& Lw, int nprob, const float* const* X, int ldx, const float* const* dpre_w, int B, float* const* out_w,
                       const LayerDev& Lx, int nsrc, const float* const* W, const float* const* dpre_x, float* out_x, const float* ysrc, int ldy, int act_src,
-                      GemmTail tail = GemmTail{nullptr, 0, 0});
+                      GemmTail tail = gemm_no_tail());
 
 // (reduce == false leaves split-K partial slabs in `partials` for the caller's batched k_reduce_multi)
 bool mfma_fwd_ok(const LayerDev& L, int ncols);

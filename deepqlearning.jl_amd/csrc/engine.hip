@@ -152,6 +152,7 @@ static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers
     e->device = device; e->hp = *hp; e->B = hp->batch_size; e->nA = hp->n_actions; e->E = hp->obs_c * hp->obs_h * hp->obs_w;
     if (build_layers(layers, n_layers, hp, e->L, &e->last_base, &e->last_val, &e->last_adv, &e->P, &e->Pint)) return -1;
     e->nl = n_layers;
+    if (const char* am = getenv("DQN_ADAM_MODE")) e->adam_mode = atoi(am);
     if (const char* sw = getenv("DQN_SIM_WORLD")) { const int k = atoi(sw); if (k >= 1 && !hp->recurrence) { e->sim_world = k; e->world = k; } }   // tests: one process plays k identical ranks
     dqn_layer_plan defp[DQN_MAX_LAYERS];
     if (!plan) { default_plan(e->L, e->nl, e->B, defp); plan = defp; }
@@ -171,6 +172,7 @@ static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+
     const int B = e->B;
     e->T = hp->recurrence ? hp->trace_length : 1;
     if (hp->recurrence && (e->T < 1 || (long long)e->T * B > 65536)) return fail("trace_length %d unsupported", e->T);
@@ -212,7 +214,7 @@ static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers
         DM(e->ep_idx, B); DM(e->ep_start, B); DM(e->r_a, Bc); DM(e->r_r, Bc); DM(e->r_done, Bc); DM(e->r_mask, Bc);
     }
     e->partials_elems = pmax; DM(e->partials, 2 * pmax);   // second half: the target net's split-K partials (fused on+tg launches)
-    DM(e->join_tmp, jmax); DM(e->gmax_part, adam_blocks(e->Pint) + 4096); HIPCHK(hipMemset(e->gmax_part, 0, (adam_blocks(e->Pint) + 4096) * 4));
+    DM(e->join_tmp, jmax); DM(e->gmax_part, gmax_slots(e->Pint)); HIPCHK(hipMemset(e->gmax_part, 0, (size_t)gmax_slots(e->Pint) * 4));
     DM(e->w_is, B); DM(e->td, Bc); DM(e->q_on_s, (size_t)B * e->nA); DM(e->q_on_sp, (size_t)B * e->nA); DM(e->q_tg_sp, (size_t)B * e->nA);
     DM(e->ytarget, B); DM(e->best, B);
     DM(e->gb_rows, (size_t)B * e->E); DM(e->gb_r, B); DM(e->gb_done, B); DM(e->gb_w, B); DM(e->gb_a, B); DM(e->gb_idx, B);
@@ -264,6 +266,7 @@ extern "C" int dqn_engine_destroy(dqn_engine_t* e) {
     if (e->stream2) hipStreamDestroy(e->stream2);
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_join) hipEventDestroy(e->ev_join);
+
     delete e; return 0;
 }
 extern "C" int dqn_engine_get_plan(dqn_engine_t* e, dqn_layer_plan* p) { if (!e) return fail("null engine handle");
@@ -535,7 +538,7 @@ int run_step(dqn_engine* e, bool sample) {
 }
 int fetch_scalars(dqn_engine* e, float* loss, float* gn) {
     // globalnorm (helpers.jl:38-46): fold the Adam kernel's per-block maxima only when the host asks for the scalar
-    if (gn) launch_update_priorities(e->stream, 0, e->cap2, e->idx, e->td, e->hp.prio_eps, e->hp.prio_alpha, e->tree, e->state, 1, 1.0, 1.0, e->gmax_part, adam_blocks(e->Pint) + 4096);
+    if (gn) launch_update_priorities(e->stream, 0, e->cap2, e->idx, e->td, e->hp.prio_eps, e->hp.prio_alpha, e->tree, e->state, 1, 1.0, 1.0, e->gmax_part, gmax_slots(e->Pint));
     StepState s; HIPCHK(hipMemcpyAsync(&s, e->state, sizeof s, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream));
     if (s.err == 2) return fail("AssertionError: all(new_priorities .> 0f0)");
     if (loss) *loss = s.loss;

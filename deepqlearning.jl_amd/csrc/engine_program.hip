@@ -34,6 +34,7 @@ const char* pname(dqn_engine* e, const char* op, int kind, int i) {
 int build_program(dqn_engine* e) {
     if (e->prog_built) return 0;
     HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemsetAsync(e->gmax_part, 0, (size_t)gmax_slots(e->Pint) * 4, e->stream));      // per-block maxima of an earlier program shape must not survive
     e->prog_names.reserve(512);
     const int B = e->Bc /* columns of one sequence set: batch_size, or T*batch_size for DRQN */, ncon = e->ncon, ld0 = 2 * B, Bb = e->B, T = e->T;
     const bool mf = e->hp.use_mfma != 0, rec = e->hp.recurrence != 0;
@@ -228,10 +229,66 @@ int build_program(dqn_engine* e) {
     }
     // ---------------- backward of the online net on the s columns (Zygote through src/solver.jl:219-225)
     std::vector<RSeg> final_segs;   // dW split-K slabs: nothing reads the gradient before Adam, so ONE reduce launch at the end
+    // ---------------- Adam overlap (single GPU).  A layer's gradient is final once the launch of its level has run (fused heads: once the launch
+    // carrying their dW tail tasks has run), and from then on nothing reads its parameters (its dX ran at its own level).  So the Adam update of
+    // every such layer -- stream (unsplit dW) or slab reduce + update (split-K dW) -- rides as TAIL workgroups of the NEXT backward launch: the
+    // bandwidth-bound work overlaps the latency-bound conv backward launches; update_priorities! (needs only idx, td) rides on the first of them.
+    // The final k_adam is left with the first level's layers and the beta-power tick.
+    bool segs_ok = true;
+    for (int i = 0; i < e->nl; i++) { const LayerDev& L = e->L[i]; if (L.kind != DQN_LAYER_LSTM && dqn_nchunks(L.npos * B, L.dw_kc) > 1) segs_ok = segs_ok && L.w_off % 4 == 0 && ((size_t)(L.K + 1) * L.N) % 4 == 0; }
+    // MEASURED (profiles/README.md, r02_c): at config 2 this does NOT pay -- every workgroup of a launch reserves the launch's LDS tile, so the tail
+    // only runs in the slots the GEMM workgroups leave, and the conv layers' slab sums (49-134 dependent-by-rounds loads per element), hidden
+    // under the 92 MB stream of the single Adam launch, become exposed: 159.3 vs 156.9 us/step.  A second stream inside the graph (fork/join)
+    // costs ~50 us/step on this stack.  So the default is ONE Adam launch (DQN_ADAM_MODE=0); DQN_ADAM_MODE=1 selects the carried jobs (kept
+    // parity-tested: tests/test_gpu_parity.py::test_adam_jobs_carried_by_backward_launches).
+    const int adam_mode = e->adam_mode;      // read once, at dqn_engine_create
+    const bool early = !rec && !e->comm && !e->sim_world && segs_ok && adam_mode == 1;
+    struct PItem { unsigned long long beg, end; const float* part; int S; };      // part != nullptr: split-K slabs to reduce; else a streamable range
+    std::vector<PItem> adam_pending; std::vector<int> adam_after_tail; int gmax_next = 0; bool prio_placed = false;
+    auto base_job = [&]() {
+        AdamJob J; memset(&J, 0, sizeof J);
+        J.p = e->p_on; J.m = e->m; J.v = e->v; J.g = e->grad; J.g_out = e->grad; J.state = e->state; J.gmax_part = e->gmax_part;
+        J.f64mode = e->hp.adam_f64_scalars; J.lr = e->hp.learning_rate; J.b1 = e->hp.adam_beta1; J.b2 = e->hp.adam_beta2; J.eps = e->hp.adam_eps; J.gscale = 1.0f;
+        return J;
+    };
+    auto prio_args = [&]() { PrioArgs pa; memset(&pa, 0, sizeof pa); pa.n = B; pa.cap2 = e->cap2; pa.idx = e->idx; pa.td = e->td; pa.eps = e->hp.prio_eps; pa.alpha = e->hp.prio_alpha; pa.tree = e->tree; return pa; };
+    const bool prio_in_adam = e->hp.prioritized_replay && !rec && Bb <= 64;      // larger batches: side stream (prio_fork)
+    // layer l's gradient is final: queue its parameter range (split-K layers: as a slab segment)
+    auto adam_queue = [&](int l, const std::vector<RSeg>& segs_known) {
+        const LayerDev& L = e->L[l]; PItem it; it.beg = L.w_off; it.end = l + 1 < e->nl ? e->L[l + 1].w_off : e->Pint; it.part = nullptr; it.S = 0;
+        for (const RSeg& r : segs_known) if (r.out == e->grad + L.w_off) { it.part = r.part; it.S = r.S; it.end = it.beg + r.elems; }
+        adam_pending.push_back(it);
+    };
+    // one job out of the queue: every slab segment, and streamable ranges up to `budget` elements (a range is cut at a multiple of 4 when the
+    // budget runs out, so that the stream can be spread over several carrier launches); what does not fit the job's tables stays queued
+    auto make_job = [&](unsigned long long budget, bool tick) {
+        AdamJob J = base_job(); std::vector<PItem> left; unsigned long long streamed = 0, slabbed = 0;
+        std::sort(adam_pending.begin(), adam_pending.end(), [](const PItem& x, const PItem& y) { return x.beg < y.beg; });
+        for (PItem it : adam_pending) {
+            if (it.part) {
+                if (J.segs.n == 8) { left.push_back(it); continue; }
+                const int q = J.segs.n++; J.segs.beg[q] = it.beg; J.segs.end[q] = it.end; J.segs.part[q] = it.part; J.segs.S[q] = it.S; slabbed += it.end - it.beg;
+                continue;
+            }
+            if (streamed >= budget) { left.push_back(it); continue; }
+            if (it.end - it.beg > budget - streamed) { PItem rest = it; it.end = it.beg + ((budget - streamed + 3) / 4) * 4; rest.beg = it.end; if (rest.beg < rest.end) left.push_back(rest); }
+            if (J.nr > 0 && J.end[J.nr - 1] == it.beg) J.end[J.nr - 1] = it.end;
+            else if (J.nr < 4) { J.beg[J.nr] = it.beg; J.end[J.nr] = it.end; J.nr++; }
+            else { left.push_back(it); continue; }
+            streamed += it.end - it.beg;
+        }
+        adam_pending = left;
+        J.segs.blocks = (unsigned)((slabbed + 255) / 256);
+        J.sblocks = streamed ? (unsigned)adam_blocks((size_t)streamed) : 0u; J.tick = tick ? 1 : 0; if (tick && J.sblocks == 0) J.sblocks = 1;
+        if (!tick && J.sblocks > 512) J.sblocks = 512;      // carried by a backward launch: two streaming workgroups per CU leave the slots beside them to the GEMM workgroups
+        J.slot0 = gmax_next; gmax_next += (int)(J.segs.blocks + J.sblocks);
+        return J;
+    };
+    auto pending_stream = [&]() { unsigned long long n = 0; for (const PItem& it : adam_pending) if (!it.part) n += it.end - it.beg; return n; };
     bool joined = false;
     std::vector<VTask> tail_pend;    // small tasks waiting for a launch to ride on (fused heads: their dW/db and the loss fold)
     auto make_tail = [&](std::vector<VTask>& v) {
-        GemmTail t{nullptr, 0, 0};
+        GemmTail t = gemm_no_tail();
         if (v.empty()) return t;
         unsigned blocks = 0;
         for (auto& q : v) { q.first_block = blocks; blocks += valu_task_blocks(q); }
@@ -249,6 +306,7 @@ int build_program(dqn_engine* e) {
                 t.out = e->grad + L.w_off; tail_pend.push_back(t);
             }
             VTask f; memset(&f, 0, sizeof f); f.kind = 3; f.dpre = hl_buf; f.B = B; f.out = &e->state->loss; tail_pend.push_back(f);
+            if (early) for (int l : lv) adam_after_tail.push_back(l);
             continue;
         }
         bool dw_done_sibling = false;   // the level's two sibling layers got their dW from one fused launch
@@ -353,22 +411,34 @@ int build_program(dqn_engine* e) {
                 emit_reduce(e, one, pname(e, "dx_reduce", L.kind, l));
             }
         }
-        GemmTail tail{nullptr, 0, 0};
+        GemmTail tail = gemm_no_tail();
         if (!tail_pend.empty()) {
             if (dwl.on || dxl.on) tail = make_tail(tail_pend);                       // rides in the last workgroups of this level's LDS-tiled launch
             else { for (auto& t : tail_pend) pend.push_back(t); tail_pend.clear(); } // or joins this level's VALU task table
         }
+        if (early && (dwl.on || dxl.on) && (!adam_pending.empty() || (prio_in_adam && !prio_placed))) {
+            // this launch and the li launches below it share the queued stream evenly
+            tail.adam = make_job((pending_stream() / (unsigned long long)(li + 1) + 3) / 4 * 4, false); tail.has_adam = 1;
+            if (prio_in_adam && !prio_placed) { tail.adam.prio = prio_args(); prio_placed = true; }
+        }
         flush_valu(e, pend, pname(e, "bwd_valu", e->L[lv[0]].kind, lv[0]));
+        auto tailed = [&](const char* base) { if (!tail.has_adam) return base; char nm[80]; snprintf(nm, sizeof nm, "%s+adam_tail", base); e->prog_names.push_back(nm); return e->prog_names.back().c_str(); };
         if (dwl.on && dxl.on) {      // dW and dX of this level in ONE launch
             const DwL a = dwl; const DxL x = dxl; dwl.on = dxl.on = false;
-            char nm[48]; snprintf(nm, sizeof nm, "%s+%s", a.name, x.name); e->prog_names.push_back(nm); const char* name = e->prog_names.back().c_str();
+            char nm[80]; snprintf(nm, sizeof nm, "%s+%s%s", a.name, x.name, tail.has_adam ? "+adam_tail" : ""); e->prog_names.push_back(nm); const char* name = e->prog_names.back().c_str();
             e->prog.push_back({name, [=](dqn_engine* en) { launch_gemm_dwdx(en->stream, a.L, a.nprob, a.X, a.ldx, a.d, B, a.o, x.L, x.nsrc, x.W, x.d, x.out, x.ys, ncon, x.act_src, tail); }});
         }
-        else if (dwl.on) { const DwL a = dwl; dwl.on = false; e->prog.push_back({a.name, [=](dqn_engine* en) { launch_gemm_dw(en->stream, a.L, a.nprob, a.X, a.ldx, a.d, B, a.o, 0, 0, 0, tail); }}); }
-        else if (dxl.on) { const DxL a = dxl; dxl.on = false; e->prog.push_back({a.name, [=](dqn_engine* en) { launch_gemm_dx(en->stream, a.L, a.nsrc, a.W, a.d, B, a.out, a.ys, ncon, a.act_src, tail); }}); }
+        else if (dwl.on) { const DwL a = dwl; dwl.on = false; e->prog.push_back({tailed(a.name), [=](dqn_engine* en) { launch_gemm_dw(en->stream, a.L, a.nprob, a.X, a.ldx, a.d, B, a.o, 0, 0, 0, tail); }}); }
+        else if (dxl.on) { const DxL a = dxl; dxl.on = false; e->prog.push_back({tailed(a.name), [=](dqn_engine* en) { launch_gemm_dx(en->stream, a.L, a.nsrc, a.W, a.d, B, a.out, a.ys, ncon, a.act_src, tail); }}); }
         flush_dw(); flush_dx();
+        if (early) {      // gradients final from here on: this level's layers, and the fused heads whose dW tasks this level carried
+            for (int l : lv) adam_queue(l, final_segs);
+            for (int l : adam_after_tail) adam_queue(l, final_segs);
+            adam_after_tail.clear();
+        }
     }
     if (!tail_pend.empty()) { std::vector<VTask> own(tail_pend); tail_pend.clear(); flush_valu(e, own, "head_dw"); }      // single-level network: nothing to ride on
+    if (early) { for (int l : adam_after_tail) adam_queue(l, final_segs); adam_after_tail.clear(); }
     if (e->prio_forked) e->prog.push_back({"prio_join", [](dqn_engine* en) { hipStreamWaitEvent(en->stream, en->ev_join, 0); }});
     memset(&e->adam_segs, 0, sizeof e->adam_segs);
     {
@@ -452,12 +522,22 @@ int build_program(dqn_engine* e) {
         }
         if (!e->dp_adam_folds) e->prog.push_back({"dp_sum_ranks", [=](dqn_engine* en) { launch_dp_unpack_sum(en->stream, dsum); }});
     }
-    e->prog.push_back({"adam", [](dqn_engine* en) {
-        PrioArgs pa; pa.n = (en->hp.prioritized_replay && !en->hp.recurrence && !en->prio_forked) ? en->B : 0; pa.cap2 = en->cap2; pa.idx = en->idx; pa.td = en->td; pa.eps = en->hp.prio_eps; pa.alpha = en->hp.prio_alpha; pa.tree = en->tree;
-        AdamSegs none; memset(&none, 0, sizeof none);
-        const bool fold = en->adam_segs.n > 0 && !en->comm && !en->sim_world;     // with a communicator the gradient must be materialised before the all-reduce
-        launch_adam(en->stream, en->Pint, en->p_on, en->m, en->v, en->grad, en->state, en->gmax_part, en->hp.adam_f64_scalars, en->hp.learning_rate,
-                    en->hp.adam_beta1, en->hp.adam_beta2, en->hp.adam_eps, en->world > 1 ? 1.0f / (float)en->world : 1.0f, pa, (en->dp_gather && en->dp_adam_folds) ? en->dp_adam_segs : (fold ? en->adam_segs : none), en->grad); }});
+    if (early) {
+        // whatever is still pending (the first level's layers; layers that found no carrier) + the beta-power tick (+ the priority update if no
+        // backward launch could carry it)
+        std::vector<AdamJob> jobs;
+        bool first = true;
+        do { AdamJob J = make_job(~0ull, first); if (first && prio_in_adam && !prio_placed) { J.prio = prio_args(); prio_placed = true; } jobs.push_back(J); first = false; } while (!adam_pending.empty());
+        e->prog.push_back({"adam_rest", [=](dqn_engine* en) { for (const AdamJob& J : jobs) launch_adam(en->stream, J); }});
+    } else {
+        AdamJob J = base_job();
+        J.nr = 1; J.beg[0] = 0; J.end[0] = e->Pint; J.sblocks = (unsigned)adam_blocks(e->Pint); J.tick = 1; J.slot0 = 0;
+        if (e->hp.prioritized_replay && !rec && !e->prio_forked) J.prio = prio_args();
+        J.gscale = e->world > 1 ? 1.0f / (float)e->world : 1.0f;
+        const bool fold = e->adam_segs.n > 0 && !e->comm && !e->sim_world;     // with a communicator the gradient must be materialised before the all-reduce
+        if (e->dp_gather && e->dp_adam_folds) J.segs = e->dp_adam_segs; else if (fold) J.segs = e->adam_segs;
+        e->prog.push_back({"adam", [=](dqn_engine* en) { launch_adam(en->stream, J); }});
+    }
     e->prog_built = true;
     return 0;
 }

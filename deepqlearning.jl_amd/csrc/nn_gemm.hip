@@ -13,6 +13,7 @@
 
 #include "common.h"
 #include "valu_tasks.h"
+#include "adam_body.h"
 #include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -21,6 +22,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 void launch_reduce_pub(hipStream_t st, const float* part, int S, size_t elems, int mode, const float* bias, int per_n, int act,
                        const float* addend, const float* ysrc, int B, int ldy, float* out);
 
+// tail workgroups of a backward launch: VALU tasks first, then the Adam stream (blk counts from the first tail workgroup)
+__device__ __forceinline__ void gemm_tail_run(const GemmTail& tail, unsigned blk) {
+    if (blk < tail.blocks) { valu_task_run(tail.tasks, tail.n, blk); return; }
+    extern __shared__ float lds[];         // every LDS-tiled launch allocates > 8.3 KB
+    adam_job_run(tail.adam, (int)(blk - tail.blocks), nullptr, lds, true);
+}
+// the priority block of a carried Adam job is workgroup 0 of the launch: its ~14 dependent tree levels need the whole launch to hide under
+#define GEMM_TAIL_PROLOGUE(tail, bid_var, main_var)                                                                                     \
+    const int pre_ = (tail.has_adam && tail.adam.prio.n > 0) ? 1 : 0;                                                                   \
+    if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; prio_update_block(tail.adam.prio.n, tail.adam.prio.cap2, tail.adam.prio.idx, tail.adam.prio.td, tail.adam.prio.eps, tail.adam.prio.alpha, tail.adam.prio.tree, tail.adam.state, reinterpret_cast<long long*>(lds)); return; } \
+    const int bid_var = (int)blockIdx.x - pre_;                                                                                         \
+    const int main_var = (int)gridDim.x - (int)gemm_tail_blocks(tail);                                                                  \
+    if (bid_var >= main_var) { gemm_tail_run(tail, (unsigned)(bid_var - main_var)); return; }
 // =====================================================================================================================
 // forward:  Y[n][pos][col] = act( sum_k X[xb(pos)+koff(k)][col] * W[k][n] + bias[n] )
 // workgroup tile = 4 M-tiles (16 columns each, drawn from consecutive (pos, column-tile) pairs; wave w owns M-tile w)
@@ -360,9 +374,13 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
 }
 template <int NT>
 __global__ __launch_bounds__(256) void k_dw_lds(LayerDev L, GDwProbs pr, int nprob, int ldx, int B, int S, int kc, DwStride ds, GemmTail tail) {
-    const int main_blocks = (int)gridDim.x - (int)tail.blocks;
-    if ((int)blockIdx.x >= main_blocks) { valu_task_run(tail.tasks, tail.n, blockIdx.x - main_blocks); return; }
-    dw_lds_body<NT>(L, pr, nprob, ldx, B, S, kc, blockIdx.x, main_blocks, ds);
+    // dispatch order: [priority block][tail: VALU tasks, Adam job][dW workgroups] -- the bandwidth-bound tail starts at once and the short dW
+    // workgroups fill the slots beside it (at the END of the grid the tail would wait for LDS: every workgroup of a launch reserves the tile size)
+    const int pre_ = (tail.has_adam && tail.adam.prio.n > 0) ? 1 : 0;
+    if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; prio_update_block(tail.adam.prio.n, tail.adam.prio.cap2, tail.adam.prio.idx, tail.adam.prio.td, tail.adam.prio.eps, tail.adam.prio.alpha, tail.adam.prio.tree, tail.adam.state, reinterpret_cast<long long*>(lds)); return; }
+    const int bid = (int)blockIdx.x - pre_, ntail = (int)gemm_tail_blocks(tail) - pre_;
+    if (bid < ntail) { gemm_tail_run(tail, (unsigned)bid); return; }
+    dw_lds_body<NT>(L, pr, nprob, ldx, B, S, kc, bid - ntail, (int)gridDim.x - pre_ - ntail, ds);
 }
 bool gemm_dw_eligible(const LayerDev& L, int B, int ldx) {
     const int KK = L.npos * B, S = dqn_nchunks(KK, L.dw_kc), kc = dqn_chunk_len(KK, L.dw_kc);
@@ -375,7 +393,7 @@ void launch_gemm_dw(hipStream_t st, const LayerDev& L, int nprob, const float* c
     GDwProbs pr;
     for (int i = 0; i < 2; i++) { const int j = i < nprob ? i : 0; pr.p[i].X = X[j]; pr.p[i].dpre = dpre[j]; pr.p[i].out = out[j]; }
     const int NT = L.N % 64 == 0 ? 4 : (L.N % 32 == 0 ? 2 : 1);
-    const int grid = ((L.K + 63) / 64) * (L.N / (16 * NT)) * S * nprob + (int)tail.blocks;
+    const int grid = ((L.K + 63) / 64) * (L.N / (16 * NT)) * S * nprob + (int)gemm_tail_blocks(tail);
     const size_t lds = (size_t)(2 * 64 * W_ST + 2 * 16 * NT * W_ST) * 4;
     if (NT == 4) hipLaunchKernelGGL((k_dw_lds<4>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, tail);
     else if (NT == 2) hipLaunchKernelGGL((k_dw_lds<2>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, tail);
@@ -592,10 +610,9 @@ static bool dx_parallel_join(const LayerDev& L, int nsrc, int S) { return nsrc =
 static size_t dx_lds_bytes(bool pj) { return pj ? (size_t)(2 * 2 * 32 * X_SA + 2 * 2 * 32 * X_SB) * 4 : (size_t)(2 * 32 * X_SA + 2 * 32 * X_SB) * 4 + 256 * 4; }
 
 __global__ __launch_bounds__(256) void k_dx_lds(LayerDev L, GDxArgs A, int B, int S, int kc, int pj, int gx, GemmTail tail) {
-    const int main_blocks = (int)gridDim.x - (int)tail.blocks;
-    if ((int)blockIdx.x >= main_blocks) { valu_task_run(tail.tasks, tail.n, blockIdx.x - main_blocks); return; }
-    if (pj) dx_lds_body_pj(L, A, B, blockIdx.x % gx, gx, blockIdx.x / gx);
-    else dx_lds_body(L, A, B, S, kc, blockIdx.x % gx, gx, blockIdx.x / gx);
+    GEMM_TAIL_PROLOGUE(tail, bid, main_blocks)
+    if (pj) dx_lds_body_pj(L, A, B, bid % gx, gx, bid / gx);
+    else dx_lds_body(L, A, B, S, kc, bid % gx, gx, bid / gx);
 }
 // dW and dX of one layer are independent given dpre: ONE launch runs both (blocks [0, dw_blocks) do dW, the rest dX), which
 // saves a dispatch and lets the latency-bound dX workgroups share the machine with the dW ones.
@@ -604,11 +621,15 @@ __global__ __launch_bounds__(256) void k_dwdx_lds(LayerDev Lw, GDwProbs pr, int 
                                                   LayerDev Lx, GDxArgs A, int Sx, int kcx, int dx_gx, int pj, GemmTail tail) {
     // the few, long-latency dX workgroups are dispatched FIRST so that they run for the whole kernel while the many short dW
     // workgroups fill the remaining CUs (dispatch order is blockIdx order); a tail of small VALU tasks comes last
-    const int main_blocks = (int)gridDim.x - (int)tail.blocks;
-    if ((int)blockIdx.x >= main_blocks) { valu_task_run(tail.tasks, tail.n, blockIdx.x - main_blocks); return; }
-    const int dx_blocks = main_blocks - dw_blocks;
-    if ((int)blockIdx.x < dx_blocks) { if (pj) dx_lds_body_pj(Lx, A, B, blockIdx.x % dx_gx, dx_gx, blockIdx.x / dx_gx); else dx_lds_body(Lx, A, B, Sx, kcx, blockIdx.x % dx_gx, dx_gx, blockIdx.x / dx_gx); }
-    else dw_lds_body<NT>(Lw, pr, nprob, ldx, B, Sw, kcw, blockIdx.x - dx_blocks, dw_blocks, DwStride{Lw.npos * B, 0, 0});
+    // dispatch order: [priority block][dX workgroups][tail: VALU tasks, Adam job][dW workgroups]: the long-latency dX chains start first, the
+    // bandwidth-bound tail streams beside them, the many short dW workgroups fill the slots as they free up
+    const int pre_ = (tail.has_adam && tail.adam.prio.n > 0) ? 1 : 0;
+    if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; prio_update_block(tail.adam.prio.n, tail.adam.prio.cap2, tail.adam.prio.idx, tail.adam.prio.td, tail.adam.prio.eps, tail.adam.prio.alpha, tail.adam.prio.tree, tail.adam.state, reinterpret_cast<long long*>(lds)); return; }
+    const int bid = (int)blockIdx.x - pre_, ntail = (int)gemm_tail_blocks(tail) - pre_;
+    const int dx_blocks = (int)gridDim.x - pre_ - ntail - dw_blocks;
+    if (bid < dx_blocks) { if (pj) dx_lds_body_pj(Lx, A, B, bid % dx_gx, dx_gx, bid / dx_gx); else dx_lds_body(Lx, A, B, Sx, kcx, bid % dx_gx, dx_gx, bid / dx_gx); }
+    else if (bid < dx_blocks + ntail) gemm_tail_run(tail, (unsigned)(bid - dx_blocks));
+    else dw_lds_body<NT>(Lw, pr, nprob, ldx, B, Sw, kcw, bid - dx_blocks - ntail, dw_blocks, DwStride{Lw.npos * B, 0, 0});
 }
 bool gemm_dx_eligible(const LayerDev& L, int B, int ldy) {
     const bool dense = L.kind == DQN_LAYER_DENSE;
@@ -626,7 +647,7 @@ void launch_gemm_dx(hipStream_t st, const LayerDev& L, int nsrc, const float* co
     for (int i = 0; i < 2; i++) { const int j = i < nsrc ? i : 0; a.src[i].W = W[j]; a.src[i].dpre = dpre[j]; }
     const int gx = dense ? ((L.K + 31) / 32) * S : (L.cin / 32) * L.ih * L.iw;
     const bool pj = dx_parallel_join(L, nsrc, S);
-    hipLaunchKernelGGL(k_dx_lds, dim3(gx * (B / 32) + tail.blocks), dim3(256), dx_lds_bytes(pj), st, L, a, B, S, kc, pj ? 1 : 0, gx, tail);
+    hipLaunchKernelGGL(k_dx_lds, dim3(gx * (B / 32) + gemm_tail_blocks(tail)), dim3(256), dx_lds_bytes(pj), st, L, a, B, S, kc, pj ? 1 : 0, gx, tail);
 }
 
 void launch_gemm_dwdx(hipStream_t st, const LayerDev& Lw, int nprob, const float* const* X, int ldx, const float* const* dpre_w, int B, float* const* out_w,
@@ -644,7 +665,7 @@ void launch_gemm_dwdx(hipStream_t st, const LayerDev& Lw, int nprob, const float
     const bool pj = dx_parallel_join(Lx, nsrc, Sx);
     const size_t lds_w = (size_t)(2 * 64 * W_ST + 2 * 16 * NT * W_ST) * 4, lds_x = dx_lds_bytes(pj);
     const size_t lds = lds_w > lds_x ? lds_w : lds_x;
-    const int grid = dw_blocks + gx * (B / 32) + (int)tail.blocks;
+    const int grid = dw_blocks + gx * (B / 32) + (int)gemm_tail_blocks(tail);
     if (NT == 4) hipLaunchKernelGGL((k_dwdx_lds<4>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, pj ? 1 : 0, tail);
     else if (NT == 2) hipLaunchKernelGGL((k_dwdx_lds<2>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, pj ? 1 : 0, tail);
     else hipLaunchKernelGGL((k_dwdx_lds<1>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, pj ? 1 : 0, tail);

@@ -6,6 +6,7 @@
 // weight is a wave-uniform (scalar) load.
 #include "common.h"
 #include "valu_tasks.h"
+#include "adam_body.h"
 
 // ------------------------------------------------------------------ split-K reduction epilogues
 // mode 0: forward      Y = act(sum_s part + bias[n])             (n = e / per_n)
@@ -480,88 +481,20 @@ void launch_q_columns(hipStream_t st, int n, int nA, int dueling, const float* v
 }
 
 // ------------------------------------------------------------------ globalnorm (helpers.jl:38-46) + Flux Adam (solver.jl:66,228), fused, HBM-bound:
-// per element 16 B read (p,m,v,g) + 12 B written.  f64mode reproduces Flux 0.14's Float64 eta/beta/eps scalars.
-__global__ __launch_bounds__(256) void k_adam(size_t P, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
-                                              StepState* state, float* __restrict__ gmax_part, int f64mode, float lr, double b1, double b2, double eps,
-                                              float gscale, PrioArgs prio, AdamSegs segs, float* __restrict__ g_out) {
+// per element 16 B read (p,m,v,g) + 12 B written; the job body lives in adam_body.h (shared with the backward launches' tails)
+__global__ __launch_bounds__(256) void k_adam(AdamJob J) {
+    __shared__ long long sidx[1024]; __shared__ float wmax[4];
+    adam_job_run(J, (int)blockIdx.x, sidx, wmax);
+}
+// jobs without a priority block: no LDS to speak of, so their workgroups fit beside the LDS-heavy GEMM workgroups of a concurrent launch
+__global__ __launch_bounds__(256) void k_adam_stream(AdamJob J) {
     __shared__ float wmax[4];
-    __shared__ long long sidx[1024];
-    // update_priorities!(replay, indices, td) (src/solver.jl:231-233): one DEDICATED extra workgroup (block 0) walks the sum-tree
-    // while the other blocks stream the parameters -- its latency-bound levels ride inside this bandwidth-bound kernel instead of
-    // costing a launch of their own; the tree is next read by the following step's sampler.
-    int bid = blockIdx.x, nblk = gridDim.x;
-    if (prio.n > 0) {
-        if (blockIdx.x == 0) { prio_update_block(prio.n, prio.cap2, prio.idx, prio.td, prio.eps, prio.alpha, prio.tree, state, sidx); return; }
-        bid = blockIdx.x - 1; nblk = gridDim.x - 1;
-    }
-    // the FIRST segs.blocks blocks (dispatched first, so their long slab sums overlap the streaming of the rest) own the
-    // elements whose gradient is still split-K slabs, one element per thread
-    const bool rblock = segs.n > 0 && bid < (int)segs.blocks;
-    const int rbid = bid;
-    if (segs.n > 0) { nblk -= (int)segs.blocks; if (!rblock) bid -= (int)segs.blocks; }
-    // beta powers are double-buffered by step parity: this step reads slot (step & 1) and block 0 writes slot ((step+1) & 1)
-    // (Flux: bp .= bp .* beta AFTER the update), so no block can observe a half-updated value.
-    const int slot = (int)(state->step & 1ull);
-    const double bp1 = state->bp[slot][0], bp2 = state->bp[slot][1];
-    if (bid == 0 && threadIdx.x == 0) { state->bp[slot ^ 1][0] = bp1 * b1; state->bp[slot ^ 1][1] = bp2 * b2; }
-    const double c1 = 1.0 - bp1, c2 = 1.0 - bp2;
-    float gmax = 0.0f;
-    auto upd = [&](float gi, float& mi, float& vi, float& pi) {
-        if (gscale != 1.0f) gi = gi * gscale;
-        gmax = fmaxf(gmax, fabsf(gi));
-        float mn, vn, dl;
-        if (f64mode) {
-            const double gd = (double)gi;
-            const double t1 = b1 * (double)mi; const double t2 = (1.0 - b1) * gd; mn = (float)(t1 + t2);
-            const double u1 = b2 * (double)vi; const double u2 = (1.0 - b2) * gd; const double u3 = u2 * gd; vn = (float)(u1 + u3);
-            const double mh = (double)mn / c1; const double vh = (double)vn / c2; const double den = sqrt(vh) + eps; const double q1 = mh / den;
-            dl = (float)(q1 * (double)lr);
-        } else {
-            const float fb1 = (float)b1, fb2 = (float)b2;
-            const float t1 = fb1 * mi; const float t2 = (1.0f - fb1) * gi; mn = t1 + t2;
-            const float u1 = fb2 * vi; const float u2 = (1.0f - fb2) * gi; const float u3 = u2 * gi; vn = u1 + u3;
-            const float mh = mn / (1.0f - (float)bp1); const float vh = vn / (1.0f - (float)bp2); const float den = sqrtf(vh) + (float)eps; const float q1 = mh / den;
-            dl = q1 * lr;
-        }
-        mi = mn; vi = vn; pi = pi - dl;
-    };
-    if (rblock) {
-        size_t e = (size_t)rbid * blockDim.x + threadIdx.x;      // index into the concatenation of the segments
-        for (int q = 0; q < segs.n; q++) {
-            const size_t len = segs.end[q] - segs.beg[q];
-            if (e < len) {
-                const float tot = slab_sum(segs.part[q] + e, segs.stride[q] ? (size_t)segs.stride[q] : len, segs.S[q]);
-                const size_t i = segs.beg[q] + e;
-                g_out[i] = tot;                                       // the materialised gradient (dqn_get_grads, parity tests)
-                upd(tot, m[i], v[i], p[i]);
-                break;
-            }
-            e -= len;
-        }
-    } else {
-        // 16-B accesses: P is a multiple of 4 and every array is 16-B aligned (internal parameter layout); segment bounds are multiples of 4
-        const size_t P4 = P / 4;
-        for (size_t i = (size_t)bid * blockDim.x + threadIdx.x; i < P4; i += (size_t)nblk * blockDim.x) {
-            bool skip = false;
-            for (int q = 0; q < segs.n; q++) skip = skip || (4 * i >= segs.beg[q] && 4 * i < segs.end[q]);
-            if (skip) continue;
-            const float4 g4 = reinterpret_cast<const float4*>(g)[i]; float4 m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i], p4 = reinterpret_cast<float4*>(p)[i];
-            upd(g4.x, m4.x, v4.x, p4.x); upd(g4.y, m4.y, v4.y, p4.y); upd(g4.z, m4.z, v4.z, p4.z); upd(g4.w, m4.w, v4.w, p4.w);
-            reinterpret_cast<float4*>(m)[i] = m4; reinterpret_cast<float4*>(v)[i] = v4; reinterpret_cast<float4*>(p)[i] = p4;
-        }
-        for (size_t i = P4 * 4 + (size_t)bid * blockDim.x + threadIdx.x; i < P; i += (size_t)nblk * blockDim.x) upd(g[i], m[i], v[i], p[i]);
-    }
-    // wave max (64 lanes) then one value per block; max is order-independent, so this is exact
-    for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off));
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = gmax;
-    __syncthreads();
-    if (threadIdx.x == 0) gmax_part[rblock ? nblk + rbid : bid] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));   // folded on demand by k_update_priorities (bid counts main + reduce blocks)
+    adam_job_run(J, (int)blockIdx.x, nullptr, wmax);
 }
 int adam_blocks(size_t P) { size_t blocks = (P + 255) / 256; if (blocks > 2048) blocks = 2048; return (int)blocks; }
-void launch_adam(hipStream_t st, size_t P, float* p, float* m, float* v, const float* g, StepState* state, float* gmax_part, int f64mode, float lr,
-                 double b1, double b2, double eps, float gscale, const PrioArgs& prio, const AdamSegs& segs, float* g_out) {
-    const unsigned grid = (unsigned)adam_blocks(P) + (prio.n > 0 ? 1u : 0u) + (segs.n > 0 ? segs.blocks : 0u);
-    hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, st, P, p, m, v, g, state, gmax_part, f64mode, lr, b1, b2, eps, gscale, prio, segs, g_out);
+void launch_adam(hipStream_t st, const AdamJob& job) {
+    if (job.prio.n > 0) hipLaunchKernelGGL(k_adam, dim3(adam_job_blocks(job)), dim3(256), 0, st, job);
+    else hipLaunchKernelGGL(k_adam_stream, dim3(adam_job_blocks(job)), dim3(256), 0, st, job);
 }
 
 // ------------------------------------------------------------------ parameter layout conversion (Flux.params order <-> internal [K][N], conv kernels flipped)
