@@ -125,6 +125,7 @@ PROTOS = {
     "comm_unique_id": [_vp],
     "comm_init": [_vp, _vp, C.c_int, C.c_int],
     "sim_ranks_step": [_vp, _i64p, _f32p, _f32p, _f32p],
+    "debug_ktrace": [_vp, _P(C.c_uint64), _sz],
     "stream_sync": [_vp],
     "stream_handle": [_vp, _P(_vp)],
     "profile_step": [_vp, C.c_int, _P(C.c_char_p), _f32p, _P(C.c_int)],

@@ -34,7 +34,7 @@ __device__ __forceinline__ void adam_job_run(const AdamJob& J, int bid, long lon
     if (J.prio.n > 0 && !prio_elsewhere) {
         // update_priorities!(replay, indices, td): one DEDICATED workgroup walks the sum-tree while the others stream -- its latency-bound
         // levels ride inside a longer launch instead of costing one of their own; the tree is next read by the following step's sampler
-        if (bid == 0) { prio_update_block(J.prio.n, J.prio.cap2, J.prio.idx, J.prio.td, J.prio.eps, J.prio.alpha, J.prio.tree, J.state, sidx); return; }
+        if (bid == 0) { prio_block_run(J.prio, J.state, sidx); return; }
         bid--;
     }
     // beta powers are double-buffered by step parity: this step reads slot (step & 1); the job with `tick` writes slot ((step+1) & 1)

@@ -39,6 +39,8 @@ struct StepState {
     float loss;
     float gnorm;
     int err;                           // sticky device-side error code
+    int pre_valid;                     // the NEXT sample()'s indices are already in idx_pre (computed in the tail of the priority block with the
+                                       // final tree); cleared by everything that changes the tree, the size or the counters in between
 };
 
 static inline __host__ __device__ int dqn_nchunks(int K, int kc) { return (kc <= 0 || kc >= K) ? 1 : (K + kc - 1) / kc; }
@@ -116,7 +118,58 @@ __device__ __forceinline__ void prio_update_block(int n, long long cap2, const l
         __syncthreads();
     }
 }
-struct PrioArgs { int n; long long cap2; const long long* idx; const float* td; float eps, alpha; float* tree; };
+#ifdef __HIPCC__
+typedef float f32x4c __attribute__((ext_vector_type(4)));
+// one stratified sum-tree descent (sample(), src/prioritized_experience_replay.jl:82-87): stratum i of B, Philox4x32-10 keyed by (seed, call counter, i)
+__device__ __forceinline__ long long tree_descend(const float* __restrict__ tree, long long cap2, long long size, unsigned long long seed,
+                                                  unsigned long long ctr, int i, float seg) {
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)i, 0x5A4D504Cu};
+    philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), c);
+    const float u = (float)(c[0] >> 8) * (1.0f / 16777216.0f);
+    float t = ((float)i + u) * seg;
+    long long node = 1;
+    // three levels per memory round trip: the 2 children, 4 grandchildren and 8 great-grandchildren of a heap node are three
+    // contiguous runs (2n.., 4n.., 8n..), fetched with independent 8/16-byte loads; the three left/right decisions then use exactly
+    // the values (and the comparisons) of the one-level walk below, so the chosen leaf is identical.
+    while (8 * node < 2 * cap2) {
+        const float2 c = *reinterpret_cast<const float2*>(tree + 2 * node);
+        const f32x4c g = *reinterpret_cast<const f32x4c*>(tree + 4 * node);
+        const f32x4c h0 = *reinterpret_cast<const f32x4c*>(tree + 8 * node), h1 = *reinterpret_cast<const f32x4c*>(tree + 8 * node + 4);
+        int b1 = 0, b2 = 0, b3 = 0;
+        if (!(t < c.x || !(c.y > 0.0f))) { t -= c.x; b1 = 1; }
+        const float gl = b1 ? g.z : g.x, gr = b1 ? g.w : g.y;
+        if (!(t < gl || !(gr > 0.0f))) { t -= gl; b2 = 1; }
+        const f32x4c hh = b1 ? h1 : h0;
+        const float hl = b2 ? hh.z : hh.x, hr = b2 ? hh.w : hh.y;
+        if (!(t < hl || !(hr > 0.0f))) { t -= hl; b3 = 1; }
+        node = 8 * node + 4 * b1 + 2 * b2 + b3;
+    }
+    while (node < cap2) {
+        const float l = tree[2 * node], rg = tree[2 * node + 1];
+        if (t < l || !(rg > 0.0f)) node = 2 * node; else { t -= l; node = 2 * node + 1; }
+    }
+    long long leaf = node - cap2; if (leaf >= size) leaf = size - 1;
+    return leaf;
+}
+#endif
+struct PrioArgs { int n; long long cap2; const long long* idx; const float* td; float eps, alpha; float* tree;
+                  long long* idx_pre; unsigned long long seed; int B; };      // idx_pre != nullptr: also draw the next step's B indices (see prio_block_run)
+#ifdef __HIPCC__
+// the priority workgroup of a step: update_priorities!(replay, idx, td), then -- the tree is final and the Philox counter of the next sample()
+// is known (k_td / k_head_td bumped it earlier in this step) -- the NEXT step's B stratified descents, so that the next gather launch starts
+// with its row loads instead of ~5 dependent round trips per workgroup.  Anything that touches the tree, the size or the counters before
+// that gather clears state->pre_valid and the gather descends itself, exactly as before.
+__device__ __forceinline__ void prio_block_run(const PrioArgs& P, StepState* state, long long* sidx) {
+    prio_update_block(P.n, P.cap2, P.idx, P.td, P.eps, P.alpha, P.tree, state, sidx);
+    if (!P.idx_pre) return;
+    __syncthreads();
+    const unsigned long long ctr = state->sample_ctr; const long long size = state->size;
+    const float seg = P.tree[1] / (float)P.B;
+    for (int i = threadIdx.x; i < P.B; i += blockDim.x) P.idx_pre[i] = tree_descend(P.tree, P.cap2, size, P.seed, ctr, i, seg);
+    __syncthreads();
+    if (threadIdx.x == 0) state->pre_valid = 1;
+}
+#endif
 // deferred dW split-K slabs reduced INSIDE the Adam launch by dedicated blocks (single-GPU path): element ranges [beg, end) of the
 // gradient vector, each the ascending sum of S slabs
 struct AdamSegs { int n; unsigned long long beg[8], end[8]; const float* part[8]; int S[8]; unsigned blocks; unsigned long long stride[8]; };   // stride 0: slabs `len` apart
@@ -189,7 +242,7 @@ void launch_reduce_multi(hipStream_t st, const RSeg* segs_dev, int nseg, unsigne
 struct BatchMeta { const int* a; const float* r; const unsigned char* done; float beta; int* a_out; float* r_out; float* done_out; float* w_out; };
 void launch_gather_fb(hipStream_t st, const void* s_rows, const void* sp_rows, int obs_u8, int E, int B,
                       long long* idx, float* x0 /*[E][2B]*/, int do_sample, long long cap2, const float* tree, unsigned long long seed,
-                      const StepState* state, const BatchMeta& meta);
+                      const StepState* state, const BatchMeta& meta, const long long* idx_pre /* or null */);
 void launch_gather_rows(hipStream_t st, const void* rows, int obs_u8, int E, int n, const long long* idx, float* out /*[n][E]*/);
 void launch_transpose_obs(hipStream_t st, const float* obs /*[n][E]*/, int E, int n, float* x /*[E][n]*/);
 void launch_replay_commit(hipStream_t st, int n, long long start, long long cap, long long cap2, const int* a_in, const float* r_in,
@@ -216,6 +269,7 @@ void launch_convert_params(hipStream_t st, const LayerDev* layers_dev, int nl, c
 
 // LDS-tiled MFMA path (nn_gemm.hip): up to two problems (online / target net) of one layer per launch
 bool gemm_fwd_eligible(const LayerDev& L, int nprob, const int* ldx, const int* col0, const int* ncols);
+void gemm_set_ktrace(unsigned long long* p);   // debug: per-workgroup timestamps of the forward kernels (nullptr = off)
 void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* const* W, const float* const* bias, const float* const* X,
                      const int* ldx, const int* col0, const int* ncols, float* const* out /* Y, or split-K partial slabs */);
 

@@ -33,7 +33,7 @@ struct dqn_engine {
     static const int ADD_CHUNK = 1024;
     int* st_a = nullptr; float* st_r = nullptr; unsigned char* st_done = nullptr; float* st_td = nullptr;
     // step workspace
-    long long* idx = nullptr; float* x0 = nullptr;
+    long long* idx = nullptr; long long* idx_pre = nullptr; float* x0 = nullptr;      // idx_pre: the next sample()'s indices, drawn by the priority block (StepState::pre_valid)
     float *act_on[DQN_MAX_LAYERS] = {}, *act_tg[DQN_MAX_LAYERS] = {}, *dact[DQN_MAX_LAYERS] = {};
     float *join_tmp = nullptr, *partials = nullptr, *gmax_part = nullptr; size_t partials_elems = 0;
     float *w_is = nullptr, *td = nullptr, *q_on_s = nullptr, *q_on_sp = nullptr, *q_tg_sp = nullptr, *ytarget = nullptr; int* best = nullptr;

@@ -191,7 +191,7 @@ static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers
     DM(e->ra, e->cap); DM(e->rr, e->cap); DM(e->rdone, e->cap); DM(e->tree, 2 * (size_t)e->cap2);
     HIPCHK(hipMemset(e->tree, 0, 2 * (size_t)e->cap2 * 4));
     DM(e->st_a, dqn_engine::ADD_CHUNK); DM(e->st_r, dqn_engine::ADD_CHUNK); DM(e->st_done, dqn_engine::ADD_CHUNK); DM(e->st_td, dqn_engine::ADD_CHUNK);
-    DM(e->idx, B); HIPCHK(hipMemset(e->idx, 0, B * 8)); DM(e->x0, (size_t)e->E * 2 * Bc);
+    DM(e->idx, B); HIPCHK(hipMemset(e->idx, 0, B * 8)); DM(e->idx_pre, B); HIPCHK(hipMemset(e->idx_pre, 0, B * 8)); DM(e->x0, (size_t)e->E * 2 * Bc);
     size_t pmax = 1, jmax = 1;
     for (int i = 0; i < e->nl; i++) {
         const LayerDev& l = e->L[i];
@@ -250,7 +250,7 @@ extern "C" int dqn_engine_destroy(dqn_engine_t* e) {
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     hipFree(e->L_dev); hipFree(e->p_on); hipFree(e->p_tg); hipFree(e->grad); hipFree(e->m); hipFree(e->v); hipFree(e->io_tmp); hipFree(e->state);
     hipFree(e->s_rows); hipFree(e->sp_rows); hipFree(e->ra); hipFree(e->rr); hipFree(e->rdone); hipFree(e->tree);
-    hipFree(e->st_a); hipFree(e->st_r); hipFree(e->st_done); hipFree(e->st_td); hipFree(e->idx); hipFree(e->x0);
+    hipFree(e->st_a); hipFree(e->st_r); hipFree(e->st_done); hipFree(e->st_td); hipFree(e->idx); hipFree(e->idx_pre); hipFree(e->x0);
     for (int i = 0; i < e->nl; i++) { hipFree(e->act_on[i]); hipFree(e->act_tg[i]); hipFree(e->dact[i]); }
     hipFree(e->join_tmp); hipFree(e->partials); hipFree(e->gmax_part); hipFree(e->w_is); hipFree(e->td); hipFree(e->q_on_s); hipFree(e->q_on_sp); hipFree(e->q_tg_sp);
     hipFree(e->ytarget); hipFree(e->best); hipFree(e->gb_rows); hipFree(e->gb_r); hipFree(e->gb_done); hipFree(e->gb_w); hipFree(e->gb_a); hipFree(e->gb_idx);
@@ -391,7 +391,7 @@ extern "C" int dqn_replay_import(dqn_engine_t* e, int64_t n, const void* s, cons
     HIPCHK(hipMemcpy(e->tree + e->cap2, prio, (size_t)n * 4, hipMemcpyHostToDevice));
     launch_tree_rebuild(e->stream, e->tree, e->cap2);
     StepState st; HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipMemcpy(&st, e->state, sizeof st, hipMemcpyDeviceToHost));
-    st.size = n; HIPCHK(hipMemcpy(e->state, &st, sizeof st, hipMemcpyHostToDevice));
+    st.size = n; st.pre_valid = 0; HIPCHK(hipMemcpy(e->state, &st, sizeof st, hipMemcpyHostToDevice));
     e->size = n; e->widx = n % e->cap;
     return 0;
 }
@@ -409,7 +409,7 @@ extern "C" int dqn_set_counters(dqn_engine_t* e, const dqn_counters* in) { if (!
     // slot (S + 1) & 1 -- the slot dqn_get_adam_state reports.  Whatever the new parity, make both slots hold the live pair.
     const int live = (int)((st.step + 1ull) & 1ull);
     st.bp[live ^ 1][0] = st.bp[live][0]; st.bp[live ^ 1][1] = st.bp[live][1];
-    st.sample_ctr = in->sample_ctr; st.step = in->train_steps;
+    st.sample_ctr = in->sample_ctr; st.step = in->train_steps; st.pre_valid = 0;
     HIPCHK(hipMemcpy(e->state, &st, sizeof st, hipMemcpyHostToDevice));
     e->widx = in->widx; return 0;
 }
@@ -482,7 +482,7 @@ void enqueue_step(dqn_engine* e, bool sample, int phase) {
             if (sample && !fused) RUN(e, "sample", launch_sample(e->stream, e->B, e->cap2, e->tree, e->hp.seed, e->idx, e->state, 0));    // k_td bumps the Philox counter
             BatchMeta bm; bm.a = e->ra; bm.r = e->rr; bm.done = e->rdone; bm.beta = e->hp.prio_beta; bm.a_out = e->gb_a2; bm.r_out = e->gb_r2; bm.done_out = e->gb_done2; bm.w_out = e->gb_w2;
             RUN(e, fused ? "sample_gather" : "gather", launch_gather_fb(e->stream, e->s_rows, e->sp_rows, e->hp.obs_dtype == DQN_OBS_U8, e->E, e->B, e->idx, e->x0,
-                                                                        fused ? 1 : 0, e->cap2, e->tree, e->hp.seed, e->state, bm));
+                                                                        fused ? 1 : 0, e->cap2, e->tree, e->hp.seed, e->state, bm, e->idx_pre));
         }
         for (size_t i = 0; i < e->prog_post_begin; i++) {
             if ((long)i == e->final_reduce_step && ((e->adam_segs.n > 0 && !e->comm && !e->sim_world) || (e->dp_gather && e->dp_pack_folds))) continue;   // folded into k_adam / k_dp_pack   // folded into k_adam
@@ -706,6 +706,16 @@ extern "C" int dqn_comm_init(dqn_engine_t* e, const void* id128, int rank, int w
 // ---------------------------------------------------------------- misc
 extern "C" int dqn_stream_sync(dqn_engine_t* e) { if (!e) return fail("null engine handle"); HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream)); return 0; }
 extern "C" int dqn_stream_handle(dqn_engine_t* e, void** s) { if (!e) return fail("null engine handle"); *s = (void*)e->stream; return 0; }
+// debug aid: per-workgroup s_memtime records of the forward GEMM kernels (nn_gemm.hip, KTRACE).  out == NULL: start recording (room for 65536
+// records); out != NULL: stop and copy counter + records (n 64-bit words) to the host.  Process-wide (one engine at a time).
+extern "C" int dqn_debug_ktrace(dqn_engine_t* e, uint64_t* out, size_t n) { if (!e) return fail("null engine handle");
+    static unsigned long long* buf = nullptr; const size_t words = 1 + 8 * 65536ull;
+    HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream));
+    if (!out) { if (!buf) HIPCHK(hipMalloc((void**)&buf, words * 8)); HIPCHK(hipMemset(buf, 0, words * 8)); gemm_set_ktrace(buf); return 0; }
+    gemm_set_ktrace(nullptr);
+    if (!buf) return fail("ktrace was not started");
+    HIPCHK(hipMemcpy(out, buf, std::min(n, words) * 8, hipMemcpyDeviceToHost)); return 0;
+}
 // Holds the stream until the host has enqueued the whole profiled step, so that the HIP events around each kernel time
 // the kernel and not the host's launch latency.  Bounded spin (~0.2 s) so a dead host can never hang the GPU.
 __global__ void k_gate(volatile int* flag) {

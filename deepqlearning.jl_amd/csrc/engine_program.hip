@@ -251,7 +251,9 @@ int build_program(dqn_engine* e) {
         J.f64mode = e->hp.adam_f64_scalars; J.lr = e->hp.learning_rate; J.b1 = e->hp.adam_beta1; J.b2 = e->hp.adam_beta2; J.eps = e->hp.adam_eps; J.gscale = 1.0f;
         return J;
     };
-    auto prio_args = [&]() { PrioArgs pa; memset(&pa, 0, sizeof pa); pa.n = B; pa.cap2 = e->cap2; pa.idx = e->idx; pa.td = e->td; pa.eps = e->hp.prio_eps; pa.alpha = e->hp.prio_alpha; pa.tree = e->tree; return pa; };
+    auto prio_args = [&]() { PrioArgs pa; memset(&pa, 0, sizeof pa); pa.n = B; pa.cap2 = e->cap2; pa.idx = e->idx; pa.td = e->td; pa.eps = e->hp.prio_eps; pa.alpha = e->hp.prio_alpha; pa.tree = e->tree;
+                              if (Bb <= 64) { pa.idx_pre = e->idx_pre; pa.seed = e->hp.seed; pa.B = Bb; }      // the fused sample+gather launch (B <= 64) consumes them
+                              return pa; };
     const bool prio_in_adam = e->hp.prioritized_replay && !rec && Bb <= 64;      // larger batches: side stream (prio_fork)
     // layer l's gradient is final: queue its parameter range (split-K layers: as a slab segment)
     auto adam_queue = [&](int l, const std::vector<RSeg>& segs_known) {

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(1024) void k_env_step(EnvDev V, RolloutDev* rs, Act
             __syncthreads();
         }
     }
-    if (threadIdx.x == 0) { long long s = R.state->size + n; R.state->size = s > R.cap ? R.cap : s; }
+    if (threadIdx.x == 0) { long long s = R.state->size + n; R.state->size = s > R.cap ? R.cap : s; R.state->pre_valid = 0; }     // the tree changed: pre-drawn indices are stale
 }
 void launch_env_step(hipStream_t st, const EnvDev& V, RolloutDev* rs, const ActHeads& Hd, const ReplayMeta& R) {
     hipLaunchKernelGGL(k_env_step, dim3(1), dim3(1024), 0, st, V, rs, Hd, R);

@@ -19,6 +19,14 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// ---- debug aid (dqn_debug_ktrace): per-workgroup timestamps of the forward kernels.  g_ktrace[0] = record counter, then 8-word records
+// {gridDim.x, blockIdx.x, s_memtime at: entry, tables ready, first tile in LDS, K loop done, chunks combined, stores issued}.
+__device__ unsigned long long* g_ktrace = nullptr;
+void gemm_set_ktrace(unsigned long long* p) { hipMemcpyToSymbol(HIP_SYMBOL(g_ktrace), &p, sizeof p); }
+#define KTRACE_BEGIN() unsigned long long* tr_ = g_ktrace; unsigned long long trs_ = 0; \
+    if (tr_ && threadIdx.x == 0) { trs_ = 1 + 8 * atomicAdd(tr_, 1ull); if (trs_ + 8 < 1 + 8 * 65536ull) { tr_[trs_] = gridDim.x; tr_[trs_ + 1] = blockIdx.x; tr_[trs_ + 2] = __builtin_amdgcn_s_memtime(); } else trs_ = 0; }
+#define KTRACE(i) do { if (trs_) tr_[trs_ + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+
 void launch_reduce_pub(hipStream_t st, const float* part, int S, size_t elems, int mode, const float* bias, int per_n, int act,
                        const float* addend, const float* ysrc, int B, int ldy, float* out);
 
@@ -31,7 +39,7 @@ __device__ __forceinline__ void gemm_tail_run(const GemmTail& tail, unsigned blk
 // the priority block of a carried Adam job is workgroup 0 of the launch: its ~14 dependent tree levels need the whole launch to hide under
 #define GEMM_TAIL_PROLOGUE(tail, bid_var, main_var)                                                                                     \
     const int pre_ = (tail.has_adam && tail.adam.prio.n > 0) ? 1 : 0;                                                                   \
-    if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; prio_update_block(tail.adam.prio.n, tail.adam.prio.cap2, tail.adam.prio.idx, tail.adam.prio.td, tail.adam.prio.eps, tail.adam.prio.alpha, tail.adam.prio.tree, tail.adam.state, reinterpret_cast<long long*>(lds)); return; } \
+    if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; prio_block_run(tail.adam.prio, tail.adam.state, reinterpret_cast<long long*>(lds)); return; } \
     const int bid_var = (int)blockIdx.x - pre_;                                                                                         \
     const int main_var = (int)gridDim.x - (int)gemm_tail_blocks(tail);                                                                  \
     if (bid_var >= main_var) { gemm_tail_run(tail, (unsigned)(bid_var - main_var)); return; }
@@ -56,13 +64,14 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     extern __shared__ float lds[];
     float* As = lds;                                   // [2][F_KT][F_SA]
     float* Bs = lds + 2 * F_KT * F_SA;                 // [2][F_KT][SB]
-    int* koff_lds = (int*)(Bs + 2 * F_KT * SB);        // [K] (conv only)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    KTRACE_BEGIN()
     const bool conv = L.kind == DQN_LAYER_CONV;
-    if (conv) {
-        const int khw = L.kh * L.kw;
-        for (int k = tid; k < L.K; k += 256) { const int ci = k / khw, ky = (k / L.kw) % L.kh, kx = k % L.kw; koff_lds[k] = (ci * L.ih + ky) * L.iw + kx; }
-    }
+    // conv: input-row offset of contraction index k = (ci, ky, kx), computed where it is used with two multiplies (floor((x + 0.5) / d) through
+    // the reciprocal is exact for these small ints).  A table of all K offsets in LDS, filled with integer divisions behind a barrier, cost
+    // 0.85-2.0 us at the head of every conv launch (ktrace, r02) before the first operand load could even be issued.
+    const float r_khw = 1.0f / (float)(L.kh * L.kw), r_kw = 1.0f / (float)L.kw; const int khw_ = L.kh * L.kw;
+    auto koff_of = [&](int k) { const int ci = (int)(((float)k + 0.5f) * r_khw); const int rem = k - ci * khw_; const int ky = (int)(((float)rem + 0.5f) * r_kw); return (ci * L.ih + ky) * L.iw + (rem - ky * L.kw); };
     int pi = 0;
     while (pi < 3 && (int)blockIdx.x >= pr.wg_end[pi]) pi++;
     const GFwdProb& p = pr.p[pi];
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     constexpr int BQ = (F_KT * BF4 + 255) / 256;       // float4 per thread (1 or 2)
     const float* Wp = p.W + n0;
 
-    if (conv) __syncthreads();                         // koff table ready
+    KTRACE(3);
     // Register staging with HAND-COUNTED waits.  hipcc's waitcnt pass drains vmcnt(0) before every prefetch issue in a
     // pipelined loop with conditional loads (seen in the ISA), which exposes the full L2/HBM latency once per K tile.
     // So the staging loads are inline asm (invisible to that pass), ALWAYS issued (tile index clamped, so the number of
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
 #pragma unroll
         for (int q = 0; q < AQ; q++) {
             const int ka = kb + arow + 16 * q;
-            const int ko = conv ? koff_lds[ka] : ka;
+            const int ko = conv ? koff_of(ka) : ka;
             r.a[q] = gld(Xa + (unsigned)(a_xb + ko) * ldx);
         }
 #pragma unroll
@@ -163,6 +172,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     // are issued into the other; one barrier per K tile.
     Stage r0, r1;
     gload(0, r0); STAGE_WAIT(0, r0); lstore(0, r0); __syncthreads();
+    KTRACE(4);
     gload(1, r0);
     for (int kt = 0; kt < nkt; kt += 2) {
         gload(kt + 2, r1);
@@ -175,6 +185,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
         __syncthreads();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the clamped tail loads before the registers are reused
+    KTRACE(5); KTRACE(6);
 #undef STAGE_WAIT
     // ---- epilogue: wave w's M-tile
     const int mt = mgrp * 4 + wave;
@@ -191,6 +202,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
         }
         *reinterpret_cast<f32x4*>(p.out + (size_t)s * per_s + ((size_t)n * L.npos + pos) * p.ncols + ct * 16 + 4 * kq) = v;
     }
+    KTRACE(7);
 }
 
 static int fwd_pick_nt(const LayerDev& L, long mgroups_total, int S) {
@@ -233,7 +245,7 @@ void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* 
     int end = 0;
     for (int i = 0; i < 4; i++) { if (i < nprob) end += pr.p[i].mgroups * ngroups * S; pr.wg_end[i] = end; }
     const int SB = NT == 4 ? FwdCfg<4>::SB : (NT == 2 ? FwdCfg<2>::SB : FwdCfg<1>::SB);
-    const size_t lds = (size_t)(2 * F_KT * F_SA + 2 * F_KT * SB) * 4 + (L.kind == DQN_LAYER_CONV ? (size_t)L.K * 4 : 0);
+    const size_t lds = (size_t)(2 * F_KT * F_SA + 2 * F_KT * SB) * 4;
     if (NT == 4) hipLaunchKernelGGL((k_fwd_lds<4>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
     else if (NT == 2) hipLaunchKernelGGL((k_fwd_lds<2>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
     else hipLaunchKernelGGL((k_fwd_lds<1>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
@@ -377,7 +389,7 @@ __global__ __launch_bounds__(256) void k_dw_lds(LayerDev L, GDwProbs pr, int npr
     // dispatch order: [priority block][tail: VALU tasks, Adam job][dW workgroups] -- the bandwidth-bound tail starts at once and the short dW
     // workgroups fill the slots beside it (at the END of the grid the tail would wait for LDS: every workgroup of a launch reserves the tile size)
     const int pre_ = (tail.has_adam && tail.adam.prio.n > 0) ? 1 : 0;
-    if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; prio_update_block(tail.adam.prio.n, tail.adam.prio.cap2, tail.adam.prio.idx, tail.adam.prio.td, tail.adam.prio.eps, tail.adam.prio.alpha, tail.adam.prio.tree, tail.adam.state, reinterpret_cast<long long*>(lds)); return; }
+    if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; prio_block_run(tail.adam.prio, tail.adam.state, reinterpret_cast<long long*>(lds)); return; }
     const int bid = (int)blockIdx.x - pre_, ntail = (int)gemm_tail_blocks(tail) - pre_;
     if (bid < ntail) { gemm_tail_run(tail, (unsigned)bid); return; }
     dw_lds_body<NT>(L, pr, nprob, ldx, B, S, kc, bid - ntail, (int)gridDim.x - pre_ - ntail, ds);
@@ -624,7 +636,7 @@ __global__ __launch_bounds__(256) void k_dwdx_lds(LayerDev Lw, GDwProbs pr, int 
     // dispatch order: [priority block][dX workgroups][tail: VALU tasks, Adam job][dW workgroups]: the long-latency dX chains start first, the
     // bandwidth-bound tail streams beside them, the many short dW workgroups fill the slots as they free up
     const int pre_ = (tail.has_adam && tail.adam.prio.n > 0) ? 1 : 0;
-    if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; prio_update_block(tail.adam.prio.n, tail.adam.prio.cap2, tail.adam.prio.idx, tail.adam.prio.td, tail.adam.prio.eps, tail.adam.prio.alpha, tail.adam.prio.tree, tail.adam.state, reinterpret_cast<long long*>(lds)); return; }
+    if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; prio_block_run(tail.adam.prio, tail.adam.state, reinterpret_cast<long long*>(lds)); return; }
     const int bid = (int)blockIdx.x - pre_, ntail = (int)gemm_tail_blocks(tail) - pre_;
     const int dx_blocks = (int)gridDim.x - pre_ - ntail - dw_blocks;
     if (bid < dx_blocks) { if (pj) dx_lds_body_pj(Lx, A, B, bid % dx_gx, dx_gx, bid / dx_gx); else dx_lds_body(Lx, A, B, Sx, kcx, bid % dx_gx, dx_gx, bid / dx_gx); }

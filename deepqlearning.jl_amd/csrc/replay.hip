@@ -16,36 +16,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // With do_sample, every workgroup first repeats the (cheap, deterministic) stratified sum-tree descent for the 2B columns
 // it needs -- B descents of log2(cap) dependent L2 hits -- instead of waiting for a separate single-workgroup sample
 // launch (~4.6 us floor); workgroup (0,0) publishes the indices for k_td.  The Philox counter is bumped by k_td.
-__device__ __forceinline__ long long tree_descend(const float* __restrict__ tree, long long cap2, long long size, unsigned long long seed,
-                                                  unsigned long long ctr, int i, float seg) {
-    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)i, 0x5A4D504Cu};
-    philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), c);
-    const float u = (float)(c[0] >> 8) * (1.0f / 16777216.0f);
-    float t = ((float)i + u) * seg;
-    long long node = 1;
-    // three levels per memory round trip: the 2 children, 4 grandchildren and 8 great-grandchildren of a heap node are three
-    // contiguous runs (2n.., 4n.., 8n..), fetched with independent 8/16-byte loads; the three left/right decisions then use exactly
-    // the values (and the comparisons) of the one-level walk below, so the chosen leaf is identical.
-    while (8 * node < 2 * cap2) {
-        const float2 c = *reinterpret_cast<const float2*>(tree + 2 * node);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(tree + 4 * node);
-        const f32x4 h0 = *reinterpret_cast<const f32x4*>(tree + 8 * node), h1 = *reinterpret_cast<const f32x4*>(tree + 8 * node + 4);
-        int b1 = 0, b2 = 0, b3 = 0;
-        if (!(t < c.x || !(c.y > 0.0f))) { t -= c.x; b1 = 1; }
-        const float gl = b1 ? g.z : g.x, gr = b1 ? g.w : g.y;
-        if (!(t < gl || !(gr > 0.0f))) { t -= gl; b2 = 1; }
-        const f32x4 hh = b1 ? h1 : h0;
-        const float hl = b2 ? hh.z : hh.x, hr = b2 ? hh.w : hh.y;
-        if (!(t < hl || !(hr > 0.0f))) { t -= hl; b3 = 1; }
-        node = 8 * node + 4 * b1 + 2 * b2 + b3;
-    }
-    while (node < cap2) {
-        const float l = tree[2 * node], rg = tree[2 * node + 1];
-        if (t < l || !(rg > 0.0f)) node = 2 * node; else { t -= l; node = 2 * node + 1; }
-    }
-    long long leaf = node - cap2; if (leaf >= size) leaf = size - 1;
-    return leaf;
-}
 // batch scalars + IS weights of the B sampled transitions (k_batch_meta's arithmetic), by the first 64 lanes of ONE workgroup at the END of the
 // gather launch: its two dependent round trips and the double-precision pow overlap the other workgroups' row traffic
 __device__ __forceinline__ void gather_batch_meta(const BatchMeta& M, const long long* rows, int c0, int B, long long cap2, const float* __restrict__ tree,
@@ -61,7 +31,8 @@ __device__ __forceinline__ void gather_batch_meta(const BatchMeta& M, const long
 }
 __global__ __launch_bounds__(256) void k_gather_fb(const void* __restrict__ s_rows, const void* __restrict__ sp_rows, int u8, int E, int B,
                                                    long long* __restrict__ idx, float* __restrict__ x0, int do_sample, long long cap2,
-                                                   const float* __restrict__ tree, unsigned long long seed, const StepState* __restrict__ state, BatchMeta meta) {
+                                                   const float* __restrict__ tree, unsigned long long seed, const StepState* __restrict__ state, BatchMeta meta,
+                                                   const long long* __restrict__ idx_pre) {
     __shared__ float tile[64][65];
     __shared__ long long rows[64];
     const int f0 = blockIdx.x * 64, c0 = blockIdx.y * 64, lane = threadIdx.x & 63, w = threadIdx.x >> 6, ld = 2 * B;
@@ -71,7 +42,8 @@ __global__ __launch_bounds__(256) void k_gather_fb(const void* __restrict__ s_ro
         if (c < ld) {
             const int i = c < B ? c : c - B;
             if (do_sample) {
-                r = tree_descend(tree, cap2, state->size, seed, state->sample_ctr, i, tree[1] / (float)B);
+                // the indices of this sample() were drawn in the tail of the previous step's priority block unless something changed the tree since
+                r = (idx_pre && state->pre_valid) ? idx_pre[i] : tree_descend(tree, cap2, state->size, seed, state->sample_ctr, i, tree[1] / (float)B);
                 if (blockIdx.x == 0 && c < B) idx[i] = r;
             } else r = idx[i];
         }
@@ -124,7 +96,8 @@ __global__ __launch_bounds__(256) void k_gather_fb(const void* __restrict__ s_ro
 // tiling also means 4x fewer repeats of the descent when it is fused.
 __global__ __launch_bounds__(256) void k_gather_fb_u8(const unsigned char* __restrict__ s_rows, const unsigned char* __restrict__ sp_rows, int E, int B,
                                                       long long* __restrict__ idx, float* __restrict__ x0, int do_sample, long long cap2,
-                                                      const float* __restrict__ tree, unsigned long long seed, const StepState* __restrict__ state, BatchMeta meta) {
+                                                      const float* __restrict__ tree, unsigned long long seed, const StepState* __restrict__ state, BatchMeta meta,
+                                                      const long long* __restrict__ idx_pre) {
     // the tile stays PACKED in LDS (64 columns x 64 words of 4 features = 16.6 KB instead of 66 KB of floats): several workgroups per CU keep the
     // random 256-B row reads in flight; bytes are unpacked and converted (256-entry table: one IEEE division per value of b, not per element)
     // on the way out
@@ -139,7 +112,8 @@ __global__ __launch_bounds__(256) void k_gather_fb_u8(const unsigned char* __res
         if (c < ld) {
             const int i = c < B ? c : c - B;
             if (do_sample) {
-                r = tree_descend(tree, cap2, state->size, seed, state->sample_ctr, i, tree[1] / (float)B);
+                // the indices of this sample() were drawn in the tail of the previous step's priority block unless something changed the tree since
+                r = (idx_pre && state->pre_valid) ? idx_pre[i] : tree_descend(tree, cap2, state->size, seed, state->sample_ctr, i, tree[1] / (float)B);
                 if (blockIdx.x == 0 && c < B) idx[i] = r;
             } else r = idx[i];
         }
@@ -171,15 +145,15 @@ __global__ __launch_bounds__(256) void k_gather_fb_u8(const unsigned char* __res
     if (blockIdx.x == 0) gather_batch_meta(meta, rows, c0, B, cap2, tree, state);
 }
 void launch_gather_fb(hipStream_t st, const void* s_rows, const void* sp_rows, int obs_u8, int E, int B, long long* idx, float* x0, int do_sample,
-                      long long cap2, const float* tree, unsigned long long seed, const StepState* state, const BatchMeta& meta) {
+                      long long cap2, const float* tree, unsigned long long seed, const StepState* state, const BatchMeta& meta, const long long* idx_pre) {
     if (obs_u8 && (E & 3) == 0) {
         dim3 grid((E + 255) / 256, (2 * B + 63) / 64);
         hipLaunchKernelGGL(k_gather_fb_u8, grid, dim3(256), 0, st, (const unsigned char*)s_rows, (const unsigned char*)sp_rows, E, B, idx, x0,
-                           do_sample, cap2, tree, seed, state, meta);
+                           do_sample, cap2, tree, seed, state, meta, idx_pre);
         return;
     }
     dim3 grid((E + 63) / 64, (2 * B + 63) / 64);
-    hipLaunchKernelGGL(k_gather_fb, grid, dim3(256), 0, st, s_rows, sp_rows, obs_u8, E, B, idx, x0, do_sample, cap2, tree, seed, state, meta);
+    hipLaunchKernelGGL(k_gather_fb, grid, dim3(256), 0, st, s_rows, sp_rows, obs_u8, E, B, idx, x0, do_sample, cap2, tree, seed, state, meta, idx_pre);
 }
 
 __global__ void k_gather_rows(const void* __restrict__ rows, int u8, int E, const long long* __restrict__ idx, float* __restrict__ out) {
@@ -234,7 +208,7 @@ __global__ __launch_bounds__(1024) void k_replay_commit(int n, long long start, 
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { long long s = state->size + n; state->size = s > cap ? cap : s; }
+    if (threadIdx.x == 0) { long long s = state->size + n; state->size = s > cap ? cap : s; state->pre_valid = 0; }
 }
 void launch_replay_commit(hipStream_t st, int n, long long start, long long cap, long long cap2, const int* a_in, const float* r_in,
                           const unsigned char* done_in, const float* td_in, float eps, float alpha, int* a, float* r, unsigned char* done,
@@ -250,7 +224,7 @@ __global__ __launch_bounds__(1024) void k_sample(int B, long long cap2, const fl
     const float total = tree[1], seg = total / (float)B;
     for (int i = threadIdx.x; i < B; i += blockDim.x) idx[i] = tree_descend(tree, cap2, size, seed, ctr, i, seg);
     __syncthreads();
-    if (threadIdx.x == 0 && bump) state->sample_ctr = ctr + 1;
+    if (threadIdx.x == 0 && bump) { state->sample_ctr = ctr + 1; state->pre_valid = 0; }      // pre-drawn indices belonged to the counter just consumed
 }
 void launch_sample(hipStream_t st, int B, long long cap2, const float* tree, unsigned long long seed, long long* idx, StepState* state, int bump) {
     int bs = ((B + 63) / 64) * 64; if (bs > 1024) bs = 1024;
@@ -288,7 +262,7 @@ __global__ __launch_bounds__(1024) void k_update_priorities(int n, long long cap
         __syncthreads();
         if (threadIdx.x == 0) { for (int w = 1; w < (int)(blockDim.x >> 6); w++) g = fmaxf(g, smax[w]); state->gnorm_bits = __float_as_uint(g); }
     }
-    if (n > 0) prio_update_block(n, cap2, idx, td, eps, alpha, tree, state, sidx);
+    if (n > 0) { if (threadIdx.x == 0) state->pre_valid = 0; prio_update_block(n, cap2, idx, td, eps, alpha, tree, state, sidx); }
 }
 void launch_update_priorities(hipStream_t st, int n, long long cap2, const long long* idx, const float* td, float eps, float alpha,
                               float* tree, StepState* state, int tick_adam, double beta1, double beta2, const float* gmax_part, int n_gmax) {

@@ -253,6 +253,10 @@ int dqn_stream_handle(dqn_engine_t* e, void** hip_stream);
  * milliseconds measured with HIP events on the engine stream. */
 int dqn_profile_step(dqn_engine_t* e, int max_entries, const char** names, float* ms, int* n_entries);
 
+/* debug aid: per-workgroup timestamps of the forward GEMM kernels (tools/ktrace.py).  out == NULL starts recording; otherwise stops and copies
+ * n 64-bit words: [0] = record count, then 8-word records {grid, block, s_memtime x 6}. */
+int dqn_debug_ktrace(dqn_engine_t* e, uint64_t* out, size_t n);
+
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop
 #endif

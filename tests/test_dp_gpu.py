@@ -29,12 +29,19 @@ def wide_dense_dueling():
     return O.Network((3, 12, 14), b, v, a)
 
 
+def concat_plan(pkg, layers, hp_rank, hp_concat):
+    """summation-order plan of the single-device step on the concatenated batch: the per-sample contractions (forward, dX) are rounded as on the
+    ranks (their chunking is per column and may depend on the per-rank batch size), the sample-axis contraction (dW) as ONE device would round
+    the k*B-sample batch"""
+    return [(pr[0], pr[1], pc[2]) for pr, pc in zip(pkg.default_plan(layers, hp_rank), pkg.default_plan(layers, hp_concat))]
+
+
 def setup(pkg, net, B, Bt, cap=256, n_fill=200, seed=0):
     layers = ref.layers_from_network(net)
     hp_g = ref.hparams_for(net, batch_size=B, buffer_size=cap, learning_rate=1e-3, gamma=0.99)
     hp_t = ref.hparams_for(net, batch_size=Bt, buffer_size=cap, learning_rate=1e-3, gamma=0.99)
     g = pkg.Engine(layers, hp_g, plan=pkg.default_plan(layers, hp_g))
-    t = ref.Twin(layers, hp_t, plan=pkg.default_plan(layers, hp_t), threads=8)
+    t = ref.Twin(layers, hp_t, plan=concat_plan(pkg, layers, hp_g, hp_t), threads=8)
     rng = np.random.default_rng(seed)
     s = rng.random((n_fill,) + net.obs_shape, dtype=np.float32); sp = rng.random((n_fill,) + net.obs_shape, dtype=np.float32)
     a = rng.integers(0, net.n_actions, n_fill).astype(np.int32); r = (rng.standard_normal(n_fill) * 2).astype(np.float32); d = (rng.random(n_fill) < 0.2).astype(np.uint8)
@@ -139,7 +146,7 @@ def test_config3_nature_dqn_8_ranks_distinct_batches(pkg, monkeypatch):
     g = pkg.Engine(layers, hp_g, plan=pkg.default_plan(layers, hp_g))
     monkeypatch.delenv("DQN_SIM_WORLD")
     hp_t = ref.hparams_for(net, batch_size=B * k, buffer_size=512, gamma=0.99)
-    t = ref.Twin(layers, hp_t, plan=pkg.default_plan(layers, hp_t), threads=64)
+    t = ref.Twin(layers, hp_t, plan=concat_plan(pkg, layers, hp_g, hp_t), threads=64)
     rng = np.random.default_rng(3)
     n = 384
     s = rng.random((n,) + net.obs_shape, dtype=np.float32); sp = rng.random((n,) + net.obs_shape, dtype=np.float32)
