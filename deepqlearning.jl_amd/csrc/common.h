@@ -92,7 +92,7 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 // update_priorities!(r, idx, td) (src/prioritized_experience_replay.jl:76-80) executed by ONE workgroup: leaves
 // p = (|td| + eps)^alpha (duplicates: last write wins, :79; assert p > 0, :78), then the ancestors level by level (one
 // barrier per level; equal parents are written with equal values).  `sidx` is >= n long longs of LDS.
-__device__ __forceinline__ void prio_update_block(int n, long long cap2, const long long* __restrict__ idx, const float* __restrict__ td, float eps,
+__device__ __forceinline__ void prio_update_block_levels(int n, long long cap2, const long long* __restrict__ idx, const float* __restrict__ td, float eps,
                                                   float alpha, float* tree, StepState* state, long long* sidx) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) sidx[i] = idx[i];
     __syncthreads();
@@ -115,6 +115,55 @@ __device__ __forceinline__ void prio_update_block(int n, long long cap2, const l
 #pragma unroll
         for (int u = 0; u < 4; u++) { const int i = threadIdx.x + u * blockDim.x; if (nd[u] >= 0) { tree[nd[u]] = vs[u]; sidx[i] = nd[u] >> 1; } }
         for (int i = threadIdx.x + 4 * blockDim.x; i < n; i += blockDim.x) { const long long node = sidx[i]; tree[node] = tree[2 * node] + tree[2 * node + 1]; sidx[i] = node >> 1; }
+        __syncthreads();
+    }
+}
+// The same update for SMALL batches (n <= 64, <= 22 levels) in TWO memory round trips instead of one per level: every path's siblings are
+// requested up front (they are independent of the new leaf values), then the ancestors are recomputed level by level in LDS -- a sibling that
+// is itself on an updated path takes that path's freshly computed value instead of the prefetched one -- and stored on the way.  Same node
+// arithmetic (node = f32(left + right) of its current children), so the resulting tree is identical.  `lds`: >= 8 KB (7808 bytes used).
+__device__ __forceinline__ void prio_update_block(int n, long long cap2, const long long* __restrict__ idx, const float* __restrict__ td, float eps,
+                                                  float alpha, float* tree, StepState* state, long long* lds) {
+    int L = 0; for (long long w = cap2; w > 1; w >>= 1) L++;
+    if (n > 64 || L > 22) { prio_update_block_levels(n, cap2, idx, td, eps, alpha, tree, state, lds); return; }
+    long long* node = lds;                                 // [64]  leaf node id of path i
+    float* val = reinterpret_cast<float*>(lds + 64);       // [64]  value of path i's node at the current level
+    float* sib = val + 64;                                 // [L][64] prefetched sibling values
+    signed char* sj = reinterpret_cast<signed char*>(sib + 22 * 64);   // [L][64] path whose node is path i's sibling at level l, or -1
+    const int t = threadIdx.x;
+    if (t < n) node[t] = cap2 + idx[t];
+    __syncthreads();
+    // siblings of every level of every path: n * L independent loads, one round trip
+    const float rn = 1.0f / (float)n;
+    for (int q = t; q < n * L; q += blockDim.x) { const int l = (int)(((float)q + 0.5f) * rn), i = q - l * n; sib[l * 64 + i] = tree[(node[i] >> l) ^ 1]; }
+    if (t < n) {
+        // duplicates: the LAST occurrence decides the leaf (last write wins, :79); every occurrence carries that value up
+        int last = t;
+        for (int l = 0; l < L; l++) sj[l * 64 + t] = -1;
+        const long long mine = node[t];
+        for (int j = 0; j < n; j++) {
+            const long long x = node[j] ^ mine;
+            if (x == 0) { if (j > last) last = j; continue; }
+            // paths i and j are siblings exactly at the level of their highest differing bit (above it they are the same node); several j with
+            // the same level have merged with each other by then, so any of them carries the sibling's value
+            sj[(63 - __clzll(x)) * 64 + t] = (signed char)j;
+        }
+        const float p = prio_f(fabsf(td[last]), eps, alpha);
+        if (!(prio_f(fabsf(td[t]), eps, alpha) > 0.0f)) state->err = 2;      // assert all(new_priorities .> 0) (:78)
+        val[t] = p;
+        if (last == t) tree[mine] = p;
+    }
+    __syncthreads();
+    for (int l = 0; l < L; l++) {
+        float parent = 0.0f; long long c = 0;
+        if (t < n) {
+            c = node[t] >> l;
+            const int j = sj[l * 64 + t];
+            const float sv = j >= 0 ? val[j] : sib[l * 64 + t];                    // an updated sibling subtree: its fresh value
+            parent = (c & 1) ? sv + val[t] : val[t] + sv;                           // left + right
+        }
+        __syncthreads();
+        if (t < n) { val[t] = parent; tree[c >> 1] = parent; }
         __syncthreads();
     }
 }

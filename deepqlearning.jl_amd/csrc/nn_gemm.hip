@@ -64,14 +64,17 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     extern __shared__ float lds[];
     float* As = lds;                                   // [2][F_KT][F_SA]
     float* Bs = lds + 2 * F_KT * F_SA;                 // [2][F_KT][SB]
+    int* koff_lds = (int*)(Bs + 2 * F_KT * SB);        // [K] (conv only)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     KTRACE_BEGIN()
     const bool conv = L.kind == DQN_LAYER_CONV;
-    // conv: input-row offset of contraction index k = (ci, ky, kx), computed where it is used with two multiplies (floor((x + 0.5) / d) through
-    // the reciprocal is exact for these small ints).  A table of all K offsets in LDS, filled with integer divisions behind a barrier, cost
-    // 0.85-2.0 us at the head of every conv launch (ktrace, r02) before the first operand load could even be issued.
-    const float r_khw = 1.0f / (float)(L.kh * L.kw), r_kw = 1.0f / (float)L.kw; const int khw_ = L.kh * L.kw;
-    auto koff_of = [&](int k) { const int ci = (int)(((float)k + 0.5f) * r_khw); const int rem = k - ci * khw_; const int ky = (int)(((float)rem + 0.5f) * r_kw); return (ci * L.ih + ky) * L.iw + (rem - ky * L.kw); };
+    if (conv) {
+        // input-row offset of contraction index k = (ci, ky, kx), tabulated once per workgroup.  The two divisions go through reciprocals
+        // (floor((x + 0.5) / d) is exact for these small ints): with integer divisions this table cost 0.85-2.0 us at the head of every conv
+        // launch (ktrace, r02) before the first operand load could be issued.
+        const float r_khw = 1.0f / (float)(L.kh * L.kw), r_kw = 1.0f / (float)L.kw; const int khw = L.kh * L.kw;
+        for (int k = tid; k < L.K; k += 256) { const int ci = (int)(((float)k + 0.5f) * r_khw); const int rem = k - ci * khw; const int ky = (int)(((float)rem + 0.5f) * r_kw); koff_lds[k] = (ci * L.ih + ky) * L.iw + (rem - ky * L.kw); }
+    }
     int pi = 0;
     while (pi < 3 && (int)blockIdx.x >= pr.wg_end[pi]) pi++;
     const GFwdProb& p = pr.p[pi];
@@ -100,6 +103,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     constexpr int BQ = (F_KT * BF4 + 255) / 256;       // float4 per thread (1 or 2)
     const float* Wp = p.W + n0;
 
+    if (conv) __syncthreads();                         // koff table ready
     KTRACE(3);
     // Register staging with HAND-COUNTED waits.  hipcc's waitcnt pass drains vmcnt(0) before every prefetch issue in a
     // pipelined loop with conditional loads (seen in the ISA), which exposes the full L2/HBM latency once per K tile.
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
 #pragma unroll
         for (int q = 0; q < AQ; q++) {
             const int ka = kb + arow + 16 * q;
-            const int ko = conv ? koff_of(ka) : ka;
+            const int ko = conv ? koff_lds[ka] : ka;
             r.a[q] = gld(Xa + (unsigned)(a_xb + ko) * ldx);
         }
 #pragma unroll
@@ -245,7 +249,7 @@ void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* 
     int end = 0;
     for (int i = 0; i < 4; i++) { if (i < nprob) end += pr.p[i].mgroups * ngroups * S; pr.wg_end[i] = end; }
     const int SB = NT == 4 ? FwdCfg<4>::SB : (NT == 2 ? FwdCfg<2>::SB : FwdCfg<1>::SB);
-    const size_t lds = (size_t)(2 * F_KT * F_SA + 2 * F_KT * SB) * 4;
+    const size_t lds = (size_t)(2 * F_KT * F_SA + 2 * F_KT * SB) * 4 + (L.kind == DQN_LAYER_CONV ? (size_t)L.K * 4 : 0);
     if (NT == 4) hipLaunchKernelGGL((k_fwd_lds<4>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
     else if (NT == 2) hipLaunchKernelGGL((k_fwd_lds<2>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
     else hipLaunchKernelGGL((k_fwd_lds<1>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
