@@ -27,6 +27,7 @@ struct LayerDev {
     // LSTM (Flux Recur(LSTMCell)): K = n_in, N = 4H.  internal block [Wi K x 4H][b 4H][Wh H x 4H][junk 4H][h0 H][c0 H][zeros 4H]:
     // Wi|b and Wh|junk are (K+1) x N blocks for the dW kernels; `zeros` is the bias of the bias-free input projection.
     int H; unsigned long long wh_off, h0_off, c0_off, z_off, ewh_off, eh0_off, ec0_off;
+    int xu8;                           // this layer reads the observation arena and the arena holds BYTES (u8 replay): value = byte / 255f0, converted in the tile load
 };
 
 // device-resident mutable state of one engine (one instance in HBM)
@@ -63,6 +64,13 @@ __device__ __forceinline__ float dact_f(float dy, float y, int act) {
     case DQN_ACT_SIGMOID: { float u = 1.0f - y; float t = y * u; return dy * t; }
     default: return dy;
     }
+}
+// (float)b / 255.0f for a byte b (u8 observations, test/test_env.jl:59) without the ~10-instruction IEEE division: one Newton step on b * fl(1/255) is
+// exact for all 256 byte values (checked exhaustively on the host, and by the u8 parity tests against the twin's plain division)
+__device__ __forceinline__ float u8_unit(unsigned b) {
+    const float x = (float)b, r = 1.0f / 255.0f;
+    const float q = x * r; const float rem = fmaf(-q, 255.0f, x);
+    return fmaf(rem, r, q);
 }
 __device__ __forceinline__ float prio_f(float td_abs, float eps, float alpha) {
     float base = td_abs + eps;  // (td + eps)^alpha through Float64 (prioritized_experience_replay.jl:67,77)
@@ -291,7 +299,7 @@ void launch_reduce_multi(hipStream_t st, const RSeg* segs_dev, int nseg, unsigne
 struct BatchMeta { const int* a; const float* r; const unsigned char* done; float beta; int* a_out; float* r_out; float* done_out; float* w_out; };
 void launch_gather_fb(hipStream_t st, const void* s_rows, const void* sp_rows, int obs_u8, int E, int B,
                       long long* idx, float* x0 /*[E][2B]*/, int do_sample, long long cap2, const float* tree, unsigned long long seed,
-                      const StepState* state, const BatchMeta& meta, const long long* idx_pre /* or null */);
+                      const StepState* state, const BatchMeta& meta, const long long* idx_pre /* or null */, int arena_u8 = 0 /* x0 is unsigned char[E][2B] */);
 void launch_gather_rows(hipStream_t st, const void* rows, int obs_u8, int E, int n, const long long* idx, float* out /*[n][E]*/);
 void launch_transpose_obs(hipStream_t st, const float* obs /*[n][E]*/, int E, int n, float* x /*[E][n]*/);
 void launch_replay_commit(hipStream_t st, int n, long long start, long long cap, long long cap2, const int* a_in, const float* r_in,

@@ -46,6 +46,7 @@ struct dqn_engine {
     int pol_n = 0; float *pol_obs = nullptr, *pol_x = nullptr, *pol_act[DQN_MAX_LAYERS] = {}, *pol_q = nullptr; int* pol_a = nullptr;
     // graphs: [0] = step with sampling, [1] = step on given indices; with a communicator the step is cut in two
     hipGraphExec_t g_full[2] = {nullptr, nullptr}, g_pre[2] = {nullptr, nullptr}, g_post = nullptr;
+    bool arena_u8 = false;  // the observation arena x0 holds bytes (u8 replay, first layer converts in its tile loads): set by build_program
     int adam_mode = 0;      // env DQN_ADAM_MODE at creation: 1 = Adam jobs carried by the backward launches (engine_program.hip)
     // comm
     void* comm = nullptr; int rank = 0, world = 1; bool force_comm = false;

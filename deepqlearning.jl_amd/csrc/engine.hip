@@ -482,7 +482,7 @@ void enqueue_step(dqn_engine* e, bool sample, int phase) {
             if (sample && !fused) RUN(e, "sample", launch_sample(e->stream, e->B, e->cap2, e->tree, e->hp.seed, e->idx, e->state, 0));    // k_td bumps the Philox counter
             BatchMeta bm; bm.a = e->ra; bm.r = e->rr; bm.done = e->rdone; bm.beta = e->hp.prio_beta; bm.a_out = e->gb_a2; bm.r_out = e->gb_r2; bm.done_out = e->gb_done2; bm.w_out = e->gb_w2;
             RUN(e, fused ? "sample_gather" : "gather", launch_gather_fb(e->stream, e->s_rows, e->sp_rows, e->hp.obs_dtype == DQN_OBS_U8, e->E, e->B, e->idx, e->x0,
-                                                                        fused ? 1 : 0, e->cap2, e->tree, e->hp.seed, e->state, bm, e->idx_pre));
+                                                                        fused ? 1 : 0, e->cap2, e->tree, e->hp.seed, e->state, bm, e->idx_pre, e->arena_u8 ? 1 : 0));
         }
         for (size_t i = 0; i < e->prog_post_begin; i++) {
             if ((long)i == e->final_reduce_step && ((e->adam_segs.n > 0 && !e->comm && !e->sim_world) || (e->dp_gather && e->dp_pack_folds))) continue;   // folded into k_adam / k_dp_pack   // folded into k_adam

@@ -48,6 +48,18 @@ int build_program(dqn_engine* e) {
     std::vector<std::vector<int>> levels; std::vector<int> val, adv;
     for (int i = 0; i < e->nl; i++) { if (e->L[i].stream == DQN_STREAM_BASE) levels.push_back({i}); else if (e->L[i].stream == DQN_STREAM_VAL) val.push_back(i); else adv.push_back(i); }
     for (size_t j = 0; j < std::max(val.size(), adv.size()); j++) { std::vector<int> lv; if (j < val.size()) lv.push_back(val[j]); if (j < adv.size()) lv.push_back(adv[j]); levels.push_back(lv); }
+    // ---------------- u8 replay: keep the observation arena in BYTES when its only consumers are the LDS-tiled forward and dW launches of ONE
+    // first layer (they convert byte / 255 inside their tile loads): the gather writes 1 byte per element instead of 4 and the first layer reads
+    // a quarter of the bytes.  Everything else (VALU / direct-MFMA fallbacks, heads fed by the observation, the operand all-gather) needs floats.
+    e->arena_u8 = false;
+    for (int i = 0; i < e->nl; i++) { e->L[i].xu8 = 0; LV[i].xu8 = 0; }
+    if (e->hp.obs_dtype == DQN_OBS_U8 && !rec && mf && B % 4 == 0 && e->E % 4 == 0 && levels.size() > 1 && getenv("DQN_NO_U8_ARENA") == nullptr) {
+        int n_src = 0; for (int i = 0; i < e->nl; i++) if (e->L[i].src < 0) n_src++;
+        const int l0 = levels[0][0];
+        int ldx2[2] = {ld0, ld0}, c02[2] = {0, B}, nc2[2] = {ncon, B};
+        if (n_src == 1 && levels[0].size() == 1 && e->L[l0].src < 0 && (e->L[l0].kind == DQN_LAYER_CONV || (!e->comm && !e->sim_world)) &&
+            gemm_fwd_eligible(LV[l0], 2, ldx2, c02, nc2) && gemm_dw_eligible(e->L[l0], B, ld0)) { e->arena_u8 = true; e->L[l0].xu8 = 1; LV[l0].xu8 = 1; }
+    }
     // ---------------- small batches: the head level (forwards of both nets), the TD kernel and the head layers' dX run as ONE launch with a
     // workgroup per batch column (k_head_td); the heads' dW/db and the loss fold ride as tail tasks of the next backward launch
     int hv_l = -1, ha_l = -1; bool fuse_heads = false;

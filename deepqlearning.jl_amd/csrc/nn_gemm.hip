@@ -58,9 +58,12 @@ constexpr int F_KT = DQN_F_KT;  // K tile depth (32 or 64)
 constexpr int F_SA = 80;        // A tile row stride (64 columns + 16 pad): ds_read_b32 of lanes (i, kq) hits banks 16*kq + i
 template <int NT> struct FwdCfg { static constexpr int NW = 16 * NT; static constexpr int SB = (NW % 32 == 0) ? NW + 16 : NW + 32; };
 
-template <int NT>
+// XU8: the A operand is the BYTE observation arena (u8 replay): a lane fetches 4 bytes = 4 columns and converts them (byte / 255f0, exactly) on
+// the way into the LDS tile -- a quarter of the operand bytes of the float arena, and the gather wrote a quarter as well
+template <int NT, bool XU8 = false>
 __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S, int kc) {
     constexpr int NW = FwdCfg<NT>::NW, SB = FwdCfg<NT>::SB;
+    using AT = std::conditional_t<XU8, uint32_t, f32x4>;
     extern __shared__ float lds[];
     float* As = lds;                                   // [2][F_KT][F_SA]
     float* Bs = lds + 2 * F_KT * F_SA;                 // [2][F_KT][SB]
@@ -96,6 +99,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
         if (conv) { const int oy = pos / L.ow, ox = pos % L.ow; a_xb = oy * L.sh * L.iw + ox * L.sw; }
     }
     const float* Xa = p.X + p.col0 + a_ct * 16 + (tid & 3) * 4;
+    const unsigned char* Xb = reinterpret_cast<const unsigned char*>(p.X) + p.col0 + a_ct * 16 + (tid & 3) * 4;      // XU8 view of the same arena
     const int arow = tid >> 4;                         // 0..15 (second float4: +16)
     const unsigned ldx = (unsigned)p.ldx;
     // ---- B tile slice: NW/4 float4 per row
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     // (cdna_hip_programming.md section 5.7 form (ii)).
     constexpr int AQ = F_KT / 16;                      // A float4 per thread
     constexpr int LPS = AQ + BQ;                       // loads per stage
-    struct Stage { f32x4 a[AQ]; f32x4 b[BQ]; };
+    struct Stage { AT a[AQ]; f32x4 b[BQ]; };
     const float* Wb[BQ]; bool bok[BQ]; int brow[BQ], bc4[BQ];
 #pragma unroll
     for (int i = 0; i < BQ; i++) {                                   // clamped B slots (threads beyond the tile re-load the last one)
@@ -120,6 +124,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
         brow[i] = qc / BF4; bc4[i] = qc % BF4; Wb[i] = Wp + (unsigned)brow[i] * (unsigned)L.N + 4 * bc4[i];
     }
     auto gld = [](const float* ptr) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory"); return v; };
+    auto gld1 = [](const unsigned char* ptr) { uint32_t v; asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr) : "memory"); return v; };
     auto gload = [&](int kt, Stage& r) {
         kt = min(kt, nkt - 1);
         const int kb = k0 + kt * F_KT;
@@ -127,14 +132,18 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
         for (int q = 0; q < AQ; q++) {
             const int ka = kb + arow + 16 * q;
             const int ko = conv ? koff_lds[ka] : ka;
-            r.a[q] = gld(Xa + (unsigned)(a_xb + ko) * ldx);
+            if constexpr (XU8) r.a[q] = gld1(Xb + (unsigned)(a_xb + ko) * ldx); else r.a[q] = gld(Xa + (unsigned)(a_xb + ko) * ldx);
         }
 #pragma unroll
         for (int i = 0; i < BQ; i++) r.b[i] = gld(Wb[i] + (unsigned)kb * (unsigned)L.N);
     };
     auto lstore = [&](int buf, const Stage& r) {
 #pragma unroll
-        for (int q = 0; q < AQ; q++) *reinterpret_cast<f32x4*>(As + (buf * F_KT + arow + 16 * q) * F_SA + (tid & 15) * 4) = r.a[q];
+        for (int q = 0; q < AQ; q++) {
+            f32x4 av;
+            if constexpr (XU8) { const uint32_t w4 = r.a[q]; av = (f32x4){u8_unit(w4 & 0xffu), u8_unit((w4 >> 8) & 0xffu), u8_unit((w4 >> 16) & 0xffu), u8_unit(w4 >> 24)}; } else av = r.a[q];
+            *reinterpret_cast<f32x4*>(As + (buf * F_KT + arow + 16 * q) * F_SA + (tid & 15) * 4) = av;
+        }
 #pragma unroll
         for (int i = 0; i < BQ; i++) if (bok[i]) *reinterpret_cast<f32x4*>(Bs + (buf * F_KT + brow[i]) * SB + 4 * bc4[i]) = r.b[i];
     };
@@ -250,7 +259,12 @@ void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* 
     for (int i = 0; i < 4; i++) { if (i < nprob) end += pr.p[i].mgroups * ngroups * S; pr.wg_end[i] = end; }
     const int SB = NT == 4 ? FwdCfg<4>::SB : (NT == 2 ? FwdCfg<2>::SB : FwdCfg<1>::SB);
     const size_t lds = (size_t)(2 * F_KT * F_SA + 2 * F_KT * SB) * 4 + (L.kind == DQN_LAYER_CONV ? (size_t)L.K * 4 : 0);
-    if (NT == 4) hipLaunchKernelGGL((k_fwd_lds<4>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
+    if (L.xu8) {
+        if (NT == 4) hipLaunchKernelGGL((k_fwd_lds<4, true>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
+        else if (NT == 2) hipLaunchKernelGGL((k_fwd_lds<2, true>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
+        else hipLaunchKernelGGL((k_fwd_lds<1, true>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
+    }
+    else if (NT == 4) hipLaunchKernelGGL((k_fwd_lds<4>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
     else if (NT == 2) hipLaunchKernelGGL((k_fwd_lds<2>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
     else hipLaunchKernelGGL((k_fwd_lds<1>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
 }
@@ -270,9 +284,10 @@ struct GDwProbs { GDwProb p[2]; };
 struct DwStride { int ldd, tpr, rstride; };
 constexpr int W_ST = 36;     // LDS row stride (32 samples + 4 pad): 16-B aligned rows, fragment reads at most 2-way conflicted
 
-template <int NT>
+template <int NT, bool XU8 = false>
 __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& pr, int nprob, int ldx, int B, int S, int kc, int bid, int nblocks, DwStride ds) {
     constexpr int NW = 16 * NT;
+    using AT = std::conditional_t<XU8, uint32_t, f32x4>;
     constexpr int BQ = (NW * 8 + 255) / 256;          // float4 per thread for the B tile (1 or 2)
     extern __shared__ float lds[];
     float* As = lds;                                   // [2][64][W_ST]
@@ -300,13 +315,16 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
         } else { koff0 = k0r; koff1 = k1r; }
     }
     const float* Xa = p.X + 4 * f4;
+    const unsigned char* Xb = reinterpret_cast<const unsigned char*>(p.X) + 4 * f4;      // XU8 view (the byte observation arena)
     // ---- B tile slice: channel rows q>>3 (clamped), float4 (q & 7)
     const int bq0 = tid < NW * 8 ? tid : NW * 8 - 1, bq1 = tid + 256 < NW * 8 ? tid + 256 : NW * 8 - 1;
     const float* Db0 = p.dpre + (size_t)(n0 + (bq0 >> 3)) * ds.ldd + 4 * (bq0 & 7);
     const float* Db1 = p.dpre + (size_t)(n0 + (bq1 >> 3)) * ds.ldd + 4 * (bq1 & 7);
     constexpr int LPS = 2 + BQ;
-    struct Stage { f32x4 a0, a1, b0, b1; };
+    struct Stage { AT a0, a1; f32x4 b0, b1; };
     auto gld = [](const float* ptr) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory"); return v; };
+    auto gld1 = [](const unsigned char* ptr) { uint32_t v; asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr) : "memory"); return v; };
+    auto cvt = [](const AT& a) { if constexpr (XU8) { const uint32_t w4 = a; return (f32x4){u8_unit(w4 & 0xffu), u8_unit((w4 >> 8) & 0xffu), u8_unit((w4 >> 16) & 0xffu), u8_unit(w4 >> 24)}; } else return a; };
     auto gload = [&](int kt, Stage& r) {
         kt = min(kt, nkt - 1);
         const int pos = pos0 + kt / nsub, sub = kt % nsub;          // 32-sample block `sub` of position `pos`
@@ -314,14 +332,14 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
         const unsigned ao = so, bo = (unsigned)pos * (unsigned)B + so;
         int xb = 0;
         if (conv) { const int oy = pos / L.ow, ox = pos % L.ow; xb = oy * L.sh * L.iw + ox * L.sw; }
-        r.a0 = gld(Xa + (unsigned)(xb + koff0) * (unsigned)ldx + ao);
-        r.a1 = gld(Xa + (unsigned)(xb + koff1) * (unsigned)ldx + ao);
+        if constexpr (XU8) { r.a0 = gld1(Xb + (unsigned)(xb + koff0) * (unsigned)ldx + ao); r.a1 = gld1(Xb + (unsigned)(xb + koff1) * (unsigned)ldx + ao); }
+        else { r.a0 = gld(Xa + (unsigned)(xb + koff0) * (unsigned)ldx + ao); r.a1 = gld(Xa + (unsigned)(xb + koff1) * (unsigned)ldx + ao); }
         r.b0 = gld(Db0 + bo);
         if (BQ > 1) r.b1 = gld(Db1 + bo);
     };
     auto lstore = [&](int buf, const Stage& r) {
-        *reinterpret_cast<f32x4*>(As + (buf * 64 + (tid >> 3)) * W_ST + 4 * f4) = r.a0;
-        *reinterpret_cast<f32x4*>(As + (buf * 64 + (tid >> 3) + 32) * W_ST + 4 * f4) = r.a1;
+        *reinterpret_cast<f32x4*>(As + (buf * 64 + (tid >> 3)) * W_ST + 4 * f4) = cvt(r.a0);
+        *reinterpret_cast<f32x4*>(As + (buf * 64 + (tid >> 3) + 32) * W_ST + 4 * f4) = cvt(r.a1);
         if (tid < NW * 8) *reinterpret_cast<f32x4*>(Bs + (buf * NW + (tid >> 3)) * W_ST + 4 * f4) = r.b0;
         if (BQ > 1) *reinterpret_cast<f32x4*>(Bs + (buf * NW + ((tid + 256) >> 3)) * W_ST + 4 * f4) = r.b1;
     };
@@ -388,7 +406,7 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
     }
     if (do_bias) out[(size_t)L.K * L.N + n0 + tid] = dbacc;
 }
-template <int NT>
+template <int NT, bool XU8 = false>
 __global__ __launch_bounds__(256) void k_dw_lds(LayerDev L, GDwProbs pr, int nprob, int ldx, int B, int S, int kc, DwStride ds, GemmTail tail) {
     // dispatch order: [priority block][tail: VALU tasks, Adam job][dW workgroups] -- the bandwidth-bound tail starts at once and the short dW
     // workgroups fill the slots beside it (at the END of the grid the tail would wait for LDS: every workgroup of a launch reserves the tile size)
@@ -396,7 +414,7 @@ __global__ __launch_bounds__(256) void k_dw_lds(LayerDev L, GDwProbs pr, int npr
     if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; prio_block_run(tail.adam.prio, tail.adam.state, reinterpret_cast<long long*>(lds)); return; }
     const int bid = (int)blockIdx.x - pre_, ntail = (int)gemm_tail_blocks(tail) - pre_;
     if (bid < ntail) { gemm_tail_run(tail, (unsigned)bid); return; }
-    dw_lds_body<NT>(L, pr, nprob, ldx, B, S, kc, bid - ntail, (int)gridDim.x - pre_ - ntail, ds);
+    dw_lds_body<NT, XU8>(L, pr, nprob, ldx, B, S, kc, bid - ntail, (int)gridDim.x - pre_ - ntail, ds);
 }
 bool gemm_dw_eligible(const LayerDev& L, int B, int ldx) {
     const int KK = L.npos * B, S = dqn_nchunks(KK, L.dw_kc), kc = dqn_chunk_len(KK, L.dw_kc);
@@ -411,7 +429,12 @@ void launch_gemm_dw(hipStream_t st, const LayerDev& L, int nprob, const float* c
     const int NT = L.N % 64 == 0 ? 4 : (L.N % 32 == 0 ? 2 : 1);
     const int grid = ((L.K + 63) / 64) * (L.N / (16 * NT)) * S * nprob + (int)gemm_tail_blocks(tail);
     const size_t lds = (size_t)(2 * 64 * W_ST + 2 * 16 * NT * W_ST) * 4;
-    if (NT == 4) hipLaunchKernelGGL((k_dw_lds<4>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, tail);
+    if (L.xu8) {
+        if (NT == 4) hipLaunchKernelGGL((k_dw_lds<4, true>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, tail);
+        else if (NT == 2) hipLaunchKernelGGL((k_dw_lds<2, true>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, tail);
+        else hipLaunchKernelGGL((k_dw_lds<1, true>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, tail);
+    }
+    else if (NT == 4) hipLaunchKernelGGL((k_dw_lds<4>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, tail);
     else if (NT == 2) hipLaunchKernelGGL((k_dw_lds<2>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, tail);
     else hipLaunchKernelGGL((k_dw_lds<1>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, tail);
 }

@@ -258,6 +258,20 @@ def test_nature_dqn_b32_full_size_bit_exact(pkg):
     check_priorities_after_step(gpu, hp, idx, pr_before, td, o["td"], batch[5])
 
 
+def test_nature_u8_b32_byte_arena_bit_exact(pkg):
+    """u8 replay with the Nature-DQN first layer: the observation arena stays in BYTES (gather writes 1 byte per element, conv1's forward and dW
+    tile loads convert byte / 255f0 exactly) -- every one of the 256 byte values occurs in the random rows; bit-exact vs the twin's plain
+    (float)b / 255f0, with the fused sample+gather launch of small batches."""
+    net = nature_dueling()
+    gpu, cpu, hp = make_pair(pkg, net, 32, cap=256, obs_dtype=1, gamma=0.99)
+    fill((gpu, cpu), net, 256, seed=12, u8=True)
+    set_same_params((gpu, cpu), net, seed=4)
+    for _ in range(3):
+        assert_step_bit_exact(gpu, cpu)
+    np.testing.assert_array_equal(gpu.get_grads(), cpu.get_grads())
+    np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+
+
 def test_config5_nature_b512_u8_bit_exact(pkg):
     """BASELINE config 5's shape under pytest: Nature-DQN dueling, B = 512, u8 replay (4096 transitions here; the 1e6-transition property
     run is test_config5_million_transition_properties): the large-batch program (own sampler launch, multi-workgroup head reduce, u8 gather,
