@@ -164,38 +164,46 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     float bias_r[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) bias_r[t] = S == 1 ? p.bias[n0 + 16 * t + l15] : 0.0f;
-    auto compute = [&](int buf) {
+    // Software pipeline of one wave (it may be alone on its SIMD at config 2): the fragments of tile kt+1 are read from LDS (into a second
+    // register set) right after the barrier that publishes them, i.e. in the MIDDLE of tile kt's MFMA chain, and the wait for tile kt+1's global
+    // loads + its LDS stores sit between the two halves of that chain -- instead of LDS-read latency, global wait, LDS store and barrier each
+    // being exposed once per tile with the MFMA pipe idle.  The chain order per accumulator is unchanged (tiles ascending, st = 0..7).
+    struct Frag { float a[F_KT / 4]; float b[F_KT / 4][NT]; };
+    auto fread = [&](int buf, Frag& f) {
         const float* Ab = As + buf * F_KT * F_SA + 16 * wave + l15;
         const float* Bb = Bs + buf * F_KT * SB + l15;
-        // all fragments of the K tile are read first (one LDS latency per tile instead of one per MFMA pair), then the
-        // 8*NT MFMAs issue back to back; chain order per accumulator is still st = 0..7
-        float af[F_KT / 4], bf[F_KT / 4][NT];
 #pragma unroll
         for (int st = 0; st < F_KT / 4; st++) {
-            af[st] = Ab[(4 * st + kq) * F_SA];
+            f.a[st] = Ab[(4 * st + kq) * F_SA];
 #pragma unroll
-            for (int t = 0; t < NT; t++) bf[st][t] = Bb[(4 * st + kq) * SB + 16 * t];
+            for (int t = 0; t < NT; t++) f.b[st][t] = Bb[(4 * st + kq) * SB + 16 * t];
         }
-#pragma unroll
-        for (int st = 0; st < F_KT / 4; st++)
-#pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = MFMA(af[st], bf[st][t], acc[t]);
     };
-    // prefetch distance 2: tile kt computes from LDS while tile kt+1 lands in one register stage and tile kt+2's loads
-    // are issued into the other; one barrier per K tile.
-    Stage r0, r1;
+    auto mma = [&](const Frag& f, int s0, int s1) {
+#pragma unroll
+        for (int st = s0; st < s1; st++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = MFMA(f.a[st], f.b[st][t], acc[t]);
+    };
+    constexpr int HS = F_KT / 8;                       // MFMA steps per half tile
+    Stage r0, r1; Frag f0, f1;
     gload(0, r0); STAGE_WAIT(0, r0); lstore(0, r0); __syncthreads();
     KTRACE(4);
+    fread(0, f0);
     gload(1, r0);
     for (int kt = 0; kt < nkt; kt += 2) {
         gload(kt + 2, r1);
-        compute(0);
+        mma(f0, 0, HS);
         STAGE_WAIT(LPS, r0); lstore(1, r0);
         __syncthreads();
+        if (kt + 1 < nkt) fread(1, f1);
+        mma(f0, HS, 2 * HS);
         gload(kt + 3, r0);
-        if (kt + 1 < nkt) compute(1);
+        if (kt + 1 < nkt) mma(f1, 0, HS);
         STAGE_WAIT(LPS, r1); lstore(0, r1);
         __syncthreads();
+        if (kt + 2 < nkt) fread(0, f0);
+        if (kt + 1 < nkt) mma(f1, HS, 2 * HS);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the clamped tail loads before the registers are reused
     KTRACE(5); KTRACE(6);
