@@ -217,7 +217,7 @@ def main():
     # world > 1 -- so EVERY rank runs the same number of them; only rank 0 uses the numbers.
     prof_acc = {}
     for _ in range(args.profile_steps):
-        for name, ms in eng.profile_step():
+        for name, ms in eng.profile_step(steady=True):      # the step dqn_train_steps(n) repeats (its timed loop below runs exactly that)
             a = prof_acc.setdefault(name, [0.0, 0])
             a[0] += ms
             a[1] += 1

@@ -129,6 +129,7 @@ PROTOS = {
     "stream_sync": [_vp],
     "stream_handle": [_vp, _P(_vp)],
     "profile_step": [_vp, C.c_int, _P(C.c_char_p), _f32p, _P(C.c_int)],
+    "profile_steady_step": [_vp, C.c_int, _P(C.c_char_p), _f32p, _P(C.c_int)],
     "hparams_default": [_P(HParams)],
     "episode_add": [_vp, _vp, _i32p, _f32p, _vp, _u8p, C.c_int],
     "episode_commit": [_vp],
@@ -470,11 +471,13 @@ class Handle:
         self._check(self.f["stream_handle"](self._h, C.byref(p)))
         return p.value
 
-    def profile_step(self, max_entries=128):
+    def profile_step(self, max_entries=128, steady=False):
+        """[(launch name, ms)] of one train step, eager launches timed with HIP events.  steady: the timed step is a MIDDLE step of
+        train_steps(n) (two steps run; see dqn_profile_steady_step)."""
         names = (C.c_char_p * max_entries)()
         ms = np.zeros(max_entries, np.float32)
         n = C.c_int()
-        self._check(self.f["profile_step"](self._h, max_entries, names, _ptr(ms, _f32p), C.byref(n)))
+        self._check(self.f["profile_steady_step" if steady else "profile_step"](self._h, max_entries, names, _ptr(ms, _f32p), C.byref(n)))
         return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
 
     def sim_ranks_step(self, idx):

@@ -40,8 +40,9 @@ struct StepState {
     float loss;
     float gnorm;
     int err;                           // sticky device-side error code
-    int pre_valid;                     // the NEXT sample()'s indices are already in idx_pre (computed in the tail of the priority block with the
-                                       // final tree); cleared by everything that changes the tree, the size or the counters in between
+    int pre_valid;                     // 1: the NEXT sample()'s indices are already in idx_pre (computed in the tail of the priority block with the
+                                       // final tree); cleared by everything that changes the tree, the size or the counters in between.
+                                       // 2: ... and their rows, batch scalars and IS weights are already in the batch arena (PreGather)
 };
 
 static inline __host__ __device__ int dqn_nchunks(int K, int kc) { return (kc <= 0 || kc >= K) ? 1 : (K + kc - 1) / kc; }
@@ -274,9 +275,10 @@ struct HeadTdArgs {
     HeadLayer val, adv;                         // adv doubles as the plain Q head when !dueling
     float *w_is, *td, *q_on_s, *q_on_sp, *q_tg_sp, *ytarget, *hl; int* best;
     StepState* st;
+    long long* idx; const long long* idx_pre;   // take_pre launches: this step's indices were drawn AND gathered by the previous step (PreGather)
 };
 size_t head_td_lds_bytes(const HeadTdArgs& a);
-void launch_head_td(hipStream_t st, const HeadTdArgs& a, const HeadTdArgs* a_dev, int bump_sample_ctr);   // a_dev: the same record in device memory
+void launch_head_td(hipStream_t st, const HeadTdArgs& a, const HeadTdArgs* a_dev, int bump_sample_ctr, int take_pre = 0);   // a_dev: the same record in device memory
 
 // task / segment tables of the batched small kernels (device-resident, built once per engine)
 struct VTask {
@@ -291,12 +293,19 @@ struct RSeg {
                                        // so that the fused head kernel reads a batch column as one contiguous run instead of one 128-B line per element
 };
 unsigned valu_task_blocks(const VTask& T);
-void launch_valu_multi(hipStream_t st, const VTask* tasks_dev, int ntasks, unsigned total_blocks);
+void launch_valu_multi(hipStream_t st, const VTask* tasks_dev, int ntasks, unsigned total_blocks, const PrioArgs* prio = nullptr /* workgroup 0 = priority block */, StepState* state = nullptr);
 void launch_reduce_multi(hipStream_t st, const RSeg* segs_dev, int nseg, unsigned total_blocks);
 
 // get_batch scalars of the sampled transitions (a, r, done, IS weight: ...replay.jl:93-102), written by ONE workgroup of the gather launch
 // for the fused head kernel (a_out == nullptr: not wanted)
 struct BatchMeta { const int* a; const float* r; const unsigned char* done; float beta; int* a_out; float* r_out; float* done_out; float* w_out; };
+// The NEXT step's get_batch, run by the first workgroups of this step's Adam launch (inside dqn_train_steps(n): the host knows that a sampled
+// step follows and that nothing touches the replay in between).  By then every reader of the arena, of the batch scalars and of the index list
+// in this step is done, the tree is final (the priority block ran in an earlier backward launch and drew idx_pre), and the Philox counter of
+// the next sample() was set by k_head_td.  The next step then runs WITHOUT its gather launch; its k_head_td copies idx_pre -> idx and checks
+// StepState::pre_valid == 2.  f32 observations, B <= 64.
+struct PreGather { int on; const void *s_rows, *sp_rows; int E, B; long long* idx_pre; float* x0; long long cap2; const float* tree; unsigned long long seed;
+                   BatchMeta meta; int gx, gy; };
 void launch_gather_fb(hipStream_t st, const void* s_rows, const void* sp_rows, int obs_u8, int E, int B,
                       long long* idx, float* x0 /*[E][2B]*/, int do_sample, long long cap2, const float* tree, unsigned long long seed,
                       const StepState* state, const BatchMeta& meta, const long long* idx_pre /* or null */, int arena_u8 = 0 /* x0 is unsigned char[E][2B] */);
@@ -320,7 +329,7 @@ void launch_valu_dx(hipStream_t st, const LayerDev& L, const float* P, const flo
 void launch_td(hipStream_t st, const TdArgs& a);
 int adam_blocks(size_t P);
 static inline int gmax_slots(size_t) { return 65536; }   // per-block max |g| of every Adam job of a step (each job owns a slot range)
-void launch_adam(hipStream_t st, const AdamJob& job);
+void launch_adam(hipStream_t st, const AdamJob& job, const PreGather* pg = nullptr /* see PreGather */);
 void launch_q_columns(hipStream_t st, int n, int nA, int dueling, const float* val, const float* adv, float* q_out /*[n][nA]*/, int* argmax_out);
 void launch_convert_params(hipStream_t st, const LayerDev* layers_dev, int nl, const float* src, float* dst, int to_internal, size_t P_ext);
 

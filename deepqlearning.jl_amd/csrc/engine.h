@@ -68,6 +68,10 @@ struct dqn_engine {
     ActProg act, evalp; std::vector<Step>* sink = nullptr; std::vector<void*>* alloc_sink = nullptr; RolloutDev *roll = nullptr, *eval_roll = nullptr;
     EnvDev eval_env{}; int eval_n = 0;
     std::vector<Step> prog; size_t prog_post_begin = 0; bool prog_built = false, step_sampled = true, prio_forked = false;
+    // pre-gather (common.h PreGather), only between the steps of one dqn_train_steps(n) call: step_pregather = this step's Adam launch gathers
+    // the next batch; step_take_pre = this step runs without its gather launch
+    bool pg_ok = false, step_pregather = false, step_take_pre = false; PreGather pg; long adam_step = -1;
+    hipGraphExec_t g_pgv[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [take_pre][pregather] variants of the sampled single-device step
     AdamSegs adam_segs; long final_reduce_step = -1;   // deferred dW slabs: reduced inside k_adam unless a communicator needs the materialised gradient
     std::vector<void*> prog_allocs; std::vector<std::string> prog_names;
     // profiling
@@ -93,7 +97,7 @@ void fwd_layer(dqn_engine* e, const LayerDev& l, const float* P, const float* X,
 void enqueue_step(dqn_engine* e, bool sample, int phase);
 int capture(dqn_engine* e, bool sample, int phase, hipGraphExec_t* out);
 int exchange_grads(dqn_engine* e);      // the one collective of a data-parallel step (all-gather or all-reduce)
-int run_step(dqn_engine* e, bool sample);
+int run_step(dqn_engine* e, bool sample, bool take_pre = false, bool pregather = false);
 int fetch_scalars(dqn_engine* e, float* loss, float* gn);
 int policy_ws(dqn_engine* e, int n);
 int policy_state(dqn_engine* e, int n, bool force_reset);
@@ -105,7 +109,7 @@ template <class T> static T* upload(dqn_engine* e, const std::vector<T>& v) {
 float* palloc(dqn_engine* e, size_t n);
 bool same_geo(const LayerDev& a, const LayerDev& b);
 void add_valu(dqn_engine* e, std::vector<VTask>& pend, const VTask& t);
-void flush_valu(dqn_engine* e, std::vector<VTask>& pend, const char* name);
+void flush_valu(dqn_engine* e, std::vector<VTask>& pend, const char* name, const PrioArgs* prio = nullptr);
 void emit_reduce(dqn_engine* e, std::vector<RSeg>& segs, const char* name);
 const char* pname(dqn_engine* e, const char* op, int kind, int i);
 int build_program(dqn_engine* e);

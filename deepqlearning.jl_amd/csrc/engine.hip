@@ -227,6 +227,7 @@ void drop_graphs(dqn_engine* e) {
     for (int i = 0; i < 2; i++) {
         if (e->g_full[i]) { hipGraphExecDestroy(e->g_full[i]); e->g_full[i] = nullptr; }
         if (e->g_pre[i]) { hipGraphExecDestroy(e->g_pre[i]); e->g_pre[i] = nullptr; }
+        for (int j = 0; j < 2; j++) if (e->g_pgv[i][j]) { hipGraphExecDestroy(e->g_pgv[i][j]); e->g_pgv[i][j] = nullptr; }
     }
     if (e->g_post) { hipGraphExecDestroy(e->g_post); e->g_post = nullptr; }
     for (dqn_engine::ActProg* a : {&e->act, &e->evalp}) if (a->graph) { hipGraphExecDestroy(a->graph); a->graph = nullptr; }
@@ -479,17 +480,20 @@ void enqueue_step(dqn_engine* e, bool sample, int phase) {
             // the descent is fused into the gather (every workgroup repeats it) while that is cheaper than a launch of its own:
             // small batches.  At B = 512 / 1e6 leaves the repeats cost more than the ~5 us launch, so sample once, then gather.
             const bool fused = sample && e->B <= 64;
+            if (e->step_take_pre) {}      // the previous step's Adam launch gathered this batch (PreGather)
+            else {
             if (sample && !fused) RUN(e, "sample", launch_sample(e->stream, e->B, e->cap2, e->tree, e->hp.seed, e->idx, e->state, 0));    // k_td bumps the Philox counter
             BatchMeta bm; bm.a = e->ra; bm.r = e->rr; bm.done = e->rdone; bm.beta = e->hp.prio_beta; bm.a_out = e->gb_a2; bm.r_out = e->gb_r2; bm.done_out = e->gb_done2; bm.w_out = e->gb_w2;
             RUN(e, fused ? "sample_gather" : "gather", launch_gather_fb(e->stream, e->s_rows, e->sp_rows, e->hp.obs_dtype == DQN_OBS_U8, e->E, e->B, e->idx, e->x0,
                                                                         fused ? 1 : 0, e->cap2, e->tree, e->hp.seed, e->state, bm, e->idx_pre, e->arena_u8 ? 1 : 0));
+            }
         }
         for (size_t i = 0; i < e->prog_post_begin; i++) {
             if ((long)i == e->final_reduce_step && ((e->adam_segs.n > 0 && !e->comm && !e->sim_world) || (e->dp_gather && e->dp_pack_folds))) continue;   // folded into k_adam / k_dp_pack   // folded into k_adam
             RUN(e, e->prog[i].name, e->prog[i].fn(e));
         }
     }
-    if (phase != PH_PRE) for (size_t i = e->prog_post_begin; i < e->prog.size(); i++) RUN(e, e->prog[i].name, e->prog[i].fn(e));
+    if (phase != PH_PRE) for (size_t i = e->prog_post_begin; i < e->prog.size(); i++) RUN(e, (e->step_pregather && (long)i == e->adam_step) ? "adam+gather" : e->prog[i].name, e->prog[i].fn(e));
 }
 int capture(dqn_engine* e, bool sample, int phase, hipGraphExec_t* out) {
     hipGraph_t g;
@@ -517,9 +521,21 @@ int exchange_grads(dqn_engine* e) {
     if (rc) return fail("ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
     return 0;
 }
-int run_step(dqn_engine* e, bool sample) {
+// take_pre / pregather: only dqn_train_steps sets them (a sampled step follows / preceded this one and nothing touches the replay in between)
+int run_step(dqn_engine* e, bool sample, bool take_pre, bool pregather) {
     if (build_program(e)) return -1;
     const int gi = sample ? 0 : 1;
+    e->step_take_pre = e->step_pregather = false;
+    if (sample && e->pg_ok && (take_pre || pregather) && e->world <= 1 && !(e->comm && e->force_comm)) {
+        e->step_take_pre = take_pre; e->step_pregather = pregather;
+        int rc = 0;
+        if (e->hp.use_graph && !e->profiling) {
+            hipGraphExec_t& g = e->g_pgv[take_pre ? 1 : 0][pregather ? 1 : 0];
+            if (!g && capture(e, true, PH_ALL, &g)) rc = -1; else HIPCHK(hipGraphLaunch(g, e->stream));
+        } else { enqueue_step(e, true, PH_ALL); HIPCHK(hipGetLastError()); }
+        e->step_take_pre = e->step_pregather = false;
+        return rc;
+    }
     if (e->world > 1 || (e->comm && e->force_comm)) {      // data-parallel replicas (also DQN_SIM_WORLD: world = k without a communicator)
         if (e->hp.use_graph && !e->profiling) {
             if (!e->g_pre[gi] && capture(e, sample, PH_PRE, &e->g_pre[gi])) return -1;
@@ -598,7 +614,9 @@ extern "C" int dqn_train_steps(dqn_engine_t* e, int n, float* loss, float* grad_
     HIPCHK(hipSetDevice(e->device));
     if (e->hp.recurrence) { for (int i = 0; i < n; i++) if (dqn_train_step_drqn(e, nullptr, nullptr, i + 1 == n ? loss : nullptr, i + 1 == n ? grad_norm : nullptr)) return -1; return 0; }
     if (e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
-    for (int i = 0; i < n; i++) if (run_step(e, true)) return -1;
+    if (build_program(e)) return -1;
+    // between the steps of this call nothing else touches the replay: step i's Adam launch gathers step i+1's batch (PreGather)
+    for (int i = 0; i < n; i++) if (run_step(e, true, e->pg_ok && i > 0, e->pg_ok && i + 1 < n)) return -1;
     if (loss || grad_norm) return fetch_scalars(e, loss, grad_norm);
     return 0;
 }
@@ -721,7 +739,12 @@ extern "C" int dqn_debug_ktrace(dqn_engine_t* e, uint64_t* out, size_t n) { if (
 __global__ void k_gate(volatile int* flag) {
     for (long i = 0; i < 2000000 && *flag == 0; i++) __builtin_amdgcn_s_sleep(32);
 }
-extern "C" int dqn_profile_step(dqn_engine_t* e, int max_entries, const char** names, float* ms, int* n_entries) { if (!e) return fail("null engine handle");
+static int profile_step(dqn_engine_t* e, int max_entries, const char** names, float* ms, int* n_entries, bool steady);
+extern "C" int dqn_profile_step(dqn_engine_t* e, int max_entries, const char** names, float* ms, int* n_entries) { return profile_step(e, max_entries, names, ms, n_entries, false); }
+// as dqn_profile_step, but the step timed is a MIDDLE step of dqn_train_steps(n) (TWO train steps run; the second is timed): without its
+// gather launch and with the next batch's gather inside its Adam launch, when the engine supports that (PreGather) -- else a plain step
+extern "C" int dqn_profile_steady_step(dqn_engine_t* e, int max_entries, const char** names, float* ms, int* n_entries) { return profile_step(e, max_entries, names, ms, n_entries, true); }
+static int profile_step(dqn_engine_t* e, int max_entries, const char** names, float* ms, int* n_entries, bool steady) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device));
     if (!e->hp.recurrence && e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
     if (e->hp.recurrence && e->ep_size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
@@ -731,7 +754,15 @@ extern "C" int dqn_profile_step(dqn_engine_t* e, int max_entries, const char** n
     *gate = 0;
     hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, e->stream, (volatile int*)gate);
     e->profiling = true; e->prof.clear();
-    const int rc = e->hp.recurrence ? dqn_train_step_drqn(e, nullptr, nullptr, nullptr, nullptr) : run_step(e, true);
+    int rc = 0;
+    if (e->hp.recurrence) rc = dqn_train_step_drqn(e, nullptr, nullptr, nullptr, nullptr);
+    else if (steady && !build_program(e)) {      // a MIDDLE step of dqn_train_steps(n): one un-timed step first (its Adam launch gathers the timed step's batch)
+        e->profiling = false; rc = run_step(e, true, false, e->pg_ok); e->profiling = true;
+        if (!rc) rc = run_step(e, true, e->pg_ok, e->pg_ok);
+        // the timed step's own pre-gather filled the arena for a step that will not come: drop it (pre_valid 2 -> 1 is implied by the next gather
+        // launch overwriting the arena; the indices in idx_pre stay valid)
+    }
+    else rc = run_step(e, true);
     e->profiling = false;
     __atomic_store_n(gate, 1, __ATOMIC_SEQ_CST);
     if (rc) return -1;

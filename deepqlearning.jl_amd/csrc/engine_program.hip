@@ -12,12 +12,18 @@ bool same_geo(const LayerDev& a, const LayerDev& b) {
            a.sh == b.sh && a.sw == b.sw && a.ih == b.ih && a.iw == b.iw && a.fwd_kc == b.fwd_kc && a.src == b.src;
 }
 void add_valu(dqn_engine* e, std::vector<VTask>& pend, const VTask& t) { pend.push_back(t); }
-void flush_valu(dqn_engine* e, std::vector<VTask>& pend, const char* name) {
+// prio: the step's priority block (update_priorities! + the next step's index draw) rides as workgroup 0 of this launch
+void flush_valu(dqn_engine* e, std::vector<VTask>& pend, const char* name, const PrioArgs* prio) {
     if (pend.empty()) return;
     unsigned blocks = 0;
     for (auto& t : pend) { t.first_block = blocks; blocks += valu_task_blocks(t); }
     VTask* dev = upload(e, pend); const int n = (int)pend.size();
-    (e->sink ? *e->sink : e->prog).push_back({name, [=](dqn_engine* en) { launch_valu_multi(en->stream, dev, n, blocks); }});
+    if (prio) {
+        const PrioArgs pa = *prio; StepState* stt = e->state;
+        char nm[80]; snprintf(nm, sizeof nm, "%s+prio", name); e->prog_names.push_back(nm); const char* name2 = e->prog_names.back().c_str();
+        (e->sink ? *e->sink : e->prog).push_back({name2, [=](dqn_engine* en) { launch_valu_multi(en->stream, dev, n, blocks, &pa, stt); }});
+    }
+    else (e->sink ? *e->sink : e->prog).push_back({name, [=](dqn_engine* en) { launch_valu_multi(en->stream, dev, n, blocks); }});
     pend.clear();
 }
 void emit_reduce(dqn_engine* e, std::vector<RSeg>& segs, const char* name) {
@@ -187,7 +193,7 @@ int build_program(dqn_engine* e) {
             h.B = B; h.nA = e->nA; h.dueling = e->hp.dueling; h.double_q = e->hp.double_q; h.gamma = e->hp.gamma; h.prio_beta = e->hp.prio_beta; h.cap2 = e->cap2;
             h.bm_a = e->gb_a2; h.bm_r = e->gb_r2; h.bm_done = e->gb_done2; h.bm_w = e->gb_w2;
             h.w_is = e->w_is; h.td = e->td; h.q_on_s = e->q_on_s; h.q_on_sp = e->q_on_sp; h.q_tg_sp = e->q_tg_sp; h.ytarget = e->ytarget; h.best = e->best; h.st = e->state;
-            h.hl = hl_buf;
+            h.hl = hl_buf; h.idx = e->idx; h.idx_pre = e->idx_pre;
             auto fill = [&](HeadLayer& H, int l) {
                 const LayerDev& L = e->L[l];
                 H.K = L.K; H.N = L.N; H.S = dqn_nchunks(L.K, L.fwd_kc); H.kc = dqn_chunk_len(L.K, L.fwd_kc); H.act = L.act;
@@ -208,7 +214,7 @@ int build_program(dqn_engine* e) {
             }
             if (const char* dv = getenv("DQN_HEAD_DBG")) h.dbg = atoi(dv);
             const HeadTdArgs* h_dev = upload(e, std::vector<HeadTdArgs>(1, h));
-            e->prog.push_back({"head_td", [=](dqn_engine* en) { launch_head_td(en->stream, h, h_dev, en->step_sampled ? 1 : 0); }});
+            e->prog.push_back({"head_td", [=](dqn_engine* en) { launch_head_td(en->stream, h, h_dev, en->step_sampled ? 1 : 0, en->step_take_pre ? 1 : 0); }});
         }
         else if (!rec) e->prog.push_back({"td_huber", [=](dqn_engine* en) { TdArgs a = t; a.bump_sample_ctr = en->step_sampled ? 1 : 0; launch_td(en->stream, a); }});
         else {
@@ -267,6 +273,9 @@ int build_program(dqn_engine* e) {
                               if (Bb <= 64) { pa.idx_pre = e->idx_pre; pa.seed = e->hp.seed; pa.B = Bb; }      // the fused sample+gather launch (B <= 64) consumes them
                               return pa; };
     const bool prio_in_adam = e->hp.prioritized_replay && !rec && Bb <= 64;      // larger batches: side stream (prio_fork)
+    // pre-gather (common.h PreGather): needs the priority block (which also draws the next indices) OUT of the Adam launch -- it rides as
+    // workgroup 0 of the first LDS-tiled backward launch instead
+    const bool pg_want = prio_in_adam && !early && !e->comm && !e->sim_world && fuse_heads && e->hp.obs_dtype != DQN_OBS_U8 && !e->arena_u8 && !getenv("DQN_NO_PREGATHER");
     // layer l's gradient is final: queue its parameter range (split-K layers: as a slab segment)
     auto adam_queue = [&](int l, const std::vector<RSeg>& segs_known) {
         const LayerDev& L = e->L[l]; PItem it; it.beg = L.w_off; it.end = l + 1 < e->nl ? e->L[l + 1].w_off : e->Pint; it.part = nullptr; it.S = 0;
@@ -435,11 +444,14 @@ int build_program(dqn_engine* e) {
             tail.adam = make_job((pending_stream() / (unsigned long long)(li + 1) + 3) / 4 * 4, false); tail.has_adam = 1;
             if (prio_in_adam && !prio_placed) { tail.adam.prio = prio_args(); prio_placed = true; }
         }
+        else if (pg_want && (dwl.on || dxl.on) && !prio_placed) { tail.adam = base_job(); tail.adam.prio = prio_args(); tail.has_adam = 1; prio_placed = true; }
+        if (pg_want && !prio_placed && !pend.empty() && !tail.has_adam) { const PrioArgs pa = prio_args(); flush_valu(e, pend, pname(e, "bwd_valu", e->L[lv[0]].kind, lv[0]), &pa); prio_placed = true; }
         flush_valu(e, pend, pname(e, "bwd_valu", e->L[lv[0]].kind, lv[0]));
-        auto tailed = [&](const char* base) { if (!tail.has_adam) return base; char nm[80]; snprintf(nm, sizeof nm, "%s+adam_tail", base); e->prog_names.push_back(nm); return e->prog_names.back().c_str(); };
+        const char* tsuf = (tail.has_adam && adam_job_blocks(tail.adam) == 1 && tail.adam.prio.n > 0) ? "+prio" : "+adam_tail";      // a job that is only the priority block
+        auto tailed = [&](const char* base) { if (!tail.has_adam) return base; char nm[80]; snprintf(nm, sizeof nm, "%s%s", base, tsuf); e->prog_names.push_back(nm); return e->prog_names.back().c_str(); };
         if (dwl.on && dxl.on) {      // dW and dX of this level in ONE launch
             const DwL a = dwl; const DxL x = dxl; dwl.on = dxl.on = false;
-            char nm[80]; snprintf(nm, sizeof nm, "%s+%s%s", a.name, x.name, tail.has_adam ? "+adam_tail" : ""); e->prog_names.push_back(nm); const char* name = e->prog_names.back().c_str();
+            char nm[80]; snprintf(nm, sizeof nm, "%s+%s%s", a.name, x.name, tail.has_adam ? tsuf : ""); e->prog_names.push_back(nm); const char* name = e->prog_names.back().c_str();
             e->prog.push_back({name, [=](dqn_engine* en) { launch_gemm_dwdx(en->stream, a.L, a.nprob, a.X, a.ldx, a.d, B, a.o, x.L, x.nsrc, x.W, x.d, x.out, x.ys, ncon, x.act_src, tail); }});
         }
         else if (dwl.on) { const DwL a = dwl; dwl.on = false; e->prog.push_back({tailed(a.name), [=](dqn_engine* en) { launch_gemm_dw(en->stream, a.L, a.nprob, a.X, a.ldx, a.d, B, a.o, 0, 0, 0, tail); }}); }
@@ -546,11 +558,18 @@ int build_program(dqn_engine* e) {
     } else {
         AdamJob J = base_job();
         J.nr = 1; J.beg[0] = 0; J.end[0] = e->Pint; J.sblocks = (unsigned)adam_blocks(e->Pint); J.tick = 1; J.slot0 = 0;
-        if (e->hp.prioritized_replay && !rec && !e->prio_forked) J.prio = prio_args();
+        if (e->hp.prioritized_replay && !rec && !e->prio_forked && !prio_placed) J.prio = prio_args();
+        memset(&e->pg, 0, sizeof e->pg); e->pg_ok = pg_want && prio_placed;
+        if (e->pg_ok) {
+            PreGather& G = e->pg; G.on = 1; G.s_rows = e->s_rows; G.sp_rows = e->sp_rows; G.E = e->E; G.B = B; G.idx_pre = e->idx_pre; G.x0 = e->x0; G.cap2 = e->cap2; G.tree = e->tree; G.seed = e->hp.seed;
+            G.meta.a = e->ra; G.meta.r = e->rr; G.meta.done = e->rdone; G.meta.beta = e->hp.prio_beta; G.meta.a_out = e->gb_a2; G.meta.r_out = e->gb_r2; G.meta.done_out = e->gb_done2; G.meta.w_out = e->gb_w2;
+            G.gx = (e->E + 63) / 64; G.gy = (2 * B + 63) / 64;
+        }
+        e->adam_step = (long)e->prog.size();
         J.gscale = e->world > 1 ? 1.0f / (float)e->world : 1.0f;
         const bool fold = e->adam_segs.n > 0 && !e->comm && !e->sim_world;     // with a communicator the gradient must be materialised before the all-reduce
         if (e->dp_gather && e->dp_adam_folds) J.segs = e->dp_adam_segs; else if (fold) J.segs = e->adam_segs;
-        e->prog.push_back({"adam", [=](dqn_engine* en) { launch_adam(en->stream, J); }});
+        e->prog.push_back({"adam", [=](dqn_engine* en) { launch_adam(en->stream, J, en->step_pregather ? &en->pg : nullptr); }});
     }
     e->prog_built = true;
     return 0;

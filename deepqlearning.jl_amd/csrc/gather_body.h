@@ -1,0 +1,82 @@
+// gather_body.h -- get_batch (src/prioritized_experience_replay.jl:89-104) of the train path as a DEVICE body, run by k_gather_fb (replay.hip) and
+// by the pre-gather workgroups of the Adam launch (nn_valu.hip, k_adam_pg): inside dqn_train_steps(n) step i's last launch already gathers
+// step i+1's batch, so that step i+1 starts with its first convolution instead of a gather launch.
+#pragma once
+#include "common.h"
+
+typedef float gb_f32x4 __attribute__((ext_vector_type(4)));
+
+// batch scalars + IS weights of the B sampled transitions (k_batch_meta's arithmetic), by the first 64 lanes of ONE workgroup at the END of the
+// gather launch: its two dependent round trips and the double-precision pow overlap the other workgroups' row traffic
+__device__ __forceinline__ void gather_batch_meta(const BatchMeta& M, const long long* rows, int c0, int B, long long cap2, const float* __restrict__ tree,
+                                                  const StepState* __restrict__ state) {
+    if (!M.a_out || threadIdx.x >= 64) return;
+    const int c = c0 + threadIdx.x;
+    if (c >= B) return;
+    const long long j = rows[threadIdx.x];
+    M.a_out[c] = M.a[j]; M.r_out[c] = M.r[j]; M.done_out[c] = (float)M.done[j];
+    const float p = tree[cap2 + j] / tree[1];                   // p = prio ./ sum(prio[1:n]), :101
+    const float x = (float)state->size * p;                     // n .* p
+    M.w_out[c] = (float)pow((double)x, -(double)M.beta);        // .^ (-beta), :102
+}
+// (bx, by): the 64-feature x 64-column tile; tile: 64 x 65 floats of LDS; rows: 64 long longs of LDS
+__device__ __forceinline__ void gather_fb_body(const void* __restrict__ s_rows, const void* __restrict__ sp_rows, int u8, int E, int B,
+                                               long long* __restrict__ idx, float* __restrict__ x0, int do_sample, long long cap2,
+                                               const float* __restrict__ tree, unsigned long long seed, const StepState* __restrict__ state, const BatchMeta& meta,
+                                               const long long* __restrict__ idx_pre, int bx, int by, float (*tile)[65], long long* rows) {
+    const int f0 = bx * 64, c0 = by * 64, lane = threadIdx.x & 63, w = threadIdx.x >> 6, ld = 2 * B;
+    if (threadIdx.x < 64) {
+        const int c = c0 + threadIdx.x;
+        long long r = 0;
+        if (c < ld) {
+            const int i = c < B ? c : c - B;
+            if (do_sample) {
+                // the indices of this sample() were drawn in the tail of the previous step's priority block unless something changed the tree since
+                r = (idx_pre && state->pre_valid) ? idx_pre[i] : tree_descend(tree, cap2, state->size, seed, state->sample_ctr, i, tree[1] / (float)B);
+                if (bx == 0 && c < B) idx[i] = r;
+            } else r = idx[i];
+        }
+        rows[threadIdx.x] = r;
+    }
+    __syncthreads();
+    if (!u8 && (E & 3) == 0) {
+        // f32 rows: 4 independent 16-B loads per thread are issued before any is consumed (HBM latency overlapped); a 64-feature
+        // row segment is 16 lanes x 16 B = one 256-B burst of a sampled transition
+        gb_f32x4 v[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int q = threadIdx.x + 256 * p, cl = q >> 4, c = c0 + cl, f = f0 + 4 * (q & 15);
+            v[p] = (gb_f32x4){0.f, 0.f, 0.f, 0.f};
+            if (c < ld && f < E) v[p] = *reinterpret_cast<const gb_f32x4*>((const float*)(c < B ? s_rows : sp_rows) + rows[cl] * E + f);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int q = threadIdx.x + 256 * p, cl = q >> 4, fl = 4 * (q & 15);
+            tile[cl][fl] = v[p].x; tile[cl][fl + 1] = v[p].y; tile[cl][fl + 2] = v[p].z; tile[cl][fl + 3] = v[p].w;
+        }
+    } else {
+#pragma unroll 4
+        for (int p = 0; p < 16; p++) {
+            const int cl = p * 4 + w, c = c0 + cl, f = f0 + lane;
+            float v = 0.0f;
+            if (c < ld && f < E) {
+                const long long row = rows[cl];
+                const void* base = c < B ? s_rows : sp_rows;
+                if (u8) v = (float)((const unsigned char*)base)[row * E + f] / 255.0f;  // test/test_env.jl:59
+                else v = ((const float*)base)[row * E + f];
+            }
+            tile[cl][lane] = v;
+        }
+    }
+    __syncthreads();
+    // 16 lanes x float4 = one 256-B row segment of the arena (64 consecutive columns of one feature); a wave writes 4 feature rows per instruction
+    const int l16 = threadIdx.x & 15, r16 = threadIdx.x >> 4;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int fl = p * 16 + r16, f = f0 + fl, c = c0 + 4 * l16;
+        if (f >= E) continue;
+        if (c + 3 < ld) *reinterpret_cast<gb_f32x4*>(x0 + (size_t)f * ld + c) = (gb_f32x4){tile[4 * l16][fl], tile[4 * l16 + 1][fl], tile[4 * l16 + 2][fl], tile[4 * l16 + 3][fl]};
+        else for (int u = 0; u < 4; u++) if (c + u < ld) x0[(size_t)f * ld + c + u] = tile[4 * l16 + u][fl];
+    }
+    if (bx == 0) gather_batch_meta(meta, rows, c0, B, cap2, tree, state);
+}

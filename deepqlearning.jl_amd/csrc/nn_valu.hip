@@ -7,6 +7,7 @@
 #include "common.h"
 #include "valu_tasks.h"
 #include "adam_body.h"
+#include "gather_body.h"
 
 // ------------------------------------------------------------------ split-K reduction epilogues
 // mode 0: forward      Y = act(sum_s part + bias[n])             (n = e / per_n)
@@ -98,8 +99,16 @@ unsigned valu_task_blocks(const VTask& T) {
     else n = 1;
     return (unsigned)((n + 255) / 256);
 }
-void launch_valu_multi(hipStream_t st, const VTask* tasks_dev, int ntasks, unsigned total_blocks) {
-    hipLaunchKernelGGL(k_valu_multi, dim3(total_blocks), dim3(256), 0, st, tasks_dev, ntasks);
+// ... with the step's priority block as workgroup 0: its dependent tree levels hide under the task table instead of inside the Adam launch,
+// which leaves the Adam launch free to gather the next batch (PreGather)
+__global__ __launch_bounds__(256) void k_valu_multi_prio(const VTask* __restrict__ tasks, int ntasks, PrioArgs P, StepState* state) {
+    __shared__ long long sidx[1024];
+    if (blockIdx.x == 0) { prio_block_run(P, state, sidx); return; }
+    valu_task_run(tasks, ntasks, blockIdx.x - 1);
+}
+void launch_valu_multi(hipStream_t st, const VTask* tasks_dev, int ntasks, unsigned total_blocks, const PrioArgs* prio, StepState* state) {
+    if (prio) hipLaunchKernelGGL(k_valu_multi_prio, dim3(total_blocks + 1), dim3(256), 0, st, tasks_dev, ntasks, *prio, state);
+    else hipLaunchKernelGGL(k_valu_multi, dim3(total_blocks), dim3(256), 0, st, tasks_dev, ntasks);
 }
 void launch_valu_dx(hipStream_t st, const LayerDev& L, const float* P, const float* dpre, int B, float* out, float* partials,
                     const float* addend, const float* ysrc, int ldy, int act_src) {
@@ -298,7 +307,7 @@ __device__ __forceinline__ void head_commit(const HeadLayer& L, int B, int b, in
 // spilled ~700 lane moves; fields are fetched with scalar loads where they are used instead.  The kernel is written for a SHORT instruction
 // stream: its 32 workgroups are lone waves on cold instruction caches, so every instruction is paid in full -- the two heads share one copy of
 // each phase (per-lane selects instead of two inlined bodies), indices are decoded with multiplies, LDS is read 16 bytes at a time.
-__global__ __launch_bounds__(256) void k_head_td(const HeadTdArgs* __restrict__ Ap, int bump_sample_ctr) {
+__global__ __launch_bounds__(256) void k_head_td(const HeadTdArgs* __restrict__ Ap, int bump_sample_ctr, int take_pre) {
     extern __shared__ float hs[];
     const HeadTdArgs& A = *Ap;
     const int B = A.B, nA = A.nA, b = blockIdx.x, tid = threadIdx.x;
@@ -318,6 +327,10 @@ __global__ __launch_bounds__(256) void k_head_td(const HeadTdArgs* __restrict__ 
     float* const qs = p; p += 3 * nA;                      // Q[slot][a]
     float* const dq = p;                                   // [1 + nA]: head pre-activation gradients of this column (val first)
     if (A.dbg == 9) return;
+    if (take_pre && b == 0) {      // the batch in the arena was gathered by the previous step's Adam launch: publish its indices (priority block, parity API)
+        if (tid < B) A.idx[tid] = A.idx_pre[tid];
+        if (tid == 0 && A.st->pre_valid != 2) A.st->err = 3;
+    }
     int act_ = 0; float rew_ = 0.0f, dn_ = 0.0f, w_ = 0.0f;
     if (tid == 0) { act_ = A.bm_a[b]; rew_ = A.bm_r[b]; dn_ = A.bm_done[b]; w_ = A.bm_w[b]; }     // get_batch scalars + IS weight (gather launch)
     // biases of the outputs this lane finishes (o = slot * N + n; adv outputs first, then val): requested now, consumed after phase 2
@@ -461,9 +474,9 @@ size_t head_td_lds_bytes(const HeadTdArgs& a) {
     for (int h = a.dueling ? 0 : 1; h < 2; h++) f += PADI((size_t)3 * H[h]->K) + (a.stage_w ? PADI((size_t)2 * H[h]->K * H[h]->N) : 0) + (size_t)3 * H[h]->N * H[h]->S + (size_t)3 * H[h]->N;
     return (f + 3 * a.nA + 1 + a.nA + 8) * sizeof(float);
 }
-void launch_head_td(hipStream_t st, const HeadTdArgs& a, const HeadTdArgs* a_dev, int bump_sample_ctr) {
+void launch_head_td(hipStream_t st, const HeadTdArgs& a, const HeadTdArgs* a_dev, int bump_sample_ctr, int take_pre) {
     const size_t lds = head_td_lds_bytes(a);
-    hipLaunchKernelGGL(k_head_td, dim3(a.B), dim3(256), lds, st, a_dev, bump_sample_ctr);
+    hipLaunchKernelGGL(k_head_td, dim3(a.B), dim3(256), lds, st, a_dev, bump_sample_ctr, take_pre);
 }
 
 // Q columns for the policy path (src/policy.jl:38-64): q_out[n][nA], argmax (first max)
@@ -491,8 +504,22 @@ __global__ __launch_bounds__(256) void k_adam_stream(AdamJob J) {
     __shared__ float wmax[4];
     adam_job_run(J, (int)blockIdx.x, nullptr, wmax);
 }
+// the Adam launch of a step that is followed by another sampled step: its FIRST workgroups gather the next batch (PreGather); their dependent
+// round trips (row index -> 256-B row segments -> LDS -> arena lines) hide under the parameter stream of the remaining workgroups
+__global__ __launch_bounds__(256) void k_adam_pg(AdamJob J, PreGather G) {
+    __shared__ float tile[64][65]; __shared__ long long rows[64]; __shared__ float wmax[4];
+    const int npg = G.gx * G.gy;
+    if ((int)blockIdx.x < npg) {
+        const int bx = (int)blockIdx.x % G.gx, by = (int)blockIdx.x / G.gx;
+        gather_fb_body(G.s_rows, G.sp_rows, 0, G.E, G.B, G.idx_pre, G.x0, 1, G.cap2, G.tree, G.seed, J.state, G.meta, G.idx_pre, bx, by, tile, rows);
+        if (blockIdx.x == 0 && threadIdx.x == 0 && J.state->pre_valid) J.state->pre_valid = 2;
+        return;
+    }
+    adam_job_run(J, (int)blockIdx.x - npg, nullptr, wmax);
+}
 int adam_blocks(size_t P) { size_t blocks = (P + 255) / 256; if (blocks > 2048) blocks = 2048; return (int)blocks; }
-void launch_adam(hipStream_t st, const AdamJob& job) {
+void launch_adam(hipStream_t st, const AdamJob& job, const PreGather* pg) {
+    if (pg && pg->on && job.prio.n == 0) { hipLaunchKernelGGL(k_adam_pg, dim3(pg->gx * pg->gy + adam_job_blocks(job)), dim3(256), 0, st, job, *pg); return; }
     if (job.prio.n > 0) hipLaunchKernelGGL(k_adam, dim3(adam_job_blocks(job)), dim3(256), 0, st, job);
     else hipLaunchKernelGGL(k_adam_stream, dim3(adam_job_blocks(job)), dim3(256), 0, st, job);
 }

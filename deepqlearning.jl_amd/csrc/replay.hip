@@ -6,6 +6,7 @@
 // The sum-tree is canonical: every internal node is exactly f32(left + right) of its current children, so the root
 // (the IS-weight denominator, :101) does not depend on update history and the CPU twin reproduces it bit for bit.
 #include "common.h"
+#include "gather_body.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -16,80 +17,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // With do_sample, every workgroup first repeats the (cheap, deterministic) stratified sum-tree descent for the 2B columns
 // it needs -- B descents of log2(cap) dependent L2 hits -- instead of waiting for a separate single-workgroup sample
 // launch (~4.6 us floor); workgroup (0,0) publishes the indices for k_td.  The Philox counter is bumped by k_td.
-// batch scalars + IS weights of the B sampled transitions (k_batch_meta's arithmetic), by the first 64 lanes of ONE workgroup at the END of the
-// gather launch: its two dependent round trips and the double-precision pow overlap the other workgroups' row traffic
-__device__ __forceinline__ void gather_batch_meta(const BatchMeta& M, const long long* rows, int c0, int B, long long cap2, const float* __restrict__ tree,
-                                                  const StepState* __restrict__ state) {
-    if (!M.a_out || threadIdx.x >= 64) return;
-    const int c = c0 + threadIdx.x;
-    if (c >= B) return;
-    const long long j = rows[threadIdx.x];
-    M.a_out[c] = M.a[j]; M.r_out[c] = M.r[j]; M.done_out[c] = (float)M.done[j];
-    const float p = tree[cap2 + j] / tree[1];                   // p = prio ./ sum(prio[1:n]), :101
-    const float x = (float)state->size * p;                     // n .* p
-    M.w_out[c] = (float)pow((double)x, -(double)M.beta);        // .^ (-beta), :102
-}
 __global__ __launch_bounds__(256) void k_gather_fb(const void* __restrict__ s_rows, const void* __restrict__ sp_rows, int u8, int E, int B,
                                                    long long* __restrict__ idx, float* __restrict__ x0, int do_sample, long long cap2,
                                                    const float* __restrict__ tree, unsigned long long seed, const StepState* __restrict__ state, BatchMeta meta,
                                                    const long long* __restrict__ idx_pre) {
     __shared__ float tile[64][65];
     __shared__ long long rows[64];
-    const int f0 = blockIdx.x * 64, c0 = blockIdx.y * 64, lane = threadIdx.x & 63, w = threadIdx.x >> 6, ld = 2 * B;
-    if (threadIdx.x < 64) {
-        const int c = c0 + threadIdx.x;
-        long long r = 0;
-        if (c < ld) {
-            const int i = c < B ? c : c - B;
-            if (do_sample) {
-                // the indices of this sample() were drawn in the tail of the previous step's priority block unless something changed the tree since
-                r = (idx_pre && state->pre_valid) ? idx_pre[i] : tree_descend(tree, cap2, state->size, seed, state->sample_ctr, i, tree[1] / (float)B);
-                if (blockIdx.x == 0 && c < B) idx[i] = r;
-            } else r = idx[i];
-        }
-        rows[threadIdx.x] = r;
-    }
-    __syncthreads();
-    if (!u8 && (E & 3) == 0) {
-        // f32 rows: 4 independent 16-B loads per thread are issued before any is consumed (HBM latency overlapped); a 64-feature
-        // row segment is 16 lanes x 16 B = one 256-B burst of a sampled transition
-        f32x4 v[4];
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const int q = threadIdx.x + 256 * p, cl = q >> 4, c = c0 + cl, f = f0 + 4 * (q & 15);
-            v[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (c < ld && f < E) v[p] = *reinterpret_cast<const f32x4*>((const float*)(c < B ? s_rows : sp_rows) + rows[cl] * E + f);
-        }
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const int q = threadIdx.x + 256 * p, cl = q >> 4, fl = 4 * (q & 15);
-            tile[cl][fl] = v[p].x; tile[cl][fl + 1] = v[p].y; tile[cl][fl + 2] = v[p].z; tile[cl][fl + 3] = v[p].w;
-        }
-    } else {
-#pragma unroll 4
-        for (int p = 0; p < 16; p++) {
-            const int cl = p * 4 + w, c = c0 + cl, f = f0 + lane;
-            float v = 0.0f;
-            if (c < ld && f < E) {
-                const long long row = rows[cl];
-                const void* base = c < B ? s_rows : sp_rows;
-                if (u8) v = (float)((const unsigned char*)base)[row * E + f] / 255.0f;  // test/test_env.jl:59
-                else v = ((const float*)base)[row * E + f];
-            }
-            tile[cl][lane] = v;
-        }
-    }
-    __syncthreads();
-    // 16 lanes x float4 = one 256-B row segment of the arena (64 consecutive columns of one feature); a wave writes 4 feature rows per instruction
-    const int l16 = threadIdx.x & 15, r16 = threadIdx.x >> 4;
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-        const int fl = p * 16 + r16, f = f0 + fl, c = c0 + 4 * l16;
-        if (f >= E) continue;
-        if (c + 3 < ld) *reinterpret_cast<f32x4*>(x0 + (size_t)f * ld + c) = (f32x4){tile[4 * l16][fl], tile[4 * l16 + 1][fl], tile[4 * l16 + 2][fl], tile[4 * l16 + 3][fl]};
-        else for (int u = 0; u < 4; u++) if (c + u < ld) x0[(size_t)f * ld + c + u] = tile[4 * l16 + u][fl];
-    }
-    if (blockIdx.x == 0) gather_batch_meta(meta, rows, c0, B, cap2, tree, state);
+    gather_fb_body(s_rows, sp_rows, u8, E, B, idx, x0, do_sample, cap2, tree, seed, state, meta, idx_pre, (int)blockIdx.x, (int)blockIdx.y, tile, rows);
 }
 // u8 rows (config 5: 1e6 transitions, 28 224 B each): 256 features x 64 columns per workgroup so that every sampled row is
 // read in 256-B segments (one uchar4 per lane, 16 independent loads in flight per thread); 4x fewer workgroups than the f32

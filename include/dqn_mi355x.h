@@ -252,6 +252,10 @@ int dqn_stream_handle(dqn_engine_t* e, void** hip_stream);
 /* per-kernel timing of the last dqn_profile_step call: names (static strings) and
  * milliseconds measured with HIP events on the engine stream. */
 int dqn_profile_step(dqn_engine_t* e, int max_entries, const char** names, float* ms, int* n_entries);
+/* as dqn_profile_step, but TWO train steps run and the second is timed as a MIDDLE step of dqn_train_steps(n): inside that call step i's last
+ * launch (Adam) already gathers step i+1's batch, so a middle step has no gather launch of its own (f32 observations, B <= 64, prioritized
+ * replay; otherwise both steps are plain ones).  Results of dqn_train_steps(n) are bit-identical to n dqn_train_step calls either way. */
+int dqn_profile_steady_step(dqn_engine_t* e, int max_entries, const char** names, float* ms, int* n_entries);
 
 /* debug aid: per-workgroup timestamps of the forward GEMM kernels (tools/ktrace.py).  out == NULL starts recording; otherwise stops and copies
  * n 64-bit words: [0] = record count, then 8-word records {grid, block, s_memtime x 6}. */

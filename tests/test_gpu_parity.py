@@ -138,6 +138,62 @@ def test_adam_jobs_carried_by_backward_launches(pkg, monkeypatch, netf, B):
     np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
 
 
+@pytest.mark.parametrize("graph", [1, 0])
+@pytest.mark.parametrize("netf,B,kw", [
+    (nature_dueling, 32, dict()),
+    (small_conv_dueling, 16, dict()),
+    (cfg1_mlp_dueling, 32, dict(gamma=0.95)),
+    (small_conv_plain, 8, dict(double_q=0, prioritized_replay=0)),       # not eligible for the pre-gather: must simply still be right
+])
+def test_train_steps_pipelined_gather_bit_exact(pkg, netf, B, kw, graph):
+    """dqn_train_steps(n): step i's Adam launch gathers step i+1's batch (common.h PreGather) and step i+1 runs without a gather launch.  Another
+    schedule of the same arithmetic: after train_steps(n) every piece of state equals the twin stepped n times one call at a time -- and single
+    steps, replay writes and explicit-index steps in between must find nothing stale."""
+    net = netf()
+    gpu, cpu, hp = make_pair(pkg, net, B, cap=128, graph=graph, learning_rate=1e-3, **kw)
+    fill((gpu, cpu), net, 100, seed=7)
+    set_same_params((gpu, cpu), net, seed=5)
+
+    def same_state():
+        np.testing.assert_array_equal(gpu.last_indices(), cpu.last_indices())
+        np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+        np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
+        mg, vg, bg = gpu.get_adam_state(); mc, vc, bc = cpu.get_adam_state()
+        np.testing.assert_array_equal(mg, mc); np.testing.assert_array_equal(vg, vc); np.testing.assert_array_equal(bg, bc)
+
+    lg = gpu.train_steps(5)
+    for _ in range(5):
+        lc = cpu.train_step()
+    assert lg[0] == lc[0] and lg[1] == lc[1]
+    same_state()
+    assert_step_bit_exact(gpu, cpu)                       # a plain step after the pipelined call
+    fill((gpu, cpu), net, 9, seed=8)                      # the replay changes: whatever was drawn ahead is stale
+    lg = gpu.train_steps(3)
+    for _ in range(3):
+        lc = cpu.train_step()
+    assert lg[0] == lc[0] and lg[1] == lc[1]
+    same_state()
+    idx = np.random.default_rng(1).integers(0, 100, B)
+    assert_step_bit_exact(gpu, cpu, idx)                  # an explicit-index step overwrites the arena
+    lg = gpu.train_steps(2)
+    for _ in range(2):
+        lc = cpu.train_step()
+    assert lg[0] == lc[0] and lg[1] == lc[1]
+    same_state()
+    lg = gpu.train_steps(1); lc = cpu.train_step()
+    assert lg[0] == lc[0] and lg[1] == lc[1]
+    same_state()
+    # the steady-state profile runs two real steps
+    names = [n for n, _ in gpu.profile_step(steady=True)]
+    cpu.train_step(); cpu.train_step()
+    same_state()
+    if kw.get("prioritized_replay", 1):      # the three prioritized cases are eligible: the middle step has no gather launch of its own
+        assert "adam+gather" in names and not any(n in ("gather", "sample_gather") for n in names), names
+    else:
+        assert "sample_gather" in names and "adam+gather" not in names, names
+    assert_step_bit_exact(gpu, cpu)
+
+
 def test_graph_and_eager_agree(pkg):
     net = small_conv_dueling()
     a, cpu, _ = make_pair(pkg, net, 16, graph=1)
