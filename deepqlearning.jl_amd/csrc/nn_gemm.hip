@@ -653,12 +653,148 @@ __device__ __forceinline__ void dx_lds_body_pj(const LayerDev& L, const GDxArgs&
     *reinterpret_cast<f32x4*>(A.out + (size_t)fl * B + b0 + 4 * kq) = v0;
     *reinterpret_cast<f32x4*>(A.out + (size_t)fl * B + b0 + 16 + 4 * kq) = v1;
 }
+// Large batches (B % 128 == 0): 32 features x 128 SAMPLES per workgroup.  Wave w owns samples 32w..32w+31 and both 16-feature tiles: four
+// accumulator tiles per source, 32 MFMAs per K tile and wave between two barriers instead of 8, and the conv prologue (tap list) is paid once
+// per 128 samples.  The per-element chain (taps ascending, output channels ascending, sources added at the end) is dx_lds_body's.
+constexpr int X_SAW = 144;   // A tile row stride (128 samples + 16 pad): fragment reads hit banks 16*kq + i
+__device__ __forceinline__ void dx_lds_body_wide(const LayerDev& L, const GDxArgs& A, int B, int S, int kc, int bid, int nblocks, int by) {
+    extern __shared__ float lds[];
+    float* As = lds;                                  // [2][32][X_SAW]
+    float* Bs = lds + 2 * 32 * X_SAW;                 // [2][32][X_SB]
+    int* taps = (int*)(Bs + 2 * 32 * X_SB);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const bool dense = L.kind == DQN_LAYER_DENSE;
+    const int b0 = by * 128;
+    int w = xcd_remap(bid, nblocks);
+    int f0, s = 0, ip = 0;
+    const int nfeat = dense ? L.K : L.cin;
+    if (dense) { const int ftiles = (L.K + 31) / 32; f0 = (w % ftiles) * 32; s = w / ftiles; }
+    else { const int ctiles = L.cin / 32; f0 = (w % ctiles) * 32; ip = w / ctiles; }
+    int nkt;
+    const int khw = L.kh * L.kw;
+    if (dense) { const int n0 = s * kc, n1 = min(L.N, n0 + kc); nkt = (n1 - n0) / 32; }
+    else {
+        if (tid < 64) {
+            const int iy = ip / L.iw, ix = ip % L.iw; bool ok = false; int val = 0;
+            if (tid < L.kh * L.kw) {
+                const int ky = tid / L.kw, kx = tid % L.kw, ty = iy - ky, tx = ix - kx;
+                if (ty >= 0 && tx >= 0 && ty % L.sh == 0 && tx % L.sw == 0) {
+                    const int oy = ty / L.sh, ox = tx / L.sw;
+                    if (oy < L.oh && ox < L.ow) { ok = true; val = (tid << 16) | (oy * L.ow + ox); }
+                }
+            }
+            const unsigned long long m = __ballot(ok);
+            if (ok) taps[__popcll(m & ((1ull << tid) - 1ull))] = val;
+            if (tid == 0) taps[255] = __popcll(m);
+        }
+        __syncthreads();
+        nkt = taps[255] * (L.N / 32);
+    }
+    const int total = nkt * A.nsrc;
+    // staging: A = 32 rows x 32 float4 (4 per thread: rows (tid >> 5) + 8p, float4 tid & 31); B = row tid >> 3, float4 tid & 7
+    const int arow = tid >> 5, af4 = tid & 31, brow = tid >> 3, bf4 = tid & 7;
+    const int frow = min(f0 + brow, nfeat - 1);
+    struct Stage { f32x4 a[4]; f32x4 b; };
+    auto gld = [](const float* ptr) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory"); return v; };
+    auto gload = [&](int kt, Stage& r) {
+        kt = min(kt, total - 1);
+        const int si = kt >= nkt ? 1 : 0; const int k = kt - si * nkt;
+        const GDxSrc& sr = A.src[si];
+        if (dense) {
+            const int nb = s * kc + k * 32;
+#pragma unroll
+            for (int p = 0; p < 4; p++) r.a[p] = gld(sr.dpre + (size_t)(nb + arow + 8 * p) * B + b0 + 4 * af4);
+            r.b = gld(sr.W + (size_t)frow * L.N + nb + 4 * bf4);
+        } else {
+            const int cot = L.N / 32; const int tp = taps[k / cot]; const int cob = (k % cot) * 32;
+            const int tap = tp >> 16, pos = tp & 0xffff;
+#pragma unroll
+            for (int p = 0; p < 4; p++) r.a[p] = gld(sr.dpre + ((size_t)(cob + arow + 8 * p) * L.npos + pos) * B + b0 + 4 * af4);
+            r.b = gld(sr.W + ((size_t)frow * khw + tap) * L.N + cob + 4 * bf4);
+        }
+    };
+    auto lstore = [&](int buf, const Stage& r) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) *reinterpret_cast<f32x4*>(As + (buf * 32 + arow + 8 * p) * X_SAW + 4 * af4) = r.a[p];
+        *reinterpret_cast<f32x4*>(Bs + (buf * 32 + brow) * X_SB + 4 * bf4) = r.b;
+    };
+#define STAGE_WAITW(N, r) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.b) : "n"(N) : "memory")
+    f32x4 acc[2][2][2];                               // [source][feature tile][sample tile]
+#pragma unroll
+    for (int i = 0; i < 8; i++) (&acc[0][0][0])[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf, int si) {
+        const float* Ab = As + buf * 32 * X_SAW + 32 * wave + l15;
+        const float* Bb = Bs + (buf * 32 + l15) * X_SB + kq;
+        float af[2][8], bf[2][8];
+#pragma unroll
+        for (int st = 0; st < 8; st++) {
+            af[0][st] = Ab[(4 * st + kq) * X_SAW]; af[1][st] = Ab[(4 * st + kq) * X_SAW + 16];
+            bf[0][st] = Bb[4 * st]; bf[1][st] = Bb[16 * X_SB + 4 * st];
+        }
+#pragma unroll
+        for (int st = 0; st < 8; st++)
+#pragma unroll
+            for (int ft = 0; ft < 2; ft++)
+#pragma unroll
+                for (int ml = 0; ml < 2; ml++) {
+                    if (si == 0) acc[0][ft][ml] = MFMA(af[ml][st], bf[ft][st], acc[0][ft][ml]);
+                    else acc[1][ft][ml] = MFMA(af[ml][st], bf[ft][st], acc[1][ft][ml]);
+                }
+    };
+    if (total > 0) {
+        Stage r0, r1;
+        gload(0, r0); STAGE_WAITW(0, r0); lstore(0, r0); __syncthreads();
+        gload(1, r0);
+        for (int kt = 0; kt < total; kt += 2) {
+            gload(kt + 2, r1);
+            compute(0, kt >= nkt ? 1 : 0);
+            STAGE_WAITW(5, r0); lstore(1, r0);
+            __syncthreads();
+            gload(kt + 3, r0);
+            if (kt + 1 < total) compute(1, kt + 1 >= nkt ? 1 : 0);
+            STAGE_WAITW(5, r1); lstore(0, r1);
+            __syncthreads();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#undef STAGE_WAITW
+    const size_t per_s = (size_t)L.in_feat * B;
+#pragma unroll
+    for (int ft = 0; ft < 2; ft++) {
+        const int fl = f0 + 16 * ft + l15;
+        if (fl >= nfeat) continue;
+        const size_t feat = dense ? (size_t)fl : (size_t)fl * L.ih * L.iw + ip;
+#pragma unroll
+        for (int ml = 0; ml < 2; ml++) {
+            const int bcol = b0 + 32 * wave + 16 * ml + 4 * kq;
+            f32x4 v = acc[0][ft][ml];
+            if (A.nsrc > 1) { const f32x4 o = acc[1][ft][ml]; v.x = v.x + o.x; v.y = v.y + o.y; v.z = v.z + o.z; v.w = v.w + o.w; }
+            if (S == 1 && A.ysrc) {
+                const f32x4 y = *reinterpret_cast<const f32x4*>(A.ysrc + feat * A.ldy + bcol);
+                v.x = dact_f(v.x, y.x, A.act_src); v.y = dact_f(v.y, y.y, A.act_src); v.z = dact_f(v.z, y.z, A.act_src); v.w = dact_f(v.w, y.w, A.act_src);
+            }
+            *reinterpret_cast<f32x4*>(A.out + (size_t)s * per_s + feat * B + bcol) = v;
+        }
+    }
+}
 static bool dx_parallel_join(const LayerDev& L, int nsrc, int S) { return nsrc == 2 && S == 1 && L.kind == DQN_LAYER_DENSE && (L.N / 32) % 2 == 0; }
-static size_t dx_lds_bytes(bool pj) { return pj ? (size_t)(2 * 2 * 32 * X_SA + 2 * 2 * 32 * X_SB) * 4 : (size_t)(2 * 32 * X_SA + 2 * 32 * X_SB) * 4 + 256 * 4; }
+// dX body of a launch: 0 = 32 x 32 tiles, 1 = parallel dueling join, 2 = 32 features x 128 samples (large batches)
+static int dx_mode(const LayerDev& L, int nsrc, int S, int B) {
+    static const bool no_wide = getenv("DQN_NO_DX_WIDE") != nullptr;
+    if (dx_parallel_join(L, nsrc, S)) return 1;
+    return (B % 128 == 0 && !no_wide) ? 2 : 0;
+}
+static int dx_cols(int mode) { return mode == 2 ? 128 : 32; }
+static size_t dx_lds_bytes(int mode) {
+    if (mode == 1) return (size_t)(2 * 2 * 32 * X_SA + 2 * 2 * 32 * X_SB) * 4;
+    if (mode == 2) return (size_t)(2 * 32 * X_SAW + 2 * 32 * X_SB) * 4 + 256 * 4;
+    return (size_t)(2 * 32 * X_SA + 2 * 32 * X_SB) * 4 + 256 * 4;
+}
 
 __global__ __launch_bounds__(256) void k_dx_lds(LayerDev L, GDxArgs A, int B, int S, int kc, int pj, int gx, GemmTail tail) {
     GEMM_TAIL_PROLOGUE(tail, bid, main_blocks)
-    if (pj) dx_lds_body_pj(L, A, B, bid % gx, gx, bid / gx);
+    if (pj == 1) dx_lds_body_pj(L, A, B, bid % gx, gx, bid / gx);
+    else if (pj == 2) dx_lds_body_wide(L, A, B, S, kc, bid % gx, gx, bid / gx);
     else dx_lds_body(L, A, B, S, kc, bid % gx, gx, bid / gx);
 }
 // dW and dX of one layer are independent given dpre: ONE launch runs both (blocks [0, dw_blocks) do dW, the rest dX), which
@@ -674,7 +810,11 @@ __global__ __launch_bounds__(256) void k_dwdx_lds(LayerDev Lw, GDwProbs pr, int 
     if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; prio_block_run(tail.adam.prio, tail.adam.state, reinterpret_cast<long long*>(lds)); return; }
     const int bid = (int)blockIdx.x - pre_, ntail = (int)gemm_tail_blocks(tail) - pre_;
     const int dx_blocks = (int)gridDim.x - pre_ - ntail - dw_blocks;
-    if (bid < dx_blocks) { if (pj) dx_lds_body_pj(Lx, A, B, bid % dx_gx, dx_gx, bid / dx_gx); else dx_lds_body(Lx, A, B, Sx, kcx, bid % dx_gx, dx_gx, bid / dx_gx); }
+    if (bid < dx_blocks) {
+        if (pj == 1) dx_lds_body_pj(Lx, A, B, bid % dx_gx, dx_gx, bid / dx_gx);
+        else if (pj == 2) dx_lds_body_wide(Lx, A, B, Sx, kcx, bid % dx_gx, dx_gx, bid / dx_gx);
+        else dx_lds_body(Lx, A, B, Sx, kcx, bid % dx_gx, dx_gx, bid / dx_gx);
+    }
     else if (bid < dx_blocks + ntail) gemm_tail_run(tail, (unsigned)(bid - dx_blocks));
     else dw_lds_body<NT>(Lw, pr, nprob, ldx, B, Sw, kcw, bid - dx_blocks - ntail, dw_blocks, DwStride{Lw.npos * B, 0, 0});
 }
@@ -693,8 +833,8 @@ void launch_gemm_dx(hipStream_t st, const LayerDev& L, int nsrc, const float* co
     GDxArgs a; a.nsrc = nsrc; a.out = out; a.ysrc = ysrc; a.ldy = ldy; a.act_src = act_src;
     for (int i = 0; i < 2; i++) { const int j = i < nsrc ? i : 0; a.src[i].W = W[j]; a.src[i].dpre = dpre[j]; }
     const int gx = dense ? ((L.K + 31) / 32) * S : (L.cin / 32) * L.ih * L.iw;
-    const bool pj = dx_parallel_join(L, nsrc, S);
-    hipLaunchKernelGGL(k_dx_lds, dim3(gx * (B / 32) + gemm_tail_blocks(tail)), dim3(256), dx_lds_bytes(pj), st, L, a, B, S, kc, pj ? 1 : 0, gx, tail);
+    const int pj = dx_mode(L, nsrc, S, B);
+    hipLaunchKernelGGL(k_dx_lds, dim3(gx * (B / dx_cols(pj)) + gemm_tail_blocks(tail)), dim3(256), dx_lds_bytes(pj), st, L, a, B, S, kc, pj, gx, tail);
 }
 
 void launch_gemm_dwdx(hipStream_t st, const LayerDev& Lw, int nprob, const float* const* X, int ldx, const float* const* dpre_w, int B, float* const* out_w,
@@ -709,11 +849,11 @@ void launch_gemm_dwdx(hipStream_t st, const LayerDev& Lw, int nprob, const float
     GDxArgs a; a.nsrc = nsrc; a.out = out_x; a.ysrc = ysrc; a.ldy = ldy; a.act_src = act_src;
     for (int i = 0; i < 2; i++) { const int j = i < nsrc ? i : 0; a.src[i].W = W[j]; a.src[i].dpre = dpre_x[j]; }
     const int gx = dense ? ((Lx.K + 31) / 32) * Sx : (Lx.cin / 32) * Lx.ih * Lx.iw;
-    const bool pj = dx_parallel_join(Lx, nsrc, Sx);
+    const int pj = dx_mode(Lx, nsrc, Sx, B);
     const size_t lds_w = (size_t)(2 * 64 * W_ST + 2 * 16 * NT * W_ST) * 4, lds_x = dx_lds_bytes(pj);
     const size_t lds = lds_w > lds_x ? lds_w : lds_x;
-    const int grid = dw_blocks + gx * (B / 32) + (int)gemm_tail_blocks(tail);
-    if (NT == 4) hipLaunchKernelGGL((k_dwdx_lds<4>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, pj ? 1 : 0, tail);
-    else if (NT == 2) hipLaunchKernelGGL((k_dwdx_lds<2>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, pj ? 1 : 0, tail);
-    else hipLaunchKernelGGL((k_dwdx_lds<1>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, pj ? 1 : 0, tail);
+    const int grid = dw_blocks + gx * (B / dx_cols(pj)) + (int)gemm_tail_blocks(tail);
+    if (NT == 4) hipLaunchKernelGGL((k_dwdx_lds<4>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, pj, tail);
+    else if (NT == 2) hipLaunchKernelGGL((k_dwdx_lds<2>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, pj, tail);
+    else hipLaunchKernelGGL((k_dwdx_lds<1>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, pj, tail);
 }

@@ -28,6 +28,16 @@ def small_conv_plain():
     return O.Network((3, 12, 14), _small_conv_layers())
 
 
+def mid_conv_plain():
+    """32-channel convolutions and a 64-wide dense layer: large enough for every LDS-tiled kernel (cin % 32 == 0, N % 32 == 0), small enough for the twin."""
+    return O.Network((4, 20, 20), [O.Conv(4, 4, 32, R, 2), O.Conv(3, 32, 32, R, 1), O.Dense(32 * 7 * 7, 64, R), O.Dense(64, 5, I)])
+
+
+def mid_conv_dueling():
+    b, v, a = O.create_dueling_network([O.Conv(4, 4, 32, R, 2), O.Conv(3, 32, 32, R, 1), O.Dense(32 * 7 * 7, 64, R), O.Dense(64, 5, I)])
+    return O.Network((4, 20, 20), b, v, a)
+
+
 def nature_dueling():
     nat = [O.Conv(8, 4, 32, R, 4), O.Conv(4, 32, 64, R, 2), O.Conv(3, 64, 64, R, 1),
            O.Dense(3136, 512, R), O.Dense(512, 4, I)]

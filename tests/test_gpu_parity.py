@@ -10,7 +10,7 @@ import pytest
 import __graft_entry__ as ge
 import dqn_oracle as O
 import ref
-from nets import GOLDEN_CASES, cfg1_mlp_dueling, nature_dueling, small_conv_dueling, small_conv_plain
+from nets import GOLDEN_CASES, cfg1_mlp_dueling, mid_conv_dueling, mid_conv_plain, nature_dueling, small_conv_dueling, small_conv_plain
 from nets import testmdp_mlp_tanh as mlp_tanh_net
 from parity_common import hand_derived_known_answer, sampler_distribution
 from test_twin_vs_oracle import check_priorities_after_step, run_case
@@ -259,6 +259,21 @@ def test_large_batch_paths_bit_exact(pkg, u8):
     set_same_params((gpu, cpu), net)
     for _ in range(4):
         assert_step_bit_exact(gpu, cpu)
+    np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+    np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
+
+
+@pytest.mark.parametrize("netf,B", [(mid_conv_plain, 128), (mid_conv_plain, 256), (mid_conv_dueling, 128), (mid_conv_plain, 96)])
+def test_wide_sample_dx_tiles_bit_exact(pkg, netf, B):
+    """B % 128 == 0 switches the LDS-tiled dX kernels to 32-feature x 128-sample workgroup tiles (dx_lds_body_wide: conv and dense, one or two
+    sources); B = 96 keeps the 32 x 32 tiles on the same network.  Another tiling of the same per-element chains: bit-identical to the twin."""
+    net = netf()
+    gpu, cpu, _ = make_pair(pkg, net, B, cap=1024, learning_rate=1e-3, gamma=0.99)
+    fill((gpu, cpu), net, 700, seed=11)
+    set_same_params((gpu, cpu), net, seed=12)
+    for _ in range(3):
+        assert_step_bit_exact(gpu, cpu)
+    np.testing.assert_array_equal(gpu.get_grads(), cpu.get_grads())
     np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
     np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
 

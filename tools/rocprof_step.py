@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""Print the dispatch sequence of ONE train step (between two consecutive k_sample launches) from a rocpd database."""
+"""Print the dispatch sequence of ONE train step from a rocpd database: everything after one Adam launch up to and including the next one (the
+steady-state step of dqn_train_steps has no gather launch of its own -- its batch was gathered by the previous step's k_adam_pg)."""
 import sqlite3
 import sys
 
 c = sqlite3.connect(sys.argv[1])
 rows = c.execute("select name, start, end, grid_x, workgroup_x, lds_size, vgpr_count from kernels order by start").fetchall()
-idxs = [i for i, r in enumerate(rows) if r[0].startswith("k_gather_fb")]
-a, b = idxs[-3], idxs[-2]
+idxs = [i for i, r in enumerate(rows) if r[0].startswith("k_adam")]
+a, b = idxs[-3] + 1, idxs[-2] + 1
 t0 = rows[a][1]
 print(f"{'t_us':>9s} {'dur_us':>8s} {'grid':>8s} {'wg':>4s} {'lds':>6s} {'vgpr':>4s}  kernel")
 for r in rows[a:b]:
