@@ -418,11 +418,14 @@ template <int NT, bool XU8 = false>
 __global__ __launch_bounds__(256) void k_dw_lds(LayerDev L, GDwProbs pr, int nprob, int ldx, int B, int S, int kc, DwStride ds, GemmTail tail) {
     // dispatch order: [priority block][tail: VALU tasks, Adam job][dW workgroups] -- the bandwidth-bound tail starts at once and the short dW
     // workgroups fill the slots beside it (at the END of the grid the tail would wait for LDS: every workgroup of a launch reserves the tile size)
+    KTRACE_BEGIN()      // record: {grid, block, entry, role (0 prio, 2 tail, 3 dW), -, -, -, exit}
     const int pre_ = (tail.has_adam && tail.adam.prio.n > 0) ? 1 : 0;
-    if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; prio_block_run(tail.adam.prio, tail.adam.state, reinterpret_cast<long long*>(lds)); return; }
+    if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; prio_block_run(tail.adam.prio, tail.adam.state, reinterpret_cast<long long*>(lds)); if (trs_) tr_[trs_ + 3] = 0; KTRACE(7); return; }
     const int bid = (int)blockIdx.x - pre_, ntail = (int)gemm_tail_blocks(tail) - pre_;
-    if (bid < ntail) { gemm_tail_run(tail, (unsigned)bid); return; }
+    if (bid < ntail) { gemm_tail_run(tail, (unsigned)bid); if (trs_) tr_[trs_ + 3] = 2; KTRACE(7); return; }
     dw_lds_body<NT, XU8>(L, pr, nprob, ldx, B, S, kc, bid - ntail, (int)gridDim.x - pre_ - ntail, ds);
+    if (trs_) tr_[trs_ + 3] = 3;
+    KTRACE(7);
 }
 bool gemm_dw_eligible(const LayerDev& L, int B, int ldx) {
     const int KK = L.npos * B, S = dqn_nchunks(KK, L.dw_kc), kc = dqn_chunk_len(KK, L.dw_kc);
@@ -806,17 +809,20 @@ __global__ __launch_bounds__(256) void k_dwdx_lds(LayerDev Lw, GDwProbs pr, int 
     // workgroups fill the remaining CUs (dispatch order is blockIdx order); a tail of small VALU tasks comes last
     // dispatch order: [priority block][dX workgroups][tail: VALU tasks, Adam job][dW workgroups]: the long-latency dX chains start first, the
     // bandwidth-bound tail streams beside them, the many short dW workgroups fill the slots as they free up
+    KTRACE_BEGIN()      // record: {grid, block, entry, role (0 prio, 1 dX, 2 tail, 3 dW), -, -, -, exit}  (tools/ktrace_bwd.py)
     const int pre_ = (tail.has_adam && tail.adam.prio.n > 0) ? 1 : 0;
-    if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; prio_block_run(tail.adam.prio, tail.adam.state, reinterpret_cast<long long*>(lds)); return; }
+    if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; prio_block_run(tail.adam.prio, tail.adam.state, reinterpret_cast<long long*>(lds)); if (trs_) tr_[trs_ + 3] = 0; KTRACE(7); return; }
     const int bid = (int)blockIdx.x - pre_, ntail = (int)gemm_tail_blocks(tail) - pre_;
     const int dx_blocks = (int)gridDim.x - pre_ - ntail - dw_blocks;
     if (bid < dx_blocks) {
         if (pj == 1) dx_lds_body_pj(Lx, A, B, bid % dx_gx, dx_gx, bid / dx_gx);
         else if (pj == 2) dx_lds_body_wide(Lx, A, B, Sx, kcx, bid % dx_gx, dx_gx, bid / dx_gx);
         else dx_lds_body(Lx, A, B, Sx, kcx, bid % dx_gx, dx_gx, bid / dx_gx);
+        if (trs_) tr_[trs_ + 3] = 1;
     }
-    else if (bid < dx_blocks + ntail) gemm_tail_run(tail, (unsigned)(bid - dx_blocks));
-    else dw_lds_body<NT>(Lw, pr, nprob, ldx, B, Sw, kcw, bid - dx_blocks - ntail, dw_blocks, DwStride{Lw.npos * B, 0, 0});
+    else if (bid < dx_blocks + ntail) { gemm_tail_run(tail, (unsigned)(bid - dx_blocks)); if (trs_) tr_[trs_ + 3] = 2; }
+    else { dw_lds_body<NT>(Lw, pr, nprob, ldx, B, Sw, kcw, bid - dx_blocks - ntail, dw_blocks, DwStride{Lw.npos * B, 0, 0}); if (trs_) tr_[trs_ + 3] = 3; }
+    KTRACE(7);
 }
 bool gemm_dx_eligible(const LayerDev& L, int B, int ldy) {
     const bool dense = L.kind == DQN_LAYER_DENSE;
