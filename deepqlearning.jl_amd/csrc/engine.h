@@ -70,6 +70,8 @@ struct dqn_engine {
     std::vector<Step> prog; size_t prog_post_begin = 0; bool prog_built = false, step_sampled = true, prio_forked = false;
     // pre-gather (common.h PreGather), only between the steps of one dqn_train_steps(n) call: step_pregather = this step's Adam launch gathers
     // the next batch; step_take_pre = this step runs without its gather launch
+    int gmax_used = 0;                    // live slots of gmax_part (per-block max |g| of the step's Adam jobs): what the on-demand fold reads
+    StepState* state_host = nullptr;      // pinned landing buffer of fetch_scalars
     bool pg_ok = false, step_pregather = false, step_take_pre = false; PreGather pg; long adam_step = -1;
     hipGraphExec_t g_pgv[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [take_pre][pregather] variants of the sampled single-device step
     AdamSegs adam_segs; long final_reduce_step = -1;   // deferred dW slabs: reduced inside k_adam unless a communicator needs the materialised gradient

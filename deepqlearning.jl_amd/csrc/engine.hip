@@ -251,6 +251,7 @@ extern "C" int dqn_engine_destroy(dqn_engine_t* e) {
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     hipFree(e->L_dev); hipFree(e->p_on); hipFree(e->p_tg); hipFree(e->grad); hipFree(e->m); hipFree(e->v); hipFree(e->io_tmp); hipFree(e->state);
     hipFree(e->s_rows); hipFree(e->sp_rows); hipFree(e->ra); hipFree(e->rr); hipFree(e->rdone); hipFree(e->tree);
+    if (e->state_host) hipHostFree(e->state_host);
     hipFree(e->st_a); hipFree(e->st_r); hipFree(e->st_done); hipFree(e->st_td); hipFree(e->idx); hipFree(e->idx_pre); hipFree(e->x0);
     for (int i = 0; i < e->nl; i++) { hipFree(e->act_on[i]); hipFree(e->act_tg[i]); hipFree(e->dact[i]); }
     hipFree(e->join_tmp); hipFree(e->partials); hipFree(e->gmax_part); hipFree(e->w_is); hipFree(e->td); hipFree(e->q_on_s); hipFree(e->q_on_sp); hipFree(e->q_tg_sp);
@@ -554,8 +555,11 @@ int run_step(dqn_engine* e, bool sample, bool take_pre, bool pregather) {
 }
 int fetch_scalars(dqn_engine* e, float* loss, float* gn) {
     // globalnorm (helpers.jl:38-46): fold the Adam kernel's per-block maxima only when the host asks for the scalar
-    if (gn) launch_update_priorities(e->stream, 0, e->cap2, e->idx, e->td, e->hp.prio_eps, e->hp.prio_alpha, e->tree, e->state, 1, 1.0, 1.0, e->gmax_part, gmax_slots(e->Pint));
-    StepState s; HIPCHK(hipMemcpyAsync(&s, e->state, sizeof s, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream));
+    if (gn) launch_update_priorities(e->stream, 0, e->cap2, e->idx, e->td, e->hp.prio_eps, e->hp.prio_alpha, e->tree, e->state, 1, 1.0, 1.0, e->gmax_part, (e->gmax_used > 0 && e->gmax_used <= gmax_slots(e->Pint)) ? e->gmax_used : gmax_slots(e->Pint));
+    // pinned landing buffer: a device -> pageable copy is staged and costs ~100 us per call (seen as a fixed cost of every dqn_train_steps)
+    if (!e->state_host) HIPCHK(hipHostMalloc((void**)&e->state_host, sizeof(StepState), hipHostMallocDefault));
+    HIPCHK(hipMemcpyAsync(e->state_host, e->state, sizeof(StepState), hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream));
+    const StepState s = *e->state_host;
     if (s.err == 2) return fail("AssertionError: all(new_priorities .> 0f0)");
     if (loss) *loss = s.loss;
     if (gn) { float g; memcpy(&g, &s.gnorm_bits, 4); *gn = g; }

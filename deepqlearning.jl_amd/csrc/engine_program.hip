@@ -555,6 +555,7 @@ int build_program(dqn_engine* e) {
         bool first = true;
         do { AdamJob J = make_job(~0ull, first); if (first && prio_in_adam && !prio_placed) { J.prio = prio_args(); prio_placed = true; } jobs.push_back(J); first = false; } while (!adam_pending.empty());
         e->prog.push_back({"adam_rest", [=](dqn_engine* en) { for (const AdamJob& J : jobs) launch_adam(en->stream, J); }});
+        e->gmax_used = gmax_next;
     } else {
         AdamJob J = base_job();
         J.nr = 1; J.beg[0] = 0; J.end[0] = e->Pint; J.sblocks = (unsigned)adam_blocks(e->Pint); J.tick = 1; J.slot0 = 0;
@@ -570,6 +571,7 @@ int build_program(dqn_engine* e) {
         const bool fold = e->adam_segs.n > 0 && !e->comm && !e->sim_world;     // with a communicator the gradient must be materialised before the all-reduce
         if (e->dp_gather && e->dp_adam_folds) J.segs = e->dp_adam_segs; else if (fold) J.segs = e->adam_segs;
         e->prog.push_back({"adam", [=](dqn_engine* en) { launch_adam(en->stream, J, en->step_pregather ? &en->pg : nullptr); }});
+        e->gmax_used = (int)(J.segs.blocks + J.sblocks);
     }
     e->prog_built = true;
     return 0;

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(1024) void k_update_priorities(int n, long long cap
 void launch_update_priorities(hipStream_t st, int n, long long cap2, const long long* idx, const float* td, float eps, float alpha,
                               float* tree, StepState* state, int tick_adam, double beta1, double beta2, const float* gmax_part, int n_gmax) {
     int bs = ((n + 63) / 64) * 64; if (bs < 64) bs = 64;
-    if (tick_adam && bs < 256) bs = 256;
+    if (tick_adam && bs < 1024) bs = 1024;      // the fold: one load per lane for the ~2100 live slots of config 2
     hipLaunchKernelGGL(k_update_priorities, dim3(1), dim3(bs), 0, st, n, cap2, idx, td, eps, alpha, tree, state, tick_adam, beta1, beta2, gmax_part, n_gmax);
 }
 
