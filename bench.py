@@ -180,18 +180,6 @@ def main():
         torch.cuda.synchronize()
         eng.sync()
 
-    eng.train_steps(max(1, args.warmup))
-    barrier()
-    t0 = time.perf_counter()
-    loss, gnorm = eng.train_steps(args.steps)       # K graph replays back to back; one host sync at the end
-    eng.sync()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    elapsed = group.max_over_ranks(t1 - t0)
-    group.barrier()
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * args.steps / elapsed            # whole-job train steps/s (each rank runs its own B=32 step)
-
     # ---- secondary: the device-resident env loop of config 3 (envs_per_rank copies of the image MDP per rank, eps-greedy + add_exp! in HBM)
     env_loop = None
     if args.env_steps > 0:
@@ -221,7 +209,28 @@ def main():
             a = prof_acc.setdefault(name, [0.0, 0])
             a[0] += ms
             a[1] += 1
+    # the gather launch of a SINGLE dqn_train_step (inside dqn_train_steps the previous step's Adam launch carries it: "adam+gather" above)
+    single_gather = {}
+    for _ in range(min(5, args.profile_steps)):
+        for name, ms in eng.profile_step():
+            if name in ("gather", "sample_gather"):
+                a = single_gather.setdefault(name, [0.0, 0]); a[0] += ms; a[1] += 1
     group.barrier()
+
+    # ---- the headline: W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize.  It runs AFTER the secondary sections
+    # above (real train steps and env steps, all untimed): the GPU needs ~10 ms of activity to reach its clocks, and with --steps 20 --warmup 5
+    # the timed region is 3 ms -- measured straight after the idle build phase it read 160 us/step instead of 152 (tools/first_call.py).
+    eng.train_steps(max(3, args.warmup))      # >= 3 so that the three step graphs of dqn_train_steps (first / middle / last) are all captured untimed
+    barrier()
+    t0 = time.perf_counter()
+    loss, gnorm = eng.train_steps(args.steps)       # K graph replays back to back; one host sync at the end
+    eng.sync()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = group.max_over_ranks(t1 - t0)
+    group.barrier()
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.steps / elapsed            # whole-job train steps/s (each rank runs its own B=32 step)
 
     out = None
     if rank == 0:
@@ -279,11 +288,14 @@ def main():
             roof["gemm_launches_frac"] = round(sum(r["mflop"] for r in gemm) * 1e6 / (sum(r["avg_us"] for r in gemm) * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
             dom = max(gemm, key=lambda r: r["avg_us"])
             roof["dominant_kernel"] = dict(dom)          # the longest GEMM launch, per-launch roofline: algorithmic FLOP / HIP-event duration
-        gname = "sample_gather" if "sample_gather" in kern else ("gather" if "gather" in kern else None)
+        gk = dict(kern); gk.update({k: v[0] / v[1] for k, v in single_gather.items()})
+        gname = "sample_gather" if "sample_gather" in gk else ("gather" if "gather" in gk else None)
         if gname:
             gbytes = op_cost(gname, g2, B, ncon, E, P, obs_b)[1]
-            roof["gather"] = {"avg_launch_ms": kern[gname], "algorithmic_bytes": gbytes, "achieved_GBs": gbytes / (kern[gname] * 1e-3) / 1e9,
-                              "frac_of_hbm_peak": gbytes / (kern[gname] * 1e-3) / 1e9 / PEAK_HBM_GBS}
+            roof["gather"] = {"avg_launch_ms": gk[gname], "algorithmic_bytes": gbytes, "achieved_GBs": gbytes / (gk[gname] * 1e-3) / 1e9,
+                              "frac_of_hbm_peak": gbytes / (gk[gname] * 1e-3) / 1e9 / PEAK_HBM_GBS}
+            if gname not in kern:
+                roof["gather"]["note"] = "launch of a single dqn_train_step; in the timed dqn_train_steps(K) loop the batch is gathered by the previous step's Adam launch (adam+gather)"
             roof["gather"].update(pmc_traffic(gname))
         adam_rows = [r for r in table if r["launch"].startswith("adam") and "traffic" in r]
         if adam_rows:
@@ -378,7 +390,7 @@ def pmc_traffic(op):
     --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this bench, values in KB; gfx950 reports half of wide reads, hence x2 on FETCH_SIZE as the
     MI355X guide prescribes).  bench.py cannot run the profiler itself; the newest committed pass is quoted, or null."""
     import glob
-    kname = {"adam": "k_adam", "sample_gather": "k_gather_fb", "gather": "k_gather_fb"}.get(op)
+    kname = {"adam": "k_adam", "adam+gather": "k_adam_pg", "sample_gather": "k_gather_fb", "gather": "k_gather_fb"}.get(op)
     if kname is None:
         return {}
     def last(pattern):
