@@ -71,6 +71,9 @@ def build_workload(pkg, args, rank, device):
 ADAM_SLAB_BYTES = [0.0]     # the engine's OWN overhead inside k_adam (conv dW split-K slabs it reduces): reported beside, never inside, the 8(d) floor
 
 
+ARENA_ELEM_BYTES = [4]      # set from the engine (dqn_batch_arena_elem_bytes) before the launch table is priced
+
+
 def op_cost(name, eng_layers, B, ncon, E, P, obs_bytes=4):
     """algorithmic (flops, bytes) of one profiled launch by its program name; names joined by '+' are one launch doing both.
     fwd_<l>      forward of layer l AND its sibling (val/adv) for the online net on [s;sp] and the target net on sp
@@ -81,7 +84,7 @@ def op_cost(name, eng_layers, B, ncon, E, P, obs_bytes=4):
         return sum(p[0] for p in parts), sum(p[1] for p in parts)
     parts = name.split("_")
     if name in ("gather", "sample_gather"):
-        return 0.0, 2.0 * B * E * (obs_bytes + 4)   # rows read (u8 or f32) + fp32 batch arena written
+        return 0.0, 2.0 * B * E * (obs_bytes + ARENA_ELEM_BYTES[0])   # rows read (u8 or f32) + batch arena written (fp32, or bytes for u8 replays)
     if name.startswith("adam"):
         return 0.0, P * 28.0
     digits = "".join(ch for ch in parts[-1] if ch.isdigit())
@@ -258,6 +261,8 @@ def main():
                 if S > 1:
                     ADAM_SLAB_BYTES[0] += (S + 1) * (K + 1) * N * 4.0
         kern = {k: v[0] / v[1] for k, v in prof_acc.items()}
+        ARENA_ELEM_BYTES[0] = eng.batch_arena_elem_bytes()
+        PMC_OK[0] = args.batch == 32 and not args.u8      # the committed PMC passes are runs of the config-2 bench
         obs_b = 1 if args.u8 else 4
         step_flops = step_flops_analytic(g2, B, ncon)
         # ---- headline: the train step is a dense contraction => bound by the fp32 MFMA peak;
@@ -385,11 +390,16 @@ def cpu_baseline(pkg, layers, hp, params, env, args):
 
 
 
+PMC_OK = [True]
+
+
 def pmc_traffic(op):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_fetch.txt / *_pmc_write.txt: separate
     --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this bench, values in KB; gfx950 reports half of wide reads, hence x2 on FETCH_SIZE as the
     MI355X guide prescribes).  bench.py cannot run the profiler itself; the newest committed pass is quoted, or null."""
     import glob
+    if not PMC_OK[0]:
+        return {}
     kname = {"adam": "k_adam", "adam+gather": "k_adam_pg", "sample_gather": "k_gather_fb", "gather": "k_gather_fb"}.get(op)
     if kname is None:
         return {}

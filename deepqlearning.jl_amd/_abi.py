@@ -104,6 +104,7 @@ PROTOS = {
     "engine_destroy": [_vp],
     "engine_get_plan": [_vp, _P(LayerPlan)],
     "n_params": [_vp, _P(_sz)],
+    "batch_arena_elem_bytes": [_vp, _P(C.c_int)],
     "set_params": [_vp, C.c_int, _f32p, _sz],
     "get_params": [_vp, C.c_int, _f32p, _sz],
     "sync_target": [_vp],
@@ -233,6 +234,11 @@ class Handle:
         p = (LayerPlan * self.n_layers)()
         self._check(self.f["engine_get_plan"](self._h, p))
         return [x.astuple() for x in p]
+
+    def batch_arena_elem_bytes(self):
+        n = C.c_int()
+        self._check(self.f["batch_arena_elem_bytes"](self._h, C.byref(n)))
+        return n.value
 
     def set_params(self, flat, which=NET_ONLINE):
         flat = _as(flat, np.float32).reshape(-1)

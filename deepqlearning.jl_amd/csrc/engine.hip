@@ -289,6 +289,10 @@ static int get_vec(dqn_engine* e, const float* dev, float* host) {
     HIPCHK(hipMemcpyAsync(host, e->io_tmp, e->P * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream)); return 0;
 }
+extern "C" int dqn_batch_arena_elem_bytes(dqn_engine_t* e, int* bytes) { if (!e) return fail("null engine handle");
+    if (build_program(e)) return -1;
+    *bytes = e->arena_u8 ? 1 : 4; return 0;
+}
 extern "C" int dqn_set_params(dqn_engine_t* e, int which, const float* flat, size_t n) { if (!e) return fail("null engine handle");
     if (n != e->P) return fail("set_params: got %zu values, the network has %zu parameters", n, e->P);
     return put_vec(e, flat, which == DQN_NET_TARGET ? e->p_tg : e->p_on);

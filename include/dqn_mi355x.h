@@ -113,6 +113,9 @@ int dqn_engine_create(const dqn_layer_desc* layers, int n_layers, const dqn_hpar
 int dqn_engine_destroy(dqn_engine_t* e);
 int dqn_engine_get_plan(dqn_engine_t* e, dqn_layer_plan* plan_out /* n_layers entries */);
 int dqn_n_params(dqn_engine_t* e, size_t* n);
+/* bytes per element of the batch arena the train step gathers into: 4 (fp32 X0[f][2B]) or 1 (byte arena: u8 replay whose first layer converts
+ * byte/255 inside its tile loads).  Decided when the step program is built (first train call); measurement tools price the gather with it. */
+int dqn_batch_arena_elem_bytes(dqn_engine_t* e, int* bytes);
 
 /* Flux.params(active_q) / Flux.loadparams! (src/solver.jl:143-144, :292, :314-315). */
 int dqn_set_params(dqn_engine_t* e, int which, const float* flat, size_t n);
