@@ -11,7 +11,7 @@ import bench  # noqa: E402
 import __graft_entry__ as ge  # noqa: E402
 import importlib
 import argparse
-args = argparse.Namespace(batch=32, u8=False, replay=2000, no_graph=True, no_mfma=False, conv_kc=0, fc_kc=0, envs_per_rank=32, device_fill=False)
+args = argparse.Namespace(batch=int(os.environ.get("KT_BATCH", "32")), u8=False, replay=2000, no_graph=True, no_mfma=False, conv_kc=0, fc_kc=0, envs_per_rank=32, device_fill=False)
 pkg = ge.load_package()
 pkg.nn = importlib.import_module(pkg.__name__ + ".nn"); pkg.envs = importlib.import_module(pkg.__name__ + ".envs")
 eng, *_ = bench.build_workload(pkg, args, 0, 0)
