@@ -153,7 +153,9 @@ int dqn_update_priorities(dqn_engine_t* e, const int64_t* idx, const float* td, 
  * enqueues work on the engine's stream (no host sync). */
 int dqn_train_step(dqn_engine_t* e, const int64_t* idx_or_null, float* loss, float* grad_norm,
                    float* td_out /* B */);
-/* run `n_steps` sampled train steps back to back; returns the last step's scalars. */
+/* run `n_steps` sampled train steps back to back; returns the last step's scalars.  Bit-identical to n_steps calls of dqn_train_step(e, NULL, ...)
+ * (tests/test_gpu_parity.py::test_train_steps_pipelined_gather_bit_exact), but inside the call nothing else can touch the replay, so step i's last
+ * launch already gathers step i+1's batch and steps 2..n run without a gather launch (f32 observations, B <= 64, prioritized replay). */
 int dqn_train_steps(dqn_engine_t* e, int n_steps, float* loss, float* grad_norm);
 
 /* Results of the last train step (parity checks; not on the hot path). */
