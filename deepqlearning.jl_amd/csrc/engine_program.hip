@@ -40,6 +40,7 @@ const char* pname(dqn_engine* e, const char* op, int kind, int i) {
 int build_program(dqn_engine* e) {
     if (e->prog_built) return 0;
     HIPCHK(hipSetDevice(e->device));
+    e->pg_ok = false; e->adam_step = -1; e->gmax_used = 0;
     HIPCHK(hipMemsetAsync(e->gmax_part, 0, (size_t)gmax_slots(e->Pint) * 4, e->stream));      // per-block maxima of an earlier program shape must not survive
     e->prog_names.reserve(512);
     const int B = e->Bc /* columns of one sequence set: batch_size, or T*batch_size for DRQN */, ncon = e->ncon, ld0 = 2 * B, Bb = e->B, T = e->T;
