@@ -74,6 +74,7 @@ struct dqn_engine {
     StepState* state_host = nullptr;      // pinned landing buffer of fetch_scalars
     bool pg_ok = false, step_pregather = false, step_take_pre = false; PreGather pg; long adam_step = -1;
     hipGraphExec_t g_pgv[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [take_pre][pregather] variants of the sampled single-device step
+    hipGraphExec_t g_pre_tp = nullptr, g_post_pg = nullptr;                      // replicas: first half without the gather launch / second half whose Adam launch gathers
     AdamSegs adam_segs; long final_reduce_step = -1;   // deferred dW slabs: reduced inside k_adam unless a communicator needs the materialised gradient
     std::vector<void*> prog_allocs; std::vector<std::string> prog_names;
     // profiling

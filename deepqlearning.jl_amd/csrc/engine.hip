@@ -230,6 +230,8 @@ void drop_graphs(dqn_engine* e) {
         for (int j = 0; j < 2; j++) if (e->g_pgv[i][j]) { hipGraphExecDestroy(e->g_pgv[i][j]); e->g_pgv[i][j] = nullptr; }
     }
     if (e->g_post) { hipGraphExecDestroy(e->g_post); e->g_post = nullptr; }
+    if (e->g_post_pg) { hipGraphExecDestroy(e->g_post_pg); e->g_post_pg = nullptr; }
+    if (e->g_pre_tp) { hipGraphExecDestroy(e->g_pre_tp); e->g_pre_tp = nullptr; }
     for (dqn_engine::ActProg* a : {&e->act, &e->evalp}) if (a->graph) { hipGraphExecDestroy(a->graph); a->graph = nullptr; }
 }
 void drop_act(dqn_engine* e, dqn_engine::ActProg& a) {
@@ -542,14 +544,24 @@ int run_step(dqn_engine* e, bool sample, bool take_pre, bool pregather) {
         return rc;
     }
     if (e->world > 1 || (e->comm && e->force_comm)) {      // data-parallel replicas (also DQN_SIM_WORLD: world = k without a communicator)
+        // the pre-gather is rank-local (own replay, own arena), so it works on replicas too: first half without the gather launch, the Adam
+        // launch of the second half gathers the next batch.  Every rank takes the same variant (same configuration, same call).
+        const bool tp = sample && e->pg_ok && take_pre, pgth = sample && e->pg_ok && pregather;
+        e->step_take_pre = tp; e->step_pregather = pgth;
+        int rc = 0;
         if (e->hp.use_graph && !e->profiling) {
-            if (!e->g_pre[gi] && capture(e, sample, PH_PRE, &e->g_pre[gi])) return -1;
-            if (!e->g_post && capture(e, sample, PH_POST, &e->g_post)) return -1;
-            HIPCHK(hipGraphLaunch(e->g_pre[gi], e->stream));
-            if (exchange_grads(e)) return -1;
-            HIPCHK(hipGraphLaunch(e->g_post, e->stream));
-        } else { enqueue_step(e, sample, PH_PRE); HIPCHK(hipGetLastError()); if (exchange_grads(e)) return -1; enqueue_step(e, sample, PH_POST); HIPCHK(hipGetLastError()); }
-        return 0;
+            hipGraphExec_t& gpre = tp ? e->g_pre_tp : e->g_pre[gi];
+            hipGraphExec_t& gpost = pgth ? e->g_post_pg : e->g_post;
+            if (!gpre && capture(e, sample, PH_PRE, &gpre)) rc = -1;
+            if (!rc && !gpost && capture(e, sample, PH_POST, &gpost)) rc = -1;
+            if (!rc) {
+                HIPCHK(hipGraphLaunch(gpre, e->stream));
+                if (exchange_grads(e)) rc = -1;
+                else HIPCHK(hipGraphLaunch(gpost, e->stream));
+            }
+        } else { enqueue_step(e, sample, PH_PRE); HIPCHK(hipGetLastError()); if (exchange_grads(e)) rc = -1; else { enqueue_step(e, sample, PH_POST); HIPCHK(hipGetLastError()); } }
+        e->step_take_pre = e->step_pregather = false;
+        return rc;
     }
     if (e->hp.use_graph && !e->profiling) {
         if (!e->g_full[gi] && capture(e, sample, PH_ALL, &e->g_full[gi])) return -1;
@@ -565,6 +577,7 @@ int fetch_scalars(dqn_engine* e, float* loss, float* gn) {
     HIPCHK(hipMemcpyAsync(e->state_host, e->state, sizeof(StepState), hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream));
     const StepState s = *e->state_host;
     if (s.err == 2) return fail("AssertionError: all(new_priorities .> 0f0)");
+    if (s.err == 3) return fail("internal error: a pre-gathered batch was consumed after the replay changed (StepState::pre_valid != 2)");
     if (loss) *loss = s.loss;
     if (gn) { float g; memcpy(&g, &s.gnorm_bits, 4); *gn = g; }
     return 0;

@@ -276,7 +276,7 @@ int build_program(dqn_engine* e) {
     const bool prio_in_adam = e->hp.prioritized_replay && !rec && Bb <= 64;      // larger batches: side stream (prio_fork)
     // pre-gather (common.h PreGather): needs the priority block (which also draws the next indices) OUT of the Adam launch -- it rides as
     // workgroup 0 of the first LDS-tiled backward launch instead
-    const bool pg_want = prio_in_adam && !early && !e->comm && !e->sim_world && fuse_heads && e->hp.obs_dtype != DQN_OBS_U8 && !e->arena_u8 && !getenv("DQN_NO_PREGATHER");
+    const bool pg_want = prio_in_adam && !early && !e->sim_world && fuse_heads && e->hp.obs_dtype != DQN_OBS_U8 && !e->arena_u8 && !getenv("DQN_NO_PREGATHER");
     // layer l's gradient is final: queue its parameter range (split-K layers: as a slab segment)
     auto adam_queue = [&](int l, const std::vector<RSeg>& segs_known) {
         const LayerDev& L = e->L[l]; PItem it; it.beg = L.w_off; it.end = l + 1 < e->nl ? e->L[l + 1].w_off : e->Pint; it.part = nullptr; it.S = 0;

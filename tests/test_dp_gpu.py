@@ -174,6 +174,42 @@ def test_rccl_allgather_world1_matches_plain(pkg, monkeypatch):
     np.testing.assert_array_equal(a.get_grads(), b.get_grads())
 
 
+def test_rccl_world1_train_steps_pipelined_gather(pkg, monkeypatch):
+    """dqn_train_steps(n) on the replica path (real RCCL communicator at world size 1, step cut in two around ncclAllGather): the second half's
+    Adam launch gathers the next batch, the next first half runs without its gather launch -- rank-local work, so it must equal the twin stepped
+    one call at a time, with replay writes and single steps in between."""
+    monkeypatch.setenv("DQN_FORCE_ALLREDUCE", "1")
+    net = wide_dense_dueling()
+    g, t, _ = setup(pkg, net, 32, 32, seed=2)
+    g.comm_init(pkg.comm_unique_id(), 0, 1)
+
+    def same():
+        np.testing.assert_array_equal(g.last_indices(), t.last_indices())
+        np.testing.assert_array_equal(g.get_params(0), t.get_params(0))
+        np.testing.assert_array_equal(g.replay_priorities(), t.replay_priorities())
+
+    lg = g.train_steps(5)
+    for _ in range(5):
+        lt = t.train_step()
+    assert lg[0] == lt[0] and lg[1] == lt[1]
+    same()
+    rg, rt = g.train_step(), t.train_step()
+    assert rg[0] == rt[0]; np.testing.assert_array_equal(rg[2], rt[2])
+    rng = np.random.default_rng(9)
+    s = rng.random((7,) + net.obs_shape, dtype=np.float32); sp = rng.random((7,) + net.obs_shape, dtype=np.float32)
+    for h in (g, t):
+        h.replay_add(s, np.arange(7, dtype=np.int32) % net.n_actions, np.ones(7, np.float32), sp, np.zeros(7, np.uint8))
+    lg = g.train_steps(3)
+    for _ in range(3):
+        lt = t.train_step()
+    assert lg[0] == lt[0] and lg[1] == lt[1]
+    same()
+    names = [n for n, _ in g.profile_step(steady=True)]
+    t.train_step(); t.train_step()
+    same()
+    assert "adam+gather" in names and "sample_gather" not in names and "dp_pack" in names, names
+
+
 def test_simulated_ranks_with_two_tiles_per_rank(pkg, monkeypatch):
     """B = 64 per rank: each rank block of the gathered sample axis spans two 32-sample K tiles (the dW kernel's tiles-per-rank stride path);
     the wide layer here is the network's FIRST layer, so its X operand is packed out of the observation arena (leading dimension 2B)."""
