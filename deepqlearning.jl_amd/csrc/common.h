@@ -303,9 +303,9 @@ struct BatchMeta { const int* a; const float* r; const unsigned char* done; floa
 // step follows and that nothing touches the replay in between).  By then every reader of the arena, of the batch scalars and of the index list
 // in this step is done, the tree is final (the priority block ran in an earlier backward launch and drew idx_pre), and the Philox counter of
 // the next sample() was set by k_head_td.  The next step then runs WITHOUT its gather launch; its k_head_td copies idx_pre -> idx and checks
-// StepState::pre_valid == 2.  f32 observations, B <= 64.
+// StepState::pre_valid == 2.  f32 observations, or u8 observations on the byte arena.
 struct PreGather { int on; const void *s_rows, *sp_rows; int E, B; long long* idx_pre; float* x0; long long cap2; const float* tree; unsigned long long seed;
-                   BatchMeta meta; int gx, gy; };
+                   BatchMeta meta; int gx, gy; int u8b; /* u8 rows into the BYTE arena (gather_u8b_body); else f32 rows into the fp32 arena */ };
 void launch_gather_fb(hipStream_t st, const void* s_rows, const void* sp_rows, int obs_u8, int E, int B,
                       long long* idx, float* x0 /*[E][2B]*/, int do_sample, long long cap2, const float* tree, unsigned long long seed,
                       const StepState* state, const BatchMeta& meta, const long long* idx_pre /* or null */, int arena_u8 = 0 /* x0 is unsigned char[E][2B] */);

@@ -276,7 +276,7 @@ int build_program(dqn_engine* e) {
     const bool prio_in_adam = e->hp.prioritized_replay && !rec && Bb <= 64;      // larger batches: side stream (prio_fork)
     // pre-gather (common.h PreGather): needs the priority block (which also draws the next indices) OUT of the Adam launch -- it rides as
     // workgroup 0 of the first LDS-tiled backward launch instead
-    const bool pg_want = prio_in_adam && !early && !e->sim_world && fuse_heads && e->hp.obs_dtype != DQN_OBS_U8 && !e->arena_u8 && !getenv("DQN_NO_PREGATHER");
+    const bool pg_want = prio_in_adam && !early && !e->sim_world && fuse_heads && (e->hp.obs_dtype != DQN_OBS_U8 || e->arena_u8) && !getenv("DQN_NO_PREGATHER");      // u8 rows: only onto the byte arena
     // layer l's gradient is final: queue its parameter range (split-K layers: as a slab segment)
     auto adam_queue = [&](int l, const std::vector<RSeg>& segs_known) {
         const LayerDev& L = e->L[l]; PItem it; it.beg = L.w_off; it.end = l + 1 < e->nl ? e->L[l + 1].w_off : e->Pint; it.part = nullptr; it.S = 0;
@@ -565,7 +565,8 @@ int build_program(dqn_engine* e) {
         if (e->pg_ok) {
             PreGather& G = e->pg; G.on = 1; G.s_rows = e->s_rows; G.sp_rows = e->sp_rows; G.E = e->E; G.B = B; G.idx_pre = e->idx_pre; G.x0 = e->x0; G.cap2 = e->cap2; G.tree = e->tree; G.seed = e->hp.seed;
             G.meta.a = e->ra; G.meta.r = e->rr; G.meta.done = e->rdone; G.meta.beta = e->hp.prio_beta; G.meta.a_out = e->gb_a2; G.meta.r_out = e->gb_r2; G.meta.done_out = e->gb_done2; G.meta.w_out = e->gb_w2;
-            G.gx = (e->E + 63) / 64; G.gy = (2 * B + 63) / 64;
+            G.u8b = e->arena_u8 ? 1 : 0;
+            if (G.u8b) { G.gx = (e->E + 255) / 256; G.gy = (2 * B + 127) / 128; } else { G.gx = (e->E + 63) / 64; G.gy = (2 * B + 63) / 64; }
         }
         e->adam_step = (long)e->prog.size();
         J.gscale = e->world > 1 ? 1.0f / (float)e->world : 1.0f;

@@ -517,9 +517,26 @@ __global__ __launch_bounds__(256) void k_adam_pg(AdamJob J, PreGather G) {
     }
     adam_job_run(J, (int)blockIdx.x - npg, nullptr, wmax);
 }
+// ... and for u8 replays on the byte arena (33 KB tile: a kernel of its own, so that the f32 variant keeps its smaller LDS footprint)
+__global__ __launch_bounds__(256) void k_adam_pg_u8(AdamJob J, PreGather G) {
+    __shared__ uint32_t tile32[128 * 65]; __shared__ long long rows[128]; __shared__ float wmax[4];
+    const int npg = G.gx * G.gy;
+    if ((int)blockIdx.x < npg) {
+        const int bx = (int)blockIdx.x % G.gx, by = (int)blockIdx.x / G.gx;
+        gather_u8b_body((const unsigned char*)G.s_rows, (const unsigned char*)G.sp_rows, G.E, G.B, G.idx_pre, (unsigned char*)G.x0, 1, G.cap2, G.tree, G.seed, J.state, G.meta,
+                        G.idx_pre, bx, by, tile32, rows);
+        if (blockIdx.x == 0 && threadIdx.x == 0 && J.state->pre_valid) J.state->pre_valid = 2;
+        return;
+    }
+    adam_job_run(J, (int)blockIdx.x - npg, nullptr, wmax);
+}
 int adam_blocks(size_t P) { size_t blocks = (P + 255) / 256; if (blocks > 2048) blocks = 2048; return (int)blocks; }
 void launch_adam(hipStream_t st, const AdamJob& job, const PreGather* pg) {
-    if (pg && pg->on && job.prio.n == 0) { hipLaunchKernelGGL(k_adam_pg, dim3(pg->gx * pg->gy + adam_job_blocks(job)), dim3(256), 0, st, job, *pg); return; }
+    if (pg && pg->on && job.prio.n == 0) {
+        if (pg->u8b) hipLaunchKernelGGL(k_adam_pg_u8, dim3(pg->gx * pg->gy + adam_job_blocks(job)), dim3(256), 0, st, job, *pg);
+        else hipLaunchKernelGGL(k_adam_pg, dim3(pg->gx * pg->gy + adam_job_blocks(job)), dim3(256), 0, st, job, *pg);
+        return;
+    }
     if (job.prio.n > 0) hipLaunchKernelGGL(k_adam, dim3(adam_job_blocks(job)), dim3(256), 0, st, job);
     else hipLaunchKernelGGL(k_adam_stream, dim3(adam_job_blocks(job)), dim3(256), 0, st, job);
 }

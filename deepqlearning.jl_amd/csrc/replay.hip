@@ -86,51 +86,9 @@ __global__ __launch_bounds__(256) void k_gather_fb_u8b(const unsigned char* __re
                                                        long long* __restrict__ idx, unsigned char* __restrict__ x0b, int do_sample, long long cap2,
                                                        const float* __restrict__ tree, unsigned long long seed, const StepState* __restrict__ state, BatchMeta meta,
                                                        const long long* __restrict__ idx_pre) {
-    __shared__ uint32_t tile32[128 * 65];             // [column][64 words of 4 features], row pitch 65
+    __shared__ uint32_t tile32[128 * 65];
     __shared__ long long rows[128];
-    const int f0 = blockIdx.x * 256, c0 = blockIdx.y * 128, ld = 2 * B;
-    if (threadIdx.x < 128) {
-        const int c = c0 + threadIdx.x;
-        long long r = 0;
-        if (c < ld) {
-            const int i = c < B ? c : c - B;
-            if (do_sample) {
-                r = (idx_pre && state->pre_valid) ? idx_pre[i] : tree_descend(tree, cap2, state->size, seed, state->sample_ctr, i, tree[1] / (float)B);
-                if (blockIdx.x == 0 && c < B) idx[i] = r;
-            } else r = idx[i];
-        }
-        rows[threadIdx.x] = r;
-    }
-    __syncthreads();
-    // 128 columns x 16 uint4 (256 bytes) = 2048 uint4 per tile, 8 per lane; rows of E bytes are 16-byte aligned when E % 16 == 0, else 4-byte loads
-    const bool a16 = (E & 15) == 0;
-    uint4 v[8];
-#pragma unroll
-    for (int p = 0; p < 8; p++) {
-        const int q = threadIdx.x + 256 * p, cl = q >> 4, c = c0 + cl, f = f0 + 16 * (q & 15);
-        v[p] = make_uint4(0, 0, 0, 0);
-        if (c < ld && f < E) {
-            const unsigned char* src = (c < B ? s_rows : sp_rows) + rows[cl] * E + f;
-            if (a16 && f + 16 <= E) v[p] = *reinterpret_cast<const uint4*>(src);
-            else { uint32_t w[4] = {0, 0, 0, 0}; for (int u = 0; u < 4; u++) if (f + 4 * u < E) w[u] = *reinterpret_cast<const uint32_t*>(src + 4 * u); v[p] = make_uint4(w[0], w[1], w[2], w[3]); }
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < 8; p++) { const int q = threadIdx.x + 256 * p; uint32_t* d = tile32 + (q >> 4) * 65 + 4 * (q & 15); d[0] = v[p].x; d[1] = v[p].y; d[2] = v[p].z; d[3] = v[p].w; }
-    __syncthreads();
-    // 32 lanes x 4 columns = one 128-byte segment of a feature row of the arena; a wave writes 2 feature rows per instruction
-    const int c4 = threadIdx.x & 31, r8 = threadIdx.x >> 5;
-#pragma unroll 4
-    for (int p = 0; p < 32; p++) {
-        const int fl = p * 8 + r8, f = f0 + fl, c = c0 + 4 * c4, sh = 8 * (fl & 3), w = fl >> 2;
-        if (f >= E) continue;
-        uint32_t o = 0;
-#pragma unroll
-        for (int u = 0; u < 4; u++) o |= ((tile32[(4 * c4 + u) * 65 + w] >> sh) & 0xffu) << (8 * u);
-        if (c + 3 < ld) *reinterpret_cast<uint32_t*>(x0b + (size_t)f * ld + c) = o;
-        else for (int u = 0; u < 4; u++) if (c + u < ld) x0b[(size_t)f * ld + c + u] = (unsigned char)(o >> (8 * u));
-    }
-    if (blockIdx.x == 0) { gather_batch_meta(meta, rows, c0, B, cap2, tree, state); gather_batch_meta(meta, rows + 64, c0 + 64, B, cap2, tree, state); }
+    gather_u8b_body(s_rows, sp_rows, E, B, idx, x0b, do_sample, cap2, tree, seed, state, meta, idx_pre, (int)blockIdx.x, (int)blockIdx.y, tile32, rows);
 }
 void launch_gather_fb(hipStream_t st, const void* s_rows, const void* sp_rows, int obs_u8, int E, int B, long long* idx, float* x0, int do_sample,
                       long long cap2, const float* tree, unsigned long long seed, const StepState* state, const BatchMeta& meta, const long long* idx_pre, int arena_u8) {

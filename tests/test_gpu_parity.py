@@ -141,6 +141,7 @@ def test_adam_jobs_carried_by_backward_launches(pkg, monkeypatch, netf, B):
 @pytest.mark.parametrize("graph", [1, 0])
 @pytest.mark.parametrize("netf,B,kw", [
     (nature_dueling, 32, dict()),
+    (nature_dueling, 32, dict(obs_dtype=1)),                              # u8 replay on the byte arena
     (small_conv_dueling, 16, dict()),
     (cfg1_mlp_dueling, 32, dict(gamma=0.95)),
     (small_conv_plain, 8, dict(double_q=0, prioritized_replay=0)),       # not eligible for the pre-gather: must simply still be right
@@ -151,7 +152,8 @@ def test_train_steps_pipelined_gather_bit_exact(pkg, netf, B, kw, graph):
     steps, replay writes and explicit-index steps in between must find nothing stale."""
     net = netf()
     gpu, cpu, hp = make_pair(pkg, net, B, cap=128, graph=graph, learning_rate=1e-3, **kw)
-    fill((gpu, cpu), net, 100, seed=7)
+    u8 = kw.get("obs_dtype", 0) == 1
+    fill((gpu, cpu), net, 100, seed=7, u8=u8)
     set_same_params((gpu, cpu), net, seed=5)
 
     def same_state():
@@ -167,7 +169,7 @@ def test_train_steps_pipelined_gather_bit_exact(pkg, netf, B, kw, graph):
     assert lg[0] == lc[0] and lg[1] == lc[1]
     same_state()
     assert_step_bit_exact(gpu, cpu)                       # a plain step after the pipelined call
-    fill((gpu, cpu), net, 9, seed=8)                      # the replay changes: whatever was drawn ahead is stale
+    fill((gpu, cpu), net, 9, seed=8, u8=u8)               # the replay changes: whatever was drawn ahead is stale
     lg = gpu.train_steps(3)
     for _ in range(3):
         lc = cpu.train_step()
