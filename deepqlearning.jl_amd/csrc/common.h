@@ -253,6 +253,7 @@ struct TdArgs {
     float *d_val, *d_adv;                              // dpre of the last layers, [*][B]
     float *w_is, *td, *q_on_s, *q_on_sp, *q_tg_sp, *ytarget; int* best;
     StepState* st;
+    long long* idx_mut; const long long* idx_pre; int take_pre;      // take_pre: this step's batch was drawn and gathered by the previous step (PreGather)
 };
 
 // ---- fused head kernel (small batches): head forwards of both nets + dueling reduce + argmax + Bellman target + TD + Huber + dL/dQ +
@@ -320,7 +321,8 @@ void launch_batch_meta(hipStream_t st, int B, long long cap2, const long long* i
                        const unsigned char* done, const float* tree, float beta, const StepState* state,
                        int* a_out, float* r_out, float* done_out, float* w_out);
 void launch_update_priorities(hipStream_t st, int n, long long cap2, const long long* idx, const float* td, float eps, float alpha,
-                              float* tree, StepState* state, int tick_adam, double beta1, double beta2, const float* gmax_part, int n_gmax);
+                              float* tree, StepState* state, int tick_adam, double beta1, double beta2, const float* gmax_part, int n_gmax,
+                              long long* idx_pre = nullptr /* also draw the NEXT sample()'s pre_B indices (prio_block_run's second half) */, unsigned long long seed = 0, int pre_B = 0);
 
 void launch_valu_fwd(hipStream_t st, const LayerDev& L, const float* P, const float* X, int ldx, int col0, int ncols, float* Y, float* partials);
 void launch_valu_dw(hipStream_t st, const LayerDev& L, const float* X, int ldx, const float* dpre, int B, float* G, float* partials);

@@ -188,7 +188,7 @@ int build_program(dqn_engine* e) {
         const int lq = e->hp.dueling ? e->last_adv : e->last_base;
         t.on_adv = head[lq][0]; t.tg_adv = head[lq][1]; t.d_adv = e->dact[lq];
         if (e->hp.dueling) { t.on_val = head[e->last_val][0]; t.tg_val = head[e->last_val][1]; t.d_val = e->dact[e->last_val]; }
-        t.w_is = e->w_is; t.td = e->td; t.q_on_s = e->q_on_s; t.q_on_sp = e->q_on_sp; t.q_tg_sp = e->q_tg_sp; t.ytarget = e->ytarget; t.best = e->best; t.st = e->state;
+        t.idx_mut = e->idx; t.idx_pre = e->idx_pre; t.w_is = e->w_is; t.td = e->td; t.q_on_s = e->q_on_s; t.q_on_sp = e->q_on_sp; t.q_tg_sp = e->q_tg_sp; t.ytarget = e->ytarget; t.best = e->best; t.st = e->state;
         if (fuse_heads) {
             HeadTdArgs h; memset(&h, 0, sizeof h);
             h.B = B; h.nA = e->nA; h.dueling = e->hp.dueling; h.double_q = e->hp.double_q; h.gamma = e->hp.gamma; h.prio_beta = e->hp.prio_beta; h.cap2 = e->cap2;
@@ -217,7 +217,7 @@ int build_program(dqn_engine* e) {
             const HeadTdArgs* h_dev = upload(e, std::vector<HeadTdArgs>(1, h));
             e->prog.push_back({"head_td", [=](dqn_engine* en) { launch_head_td(en->stream, h, h_dev, en->step_sampled ? 1 : 0, en->step_take_pre ? 1 : 0); }});
         }
-        else if (!rec) e->prog.push_back({"td_huber", [=](dqn_engine* en) { TdArgs a = t; a.bump_sample_ctr = en->step_sampled ? 1 : 0; launch_td(en->stream, a); }});
+        else if (!rec) e->prog.push_back({"td_huber", [=](dqn_engine* en) { TdArgs a = t; a.bump_sample_ctr = en->step_sampled ? 1 : 0; a.take_pre = en->step_take_pre ? 1 : 0; launch_td(en->stream, a); }});
         else {
             TdDrqnArgs d; memset(&d, 0, sizeof d); d.B = Bb; d.T = T; d.nA = e->nA; d.ncon = ncon; d.dueling = e->hp.dueling; d.double_q = e->hp.double_q; d.gamma = e->hp.gamma;
             d.on_val = t.on_val; d.on_adv = t.on_adv; d.tg_val = t.tg_val; d.tg_adv = t.tg_adv; d.d_val = t.d_val; d.d_adv = t.d_adv;
@@ -233,7 +233,8 @@ int build_program(dqn_engine* e) {
             e->prio_forked = true;
             e->prog.push_back({"prio_fork", [](dqn_engine* en) {
                 hipEventRecord(en->ev_fork, en->stream); hipStreamWaitEvent(en->stream2, en->ev_fork, 0);
-                launch_update_priorities(en->stream2, en->B, en->cap2, en->idx, en->td, en->hp.prio_eps, en->hp.prio_alpha, en->tree, en->state, 0, 1.0, 1.0, nullptr, 0);
+                launch_update_priorities(en->stream2, en->B, en->cap2, en->idx, en->td, en->hp.prio_eps, en->hp.prio_alpha, en->tree, en->state, 0, 1.0, 1.0, nullptr, 0,
+                                         en->idx_pre, en->hp.seed, en->B);      // + the next step's index draw
                 hipEventRecord(en->ev_join, en->stream2); }});
         } else e->prio_forked = false;
     }
@@ -276,7 +277,9 @@ int build_program(dqn_engine* e) {
     const bool prio_in_adam = e->hp.prioritized_replay && !rec && Bb <= 64;      // larger batches: side stream (prio_fork)
     // pre-gather (common.h PreGather): needs the priority block (which also draws the next indices) OUT of the Adam launch -- it rides as
     // workgroup 0 of the first LDS-tiled backward launch instead
-    const bool pg_want = prio_in_adam && !early && !e->sim_world && fuse_heads && (e->hp.obs_dtype != DQN_OBS_U8 || e->arena_u8) && !getenv("DQN_NO_PREGATHER");      // u8 rows: only onto the byte arena
+    // large batches: the priority update runs on the side stream (prio_fork) and draws the next indices there; k_td takes the pre-drawn batch
+    const bool pg_want = e->hp.prioritized_replay && !rec && (prio_in_adam ? fuse_heads : e->prio_forked) && !early && !e->sim_world &&
+                         (e->hp.obs_dtype != DQN_OBS_U8 || e->arena_u8) && !getenv("DQN_NO_PREGATHER");      // u8 rows: only onto the byte arena
     // layer l's gradient is final: queue its parameter range (split-K layers: as a slab segment)
     auto adam_queue = [&](int l, const std::vector<RSeg>& segs_known) {
         const LayerDev& L = e->L[l]; PItem it; it.beg = L.w_off; it.end = l + 1 < e->nl ? e->L[l + 1].w_off : e->Pint; it.part = nullptr; it.S = 0;
@@ -445,8 +448,8 @@ int build_program(dqn_engine* e) {
             tail.adam = make_job((pending_stream() / (unsigned long long)(li + 1) + 3) / 4 * 4, false); tail.has_adam = 1;
             if (prio_in_adam && !prio_placed) { tail.adam.prio = prio_args(); prio_placed = true; }
         }
-        else if (pg_want && (dwl.on || dxl.on) && !prio_placed) { tail.adam = base_job(); tail.adam.prio = prio_args(); tail.has_adam = 1; prio_placed = true; }
-        if (pg_want && !prio_placed && !pend.empty() && !tail.has_adam) { const PrioArgs pa = prio_args(); flush_valu(e, pend, pname(e, "bwd_valu", e->L[lv[0]].kind, lv[0]), &pa); prio_placed = true; }
+        else if (pg_want && prio_in_adam && (dwl.on || dxl.on) && !prio_placed) { tail.adam = base_job(); tail.adam.prio = prio_args(); tail.has_adam = 1; prio_placed = true; }
+        if (pg_want && prio_in_adam && !prio_placed && !pend.empty() && !tail.has_adam) { const PrioArgs pa = prio_args(); flush_valu(e, pend, pname(e, "bwd_valu", e->L[lv[0]].kind, lv[0]), &pa); prio_placed = true; }
         flush_valu(e, pend, pname(e, "bwd_valu", e->L[lv[0]].kind, lv[0]));
         const char* tsuf = (tail.has_adam && adam_job_blocks(tail.adam) == 1 && tail.adam.prio.n > 0) ? "+prio" : "+adam_tail";      // a job that is only the priority block
         auto tailed = [&](const char* base) { if (!tail.has_adam) return base; char nm[80]; snprintf(nm, sizeof nm, "%s%s", base, tsuf); e->prog_names.push_back(nm); return e->prog_names.back().c_str(); };
@@ -561,7 +564,7 @@ int build_program(dqn_engine* e) {
         AdamJob J = base_job();
         J.nr = 1; J.beg[0] = 0; J.end[0] = e->Pint; J.sblocks = (unsigned)adam_blocks(e->Pint); J.tick = 1; J.slot0 = 0;
         if (e->hp.prioritized_replay && !rec && !e->prio_forked && !prio_placed) J.prio = prio_args();
-        memset(&e->pg, 0, sizeof e->pg); e->pg_ok = pg_want && prio_placed;
+        memset(&e->pg, 0, sizeof e->pg); e->pg_ok = pg_want && (prio_placed || e->prio_forked);
         if (e->pg_ok) {
             PreGather& G = e->pg; G.on = 1; G.s_rows = e->s_rows; G.sp_rows = e->sp_rows; G.E = e->E; G.B = B; G.idx_pre = e->idx_pre; G.x0 = e->x0; G.cap2 = e->cap2; G.tree = e->tree; G.seed = e->hp.seed;
             G.meta.a = e->ra; G.meta.r = e->rr; G.meta.done = e->rdone; G.meta.beta = e->hp.prio_beta; G.meta.a_out = e->gb_a2; G.meta.r_out = e->gb_r2; G.meta.done_out = e->gb_done2; G.meta.w_out = e->gb_w2;

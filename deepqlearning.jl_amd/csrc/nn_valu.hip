@@ -165,7 +165,9 @@ __global__ __launch_bounds__(1024) void k_td(TdArgs A) {
     long long j_ = 0; int act_ = 0; float rew_ = 0.0f, dn_ = 0.0f, w_ = 0.0f;
     if (hasb) {
         const float total = A.tree[1]; const long long size = A.st->size;
-        j_ = A.idx[b_]; act_ = A.a[j_]; rew_ = A.r[j_]; dn_ = (float)A.done[j_];
+        j_ = A.take_pre ? A.idx_pre[b_] : A.idx[b_];
+        if (A.take_pre) { A.idx_mut[b_] = j_; if (b_ == 0 && A.st->pre_valid != 2) A.st->err = 3; }      // publish the pre-drawn indices (priority update, parity API)
+        act_ = A.a[j_]; rew_ = A.r[j_]; dn_ = (float)A.done[j_];
         const float p = A.tree[A.cap2 + j_] / total; const float xw = (float)size * p;
         w_ = (float)pow((double)xw, -(double)A.prio_beta);               // IS weight, ...replay.jl:101-102
     }

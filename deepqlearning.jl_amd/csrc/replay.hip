@@ -203,7 +203,8 @@ void launch_batch_meta(hipStream_t st, int B, long long cap2, const long long* i
 // ------------------------------------------------------------------ update_priorities! (host-called seam) / grad-norm fold (tick_adam != 0, on demand)
 __global__ __launch_bounds__(1024) void k_update_priorities(int n, long long cap2, const long long* __restrict__ idx, const float* __restrict__ td,
                                                             float eps, float alpha, float* tree, StepState* state, int tick_adam, double beta1,
-                                                            double beta2, const float* __restrict__ gmax_part, int n_gmax) {
+                                                            double beta2, const float* __restrict__ gmax_part, int n_gmax,
+                                                            long long* __restrict__ idx_pre, unsigned long long seed, int pre_B) {
     __shared__ long long sidx[1024];
     __shared__ float smax[16];
     if (tick_adam) {   // globalnorm (helpers.jl:38-46): fold the Adam kernel's per-block max-abs (max is order-independent => exact)
@@ -215,12 +216,21 @@ __global__ __launch_bounds__(1024) void k_update_priorities(int n, long long cap
         if (threadIdx.x == 0) { for (int w = 1; w < (int)(blockDim.x >> 6); w++) g = fmaxf(g, smax[w]); state->gnorm_bits = __float_as_uint(g); }
     }
     if (n > 0) { if (threadIdx.x == 0) state->pre_valid = 0; prio_update_block(n, cap2, idx, td, eps, alpha, tree, state, sidx); }
+    if (n > 0 && idx_pre) {      // the tree is final and the next sample()'s Philox counter is known: draw its indices now (see prio_block_run)
+        __syncthreads();
+        const unsigned long long ctr = state->sample_ctr; const long long size = state->size;
+        const float seg = tree[1] / (float)pre_B;
+        for (int i = threadIdx.x; i < pre_B; i += blockDim.x) idx_pre[i] = tree_descend(tree, cap2, size, seed, ctr, i, seg);
+        __syncthreads();
+        if (threadIdx.x == 0) state->pre_valid = 1;
+    }
 }
 void launch_update_priorities(hipStream_t st, int n, long long cap2, const long long* idx, const float* td, float eps, float alpha,
-                              float* tree, StepState* state, int tick_adam, double beta1, double beta2, const float* gmax_part, int n_gmax) {
+                              float* tree, StepState* state, int tick_adam, double beta1, double beta2, const float* gmax_part, int n_gmax,
+                              long long* idx_pre, unsigned long long seed, int pre_B) {
     int bs = ((n + 63) / 64) * 64; if (bs < 64) bs = 64;
     if (tick_adam && bs < 1024) bs = 1024;      // the fold: one load per lane for the ~2100 live slots of config 2
-    hipLaunchKernelGGL(k_update_priorities, dim3(1), dim3(bs), 0, st, n, cap2, idx, td, eps, alpha, tree, state, tick_adam, beta1, beta2, gmax_part, n_gmax);
+    hipLaunchKernelGGL(k_update_priorities, dim3(1), dim3(bs), 0, st, n, cap2, idx, td, eps, alpha, tree, state, tick_adam, beta1, beta2, gmax_part, n_gmax, idx_pre, seed, pre_B);
 }
 
 // ------------------------------------------------------------------ checkpoint import: rebuild every internal node of the sum-tree from the leaves

@@ -360,6 +360,30 @@ def test_config5_nature_b512_u8_bit_exact(pkg):
     np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
 
 
+def test_large_batch_train_steps_pipelined(pkg):
+    """B > 64: the priority update runs on the side stream and also draws the next step's indices; inside dqn_train_steps the Adam launch gathers
+    the next batch (byte arena) and the next step starts without its sample and gather launches (k_td publishes the indices).  Mid-size network at
+    B = 128 / u8: equal to the twin stepped one call at a time."""
+    net = mid_conv_dueling()
+    gpu, cpu, hp = make_pair(pkg, net, 128, cap=1024, obs_dtype=1, learning_rate=1e-3, gamma=0.99)
+    fill((gpu, cpu), net, 900, seed=41, u8=True)
+    set_same_params((gpu, cpu), net, seed=42)
+    lg = gpu.train_steps(4)
+    for _ in range(4):
+        lc = cpu.train_step()
+    assert lg[0] == lc[0] and lg[1] == lc[1]
+    np.testing.assert_array_equal(gpu.last_indices(), cpu.last_indices())
+    np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+    np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
+    assert_step_bit_exact(gpu, cpu)
+    names = [n for n, _ in gpu.profile_step(steady=True)]
+    cpu.train_step(); cpu.train_step()
+    np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+    if gpu.batch_arena_elem_bytes() == 1:
+        assert "adam+gather" in names and "gather" not in names and "sample" not in names, names
+    assert_step_bit_exact(gpu, cpu)
+
+
 def test_config5_million_transition_properties(pkg):
     """BASELINE config 5 at FULL size: replay of 1 000 000 u8 transitions (56 GB of rows in HBM), filled by the device env loop; size-independent
     properties: every sampled index in range and spread over the whole ring, finite loss, the sum-tree root equals the sum of the leaves, the
