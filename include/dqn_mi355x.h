@@ -155,7 +155,8 @@ int dqn_train_step(dqn_engine_t* e, const int64_t* idx_or_null, float* loss, flo
                    float* td_out /* B */);
 /* run `n_steps` sampled train steps back to back; returns the last step's scalars.  Bit-identical to n_steps calls of dqn_train_step(e, NULL, ...)
  * (tests/test_gpu_parity.py::test_train_steps_pipelined_gather_bit_exact), but inside the call nothing else can touch the replay, so step i's last
- * launch already gathers step i+1's batch and steps 2..n run without a gather launch (f32 observations, B <= 64, prioritized replay). */
+ * launch already gathers step i+1's batch and steps 2..n run without a sample / gather launch (prioritized replay; f32 observations, or u8
+ * observations on the byte arena; any batch size; replicas too -- the gather is rank-local). */
 int dqn_train_steps(dqn_engine_t* e, int n_steps, float* loss, float* grad_norm);
 
 /* Results of the last train step (parity checks; not on the hot path). */
@@ -258,8 +259,8 @@ int dqn_stream_handle(dqn_engine_t* e, void** hip_stream);
  * milliseconds measured with HIP events on the engine stream. */
 int dqn_profile_step(dqn_engine_t* e, int max_entries, const char** names, float* ms, int* n_entries);
 /* as dqn_profile_step, but TWO train steps run and the second is timed as a MIDDLE step of dqn_train_steps(n): inside that call step i's last
- * launch (Adam) already gathers step i+1's batch, so a middle step has no gather launch of its own (f32 observations, B <= 64, prioritized
- * replay; otherwise both steps are plain ones).  Results of dqn_train_steps(n) are bit-identical to n dqn_train_step calls either way. */
+ * launch (Adam) already gathers step i+1's batch, so a middle step has no gather launch of its own (where dqn_train_steps pipelines it;
+ * otherwise both steps are plain ones).  Results of dqn_train_steps(n) are bit-identical to n dqn_train_step calls either way. */
 int dqn_profile_steady_step(dqn_engine_t* e, int max_entries, const char** names, float* ms, int* n_entries);
 
 /* debug aid: per-workgroup timestamps of the forward GEMM kernels (tools/ktrace.py).  out == NULL starts recording; otherwise stops and copies
