@@ -196,6 +196,34 @@ def test_train_steps_pipelined_gather_bit_exact(pkg, netf, B, kw, graph):
     assert_step_bit_exact(gpu, cpu)
 
 
+@pytest.mark.parametrize("netf,B", [(small_conv_dueling, 16), (cfg1_mlp_dueling, 32)])
+def test_train_steps_long_run_bit_exact(pkg, netf, B):
+    """300 sampled steps issued as dqn_train_steps calls of assorted lengths (1, 2, 3, 7, 50, ...) with replay writes between some of them: the
+    pipelined gather must never hand a stale or half-written batch to a step -- parameters, priorities and Adam state equal the twin's after every call."""
+    net = netf()
+    gpu, cpu, _ = make_pair(pkg, net, B, cap=256, learning_rate=1e-3, gamma=0.95)
+    fill((gpu, cpu), net, 200, seed=51)
+    set_same_params((gpu, cpu), net, seed=52)
+    rng = np.random.default_rng(5)
+    done = 0
+    for call, n in enumerate([1, 2, 3, 7, 50, 1, 13, 64, 2, 31, 100, 5, 21]):
+        lg = gpu.train_steps(n)
+        for _ in range(n):
+            lc = cpu.train_step()
+        done += n
+        assert lg[0] == lc[0] and lg[1] == lc[1], (call, n)
+        np.testing.assert_array_equal(gpu.last_indices(), cpu.last_indices())
+        np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+        np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
+        if call % 3 == 2:
+            fill((gpu, cpu), net, int(rng.integers(1, 9)), seed=100 + call)
+        if call % 4 == 1:
+            gpu.sync_target(); cpu.sync_target()
+    assert done == 300
+    mg, vg, bg = gpu.get_adam_state(); mc, vc, bc = cpu.get_adam_state()
+    np.testing.assert_array_equal(mg, mc); np.testing.assert_array_equal(vg, vc); np.testing.assert_array_equal(bg, bc)
+
+
 def test_graph_and_eager_agree(pkg):
     net = small_conv_dueling()
     a, cpu, _ = make_pair(pkg, net, 16, graph=1)
