@@ -21,7 +21,7 @@ import DeepQLearning: batch_train!, add_exp!, update_priorities!, get_batch, pop
 import CommonRLInterface: AbstractEnv, observe, actions, act!, reset!, terminated
 import TensorBoardLogger: TBLogger, log_value
 import StatsBase
-export MI355XSolver, HIPReplayBuffer, HIPEpisodeReplayBuffer, HIPNNPolicy
+export MI355XSolver, HIPReplayBuffer, HIPEpisodeReplayBuffer, HIPNNPolicy, train_steps!
 
 const LIB = get(ENV, "DQN_MI355X_LIB", "libdqn_mi355x.so")
 
@@ -160,6 +160,14 @@ function batch_train!(solver::DeepQLearningSolver, env::AbstractEnv, policy::Abs
                       replay::HIPReplayBuffer; discount=DeepQLearning.default_discount(env))
     loss = Ref{Float32}(0); gn = Ref{Float32}(0)
     check(ccall((:dqn_train_step, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ref{Float32}, Ref{Float32}, Ptr{Float32}), replay.e.h, C_NULL, loss, gn, C_NULL))
+    return loss[], gn[]
+end
+
+# n sampled batch_train! steps back to back with nothing in between (no reference equivalent: offline / catch-up training on a filled replay).
+# Bit-identical to n batch_train! calls; inside the call step i's last launch already gathers step i+1's batch (dqn_train_steps).
+function train_steps!(e::Engine, n::Integer)
+    loss = Ref{Float32}(0); gn = Ref{Float32}(0)
+    check(ccall((:dqn_train_steps, LIB), Cint, (Ptr{Cvoid}, Cint, Ref{Float32}, Ref{Float32}), e.h, n, loss, gn))
     return loss[], gn[]
 end
 
