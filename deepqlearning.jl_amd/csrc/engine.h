@@ -74,6 +74,7 @@ struct dqn_engine {
     StepState* state_host = nullptr;      // pinned landing buffer of fetch_scalars
     bool pg_ok = false, step_pregather = false, step_take_pre = false; PreGather pg; long adam_step = -1;
     hipGraphExec_t g_pgv[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [take_pre][pregather] variants of the sampled single-device step
+    hipGraphExec_t g_mid = nullptr; int mid_group = 4;                          // mid_group consecutive middle steps of dqn_train_steps as one graph
     hipGraphExec_t g_pre_tp = nullptr, g_post_pg = nullptr;                      // replicas: first half without the gather launch / second half whose Adam launch gathers
     AdamSegs adam_segs; long final_reduce_step = -1;   // deferred dW slabs: reduced inside k_adam unless a communicator needs the materialised gradient
     std::vector<void*> prog_allocs; std::vector<std::string> prog_names;
@@ -98,7 +99,7 @@ void drop_graphs(dqn_engine* e);
 void drop_act(dqn_engine* e, dqn_engine::ActProg& a);
 void fwd_layer(dqn_engine* e, const LayerDev& l, const float* P, const float* X, int ldx, int col0, int ncols, float* Y, const char* name);
 void enqueue_step(dqn_engine* e, bool sample, int phase);
-int capture(dqn_engine* e, bool sample, int phase, hipGraphExec_t* out);
+int capture(dqn_engine* e, bool sample, int phase, hipGraphExec_t* out, int repeat = 1);
 int exchange_grads(dqn_engine* e);      // the one collective of a data-parallel step (all-gather or all-reduce)
 int run_step(dqn_engine* e, bool sample, bool take_pre = false, bool pregather = false);
 int fetch_scalars(dqn_engine* e, float* loss, float* gn);
