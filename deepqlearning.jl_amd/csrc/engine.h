@@ -64,7 +64,10 @@ struct dqn_engine {
     // static launch program
     struct Step { const char* name; std::function<void(dqn_engine*)> fn; };
     // acting programs (forward on n columns + env kernels), one for the training envs and one for the evaluation envs
-    struct ActProg { std::vector<Step> steps; int n = 0; hipGraphExec_t graph = nullptr; std::vector<void*> allocs; };
+    // cycle: ONE graph of `cycle_F` acting steps (+ a plain sampled train step when cycle_train) -- the device loop's unit of work between two
+    // train steps; a graph launch costs ~5 us of stream time, a GridWorld vector step 28
+    struct ActProg { std::vector<Step> steps; int n = 0; hipGraphExec_t graph = nullptr; std::vector<void*> allocs;
+                     hipGraphExec_t cycle = nullptr; int cycle_F = 0; bool cycle_train = false; };
     ActProg act, evalp; std::vector<Step>* sink = nullptr; std::vector<void*>* alloc_sink = nullptr; RolloutDev *roll = nullptr, *eval_roll = nullptr;
     EnvDev eval_env{}; int eval_n = 0;
     std::vector<Step> prog; size_t prog_post_begin = 0; bool prog_built = false, step_sampled = true, prio_forked = false;

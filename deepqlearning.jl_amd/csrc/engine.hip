@@ -234,10 +234,11 @@ void drop_graphs(dqn_engine* e) {
     if (e->g_post_pg) { hipGraphExecDestroy(e->g_post_pg); e->g_post_pg = nullptr; }
     if (e->g_mid) { hipGraphExecDestroy(e->g_mid); e->g_mid = nullptr; }
     if (e->g_pre_tp) { hipGraphExecDestroy(e->g_pre_tp); e->g_pre_tp = nullptr; }
-    for (dqn_engine::ActProg* a : {&e->act, &e->evalp}) if (a->graph) { hipGraphExecDestroy(a->graph); a->graph = nullptr; }
+    for (dqn_engine::ActProg* a : {&e->act, &e->evalp}) { if (a->graph) { hipGraphExecDestroy(a->graph); a->graph = nullptr; } if (a->cycle) { hipGraphExecDestroy(a->cycle); a->cycle = nullptr; } }
 }
 void drop_act(dqn_engine* e, dqn_engine::ActProg& a) {
     if (a.graph) { hipGraphExecDestroy(a.graph); a.graph = nullptr; }
+    if (a.cycle) { hipGraphExecDestroy(a.cycle); a.cycle = nullptr; }
     if (!a.allocs.empty()) hipStreamSynchronize(e->stream);
     for (void* p : a.allocs) hipFree(p);
     a.allocs.clear(); a.steps.clear(); a.n = 0;

@@ -129,6 +129,22 @@ static int act_graph(dqn_engine* e, dqn_engine::ActProg& ap) {
     HIPCHK(hipStreamEndCapture(e->stream, &g));
     HIPCHK(hipGraphInstantiate(&ap.graph, g, nullptr, nullptr, 0)); HIPCHK(hipGraphDestroy(g)); return 0;
 }
+// F acting steps (+ one plain sampled train step) as one graph
+static int cycle_graph(dqn_engine* e, dqn_engine::ActProg& ap, int F, bool with_train) {
+    if (ap.cycle && ap.cycle_F == F && ap.cycle_train == with_train) return 0;
+    if (ap.cycle) { hipGraphExecDestroy(ap.cycle); ap.cycle = nullptr; }
+    hipGraph_t g;
+    (void)hipGetLastError();
+    e->step_take_pre = e->step_pregather = false;
+    HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+    for (int f = 0; f < F; f++) for (auto& s : ap.steps) s.fn(e);
+    if (with_train) enqueue_step(e, true, PH_ALL);
+    const hipError_t lerr = hipGetLastError();
+    HIPCHK(hipStreamEndCapture(e->stream, &g));
+    if (lerr != hipSuccess) { hipGraphDestroy(g); return fail("HIP error %s while capturing the rollout cycle", hipGetErrorString(lerr)); }
+    HIPCHK(hipGraphInstantiate(&ap.cycle, g, nullptr, nullptr, 0)); HIPCHK(hipGraphDestroy(g));
+    ap.cycle_F = F; ap.cycle_train = with_train; return 0;
+}
 extern "C" int dqn_rollout(dqn_engine_t* e, int n_steps, const dqn_rollout_cfg* cfg, dqn_rollout_stats* out) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device));
     if (!e->has_envs) return fail("no device environments: call dqn_envs_create");
@@ -142,8 +158,27 @@ extern "C" int dqn_rollout(dqn_engine_t* e, int n_steps, const dqn_rollout_cfg* 
     const bool graph = e->hp.use_graph && !e->profiling;
     if (graph && act_graph(e, e->act)) return -1;
     long long trained = 0;
+    // whole cycles -- train_freq acting steps ending on a train step (or 4 acting steps when nothing trains) -- replay as ONE graph where the
+    // schedule allows it: single device, the train step due exactly at the cycle's last step, the replay already holding a batch, no target sync
+    // before the cycle's last step
+    const bool single = e->world <= 1 && !(e->comm && e->force_comm);
+    const int F = cfg->train_freq > 0 ? cfg->train_freq : 4;
+    const bool cyc = graph && single && F >= 2 && F <= 16 && getenv("DQN_NO_ROLLOUT_CYCLE") == nullptr;
     for (int k = 0; k < n_steps; k++) {
         const long long t = cfg->t0 + k;
+        if (cyc && k + F <= n_steps) {
+            const long long tl = t + F - 1;      // the cycle's last step
+            bool ok = cfg->train_freq > 0 ? (tl % cfg->train_freq == 0 && std::min(e->cap, e->size + (long long)F * n) >= e->B) : true;
+            if (cfg->target_update_freq > 0) for (long long u = t; u < tl; u++) ok = ok && (u % cfg->target_update_freq != 0);
+            if (ok) {
+                if (cycle_graph(e, e->act, F, cfg->train_freq > 0)) return -1;
+                HIPCHK(hipGraphLaunch(e->act.cycle, e->stream));
+                for (int f = 0; f < F; f++) { e->widx = (e->widx + n) % e->cap; e->size = std::min(e->cap, e->size + n); }
+                if (cfg->train_freq > 0) trained++;
+                if (cfg->target_update_freq > 0 && tl % cfg->target_update_freq == 0) { if (dqn_sync_target(e)) return -1; }
+                k += F - 1; continue;
+            }
+        }
         if (graph) HIPCHK(hipGraphLaunch(e->act.graph, e->stream));
         else for (auto& s : e->act.steps) { prof_begin(e, s.name); s.fn(e); prof_end(e); }
         e->widx = (e->widx + n) % e->cap; e->size = std::min(e->cap, e->size + n);
