@@ -47,6 +47,8 @@ struct StepState {
 
 static inline __host__ __device__ int dqn_nchunks(int K, int kc) { return (kc <= 0 || kc >= K) ? 1 : (K + kc - 1) / kc; }
 static inline __host__ __device__ int dqn_chunk_len(int K, int kc) { return (kc <= 0 || kc >= K) ? K : kc; }
+// conv dX: RAW kernel taps (index ky*kw + kx, ascending) per summation chunk (plan.dx_kc; 0 / >= kh*kw = one chunk)
+#define DQN_CONV_TAP_CHUNK(L) (((L).dx_kc > 0 && (L).dx_kc < (L).kh * (L).kw) ? (L).dx_kc : (L).kh * (L).kw)
 
 // ---- device math shared by VALU and MFMA epilogues (compiled with -ffp-contract=off: every fused
 //      multiply-add is an explicit fmaf / MFMA, never a compiler contraction)
@@ -458,7 +460,8 @@ static inline GemmTail gemm_no_tail() { GemmTail t; memset(&t, 0, sizeof t); ret
 void launch_gemm_dw(hipStream_t st, const LayerDev& L, int nprob, const float* const* X, int ldx, const float* const* dpre, int B, float* const* out,
                     int ldd = 0, int tpr = 0, int rstride = 0, GemmTail tail = gemm_no_tail());   // ldd 0 = plain layout; else gathered rank blocks (see DwStride in nn_gemm.hip)
 
-bool gemm_dx_eligible(const LayerDev& L, int B, int ldy);
+bool gemm_dx_eligible(const LayerDev& L, int B, int ldy, int nsrc = 1);
+bool gemm_dx_internal_chunks(const LayerDev& L, int B, int ldy, int nsrc = 1);   // plan chunks combined inside the launch: no partial slabs
 void launch_gemm_dx(hipStream_t st, const LayerDev& L, int nsrc, const float* const* W, const float* const* dpre, int B, float* out /* dact or partial slabs */,
                     const float* ysrc, int ldy, int act_src, GemmTail tail = gemm_no_tail());
 

@@ -115,6 +115,16 @@ static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out) {
         if (L[i].K > 1024) { const int s = (L[i].K + 511) / 512; int kc = (L[i].K + s - 1) / s; kc = (kc + 3) / 4 * 4; out[i].fwd_kc = kc; }
         else if (L[i].kind == DQN_LAYER_DENSE && L[i].N < 16 && L[i].K >= 128) out[i].fwd_kc = 32;   // heads: 16+ short chains instead of one long one
         out[i].dx_kc = (L[i].kind != DQN_LAYER_CONV && L[i].N > 512) ? 256 : 0;
+        // small batches (the 32 x 32 output tiles of k_dx_units, nn_gemm.hip): cut the dX contraction so that an output tile has up to four
+        // independent chains, one per wave -- dense: N/4 (N/2 per stream at the dueling join, where two sources meet); conv: RAW taps per chunk
+        // such that an interior input position has <= 4 chunks with a valid tap.  Only the rounding order changes.
+        const bool join = L[i].stream != DQN_STREAM_BASE && L[i].src >= 0 && L[L[i].src].stream == DQN_STREAM_BASE;
+        if (L[i].kind == DQN_LAYER_DENSE && L[i].N <= 512 && B <= 64 && L[i].N >= 128) {
+            const int S = join ? 2 : 4; const int kc = ((L[i].N + S - 1) / S + 31) / 32 * 32; if (kc < L[i].N) out[i].dx_kc = kc;
+        } else if (L[i].kind == DQN_LAYER_CONV && B <= 64) {
+            const int valid = ((L[i].kh + L[i].sh - 1) / L[i].sh) * ((L[i].kw + L[i].sw - 1) / L[i].sw), raw = ((valid + 3) / 4) * L[i].sw;
+            if (raw < L[i].kh * L[i].kw) out[i].dx_kc = raw;
+        }
         out[i].dw_kc = 0;
         if (L[i].kind == DQN_LAYER_DENSE && L[i].N < 16 && B >= 128) out[i].dw_kc = 64;   // head layers at large batches: 64-sample chains on 8x more threads instead of one B-long chain per output
         if (L[i].kind == DQN_LAYER_CONV) {   // positions per chunk so that (K/64 row tiles) x chunks >= ~512 workgroups

@@ -375,7 +375,8 @@ int build_program(dqn_engine* e) {
                 emit_dw1(Vi, X, ldx, pname(e, "dw_wi", L.kind, l));
                 if (L.src >= 0) {
                     const int src = L.src; const int act_src = e->L[src].act; float* out = e->dact[src]; const float* ysrc = e->act_on[src]; const float* P = e->p_on;
-                    const int S = dqn_nchunks(Vi.N, Vi.dx_kc); float* part = S > 1 ? palloc(e, (size_t)S * Vi.in_feat * B) : nullptr;
+                    const int S = (mf && gemm_dx_internal_chunks(Vi, B, ncon)) ? 1 : dqn_nchunks(Vi.N, Vi.dx_kc);      // internal: the launch combines its plan chunks itself
+                    float* part = S > 1 ? palloc(e, (size_t)S * Vi.in_feat * B) : nullptr;
                     if (mf && gemm_dx_eligible(Vi, B, ncon)) { struct A1 { const float* W[1]; const float* d[1]; } a; a.W[0] = P + Vi.w_off; a.d[0] = dG; float* dst = S > 1 ? part : out; const float* ys = S > 1 ? nullptr : ysrc;
                         e->prog.push_back({pname(e, "dx", L.kind, l), [=](dqn_engine* en) { launch_gemm_dx(en->stream, Vi, 1, a.W, a.d, B, dst, ys, ncon, act_src); }}); }
                     else if (mf && mfma_dx_ok(Vi, B, ncon)) e->prog.push_back({pname(e, "dx", L.kind, l), [=](dqn_engine* en) { launch_mfma_dx(en->stream, Vi, P, dG, B, out, part, nullptr, ysrc, ncon, act_src, false); }});
@@ -410,9 +411,11 @@ int build_program(dqn_engine* e) {
             if (L.src < 0) continue;
             // dX, then act' of the producing layer; the two streams of a dueling net meet at the base output (dX_val + dX_adv)
             const int src = L.src; const bool is_join = e->hp.dueling && src == e->last_base && L.stream != DQN_STREAM_BASE;
-            const bool dense = L.kind == DQN_LAYER_DENSE; const int S = dense ? dqn_nchunks(L.N, L.dx_kc) : 1;
+            const bool dense = L.kind == DQN_LAYER_DENSE; const int S_plan = dense ? dqn_nchunks(L.N, L.dx_kc) : 1;
             const float* P = e->p_on; const int act_src = e->L[src].act;
-            if (is_join && lv.size() == 2 && S == 1 && mf && same_geo(e->L[lv[0]], e->L[lv[1]]) && gemm_dx_eligible(L, B, ncon)) {
+            const bool join_lds = is_join && lv.size() == 2 && mf && same_geo(e->L[lv[0]], e->L[lv[1]]) && e->L[lv[0]].dx_kc == e->L[lv[1]].dx_kc &&
+                                  gemm_dx_eligible(L, B, ncon, 2) && (S_plan == 1 || gemm_dx_internal_chunks(L, B, ncon, 2));
+            if (join_lds) {
                 // both streams in ONE launch: the kernel accumulates dX_val and dX_adv separately and adds them (val first)
                 if (k == (int)lv.size() - 1) {
                     const LayerDev Lv = e->L[lv[0]], La = e->L[lv[1]];
@@ -424,6 +427,7 @@ int build_program(dqn_engine* e) {
             float* out = e->dact[src]; const float *addend = nullptr, *ysrc = e->act_on[src];
             if (is_join && !joined) { out = e->join_tmp; ysrc = nullptr; joined = true; }
             else if (is_join) { addend = e->join_tmp; flush_valu(e, pend, pname(e, "bwd_valu", L.kind, l)); }   // depends on the first stream's dX
+            const int S = (mf && !addend && gemm_dx_internal_chunks(L, B, ncon)) ? 1 : S_plan;      // internal: the launch combines its plan chunks itself (no slabs)
             float* part = S > 1 ? palloc(e, (size_t)S * L.in_feat * B) : nullptr;
             if (mf && !addend && gemm_dx_eligible(L, B, ncon)) {
                 flush_dx(); dxl.on = true; dxl.L = L; dxl.nsrc = 1; dxl.W[0] = dxl.W[1] = P + L.w_off; dxl.d[0] = dxl.d[1] = dpre;

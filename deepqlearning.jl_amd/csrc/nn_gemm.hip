@@ -290,7 +290,17 @@ struct GDwProbs { GDwProb p[2]; };
 // operand layout: ldd = row stride of dpre ([n][pos][b]: npos*B).  The sample axis of a position is either one plain run (tpr = 0) or the
 // concatenation of gathered per-rank blocks (dp.hip): tpr 32-sample tiles per rank, consecutive ranks rstride floats apart (X and dpre alike)
 struct DwStride { int ldd, tpr, rstride; };
-constexpr int W_ST = 36;     // LDS row stride (32 samples + 4 pad): 16-B aligned rows, fragment reads at most 2-way conflicted
+// LDS row stride of the tiles whose rows are read as MFMA fragments ALONG the row (lane (i, kq) reads dword kq + 4*st of row i): 32 + 2.
+// ds_read_b32 banks are (dword address) mod 32 per 32-lane half, so row stride 34 puts lane (i, kq) on bank 2*i + kq (+ 4*st): all 32
+// lanes of a half on distinct banks.  (Stride 36 -- 16-B aligned rows for ds_write_b128 -- maps rows i and i + 8 to one bank: every
+// fragment read 2-way conflicted, r02 PMC: 29-37 % of the LDS cycles of the backward launches.)  Rows are only 8-B aligned, so the
+// staging stores are ds_write_b64 pairs (lds_st4): conflict-free too (16-lane groups: two rows x 8 float4 = 32 distinct banks).
+constexpr int W_ST = 34;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lds_st4(float* p, f32x4 v) {
+    *reinterpret_cast<f32x2*>(p) = (f32x2){v.x, v.y};
+    *reinterpret_cast<f32x2*>(p + 2) = (f32x2){v.z, v.w};
+}
 
 template <int NT, bool XU8 = false>
 __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& pr, int nprob, int ldx, int B, int S, int kc, int bid, int nblocks, DwStride ds) {
@@ -346,10 +356,10 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
         if (BQ > 1) r.b1 = gld(Db1 + bo);
     };
     auto lstore = [&](int buf, const Stage& r) {
-        *reinterpret_cast<f32x4*>(As + (buf * 64 + (tid >> 3)) * W_ST + 4 * f4) = cvt(r.a0);
-        *reinterpret_cast<f32x4*>(As + (buf * 64 + (tid >> 3) + 32) * W_ST + 4 * f4) = cvt(r.a1);
-        if (tid < NW * 8) *reinterpret_cast<f32x4*>(Bs + (buf * NW + (tid >> 3)) * W_ST + 4 * f4) = r.b0;
-        if (BQ > 1) *reinterpret_cast<f32x4*>(Bs + (buf * NW + ((tid + 256) >> 3)) * W_ST + 4 * f4) = r.b1;
+        lds_st4(As + (buf * 64 + (tid >> 3)) * W_ST + 4 * f4, cvt(r.a0));
+        lds_st4(As + (buf * 64 + (tid >> 3) + 32) * W_ST + 4 * f4, cvt(r.a1));
+        if (tid < NW * 8) lds_st4(Bs + (buf * NW + (tid >> 3)) * W_ST + 4 * f4, r.b0);
+        if (BQ > 1) lds_st4(Bs + (buf * NW + ((tid + 256) >> 3)) * W_ST + 4 * f4, r.b1);
     };
 #define STAGE_WAIT(N, r) do { if (BQ > 1) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r.a0), "+v"(r.a1), "+v"(r.b0), "+v"(r.b1) : "n"(N) : "memory"); \
                               else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r.a0), "+v"(r.a1), "+v"(r.b0) : "n"(N) : "memory"); } while (0)
@@ -461,200 +471,164 @@ void launch_gemm_dw(hipStream_t st, const LayerDev& L, int nprob, const float* c
 // =====================================================================================================================
 struct GDxSrc { const float* W; const float* dpre; };
 struct GDxArgs { GDxSrc src[2]; int nsrc; float* out; const float* ysrc; int ldy, act_src; };
-constexpr int X_SA = 48;     // A tile row stride (32 samples + 16 pad): fragment reads hit banks 16*kq + i
-constexpr int X_SB = 36;     // B tile row stride (32 k + 4 pad)
+constexpr int X_SB = 34;     // B tile row stride (32 k + 2 pad): fragment reads along the row, conflict-free like W_ST (stores: lds_st4)
 
-__device__ __forceinline__ void dx_lds_body(const LayerDev& L, const GDxArgs& A, int B, int S, int kc, int bid, int nblocks, int by) {
+// ---- small batches: ONE output tile (32 features x 32 samples) per workgroup, its contraction cut into up to four UNITS -- (source, plan chunk)
+// pairs: the two streams of a dueling join x dense chunks of n (plan.dx_kc) or conv chunks of RAW taps -- and every unit contracted by ONE wave
+// through a wave-PRIVATE pipeline: own register stages (two K tiles of global loads in flight), own LDS tiles, all four accumulator tiles
+// (32 MFMAs per 32-deep K tile), no workgroup barrier inside the loop (LDS operations of one wave execute in order).  r02 ktrace: the dX
+// workgroups were the critical path of every backward launch -- a lone wave per SIMD walking load -> LDS -> barrier -> LDS -> 8 MFMAs through
+// 16-18 K tiles (8.7-15 us) -- while the chip idled; here the serial chain of a workgroup is its longest unit (4-8 K tiles at config 2).
+// The unit sums meet in LDS and are added in canonical order: chunks ascending per source, then source 0 + source 1.
+constexpr int U_AW = 32 * 32;            // A tile [32 k][32 samples]: row stride 32, the two 16-sample halves of ODD rows swapped, so the fragment read
+                                         // of lanes (i, kq) hits bank 16*((mt ^ kq) & 1) + i: conflict-free without padding
+constexpr int U_BW = 32 * X_SB;          // B tile [32 features][34]
+constexpr int U_WAVE = U_AW + U_BW;      // floats per wave (8448 B)
+constexpr int U_MAX = 4;                 // units per workgroup = waves
+static size_t dx_units_lds_bytes() { return (size_t)(4 * U_WAVE + 64 + 8) * 4; }
+__device__ __forceinline__ void dx_units_body(const LayerDev& L, const GDxArgs& A, int B, int S, int kc, int bid, int nblocks, int by) {
     extern __shared__ float lds[];
-    float* As = lds;                                  // [2][32][X_SA]
-    float* Bs = lds + 2 * 32 * X_SA;                  // [2][32][X_SB]
-    int* taps = (int*)(Bs + 2 * 32 * X_SB);           // conv: valid taps of this input position, (tap << 16) | pos; taps[255] = count
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    float* As = lds + wave * U_WAVE; float* Bs = As + U_AW;
+    int* taps = (int*)(lds + 4 * U_WAVE);             // conv: valid taps of this input position ((tap << 16) | pos), raw-tap ascending
+    int* cst = taps + 64;                             // conv: cst[j] = first entry of non-empty chunk j, cst[n] = number of taps, cst[7] = n
     const bool dense = L.kind == DQN_LAYER_DENSE;
-    const int ft = wave & 1, mt = wave >> 1;
     const int b0 = by * 32;
-    int w = xcd_remap(bid, nblocks);
-    int f0, s = 0, ip = 0;                            // f0: first feature row (dense) / first input channel (conv)
-    const int nfeat = dense ? L.K : L.cin;
-    if (dense) { const int ftiles = (L.K + 31) / 32; f0 = (w % ftiles) * 32; s = w / ftiles; }
-    else { const int ctiles = L.cin / 32; f0 = (w % ctiles) * 32; ip = w / ctiles; }
-    int nkt;                                           // K tiles per source
-    const int khw = L.kh * L.kw;
-    if (dense) { const int n0 = s * kc, n1 = min(L.N, n0 + kc); nkt = (n1 - n0) / 32; }
+    const int w = xcd_remap(bid, nblocks);
+    const int nfeat = dense ? L.K : L.cin, khw = L.kh * L.kw;
+    int f0, ip = 0, nch;
+    if (dense) { const int ftiles = (L.K + 31) / 32; f0 = (w % ftiles) * 32; nch = S; }
     else {
-        // taps of input position ip: kernel offsets (ky, kx) whose output position exists; lane (ky*kw + kx) of wave 0 tests its own
-        // tap and a ballot prefix compacts them in (ky, kx)-ascending order -- the canonical contraction order
+        const int ctiles = L.cin / 32; f0 = (w % ctiles) * 32; ip = w / ctiles;
         if (tid < 64) {
+            // lane (ky*kw + kx) tests its own tap; ballots compact the valid ones in raw-tap order and mark the first valid tap of every chunk
             const int iy = ip / L.iw, ix = ip % L.iw; bool ok = false; int val = 0;
-            if (tid < L.kh * L.kw) {
+            if (tid < khw) {
                 const int ky = tid / L.kw, kx = tid % L.kw, ty = iy - ky, tx = ix - kx;
                 if (ty >= 0 && tx >= 0 && ty % L.sh == 0 && tx % L.sw == 0) {
                     const int oy = ty / L.sh, ox = tx / L.sw;
                     if (oy < L.oh && ox < L.ow) { ok = true; val = (tid << 16) | (oy * L.ow + ox); }
                 }
             }
-            const unsigned long long m = __ballot(ok);
-            if (ok) taps[__popcll(m & ((1ull << tid) - 1ull))] = val;
-            if (tid == 0) taps[255] = __popcll(m);
+            const int tcr = DQN_CONV_TAP_CHUNK(L);
+            const unsigned long long m = __ballot(ok), below = (1ull << tid) - 1ull, mb = m & below;
+            const bool first = ok && (mb == 0 || (63 - __clzll(mb)) / tcr != tid / tcr);
+            const unsigned long long fm = __ballot(first);
+            if (ok) taps[__popcll(mb)] = val;
+            if (first) cst[__popcll(fm & below)] = __popcll(mb);
+            if (tid == 0) { const int n = __popcll(fm); cst[n] = __popcll(m); cst[7] = n; }
         }
         __syncthreads();
-        nkt = taps[255] * (L.N / 32);
+        nch = cst[7];
     }
-    const int total = nkt * A.nsrc;
-    // ---- staging slices: A row (tid >> 3), float4 (tid & 7); B row (tid >> 3), float4 (tid & 7)
-    const int row = tid >> 3, f4 = tid & 7;
-    const int frow = min(f0 + row, nfeat - 1);
-    struct Stage { f32x4 a, b; };
-    auto gld = [](const float* ptr) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory"); return v; };
-    auto gload = [&](int kt, Stage& r) {
-        kt = min(kt, total - 1);
-        const int si = kt >= nkt ? 1 : 0; const int k = kt - si * nkt;
-        const GDxSrc& sr = A.src[si];
-        if (dense) {
-            const int nb = s * kc + k * 32;
-            r.a = gld(sr.dpre + (size_t)(nb + row) * B + b0 + 4 * f4);
-            r.b = gld(sr.W + (size_t)frow * L.N + nb + 4 * f4);
-        } else {
-            const int cot = L.N / 32; const int tp = taps[k / cot]; const int cob = (k % cot) * 32;
-            const int tap = tp >> 16, pos = tp & 0xffff;
-            r.a = gld(sr.dpre + ((size_t)(cob + row) * L.npos + pos) * B + b0 + 4 * f4);
-            r.b = gld(sr.W + ((size_t)frow * khw + tap) * L.N + cob + 4 * f4);
-        }
-    };
-    auto lstore = [&](int buf, const Stage& r) {
-        *reinterpret_cast<f32x4*>(As + (buf * 32 + row) * X_SA + 4 * f4) = r.a;
-        *reinterpret_cast<f32x4*>(Bs + (buf * 32 + row) * X_SB + 4 * f4) = r.b;
-    };
-#define STAGE_WAIT(N, r) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.a), "+v"(r.b) : "n"(N) : "memory")
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    // epilogue operands requested up front (see k_fwd_lds): the producer's activation for the fused act' multiply
-    const int fl_e = f0 + 16 * ft + l15;
-    const size_t feat_e = dense ? (size_t)min(fl_e, nfeat - 1) : (size_t)min(fl_e, nfeat - 1) * L.ih * L.iw + ip;
+    const int NU = A.nsrc * nch;
+    const bool active = wave < NU;
+    const int ft = wave & 1, mt = wave >> 1;          // the accumulator tile this wave FINISHES (epilogue)
+    // epilogue operand requested up front: the producer's activation for the fused act' multiply
+    const int fl = f0 + 16 * ft + l15;
+    const size_t feat = dense ? (size_t)min(fl, nfeat - 1) : (size_t)min(fl, nfeat - 1) * L.ih * L.iw + ip;
     f32x4 y_e = {0.f, 0.f, 0.f, 0.f};
-    if (S == 1 && A.ysrc) y_e = *reinterpret_cast<const f32x4*>(A.ysrc + feat_e * A.ldy + b0 + 16 * mt + 4 * kq);
-    auto compute = [&](int buf, bool second) {
-        const float* Ab = As + buf * 32 * X_SA + 16 * mt + l15;
-        const float* Bb = Bs + (buf * 32 + 16 * ft + l15) * X_SB + kq;
-        float af[8], bf[8];
+    if (A.ysrc) y_e = *reinterpret_cast<const f32x4*>(A.ysrc + feat * A.ldy + b0 + 16 * mt + 4 * kq);
+    f32x4 acc[4];                                      // [sample tile * 2 + feature tile] of this wave's unit
 #pragma unroll
-        for (int st = 0; st < 8; st++) { af[st] = Ab[(4 * st + kq) * X_SA]; bf[st] = Bb[4 * st]; }
-        if (!second) {
+    for (int j = 0; j < 4; j++) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        const int si = wave / nch, cj = wave - si * nch;
+        const GDxSrc& sr = A.src[si];
+        const int cot = L.N / 32;
+        int nt, n0 = 0, t0 = 0;
+        if (dense) { n0 = cj * kc; nt = (min(L.N, n0 + kc) - n0) / 32; }
+        else { t0 = cst[cj]; nt = (cst[cj + 1] - t0) * cot; }
+        // staging slices of this lane: rows (lane >> 3) + 8p, float4 (lane & 7) of both tiles
+        const int row0 = lane >> 3, f4 = lane & 7;
+        const float* Ap = sr.dpre + b0 + 4 * f4;
+        unsigned boff[4];
 #pragma unroll
-            for (int st = 0; st < 8; st++) acc0 = MFMA(af[st], bf[st], acc0);
-        } else {
+        for (int p = 0; p < 4; p++) { const unsigned frow = (unsigned)min(f0 + row0 + 8 * p, nfeat - 1); boff[p] = dense ? frow * (unsigned)L.N + 4u * f4 : frow * (unsigned)(khw * L.N) + 4u * f4; }
+        const float* Wp = sr.W;
+        const float r_cot = 1.0f / (float)cot;
+        struct Stage { f32x4 a[4], b[4]; };
+        auto gld = [](const float* ptr) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory"); return v; };
+        auto gload = [&](int t, Stage& r) {
+            t = min(t, nt - 1);
+            unsigned ao, astep, bo;
+            if (dense) { const unsigned nb = (unsigned)(n0 + 32 * t); ao = (nb + row0) * (unsigned)B; astep = 8u * (unsigned)B; bo = nb; }
+            else {
+                const int ti = (int)(((float)t + 0.5f) * r_cot); const int cob = (t - ti * cot) * 32;     // tile t = (tap ti of the chunk, channel tile)
+                const int tp = taps[t0 + ti]; const unsigned tap = (unsigned)tp >> 16, pos = (unsigned)tp & 0xffffu;
+                ao = ((unsigned)(cob + row0) * (unsigned)L.npos + pos) * (unsigned)B; astep = 8u * (unsigned)L.npos * (unsigned)B; bo = tap * (unsigned)L.N + (unsigned)cob;
+            }
 #pragma unroll
-            for (int st = 0; st < 8; st++) acc1 = MFMA(af[st], bf[st], acc1);
-        }
-    };
-    if (total > 0) {
-        Stage r0, r1;
-        gload(0, r0); STAGE_WAIT(0, r0); lstore(0, r0); __syncthreads();
-        gload(1, r0);
-        for (int kt = 0; kt < total; kt += 2) {
-            gload(kt + 2, r1);
-            compute(0, kt >= nkt);
-            STAGE_WAIT(2, r0); lstore(1, r0);
-            __syncthreads();
-            gload(kt + 3, r0);
-            if (kt + 1 < total) compute(1, kt + 1 >= nkt);
-            STAGE_WAIT(2, r1); lstore(0, r1);
-            __syncthreads();
+            for (int p = 0; p < 4; p++) r.a[p] = gld(Ap + ao + p * astep);
+#pragma unroll
+            for (int p = 0; p < 4; p++) r.b[p] = gld(Wp + boff[p] + bo);
+        };
+        const int aswz = ((row0 & 1) << 2) ^ f4;     // float4 column of this lane's A rows (all of one parity: row0 + 8p)
+        auto lstore = [&](const Stage& r) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) *reinterpret_cast<f32x4*>(As + (row0 + 8 * p) * 32 + 4 * aswz) = r.a[p];
+#pragma unroll
+            for (int p = 0; p < 4; p++) lds_st4(Bs + (row0 + 8 * p) * X_SB + 4 * f4, r.b[p]);
+        };
+#define STAGE_WAIT8(N, r) asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.b[0]), "+v"(r.b[1]), "+v"(r.b[2]), "+v"(r.b[3]) : "n"(N) : "memory")
+        struct Frag { float a[8][2], b[8][2]; };
+        auto fread = [&](Frag& f) {
+            const float* Ab = As + kq * 32 + l15;
+            const float* Bb = Bs + l15 * X_SB + kq;
+#pragma unroll
+            for (int st = 0; st < 8; st++) {
+                f.a[st][0] = Ab[st * 128 + ((kq & 1) << 4)]; f.a[st][1] = Ab[st * 128 + (((kq & 1) ^ 1) << 4)];
+                f.b[st][0] = Bb[4 * st]; f.b[st][1] = Bb[16 * X_SB + 4 * st];
+            }
+        };
+        auto mma = [&](const Frag& f, int s0, int s1) {
+#pragma unroll
+            for (int st = s0; st < s1; st++)
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int q = 0; q < 2; q++) acc[m * 2 + q] = MFMA(f.a[st][m], f.b[st][q], acc[m * 2 + q]);
+        };
+        Stage r0, r1; Frag fc, fn;
+        gload(0, r0); gload(1, r1);
+        STAGE_WAIT8(8, r0); lstore(r0); gload(2, r0); fread(fc);
+        for (int t = 0; t < nt; t += 2) {
+            // tile t in fc; r1 = tile t + 1 and r0 = tile t + 2 in flight.  The next tile's LDS round trip sits between the two halves of the chain
+            mma(fc, 0, 4);
+            STAGE_WAIT8(8, r1); lstore(r1); gload(t + 3, r1);
+            if (t + 1 < nt) fread(fn);
+            mma(fc, 4, 8);
+            if (t + 1 < nt) {
+                mma(fn, 0, 4);
+                STAGE_WAIT8(8, r0); lstore(r0); gload(t + 4, r0);
+                if (t + 2 < nt) fread(fc);
+                mma(fn, 4, 8);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef STAGE_WAIT8
     }
-#undef STAGE_WAIT
-    // ---- epilogue
-    const int fl = f0 + 16 * ft + l15;
-    if (fl >= nfeat) return;
-    const size_t feat = dense ? (size_t)fl : (size_t)fl * L.ih * L.iw + ip;
-    const int bcol = b0 + 16 * mt + 4 * kq;
-    f32x4 v = acc0;
-    if (A.nsrc > 1) { v.x = v.x + acc1.x; v.y = v.y + acc1.y; v.z = v.z + acc1.z; v.w = v.w + acc1.w; }
-    const size_t per_s = (size_t)L.in_feat * B;
-    if (S == 1 && A.ysrc) {
-        const f32x4 y = y_e;
-        v.x = dact_f(v.x, y.x, A.act_src); v.y = dact_f(v.y, y.y, A.act_src); v.z = dact_f(v.z, y.z, A.act_src); v.w = dact_f(v.w, y.w, A.act_src);
-    }
-    *reinterpret_cast<f32x4*>(A.out + (size_t)s * per_s + feat * B + bcol) = v;
-}
-// Dense dueling join with the two sources advancing CONCURRENTLY: waves 0-1 contract source 0 (val), waves 2-3 source 1 (adv), each
-// wave owning one 16-feature tile and both 16-sample tiles, so the serial chain of a workgroup is N/32 K tiles instead of 2*N/32;
-// the accumulators meet through LDS at the end as (val + adv) -- the same per-source chains and the same final addition as the
-// sequential body above, hence identical bits.  (FC-pair backward of config 2: 32 -> 16 K tiles on the critical path.)
-__device__ __forceinline__ void dx_lds_body_pj(const LayerDev& L, const GDxArgs& A, int B, int bid, int nblocks, int by) {
-    extern __shared__ float lds[];
-    float* As = lds;                                  // [2 buf][2 src][32][X_SA]
-    float* Bs = lds + 2 * 2 * 32 * X_SA;              // [2 buf][2 src][32][X_SB]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
-    const int ft = wave & 1, src = wave >> 1;
-    const int b0 = by * 32;
-    const int w = xcd_remap(bid, nblocks);
-    const int ftiles = (L.K + 31) / 32, f0 = (w % ftiles) * 32, nfeat = L.K;
-    const int nkt = L.N / 32;
-    const int row = tid >> 3, f4 = tid & 7;
-    const int frow = min(f0 + row, nfeat - 1);
-    struct Stage { f32x4 a0, b0, a1, b1; };
-    auto gld = [](const float* ptr) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory"); return v; };
-    auto gload = [&](int kt, Stage& r) {
-        kt = min(kt, nkt - 1);
-        const int nb = kt * 32;
-        r.a0 = gld(A.src[0].dpre + (size_t)(nb + row) * B + b0 + 4 * f4);
-        r.b0 = gld(A.src[0].W + (size_t)frow * L.N + nb + 4 * f4);
-        r.a1 = gld(A.src[1].dpre + (size_t)(nb + row) * B + b0 + 4 * f4);
-        r.b1 = gld(A.src[1].W + (size_t)frow * L.N + nb + 4 * f4);
-    };
-    auto lstore = [&](int buf, const Stage& r) {
-        *reinterpret_cast<f32x4*>(As + ((buf * 2 + 0) * 32 + row) * X_SA + 4 * f4) = r.a0;
-        *reinterpret_cast<f32x4*>(Bs + ((buf * 2 + 0) * 32 + row) * X_SB + 4 * f4) = r.b0;
-        *reinterpret_cast<f32x4*>(As + ((buf * 2 + 1) * 32 + row) * X_SA + 4 * f4) = r.a1;
-        *reinterpret_cast<f32x4*>(Bs + ((buf * 2 + 1) * 32 + row) * X_SB + 4 * f4) = r.b1;
-    };
-#define STAGE_WAIT4(N, r) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r.a0), "+v"(r.b0), "+v"(r.a1), "+v"(r.b1) : "n"(N) : "memory")
-    f32x4 accm0 = {0.f, 0.f, 0.f, 0.f}, accm1 = {0.f, 0.f, 0.f, 0.f};      // sample tiles 0 and 1 of this wave's (source, feature tile)
-    // epilogue operands of the source-0 waves, requested up front
-    const int fl = f0 + 16 * ft + l15;
-    const size_t feat = (size_t)min(fl, nfeat - 1);
-    f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = {0.f, 0.f, 0.f, 0.f};
-    if (src == 0 && A.ysrc) { y0 = *reinterpret_cast<const f32x4*>(A.ysrc + feat * A.ldy + b0 + 4 * kq); y1 = *reinterpret_cast<const f32x4*>(A.ysrc + feat * A.ldy + b0 + 16 + 4 * kq); }
-    auto compute = [&](int buf) {
-        const float* Ab = As + (buf * 2 + src) * 32 * X_SA + l15;
-        const float* Bb = Bs + ((buf * 2 + src) * 32 + 16 * ft + l15) * X_SB + kq;
-        float a0f[8], a1f[8], bf[8];
+    __syncthreads();                                   // every wave is done with its staging tiles: the unit sums alias them
+    f32x4* slot = reinterpret_cast<f32x4*>(lds);       // [unit][accumulator tile][lane]
+    if (active) {
 #pragma unroll
-        for (int st = 0; st < 8; st++) { a0f[st] = Ab[(4 * st + kq) * X_SA]; a1f[st] = Ab[(4 * st + kq) * X_SA + 16]; bf[st] = Bb[4 * st]; }
-#pragma unroll
-        for (int st = 0; st < 8; st++) { accm0 = MFMA(a0f[st], bf[st], accm0); accm1 = MFMA(a1f[st], bf[st], accm1); }
-    };
-    Stage r0, r1;
-    gload(0, r0); STAGE_WAIT4(0, r0); lstore(0, r0); __syncthreads();
-    gload(1, r0);
-    for (int kt = 0; kt < nkt; kt += 2) {
-        gload(kt + 2, r1);
-        compute(0);
-        STAGE_WAIT4(4, r0); lstore(1, r0);
-        __syncthreads();
-        gload(kt + 3, r0);
-        if (kt + 1 < nkt) compute(1);
-        STAGE_WAIT4(4, r1); lstore(0, r1);
-        __syncthreads();
+        for (int j = 0; j < 4; j++) slot[(wave * 4 + j) * 64 + lane] = acc[j];
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#undef STAGE_WAIT4
-    // ---- join: the source-1 waves hand their accumulators over through LDS (the tiles are dead after the last barrier)
-    f32x4* xch = reinterpret_cast<f32x4*>(lds);       // [2 ft][2 mt][64 lanes]
-    if (src == 1) { xch[(ft * 2 + 0) * 64 + lane] = accm0; xch[(ft * 2 + 1) * 64 + lane] = accm1; }
     __syncthreads();
-    if (src == 1 || fl >= nfeat) return;
-    const f32x4 o0 = xch[(ft * 2 + 0) * 64 + lane], o1 = xch[(ft * 2 + 1) * 64 + lane];
-    f32x4 v0 = accm0, v1 = accm1;
-    v0.x = v0.x + o0.x; v0.y = v0.y + o0.y; v0.z = v0.z + o0.z; v0.w = v0.w + o0.w;
-    v1.x = v1.x + o1.x; v1.y = v1.y + o1.y; v1.z = v1.z + o1.z; v1.w = v1.w + o1.w;
-    if (A.ysrc) {
-        v0.x = dact_f(v0.x, y0.x, A.act_src); v0.y = dact_f(v0.y, y0.y, A.act_src); v0.z = dact_f(v0.z, y0.z, A.act_src); v0.w = dact_f(v0.w, y0.w, A.act_src);
-        v1.x = dact_f(v1.x, y1.x, A.act_src); v1.y = dact_f(v1.y, y1.y, A.act_src); v1.z = dact_f(v1.z, y1.z, A.act_src); v1.w = dact_f(v1.w, y1.w, A.act_src);
+    if (fl >= nfeat) return;
+    // wave w finishes accumulator tile w = (sample tile mt, feature tile ft): chunk sums ascending per source, then the two sources
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int si = 0; si < A.nsrc; si++) {
+        f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < nch; c++) {
+            const f32x4 x = slot[((si * nch + c) * 4 + wave) * 64 + lane];
+            if (c == 0) tot = x; else { tot.x = tot.x + x.x; tot.y = tot.y + x.y; tot.z = tot.z + x.z; tot.w = tot.w + x.w; }
+        }
+        if (si == 0) v = tot; else { v.x = v.x + tot.x; v.y = v.y + tot.y; v.z = v.z + tot.z; v.w = v.w + tot.w; }
     }
-    *reinterpret_cast<f32x4*>(A.out + (size_t)fl * B + b0 + 4 * kq) = v0;
-    *reinterpret_cast<f32x4*>(A.out + (size_t)fl * B + b0 + 16 + 4 * kq) = v1;
+    if (A.ysrc) { v.x = dact_f(v.x, y_e.x, A.act_src); v.y = dact_f(v.y, y_e.y, A.act_src); v.z = dact_f(v.z, y_e.z, A.act_src); v.w = dact_f(v.w, y_e.w, A.act_src); }
+    const size_t featx = dense ? (size_t)fl : (size_t)fl * L.ih * L.iw + ip;
+    *reinterpret_cast<f32x4*>(A.out + featx * B + b0 + 16 * mt + 4 * kq) = v;
 }
 // Large batches (B % 128 == 0): 32 features x 128 SAMPLES per workgroup.  Wave w owns samples 32w..32w+31 and both 16-feature tiles: four
 // accumulator tiles per source, 32 MFMAs per K tile and wave between two barriers instead of 8, and the conv prologue (tap list) is paid once
@@ -719,7 +693,7 @@ __device__ __forceinline__ void dx_lds_body_wide(const LayerDev& L, const GDxArg
     auto lstore = [&](int buf, const Stage& r) {
 #pragma unroll
         for (int p = 0; p < 4; p++) *reinterpret_cast<f32x4*>(As + (buf * 32 + arow + 8 * p) * X_SAW + 4 * af4) = r.a[p];
-        *reinterpret_cast<f32x4*>(Bs + (buf * 32 + brow) * X_SB + 4 * bf4) = r.b;
+        lds_st4(Bs + (buf * 32 + brow) * X_SB + 4 * bf4, r.b);
     };
 #define STAGE_WAITW(N, r) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.b) : "n"(N) : "memory")
     f32x4 acc[2][2][2];                               // [source][feature tile][sample tile]
@@ -780,25 +754,40 @@ __device__ __forceinline__ void dx_lds_body_wide(const LayerDev& L, const GDxArg
         }
     }
 }
-static bool dx_parallel_join(const LayerDev& L, int nsrc, int S) { return nsrc == 2 && S == 1 && L.kind == DQN_LAYER_DENSE && (L.N / 32) % 2 == 0; }
-// dX body of a launch: 0 = 32 x 32 tiles, 1 = parallel dueling join, 2 = 32 features x 128 samples (large batches)
-static int dx_mode(const LayerDev& L, int nsrc, int S, int B) {
+// most non-empty tap chunks any input position of a conv layer can have: per stride-parity class (ky = iy mod sh, kx = ix mod sw) the distinct
+// chunk ids among its taps (edge positions see subsets)
+static int conv_max_chunks(const LayerDev& L) {
+    const int tc = DQN_CONV_TAP_CHUNK(L); int best = 0;
+    for (int py = 0; py < L.sh; py++) for (int px = 0; px < L.sw; px++) {
+        int last = -1, n = 0;
+        for (int ky = py; ky < L.kh; ky += L.sh) for (int kx = px; kx < L.kw; kx += L.sw) { const int c = (ky * L.kw + kx) / tc; if (c != last) { n++; last = c; } }
+        if (n > best) best = n;
+    }
+    return best;
+}
+// dX body of a launch: 2 = 32 features x 128 samples per workgroup (large batches; dense plan chunks go through slabs, conv taps unchunked),
+// 3 = 32 x 32 tiles with one wave per (source, chunk) unit (dx_units_body; chunks combined in the workgroup), -1 = not covered by the LDS kernels
+static int dx_mode(const LayerDev& L, int nsrc, int B, int ldy) {
     static const bool no_wide = getenv("DQN_NO_DX_WIDE") != nullptr;
-    if (dx_parallel_join(L, nsrc, S)) return 1;
-    return (B % 128 == 0 && !no_wide) ? 2 : 0;
+    const bool dense = L.kind == DQN_LAYER_DENSE;
+    const int S = dense ? dqn_nchunks(L.N, L.dx_kc) : 1, kc = dqn_chunk_len(L.N, L.dx_kc);
+    if (B % 32 || ldy % 4 || L.N % 32 || (S > 1 && kc % 32) || L.w_off % 4) return -1;
+    if (!dense && (L.cin % 32 || L.kh * L.kw > 64 || L.npos > 65535)) return -1;
+    const int nch = dense ? S : conv_max_chunks(L);
+    if (B % 128 == 0 && !no_wide && (dense || nch <= 1) && (nsrc == 1 || S == 1)) return 2;
+    if (nsrc * nch <= U_MAX) return 3;
+    return -1;
 }
 static int dx_cols(int mode) { return mode == 2 ? 128 : 32; }
 static size_t dx_lds_bytes(int mode) {
-    if (mode == 1) return (size_t)(2 * 2 * 32 * X_SA + 2 * 2 * 32 * X_SB) * 4;
     if (mode == 2) return (size_t)(2 * 32 * X_SAW + 2 * 32 * X_SB) * 4 + 256 * 4;
-    return (size_t)(2 * 32 * X_SA + 2 * 32 * X_SB) * 4 + 256 * 4;
+    return dx_units_lds_bytes();
 }
 
 __global__ __launch_bounds__(256) void k_dx_lds(LayerDev L, GDxArgs A, int B, int S, int kc, int pj, int gx, GemmTail tail) {
     GEMM_TAIL_PROLOGUE(tail, bid, main_blocks)
-    if (pj == 1) dx_lds_body_pj(L, A, B, bid % gx, gx, bid / gx);
-    else if (pj == 2) dx_lds_body_wide(L, A, B, S, kc, bid % gx, gx, bid / gx);
-    else dx_lds_body(L, A, B, S, kc, bid % gx, gx, bid / gx);
+    if (pj == 2) dx_lds_body_wide(L, A, B, S, kc, bid % gx, gx, bid / gx);
+    else dx_units_body(L, A, B, S, kc, bid % gx, gx, bid / gx);
 }
 // dW and dX of one layer are independent given dpre: ONE launch runs both (blocks [0, dw_blocks) do dW, the rest dX), which
 // saves a dispatch and lets the latency-bound dX workgroups share the machine with the dW ones.
@@ -815,31 +804,26 @@ __global__ __launch_bounds__(256) void k_dwdx_lds(LayerDev Lw, GDwProbs pr, int 
     const int bid = (int)blockIdx.x - pre_, ntail = (int)gemm_tail_blocks(tail) - pre_;
     const int dx_blocks = (int)gridDim.x - pre_ - ntail - dw_blocks;
     if (bid < dx_blocks) {
-        if (pj == 1) dx_lds_body_pj(Lx, A, B, bid % dx_gx, dx_gx, bid / dx_gx);
-        else if (pj == 2) dx_lds_body_wide(Lx, A, B, Sx, kcx, bid % dx_gx, dx_gx, bid / dx_gx);
-        else dx_lds_body(Lx, A, B, Sx, kcx, bid % dx_gx, dx_gx, bid / dx_gx);
+        if (pj == 2) dx_lds_body_wide(Lx, A, B, Sx, kcx, bid % dx_gx, dx_gx, bid / dx_gx);
+        else dx_units_body(Lx, A, B, Sx, kcx, bid % dx_gx, dx_gx, bid / dx_gx);
         if (trs_) tr_[trs_ + 3] = 1;
     }
     else if (bid < dx_blocks + ntail) { gemm_tail_run(tail, (unsigned)(bid - dx_blocks)); if (trs_) tr_[trs_ + 3] = 2; }
     else { dw_lds_body<NT>(Lw, pr, nprob, ldx, B, Sw, kcw, bid - dx_blocks - ntail, dw_blocks, DwStride{Lw.npos * B, 0, 0}); if (trs_) tr_[trs_ + 3] = 3; }
     KTRACE(7);
 }
-bool gemm_dx_eligible(const LayerDev& L, int B, int ldy) {
-    const bool dense = L.kind == DQN_LAYER_DENSE;
-    const int S = dense ? dqn_nchunks(L.N, L.dx_kc) : 1, kc = dqn_chunk_len(L.N, L.dx_kc);
-    if (B % 32 || ldy % 4 || L.N % 32 || (S > 1 && kc % 32) || L.w_off % 4) return false;
-    if (!dense && (L.cin % 32 || L.kh * L.kw > 64 || L.npos > 65535)) return false;
-    return true;
-}
-// nsrc == 2: the two dueling streams (identical geometry, S == 1), out = dact(dX_src0 + dX_src1)
+bool gemm_dx_eligible(const LayerDev& L, int B, int ldy, int nsrc) { return dx_mode(L, nsrc, B, ldy) >= 0; }
+// true: the plan chunks of this dX are contracted and combined INSIDE the launch (no partial slabs, no reduce launch)
+bool gemm_dx_internal_chunks(const LayerDev& L, int B, int ldy, int nsrc) { return dx_mode(L, nsrc, B, ldy) == 3; }
+// nsrc == 2: the two dueling streams (identical geometry), out = dact(dX_src0 + dX_src1)
 void launch_gemm_dx(hipStream_t st, const LayerDev& L, int nsrc, const float* const* W, const float* const* dpre, int B, float* out,
                     const float* ysrc, int ldy, int act_src, GemmTail tail) {
     const bool dense = L.kind == DQN_LAYER_DENSE;
     const int S = dense ? dqn_nchunks(L.N, L.dx_kc) : 1, kc = dqn_chunk_len(L.N, L.dx_kc);
     GDxArgs a; a.nsrc = nsrc; a.out = out; a.ysrc = ysrc; a.ldy = ldy; a.act_src = act_src;
     for (int i = 0; i < 2; i++) { const int j = i < nsrc ? i : 0; a.src[i].W = W[j]; a.src[i].dpre = dpre[j]; }
-    const int gx = dense ? ((L.K + 31) / 32) * S : (L.cin / 32) * L.ih * L.iw;
-    const int pj = dx_mode(L, nsrc, S, B);
+    const int pj = dx_mode(L, nsrc, B, ldy);
+    const int gx = dense ? ((L.K + 31) / 32) * (pj == 2 ? S : 1) : (L.cin / 32) * L.ih * L.iw;
     hipLaunchKernelGGL(k_dx_lds, dim3(gx * (B / dx_cols(pj)) + gemm_tail_blocks(tail)), dim3(256), dx_lds_bytes(pj), st, L, a, B, S, kc, pj, gx, tail);
 }
 
@@ -854,8 +838,8 @@ void launch_gemm_dwdx(hipStream_t st, const LayerDev& Lw, int nprob, const float
     const int Sx = dense ? dqn_nchunks(Lx.N, Lx.dx_kc) : 1, kcx = dqn_chunk_len(Lx.N, Lx.dx_kc);
     GDxArgs a; a.nsrc = nsrc; a.out = out_x; a.ysrc = ysrc; a.ldy = ldy; a.act_src = act_src;
     for (int i = 0; i < 2; i++) { const int j = i < nsrc ? i : 0; a.src[i].W = W[j]; a.src[i].dpre = dpre_x[j]; }
-    const int gx = dense ? ((Lx.K + 31) / 32) * Sx : (Lx.cin / 32) * Lx.ih * Lx.iw;
-    const int pj = dx_mode(Lx, nsrc, Sx, B);
+    const int pj = dx_mode(Lx, nsrc, B, ldy);
+    const int gx = dense ? ((Lx.K + 31) / 32) * (pj == 2 ? Sx : 1) : (Lx.cin / 32) * Lx.ih * Lx.iw;
     const size_t lds_w = (size_t)(2 * 64 * W_ST + 2 * 16 * NT * W_ST) * 4, lds_x = dx_lds_bytes(pj);
     const size_t lds = lds_w > lds_x ? lds_w : lds_x;
     const int grid = dw_blocks + gx * (B / dx_cols(pj)) + (int)gemm_tail_blocks(tail);

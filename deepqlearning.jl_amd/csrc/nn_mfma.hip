@@ -148,7 +148,7 @@ bool launch_mfma_fwd(hipStream_t st, const LayerDev& L, const float* P, const fl
 
 // ------------------------------------------------------------------ dX (then act' of the producing layer, + addend at the dueling join)
 //   dense: dX[f][b] = sum_n dpre[n][b] W[f][n]                        (chunks over n per plan.dx_kc)
-//   conv : dX[ci][iy][ix][b] = sum_{valid taps (ky,kx)} sum_co dpre[co][oy][ox][b] W[(ci,ky,kx)][co]   (unsplit)
+//   conv : dX[ci][iy][ix][b] = sum_{valid taps (ky,kx)} sum_co dpre[co][oy][ox][b] W[(ci,ky,kx)][co]   (chunks of RAW taps per plan.dx_kc)
 template <int MT>
 __global__ __launch_bounds__(256) void k_mfma_dx(LayerDev L, const float* __restrict__ P, const float* __restrict__ dpre, int B, int S, int kc,
                                                  float* __restrict__ out, const float* __restrict__ addend, const float* __restrict__ ysrc, int ldy,
@@ -193,10 +193,23 @@ __global__ __launch_bounds__(256) void k_mfma_dx(LayerDev L, const float* __rest
         const int ctiles = L.cin / 16; const int ct = task % ctiles; const int ip = task / ctiles;
         const int iy = ip / L.iw, ix = ip % L.iw; const int ci = ct * 16 + l15;
         feat = (size_t)ci * L.ih * L.iw + ip;
+        // plan.dx_kc: RAW taps per chunk; a chunk = one chain from +0 over its valid taps, chunk sums added in ascending order
+        const int tc = DQN_CONV_TAP_CHUNK(L); int cur = -1; bool have = false; f32x4 tot[MT];
+#pragma unroll
+        for (int m = 0; m < MT; m++) tot[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int ky = 0; ky < L.kh; ky++) {
             const int ty = iy - ky; if (ty < 0 || ty % L.sh) continue; const int oy = ty / L.sh; if (oy >= L.oh) continue;
             for (int kx = 0; kx < L.kw; kx++) {
                 const int tx = ix - kx; if (tx < 0 || tx % L.sw) continue; const int ox = tx / L.sw; if (ox >= L.ow) continue;
+                const int cid = (ky * L.kw + kx) / tc;
+                if (cid != cur) {
+                    if (cur >= 0) {
+#pragma unroll
+                        for (int m = 0; m < MT; m++) { if (have) { tot[m].x = tot[m].x + acc[m].x; tot[m].y = tot[m].y + acc[m].y; tot[m].z = tot[m].z + acc[m].z; tot[m].w = tot[m].w + acc[m].w; } else tot[m] = acc[m]; acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+                        have = true;
+                    }
+                    cur = cid;
+                }
                 const float* wr = W + (size_t)((ci * L.kh + ky) * L.kw + kx) * L.N;
                 const float* dp = dpre + (size_t)(oy * L.ow + ox) * B + b0 + l15;
                 constexpr int U = 16;
@@ -221,6 +234,10 @@ __global__ __launch_bounds__(256) void k_mfma_dx(LayerDev L, const float* __rest
                     for (int m = 0; m < MT; m++) acc[m] = MFMA(dp[(size_t)co * L.npos * B + 16 * m], b, acc[m]);
                 }
             }
+        }
+        if (have) {
+#pragma unroll
+            for (int m = 0; m < MT; m++) { acc[m].x = tot[m].x + acc[m].x; acc[m].y = tot[m].y + acc[m].y; acc[m].z = tot[m].z + acc[m].z; acc[m].w = tot[m].w + acc[m].w; }
         }
     }
     const size_t per_s = (size_t)L.in_feat * B;

@@ -129,14 +129,19 @@ __device__ __forceinline__ void valu_dx_body(const LayerDev& L, const float* __r
         for (int n = n0; n < n1; n++) acc = fmaf(dpre[(size_t)n * B + b], W[(size_t)feat * L.N + n], acc);
     } else {
         const int hw = L.ih * L.iw; const int ci = feat / hw, iy = (feat % hw) / L.iw, ix = feat % L.iw;
+        // plan.dx_kc: RAW taps (ky*kw + kx) per chunk; a chunk = one chain from +0 over its valid taps, chunk sums added in ascending order
+        const int tc = DQN_CONV_TAP_CHUNK(L); int cur = -1; bool have = false; float tot = 0.0f;
         for (int ky = 0; ky < L.kh; ky++) {
             const int ty = iy - ky; if (ty < 0 || ty % L.sh) continue; const int oy = ty / L.sh; if (oy >= L.oh) continue;
             for (int kx = 0; kx < L.kw; kx++) {
                 const int tx = ix - kx; if (tx < 0 || tx % L.sw) continue; const int ox = tx / L.sw; if (ox >= L.ow) continue;
+                const int cid = (ky * L.kw + kx) / tc;
+                if (cid != cur) { if (cur >= 0) { tot = have ? tot + acc : acc; have = true; acc = 0.0f; } cur = cid; }
                 const float* wr = W + (size_t)((ci * L.kh + ky) * L.kw + kx) * L.N; const int pos = oy * L.ow + ox;
                 for (int co = 0; co < L.N; co++) acc = fmaf(dpre[((size_t)co * L.npos + pos) * B + b], wr[co], acc);
             }
         }
+        if (have) acc = tot + acc;
     }
     if (S == 1) {
         if (addend) acc = addend[e] + acc;

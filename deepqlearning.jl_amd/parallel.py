@@ -77,13 +77,15 @@ class Group:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return (t / self.world).cpu().numpy()
 
-    def attach_engine(self, pkg, engine):
-        """create the engine's RCCL communicator: rank 0 makes the id, everyone joins."""
+    def attach_engine(self, pkg, engine, init_comm=True):
+        """create the engine's RCCL communicator: rank 0 makes the id, everyone joins.  init_comm=False (bench.py's one-GPU self-test of the
+        N > 1 script path, engines created under DQN_SIM_WORLD): the id is still made and broadcast, only ncclCommInitRank is skipped."""
         if self.world == 1:
             return
         uid = pkg.comm_unique_id() if self.rank == 0 else None
         uid = self.bcast_bytes(uid, 128, 0)
-        engine.comm_init(uid, self.rank, self.world)
+        if init_comm:
+            engine.comm_init(uid, self.rank, self.world)
 
     def close(self):
         if self.world > 1 and self.dist.is_initialized():

@@ -66,7 +66,7 @@ typedef struct {
  * fixes rounding order; DESIGN.md section 4 states it. */
 typedef struct {
     int32_t fwd_kc; /* forward:  K = n_in            | cin*kh*kw           */
-    int32_t dx_kc;  /* dX:       K = n_out           | (conv: never split)  */
+    int32_t dx_kc;  /* dX:       K = n_out           | conv: RAW kernel taps (ky*kw + kx ascending) per chunk; each chunk chains its VALID taps, co innermost */
     int32_t dw_kc;  /* dW, db:   K = batch           | out_positions*batch  */
 } dqn_layer_plan;
 

@@ -125,22 +125,29 @@ static inline void philox(uint32_t k0, uint32_t k1, uint32_t c[4]) {
 int ref_plan_default(const dqn_layer_desc* d, int n, const dqn_hparams* hp, dqn_layer_plan* out) {
     /* independent restatement of the rule in DESIGN.md section 4 (the tests check it
      * equals dqn_plan_default of the product) */
-    int c = hp->obs_c, h = hp->obs_h, w = hp->obs_w; int bc = c, bh = h, bw = w; int seen_val = 0, seen_adv = 0;
+    int c = hp->obs_c, h = hp->obs_h, w = hp->obs_w; int bc = c, bh = h, bw = w; int seen_val = 0, seen_adv = 0, has_base = 0;
     for (int i = 0; i < n; i++) {
-        if (d[i].stream == DQN_STREAM_VAL && !seen_val) { seen_val = 1; c = bc; h = bh; w = bw; }
-        if (d[i].stream == DQN_STREAM_ADV && !seen_adv) { seen_adv = 1; c = bc; h = bh; w = bw; }
+        int join = 0;      /* first layer of a dueling stream: its dX meets the other stream's at the base output */
+        if (d[i].stream == DQN_STREAM_VAL && !seen_val) { seen_val = 1; c = bc; h = bh; w = bw; join = has_base; }
+        if (d[i].stream == DQN_STREAM_ADV && !seen_adv) { seen_adv = 1; c = bc; h = bh; w = bw; join = has_base; }
         int K, posB;
         if (d[i].kind == DQN_LAYER_CONV) {
             int oh = (h - d[i].kh) / d[i].sh + 1, ow = (w - d[i].kw) / d[i].sw + 1;
             K = d[i].cin * d[i].kh * d[i].kw; c = d[i].cout; h = oh; w = ow; posB = 1;
         } else { K = d[i].n_in; c = d[i].n_out; h = 1; w = 1; posB = 0; }
-        if (d[i].stream == DQN_STREAM_BASE) { bc = c; bh = h; bw = w; }
+        if (d[i].stream == DQN_STREAM_BASE) { bc = c; bh = h; bw = w; has_base = 1; }
         int B = hp->batch_size; const int nout = d[i].kind == DQN_LAYER_LSTM ? 4 * d[i].n_out : d[i].n_out;
         out[i].fwd_kc = 0;
         if (K > 1024) { int s = (K + 511) / 512; int kc = (K + s - 1) / s; kc = (kc + 3) / 4 * 4; out[i].fwd_kc = kc; }
         else if (d[i].kind == DQN_LAYER_DENSE && d[i].n_out < 16 && K >= 128) out[i].fwd_kc = 32;
         out[i].dx_kc = 0;
         if (d[i].kind != DQN_LAYER_CONV && nout > 512) out[i].dx_kc = 256;
+        else if (d[i].kind == DQN_LAYER_DENSE && B <= 64 && nout >= 128) {      /* small batches: 4 concurrent chains per output tile (2 per stream at the dueling join) */
+            int S = join ? 2 : 4; int kc = ((nout + S - 1) / S + 31) / 32 * 32; if (kc < nout) out[i].dx_kc = kc;
+        } else if (d[i].kind == DQN_LAYER_CONV && B <= 64) {                    /* RAW taps per chunk so that an interior position has <= 4 non-empty chunks */
+            int valid = ((d[i].kh + d[i].sh - 1) / d[i].sh) * ((d[i].kw + d[i].sw - 1) / d[i].sw); int raw = ((valid + 3) / 4) * d[i].sw;
+            if (raw < d[i].kh * d[i].kw) out[i].dx_kc = raw;
+        }
         out[i].dw_kc = 0;
         if (d[i].kind == DQN_LAYER_DENSE && d[i].n_out < 16 && B >= 128) out[i].dw_kc = 64;
         if (posB) { int mrows = (K + 63) / 64; int st = (512 + mrows - 1) / mrows; int ppc = (h * w) / st; if (ppc < 1) ppc = 1; out[i].dw_kc = ppc * B; }
@@ -440,7 +447,7 @@ static void layer_backward_w(const RLayer* L, const float* X, int ldx, const flo
         db[n] = tot;
     }
 }
-/* dX[in_feat][B] = W * dpre (dense: chunks over n; conv: valid taps (ky,kx) ascending, co innermost, unsplit) */
+/* dX[in_feat][B] = W * dpre (dense: chunks over n; conv: valid taps (ky,kx) ascending, co innermost, chunks of RAW taps per plan.dx_kc) */
 static void layer_backward_x(const RLayer* L, const float* P, const float* dpre, int B, float* dX) {
     const float* W = P + L->w_off; const int N = L->N;
     if (L->kind == DQN_LAYER_DENSE) {
@@ -462,20 +469,30 @@ static void layer_backward_x(const RLayer* L, const float* P, const float* dpre,
         return;
     }
     const int npos = L->oh * L->ow;
+    /* plan.dx_kc > 0 cuts the RAW tap list (index ky*kw + kx, ascending) into chunks of dx_kc taps: each chunk is one fma chain from +0 over its
+     * VALID taps (co innermost), chunk sums are added in ascending chunk order; chunks without a valid tap contribute nothing */
+    const int tc = (L->plan.dx_kc > 0 && L->plan.dx_kc < L->kh * L->kw) ? L->plan.dx_kc : L->kh * L->kw;
 #pragma omp parallel for collapse(2) schedule(static)
     for (int ci = 0; ci < L->cin; ci++) for (int ip = 0; ip < L->ih * L->iw; ip++) {
-        int iy = ip / L->iw, ix = ip % L->iw; float acc[1024];
+        int iy = ip / L->iw, ix = ip % L->iw; float acc[1024], tot[1024];
         for (int c0 = 0; c0 < B; c0 += 1024) {
             int nc = B - c0 < 1024 ? B - c0 : 1024;
+            int cur = -1, have = 0;
             for (int b = 0; b < nc; b++) acc[b] = 0.0f;
             for (int ky = 0; ky < L->kh; ky++) {
                 int ty = iy - ky; if (ty < 0 || ty % L->sh) continue; int oy = ty / L->sh; if (oy >= L->oh) continue;
                 for (int kx = 0; kx < L->kw; kx++) {
                     int tx = ix - kx; if (tx < 0 || tx % L->sw) continue; int ox = tx / L->sw; if (ox >= L->ow) continue;
+                    const int cid = (ky * L->kw + kx) / tc;
+                    if (cid != cur) {
+                        if (cur >= 0) { if (have) for (int b = 0; b < nc; b++) tot[b] = tot[b] + acc[b]; else for (int b = 0; b < nc; b++) tot[b] = acc[b]; have = 1; for (int b = 0; b < nc; b++) acc[b] = 0.0f; }
+                        cur = cid;
+                    }
                     const size_t krow = (size_t)((ci * L->kh + ky) * L->kw + kx) * N; const int pos = oy * L->ow + ox;
                     for (int co = 0; co < N; co++) { const float w = W[krow + co]; const float* d = dpre + ((size_t)co * npos + pos) * B + c0; for (int b = 0; b < nc; b++) acc[b] = fmaf(d[b], w, acc[b]); }
                 }
             }
+            if (have) for (int b = 0; b < nc; b++) acc[b] = tot[b] + acc[b];
             for (int b = 0; b < nc; b++) dX[((size_t)ci * L->ih * L->iw + ip) * B + c0 + b] = acc[b];
         }
     }
