@@ -30,11 +30,11 @@ __device__ __forceinline__ float adam_upd(float gi, float& mi, float& vi, float&
 }
 // workgroup `bid` (256 threads) of job J.  sidx: 1024 long longs of LDS for the priority block (unused when the job has none or it runs
 // elsewhere); wmax: 4 floats of LDS.
-__device__ __forceinline__ void adam_job_run(const AdamJob& J, int bid, long long* sidx, float* wmax, bool prio_elsewhere = false) {
+__device__ __forceinline__ void adam_job_run(const AdamJob& J, int bid, long long* sidx, float* wmax, bool prio_elsewhere = false, unsigned sidx_bytes = 0) {
     if (J.prio.n > 0 && !prio_elsewhere) {
         // update_priorities!(replay, indices, td): one DEDICATED workgroup walks the sum-tree while the others stream -- its latency-bound
         // levels ride inside a longer launch instead of costing one of their own; the tree is next read by the following step's sampler
-        if (bid == 0) { prio_block_run(J.prio, J.state, sidx); return; }
+        if (bid == 0) { prio_block_run(J.prio, J.state, sidx, sidx_bytes); return; }
         bid--;
     }
     // beta powers are double-buffered by step parity: this step reads slot (step & 1); the job with `tick` writes slot ((step+1) & 1)

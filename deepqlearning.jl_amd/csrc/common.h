@@ -213,15 +213,143 @@ __device__ __forceinline__ long long tree_descend(const float* __restrict__ tree
 }
 #endif
 struct PrioArgs { int n; long long cap2; const long long* idx; const float* td; float eps, alpha; float* tree;
-                  long long* idx_pre; unsigned long long seed; int B; };      // idx_pre != nullptr: also draw the next step's B indices (see prio_block_run)
+                  long long* idx_pre; unsigned long long seed; int B;       // idx_pre != nullptr: also draw the next step's B indices (see prio_block_run)
+                  int phase; };                                          // prio_block_fast only: 0 = update + draw, 1 = update, 2 = draw (split over two launches of one step)
 #ifdef __HIPCC__
 // the priority workgroup of a step: update_priorities!(replay, idx, td), then -- the tree is final and the Philox counter of the next sample()
 // is known (k_td / k_head_td bumped it earlier in this step) -- the NEXT step's B stratified descents, so that the next gather launch starts
 // with its row loads instead of ~5 dependent round trips per workgroup.  Anything that touches the tree, the size or the counters before
 // that gather clears state->pre_valid and the gather descends itself, exactly as before.
-__device__ __forceinline__ void prio_block_run(const PrioArgs& P, StepState* state, long long* sidx) {
-    prio_update_block(P.n, P.cap2, P.idx, P.td, P.eps, P.alpha, P.tree, state, sidx);
-    if (!P.idx_pre) return;
+// continue a descent from `node` with residual mass t: three levels per memory round trip, exactly tree_descend's decisions
+__device__ __forceinline__ long long tree_descend_from(const float* __restrict__ tree, long long cap2, long long node, float t) {
+    while (8 * node < 2 * cap2) {
+        const float2 c = *reinterpret_cast<const float2*>(tree + 2 * node);
+        const f32x4c g = *reinterpret_cast<const f32x4c*>(tree + 4 * node);
+        const f32x4c h0 = *reinterpret_cast<const f32x4c*>(tree + 8 * node), h1 = *reinterpret_cast<const f32x4c*>(tree + 8 * node + 4);
+        int b1 = 0, b2 = 0, b3 = 0;
+        if (!(t < c.x || !(c.y > 0.0f))) { t -= c.x; b1 = 1; }
+        const float gl = b1 ? g.z : g.x, gr = b1 ? g.w : g.y;
+        if (!(t < gl || !(gr > 0.0f))) { t -= gl; b2 = 1; }
+        const f32x4c hh = b1 ? h1 : h0;
+        const float hl = b2 ? hh.z : hh.x, hr = b2 ? hh.w : hh.y;
+        if (!(t < hl || !(hr > 0.0f))) { t -= hl; b3 = 1; }
+        node = 8 * node + 4 * b1 + 2 * b2 + b3;
+    }
+    if (4 * node < 2 * cap2) {      // two levels left: one round trip
+        const float2 c = *reinterpret_cast<const float2*>(tree + 2 * node);
+        const f32x4c g = *reinterpret_cast<const f32x4c*>(tree + 4 * node);
+        int b1 = 0, b2 = 0;
+        if (!(t < c.x || !(c.y > 0.0f))) { t -= c.x; b1 = 1; }
+        const float gl = b1 ? g.z : g.x, gr = b1 ? g.w : g.y;
+        if (!(t < gl || !(gr > 0.0f))) { t -= gl; b2 = 1; }
+        node = 4 * node + 2 * b1 + b2;
+    }
+    while (node < cap2) {
+        const float l = tree[2 * node], rg = tree[2 * node + 1];
+        if (t < l || !(rg > 0.0f)) node = 2 * node; else { t -= l; node = 2 * node + 1; }
+    }
+    return node;
+}
+// The priority workgroup in FEWER DEPENDENT ROUND TRIPS (small batches: n <= 64 paths, B <= blockDim draws): the top TOPN nodes of the sum-tree
+// are copied into LDS while the index list is fetched, the update patches that copy as it rewrites the ancestors (one wave, no workgroup
+// barrier per level), and the B descents of the next sample() walk the copy -- 11-12 of the 14 levels at 10 000 transitions -- before ONE global
+// round trip finishes them.  Same node arithmetic, same comparisons, same Philox draws as prio_update_block + tree_descend: identical tree,
+// identical indices.  r03 ktrace: the two-phase block lived 10-13 us (9 dependent round trips at 0.7-1.5 us) and bounded whichever backward
+// launch carried it.  lds: 7808 bytes of path state + TOPN floats.
+__device__ __forceinline__ bool prio_block_fast(const PrioArgs& P, StepState* state, long long* lds, unsigned lds_bytes, unsigned long long* ktr = nullptr) {
+    int L = 0; for (long long w = P.cap2; w > 1; w >>= 1) L++;
+    const int n = P.n, B = P.B;
+    if (n < 1 || n > 64 || L > 22 || L < 3 || !P.idx_pre || B > (int)blockDim.x || lds_bytes < 7808 + 64 * 4 || P.cap2 < 64) return false;
+    long long* node = lds;                                 // [64]  leaf node id of path i
+    float* val = reinterpret_cast<float*>(lds + 64);       // [64]  value of path i's node at the current level
+    float* sib = val + 64;                                 // [L][64] prefetched sibling values
+    signed char* sj = reinterpret_cast<signed char*>(sib + 22 * 64);   // [L][64]
+    float* top = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + 7808);          // 16-B aligned (lds is): node ids [0, TOPN)
+    long long topn = 64; { const long long avail = (long long)(lds_bytes - 7808) / 4; while (2 * topn <= avail && 2 * topn <= P.cap2 && 2 * topn <= 8192) topn *= 2; }
+    const int t = threadIdx.x;
+    float* tree = P.tree;
+    const int phase = P.phase;                             // 0: update + draw; 1: update only; 2: draw only (the tree is final: a later launch of the same step)
+    // ---- round trip 1: the index list, the TD errors, the step counters, the top of the tree (all independent).  The Float64 pow of the new
+    // priorities (~1.7 us of dependent arithmetic per lane) runs while the tree copy is in flight.
+    long long my_idx = 0; float my_td = 0.0f; if (t < n && phase != 2) { my_idx = P.idx[t]; my_td = P.td[t]; }
+    const unsigned long long ctr = state->sample_ctr; const long long size = state->size;
+    f32x4c tq[8];                                          // <= 8192 nodes at 256 threads
+    const int nq = (int)((topn / 4 + blockDim.x - 1) / blockDim.x);
+#pragma unroll
+    for (int q = 0; q < 8; q++) if (q < nq) { const long long i = 4 * ((long long)q * blockDim.x + t); if (i < topn) tq[q] = *reinterpret_cast<const f32x4c*>(tree + i); }
+    float my_p = 0.0f;
+    if (t < n && phase != 2) { my_p = prio_f(fabsf(my_td), P.eps, P.alpha); if (!(my_p > 0.0f)) state->err = 2; val[t] = my_p; node[t] = P.cap2 + my_idx; }      // assert all(new_priorities .> 0) (:78)
+#pragma unroll
+    for (int q = 0; q < 8; q++) if (q < nq) { const long long i = 4 * ((long long)q * blockDim.x + t); if (i < topn) *reinterpret_cast<f32x4c*>(top + i) = tq[q]; }
+    __syncthreads();
+    if (ktr) ktr[4] = __builtin_amdgcn_s_memtime();
+    if (phase != 2) {
+    // ---- round trip 2: siblings below the LDS copy; everything above comes out of the copy
+    const float rn = 1.0f / (float)n;
+    for (int q = t; q < n * L; q += blockDim.x) { const int l = (int)(((float)q + 0.5f) * rn), i = q - l * n; const long long sid = (node[i] >> l) ^ 1; sib[l * 64 + i] = sid < topn ? top[sid] : tree[sid]; }
+    float leaf_p = 0.0f; int last = t;
+    if (t < n) {
+        for (int l = 0; l < L; l++) sj[l * 64 + t] = -1;
+        const long long mine = node[t];
+        for (int j = 0; j < n; j++) {
+            const long long x = node[j] ^ mine;
+            if (x == 0) { if (j > last) last = j; continue; }
+            sj[(63 - __clzll(x)) * 64 + t] = (signed char)j;
+        }
+        leaf_p = val[last];                                // duplicates: the LAST occurrence decides the leaf (:79); every occurrence carries that value up
+    }
+    __syncthreads();
+    if (t < n) { val[t] = leaf_p; if (last == t) tree[node[t]] = leaf_p; }
+    __syncthreads();
+    if (ktr) ktr[5] = __builtin_amdgcn_s_memtime();
+    // ---- the ancestors, level by level, by ONE wave (LDS operations of a wave execute in order: no barrier between levels)
+    if (t < 64) {
+        for (int l = 0; l < L; l++) {
+            float parent = 0.0f; long long c = 0;
+            if (t < n) {
+                c = node[t] >> l;
+                const int j = sj[l * 64 + t];
+                const float sv = j >= 0 ? val[j] : sib[l * 64 + t];
+                parent = (c & 1) ? sv + val[t] : val[t] + sv;                           // left + right
+            }
+            __builtin_amdgcn_wave_barrier();      // every lane has read this level's val[] before any lane overwrites it
+            if (t < n) { val[t] = parent; tree[c >> 1] = parent; if ((c >> 1) < topn) top[c >> 1] = parent; }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    }
+    if (ktr) ktr[6] = __builtin_amdgcn_s_memtime();
+    if (phase == 1) return true;
+    // ---- the next sample(): B stratified descents; the LDS copy serves the levels whose children it holds
+    if (t < B) {
+        const float seg = top[1] / (float)B;
+        uint32_t c4[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)t, 0x5A4D504Cu};
+        philox4x32_10((uint32_t)P.seed, (uint32_t)(P.seed >> 32), c4);
+        const float u = (float)(c4[0] >> 8) * (1.0f / 16777216.0f);
+        float m = ((float)t + u) * seg;
+        long long nd = 1;
+        while (2 * nd + 1 < topn) {
+            const float l = top[2 * nd], rg = top[2 * nd + 1];
+            if (m < l || !(rg > 0.0f)) nd = 2 * nd; else { m -= l; nd = 2 * nd + 1; }
+        }
+        nd = tree_descend_from(tree, P.cap2, nd, m);
+        long long leaf = nd - P.cap2; if (leaf >= size) leaf = size - 1;
+        P.idx_pre[t] = leaf;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) state->pre_valid = 1;
+    return true;
+}
+// the priority workgroup of a step: update_priorities!(replay, idx, td), then -- the tree is final and the Philox counter of the next sample()
+// is known (k_td / k_head_td bumped it earlier in this step) -- the NEXT step's B stratified descents, so that the next gather launch starts
+// with its row loads instead of ~5 dependent round trips per workgroup.  Anything that touches the tree, the size or the counters before
+// that gather clears state->pre_valid and the gather descends itself, exactly as before.  lds_bytes: LDS behind `sidx` (0: unknown -- the
+// two-phase form, which needs 8 KB).
+__device__ __forceinline__ void prio_block_run(const PrioArgs& P, StepState* state, long long* sidx, unsigned lds_bytes = 0, unsigned long long* ktr = nullptr) {
+    if (lds_bytes && prio_block_fast(P, state, sidx, lds_bytes, ktr)) return;
+    if (P.phase != 2) prio_update_block(P.n, P.cap2, P.idx, P.td, P.eps, P.alpha, P.tree, state, sidx);
+    if (!P.idx_pre || P.phase == 1) return;
     __syncthreads();
     const unsigned long long ctr = state->sample_ctr; const long long size = state->size;
     const float seg = P.tree[1] / (float)P.B;
@@ -339,7 +467,7 @@ void launch_convert_params(hipStream_t st, const LayerDev* layers_dev, int nl, c
 
 // LDS-tiled MFMA path (nn_gemm.hip): up to two problems (online / target net) of one layer per launch
 bool gemm_fwd_eligible(const LayerDev& L, int nprob, const int* ldx, const int* col0, const int* ncols);
-void gemm_set_ktrace(unsigned long long* p);   // debug: per-workgroup timestamps of the forward kernels (nullptr = off)
+int gemm_set_ktrace(unsigned long long* p);   // debug (-DDQN_KTRACE builds): per-workgroup timestamps of the LDS-tiled kernels (nullptr = off); -1 = not a trace build
 void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* const* W, const float* const* bias, const float* const* X,
                      const int* ldx, const int* col0, const int* ncols, float* const* out /* Y, or split-K partial slabs */);
 
@@ -453,7 +581,8 @@ void launch_dp_unpack_sum(hipStream_t st, const DpSumArgs& a);
 // which computes bit-identical values)
 bool gemm_dw_eligible(const LayerDev& L, int B, int ldx);
 // a TAIL riding in the last workgroups of an LDS-tiled launch: small independent VALU tasks (valu_tasks.h), then (has_adam) an Adam job
-struct GemmTail { const VTask* tasks; int n; unsigned blocks; int has_adam; AdamJob adam; };
+struct GemmTail { const VTask* tasks; int n; unsigned blocks; int has_adam; AdamJob adam; unsigned lds_bytes; /* dynamic LDS of the launch (set by the launcher): the priority block's tree cache */
+                  int probe; /* trace builds: timing-probe bits (env DQN_PROBE), see nn_gemm.hip */ };
 static inline __host__ __device__ unsigned gemm_tail_blocks(const GemmTail& t) { return t.blocks + (t.has_adam ? adam_job_blocks(t.adam) : 0u); }
 static inline GemmTail gemm_no_tail() { GemmTail t; memset(&t, 0, sizeof t); return t; }
 

@@ -48,6 +48,7 @@ struct dqn_engine {
     hipGraphExec_t g_full[2] = {nullptr, nullptr}, g_pre[2] = {nullptr, nullptr}, g_post = nullptr;
     bool arena_u8 = false;  // the observation arena x0 holds bytes (u8 replay, first layer converts in its tile loads): set by build_program
     int adam_mode = 0;      // env DQN_ADAM_MODE at creation: 1 = Adam jobs carried by the backward launches (engine_program.hip)
+    unsigned long long* ktrace_buf = nullptr;     // dqn_debug_ktrace (trace builds): owned by the engine, freed with it
     // comm
     void* comm = nullptr; int rank = 0, world = 1; bool force_comm = false;
     // exchange mode of the replicas: gather = all-gather of the wide dense layers' operands + small gradients (dp.hip); else all-reduce of the gradient.

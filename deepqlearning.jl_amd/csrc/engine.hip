@@ -172,6 +172,7 @@ static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers
         if (e->L[i].kind == DQN_LAYER_CONV && e->L[i].dw_kc > 0 && e->L[i].dw_kc % e->B) return fail("plan: conv dw_kc must be a multiple of batch_size");
     }
     HIPCHK(hipSetDevice(device));
+    gemm_set_ktrace(nullptr);      // trace builds: (re)reads DQN_PROBE; a no-op otherwise
     if (!hp->recurrence) {
         // the TD kernel keeps every head output of the step in LDS: (B + (1 + nA) * (ncon + B)) floats.  Shapes that do not fit the
         // workgroup limit of this device are refused HERE with a message instead of failing at launch time (a failed launch would
@@ -264,6 +265,7 @@ extern "C" int dqn_engine_destroy(dqn_engine_t* e) {
     if (e->stream) hipStreamSynchronize(e->stream);
     drop_graphs(e);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
+    if (e->ktrace_buf) { gemm_set_ktrace(nullptr); hipFree(e->ktrace_buf); }
     hipFree(e->L_dev); hipFree(e->p_on); hipFree(e->p_tg); hipFree(e->grad); hipFree(e->m); hipFree(e->v); hipFree(e->io_tmp); hipFree(e->state);
     hipFree(e->s_rows); hipFree(e->sp_rows); hipFree(e->ra); hipFree(e->rr); hipFree(e->rdone); hipFree(e->tree);
     if (e->state_host) hipHostFree(e->state_host);
@@ -781,12 +783,17 @@ extern "C" int dqn_stream_handle(dqn_engine_t* e, void** s) { if (!e) return fai
 // debug aid: per-workgroup s_memtime records of the forward GEMM kernels (nn_gemm.hip, KTRACE).  out == NULL: start recording (room for 65536
 // records); out != NULL: stop and copy counter + records (n 64-bit words) to the host.  Process-wide (one engine at a time).
 extern "C" int dqn_debug_ktrace(dqn_engine_t* e, uint64_t* out, size_t n) { if (!e) return fail("null engine handle");
-    static unsigned long long* buf = nullptr; const size_t words = 1 + 8 * 65536ull;
+    const size_t words = 1 + 8 * 65536ull;
     HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream));
-    if (!out) { if (!buf) HIPCHK(hipMalloc((void**)&buf, words * 8)); HIPCHK(hipMemset(buf, 0, words * 8)); gemm_set_ktrace(buf); return 0; }
+    if (!out) {
+        if (!e->ktrace_buf) HIPCHK(hipMalloc((void**)&e->ktrace_buf, words * 8));
+        HIPCHK(hipMemset(e->ktrace_buf, 0, words * 8));
+        if (gemm_set_ktrace(e->ktrace_buf)) return fail("this library was built without -DDQN_KTRACE (DQN_EXTRA_DEF=DQN_KTRACE python __graft_entry__.py --force)");
+        return 0;
+    }
     gemm_set_ktrace(nullptr);
-    if (!buf) return fail("ktrace was not started");
-    HIPCHK(hipMemcpy(out, buf, std::min(n, words) * 8, hipMemcpyDeviceToHost)); return 0;
+    if (!e->ktrace_buf) return fail("ktrace was not started");
+    HIPCHK(hipMemcpy(out, e->ktrace_buf, std::min(n, words) * 8, hipMemcpyDeviceToHost)); return 0;
 }
 // Holds the stream until the host has enqueued the whole profiled step, so that the HIP events around each kernel time
 // the kernel and not the host's launch latency.  Bounded spin (~0.2 s) so a dead host can never hang the GPU.

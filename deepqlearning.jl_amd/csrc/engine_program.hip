@@ -264,7 +264,8 @@ int build_program(dqn_engine* e) {
     const int adam_mode = e->adam_mode;      // read once, at dqn_engine_create
     const bool early = !rec && !e->comm && !e->sim_world && segs_ok && adam_mode == 1;
     struct PItem { unsigned long long beg, end; const float* part; int S; };      // part != nullptr: split-K slabs to reduce; else a streamable range
-    std::vector<PItem> adam_pending; std::vector<int> adam_after_tail; int gmax_next = 0; bool prio_placed = false;
+    std::vector<PItem> adam_pending; std::vector<int> adam_after_tail; int gmax_next = 0; bool prio_placed = false, prio_draw_pending = false;
+    int prio_skip = getenv("DQN_PRIO_LEVEL") ? atoi(getenv("DQN_PRIO_LEVEL")) : 0;      // experiment knob: which LDS-tiled backward launch carries the priority block (0 = the first)
     auto base_job = [&]() {
         AdamJob J; memset(&J, 0, sizeof J);
         J.p = e->p_on; J.m = e->m; J.v = e->v; J.g = e->grad; J.g_out = e->grad; J.state = e->state; J.gmax_part = e->gmax_part;
@@ -452,8 +453,22 @@ int build_program(dqn_engine* e) {
             tail.adam = make_job((pending_stream() / (unsigned long long)(li + 1) + 3) / 4 * 4, false); tail.has_adam = 1;
             if (prio_in_adam && !prio_placed) { tail.adam.prio = prio_args(); prio_placed = true; }
         }
-        else if (pg_want && prio_in_adam && (dwl.on || dxl.on) && !prio_placed) { tail.adam = base_job(); tail.adam.prio = prio_args(); tail.has_adam = 1; prio_placed = true; }
-        if (pg_want && prio_in_adam && !prio_placed && !pend.empty() && !tail.has_adam) { const PrioArgs pa = prio_args(); flush_valu(e, pend, pname(e, "bwd_valu", e->L[lv[0]].kind, lv[0]), &pa); prio_placed = true; }
+        else if (pg_want && prio_in_adam && (dwl.on || dxl.on) && prio_draw_pending) {      // second half of a split priority block: the next sample()'s draws
+            tail.adam = base_job(); tail.adam.prio = prio_args(); tail.adam.prio.phase = 2; tail.has_adam = 1; prio_draw_pending = false; prio_placed = true;
+        }
+        else if (pg_want && prio_in_adam && (dwl.on || dxl.on) && !prio_placed && !prio_draw_pending && prio_skip-- <= 0) {
+            // the block rides as workgroup 0 of this launch.  When a LATER backward launch can carry a workgroup too, the block is SPLIT: update_priorities!
+            // here, the draws there -- each half shorter than the dX chains it hides under (r03 ktrace: the whole block lived 11 us, longer than any)
+            bool later = false;
+            static const bool no_split = getenv("DQN_PRIO_NOSPLIT") != nullptr;
+            for (int lj = li - 1; lj >= 0 && !later && !no_split; lj--) for (int l2 : levels[lj]) {
+                const LayerDev& L2 = e->L[l2]; const int ldx2 = L2.src < 0 ? ld0 : ncon;
+                if (mf && L2.kind != DQN_LAYER_LSTM && !dp_layer[l2] && gemm_dw_eligible(L2, B, ldx2)) later = true;
+            }
+            tail.adam = base_job(); tail.adam.prio = prio_args(); tail.has_adam = 1;
+            if (later) { tail.adam.prio.phase = 1; prio_draw_pending = true; } else prio_placed = true;
+        }
+        if (pg_want && prio_in_adam && !prio_placed && !pend.empty() && !tail.has_adam) { PrioArgs pa = prio_args(); if (prio_draw_pending) { pa.phase = 2; prio_draw_pending = false; } flush_valu(e, pend, pname(e, "bwd_valu", e->L[lv[0]].kind, lv[0]), &pa); prio_placed = true; }
         flush_valu(e, pend, pname(e, "bwd_valu", e->L[lv[0]].kind, lv[0]));
         const char* tsuf = (tail.has_adam && adam_job_blocks(tail.adam) == 1 && tail.adam.prio.n > 0) ? "+prio" : "+adam_tail";      // a job that is only the priority block
         auto tailed = [&](const char* base) { if (!tail.has_adam) return base; char nm[80]; snprintf(nm, sizeof nm, "%s%s", base, tsuf); e->prog_names.push_back(nm); return e->prog_names.back().c_str(); };
@@ -561,13 +576,13 @@ int build_program(dqn_engine* e) {
         // backward launch could carry it)
         std::vector<AdamJob> jobs;
         bool first = true;
-        do { AdamJob J = make_job(~0ull, first); if (first && prio_in_adam && !prio_placed) { J.prio = prio_args(); prio_placed = true; } jobs.push_back(J); first = false; } while (!adam_pending.empty());
+        do { AdamJob J = make_job(~0ull, first); if (first && prio_in_adam && !prio_placed) { J.prio = prio_args(); if (prio_draw_pending) { J.prio.phase = 2; prio_draw_pending = false; } prio_placed = true; } jobs.push_back(J); first = false; } while (!adam_pending.empty());
         e->prog.push_back({"adam_rest", [=](dqn_engine* en) { for (const AdamJob& J : jobs) launch_adam(en->stream, J); }});
         e->gmax_used = gmax_next;
     } else {
         AdamJob J = base_job();
         J.nr = 1; J.beg[0] = 0; J.end[0] = e->Pint; J.sblocks = (unsigned)adam_blocks(e->Pint); J.tick = 1; J.slot0 = 0;
-        if (e->hp.prioritized_replay && !rec && !e->prio_forked && !prio_placed) J.prio = prio_args();
+        if (e->hp.prioritized_replay && !rec && !e->prio_forked && !prio_placed) { J.prio = prio_args(); if (prio_draw_pending) { J.prio.phase = 2; prio_draw_pending = false; } }
         memset(&e->pg, 0, sizeof e->pg); e->pg_ok = pg_want && (prio_placed || e->prio_forked);
         if (e->pg_ok) {
             PreGather& G = e->pg; G.on = 1; G.s_rows = e->s_rows; G.sp_rows = e->sp_rows; G.E = e->E; G.B = B; G.idx_pre = e->idx_pre; G.x0 = e->x0; G.cap2 = e->cap2; G.tree = e->tree; G.seed = e->hp.seed;

@@ -19,27 +19,69 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-// ---- debug aid (dqn_debug_ktrace): per-workgroup timestamps of the forward kernels.  g_ktrace[0] = record counter, then 8-word records
-// {gridDim.x, blockIdx.x, s_memtime at: entry, tables ready, first tile in LDS, K loop done, chunks combined, stores issued}.
+// ---- debug aid (dqn_debug_ktrace, builds with -DDQN_KTRACE only: `DQN_EXTRA_DEF=DQN_KTRACE python __graft_entry__.py --force`): per-workgroup
+// timestamps of the LDS-tiled kernels.  g_ktrace[0] = record counter, then 8-word records {gridDim.x, blockIdx.x, s_memtime at: entry, tables
+// ready | role, first tile in LDS, K loop done, chunks combined, stores issued}.  The product build carries none of it: reading the trace
+// pointer is a global load + wait at the top of every workgroup.
+#ifdef DQN_KTRACE
 __device__ unsigned long long* g_ktrace = nullptr;
-void gemm_set_ktrace(unsigned long long* p) { hipMemcpyToSymbol(HIP_SYMBOL(g_ktrace), &p, sizeof p); }
-#define KTRACE_BEGIN() unsigned long long* tr_ = g_ktrace; unsigned long long trs_ = 0; \
-    if (tr_ && threadIdx.x == 0) { trs_ = 1 + 8 * atomicAdd(tr_, 1ull); if (trs_ + 8 < 1 + 8 * 65536ull) { tr_[trs_] = gridDim.x; tr_[trs_ + 1] = blockIdx.x; tr_[trs_ + 2] = __builtin_amdgcn_s_memtime(); } else trs_ = 0; }
-#define KTRACE(i) do { if (trs_) tr_[trs_ + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// timing probes (WRONG numbers, right schedule; env DQN_PROBE): bit 0 = dW workgroups of the fused backward launches return at once, bit 1 = the
+// priority block returns at once, bit 2 = dW workgroups skip their stores, bit 3 = dX workgroups return at once.  A kernel argument
+// (GemmTail::probe): a __device__ variable set before the module's first launch is reset by the lazy module load.
+static int host_probe() { static const int v = getenv("DQN_PROBE") ? atoi(getenv("DQN_PROBE")) : 0; return v; }
+#define HOST_PROBE() host_probe()
+int gemm_set_ktrace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ktrace), &p, sizeof p); return 0; }
+// stamps are taken into REGISTERS (s_memtime is a scalar instruction: no memory traffic) and the record -- slot from an atomic counter, eight
+// stores -- is written when the workgroup is done, so tracing does not perturb what it times (the first version fetched the trace pointer, ran the
+// atomic and stored as it went: 1-3 us of round trips inside the timed prologue).  The probe word is read BEFORE the entry stamp.
+// Word 0 / 1 carry, in their upper halves, the low 32 bits of s_memrealtime (the 100 MHz constant clock, common to all XCDs -- s_memtime is not) at
+// entry / exit: the only stamps that can be compared ACROSS workgroups.
+#define KTRACE_BEGIN() unsigned long long kts_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; kts_[0] = __builtin_amdgcn_s_memrealtime() << 32; kts_[2] = __builtin_amdgcn_s_memtime();
+#define KTRACE(i) do { kts_[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define KTRACE_SET(i, v) do { kts_[i] = (v); } while (0)
+#define KTRACE_REC() kts_
+#define KTRACE_PROBE() tail.probe
+#define KTRACE_END() do { unsigned long long* tr_ = g_ktrace; if (tr_ && threadIdx.x == 0) { const unsigned long long rt_ = __builtin_amdgcn_s_memrealtime(); const unsigned long long o_ = 1 + 8 * atomicAdd(tr_, 1ull); if (o_ + 8 < 1 + 8 * 65536ull) { \
+    kts_[0] |= gridDim.x; kts_[1] = (rt_ << 32) | blockIdx.x; for (int i_ = 0; i_ < 8; i_++) tr_[o_ + i_] = kts_[i_]; } } } while (0)
+#else
+int gemm_set_ktrace(unsigned long long*) { return -1; }     // not a trace build
+#define HOST_PROBE() 0
+#define KTRACE_BEGIN()
+#define KTRACE_END() do {} while (0)
+#define KTRACE(i) do {} while (0)
+#define KTRACE_SET(i, v) do {} while (0)
+#define KTRACE_REC() nullptr
+#define KTRACE_PROBE() 0
+#endif
 
 void launch_reduce_pub(hipStream_t st, const float* part, int S, size_t elems, int mode, const float* bias, int per_n, int act,
                        const float* addend, const float* ysrc, int B, int ldy, float* out);
 
+// Kernel arguments are fetched with scalar loads where they are first USED; with kilobyte-sized by-value records (LayerDev, GemmTail, ...) and
+// branchy prologues that is a chain of 6-10 DEPENDENT round trips to a cold scalar cache before the first operand load goes out (ISA of
+// k_dwdx_lds / k_fwd_lds; ktrace r03: 2.7-3.8 us from workgroup entry to the first global_load of a dX workgroup, the loads themselves back in
+// 0.15 us).  karg_warm touches one dword of every 64-byte line of the kernarg segment at the top of the kernel: independent loads, issued back to
+// back, retired behind ONE wait -- afterwards every argument load hits the scalar cache.
+template <int NBYTES> __device__ __forceinline__ void karg_warm() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const uint32_t __attribute__((address_space(4))) karg_u32;
+    karg_u32* p = (karg_u32*)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t x = 0;
+#pragma unroll
+    for (int i = 0; i < (NBYTES + 63) / 64; i++) x ^= p[16 * i];
+    asm volatile("" ::"s"(x));
+#endif
+}
 // tail workgroups of a backward launch: VALU tasks first, then the Adam stream (blk counts from the first tail workgroup)
 __device__ __forceinline__ void gemm_tail_run(const GemmTail& tail, unsigned blk) {
-    if (blk < tail.blocks) { valu_task_run(tail.tasks, tail.n, blk); return; }
+    if (blk < tail.blocks) { valu_task_run<false>(tail.tasks, tail.n, blk); return; }
     extern __shared__ float lds[];         // every LDS-tiled launch allocates > 8.3 KB
     adam_job_run(tail.adam, (int)(blk - tail.blocks), nullptr, lds, true);
 }
 // the priority block of a carried Adam job is workgroup 0 of the launch: its ~14 dependent tree levels need the whole launch to hide under
 #define GEMM_TAIL_PROLOGUE(tail, bid_var, main_var)                                                                                     \
     const int pre_ = (tail.has_adam && tail.adam.prio.n > 0) ? 1 : 0;                                                                   \
-    if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; prio_block_run(tail.adam.prio, tail.adam.state, reinterpret_cast<long long*>(lds)); return; } \
+    if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; prio_block_run(tail.adam.prio, tail.adam.state, reinterpret_cast<long long*>(lds), tail.lds_bytes); return; } \
     const int bid_var = (int)blockIdx.x - pre_;                                                                                         \
     const int main_var = (int)gridDim.x - (int)gemm_tail_blocks(tail);                                                                  \
     if (bid_var >= main_var) { gemm_tail_run(tail, (unsigned)(bid_var - main_var)); return; }
@@ -69,6 +111,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     float* Bs = lds + 2 * F_KT * F_SA;                 // [2][F_KT][SB]
     int* koff_lds = (int*)(Bs + 2 * F_KT * SB);        // [K] (conv only)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    karg_warm<sizeof(LayerDev) + sizeof(GFwdProbs) + 8>();
     KTRACE_BEGIN()
     const bool conv = L.kind == DQN_LAYER_CONV;
     if (conv) {
@@ -223,7 +266,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
         }
         *reinterpret_cast<f32x4*>(p.out + (size_t)s * per_s + ((size_t)n * L.npos + pos) * p.ncols + ct * 16 + 4 * kq) = v;
     }
-    KTRACE(7);
+    KTRACE(7); KTRACE_END();
 }
 
 static int fwd_pick_nt(const LayerDev& L, long mgroups_total, int S) {
@@ -303,7 +346,7 @@ __device__ __forceinline__ void lds_st4(float* p, f32x4 v) {
 }
 
 template <int NT, bool XU8 = false>
-__device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& pr, int nprob, int ldx, int B, int S, int kc, int bid, int nblocks, DwStride ds) {
+__device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& pr, int nprob, int ldx, int B, int S, int kc, int bid, int nblocks, DwStride ds, int probe = 0) {
     constexpr int NW = 16 * NT;
     using AT = std::conditional_t<XU8, uint32_t, f32x4>;
     constexpr int BQ = (NW * 8 + 255) / 256;          // float4 per thread for the B tile (1 or 2)
@@ -412,6 +455,7 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
 #undef STAGE_WAIT
     const size_t per_s = (size_t)(L.K + 1) * L.N;
     float* out = p.out + (size_t)s * per_s;
+    if (probe & 4) return;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         const int n = n0 + 16 * t + l15;
@@ -419,7 +463,7 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int k = mr * 64 + 16 * wave + 4 * kq + r;
-            if (k < L.K) out[(size_t)k * L.N + n] = v[r];
+            if (k < L.K) __builtin_nontemporal_store(v[r], &out[(size_t)k * L.N + n]);
         }
     }
     if (do_bias) out[(size_t)L.K * L.N + n0 + tid] = dbacc;
@@ -428,14 +472,15 @@ template <int NT, bool XU8 = false>
 __global__ __launch_bounds__(256) void k_dw_lds(LayerDev L, GDwProbs pr, int nprob, int ldx, int B, int S, int kc, DwStride ds, GemmTail tail) {
     // dispatch order: [priority block][tail: VALU tasks, Adam job][dW workgroups] -- the bandwidth-bound tail starts at once and the short dW
     // workgroups fill the slots beside it (at the END of the grid the tail would wait for LDS: every workgroup of a launch reserves the tile size)
+    karg_warm<sizeof(LayerDev) + sizeof(GDwProbs) + 32 + sizeof(DwStride) + sizeof(GemmTail)>();
     KTRACE_BEGIN()      // record: {grid, block, entry, role (0 prio, 2 tail, 3 dW), -, -, -, exit}
     const int pre_ = (tail.has_adam && tail.adam.prio.n > 0) ? 1 : 0;
-    if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; prio_block_run(tail.adam.prio, tail.adam.state, reinterpret_cast<long long*>(lds)); if (trs_) tr_[trs_ + 3] = 0; KTRACE(7); return; }
+    if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; prio_block_run(tail.adam.prio, tail.adam.state, reinterpret_cast<long long*>(lds), tail.lds_bytes); KTRACE_SET(3, 0); KTRACE(7); KTRACE_END(); return; }
     const int bid = (int)blockIdx.x - pre_, ntail = (int)gemm_tail_blocks(tail) - pre_;
-    if (bid < ntail) { gemm_tail_run(tail, (unsigned)bid); if (trs_) tr_[trs_ + 3] = 2; KTRACE(7); return; }
+    if (bid < ntail) { gemm_tail_run(tail, (unsigned)bid); KTRACE_SET(3, 2); KTRACE(7); KTRACE_END(); return; }
     dw_lds_body<NT, XU8>(L, pr, nprob, ldx, B, S, kc, bid - ntail, (int)gridDim.x - pre_ - ntail, ds);
-    if (trs_) tr_[trs_ + 3] = 3;
-    KTRACE(7);
+    KTRACE_SET(3, 3);
+    KTRACE(7); KTRACE_END();
 }
 bool gemm_dw_eligible(const LayerDev& L, int B, int ldx) {
     const int KK = L.npos * B, S = dqn_nchunks(KK, L.dw_kc), kc = dqn_chunk_len(KK, L.dw_kc);
@@ -450,6 +495,7 @@ void launch_gemm_dw(hipStream_t st, const LayerDev& L, int nprob, const float* c
     const int NT = L.N % 64 == 0 ? 4 : (L.N % 32 == 0 ? 2 : 1);
     const int grid = ((L.K + 63) / 64) * (L.N / (16 * NT)) * S * nprob + (int)gemm_tail_blocks(tail);
     const size_t lds = (size_t)(2 * 64 * W_ST + 2 * 16 * NT * W_ST) * 4;
+    tail.lds_bytes = (unsigned)lds; tail.probe = HOST_PROBE();
     if (L.xu8) {
         if (NT == 4) hipLaunchKernelGGL((k_dw_lds<4, true>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, tail);
         else if (NT == 2) hipLaunchKernelGGL((k_dw_lds<2, true>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, tail);
@@ -485,8 +531,16 @@ constexpr int U_AW = 32 * 32;            // A tile [32 k][32 samples]: row strid
 constexpr int U_BW = 32 * X_SB;          // B tile [32 features][34]
 constexpr int U_WAVE = U_AW + U_BW;      // floats per wave (8448 B)
 constexpr int U_MAX = 4;                 // units per workgroup = waves
+#ifndef DQN_U_FT
+#define DQN_U_FT 1
+#endif
+constexpr int U_FT = DQN_U_FT;           // 16-feature tiles per workgroup (1: 16 x 32 output tiles; 2: 32 x 32 -- measured, r03: see dx_units_body)
 static size_t dx_units_lds_bytes() { return (size_t)(4 * U_WAVE + 64 + 8) * 4; }
-__device__ __forceinline__ void dx_units_body(const LayerDev& L, const GDxArgs& A, int B, int S, int kc, int bid, int nblocks, int by) {
+// FT = 16-feature tiles per workgroup: 2 (32 x 32 output tiles) or 1 (16 x 32: twice the workgroups -- a CU draws ~10 B/clk from HBM whatever it has
+// in flight (MI355X guide), so a weight-streaming dX confined to 98 CUs (the FC join with 32-feature tiles) could not exceed ~2.3 TB/s)
+template <int FT>
+__device__ __forceinline__ void dx_units_body(const LayerDev& L, const GDxArgs& A, int B, int S, int kc, int bid, int nblocks, int by, unsigned long long* ktr = nullptr /* debug: words 4..6 of this workgroup's ktrace record */) {
+    constexpr int FW = 16 * FT;
     extern __shared__ float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     float* As = lds + wave * U_WAVE; float* Bs = As + U_AW;
@@ -497,9 +551,9 @@ __device__ __forceinline__ void dx_units_body(const LayerDev& L, const GDxArgs& 
     const int w = xcd_remap(bid, nblocks);
     const int nfeat = dense ? L.K : L.cin, khw = L.kh * L.kw;
     int f0, ip = 0, nch;
-    if (dense) { const int ftiles = (L.K + 31) / 32; f0 = (w % ftiles) * 32; nch = S; }
+    if (dense) { const int ftiles = (L.K + FW - 1) / FW; f0 = (w % ftiles) * FW; nch = S; }
     else {
-        const int ctiles = L.cin / 32; f0 = (w % ctiles) * 32; ip = w / ctiles;
+        const int ctiles = L.cin / FW; f0 = (w % ctiles) * FW; ip = w / ctiles;
         if (tid < 64) {
             // lane (ky*kw + kx) tests its own tap; ballots compact the valid ones in raw-tap order and mark the first valid tap of every chunk
             const int iy = ip / L.iw, ix = ip % L.iw; bool ok = false; int val = 0;
@@ -523,15 +577,18 @@ __device__ __forceinline__ void dx_units_body(const LayerDev& L, const GDxArgs& 
     }
     const int NU = A.nsrc * nch;
     const bool active = wave < NU;
-    const int ft = wave & 1, mt = wave >> 1;          // the accumulator tile this wave FINISHES (epilogue)
+    const int ft = wave % FT, mt = wave / FT;         // the accumulator tile this wave FINISHES (epilogue; waves >= 2 * FT have none)
+    const bool fin = wave < 2 * FT;
     // epilogue operand requested up front: the producer's activation for the fused act' multiply
     const int fl = f0 + 16 * ft + l15;
     const size_t feat = dense ? (size_t)min(fl, nfeat - 1) : (size_t)min(fl, nfeat - 1) * L.ih * L.iw + ip;
+    // (requested AFTER the first operand tiles: the register allocator parks this long-lived value in an AGPR, which needs the loaded data -- issued
+    // first, that copy put a full cold round trip in front of the tile loads: 4-5 us from entry to the first global_load, ktrace r03)
     f32x4 y_e = {0.f, 0.f, 0.f, 0.f};
-    if (A.ysrc) y_e = *reinterpret_cast<const f32x4*>(A.ysrc + feat * A.ldy + b0 + 16 * mt + 4 * kq);
-    f32x4 acc[4];                                      // [sample tile * 2 + feature tile] of this wave's unit
+    const float* y_ptr = (A.ysrc && fin) ? A.ysrc + feat * A.ldy + b0 + 16 * mt + 4 * kq : nullptr;
+    f32x4 acc[2 * FT];                                 // [sample tile * FT + feature tile] of this wave's unit
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 2 * FT; j++) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (active) {
         const int si = wave / nch, cj = wave - si * nch;
         const GDxSrc& sr = A.src[si];
@@ -542,12 +599,12 @@ __device__ __forceinline__ void dx_units_body(const LayerDev& L, const GDxArgs& 
         // staging slices of this lane: rows (lane >> 3) + 8p, float4 (lane & 7) of both tiles
         const int row0 = lane >> 3, f4 = lane & 7;
         const float* Ap = sr.dpre + b0 + 4 * f4;
-        unsigned boff[4];
+        unsigned boff[2 * FT];
 #pragma unroll
-        for (int p = 0; p < 4; p++) { const unsigned frow = (unsigned)min(f0 + row0 + 8 * p, nfeat - 1); boff[p] = dense ? frow * (unsigned)L.N + 4u * f4 : frow * (unsigned)(khw * L.N) + 4u * f4; }
+        for (int p = 0; p < 2 * FT; p++) { const unsigned frow = (unsigned)min(f0 + row0 + 8 * p, nfeat - 1); boff[p] = dense ? frow * (unsigned)L.N + 4u * f4 : frow * (unsigned)(khw * L.N) + 4u * f4; }
         const float* Wp = sr.W;
         const float r_cot = 1.0f / (float)cot;
-        struct Stage { f32x4 a[4], b[4]; };
+        struct Stage { f32x4 a[4], b[2 * FT]; };
         auto gld = [](const float* ptr) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory"); return v; };
         auto gload = [&](int t, Stage& r) {
             t = min(t, nt - 1);
@@ -561,67 +618,78 @@ __device__ __forceinline__ void dx_units_body(const LayerDev& L, const GDxArgs& 
 #pragma unroll
             for (int p = 0; p < 4; p++) r.a[p] = gld(Ap + ao + p * astep);
 #pragma unroll
-            for (int p = 0; p < 4; p++) r.b[p] = gld(Wp + boff[p] + bo);
+            for (int p = 0; p < 2 * FT; p++) r.b[p] = gld(Wp + boff[p] + bo);
         };
         const int aswz = ((row0 & 1) << 2) ^ f4;     // float4 column of this lane's A rows (all of one parity: row0 + 8p)
         auto lstore = [&](const Stage& r) {
 #pragma unroll
             for (int p = 0; p < 4; p++) *reinterpret_cast<f32x4*>(As + (row0 + 8 * p) * 32 + 4 * aswz) = r.a[p];
 #pragma unroll
-            for (int p = 0; p < 4; p++) lds_st4(Bs + (row0 + 8 * p) * X_SB + 4 * f4, r.b[p]);
+            for (int p = 0; p < 2 * FT; p++) lds_st4(Bs + (row0 + 8 * p) * X_SB + 4 * f4, r.b[p]);
         };
-#define STAGE_WAIT8(N, r) asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.b[0]), "+v"(r.b[1]), "+v"(r.b[2]), "+v"(r.b[3]) : "n"(N) : "memory")
-        struct Frag { float a[8][2], b[8][2]; };
-        auto fread = [&](Frag& f) {
-            const float* Ab = As + kq * 32 + l15;
-            const float* Bb = Bs + l15 * X_SB + kq;
+        constexpr int LPS = 4 + 2 * FT;                // loads per stage
+#define STAGE_WAIT8(r) do { if constexpr (FT == 2) asm volatile("s_waitcnt vmcnt(8)" : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.b[0]), "+v"(r.b[1]), "+v"(r.b[2]), "+v"(r.b[3 % (2 * FT)]) :: "memory"); \
+                            else asm volatile("s_waitcnt vmcnt(6)" : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.b[0]), "+v"(r.b[1]) :: "memory"); } while (0)
+        static_assert(LPS == 8 || LPS == 6, "STAGE_WAIT8 counts");
+        // fragments of HALF a tile (4 MFMA steps x 2 sample tiles / 2 feature tiles = 16 registers), two sets: the reads of one half ride under
+        // the 16 MFMAs of the other, and the next tile's LDS round trip (wait, stores, reads of its first half) under the second half's MFMAs
+        struct Frag { float a[4][2], b[4][FT]; };
+        auto fread = [&](Frag& f, int h) {
+            const float* Ab = As + (16 * h + kq) * 32 + l15;
+            const float* Bb = Bs + l15 * X_SB + kq + 16 * h;
 #pragma unroll
-            for (int st = 0; st < 8; st++) {
+            for (int st = 0; st < 4; st++) {
                 f.a[st][0] = Ab[st * 128 + ((kq & 1) << 4)]; f.a[st][1] = Ab[st * 128 + (((kq & 1) ^ 1) << 4)];
-                f.b[st][0] = Bb[4 * st]; f.b[st][1] = Bb[16 * X_SB + 4 * st];
+#pragma unroll
+                for (int q = 0; q < FT; q++) f.b[st][q] = Bb[16 * q * X_SB + 4 * st];
             }
         };
-        auto mma = [&](const Frag& f, int s0, int s1) {
+        auto mma = [&](const Frag& f) {
 #pragma unroll
-            for (int st = s0; st < s1; st++)
+            for (int st = 0; st < 4; st++)
 #pragma unroll
                 for (int m = 0; m < 2; m++)
 #pragma unroll
-                    for (int q = 0; q < 2; q++) acc[m * 2 + q] = MFMA(f.a[st][m], f.b[st][q], acc[m * 2 + q]);
+                    for (int q = 0; q < FT; q++) acc[m * FT + q] = MFMA(f.a[st][m], f.b[st][q], acc[m * FT + q]);
         };
-        Stage r0, r1; Frag fc, fn;
+        Stage r0, r1; Frag fa, fb;
         gload(0, r0); gload(1, r1);
-        STAGE_WAIT8(8, r0); lstore(r0); gload(2, r0); fread(fc);
+        if (y_ptr) y_e = *reinterpret_cast<const f32x4*>(y_ptr);
+        STAGE_WAIT8(r0); lstore(r0); gload(2, r0); fread(fa, 0);
+        if (ktr) ktr[4] = __builtin_amdgcn_s_memtime();
         for (int t = 0; t < nt; t += 2) {
-            // tile t in fc; r1 = tile t + 1 and r0 = tile t + 2 in flight.  The next tile's LDS round trip sits between the two halves of the chain
-            mma(fc, 0, 4);
-            STAGE_WAIT8(8, r1); lstore(r1); gload(t + 3, r1);
-            if (t + 1 < nt) fread(fn);
-            mma(fc, 4, 8);
+            // tile t is in LDS, its first half in fa; r1 = tile t + 1 and r0 = tile t + 2 in flight
+            fread(fb, 1); mma(fa);
+            STAGE_WAIT8(r1); lstore(r1); gload(t + 3, r1);      // LDS operations of a wave execute in order: the stores follow the reads above
+            if (t + 1 < nt) fread(fa, 0);
+            mma(fb);
             if (t + 1 < nt) {
-                mma(fn, 0, 4);
-                STAGE_WAIT8(8, r0); lstore(r0); gload(t + 4, r0);
-                if (t + 2 < nt) fread(fc);
-                mma(fn, 4, 8);
+                fread(fb, 1); mma(fa);
+                STAGE_WAIT8(r0); lstore(r0); gload(t + 4, r0);
+                if (t + 2 < nt) fread(fa, 0);
+                mma(fb);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef STAGE_WAIT8
+        if (ktr) ktr[5] = __builtin_amdgcn_s_memtime();
     }
+    else if (y_ptr) y_e = *reinterpret_cast<const f32x4*>(y_ptr);
     __syncthreads();                                   // every wave is done with its staging tiles: the unit sums alias them
     f32x4* slot = reinterpret_cast<f32x4*>(lds);       // [unit][accumulator tile][lane]
     if (active) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) slot[(wave * 4 + j) * 64 + lane] = acc[j];
+        for (int j = 0; j < 2 * FT; j++) slot[(wave * 2 * FT + j) * 64 + lane] = acc[j];
     }
     __syncthreads();
-    if (fl >= nfeat) return;
+    if (ktr) ktr[6] = __builtin_amdgcn_s_memtime();
+    if (!fin || fl >= nfeat) return;
     // wave w finishes accumulator tile w = (sample tile mt, feature tile ft): chunk sums ascending per source, then the two sources
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     for (int si = 0; si < A.nsrc; si++) {
         f32x4 tot = {0.f, 0.f, 0.f, 0.f};
         for (int c = 0; c < nch; c++) {
-            const f32x4 x = slot[((si * nch + c) * 4 + wave) * 64 + lane];
+            const f32x4 x = slot[((si * nch + c) * 2 * FT + wave) * 64 + lane];
             if (c == 0) tot = x; else { tot.x = tot.x + x.x; tot.y = tot.y + x.y; tot.z = tot.z + x.z; tot.w = tot.w + x.w; }
         }
         if (si == 0) v = tot; else { v.x = v.x + tot.x; v.y = v.y + tot.y; v.z = v.z + tot.z; v.w = v.w + tot.w; }
@@ -772,9 +840,9 @@ static int dx_mode(const LayerDev& L, int nsrc, int B, int ldy) {
     const bool dense = L.kind == DQN_LAYER_DENSE;
     const int S = dense ? dqn_nchunks(L.N, L.dx_kc) : 1, kc = dqn_chunk_len(L.N, L.dx_kc);
     if (B % 32 || ldy % 4 || L.N % 32 || (S > 1 && kc % 32) || L.w_off % 4) return -1;
-    if (!dense && (L.cin % 32 || L.kh * L.kw > 64 || L.npos > 65535)) return -1;
+    if (!dense && (L.cin % (16 * U_FT) || L.kh * L.kw > 64 || L.npos > 65535)) return -1;
     const int nch = dense ? S : conv_max_chunks(L);
-    if (B % 128 == 0 && !no_wide && (dense || nch <= 1) && (nsrc == 1 || S == 1)) return 2;
+    if (B % 128 == 0 && !no_wide && (dense || (nch <= 1 && L.cin % 32 == 0)) && (nsrc == 1 || S == 1)) return 2;
     if (nsrc * nch <= U_MAX) return 3;
     return -1;
 }
@@ -784,33 +852,40 @@ static size_t dx_lds_bytes(int mode) {
     return dx_units_lds_bytes();
 }
 
-__global__ __launch_bounds__(256) void k_dx_lds(LayerDev L, GDxArgs A, int B, int S, int kc, int pj, int gx, GemmTail tail) {
+// WIDE: the 128-sample dX body (large batches) -- a kernel of its own: compiled beside the small-batch body it set the register budget of both
+// (154 + 36 VGPRs: two waves per SIMD) and halved the workgroups in flight of every B = 32 backward launch
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_dx_lds(LayerDev L, GDxArgs A, int B, int S, int kc, int gx, GemmTail tail) {
+    karg_warm<sizeof(LayerDev) + sizeof(GDxArgs) + 32 + sizeof(GemmTail)>();
     GEMM_TAIL_PROLOGUE(tail, bid, main_blocks)
-    if (pj == 2) dx_lds_body_wide(L, A, B, S, kc, bid % gx, gx, bid / gx);
-    else dx_units_body(L, A, B, S, kc, bid % gx, gx, bid / gx);
+    if constexpr (WIDE) dx_lds_body_wide(L, A, B, S, kc, bid % gx, gx, bid / gx);
+    else dx_units_body<U_FT>(L, A, B, S, kc, bid % gx, gx, bid / gx);
 }
 // dW and dX of one layer are independent given dpre: ONE launch runs both (blocks [0, dw_blocks) do dW, the rest dX), which
 // saves a dispatch and lets the latency-bound dX workgroups share the machine with the dW ones.
-template <int NT>
+template <int NT, bool WIDE>
 __global__ __launch_bounds__(256) void k_dwdx_lds(LayerDev Lw, GDwProbs pr, int nprob, int ldx, int B, int Sw, int kcw, int dw_blocks,
-                                                  LayerDev Lx, GDxArgs A, int Sx, int kcx, int dx_gx, int pj, GemmTail tail) {
+                                                  LayerDev Lx, GDxArgs A, int Sx, int kcx, int dx_gx, GemmTail tail) {
     // the few, long-latency dX workgroups are dispatched FIRST so that they run for the whole kernel while the many short dW
     // workgroups fill the remaining CUs (dispatch order is blockIdx order); a tail of small VALU tasks comes last
     // dispatch order: [priority block][dX workgroups][tail: VALU tasks, Adam job][dW workgroups]: the long-latency dX chains start first, the
     // bandwidth-bound tail streams beside them, the many short dW workgroups fill the slots as they free up
+    karg_warm<2 * sizeof(LayerDev) + sizeof(GDwProbs) + sizeof(GDxArgs) + sizeof(GemmTail) + 64>();
     KTRACE_BEGIN()      // record: {grid, block, entry, role (0 prio, 1 dX, 2 tail, 3 dW), -, -, -, exit}  (tools/ktrace_bwd.py)
     const int pre_ = (tail.has_adam && tail.adam.prio.n > 0) ? 1 : 0;
-    if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; prio_block_run(tail.adam.prio, tail.adam.state, reinterpret_cast<long long*>(lds)); if (trs_) tr_[trs_ + 3] = 0; KTRACE(7); return; }
+    const int probe = KTRACE_PROBE();
+    if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; if (!(probe & 2)) prio_block_run(tail.adam.prio, tail.adam.state, reinterpret_cast<long long*>(lds), tail.lds_bytes, KTRACE_REC()); KTRACE_SET(3, 0); KTRACE(7); KTRACE_END(); return; }
     const int bid = (int)blockIdx.x - pre_, ntail = (int)gemm_tail_blocks(tail) - pre_;
     const int dx_blocks = (int)gridDim.x - pre_ - ntail - dw_blocks;
     if (bid < dx_blocks) {
-        if (pj == 2) dx_lds_body_wide(Lx, A, B, Sx, kcx, bid % dx_gx, dx_gx, bid / dx_gx);
-        else dx_units_body(Lx, A, B, Sx, kcx, bid % dx_gx, dx_gx, bid / dx_gx);
-        if (trs_) tr_[trs_ + 3] = 1;
+        if (probe & 8) {}      // timing probe: dX workgroups return at once
+        else if constexpr (WIDE) dx_lds_body_wide(Lx, A, B, Sx, kcx, bid % dx_gx, dx_gx, bid / dx_gx);
+        else dx_units_body<U_FT>(Lx, A, B, Sx, kcx, bid % dx_gx, dx_gx, bid / dx_gx, KTRACE_REC());
+        KTRACE_SET(3, 1);
     }
-    else if (bid < dx_blocks + ntail) { gemm_tail_run(tail, (unsigned)(bid - dx_blocks)); if (trs_) tr_[trs_ + 3] = 2; }
-    else { dw_lds_body<NT>(Lw, pr, nprob, ldx, B, Sw, kcw, bid - dx_blocks - ntail, dw_blocks, DwStride{Lw.npos * B, 0, 0}); if (trs_) tr_[trs_ + 3] = 3; }
-    KTRACE(7);
+    else if (bid < dx_blocks + ntail) { gemm_tail_run(tail, (unsigned)(bid - dx_blocks)); KTRACE_SET(3, 2); }
+    else { if (!(probe & 1)) dw_lds_body<NT>(Lw, pr, nprob, ldx, B, Sw, kcw, bid - dx_blocks - ntail, dw_blocks, DwStride{Lw.npos * B, 0, 0}, probe); KTRACE_SET(3, 3); }
+    KTRACE(7); KTRACE_END();
 }
 bool gemm_dx_eligible(const LayerDev& L, int B, int ldy, int nsrc) { return dx_mode(L, nsrc, B, ldy) >= 0; }
 // true: the plan chunks of this dX are contracted and combined INSIDE the launch (no partial slabs, no reduce launch)
@@ -823,8 +898,11 @@ void launch_gemm_dx(hipStream_t st, const LayerDev& L, int nsrc, const float* co
     GDxArgs a; a.nsrc = nsrc; a.out = out; a.ysrc = ysrc; a.ldy = ldy; a.act_src = act_src;
     for (int i = 0; i < 2; i++) { const int j = i < nsrc ? i : 0; a.src[i].W = W[j]; a.src[i].dpre = dpre[j]; }
     const int pj = dx_mode(L, nsrc, B, ldy);
-    const int gx = dense ? ((L.K + 31) / 32) * (pj == 2 ? S : 1) : (L.cin / 32) * L.ih * L.iw;
-    hipLaunchKernelGGL(k_dx_lds, dim3(gx * (B / dx_cols(pj)) + gemm_tail_blocks(tail)), dim3(256), dx_lds_bytes(pj), st, L, a, B, S, kc, pj, gx, tail);
+    const int fw = pj == 3 ? 16 * U_FT : 32;
+    const int gx = dense ? ((L.K + fw - 1) / fw) * (pj == 2 ? S : 1) : (L.cin / fw) * L.ih * L.iw;
+    tail.lds_bytes = (unsigned)dx_lds_bytes(pj); tail.probe = HOST_PROBE();
+    if (pj == 2) hipLaunchKernelGGL((k_dx_lds<true>), dim3(gx * (B / dx_cols(pj)) + gemm_tail_blocks(tail)), dim3(256), dx_lds_bytes(pj), st, L, a, B, S, kc, gx, tail);
+    else hipLaunchKernelGGL((k_dx_lds<false>), dim3(gx * (B / dx_cols(pj)) + gemm_tail_blocks(tail)), dim3(256), dx_lds_bytes(pj), st, L, a, B, S, kc, gx, tail);
 }
 
 void launch_gemm_dwdx(hipStream_t st, const LayerDev& Lw, int nprob, const float* const* X, int ldx, const float* const* dpre_w, int B, float* const* out_w,
@@ -839,11 +917,14 @@ void launch_gemm_dwdx(hipStream_t st, const LayerDev& Lw, int nprob, const float
     GDxArgs a; a.nsrc = nsrc; a.out = out_x; a.ysrc = ysrc; a.ldy = ldy; a.act_src = act_src;
     for (int i = 0; i < 2; i++) { const int j = i < nsrc ? i : 0; a.src[i].W = W[j]; a.src[i].dpre = dpre_x[j]; }
     const int pj = dx_mode(Lx, nsrc, B, ldy);
-    const int gx = dense ? ((Lx.K + 31) / 32) * (pj == 2 ? Sx : 1) : (Lx.cin / 32) * Lx.ih * Lx.iw;
+    const int fw = pj == 3 ? 16 * U_FT : 32;
+    const int gx = dense ? ((Lx.K + fw - 1) / fw) * (pj == 2 ? Sx : 1) : (Lx.cin / fw) * Lx.ih * Lx.iw;
     const size_t lds_w = (size_t)(2 * 64 * W_ST + 2 * 16 * NT * W_ST) * 4, lds_x = dx_lds_bytes(pj);
     const size_t lds = lds_w > lds_x ? lds_w : lds_x;
+    tail.lds_bytes = (unsigned)lds; tail.probe = HOST_PROBE();
     const int grid = dw_blocks + gx * (B / dx_cols(pj)) + (int)gemm_tail_blocks(tail);
-    if (NT == 4) hipLaunchKernelGGL((k_dwdx_lds<4>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, pj, tail);
-    else if (NT == 2) hipLaunchKernelGGL((k_dwdx_lds<2>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, pj, tail);
-    else hipLaunchKernelGGL((k_dwdx_lds<1>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, pj, tail);
+#define DWDX_LAUNCH(NTv, Wv) hipLaunchKernelGGL((k_dwdx_lds<NTv, Wv>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, tail)
+    if (pj == 2) { if (NT == 4) DWDX_LAUNCH(4, true); else if (NT == 2) DWDX_LAUNCH(2, true); else DWDX_LAUNCH(1, true); }
+    else { if (NT == 4) DWDX_LAUNCH(4, false); else if (NT == 2) DWDX_LAUNCH(2, false); else DWDX_LAUNCH(1, false); }
+#undef DWDX_LAUNCH
 }

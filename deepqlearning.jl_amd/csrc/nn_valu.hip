@@ -102,8 +102,8 @@ unsigned valu_task_blocks(const VTask& T) {
 // ... with the step's priority block as workgroup 0: its dependent tree levels hide under the task table instead of inside the Adam launch,
 // which leaves the Adam launch free to gather the next batch (PreGather)
 __global__ __launch_bounds__(256) void k_valu_multi_prio(const VTask* __restrict__ tasks, int ntasks, PrioArgs P, StepState* state) {
-    __shared__ long long sidx[1024];
-    if (blockIdx.x == 0) { prio_block_run(P, state, sidx); return; }
+    __shared__ __attribute__((aligned(16))) long long sidx[1024 + 128];      // 7808 B of path state + the top 256 nodes (small replays: most of the tree)
+    if (blockIdx.x == 0) { prio_block_run(P, state, sidx, (unsigned)sizeof sidx); return; }
     valu_task_run(tasks, ntasks, blockIdx.x - 1);
 }
 void launch_valu_multi(hipStream_t st, const VTask* tasks_dev, int ntasks, unsigned total_blocks, const PrioArgs* prio, StepState* state) {
@@ -498,8 +498,8 @@ void launch_q_columns(hipStream_t st, int n, int nA, int dueling, const float* v
 // ------------------------------------------------------------------ globalnorm (helpers.jl:38-46) + Flux Adam (solver.jl:66,228), fused, HBM-bound:
 // per element 16 B read (p,m,v,g) + 12 B written; the job body lives in adam_body.h (shared with the backward launches' tails)
 __global__ __launch_bounds__(256) void k_adam(AdamJob J) {
-    __shared__ long long sidx[1024]; __shared__ float wmax[4];
-    adam_job_run(J, (int)blockIdx.x, sidx, wmax);
+    __shared__ __attribute__((aligned(16))) long long sidx[3072]; __shared__ float wmax[4];      // 7808 B of path state + the top 4096 nodes of the sum-tree (prio_block_fast)
+    adam_job_run(J, (int)blockIdx.x, sidx, wmax, false, (unsigned)sizeof sidx);
 }
 // jobs without a priority block: no LDS to speak of, so their workgroups fit beside the LDS-heavy GEMM workgroups of a concurrent launch
 __global__ __launch_bounds__(256) void k_adam_stream(AdamJob J) {

@@ -63,31 +63,22 @@ __device__ __forceinline__ void valu_dw_body(const LayerDev& L, const float* __r
     if (L.kind != DQN_LAYER_CONV) {      // dense: one "position"; operands are two contiguous rows -> 16 loads in flight, chain order unchanged
         const float* dr = dpre + (size_t)n * B; const float* xr = k < L.K ? X + (size_t)k * ldx : nullptr;
         int j = j0;
-        if (j1 - j0 == 64) {                 // a 64-sample chunk (head layers at large batches): one round of 32 float4 loads
-            f32x4v dq[16], xq[16];
+        // rounds of 16 samples (4 + 4 float4 loads in flight), chain order unchanged.  One round of 32 or 64 samples held 64-128 registers here and,
+        // through the tail tasks, set the register budget -- and the occupancy -- of every LDS-tiled backward launch.
+        if (((j1 - j0) & 15) == 0 && (((size_t)dr | (size_t)(xr ? xr : dr)) & 15) == 0 && (j0 & 3) == 0) {
+#pragma unroll 1
+            for (; j < j1; j += 16) {
+                f32x4v dq[4], xq[4];
 #pragma unroll
-            for (int u = 0; u < 16; u++) { dq[u] = *reinterpret_cast<const f32x4v*>(dr + j0 + 4 * u); xq[u] = xr ? *reinterpret_cast<const f32x4v*>(xr + j0 + 4 * u) : (f32x4v){1.f, 1.f, 1.f, 1.f}; }
-            if (xr) {
+                for (int u = 0; u < 4; u++) { dq[u] = *reinterpret_cast<const f32x4v*>(dr + j + 4 * u); xq[u] = xr ? *reinterpret_cast<const f32x4v*>(xr + j + 4 * u) : (f32x4v){1.f, 1.f, 1.f, 1.f}; }
+                if (xr) {
 #pragma unroll
-                for (int u = 0; u < 16; u++) { acc = fmaf(xq[u].x, dq[u].x, acc); acc = fmaf(xq[u].y, dq[u].y, acc); acc = fmaf(xq[u].z, dq[u].z, acc); acc = fmaf(xq[u].w, dq[u].w, acc); }
-            } else {
+                    for (int u = 0; u < 4; u++) { acc = fmaf(xq[u].x, dq[u].x, acc); acc = fmaf(xq[u].y, dq[u].y, acc); acc = fmaf(xq[u].z, dq[u].z, acc); acc = fmaf(xq[u].w, dq[u].w, acc); }
+                } else {
 #pragma unroll
-                for (int u = 0; u < 16; u++) { acc = acc + dq[u].x; acc = acc + dq[u].y; acc = acc + dq[u].z; acc = acc + dq[u].w; }
+                    for (int u = 0; u < 4; u++) { acc = acc + dq[u].x; acc = acc + dq[u].y; acc = acc + dq[u].z; acc = acc + dq[u].w; }
+                }
             }
-            j = j1;
-        }
-        if (j1 - j0 == 32) {                 // B = 32: the whole sample axis in one round of loads
-            float dv[32], xv[32];
-#pragma unroll
-            for (int u = 0; u < 32; u++) { dv[u] = dr[j0 + u]; xv[u] = xr ? xr[j0 + u] : 1.0f; }
-            if (xr) {
-#pragma unroll
-                for (int u = 0; u < 32; u++) acc = fmaf(xv[u], dv[u], acc);
-            } else {
-#pragma unroll
-                for (int u = 0; u < 32; u++) acc = acc + dv[u];
-            }
-            j = j1;
         }
         for (; j + 8 <= j1; j += 8) {
             float dv[8], xv[8];
@@ -157,12 +148,15 @@ __device__ __forceinline__ void valu_loss_fold(const float* __restrict__ hl, int
     *out = lsum / (float)B;
 }
 // run workgroup `blk` (256 threads) of a task table: task i owns blocks [first_block_i, first_block_{i+1})
+// FWD = false: the table holds no forward task (the TAIL tables of the backward launches: heads' dW / dX, the loss fold) -- the forward body is the
+// register-hungriest of the four and, compiled into an LDS-tiled kernel, cost that kernel a third of its occupancy (123 vs 80 VGPRs)
+template <bool FWD = true>
 __device__ __forceinline__ void valu_task_run(const VTask* __restrict__ tasks, int ntasks, unsigned blk) {
     int ti = 0;
     while (ti + 1 < ntasks && blk >= tasks[ti + 1].first_block) ti++;
     const VTask& T = tasks[ti];
     const size_t t = (size_t)(blk - T.first_block) * 256 + threadIdx.x;
-    if (T.kind == 0) valu_fwd_body(T.L, T.P, T.X, T.ldx, T.col0, T.ncols, T.S, T.kc, T.out, t);
+    if (T.kind == 0) { if constexpr (FWD) valu_fwd_body(T.L, T.P, T.X, T.ldx, T.col0, T.ncols, T.S, T.kc, T.out, t); }
     else if (T.kind == 1) valu_dw_body(T.L, T.X, T.ldx, T.dpre, T.B, T.S, T.kc, T.out, t);
     else if (T.kind == 2) valu_dx_body(T.L, T.P, T.dpre, T.B, T.S, T.kc, T.out, T.addend, T.ysrc, T.ldy, T.act_src, t);
     else valu_loss_fold(T.dpre, T.B, T.out, t);

@@ -25,17 +25,30 @@ eng.train_step()
 n = 1 + 8 * 65536
 buf = np.zeros(n, np.uint64)
 assert f(eng._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), n) == 0
-cnt = int(buf[0]); rec = buf[1:1 + 8 * cnt].reshape(cnt, 8).astype(np.int64)
+cnt = int(buf[0]); raw = buf[1:1 + 8 * cnt].reshape(cnt, 8)
+rt0 = (raw[:, 0] >> np.uint64(32)).astype(np.int64); rt1 = (raw[:, 1] >> np.uint64(32)).astype(np.int64)      # s_memrealtime (100 MHz, common to all XCDs) at entry / exit
+rec = raw.astype(np.int64); rec[:, 0] &= 0xffffffff; rec[:, 1] &= 0xffffffff
 roles = {0: "prio", 1: "dX", 2: "tail", 3: "dW"}
 # forward records use words 3..7 as timestamps (large); backward records hold a role < 4 in word 3
-bw = rec[rec[:, 3] < 4]
+sel = rec[:, 3] < 4
+bw = rec[sel]; rt0 = rt0[sel]; rt1 = rt1[sel]
 print("backward records", len(bw))
 for grid in sorted(set(bw[:, 0])):
-    r = bw[bw[:, 0] == grid]
-    t0 = r[:, 2].min()
-    print(f"grid {grid}: {len(r)} workgroups, span {(r[:, 7].max() - t0) / TPU:.2f} us, entry spread {(r[:, 2].max() - t0) / TPU:.2f} us")
+    g = bw[:, 0] == grid
+    r = bw[g]; a0 = rt0[g]; a1 = rt1[g]
+    t0 = r[:, 2].min(); T0 = a0.min()
+    print(f"grid {grid}: {len(r)} workgroups; wall clock (s_memrealtime, 0.01 us ticks): first entry 0, last entry {(a0.max() - T0) / 100:.2f} us, last exit {(a1.max() - T0) / 100:.2f} us")
+    for role in sorted(set(r[:, 3])):
+        q = r[:, 3] == role
+        e0 = (a0[q] - T0) / 100; e1 = (a1[q] - T0) / 100
+        print(f"   {roles[int(role)]:5s} wall: entries {e0.min():6.2f} .. {e0.max():6.2f} (median {np.median(e0):6.2f}), exits {e1.min():6.2f} .. {e1.max():6.2f} (median {np.median(e1):6.2f}) us")
     for role in sorted(set(r[:, 3])):
         q = r[r[:, 3] == role]
         life = (q[:, 7] - q[:, 2]) / TPU
+        if int(role) == 0 and (q[:, 4] > 0).all():      # priority block (prio_block_fast): words 4..6 = tree top + indices in LDS, siblings / TD / leaves done, ancestors done
+            print("   prio phases (us): indices + tree top in LDS %.2f, siblings + pow + leaves %.2f, ancestors (one wave) %.2f, draws + exit %.2f" % tuple(float(x[0]) / TPU for x in (q[:, 4] - q[:, 2], q[:, 5] - q[:, 4], q[:, 6] - q[:, 5], q[:, 7] - q[:, 6])))
+        if int(role) == 1 and (q[:, 4] > 0).all():      # dX (dx_units_body): words 4..6 = first tile staged, K loop done, unit sums combined
+            ph = [(q[:, 4] - q[:, 2]) / TPU, (q[:, 5] - q[:, 4]) / TPU, (q[:, 6] - q[:, 5]) / TPU, (q[:, 7] - q[:, 6]) / TPU]
+            print("   dX phases of wave 0 (median / max us): first tile staged %.2f / %.2f, K loop %.2f / %.2f, wait for the other units %.2f / %.2f, combine + store %.2f / %.2f" % tuple(x for p_ in ph for x in (np.median(p_), p_.max())))
         print(f"   {roles[int(role)]:5s} n={len(q):5d}  first entry {(q[:, 2].min() - t0) / TPU:6.2f}  last entry {(q[:, 2].max() - t0) / TPU:6.2f}  last exit {(q[:, 7].max() - t0) / TPU:6.2f}"
               f"  lifetime median {np.median(life):6.2f}  p10 {np.percentile(life, 10):6.2f}  p90 {np.percentile(life, 90):6.2f}  max {life.max():6.2f} us")
