@@ -128,7 +128,8 @@ static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out) {
         out[i].dw_kc = 0;
         if (L[i].kind == DQN_LAYER_DENSE && L[i].N < 16 && B >= 128) out[i].dw_kc = 64;   // head layers at large batches: 64-sample chains on 8x more threads instead of one B-long chain per output
         if (L[i].kind == DQN_LAYER_CONV) {   // positions per chunk so that (K/64 row tiles) x chunks >= ~512 workgroups
-            const int st = (512 + (L[i].K + 63) / 64 - 1) / ((L[i].K + 63) / 64); int ppc = L[i].npos / st; if (ppc < 1) ppc = 1; out[i].dw_kc = ppc * B;
+            static const int tgt = getenv("DQN_DW_WGS") ? atoi(getenv("DQN_DW_WGS")) : 512;      // experiment knob
+            const int st = (tgt + (L[i].K + 63) / 64 - 1) / ((L[i].K + 63) / 64); int ppc = L[i].npos / st; if (ppc < 1) ppc = 1; out[i].dw_kc = ppc * B;
         }
     }
 }
@@ -591,6 +592,7 @@ int fetch_scalars(dqn_engine* e, float* loss, float* gn) {
     if (!e->state_host) HIPCHK(hipHostMalloc((void**)&e->state_host, sizeof(StepState), hipHostMallocDefault));
     HIPCHK(hipMemcpyAsync(e->state_host, e->state, sizeof(StepState), hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream));
     const StepState s = *e->state_host;
+    if (s.err) { HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&e->state->err, 0, 1, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); }      // reported once, not on every later call
     if (s.err == 2) return fail("AssertionError: all(new_priorities .> 0f0)");
     if (s.err == 3) return fail("internal error: a pre-gathered batch was consumed after the replay changed (StepState::pre_valid != 2)");
     if (loss) *loss = s.loss;
@@ -820,8 +822,9 @@ static int profile_step(dqn_engine_t* e, int max_entries, const char** names, fl
     else if (steady && !build_program(e)) {      // a MIDDLE step of dqn_train_steps(n): one un-timed step first (its Adam launch gathers the timed step's batch)
         e->profiling = false; rc = run_step(e, true, false, e->pg_ok); e->profiling = true;
         if (!rc) rc = run_step(e, true, e->pg_ok, e->pg_ok);
-        // the timed step's own pre-gather filled the arena for a step that will not come: drop it (pre_valid 2 -> 1 is implied by the next gather
-        // launch overwriting the arena; the indices in idx_pre stay valid)
+        // the timed step's own pre-gather filled the arena for a step that will not come: drop it (2 -> 1: the indices in idx_pre stay valid, the
+        // next gather launch overwrites the arena)
+        if (!rc && e->pg_ok) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&e->state->pre_valid, 1, 1, e->stream));      // (a memset node: no host buffer, safe behind the gate kernel)
     }
     else rc = run_step(e, true);
     e->profiling = false;

@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256) void k_adam_pg(AdamJob J, PreGather G) {
     if ((int)blockIdx.x < npg) {
         const int bx = (int)blockIdx.x % G.gx, by = (int)blockIdx.x / G.gx;
         gather_fb_body(G.s_rows, G.sp_rows, 0, G.E, G.B, G.idx_pre, G.x0, 1, G.cap2, G.tree, G.seed, J.state, G.meta, G.idx_pre, bx, by, tile, rows);
-        if (blockIdx.x == 0 && threadIdx.x == 0 && J.state->pre_valid) J.state->pre_valid = 2;
+        if (blockIdx.x == 0 && threadIdx.x == 0) J.state->pre_valid = 2;      // unconditionally: without pre-drawn indices the gather body descended itself and wrote the same batch (+ idx_pre)
         return;
     }
     adam_job_run(J, (int)blockIdx.x - npg, nullptr, wmax);
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void k_adam_pg_u8(AdamJob J, PreGather G) {
         const int bx = (int)blockIdx.x % G.gx, by = (int)blockIdx.x / G.gx;
         gather_u8b_body((const unsigned char*)G.s_rows, (const unsigned char*)G.sp_rows, G.E, G.B, G.idx_pre, (unsigned char*)G.x0, 1, G.cap2, G.tree, G.seed, J.state, G.meta,
                         G.idx_pre, bx, by, tile32, rows);
-        if (blockIdx.x == 0 && threadIdx.x == 0 && J.state->pre_valid) J.state->pre_valid = 2;
+        if (blockIdx.x == 0 && threadIdx.x == 0) J.state->pre_valid = 2;      // unconditionally: without pre-drawn indices the gather body descended itself and wrote the same batch (+ idx_pre)
         return;
     }
     adam_job_run(J, (int)blockIdx.x - npg, nullptr, wmax);

@@ -82,7 +82,17 @@ flatparams(q) = reduce(vcat, [vec(Float32.(w)) for w in Flux.params(q)])   # Flu
 mutable struct Engine
     h::Ptr{Cvoid}
     B::Int; nA::Int; obs_dims::Tuple
+    obs_u8::Bool      # replay rows are BYTES (hp.obs_dtype = DQN_OBS_U8): training reads byte / 255f0 (test/test_env.jl:59)
 end
+# observation rows in the replay's storage type.  dqn_replay_add / dqn_episode_add read the void* as bytes for a u8 replay: a Float32 buffer there
+# would be cut to its first E bytes, so only UInt8 arrays are accepted (the Python mirror's _obs_rows does the same)
+function obs_rows(e::Engine, x, what)
+    e.obs_u8 || return Float32.(vec(x))
+    eltype(x) == UInt8 || error("$what: this replay stores UInt8 observations (obs_u8 = true); got $(eltype(x)) -- pass the raw bytes")
+    return collect(vec(x))
+end
+# what the POLICY must see for such a replay: the scale training uses
+policy_obs(e::Engine, o) = (e.obs_u8 && eltype(o) == UInt8) ? Float32.(vec(o)) ./ 255f0 : Float32.(vec(o))
 function Engine(solver::DeepQLearningSolver, env::AbstractEnv, q; device=0, obs_u8=false)
     o = observe(env); dims = size(o)
     c, h, w = length(dims) == 3 ? (dims[3], dims[2], dims[1]) : (prod(dims), 1, 1)   # Julia (W,H,C) -> C [C][H][W]
@@ -96,7 +106,7 @@ function Engine(solver::DeepQLearningSolver, env::AbstractEnv, q; device=0, obs_
     descs = lower(q); out = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:dqn_engine_create, LIB), Cint, (Ptr{LayerDesc}, Cint, Ref{HParams}, Ptr{Cvoid}, Cint, Ref{Ptr{Cvoid}}),
                 descs, length(descs), hp, C_NULL, device, out))
-    e = Engine(out[], solver.batch_size, length(actions(env)), dims)
+    e = Engine(out[], solver.batch_size, length(actions(env)), dims, obs_u8)
     finalizer(x -> ccall((:dqn_engine_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), e)
     p = flatparams(q)
     check(ccall((:dqn_set_params, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Float32}, Csize_t), e.h, 0, p, length(p)))
@@ -114,7 +124,7 @@ cur_size(r::HIPReplayBuffer) = (cur = Ref{Int64}(); ccall((:dqn_replay_size, LIB
 is_full(r::HIPReplayBuffer) = cur_size(r) == max_size(r)
 
 function add_exp!(r::HIPReplayBuffer, expe::DQExperience, td_err=abs(expe.r))      # :65-74
-    s = Float32.(vec(expe.s)); sp = Float32.(vec(expe.sp))
+    s = obs_rows(r.e, expe.s, "add_exp!"); sp = obs_rows(r.e, expe.sp, "add_exp!")
     check(ccall((:dqn_replay_add, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int32}, Ref{Float32}, Ptr{Cvoid}, Ref{UInt8}, Ref{Float32}, Cint),
                 r.e.h, s, Int32(expe.a - 1), Float32(expe.r), sp, UInt8(expe.done), Float32(td_err), 1))   # 1-based -> 0-based action
 end
@@ -178,7 +188,7 @@ mutable struct HIPEpisodeReplayBuffer
 end
 function add_exp!(r::HIPEpisodeReplayBuffer, expe::DQExperience)                      # :46-52 (the engine stores the episode when done)
     check(ccall((:dqn_episode_add, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int32}, Ref{Float32}, Ptr{Cvoid}, Ref{UInt8}, Cint),
-                r.e.h, Float32.(vec(expe.s)), Int32(expe.a - 1), Float32(expe.r), Float32.(vec(expe.sp)), UInt8(expe.done), 1))
+                r.e.h, obs_rows(r.e, expe.s, "add_exp!"), Int32(expe.a - 1), Float32(expe.r), obs_rows(r.e, expe.sp, "add_exp!"), UInt8(expe.done), 1))
 end
 add_episode!(r::HIPEpisodeReplayBuffer) = check(ccall((:dqn_episode_commit, LIB), Cint, (Ptr{Cvoid},), r.e.h))   # :54-60, after generate_episode
 ep_count(r::HIPEpisodeReplayBuffer) = (cur = Ref{Int64}(); ccall((:dqn_episode_count, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}, Ptr{Int64}), r.e.h, cur, C_NULL); cur[])
@@ -225,7 +235,7 @@ actionmap(p::HIPNNPolicy) = p.action_map
 function _q(p::HIPNNPolicy, o)
     ndims(o) == p.n_input_dims || throw("NNPolicyError: was expecting an array with $(p.n_input_dims) dimensions, got $(ndims(o))")
     q = zeros(Float32, p.e.nA)
-    check(ccall((:dqn_forward, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Float32}, Cint, Ptr{Float32}), p.e.h, 0, Float32.(vec(o)), 1, q))
+    check(ccall((:dqn_forward, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Float32}, Cint, Ptr{Float32}), p.e.h, 0, policy_obs(p.e, o), 1, q))
     q
 end
 POMDPs.action(p::HIPNNPolicy, o::AbstractArray) = p.action_map[argmax(_q(p, o))]

@@ -166,3 +166,17 @@ def test_julia_delimiters_balance():
     opens += len(re.findall(r"(?:^|;|\n)[ \t]*for\b", src))       # statement-level `for` only: comprehensions / generators carry no `end`
     ends = len(re.findall(r"(?<![\w!.:\[])end\b", src))
     assert opens == ends, (opens, ends)
+
+
+def test_u8_replay_is_fed_bytes_and_policy_sees_training_scale():
+    """with MI355XSolver(...; obs_u8 = true) the engine reads the void* of dqn_replay_add / dqn_episode_add as BYTES; the shim
+    must hand over UInt8 rows (never Float32.(...)) and the policy forward must see byte / 255f0, the scale training uses."""
+    src = open(SHIM).read()
+    assert re.search(r"obs_u8::Bool", src) and "Engine(out[], solver.batch_size, length(actions(env)), dims, obs_u8)" in src
+    for call in ("dqn_replay_add", "dqn_episode_add"):
+        stmt = src[src.index(f"(:{call}, LIB)") - 200:src.index(f"(:{call}, LIB)") + 400]
+        assert "obs_rows(r.e, expe.s" in stmt and "obs_rows(r.e, expe.sp" in stmt, call
+        assert "Float32.(vec(expe" not in stmt, call
+    fwd = src[src.index("(:dqn_forward, LIB)"):src.index("(:dqn_forward, LIB)") + 200]
+    assert "policy_obs(p.e, o)" in fwd
+    assert "./ 255f0" in src and 'eltype(x) == UInt8 || error(' in src
