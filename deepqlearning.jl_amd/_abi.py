@@ -147,6 +147,8 @@ PROTOS = {
     "evaluate": [_vp, C.c_int, C.c_int, C.c_uint64, _f64p, _f64p],
     "replay_export": [_vp, C.c_int64, C.c_int64, _vp, _vp, _i32p, _f32p, _u8p, _f32p],
     "replay_import": [_vp, C.c_int64, _vp, _vp, _i32p, _f32p, _u8p, _f32p],
+    "episode_export": [_vp, C.c_int64, C.c_int64, _f32p, _f32p, _i32p, _f32p, _u8p, _i32p],
+    "episode_import": [_vp, C.c_int64, _f32p, _f32p, _i32p, _f32p, _u8p, _i32p],
     "get_counters": [_vp, _P(Counters)],
     "set_counters": [_vp, _P(Counters)],
 }
@@ -453,8 +455,27 @@ class Handle:
         c = Counters(int(size), int(widx), int(sample_ctr), int(train_steps))
         self._check(self.f["set_counters"](self._h, C.byref(c)))
 
+    def episode_export(self, first=0, n=None):
+        n = self.episode_count()[0] - first if n is None else n
+        T = self.hp.trace_length
+        s = np.empty((n, T) + self.obs_shape, np.float32); sp = np.empty_like(s)
+        a, r, d, ln = np.empty((n, T), np.int32), np.empty((n, T), np.float32), np.empty((n, T), np.uint8), np.empty(n, np.int32)
+        self._check(self.f["episode_export"](self._h, first, n, _ptr(s, _f32p), _ptr(sp, _f32p), _ptr(a, _i32p), _ptr(r, _f32p), _ptr(d, _u8p), _ptr(ln, _i32p)))
+        return s, sp, a, r, d, ln
+
+    def episode_import(self, s, sp, a, r, done, ep_len):
+        s, sp = _as(s, np.float32), _as(sp, np.float32)
+        a, r, done, ep_len = _as(a, np.int32), _as(r, np.float32), _as(done, np.uint8), _as(ep_len, np.int32)
+        self._check(self.f["episode_import"](self._h, ep_len.size, _ptr(s, _f32p), _ptr(sp, _f32p), _ptr(a, _i32p), _ptr(r, _f32p), _ptr(done, _u8p), _ptr(ep_len, _i32p)))
+
     def checkpoint(self):
         """everything a bit-exact resume of the train loop needs, as a dict of NumPy arrays (np.savez-able)."""
+        if self.hp.recurrence:
+            s, sp, a, r, d, ln = self.episode_export()
+            m, v, bp = self.get_adam_state()
+            c = self.get_counters()
+            return dict(p_on=self.get_params(NET_ONLINE), p_tg=self.get_params(NET_TARGET), adam_m=m, adam_v=v, adam_bp=np.asarray(bp, np.float64),
+                        s=s, sp=sp, a=a, r=r, done=d, ep_len=ln, counters=np.array([c["size"], c["widx"], c["sample_ctr"], c["train_steps"]], np.uint64))      # the draw counter uses all 64 bits
         s, sp, a, r, d, pr = self.replay_export()
         m, v, bp = self.get_adam_state()
         c = self.get_counters()
@@ -463,7 +484,10 @@ class Handle:
 
     def restore(self, ck):
         self.set_params(ck["p_on"], NET_ONLINE); self.set_params(ck["p_tg"], NET_TARGET)
-        self.replay_import(ck["s"], ck["sp"], ck["a"], ck["r"], ck["done"], ck["priorities"])
+        if self.hp.recurrence:
+            self.episode_import(ck["s"], ck["sp"], ck["a"], ck["r"], ck["done"], ck["ep_len"])
+        else:
+            self.replay_import(ck["s"], ck["sp"], ck["a"], ck["r"], ck["done"], ck["priorities"])
         size, widx, sctr, steps = (int(x) for x in ck["counters"])
         self.set_counters(size, widx, sctr, steps)
         self.set_adam_state(ck["adam_m"], ck["adam_v"], ck["adam_bp"])

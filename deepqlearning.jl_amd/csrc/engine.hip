@@ -386,7 +386,7 @@ extern "C" int dqn_replay_get_priorities(dqn_engine_t* e, float* prio, int64_t n
 // ---------------------------------------------------------------- checkpoint / resume
 extern "C" int dqn_replay_export(dqn_engine_t* e, int64_t first, int64_t n, void* s, void* sp, int32_t* a, float* r, uint8_t* done, float* prio) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device));
-    if (e->hp.recurrence) return fail("recurrence = true: the episode replay has no export yet");
+    if (e->hp.recurrence) return fail("recurrence = true: use dqn_episode_export");
     if (first < 0 || n < 0 || first + n > e->size) return fail("BoundsError: rows %lld..%lld outside 0..%lld", (long long)first, (long long)(first + n - 1), (long long)e->size - 1);
     HIPCHK(hipStreamSynchronize(e->stream));
     const size_t row = (size_t)e->E * (e->hp.obs_dtype == DQN_OBS_U8 ? 1 : 4);
@@ -400,7 +400,7 @@ extern "C" int dqn_replay_export(dqn_engine_t* e, int64_t first, int64_t n, void
 }
 extern "C" int dqn_replay_import(dqn_engine_t* e, int64_t n, const void* s, const void* sp, const int32_t* a, const float* r, const uint8_t* done, const float* prio) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device));
-    if (e->hp.recurrence) return fail("recurrence = true: the episode replay has no import yet");
+    if (e->hp.recurrence) return fail("recurrence = true: use dqn_episode_import");
     if (n < 0 || n > e->cap) return fail("import of %lld transitions into a replay of capacity %lld", (long long)n, (long long)e->cap);
     for (int64_t i = 0; i < n; i++) {
         if (a[i] < 0 || a[i] >= e->nA) return fail("action index %d out of range 0..%d", a[i], e->nA - 1);
@@ -422,20 +422,24 @@ extern "C" int dqn_replay_import(dqn_engine_t* e, int64_t n, const void* s, cons
 extern "C" int dqn_get_counters(dqn_engine_t* e, dqn_counters* out) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream));
     StepState st; HIPCHK(hipMemcpy(&st, e->state, sizeof st, hipMemcpyDeviceToHost));
+    if (e->hp.recurrence) { out->size = e->ep_size; out->widx = e->ep_widx; out->sample_ctr = e->drqn_draws; out->train_steps = st.step; return 0; }      // episode replay: episodes, ring cursor, the host sampler's draw counter
     out->size = e->size; out->widx = e->widx; out->sample_ctr = st.sample_ctr; out->train_steps = st.step; return 0;
 }
 extern "C" int dqn_set_counters(dqn_engine_t* e, const dqn_counters* in) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream));
-    if (in->size != e->size) return fail("counters.size (%lld) differs from the replay's (%lld): import the replay first", (long long)in->size, (long long)e->size);
-    if (in->widx < 0 || in->widx >= e->cap) return fail("counters.widx out of range");
+    const long long have = e->hp.recurrence ? e->ep_size : e->size, capn = e->hp.recurrence ? e->ep_cap : e->cap;
+    if (in->size != have) return fail("counters.size (%lld) differs from the replay's (%lld): import the replay first", (long long)in->size, have);
+    if (in->widx < 0 || in->widx >= capn) return fail("counters.widx out of range");
     StepState st; HIPCHK(hipMemcpy(&st, e->state, sizeof st, hipMemcpyDeviceToHost));
     // the Adam beta powers are double-buffered by step parity: after a step with counter S the LIVE pair (the one the next step reads) sits in
     // slot (S + 1) & 1 -- the slot dqn_get_adam_state reports.  Whatever the new parity, make both slots hold the live pair.
     const int live = (int)((st.step + 1ull) & 1ull);
     st.bp[live ^ 1][0] = st.bp[live][0]; st.bp[live ^ 1][1] = st.bp[live][1];
-    st.sample_ctr = in->sample_ctr; st.step = in->train_steps; st.pre_valid = 0;
+    if (!e->hp.recurrence) st.sample_ctr = in->sample_ctr;
+    st.step = in->train_steps; st.pre_valid = 0;
     HIPCHK(hipMemcpy(e->state, &st, sizeof st, hipMemcpyHostToDevice));
-    e->widx = in->widx; return 0;
+    if (e->hp.recurrence) { e->ep_widx = in->widx; e->drqn_draws = in->sample_ctr; } else e->widx = in->widx;
+    return 0;
 }
 static int check_idx(dqn_engine* e, const int64_t* idx, int n) {
     for (int i = 0; i < n; i++) if (idx[i] < 0 || idx[i] >= e->size) return fail("BoundsError: index %lld outside 0..%lld", (long long)idx[i], (long long)e->size - 1);

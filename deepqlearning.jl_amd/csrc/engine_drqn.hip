@@ -31,6 +31,43 @@ extern "C" int dqn_episode_add(dqn_engine_t* e, const void* s, const int32_t* a,
     }
     return 0;
 }
+// ---------------------------------------------------------------- checkpoint / resume of the episode replay (SURVEY 8f-3 for config 4)
+// episodes first .. first+n-1 in slot order: rows [n][T][E] (only the first trace_length transitions of an episode are ever stored, see
+// dqn_episode_add), a / r / done [n][T], len [n] (the episode's TRUE length, which the start draw uses).  An episode still being collected
+// (dqn_episode_add without its terminal transition) is not part of a checkpoint: commit or finish it first.
+extern "C" int dqn_episode_export(dqn_engine_t* e, int64_t first, int64_t n, float* s, float* sp, int32_t* a, float* r, uint8_t* done, int32_t* len) { if (!e) return fail("null engine handle");
+    NEED_REC(e); HIPCHK(hipSetDevice(e->device));
+    if (first < 0 || n < 0 || first + n > e->ep_size) return fail("BoundsError: episodes %lld..%lld outside 0..%lld", (long long)first, (long long)(first + n - 1), (long long)e->ep_size - 1);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const size_t T = (size_t)e->T, row = (size_t)e->E * 4, off = (size_t)first * T, cnt = (size_t)n * T;
+    if (s) HIPCHK(hipMemcpy(s, (const char*)e->ep_s + off * row, cnt * row, hipMemcpyDeviceToHost));
+    if (sp) HIPCHK(hipMemcpy(sp, (const char*)e->ep_sp + off * row, cnt * row, hipMemcpyDeviceToHost));
+    if (a) HIPCHK(hipMemcpy(a, e->ep_a + off, cnt * 4, hipMemcpyDeviceToHost));
+    if (r) HIPCHK(hipMemcpy(r, e->ep_r + off, cnt * 4, hipMemcpyDeviceToHost));
+    if (done) HIPCHK(hipMemcpy(done, e->ep_done + off, cnt, hipMemcpyDeviceToHost));
+    if (len) for (int64_t i = 0; i < n; i++) len[i] = e->ep_len_host[(size_t)(first + i)];
+    return 0;
+}
+// replaces the whole episode replay: n <= capacity committed episodes go to slots 0..n-1; the ring cursor becomes n mod capacity (override it,
+// and the host sampler's draw counter, with dqn_set_counters: widx, sample_ctr)
+extern "C" int dqn_episode_import(dqn_engine_t* e, int64_t n, const float* s, const float* sp, const int32_t* a, const float* r, const uint8_t* done, const int32_t* len) { if (!e) return fail("null engine handle");
+    NEED_REC(e); HIPCHK(hipSetDevice(e->device));
+    if (n < 0 || n > e->ep_cap) return fail("import of %lld episodes into an episode replay of capacity %lld", (long long)n, (long long)e->ep_cap);
+    const size_t T = (size_t)e->T, row = (size_t)e->E * 4, cnt = (size_t)n * T;
+    for (int64_t i = 0; i < n; i++) {
+        if (len[i] < 1) return fail("episode %lld: length %d < 1", (long long)i, len[i]);
+        const int m = len[i] < e->T ? len[i] : e->T;
+        for (int t = 0; t < m; t++) if (a[(size_t)i * T + t] < 0 || a[(size_t)i * T + t] >= e->nA) return fail("action index %d out of range 0..%d", a[(size_t)i * T + t], e->nA - 1);
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(e->ep_s, s, cnt * row, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(e->ep_sp, sp, cnt * row, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->ep_a, a, cnt * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(e->ep_r, r, cnt * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->ep_done, done, cnt, hipMemcpyHostToDevice));
+    for (int64_t i = 0; i < n; i++) e->ep_len_host[(size_t)i] = len[i];
+    HIPCHK(hipMemcpy(e->ep_len, e->ep_len_host.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    e->ep_size = n; e->ep_widx = n % e->ep_cap; e->ep_cur_len = 0; e->ep_perm.clear();
+    return 0;
+}
 extern "C" int dqn_episode_count(dqn_engine_t* e, int64_t* cur, int64_t* cap) { if (!e) return fail("null engine handle"); NEED_REC(e); if (cur) *cur = e->ep_size; if (cap) *cap = e->ep_cap; return 0; }
 static int drqn_check(dqn_engine* e, const int64_t* ep_idx, const int32_t* ep_start) {
     if (e->ep_size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");

@@ -236,6 +236,12 @@ typedef struct { int64_t size, widx; uint64_t sample_ctr, train_steps; } dqn_cou
 int dqn_replay_export(dqn_engine_t* e, int64_t first, int64_t n, void* s, void* sp, int32_t* a, float* r, uint8_t* done, float* priorities);
 /* replaces the whole replay: n <= capacity transitions go to slots 0..n-1 with the given priorities (NOT td errors); the sum-tree is rebuilt */
 int dqn_replay_import(dqn_engine_t* e, int64_t n, const void* s, const void* sp, const int32_t* a, const float* r, const uint8_t* done, const float* priorities);
+/* ... and for the episode replay of a recurrent engine (src/episode_replay.jl; config 4): episodes first..first+n-1 in slot order, rows
+ * [n][trace_length][obs] float (only the first trace_length transitions of an episode can ever be sampled, :82-92, so only they are stored),
+ * a / r / done [n][trace_length], len[n] = the episode's true length.  dqn_get/set_counters then mean: size = episodes, widx = ring cursor,
+ * sample_ctr = the host sampler's draw counter.  An episode still being collected is not part of a checkpoint. */
+int dqn_episode_export(dqn_engine_t* e, int64_t first, int64_t n, float* s, float* sp, int32_t* a, float* r, uint8_t* done, int32_t* len);
+int dqn_episode_import(dqn_engine_t* e, int64_t n, const float* s, const float* sp, const int32_t* a, const float* r, const uint8_t* done, const int32_t* len);
 int dqn_get_counters(dqn_engine_t* e, dqn_counters* out);
 int dqn_set_counters(dqn_engine_t* e, const dqn_counters* in);   /* size must equal the imported n; widx < capacity */
 

@@ -100,3 +100,36 @@ def test_recurrent_policy_and_sampled_draws_bit_exact_vs_twin(pkg, name):
         assert gpu.train_step_drqn() == cpu.train_step_drqn()
     np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
     gpu.close(); cpu.close()
+
+
+def test_drqn_checkpoint_resume_is_bit_exact(pkg, tmp_path):
+    """SURVEY 8(f)-3 for BASELINE config 4: dqn_episode_export/import + counters (episodes, ring cursor, the host sampler's draw counter) +
+    parameters + Adam state: a DRQN run continued in a NEW engine reproduces the uninterrupted run bit for bit, with the engine's own
+    episode draws (train_step_drqn()) -- and the next episode lands in the same ring slot."""
+    name = "cfg4_lstm_plain" if "cfg4_lstm_plain" in drqn_nets() else list(drqn_nets())[0]
+    net, B, T, kw, rng, a, cpu, ring, params = setup(pkg, name)
+    cpu.close()
+    for _ in range(3):
+        a.train_step_drqn()
+    ck = a.checkpoint()
+    np.savez(tmp_path / "ck.npz", **ck)
+    want = [a.train_step_drqn() for _ in range(4)]
+    cap = max(12, B + 4)
+    b, hp, layers = make_handle(pkg.Engine, net, B, T, dict(kw, use_mfma=1, use_graph=1), cap=cap)
+    b.restore(dict(np.load(tmp_path / "ck.npz")))
+    assert b.get_counters() == {k: int(v) for k, v in zip(("size", "widx", "sample_ctr", "train_steps"), ck["counters"])}
+    assert b.episode_count() == a.episode_count()
+    got = [b.train_step_drqn() for _ in range(4)]
+    assert got == want, (got, want)
+    np.testing.assert_array_equal(a.get_params(0), b.get_params(0)); np.testing.assert_array_equal(a.get_params(1), b.get_params(1))
+    ma, va, ba = a.get_adam_state(); mb, vb, bb = b.get_adam_state()
+    np.testing.assert_array_equal(ma, mb); np.testing.assert_array_equal(va, vb); np.testing.assert_array_equal(ba, bb)
+    # the ring cursor survives: one more episode lands in the same slot of both buffers
+    ep = make_episodes(net, 1, T, np.random.default_rng(77))
+    feed(a, ep); feed(b, ep)
+    for x, y in zip(a.episode_export(), b.episode_export()):
+        np.testing.assert_array_equal(x, y)
+    with pytest.raises(pkg.DQNError, match="capacity"):
+        z = np.zeros((cap + 1, T) + net.obs_shape, np.float32)
+        b.episode_import(z, z, np.zeros((cap + 1, T), np.int32), np.zeros((cap + 1, T), np.float32), np.zeros((cap + 1, T), np.uint8), np.ones(cap + 1, np.int32))
+    a.close(); b.close()

@@ -245,3 +245,43 @@ def test_headline_config_end_to_end_on_device(mods):
     r, st = policy.engine.evaluate(64, 100, seed=99)
     assert r >= 1.5 and st == 5.0, (r, st)
     policy.engine.close()
+
+
+@pytest.mark.parametrize("device_envs", [False, True], ids=["host_loop", "device_envs"])
+def test_save_model_and_restore_best_model_through_the_hip_engine(mods, tmp_path, monkeypatch, capsys, device_envs):
+    """SURVEY 8(f)-3 / src/solver.jl:290-318 on the HIP engine: solve(...; logdir) writes qnetwork.bson at the evaluations that follow a
+    save_freq mark whenever the score did not get worse; the arrays in the file are the engine's online parameters AT SAVE TIME bit for bit
+    (Flux.params order, Julia sizes), and restore_best_model (verbose route, :170-172) puts exactly them back into the engine."""
+    pkg, nn, envs, S = mods
+    bson = importlib.import_module(pkg.__name__ + ".bson")
+    env = envs.TestMDP((5, 5), 4, 6, n=8 if device_envs else 1, seed=7)
+    model = nn.Chain(nn.flattenbatch, nn.Dense(100, 8, nn.tanh), nn.Dense(8, env.n_actions))
+    expl = S.EpsGreedyPolicy(env, S.LinearDecaySchedule(start=1.0, stop=0.05, steps=600), rng=np.random.default_rng(1))
+    solver = S.DeepQLearningSolver(qnetwork=model, max_steps=1200, learning_rate=0.005, exploration_policy=expl, eval_freq=200, save_freq=200,
+                                   num_ep_eval=20, log_freq=400, double_q=True, dueling=True, prioritized_replay=True, train_start=64,
+                                   verbose=True, logdir=str(tmp_path / "log"), **({"device_envs": True} if device_envs else {}))
+    saved = []                                        # (flat online parameters at save time, shapes) of every save
+    real_save = bson.save_qnetwork
+
+    def spy(path, flat, shapes):
+        saved.append((np.array(flat, np.float32, copy=True), list(shapes)))
+        return real_save(path, flat, shapes)
+
+    monkeypatch.setattr(bson, "save_qnetwork", spy)
+    policy = S.solve(solver, env)
+    out = capsys.readouterr().out
+    path = tmp_path / "log" / "qnetwork.bson"
+    assert path.exists() and saved, "no model was saved"
+    assert "Saving new model with eval reward" in out
+    w, sizes = bson.load_qnetwork(path)
+    last_flat, last_shapes = saved[-1]
+    np.testing.assert_array_equal(w, last_flat)                                   # the file holds the parameters of the LAST save, bit for bit
+    assert sizes == [s for s, _ in last_shapes] == [s for s, _ in bson.julia_param_shapes(policy.qnetwork)]
+    assert sum(int(np.prod(s)) for s in sizes) == policy.engine.P
+    # verbose route: restore_best_model ran at the end of dqn_train! -> the engine's online network IS the saved one again
+    np.testing.assert_array_equal(policy.engine.get_params(pkg.NET_ONLINE), w)
+    # and the restore works on its own: perturb the engine, restore, compare
+    policy.engine.set_params(w * np.float32(0.5), pkg.NET_ONLINE)
+    S.restore_best_model(solver, policy)
+    np.testing.assert_array_equal(policy.engine.get_params(pkg.NET_ONLINE), w)
+    policy.engine.close()
