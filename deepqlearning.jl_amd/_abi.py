@@ -45,7 +45,7 @@ class HParams(C.Structure):
                 ("seed", C.c_uint64),
                 ("use_graph", C.c_int32), ("use_mfma", C.c_int32),
                 ("recurrence", C.c_int32), ("trace_length", C.c_int32),
-                ("reserved", C.c_int32 * 4)]
+                ("sample_distinct", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 def default_hparams(**kw) -> HParams:

@@ -212,6 +212,50 @@ __device__ __forceinline__ long long tree_descend(const float* __restrict__ tree
     return leaf;
 }
 #endif
+#ifdef __HIPCC__
+// hp.sample_distinct (...replay.jl:85, replace=false): after the stratified draws, ONE lane visits the positions in ascending order and redraws every
+// index an earlier position already took by successive sampling on the residual priorities -- u * (total - taken mass) walked down the tree, a
+// child's mass being its stored sum minus the priorities of the taken leaves below it (in the order they were taken), 0 when no untaken leaf is
+// left below it; Philox lane B + i, word 3 offset by the attempt; after 8 attempts the first untaken leaf in index order.  Sequential by
+// construction (each redraw excludes the ones before it); duplicates are rare unless one priority dominates.  taken / tp: B entries of scratch.
+__device__ __forceinline__ void sample_distinct_fix(const float* __restrict__ tree, long long cap2, long long size, unsigned long long seed, unsigned long long ctr,
+                                                    int B, long long* idx, long long* taken, float* tp) {
+    int L = 0; for (long long w = cap2; w > 1; w >>= 1) L++;
+    if (size < B) return;
+    int nt = 0;
+    for (int i = 0; i < B; i++) {
+        bool dup = false; for (int j = 0; j < nt; j++) if (taken[j] == idx[i]) { dup = true; break; }
+        long long leaf = idx[i];
+        if (dup) {
+            bool ok = false;
+            for (int att = 0; att < 8 && !ok; att++) {
+                float R = tree[1]; for (int j = 0; j < nt; j++) R = R - tp[j];
+                uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)(B + i), 0x5A4D504Cu + (uint32_t)(att + 1)};
+                philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), c);
+                float t = (float)(c[0] >> 8) * (1.0f / 16777216.0f) * R;
+                long long node = 1;
+                for (int lev = 0; lev < L; lev++) {
+                    float m[2];
+#pragma unroll
+                    for (int ch = 0; ch < 2; ch++) {
+                        const long long cn = 2 * node + ch; const int sh = L - lev - 1;
+                        long long lo = (cn << sh) - cap2, hi = ((cn + 1) << sh) - cap2; if (hi > size) hi = size;
+                        long long cnt = hi > lo ? hi - lo : 0; float v = tree[cn];
+                        for (int j = 0; j < nt; j++) if (((taken[j] + cap2) >> sh) == cn) { v = v - tp[j]; cnt--; }
+                        m[ch] = (cnt > 0 && v > 0.0f) ? v : 0.0f;
+                    }
+                    if (t < m[0] || !(m[1] > 0.0f)) node = 2 * node; else { t -= m[0]; node = 2 * node + 1; }
+                }
+                leaf = node - cap2; if (leaf >= size) leaf = size - 1;
+                ok = true; for (int j = 0; j < nt; j++) if (taken[j] == leaf) { ok = false; break; }
+            }
+            if (!ok) for (leaf = 0; leaf < size; leaf++) { bool tk = false; for (int j = 0; j < nt; j++) if (taken[j] == leaf) { tk = true; break; } if (!tk) break; }
+            idx[i] = leaf;
+        }
+        taken[nt] = leaf; tp[nt] = tree[cap2 + leaf]; nt++;
+    }
+}
+#endif
 struct PrioArgs { int n; long long cap2; const long long* idx; const float* td; float eps, alpha; float* tree;
                   long long* idx_pre; unsigned long long seed; int B;       // idx_pre != nullptr: also draw the next step's B indices (see prio_block_run)
                   int phase; };                                          // prio_block_fast only: 0 = update + draw, 1 = update, 2 = draw (split over two launches of one step)
@@ -446,7 +490,7 @@ void launch_replay_commit(hipStream_t st, int n, long long start, long long cap,
                           const unsigned char* done_in, const float* td_in, float eps, float alpha, int* a, float* r,
                           unsigned char* done, float* tree, StepState* state);
 void launch_tree_rebuild(hipStream_t st, float* tree, long long cap2);
-void launch_sample(hipStream_t st, int B, long long cap2, const float* tree, unsigned long long seed, long long* idx, StepState* state, int bump);
+void launch_sample(hipStream_t st, int B, long long cap2, const float* tree, unsigned long long seed, long long* idx, StepState* state, int bump, int distinct = 0);
 void launch_batch_meta(hipStream_t st, int B, long long cap2, const long long* idx, const int* a, const float* r,
                        const unsigned char* done, const float* tree, float beta, const StepState* state,
                        int* a_out, float* r_out, float* done_out, float* w_out);

@@ -448,7 +448,7 @@ static int check_idx(dqn_engine* e, const int64_t* idx, int n) {
 extern "C" int dqn_replay_sample(dqn_engine_t* e, int64_t* idx_out) { if (!e) return fail("null engine handle");
     if (e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");   // ...replay.jl:83
     HIPCHK(hipSetDevice(e->device));
-    launch_sample(e->stream, e->B, e->cap2, e->tree, e->hp.seed, e->idx, e->state, 1);
+    launch_sample(e->stream, e->B, e->cap2, e->tree, e->hp.seed, e->idx, e->state, 1, e->hp.sample_distinct);
     if (idx_out) { HIPCHK(hipMemcpyAsync(idx_out, e->idx, (size_t)e->B * 8, hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); }
     return 0;
 }
@@ -506,13 +506,13 @@ void enqueue_step(dqn_engine* e, bool sample, int phase) {
         } else {
             // the descent is fused into the gather (every workgroup repeats it) while that is cheaper than a launch of its own:
             // small batches.  At B = 512 / 1e6 leaves the repeats cost more than the ~5 us launch, so sample once, then gather.
-            const bool fused = sample && e->B <= 64;
+            const bool fused = sample && e->B <= 64 && !e->hp.sample_distinct;      // distinct indices: one workgroup draws AND dedupes, then the gather reads the list
             if (e->step_take_pre) {}      // the previous step's Adam launch gathered this batch (PreGather)
             else {
-            if (sample && !fused) RUN(e, "sample", launch_sample(e->stream, e->B, e->cap2, e->tree, e->hp.seed, e->idx, e->state, 0));    // k_td bumps the Philox counter
+            if (sample && !fused) RUN(e, "sample", launch_sample(e->stream, e->B, e->cap2, e->tree, e->hp.seed, e->idx, e->state, 0, e->hp.sample_distinct));    // k_td bumps the Philox counter
             BatchMeta bm; bm.a = e->ra; bm.r = e->rr; bm.done = e->rdone; bm.beta = e->hp.prio_beta; bm.a_out = e->gb_a2; bm.r_out = e->gb_r2; bm.done_out = e->gb_done2; bm.w_out = e->gb_w2;
             RUN(e, fused ? "sample_gather" : "gather", launch_gather_fb(e->stream, e->s_rows, e->sp_rows, e->hp.obs_dtype == DQN_OBS_U8, e->E, e->B, e->idx, e->x0,
-                                                                        fused ? 1 : 0, e->cap2, e->tree, e->hp.seed, e->state, bm, e->idx_pre, e->arena_u8 ? 1 : 0));
+                                                                        fused ? 1 : 0, e->cap2, e->tree, e->hp.seed, e->state, bm, e->hp.sample_distinct ? nullptr : e->idx_pre, e->arena_u8 ? 1 : 0));
             }
         }
         for (size_t i = 0; i < e->prog_post_begin; i++) {

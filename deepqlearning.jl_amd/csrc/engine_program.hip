@@ -234,7 +234,7 @@ int build_program(dqn_engine* e) {
             e->prog.push_back({"prio_fork", [](dqn_engine* en) {
                 hipEventRecord(en->ev_fork, en->stream); hipStreamWaitEvent(en->stream2, en->ev_fork, 0);
                 launch_update_priorities(en->stream2, en->B, en->cap2, en->idx, en->td, en->hp.prio_eps, en->hp.prio_alpha, en->tree, en->state, 0, 1.0, 1.0, nullptr, 0,
-                                         en->idx_pre, en->hp.seed, en->B);      // + the next step's index draw
+                                         en->hp.sample_distinct ? nullptr : en->idx_pre, en->hp.seed, en->B);      // + the next step's index draw (stratified mode)
                 hipEventRecord(en->ev_join, en->stream2); }});
         } else e->prio_forked = false;
     }
@@ -273,14 +273,14 @@ int build_program(dqn_engine* e) {
         return J;
     };
     auto prio_args = [&]() { PrioArgs pa; memset(&pa, 0, sizeof pa); pa.n = B; pa.cap2 = e->cap2; pa.idx = e->idx; pa.td = e->td; pa.eps = e->hp.prio_eps; pa.alpha = e->hp.prio_alpha; pa.tree = e->tree;
-                              if (Bb <= 64) { pa.idx_pre = e->idx_pre; pa.seed = e->hp.seed; pa.B = Bb; }      // the fused sample+gather launch (B <= 64) consumes them
+                              if (Bb <= 64 && !e->hp.sample_distinct) { pa.idx_pre = e->idx_pre; pa.seed = e->hp.seed; pa.B = Bb; }      // the fused sample+gather launch (B <= 64) consumes them
                               return pa; };
     const bool prio_in_adam = e->hp.prioritized_replay && !rec && Bb <= 64;      // larger batches: side stream (prio_fork)
     // pre-gather (common.h PreGather): needs the priority block (which also draws the next indices) OUT of the Adam launch -- it rides as
     // workgroup 0 of the first LDS-tiled backward launch instead
     // large batches: the priority update runs on the side stream (prio_fork) and draws the next indices there; k_td takes the pre-drawn batch
     const bool pg_want = e->hp.prioritized_replay && !rec && (prio_in_adam ? fuse_heads : e->prio_forked) && !early && !e->sim_world &&
-                         (e->hp.obs_dtype != DQN_OBS_U8 || e->arena_u8) && !getenv("DQN_NO_PREGATHER");      // u8 rows: only onto the byte arena
+                         (e->hp.obs_dtype != DQN_OBS_U8 || e->arena_u8) && !getenv("DQN_NO_PREGATHER") && !e->hp.sample_distinct;      // distinct mode: sample launch + gather launch every step      // u8 rows: only onto the byte arena
     // layer l's gradient is final: queue its parameter range (split-K layers: as a slab segment)
     auto adam_queue = [&](int l, const std::vector<RSeg>& segs_known) {
         const LayerDev& L = e->L[l]; PItem it; it.beg = L.w_off; it.end = l + 1 < e->nl ? e->L[l + 1].w_off : e->Pint; it.part = nullptr; it.S = 0;

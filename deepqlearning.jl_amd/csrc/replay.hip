@@ -170,17 +170,22 @@ void launch_replay_commit(hipStream_t st, int n, long long start, long long cap,
 
 // ------------------------------------------------------------------ sample
 __global__ __launch_bounds__(1024) void k_sample(int B, long long cap2, const float* __restrict__ tree, unsigned long long seed,
-                                                 long long* __restrict__ idx, StepState* state, int bump) {
+                                                 long long* __restrict__ idx, StepState* state, int bump, int distinct) {
+    __shared__ long long taken[1024]; __shared__ float tp[1024];
     const unsigned long long ctr = state->sample_ctr;
     const long long size = state->size;
     const float total = tree[1], seg = total / (float)B;
     for (int i = threadIdx.x; i < B; i += blockDim.x) idx[i] = tree_descend(tree, cap2, size, seed, ctr, i, seg);
+    if (distinct && B <= 1024) {      // hp.sample_distinct: redraw later duplicates on the residual priorities (one lane; see sample_distinct_fix)
+        __syncthreads();
+        if (threadIdx.x == 0) sample_distinct_fix(tree, cap2, size, seed, ctr, B, idx, taken, tp);
+    }
     __syncthreads();
     if (threadIdx.x == 0 && bump) { state->sample_ctr = ctr + 1; state->pre_valid = 0; }      // pre-drawn indices belonged to the counter just consumed
 }
-void launch_sample(hipStream_t st, int B, long long cap2, const float* tree, unsigned long long seed, long long* idx, StepState* state, int bump) {
+void launch_sample(hipStream_t st, int B, long long cap2, const float* tree, unsigned long long seed, long long* idx, StepState* state, int bump, int distinct) {
     int bs = ((B + 63) / 64) * 64; if (bs > 1024) bs = 1024;
-    hipLaunchKernelGGL(k_sample, dim3(1), dim3(bs), 0, st, B, cap2, tree, seed, idx, state, bump);
+    hipLaunchKernelGGL(k_sample, dim3(1), dim3(bs), 0, st, B, cap2, tree, seed, idx, state, bump, distinct);
 }
 
 // ------------------------------------------------------------------ get_batch scalars + IS weights (parity seam)

@@ -44,7 +44,8 @@ mutable struct HParams
     seed::UInt64
     use_graph::Int32; use_mfma::Int32
     recurrence::Int32; trace_length::Int32
-    reserved::NTuple{4,Int32}
+    sample_distinct::Int32
+    reserved::NTuple{3,Int32}
     HParams() = new()
 end
 

@@ -92,7 +92,10 @@ typedef struct {
     int32_t use_mfma;          /* 1: fp32 MFMA kernels where shapes allow (bit-identical to the VALU path) */
     int32_t recurrence;        /* solver.recurrence: DRQN on an EpisodeReplayBuffer (src/solver.jl:12,182-183,239-287) */
     int32_t trace_length;      /* solver.trace_length (40) */
-    int32_t reserved[4];
+    int32_t sample_distinct;   /* 0 (default): stratified sum-tree draws, duplicates possible within a batch.  1: B DISTINCT indices like the reference's
+                                * sample(rng, 1:n, Weights(p), B, replace=false) (...replay.jl:85): after the stratified draws, every later duplicate is redrawn
+                                * from the tree with the mass of all taken leaves removed (successive sampling on the residual priorities) */
+    int32_t reserved[3];
 } dqn_hparams;
 
 const char* dqn_last_error(void);

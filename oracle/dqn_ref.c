@@ -319,6 +319,46 @@ int ref_replay_add(ref_engine* e, const void* s, const int32_t* a, const float* 
 int ref_replay_size(ref_engine* e, int64_t* cur, int64_t* cap) { if (cur) *cur = e->size; if (cap) *cap = e->cap; return 0; }
 int ref_replay_get_priorities(ref_engine* e, float* p, int64_t n) { memcpy(p, e->tree + e->cap2, (size_t)n * 4); return 0; }
 
+/* hp.sample_distinct: B DISTINCT indices (sample(..., replace=false), ...replay.jl:85).  Positions are visited in ascending order; a position
+ * whose index was already taken by an earlier one is redrawn by SUCCESSIVE SAMPLING on the residual priorities: u * (total - taken mass) walked
+ * down the tree, where a child's mass is its stored sum minus the priorities of the taken leaves below it (subtracted in the order they were
+ * taken), and 0 when no untaken leaf is left below it.  Philox lane B + i, word 3 offset by the attempt; after 8 attempts (float round-off can
+ * leave a sliver of mass on a taken leaf) the first untaken leaf in index order is used. */
+static void distinct_fix(ref_engine* e, uint64_t ctr) {
+    const int B = e->B; int L = 0; for (int64_t w = e->cap2; w > 1; w >>= 1) L++;
+    int64_t taken[4096]; float tp[4096]; int nt = 0;
+    if (B > 4096 || e->size < B) return;
+    for (int i = 0; i < B; i++) {
+        int dup = 0; for (int j = 0; j < nt; j++) if (taken[j] == e->idx[i]) { dup = 1; break; }
+        int64_t leaf = e->idx[i];
+        if (dup) {
+            int ok = 0;
+            for (int att = 0; att < 8 && !ok; att++) {
+                float R = e->tree[1]; for (int j = 0; j < nt; j++) R = R - tp[j];
+                uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)(B + i), 0x5A4D504Cu + (uint32_t)(att + 1)};
+                philox((uint32_t)e->hp.seed, (uint32_t)(e->hp.seed >> 32), c);
+                float t = (float)(c[0] >> 8) * (1.0f / 16777216.0f) * R;
+                int64_t node = 1;
+                for (int lev = 0; lev < L; lev++) {
+                    float m[2];
+                    for (int ch = 0; ch < 2; ch++) {
+                        const int64_t cn = 2 * node + ch; const int sh = L - lev - 1;          /* leaves below cn: [cn << sh, (cn + 1) << sh) - cap2 */
+                        int64_t lo = (cn << sh) - e->cap2, hi = ((cn + 1) << sh) - e->cap2; if (hi > e->size) hi = e->size;
+                        int64_t cnt = hi > lo ? hi - lo : 0; float v = e->tree[cn];
+                        for (int j = 0; j < nt; j++) if (((taken[j] + e->cap2) >> sh) == cn) { v = v - tp[j]; cnt--; }
+                        m[ch] = (cnt > 0 && v > 0.0f) ? v : 0.0f;
+                    }
+                    if (t < m[0] || !(m[1] > 0.0f)) node = 2 * node; else { t -= m[0]; node = 2 * node + 1; }
+                }
+                leaf = node - e->cap2; if (leaf >= e->size) leaf = e->size - 1;
+                ok = 1; for (int j = 0; j < nt; j++) if (taken[j] == leaf) { ok = 0; break; }
+            }
+            if (!ok) for (leaf = 0; leaf < e->size; leaf++) { int tk = 0; for (int j = 0; j < nt; j++) if (taken[j] == leaf) { tk = 1; break; } if (!tk) break; }
+            e->idx[i] = leaf;
+        }
+        taken[nt] = leaf; tp[nt] = e->tree[e->cap2 + leaf]; nt++;
+    }
+}
 int ref_replay_sample(ref_engine* e, int64_t* idx_out) {
     int B = e->B;
     if (e->size < B) FAIL("AssertionError: r._curr_size >= r.batch_size");
@@ -337,6 +377,7 @@ int ref_replay_sample(ref_engine* e, int64_t* idx_out) {
         int64_t leaf = node - e->cap2; if (leaf >= e->size) leaf = e->size - 1;
         e->idx[i] = leaf;
     }
+    if (e->hp.sample_distinct) distinct_fix(e, ctr);
     if (idx_out) memcpy(idx_out, e->idx, (size_t)B * 8);
     return 0;
 }

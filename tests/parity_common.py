@@ -106,3 +106,42 @@ def sampler_distribution(Engine, draws=2000, **engine_kw):
     assert ((counts - uniform) ** 2 / uniform).sum() > 50 * dof         # and the test can fail: a uniform sampler is nowhere near
     h.close()
     return chi2
+
+
+def sampler_distinct(Engine, draws=400, **engine_kw):
+    """hp.sample_distinct = 1 (...replay.jl:85: sample(rng, 1:n, Weights(p), B, replace=false)): B DISTINCT indices per call, always; a leaf whose
+    priority spans several strata -- the stratified default returns it several times -- is returned once and the freed positions are redrawn on
+    the RESIDUAL priorities (successive sampling): with one dominant leaf and equal light leaves the redraws must be uniform over the light ones."""
+    n, B = 96, 16
+    layers = _dense_layers(2, 2)
+    hp = abi.default_hparams(batch_size=B, n_actions=2, obs_c=2, obs_h=1, obs_w=1, dueling=0, buffer_size=n, prio_alpha=1.0, prio_eps=0.5, seed=31, sample_distinct=1)
+    h = Engine(layers, hp, **engine_kw)
+    p = np.full(n, 1.0, np.float32); p[37] = 900.0                      # leaf 37 holds 90 % of the mass: 14-15 of the 16 strata
+    obs = np.random.default_rng(2).random((n, 2), dtype=np.float32)
+    h.replay_add(obs, np.zeros(n, np.int32), np.zeros(n, np.float32), obs, np.zeros(n, np.uint8), td_err=p - np.float32(0.5))
+    counts = np.zeros(n)
+    seen = []
+    for _ in range(draws):
+        idx = h.replay_sample()
+        assert len(set(idx.tolist())) == B, idx                         # distinct, every time
+        assert idx.min() >= 0 and idx.max() < n and 37 in idx           # the dominant leaf is always in the batch, once
+        np.add.at(counts, idx, 1)
+        seen.append(idx.copy())
+    light = np.delete(counts, 37)
+    expect = draws * (B - 1) / (n - 1)                                   # B - 1 of the n - 1 equal light leaves per call
+    assert abs(light.sum() - draws * (B - 1)) < 1e-9
+    chi2 = float(((light - expect) ** 2 / expect).sum()); dof = n - 2
+    assert chi2 < dof + 6.0 * np.sqrt(2.0 * dof), (chi2, dof)           # uniform over the light leaves (a sampler that redraws "the next leaf" fails by far)
+    # a skewed vector without a dominant leaf: still distinct, and heavier leaves are included more often
+    pr = (0.5 + 40.0 * np.random.default_rng(5).random(n) ** 4).astype(np.float32)
+    h.update_priorities(np.arange(n, dtype=np.int64), pr - np.float32(0.5))
+    cnt2 = np.zeros(n)
+    for _ in range(draws):
+        idx = h.replay_sample()
+        assert len(set(idx.tolist())) == B, idx
+        np.add.at(cnt2, idx, 1)
+    order = np.argsort(pr)
+    assert cnt2[order[-10:]].mean() > 4 * cnt2[order[:40]].mean()
+    assert cnt2.max() <= draws                                           # inclusion frequency <= 1 per call
+    h.close()
+    return np.array(seen)

@@ -12,7 +12,7 @@ import dqn_oracle as O
 import ref
 from nets import GOLDEN_CASES, cfg1_mlp_dueling, mid_conv_dueling, mid_conv_plain, nature_dueling, small_conv_dueling, small_conv_plain
 from nets import testmdp_mlp_tanh as mlp_tanh_net
-from parity_common import hand_derived_known_answer, sampler_distribution
+from parity_common import hand_derived_known_answer, sampler_distinct, sampler_distribution
 from test_twin_vs_oracle import check_priorities_after_step, run_case
 
 pytestmark = pytest.mark.gpu
@@ -530,3 +530,37 @@ def test_checkpoint_resume_is_bit_exact(pkg, u8, tmp_path):
     z = np.zeros((101,) + net.obs_shape, b.obs_np)
     with pytest.raises(pkg.DQNError, match="capacity"):
         b.replay_import(z, z, np.zeros(101, np.int32), np.zeros(101, np.float32), np.zeros(101, np.uint8), np.ones(101, np.float32))
+
+
+def test_sampler_distinct_gpu_equals_twin(pkg):
+    """hp.sample_distinct = 1 (...replay.jl:85 replace=false): the engine's draws are distinct, pass the distribution checks of
+    parity_common.sampler_distinct, and are the twin's draws index for index."""
+    g = sampler_distinct(pkg.Engine)
+    c = sampler_distinct(ref.Twin, threads=1)
+    np.testing.assert_array_equal(g, c)
+
+
+@pytest.mark.parametrize("B,cap", [(32, 64), (128, 200)], ids=["B32_fused_heads", "B128_large_batch_path"])
+def test_train_steps_with_distinct_sampling_bit_exact(pkg, B, cap):
+    """train steps in distinct mode (sample launch + gather launch, no pre-drawn indices, no pre-gather): sampled indices never repeat inside a
+    batch even with a dominant priority, and indices / TD errors / loss / parameters equal the twin's bit for bit, single steps and train_steps(n)."""
+    net = small_conv_dueling()
+    gpu, cpu, hp = make_pair(pkg, net, B, cap=cap, sample_distinct=1, learning_rate=1e-3)
+    fill((gpu, cpu), net, cap, seed=4)
+    set_same_params((gpu, cpu), net)
+    big = np.full(cap, 0.01, np.float32); big[5] = 50.0                 # one transition dominates: the stratified default would repeat it
+    for h in (gpu, cpu):
+        h.update_priorities(np.arange(cap, dtype=np.int64), big)
+    for step in range(4):
+        assert_step_bit_exact(gpu, cpu)
+        idx = gpu.last_indices()
+        assert len(set(idx.tolist())) == B, idx
+    lg = gpu.train_steps(3)
+    for _ in range(3):
+        lc = cpu.train_step()
+    assert lg[0] == lc[0], (lg, lc)
+    np.testing.assert_array_equal(gpu.last_indices(), cpu.last_indices())
+    assert len(set(gpu.last_indices().tolist())) == B
+    np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+    np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
+    gpu.close(); cpu.close()

@@ -5,7 +5,7 @@ import numpy as np
 
 import dqn_oracle as O
 import ref
-from parity_common import hand_derived_known_answer, sampler_distribution
+from parity_common import hand_derived_known_answer, sampler_distinct, sampler_distribution
 
 
 def test_hand_derived_known_answer_twin():
@@ -14,6 +14,11 @@ def test_hand_derived_known_answer_twin():
 
 def test_sampler_distribution_twin():
     sampler_distribution(ref.Twin, threads=1)
+
+
+def test_sampler_distinct_twin():
+    """hp.sample_distinct = 1: the twin's restatement of the reference's replace=false draw (no duplicates, uniform redraws on the residual mass)"""
+    sampler_distinct(ref.Twin, threads=1)
 
 
 def test_hand_derived_known_answer_oracle():
