@@ -103,13 +103,17 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 // update_priorities!(r, idx, td) (src/prioritized_experience_replay.jl:76-80) executed by ONE workgroup: leaves
 // p = (|td| + eps)^alpha (duplicates: last write wins, :79; assert p > 0, :78), then the ancestors level by level (one
 // barrier per level; equal parents are written with equal values).  `sidx` is >= n long longs of LDS.
+// dense_floats > 0: LDS floats available BEHIND sidx[n] for the dense top (see below).
 __device__ __forceinline__ void prio_update_block_levels(int n, long long cap2, const long long* __restrict__ idx, const float* __restrict__ td, float eps,
-                                                  float alpha, float* tree, StepState* state, long long* sidx) {
+                                                  float alpha, float* tree, StepState* state, long long* sidx, long long dense_floats = 0) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) sidx[i] = idx[i];
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        bool last = true;
-        for (int j = i + 1; j < n; j++) if (sidx[j] == sidx[i]) { last = false; break; }
+        // last occurrence of this index?  A branch-free scan (the early-exit form walked up to n dependent LDS round trips per lane: ~40 us at n = 512)
+        const long long mine = sidx[i]; int dupes = 0;
+#pragma unroll 8
+        for (int j = 0; j < n; j++) dupes += (j > i && sidx[j] == mine) ? 1 : 0;
+        const bool last = dupes == 0;
         const float p = prio_f(fabsf(td[i]), eps, alpha);
         if (!(p > 0.0f)) state->err = 2;
         if (last) tree[cap2 + sidx[i]] = p;
@@ -117,7 +121,15 @@ __device__ __forceinline__ void prio_update_block_levels(int n, long long cap2, 
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += blockDim.x) sidx[i] = (cap2 + sidx[i]) >> 1;
     __syncthreads();
-    for (long long width = cap2; width > 1; width >>= 1) {
+    // The TOP of the tree is recomputed DENSELY out of LDS: with hundreds of paths nearly every node of the upper levels is an ancestor of an
+    // updated leaf, and walking them path by path costs a dependent global round trip per level (r03: 120 us for 512 paths x 20 levels, 6 us per
+    // level).  So the sparse walk stops at the level of W nodes; those W values are then read back in one round trip, every level above is
+    // rebuilt as node = left + right (for an untouched node that reproduces the stored bits: every internal node always was the fp32 sum of its
+    // current children) and stored in one coalesced pass.
+    long long W = 0;
+    if (dense_floats >= 128) { W = 64; while (4 * W <= dense_floats && 2 * W <= cap2 / 2) W *= 2; if (W > cap2 / 2) W = 0; }
+    float* top = reinterpret_cast<float*>(sidx + ((n + 1) / 2) * 2);      // 16-B aligned behind the n indices; top[id], ids in [1, 2W)
+    for (long long width = cap2; width > 1 && (W == 0 || width >= 2 * W); width >>= 1) {
         // up to 4 nodes per thread (n <= 1024 at 256 threads): all child loads are issued before any store, so a level costs one
         // memory round trip however many nodes a thread owns
         long long nd[4]; float vs[4];
@@ -128,15 +140,28 @@ __device__ __forceinline__ void prio_update_block_levels(int n, long long cap2, 
         for (int i = threadIdx.x + 4 * blockDim.x; i < n; i += blockDim.x) { const long long node = sidx[i]; tree[node] = tree[2 * node] + tree[2 * node + 1]; sidx[i] = node >> 1; }
         __syncthreads();
     }
+    if (W > 0) {
+        for (long long i = threadIdx.x; i < W; i += blockDim.x) top[W + i] = tree[W + i];       // the level of W nodes: final in memory
+        __syncthreads();
+        for (long long w = W / 2; w >= 1; w >>= 1) {
+            for (long long i = threadIdx.x; i < w; i += blockDim.x) top[w + i] = top[2 * (w + i)] + top[2 * (w + i) + 1];
+            __syncthreads();
+        }
+        for (long long i = threadIdx.x + 1; i < W; i += blockDim.x) tree[i] = top[i];
+        __syncthreads();
+    }
 }
 // The same update for SMALL batches (n <= 64, <= 22 levels) in TWO memory round trips instead of one per level: every path's siblings are
 // requested up front (they are independent of the new leaf values), then the ancestors are recomputed level by level in LDS -- a sibling that
 // is itself on an updated path takes that path's freshly computed value instead of the prefetched one -- and stored on the way.  Same node
 // arithmetic (node = f32(left + right) of its current children), so the resulting tree is identical.  `lds`: >= 8 KB (7808 bytes used).
 __device__ __forceinline__ void prio_update_block(int n, long long cap2, const long long* __restrict__ idx, const float* __restrict__ td, float eps,
-                                                  float alpha, float* tree, StepState* state, long long* lds) {
+                                                  float alpha, float* tree, StepState* state, long long* lds, unsigned lds_bytes = 0) {
     int L = 0; for (long long w = cap2; w > 1; w >>= 1) L++;
-    if (n > 64 || L > 22) { prio_update_block_levels(n, cap2, idx, td, eps, alpha, tree, state, lds); return; }
+    if (n > 64 || L > 22) {
+        const long long used = (long long)((n + 1) / 2) * 16;      // bytes of the index list (padded to 16)
+        prio_update_block_levels(n, cap2, idx, td, eps, alpha, tree, state, lds, (long long)lds_bytes > used ? ((long long)lds_bytes - used) / 4 : 0); return;
+    }
     long long* node = lds;                                 // [64]  leaf node id of path i
     float* val = reinterpret_cast<float*>(lds + 64);       // [64]  value of path i's node at the current level
     float* sib = val + 64;                                 // [L][64] prefetched sibling values
@@ -392,7 +417,7 @@ __device__ __forceinline__ bool prio_block_fast(const PrioArgs& P, StepState* st
 // two-phase form, which needs 8 KB).
 __device__ __forceinline__ void prio_block_run(const PrioArgs& P, StepState* state, long long* sidx, unsigned lds_bytes = 0, unsigned long long* ktr = nullptr) {
     if (lds_bytes && prio_block_fast(P, state, sidx, lds_bytes, ktr)) return;
-    if (P.phase != 2) prio_update_block(P.n, P.cap2, P.idx, P.td, P.eps, P.alpha, P.tree, state, sidx);
+    if (P.phase != 2) prio_update_block(P.n, P.cap2, P.idx, P.td, P.eps, P.alpha, P.tree, state, sidx, lds_bytes);
     if (!P.idx_pre || P.phase == 1) return;
     __syncthreads();
     const unsigned long long ctr = state->sample_ctr; const long long size = state->size;

@@ -71,7 +71,7 @@ struct dqn_engine {
                      hipGraphExec_t cycle = nullptr; int cycle_F = 0; bool cycle_train = false; };
     ActProg act, evalp; std::vector<Step>* sink = nullptr; std::vector<void*>* alloc_sink = nullptr; RolloutDev *roll = nullptr, *eval_roll = nullptr;
     EnvDev eval_env{}; int eval_n = 0;
-    std::vector<Step> prog; size_t prog_post_begin = 0; bool prog_built = false, step_sampled = true, prio_forked = false;
+    std::vector<Step> prog; size_t prog_post_begin = 0; bool prog_built = false, step_sampled = true, prio_forked = false, prio_in_bwd = false;
     // pre-gather (common.h PreGather), only between the steps of one dqn_train_steps(n) call: step_pregather = this step's Adam launch gathers
     // the next batch; step_take_pre = this step runs without its gather launch
     int gmax_used = 0;                    // live slots of gmax_part (per-block max |g| of the step's Adam jobs): what the on-demand fold reads

@@ -229,7 +229,16 @@ int build_program(dqn_engine* e) {
         // update_priorities! (src/solver.jl:231-233) needs only idx and td.  For small batches it rides as a dedicated block of the Adam launch; at
         // B > 64 its B leaf paths x log2(cap) levels (~70 us at B = 512, 1e6 leaves) would be that launch's tail, so it runs on a side stream
         // concurrently with the whole backward pass and is joined before the optimizer (a graph fork/join costs ~15 us -- only worth it here).
-        if (!rec && e->hp.prioritized_replay && Bb > 64) {
+        // ... unless a backward launch can carry it as a workgroup of its own (r03: the fork + join nodes themselves cost 12 + 10 us of the main
+        // stream at config 5, and the block -- split in two, update then draws -- is shorter than the 57-87 us launches it rides in)
+        bool big_in_bwd = false;
+        if (!rec && e->hp.prioritized_replay && Bb > 64 && Bb <= 1024 && mf && !e->comm && !e->sim_world && !getenv("DQN_PRIO_FORK")) {
+            int carriers = 0;
+            for (const auto& lvq : levels) for (int l2 : lvq) { const LayerDev& L2 = e->L[l2]; if (L2.kind != DQN_LAYER_LSTM && gemm_dw_eligible(L2, B, L2.src < 0 ? ld0 : ncon)) { carriers++; break; } }
+            big_in_bwd = carriers >= 2;
+        }
+        e->prio_in_bwd = big_in_bwd;
+        if (!rec && e->hp.prioritized_replay && Bb > 64 && !big_in_bwd) {
             e->prio_forked = true;
             e->prog.push_back({"prio_fork", [](dqn_engine* en) {
                 hipEventRecord(en->ev_fork, en->stream); hipStreamWaitEvent(en->stream2, en->ev_fork, 0);
@@ -273,13 +282,13 @@ int build_program(dqn_engine* e) {
         return J;
     };
     auto prio_args = [&]() { PrioArgs pa; memset(&pa, 0, sizeof pa); pa.n = B; pa.cap2 = e->cap2; pa.idx = e->idx; pa.td = e->td; pa.eps = e->hp.prio_eps; pa.alpha = e->hp.prio_alpha; pa.tree = e->tree;
-                              if (Bb <= 64 && !e->hp.sample_distinct) { pa.idx_pre = e->idx_pre; pa.seed = e->hp.seed; pa.B = Bb; }      // the fused sample+gather launch (B <= 64) consumes them
+                              if ((Bb <= 64 || e->prio_in_bwd) && !e->hp.sample_distinct) { pa.idx_pre = e->idx_pre; pa.seed = e->hp.seed; pa.B = Bb; }      // the fused sample+gather launch (B <= 64) consumes them
                               return pa; };
-    const bool prio_in_adam = e->hp.prioritized_replay && !rec && Bb <= 64;      // larger batches: side stream (prio_fork)
+    const bool prio_in_adam = e->hp.prioritized_replay && !rec && (Bb <= 64 || e->prio_in_bwd);      // larger batches: a backward launch's workgroup, or the side stream (prio_fork)
     // pre-gather (common.h PreGather): needs the priority block (which also draws the next indices) OUT of the Adam launch -- it rides as
     // workgroup 0 of the first LDS-tiled backward launch instead
     // large batches: the priority update runs on the side stream (prio_fork) and draws the next indices there; k_td takes the pre-drawn batch
-    const bool pg_want = e->hp.prioritized_replay && !rec && (prio_in_adam ? fuse_heads : e->prio_forked) && !early && !e->sim_world &&
+    const bool pg_want = e->hp.prioritized_replay && !rec && (prio_in_adam ? (fuse_heads || e->prio_in_bwd) : e->prio_forked) && !early && !e->sim_world &&
                          (e->hp.obs_dtype != DQN_OBS_U8 || e->arena_u8) && !getenv("DQN_NO_PREGATHER") && !e->hp.sample_distinct;      // distinct mode: sample launch + gather launch every step      // u8 rows: only onto the byte arena
     // layer l's gradient is final: queue its parameter range (split-K layers: as a slab segment)
     auto adam_queue = [&](int l, const std::vector<RSeg>& segs_known) {
@@ -468,7 +477,7 @@ int build_program(dqn_engine* e) {
             tail.adam = base_job(); tail.adam.prio = prio_args(); tail.has_adam = 1;
             if (later) { tail.adam.prio.phase = 1; prio_draw_pending = true; } else prio_placed = true;
         }
-        if (pg_want && prio_in_adam && !prio_placed && !pend.empty() && !tail.has_adam) { PrioArgs pa = prio_args(); if (prio_draw_pending) { pa.phase = 2; prio_draw_pending = false; } flush_valu(e, pend, pname(e, "bwd_valu", e->L[lv[0]].kind, lv[0]), &pa); prio_placed = true; }
+        if (pg_want && prio_in_adam && !prio_placed && !pend.empty() && !tail.has_adam && !e->prio_in_bwd /* large batches: only the long LDS-tiled launches can hide the block */) { PrioArgs pa = prio_args(); if (prio_draw_pending) { pa.phase = 2; prio_draw_pending = false; } flush_valu(e, pend, pname(e, "bwd_valu", e->L[lv[0]].kind, lv[0]), &pa); prio_placed = true; }
         flush_valu(e, pend, pname(e, "bwd_valu", e->L[lv[0]].kind, lv[0]));
         const char* tsuf = (tail.has_adam && adam_job_blocks(tail.adam) == 1 && tail.adam.prio.n > 0) ? "+prio" : "+adam_tail";      // a job that is only the priority block
         auto tailed = [&](const char* base) { if (!tail.has_adam) return base; char nm[80]; snprintf(nm, sizeof nm, "%s%s", base, tsuf); e->prog_names.push_back(nm); return e->prog_names.back().c_str(); };

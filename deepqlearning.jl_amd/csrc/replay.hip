@@ -210,7 +210,7 @@ __global__ __launch_bounds__(1024) void k_update_priorities(int n, long long cap
                                                             float eps, float alpha, float* tree, StepState* state, int tick_adam, double beta1,
                                                             double beta2, const float* __restrict__ gmax_part, int n_gmax,
                                                             long long* __restrict__ idx_pre, unsigned long long seed, int pre_B) {
-    __shared__ long long sidx[1024];
+    __shared__ __attribute__((aligned(16))) long long sidx[1024 + 4096];      // n <= 1024 indices + the dense top of the sum-tree (8192 floats: the level of 4096 nodes and everything above)
     __shared__ float smax[16];
     if (tick_adam) {   // globalnorm (helpers.jl:38-46): fold the Adam kernel's per-block max-abs (max is order-independent => exact)
         float g = 0.0f;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(1024) void k_update_priorities(int n, long long cap
         __syncthreads();
         if (threadIdx.x == 0) { for (int w = 1; w < (int)(blockDim.x >> 6); w++) g = fmaxf(g, smax[w]); state->gnorm_bits = __float_as_uint(g); }
     }
-    if (n > 0) { if (threadIdx.x == 0) state->pre_valid = 0; prio_update_block(n, cap2, idx, td, eps, alpha, tree, state, sidx); }
+    if (n > 0) { if (threadIdx.x == 0) state->pre_valid = 0; prio_update_block(n, cap2, idx, td, eps, alpha, tree, state, sidx, (unsigned)sizeof sidx); }
     if (n > 0 && idx_pre) {      // the tree is final and the next sample()'s Philox counter is known: draw its indices now (see prio_block_run)
         __syncthreads();
         const unsigned long long ctr = state->sample_ctr; const long long size = state->size;
