@@ -456,6 +456,27 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
     const size_t per_s = (size_t)(L.K + 1) * L.N;
     float* out = p.out + (size_t)s * per_s;
     if (probe & 4) return;
+    if ((((size_t)out) & 15) == 0) {
+        // epilogue through LDS: the accumulators hold 4 rows x 1 column per lane (16 scattered 64-byte pieces per wave and N tile); transposed through the
+        // wave's OWN rows of the A tile (no other wave reads them, every staging store is behind the last barrier) each store instruction writes whole
+        // 16*NT-float row segments -- NT instead of 4*NT store instructions per wave, full lines instead of halves (r03_i PMC: the non-temporal
+        // half-line stores moved 21.7 MB for the 12.8 MB dense gradient).  Non-temporal: the gradient is read once, by the Adam launch.
+        float* T0 = As + (16 * wave) * W_ST;           // rows 16w.. of buffer 0: N tiles 0, 1;   buffer 1 (+ 64 rows): N tiles 2, 3
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            float* Tt = T0 + (t >> 1) * 64 * W_ST + 16 * (t & 1) + l15;
+            Tt[(4 * kq + 0) * W_ST] = acc[t].x; Tt[(4 * kq + 1) * W_ST] = acc[t].y; Tt[(4 * kq + 2) * W_ST] = acc[t].z; Tt[(4 * kq + 3) * W_ST] = acc[t].w;
+        }
+        constexpr int F = 4 * NT, RPI = 64 / F;        // float4 per row segment, rows per store instruction
+        const int rl = lane / F, n4 = lane % F;
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            const int row = i * RPI + rl, k = mr * 64 + 16 * wave + row;
+            const float* src = T0 + (n4 >> 3) * 64 * W_ST + row * W_ST + 4 * (n4 & 7);
+            const f32x2 lo = *reinterpret_cast<const f32x2*>(src), hi = *reinterpret_cast<const f32x2*>(src + 2);
+            if (k < L.K) __builtin_nontemporal_store((f32x4){lo.x, lo.y, hi.x, hi.y}, reinterpret_cast<f32x4*>(out + (size_t)k * L.N + n0 + 4 * n4));
+        }
+    } else {
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         const int n = n0 + 16 * t + l15;
@@ -465,6 +486,7 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
             const int k = mr * 64 + 16 * wave + 4 * kq + r;
             if (k < L.K) __builtin_nontemporal_store(v[r], &out[(size_t)k * L.N + n]);
         }
+    }
     }
     if (do_bias) out[(size_t)L.K * L.N + n0 + tid] = dbacc;
 }
