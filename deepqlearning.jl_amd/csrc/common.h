@@ -561,7 +561,7 @@ struct LstmSeqF {
     float *gates, *tc, *hprev_out, *cprev_out; int keep_ld, keep_c0;
 };
 struct LstmSeqArgs { LstmSeqF s[3]; int nseq, H, B, T; };
-bool lstm_seq_fits(int H, int B);
+bool lstm_seq_fits(int H, int B, int T);
 void launch_lstm_seq(hipStream_t st, const LstmSeqArgs& a);
 void launch_lstm_bwd_seq(hipStream_t st, const LstmBwdArgs& a);   // a.t ignored
 struct EpGatherArgs {

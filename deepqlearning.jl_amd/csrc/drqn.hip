@@ -114,12 +114,17 @@ void launch_lstm_bwd_step(hipStream_t st, const LstmBwdArgs& a) {
 // each, its own LDS copy of Wh): H*CB ~ 256 outputs per step keeps one wave per SIMD busy and the double-precision sigm/tanh
 // (most of a step's instructions) spread over 4x more CUs.
 static int lstm_cb(int H, int B) { int cb = 256 / H; if (cb < 1) cb = 1; if (cb > B) cb = B; while (B % cb) cb--; return cb; }
-bool lstm_seq_fits(int H, int B) {     // both kernels within 64 KB of dynamic LDS
+bool lstm_seq_fits(int H, int B, int T) {     // both kernels within 64 KB of dynamic LDS; the gate-parallel forward wants whole waves per gate
     const int cb = lstm_cb(H, B);
-    const size_t fwd = (size_t)H * 4 * H + 4 * H + 3 * (size_t)H * cb, bwd = (size_t)H * 4 * H + 6 * (size_t)H * cb;
-    return fwd <= 16384 && bwd <= 16384;
+    const size_t fwd = (size_t)H * 4 * H + 4 * H + 7 * (size_t)H * cb, bwd = (size_t)H * (4 * H + 1) + 6 * (size_t)H * cb;
+    return fwd <= 16384 && bwd <= 16384 && (H * cb) % 64 == 0 && H * cb <= 256 && T <= 64;
 }
 
+// r03: (1) the FOUR gates of an output advance on four threads (thread = (gate, unit, column): one 32-deep chain and ONE Float64 sigm/tanh each
+// instead of four chains and five transcendentals in sequence), the gates meet in LDS and the (unit, column) thread of gate 0 finishes c, tanh(c), h;
+// (2) the input projections Gx of ALL time steps are requested before the recurrence starts (they do not depend on it) -- one round trip instead of one
+// per time step.  Per-element arithmetic unchanged (same chains, same association), so every bit is k_lstm_step's.  TT: compile-time bound on T.
+template <int TT>
 __global__ __launch_bounds__(1024) void k_lstm_seq(LstmSeqArgs A, int CB) {
     extern __shared__ float lds[];
     const int H = A.H, B = A.B, N = 4 * H, per = H * CB, T = A.T, nsplit = B / CB;
@@ -127,40 +132,42 @@ __global__ __launch_bounds__(1024) void k_lstm_seq(LstmSeqArgs A, int CB) {
     float* bias_s = Wh_s + H * N;      // [4H]
     float* h_s = bias_s + N;           // [2][H*CB]
     float* c_s = h_s + 2 * per;        // [H*CB]
+    float* g_s = c_s + per;            // [4][H*CB] activated gates of the current step
     const LstmSeqF& S = A.s[blockIdx.x / nsplit];
     const int b0 = (blockIdx.x % nsplit) * CB;
     for (int i = threadIdx.x; i < H * N; i += blockDim.x) Wh_s[i] = S.Wh[i];
     for (int i = threadIdx.x; i < N; i += blockDim.x) bias_s[i] = S.bias[i];
     for (int e = threadIdx.x; e < per; e += blockDim.x) { const int u = e / CB; h_s[e] = S.h0[u]; c_s[e] = S.c0v[u]; }      // Flux.reset!: state0 broadcast over the batch
+    const int q = threadIdx.x / per, e = threadIdx.x - q * per;      // gate, (unit, column) element; per is a multiple of 64, so a wave has one gate
+    const bool on = q < 4;
+    const int u = e / CB, bl = e - u * CB, b = b0 + bl;
+    float gxr[TT];
+#pragma unroll
+    for (int t = 0; t < TT; t++) gxr[t] = (on && t < T) ? S.Gx[(size_t)(q * H + u) * S.ld + S.c0 + t * B + b] : 0.0f;
     __syncthreads();
     int cur = 0;
-    for (int t = 0; t < T; t++) {
+#pragma unroll
+    for (int t = 0; t < TT; t++) {
+        if (t >= T) break;
         const float* hp = h_s + cur * per; float* hn = h_s + (cur ^ 1) * per;
-        for (int e = threadIdx.x; e < per; e += blockDim.x) {
-            const int u = e / CB, bl = e - u * CB, b = b0 + bl;
-            const int col = S.c0 + t * B + b;
-            float gx[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) gx[q] = S.Gx[(size_t)(q * H + u) * S.ld + col];       // requested before the chains: their latency rides under them
-            // the four gate chains advance together: one h read per j and four independent fma chains (each still j-ascending)
-            float ch[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const int col = S.c0 + t * B + b;
+        if (on) {
+            float ch = 0.0f;
+            const float* wr = Wh_s + q * H + u;
 #pragma unroll 8
-            for (int j = 0; j < H; j++) {
-                const float hv = hp[j * CB + bl]; const float* wr = Wh_s + j * N + u;
-                ch[0] = fmaf(hv, wr[0], ch[0]); ch[1] = fmaf(hv, wr[H], ch[1]); ch[2] = fmaf(hv, wr[2 * H], ch[2]); ch[3] = fmaf(hv, wr[3 * H], ch[3]);
-            }
-            float g[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) g[q] = (gx[q] + ch[q]) + bias_s[q * H + u];
-            const float ig = sigm_f(g[0]), fg = sigm_f(g[1]), gg = tanh_f(g[2]), og = sigm_f(g[3]);
+            for (int j = 0; j < H; j++) ch = fmaf(hp[j * CB + bl], wr[j * N], ch);
+            const float g = (gxr[t] + ch) + bias_s[q * H + u];
+            const float act = q == 2 ? tanh_f(g) : sigm_f(g);
+            g_s[q * per + e] = act;
+            if (S.gates) S.gates[(size_t)(q * H + u) * S.keep_ld + (size_t)S.keep_c0 + t * B + b] = act;
+        }
+        __syncthreads();
+        if (q == 0) {
+            const float ig = g_s[e], fg = g_s[per + e], gg = g_s[2 * per + e], og = g_s[3 * per + e];
             const float cp = c_s[e];
             const float t1 = fg * cp; const float t2 = ig * gg; const float c = t1 + t2; const float tc = tanh_f(c); const float h = og * tc;
             S.Hout[(size_t)u * S.ld + col] = h; S.Cst[(size_t)u * S.ld + col] = c;
-            if (S.gates) {
-                const size_t k = (size_t)S.keep_c0 + t * B + b; const size_t kl = S.keep_ld;
-                S.gates[(size_t)(0 * H + u) * kl + k] = ig; S.gates[(size_t)(1 * H + u) * kl + k] = fg; S.gates[(size_t)(2 * H + u) * kl + k] = gg; S.gates[(size_t)(3 * H + u) * kl + k] = og;
-                S.tc[(size_t)u * kl + k] = tc; S.hprev_out[(size_t)u * kl + k] = hp[e]; S.cprev_out[(size_t)u * kl + k] = cp;
-            }
+            if (S.gates) { const size_t k = (size_t)S.keep_c0 + t * B + b; const size_t kl = S.keep_ld; S.tc[(size_t)u * kl + k] = tc; S.hprev_out[(size_t)u * kl + k] = hp[e]; S.cprev_out[(size_t)u * kl + k] = cp; }
             hn[e] = h; c_s[e] = c;
         }
         __syncthreads();
@@ -169,21 +176,27 @@ __global__ __launch_bounds__(1024) void k_lstm_seq(LstmSeqArgs A, int CB) {
 }
 void launch_lstm_seq(hipStream_t st, const LstmSeqArgs& a) {
     const int cb = lstm_cb(a.H, a.B);
-    const size_t lds = ((size_t)a.H * 4 * a.H + 4 * a.H + 3 * (size_t)a.H * cb) * sizeof(float);
-    int bs = ((a.H * cb + 63) / 64) * 64; if (bs > 1024) bs = 1024;
-    hipLaunchKernelGGL(k_lstm_seq, dim3(a.nseq * (a.B / cb)), dim3(bs), lds, st, a, cb);
+    const size_t lds = ((size_t)a.H * 4 * a.H + 4 * a.H + 7 * (size_t)a.H * cb) * sizeof(float);
+    const int bs = 4 * a.H * cb;                      // 4 gates x (unit, column) elements; lstm_seq_fits: H * cb is a multiple of 64 and <= 256
+    if (a.T <= 8) hipLaunchKernelGGL((k_lstm_seq<8>), dim3(a.nseq * (a.B / cb)), dim3(bs), lds, st, a, cb);
+    else if (a.T <= 32) hipLaunchKernelGGL((k_lstm_seq<32>), dim3(a.nseq * (a.B / cb)), dim3(bs), lds, st, a, cb);
+    else hipLaunchKernelGGL((k_lstm_seq<64>), dim3(a.nseq * (a.B / cb)), dim3(bs), lds, st, a, cb);      // lstm_seq_fits: T <= 64
 }
 
 // BPTT over the whole s-sequence, one workgroup per group of CB columns (same arithmetic as T calls of k_lstm_bwd_step); the
 // trainable state0's gradient (a sum over ALL columns, ascending b) is folded by k_state0_grad afterwards.
+// PF: the seven stashed values of EVERY time step are requested before the loop (T <= 8: 56 registers) instead of one step ahead -- their round trip
+// was longer than a step's arithmetic (r03: 4.6 us per time step)
+template <bool PF>
 __global__ __launch_bounds__(1024) void k_lstm_bwd_seq(LstmBwdArgs A, int CB) {
     extern __shared__ float lds[];
     const int H = A.H, B = A.B, TB = A.TB, N = 4 * H, per = H * CB, b0 = blockIdx.x * CB;
-    float* Wh_s = lds;                 // [H][4H]
-    float* dG_s = Wh_s + H * N;        // [4H][CB]
+    const int NP = N + 1;              // padded row stride: lanes of one wave hold different rows j of Wh at the same n -- stride 4H put all of them on ONE bank (8-way conflict on every read of the 128-deep chain)
+    float* Wh_s = lds;                 // [H][4H + 1]
+    float* dG_s = Wh_s + H * NP;       // [4H][CB]
     float* dhn_s = dG_s + N * CB;      // [H*CB]
     float* dcn_s = dhn_s + per;        // [H*CB]
-    for (int i = threadIdx.x; i < H * N; i += blockDim.x) Wh_s[i] = A.Wh[i];
+    for (int i = threadIdx.x; i < H * N; i += blockDim.x) Wh_s[(i / N) * NP + i % N] = A.Wh[i];
     for (int e = threadIdx.x; e < per; e += blockDim.x) { dhn_s[e] = 0.0f; dcn_s[e] = 0.0f; }
     __syncthreads();
     // one (u, column) element per thread (per <= blockDim by construction); the seven stashed values of step t-1 are requested
@@ -194,9 +207,18 @@ __global__ __launch_bounds__(1024) void k_lstm_bwd_seq(LstmBwdArgs A, int CB) {
     auto fetch = [&](int t) { St s; const size_t k = (size_t)t * B + b0 + bl;
         s.ig = A.gates[(size_t)u * TB + k]; s.fg = A.gates[(size_t)(H + u) * TB + k]; s.gg = A.gates[(size_t)(2 * H + u) * TB + k]; s.og = A.gates[(size_t)(3 * H + u) * TB + k];
         s.tc = A.tc[(size_t)u * TB + k]; s.cprev = A.cprev[(size_t)u * TB + k]; s.dH = A.dH[(size_t)u * TB + k]; return s; };
-    St nx = fetch(A.T - 1);
-    for (int t = A.T - 1; t >= 0; t--) {
-        const St c = nx;
+    St all[PF ? 8 : 1];
+    if constexpr (PF) {
+#pragma unroll
+        for (int t = 0; t < 8; t++) if (t < A.T) all[t] = fetch(t);
+    }
+    St nx; if constexpr (!PF) nx = fetch(A.T - 1);
+#pragma unroll
+    for (int tt = 0; tt < (PF ? 8 : 1 << 30); tt++) {
+        const int t = (PF ? 7 : A.T - 1) - tt;
+        if (t < 0) break;
+        if (PF && t >= A.T) continue;
+        St c; if constexpr (PF) c = all[PF ? t : 0]; else c = nx;
         if (on) {
             const size_t k = (size_t)t * B + b0 + bl;
             const float ig = c.ig, fg = c.fg, gg = c.gg, og = c.og, tc = c.tc, cprev = c.cprev;
@@ -211,12 +233,12 @@ __global__ __launch_bounds__(1024) void k_lstm_bwd_seq(LstmBwdArgs A, int CB) {
             A.dG[(size_t)u * TB + k] = v0; A.dG[(size_t)(H + u) * TB + k] = v1; A.dG[(size_t)(2 * H + u) * TB + k] = v2; A.dG[(size_t)(3 * H + u) * TB + k] = v3;
             dG_s[u * CB + bl] = v0; dG_s[(H + u) * CB + bl] = v1; dG_s[(2 * H + u) * CB + bl] = v2; dG_s[(3 * H + u) * CB + bl] = v3;
         }
-        if (t > 0) nx = fetch(t - 1);
+        if constexpr (!PF) { if (t > 0) nx = fetch(t - 1); }
         __syncthreads();
         if (on) {                                                  // dh_{t-1}[j][b] = sum_n dG[n][t,b] Wh[j][n], n ascending  (j == u)
             float acc = 0.0f;
 #pragma unroll 8
-            for (int n = 0; n < N; n++) acc = fmaf(dG_s[n * CB + bl], Wh_s[u * N + n], acc);
+            for (int n = 0; n < N; n++) acc = fmaf(dG_s[n * CB + bl], Wh_s[u * NP + n], acc);
             dhn_s[e] = acc;
         }
         __syncthreads();
@@ -232,9 +254,10 @@ __global__ void k_state0_grad(int H, int B, const float* __restrict__ dhn, const
 }
 void launch_lstm_bwd_seq(hipStream_t st, const LstmBwdArgs& a) {
     const int cb = lstm_cb(a.H, a.B);
-    const size_t lds = ((size_t)a.H * 4 * a.H + 6 * (size_t)a.H * cb) * sizeof(float);
+    const size_t lds = ((size_t)a.H * (4 * a.H + 1) + 6 * (size_t)a.H * cb) * sizeof(float);
     int bs = ((a.H * cb + 63) / 64) * 64; if (bs > 1024) bs = 1024;
-    hipLaunchKernelGGL(k_lstm_bwd_seq, dim3(a.B / cb), dim3(bs), lds, st, a, cb);
+    if (a.T <= 8) hipLaunchKernelGGL((k_lstm_bwd_seq<true>), dim3(a.B / cb), dim3(bs), lds, st, a, cb);
+    else hipLaunchKernelGGL((k_lstm_bwd_seq<false>), dim3(a.B / cb), dim3(bs), lds, st, a, cb);
     hipLaunchKernelGGL(k_state0_grad, dim3((a.H + 63) / 64), dim3(64), 0, st, a.H, a.B, a.dhn, a.dcn, a.g_h0, a.g_c0);
 }
 

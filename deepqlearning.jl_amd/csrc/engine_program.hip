@@ -151,7 +151,7 @@ int build_program(dqn_engine* e) {
             // the recurrence: T launches, each advancing the online s-sequence, the online sp-sequence (double-Q) and the target
             // sp-sequence by one step from the reset state (Flux.reset!, src/solver.jl:249-250,271)
             const int l = lv[0]; const LayerDev L = e->L[l]; const int H = L.H;
-            if (lstm_seq_fits(H, Bb)) {        // small LSTM: the whole recurrence of the three sequence sets in ONE launch
+            if (lstm_seq_fits(H, Bb, T)) {        // small LSTM: the whole recurrence of the three sequence sets in ONE launch
                 LstmSeqArgs a; memset(&a, 0, sizeof a); a.H = H; a.B = Bb; a.T = T; int ns = 0;
                 auto seq = [&](const float* P, const float* gx, float* hout, float* cst, int ld, int c0, bool keep) {
                     LstmSeqF& q = a.s[ns++]; q.Gx = gx; q.Hout = hout; q.Cst = cst; q.ld = ld; q.c0 = c0; q.Wh = P + L.wh_off; q.bias = P + L.b_off; q.h0 = P + L.h0_off; q.c0v = P + L.c0_off;
@@ -359,7 +359,7 @@ int build_program(dqn_engine* e) {
                 // BPTT over the s-sequence: T single-workgroup steps produce dG (gate pre-activation gradients) for all columns,
                 // then Wi|b, Wh and the input gradient are ordinary dense contractions over the T*B columns.
                 float* grad = e->grad;
-                if (lstm_seq_fits(L.H, Bb)) {
+                if (lstm_seq_fits(L.H, Bb, T)) {
                     LstmBwdArgs a; a.t = 0; a.T = T; a.H = L.H; a.B = Bb; a.TB = B; a.gates = e->gates[l]; a.tc = e->tcb[l]; a.cprev = e->cprev_buf[l]; a.Wh = e->p_on + L.wh_off;
                     a.dH = dpre; a.dG = e->dG[l]; a.dhn = e->dhn[l]; a.dcn = e->dcn[l]; a.g_h0 = grad + L.h0_off; a.g_c0 = grad + L.c0_off;
                     e->prog.push_back({pname(e, "lstm_bwd_seq", L.kind, l), [=](dqn_engine* en) { launch_lstm_bwd_seq(en->stream, a); }});

@@ -26,3 +26,11 @@ t0 = time.perf_counter(); eng.rollout(1000, t0=41, train_freq=0, stats=False); e
 print(f"device env loop, 256 GridWorld copies, acting only: {dt / 1000 * 1e6:.1f} us per vector step = {256 * 1000 / dt:.0f} env steps/s")
 t0 = time.perf_counter(); st = eng.rollout(1000, t0=1041, train_freq=4); dt = time.perf_counter() - t0
 print(f"with train_freq=4: {dt / 1000 * 1e6:.1f} us per vector step = {256 * 1000 / dt:.0f} env steps/s + {st['train_steps'] / dt:.0f} train steps/s")
+if "--profile" in sys.argv:
+    acc = {}
+    for _ in range(20):
+        for name, ms in eng.profile_step(steady=True):
+            a = acc.setdefault(name, [0.0, 0]); a[0] += ms; a[1] += 1
+    print("per-launch (HIP events, eager, steady-state step):")
+    for k, (t, c) in acc.items():
+        print(f"    {k:36s} {t / c * 1e3:7.2f} us")
