@@ -21,6 +21,7 @@ struct ProfEntry { const char* name; hipEvent_t a, b; };
 
 struct dqn_engine {
     int device = 0; hipStream_t stream = nullptr, stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream3 = nullptr; hipEvent_t ev_xa = nullptr, ev_xb = nullptr, ev_xc = nullptr;      // replicas: the exchange runs on its own stream (dp_overlap)
     int nl = 0; LayerDev L[DQN_MAX_LAYERS]; LayerDev* L_dev = nullptr;
     dqn_hparams hp; int B = 0, nA = 0, E = 0, ncon = 0;
     int last_base = -1, last_val = -1, last_adv = -1;
@@ -53,7 +54,10 @@ struct dqn_engine {
     void* comm = nullptr; int rank = 0, world = 1; bool force_comm = false;
     // exchange mode of the replicas: gather = all-gather of the wide dense layers' operands + small gradients (dp.hip); else all-reduce of the gradient.
     // sim_world = k (env DQN_SIM_WORLD, tests): one process plays k identical ranks, the collective is k local copies.
-    bool dp_gather = false, dp_pack_folds = false, dp_adam_folds = false; AdamSegs dp_adam_segs; int sim_world = 0; float *dp_send = nullptr, *dp_recv = nullptr; size_t dp_count = 0;   // force_comm: run the all-reduce path even at world == 1 (tests)
+    bool dp_gather = false, dp_pack_folds = false, dp_adam_folds = false; AdamSegs dp_adam_segs; int sim_world = 0; float *dp_send = nullptr, *dp_recv = nullptr; size_t dp_count = 0;
+    // dp_overlap: the block is exchanged in TWO collectives -- [0, dp_count_a): X | dpre of the wide dense layers, final right after the head level, gathered (into dp_recv) on
+    // stream3 WHILE the conv backward runs; [dp_count_a, dp_count): the small gradients, gathered (into dp_recv_b) after the backward pass
+    bool dp_overlap = false; size_t dp_count_a = 0; float* dp_recv_b = nullptr; DpPackArgs dp_pk_a;   // force_comm: run the all-reduce path even at world == 1 (tests)
     // DRQN (recurrence = true): column count per sequence set Bc = T*B (B otherwise); EpisodeReplayBuffer storage; LSTM workspaces
     int Bc = 0, T = 1; long long ep_cap = 0, ep_size = 0, ep_widx = 0, ep_cur_len = 0; std::vector<int> ep_len_host; std::vector<int64_t> ep_perm;
     float *ep_s = nullptr, *ep_sp = nullptr, *ep_r = nullptr; int* ep_a = nullptr; unsigned char* ep_done = nullptr; int* ep_len = nullptr;
@@ -71,7 +75,7 @@ struct dqn_engine {
                      hipGraphExec_t cycle = nullptr; int cycle_F = 0; bool cycle_train = false; };
     ActProg act, evalp; std::vector<Step>* sink = nullptr; std::vector<void*>* alloc_sink = nullptr; RolloutDev *roll = nullptr, *eval_roll = nullptr;
     EnvDev eval_env{}; int eval_n = 0;
-    std::vector<Step> prog; size_t prog_post_begin = 0; bool prog_built = false, step_sampled = true, prio_forked = false, prio_in_bwd = false;
+    std::vector<Step> prog; size_t prog_post_begin = 0, prog_pre1_end = 0; bool prog_built = false, step_sampled = true, prio_forked = false, prio_in_bwd = false;
     // pre-gather (common.h PreGather), only between the steps of one dqn_train_steps(n) call: step_pregather = this step's Adam launch gathers
     // the next batch; step_take_pre = this step runs without its gather launch
     int gmax_used = 0;                    // live slots of gmax_part (per-block max |g| of the step's Adam jobs): what the on-demand fold reads
@@ -79,6 +83,8 @@ struct dqn_engine {
     bool pg_ok = false, step_pregather = false, step_take_pre = false; PreGather pg; long adam_step = -1;
     hipGraphExec_t g_pgv[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [take_pre][pregather] variants of the sampled single-device step
     hipGraphExec_t g_mid = nullptr; int mid_group = 4;                          // mid_group consecutive middle steps of dqn_train_steps as one graph
+    hipGraphExec_t g_pre1[3] = {nullptr, nullptr, nullptr}, g_pre2 = nullptr;
+    hipGraphExec_t g_dp_one[4] = {nullptr, nullptr, nullptr, nullptr}; int dp_one_state = 0;      // replicas: the WHOLE step incl. its collective(s) as ONE graph ([take_pre][pregather]); state 0 untried, 1 works, -1 RCCL refused the capture      // dp_overlap: first half cut in two ([0] sampled, [1] given indices, [2] without the gather launch)
     hipGraphExec_t g_pre_tp = nullptr, g_post_pg = nullptr;                      // replicas: first half without the gather launch / second half whose Adam launch gathers
     AdamSegs adam_segs; long final_reduce_step = -1;   // deferred dW slabs: reduced inside k_adam unless a communicator needs the materialised gradient
     std::vector<void*> prog_allocs; std::vector<std::string> prog_names;
@@ -89,7 +95,7 @@ struct dqn_engine {
 void prof_begin(dqn_engine* e, const char* name);
 void prof_end(dqn_engine* e);
 #define RUN(e, name, call) do { prof_begin(e, name); call; prof_end(e); } while (0)
-enum { PH_ALL = 0, PH_PRE = 1, PH_POST = 2 };
+enum { PH_ALL = 0, PH_PRE = 1, PH_POST = 2, PH_PRE1 = 3, PH_PRE2 = 4, PH_DP_ONE = 5 };      // PRE = PRE1 (up to the point where the wide layers' operands are final) + PRE2 (the rest of the backward pass)
 template <class T> static int dmalloc(T** p, size_t n) {
     hipError_t e = hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T));
     if (e != hipSuccess) return fail("hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));

@@ -186,6 +186,8 @@ static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers
     }
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_xa, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_xb, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_xc, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
 
     const int B = e->B;
@@ -248,6 +250,9 @@ void drop_graphs(dqn_engine* e) {
     if (e->g_post_pg) { hipGraphExecDestroy(e->g_post_pg); e->g_post_pg = nullptr; }
     if (e->g_mid) { hipGraphExecDestroy(e->g_mid); e->g_mid = nullptr; }
     if (e->g_pre_tp) { hipGraphExecDestroy(e->g_pre_tp); e->g_pre_tp = nullptr; }
+    for (int i = 0; i < 3; i++) if (e->g_pre1[i]) { hipGraphExecDestroy(e->g_pre1[i]); e->g_pre1[i] = nullptr; }
+    for (int i = 0; i < 4; i++) if (e->g_dp_one[i]) { hipGraphExecDestroy(e->g_dp_one[i]); e->g_dp_one[i] = nullptr; }
+    if (e->g_pre2) { hipGraphExecDestroy(e->g_pre2); e->g_pre2 = nullptr; }
     for (dqn_engine::ActProg* a : {&e->act, &e->evalp}) { if (a->graph) { hipGraphExecDestroy(a->graph); a->graph = nullptr; } if (a->cycle) { hipGraphExecDestroy(a->cycle); a->cycle = nullptr; } }
 }
 void drop_act(dqn_engine* e, dqn_engine::ActProg& a) {
@@ -286,6 +291,9 @@ extern "C" int dqn_engine_destroy(dqn_engine_t* e) {
     if (e->g_drqn) hipGraphExecDestroy(e->g_drqn);
     if (e->stream) hipStreamDestroy(e->stream);
     if (e->stream2) hipStreamDestroy(e->stream2);
+    if (e->stream3) hipStreamDestroy(e->stream3);
+    if (e->ev_xa) hipEventDestroy(e->ev_xa); if (e->ev_xb) hipEventDestroy(e->ev_xb); if (e->ev_xc) hipEventDestroy(e->ev_xc);
+    hipFree(e->dp_recv_b);
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_join) hipEventDestroy(e->ev_join);
 
@@ -500,6 +508,7 @@ void fwd_layer(dqn_engine* e, const LayerDev& l, const float* P, const float* X,
 
 void enqueue_step(dqn_engine* e, bool sample, int phase) {
     e->step_sampled = sample;
+    if (phase == PH_PRE2) { for (size_t i = e->prog_pre1_end; i < e->prog_post_begin; i++) { if ((long)i == e->final_reduce_step && ((e->adam_segs.n > 0 && !e->comm && !e->sim_world) || (e->dp_gather && e->dp_pack_folds))) continue; RUN(e, e->prog[i].name, e->prog[i].fn(e)); } return; }
     if (phase != PH_POST) {
         if (e->hp.recurrence) {
             EpGatherArgs g; g.ep_s = e->ep_s; g.ep_sp = e->ep_sp; g.ep_a = e->ep_a; g.ep_r = e->ep_r; g.ep_done = e->ep_done; g.ep_len = e->ep_len; g.ep_idx = e->ep_idx; g.ep_start = e->ep_start;
@@ -517,23 +526,46 @@ void enqueue_step(dqn_engine* e, bool sample, int phase) {
                                                                         fused ? 1 : 0, e->cap2, e->tree, e->hp.seed, e->state, bm, e->hp.sample_distinct ? nullptr : e->idx_pre, e->arena_u8 ? 1 : 0));
             }
         }
-        for (size_t i = 0; i < e->prog_post_begin; i++) {
+        for (size_t i = 0; i < (phase == PH_PRE1 ? e->prog_pre1_end : e->prog_post_begin); i++) {
             if ((long)i == e->final_reduce_step && ((e->adam_segs.n > 0 && !e->comm && !e->sim_world) || (e->dp_gather && e->dp_pack_folds))) continue;   // folded into k_adam / k_dp_pack   // folded into k_adam
             RUN(e, e->prog[i].name, e->prog[i].fn(e));
         }
     }
-    if (phase != PH_PRE) for (size_t i = e->prog_post_begin; i < e->prog.size(); i++) RUN(e, (e->step_pregather && (long)i == e->adam_step) ? "adam+gather" : e->prog[i].name, e->prog[i].fn(e));
+    if (phase != PH_PRE && phase != PH_PRE1) for (size_t i = e->prog_post_begin; i < e->prog.size(); i++) RUN(e, (e->step_pregather && (long)i == e->adam_step) ? "adam+gather" : e->prog[i].name, e->prog[i].fn(e));
 }
+int exchange_grads(dqn_engine* e);
+int exchange_segment(dqn_engine* e, int seg);
 int capture(dqn_engine* e, bool sample, int phase, hipGraphExec_t* out, int repeat) {
     hipGraph_t g;
     (void)hipGetLastError();
     HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+    int xrc = 0;
+    if (phase == PH_DP_ONE) {
+        // the replica step with its collective(s) INSIDE the graph (RCCL supports stream capture): one graph launch and no host-side collective enqueue
+        // per step.  dp_overlap: the exchange stream is forked from / joined to the captured stream with events, so all-gather A runs beside PRE2.
+        if (e->dp_gather && e->dp_overlap) {
+            enqueue_step(e, sample, PH_PRE1);
+            hipEventRecord(e->ev_xa, e->stream); hipStreamWaitEvent(e->stream3, e->ev_xa, 0); xrc |= exchange_segment(e, 0);
+            enqueue_step(e, sample, PH_PRE2);
+            hipEventRecord(e->ev_xb, e->stream); hipStreamWaitEvent(e->stream3, e->ev_xb, 0); xrc |= exchange_segment(e, 1);
+            hipEventRecord(e->ev_xc, e->stream3); hipStreamWaitEvent(e->stream, e->ev_xc, 0);
+            enqueue_step(e, sample, PH_POST);
+        } else { enqueue_step(e, sample, PH_PRE); xrc |= exchange_grads(e); enqueue_step(e, sample, PH_POST); }
+    } else
     for (int r = 0; r < repeat; r++) enqueue_step(e, sample, phase);
     const hipError_t lerr = hipGetLastError();          // a launch refused during capture never becomes a graph node
-    HIPCHK(hipStreamEndCapture(e->stream, &g));
+    { const hipError_t ce = hipStreamEndCapture(e->stream, &g); if (ce != hipSuccess || xrc) { (void)hipGetLastError(); if (ce == hipSuccess) hipGraphDestroy(g); return fail("capturing the train step failed (%s%s)", hipGetErrorString(ce), xrc ? "; collective refused" : ""); } }
     if (lerr != hipSuccess) { hipGraphDestroy(g); return fail("HIP error %s while capturing the train step", hipGetErrorString(lerr)); }
     HIPCHK(hipGraphInstantiate(out, g, nullptr, nullptr, 0));
     HIPCHK(hipGraphDestroy(g)); return 0;
+}
+// dp_overlap: segment 0 = the wide layers' operands [0, dp_count_a) -> dp_recv, segment 1 = the small gradients [dp_count_a, dp_count) -> dp_recv_b, both on stream3
+int exchange_segment(dqn_engine* e, int seg) {
+    const size_t beg = seg ? e->dp_count_a : 0, cnt = seg ? e->dp_count - e->dp_count_a : e->dp_count_a; float* recv = seg ? e->dp_recv_b : e->dp_recv;
+    if (e->sim_world) { for (int r = 0; r < e->sim_world; r++) HIPCHK(hipMemcpyAsync(recv + (size_t)r * cnt, e->dp_send + beg, cnt * 4, hipMemcpyDeviceToDevice, e->stream3)); return 0; }
+    const int rc = g_rccl.AllGather(e->dp_send + beg, recv, cnt, /*ncclFloat*/ 7, e->comm, e->stream3);
+    if (rc) return fail("ncclAllGather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    return 0;
 }
 int exchange_grads(dqn_engine* e) {
     if (e->dp_gather) {      // every rank's packed block -> all ranks (rank-major), on the engine stream between the two halves of the step
@@ -571,7 +603,32 @@ int run_step(dqn_engine* e, bool sample, bool take_pre, bool pregather) {
         const bool tp = sample && e->pg_ok && take_pre, pgth = sample && e->pg_ok && pregather;
         e->step_take_pre = tp; e->step_pregather = pgth;
         int rc = 0;
-        if (e->hp.use_graph && !e->profiling) {
+        static const bool one_graph_ok = getenv("DQN_DP_NO_ONE_GRAPH") == nullptr;
+        if (one_graph_ok && e->hp.use_graph && !e->profiling && !e->sim_world && e->comm && e->dp_one_state >= 0) {
+            hipGraphExec_t& g = e->g_dp_one[(tp ? 2 : 0) + (pgth ? 1 : 0) + 0];
+            if (!g && gi == 0) { if (capture(e, sample, PH_DP_ONE, &g)) { e->dp_one_state = -1; g = nullptr; } else e->dp_one_state = 1; }
+            if (g && gi == 0) { HIPCHK(hipGraphLaunch(g, e->stream)); e->step_take_pre = e->step_pregather = false; return 0; }
+        }
+        if (e->dp_gather && e->dp_overlap) {
+            // three segments: [.. head level, pack of the wide operands] | all-gather A on stream3, concurrently: [rest of the backward pass, pack of the small
+            // gradients] | all-gather B on stream3 | [wide dW over the gathered samples, sum over ranks, Adam]
+            const bool gr = e->hp.use_graph && !e->profiling;
+            hipGraphExec_t& g1 = e->g_pre1[tp ? 2 : gi]; hipGraphExec_t& gpost = pgth ? e->g_post_pg : e->g_post;
+            if (gr) { if (!g1 && capture(e, sample, PH_PRE1, &g1)) rc = -1; if (!rc && !e->g_pre2 && capture(e, sample, PH_PRE2, &e->g_pre2)) rc = -1; if (!rc && !gpost && capture(e, sample, PH_POST, &gpost)) rc = -1; }
+            if (!rc) {
+                if (gr) HIPCHK(hipGraphLaunch(g1, e->stream)); else { enqueue_step(e, sample, PH_PRE1); HIPCHK(hipGetLastError()); }
+                HIPCHK(hipEventRecord(e->ev_xa, e->stream)); HIPCHK(hipStreamWaitEvent(e->stream3, e->ev_xa, 0));
+                if (exchange_segment(e, 0)) rc = -1;
+            }
+            if (!rc) {
+                if (gr) HIPCHK(hipGraphLaunch(e->g_pre2, e->stream)); else { enqueue_step(e, sample, PH_PRE2); HIPCHK(hipGetLastError()); }
+                HIPCHK(hipEventRecord(e->ev_xb, e->stream)); HIPCHK(hipStreamWaitEvent(e->stream3, e->ev_xb, 0));
+                if (exchange_segment(e, 1)) rc = -1;
+                HIPCHK(hipEventRecord(e->ev_xc, e->stream3)); HIPCHK(hipStreamWaitEvent(e->stream, e->ev_xc, 0));
+            }
+            if (!rc) { if (gr) HIPCHK(hipGraphLaunch(gpost, e->stream)); else { enqueue_step(e, sample, PH_POST); HIPCHK(hipGetLastError()); } }
+        }
+        else if (e->hp.use_graph && !e->profiling) {
             hipGraphExec_t& gpre = tp ? e->g_pre_tp : e->g_pre[gi];
             hipGraphExec_t& gpost = pgth ? e->g_post_pg : e->g_post;
             if (!gpre && capture(e, sample, PH_PRE, &gpre)) rc = -1;
@@ -635,6 +692,11 @@ extern "C" int dqn_sim_ranks_step(dqn_engine_t* e, const int64_t* idx, float* lo
         HIPCHK(hipMemcpyAsync(e->idx, idx + (size_t)r * B, (size_t)B * 8, hipMemcpyHostToDevice, e->stream));
         if (e->hp.use_graph) { if (!e->g_pre[1] && capture(e, false, PH_PRE, &e->g_pre[1])) { rc = -1; break; } HIPCHK(hipGraphLaunch(e->g_pre[1], e->stream)); }
         else enqueue_step(e, false, PH_PRE);
+        if (e->dp_overlap) {
+            const size_t ca = e->dp_count_a, cb = e->dp_count - ca;
+            HIPCHK(hipMemcpyAsync(e->dp_recv + (size_t)r * ca, e->dp_send, ca * 4, hipMemcpyDeviceToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync(e->dp_recv_b + (size_t)r * cb, e->dp_send + ca, cb * 4, hipMemcpyDeviceToDevice, e->stream));
+        } else
         HIPCHK(hipMemcpyAsync(e->dp_recv + (size_t)r * e->dp_count, e->dp_send, e->dp_count * 4, hipMemcpyDeviceToDevice, e->stream));
         HIPCHK(hipMemcpyAsync(s_idx + (size_t)r * B, e->idx, (size_t)B * 8, hipMemcpyDeviceToDevice, e->stream));
         HIPCHK(hipMemcpyAsync(s_td + (size_t)r * B, e->td, (size_t)B * 4, hipMemcpyDeviceToDevice, e->stream));

@@ -332,6 +332,14 @@ int build_program(dqn_engine* e) {
         t.tasks = upload(e, v); t.n = (int)v.size(); t.blocks = blocks; v.clear();
         return t;
     };
+    // dp_overlap: with fused heads the operands of the flagged wide dense layers (X from the forward pass, dpre from k_head_td) are final HERE, before any
+    // backward launch: pack and exchange them now, on the exchange stream, while the conv backward runs (SURVEY 8e "overlapped with backward")
+    // OPT-IN (DQN_DP_OVERLAP=1): measured at world 1, where there is nothing to hide, the fork + join of the exchange stream cost 26 us per step (one-graph
+    // replica step 155.8 -> 181.9 us) -- it pays once the first all-gather takes longer than that, which only a multi-GPU box can tell
+    bool overlap_cand = dp_on && n_dp > 0 && fuse_heads && levels.size() >= 2 && getenv("DQN_DP_OVERLAP") != nullptr;
+    if (overlap_cand) for (int i = 0; i < e->nl; i++) if (dp_layer[i]) { bool in_lvl = false; for (int l : levels[levels.size() - 2]) in_lvl = in_lvl || l == i; overlap_cand = overlap_cand && in_lvl; }
+    e->dp_overlap = false; e->prog_pre1_end = 0;
+    if (overlap_cand) { e->prog.push_back({"dp_pack_wide", [](dqn_engine* en) { if (en->dp_overlap) launch_dp_pack(en->stream, en->dp_pk_a); }}); e->prog_pre1_end = e->prog.size(); }
     for (int li = (int)levels.size() - 1; li >= 0; li--) {
         const auto& lv = levels[li];
         std::vector<VTask> pend;
@@ -554,20 +562,30 @@ int build_program(dqn_engine* e) {
         off = (off + 3) / 4 * 4;
         if (e->dp_count != off) { hipFree(e->dp_send); hipFree(e->dp_recv); e->dp_send = e->dp_recv = nullptr; HIPCHK(hipMalloc((void**)&e->dp_send, off * 4)); HIPCHK(hipMalloc((void**)&e->dp_recv, off * 4 * W)); e->dp_count = off; }
         pk.send = e->dp_send; dsum.recv = e->dp_recv; dsum.stride = off; dsum.world = W; dsum.grad = e->grad;
+        unsigned long long off_a = 0;      // end of the wide layers' operands inside the block
+        for (auto& q : dpdw) off_a = std::max(off_a, q.d_off + (unsigned long long)q.L.N * B);
+        if (overlap_cand && off_a % 4 == 0 && off_a < off) {
+            e->dp_overlap = true; e->dp_count_a = off_a;
+            hipFree(e->dp_recv_b); e->dp_recv_b = nullptr; HIPCHK(hipMalloc((void**)&e->dp_recv_b, (off - off_a) * 4 * W));
+            DpPackArgs pa; memset(&pa, 0, sizeof pa); DpPackArgs pb; memset(&pb, 0, sizeof pb); pa.send = pb.send = e->dp_send;
+            for (int i = 0; i < pk.n; i++) { if (pk.r[i].dst < off_a) pa.r[pa.n++] = pk.r[i]; else pb.r[pb.n++] = pk.r[i]; }
+            e->dp_pk_a = pa; pk = pb;
+            dsum.recv = e->dp_recv_b; dsum.stride = off - off_a; for (int i = 0; i < dsum.n; i++) dsum.r[i].src -= off_a;
+        }
         e->prog.push_back({"dp_pack", [=](dqn_engine* en) { launch_dp_pack(en->stream, pk); }});
         e->dp_gather = true; e->dp_pack_folds = pack_folds;
         // the ascending sum over ranks of the small gradient ranges rides inside k_adam (its slab-reduce blocks) when the ranges allow it
         memset(&e->dp_adam_segs, 0, sizeof e->dp_adam_segs);
         bool af = dsum.n > 0 && dsum.n <= 8; unsigned long long tot = 0;
         for (int i = 0; i < dsum.n; i++) af = af && dsum.r[i].dst % 4 == 0 && dsum.r[i].n % 4 == 0;
-        if (af) for (int i = 0; i < dsum.n; i++) { AdamSegs& A = e->dp_adam_segs; const int q = A.n++; A.beg[q] = dsum.r[i].dst; A.end[q] = dsum.r[i].dst + dsum.r[i].n; A.part[q] = e->dp_recv + dsum.r[i].src; A.S[q] = W; A.stride[q] = off; tot += dsum.r[i].n; }
+        if (af) for (int i = 0; i < dsum.n; i++) { AdamSegs& A = e->dp_adam_segs; const int q = A.n++; A.beg[q] = dsum.r[i].dst; A.end[q] = dsum.r[i].dst + dsum.r[i].n; A.part[q] = dsum.recv + dsum.r[i].src; A.S[q] = W; A.stride[q] = dsum.stride; tot += dsum.r[i].n; }
         e->dp_adam_segs.blocks = (unsigned)((tot + 255) / 256);
         e->dp_adam_folds = af;
     }
     e->prog_post_begin = e->prog.size();
     if (e->dp_gather) {
         // big dense dW over the W*B gathered samples (rank-major = the concatenated batch); siblings with the same X and geometry share a launch
-        const float* recv = e->dp_recv; const int cnt = (int)e->dp_count; float* grad = e->grad;
+        const float* recv = e->dp_recv; const int cnt = (int)(e->dp_overlap ? e->dp_count_a : e->dp_count); float* grad = e->grad;      // rank stride of the buffer that holds X | dpre
         std::vector<bool> used(dpdw.size(), false);
         for (size_t i = 0; i < dpdw.size(); i++) {
             if (used[i]) continue; used[i] = true;

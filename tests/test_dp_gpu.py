@@ -228,3 +228,51 @@ def test_simulated_ranks_with_two_tiles_per_rank(pkg, monkeypatch):
     for x, y in wide:
         np.testing.assert_array_equal(x, y)
     np.testing.assert_allclose(Gg, Gt, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("env", [{"DQN_DP_OVERLAP": "1"}, {"DQN_DP_OVERLAP": "1", "DQN_DP_NO_ONE_GRAPH": "1"}, {"DQN_DP_NO_ONE_GRAPH": "1"}],
+                         ids=["overlap_one_graph", "overlap_eager_collectives", "no_overlap_eager_collectives"])
+def test_rccl_world1_exchange_variants_bit_exact(pkg, monkeypatch, env):
+    """The three other schedules of the replica step (default: ONE graph holding [first half | ncclAllGather | second half]):
+    DQN_DP_OVERLAP=1 -- the wide layers' operands X | dpre are packed right after k_head_td and all-gathered on the exchange stream WHILE the conv
+    backward runs, the small gradients in a second all-gather after it; DQN_DP_NO_ONE_GRAPH=1 -- collectives enqueued
+    eagerly between graph segments.  Real RCCL communicator at world size 1; every variant must reproduce the twin bit for bit over single steps,
+    train_steps(n) with the pipelined gather, and replay writes in between."""
+    monkeypatch.setenv("DQN_FORCE_ALLREDUCE", "1")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    net = wide_dense_dueling()
+    g, t, _ = setup(pkg, net, 32, 32, seed=4)
+    g.comm_init(pkg.comm_unique_id(), 0, 1)
+    for _ in range(3):
+        rg, rt = g.train_step(), t.train_step()
+        assert rg[0] == rt[0] and rg[1] == rt[1]
+        np.testing.assert_array_equal(rg[2], rt[2])
+    lg = g.train_steps(5)
+    for _ in range(5):
+        lt = t.train_step()
+    assert lg[0] == lt[0] and lg[1] == lt[1]
+    np.testing.assert_array_equal(g.last_indices(), t.last_indices())
+    np.testing.assert_array_equal(g.get_params(0), t.get_params(0))
+    np.testing.assert_array_equal(g.get_grads(), t.get_grads())
+    np.testing.assert_array_equal(g.replay_priorities(), t.replay_priorities())
+    names = [n for n, _ in g.profile_step(steady=True)]
+    t.train_step(); t.train_step()
+    np.testing.assert_array_equal(g.get_params(0), t.get_params(0))
+    assert ("dp_pack_wide" in names) == ("DQN_DP_OVERLAP" in env), names
+    g.close(); t.close()
+
+
+def test_simulated_ranks_with_overlapped_exchange(pkg, monkeypatch):
+    """DQN_DP_OVERLAP=1 under DQN_SIM_WORLD: k DISTINCT rank batches, the two segments of every rank's block landing in its slots of the two gathered
+    buffers -- the step must still equal the twin's single-device step on the concatenated batch (and notice swapped rank blocks)."""
+    monkeypatch.setenv("DQN_DP_OVERLAP", "1")
+    net = wide_dense_dueling()
+    k, B = 4, 32
+    monkeypatch.setenv("DQN_SIM_WORLD", str(k))
+    g, t, rng = setup(pkg, net, B, k * B, cap=512, n_fill=400, seed=6)
+    monkeypatch.delenv("DQN_SIM_WORLD")
+    idx = rng.choice(400, (k, B), replace=False).astype(np.int64)
+    _distinct_rank_step(g, t, net, k, B, idx, (192, 512), 1e-3)
+    names = [n for n, _ in g.profile_step()]
+    assert "dp_pack_wide" in names and "dp_pack" in names, names

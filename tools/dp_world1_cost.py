@@ -1,4 +1,5 @@
-"""Compute side of the data-parallel step on ONE GPU: the engine's RCCL path forced on at world size 1 (DQN_FORCE_ALLREDUCE=1: step graph cut in
+"""(env DQN_DP_OVERLAP=1: exchange on its own stream beside the conv backward; DQN_DP_NO_ONE_GRAPH=1: collectives enqueued eagerly between graph halves)
+Compute side of the data-parallel step on ONE GPU: the engine's RCCL path forced on at world size 1 (DQN_FORCE_ALLREDUCE=1: step graph cut in
 two around the collective, k_dp_pack, the wide dW over the gathered operands, Adam on the exchanged gradient) against the plain single-GPU step."""
 import time, sys, os, importlib, argparse
 sys.path.insert(0, os.getcwd())
