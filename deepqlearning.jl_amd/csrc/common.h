@@ -105,15 +105,27 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 // barrier per level; equal parents are written with equal values).  `sidx` is >= n long longs of LDS.
 // dense_floats > 0: LDS floats available BEHIND sidx[n] for the dense top (see below).
 __device__ __forceinline__ void prio_update_block_levels(int n, long long cap2, const long long* __restrict__ idx, const float* __restrict__ td, float eps,
-                                                  float alpha, float* tree, StepState* state, long long* sidx, long long dense_floats = 0) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) sidx[i] = idx[i];
+                                                  float alpha, float* tree, StepState* state, long long* sidx, long long dense_floats = 0, unsigned long long* ktr = nullptr) {
+    // 32-bit copies of the indices behind the 64-bit list (the region the dense top uses later): the "last occurrence wins" scan (:79) reads them four
+    // at a time.  (r03 ktrace, 512 paths: the scan over the 64-bit list took 57 us of the block's 89 -- one dependent LDS round trip per comparison.)
+    int* s32 = reinterpret_cast<int*>(sidx + ((n + 1) / 2) * 2);
+    const int n4 = (n + 3) / 4; const bool fast_scan = dense_floats >= (long long)n4 * 4;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { const long long v = idx[i]; sidx[i] = v; if (fast_scan) s32[i] = (int)v; }
+    if (fast_scan) for (int i = n + threadIdx.x; i < 4 * n4; i += blockDim.x) s32[i] = -1;
     __syncthreads();
+    if (ktr) ktr[6] = __builtin_amdgcn_s_memtime();
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        // last occurrence of this index?  A branch-free scan (the early-exit form walked up to n dependent LDS round trips per lane: ~40 us at n = 512)
         const long long mine = sidx[i]; int dupes = 0;
+        if (fast_scan) {
+            const int m32 = (int)mine; const int4* q4 = reinterpret_cast<const int4*>(s32);
+#pragma unroll 4
+            for (int j4 = (i + 1) / 4; j4 < n4; j4++) { const int4 v = q4[j4]; const int jb = 4 * j4; dupes += (jb > i && v.x == m32) + (jb + 1 > i && v.y == m32) + (jb + 2 > i && v.z == m32) + (jb + 3 > i && v.w == m32); }
+        } else {
 #pragma unroll 8
-        for (int j = 0; j < n; j++) dupes += (j > i && sidx[j] == mine) ? 1 : 0;
+            for (int j = 0; j < n; j++) dupes += (j > i && sidx[j] == mine) ? 1 : 0;
+        }
         const bool last = dupes == 0;
+        if (ktr && i < (int)blockDim.x) ktr[5] = __builtin_amdgcn_s_memtime();
         const float p = prio_f(fabsf(td[i]), eps, alpha);
         if (!(p > 0.0f)) state->err = 2;
         if (last) tree[cap2 + sidx[i]] = p;
@@ -121,6 +133,7 @@ __device__ __forceinline__ void prio_update_block_levels(int n, long long cap2, 
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += blockDim.x) sidx[i] = (cap2 + sidx[i]) >> 1;
     __syncthreads();
+    if (ktr) ktr[4] = __builtin_amdgcn_s_memtime();
     // The TOP of the tree is recomputed DENSELY out of LDS: with hundreds of paths nearly every node of the upper levels is an ancestor of an
     // updated leaf, and walking them path by path costs a dependent global round trip per level (r03: 120 us for 512 paths x 20 levels, 6 us per
     // level).  So the sparse walk stops at the level of W nodes; those W values are then read back in one round trip, every level above is
@@ -156,11 +169,11 @@ __device__ __forceinline__ void prio_update_block_levels(int n, long long cap2, 
 // is itself on an updated path takes that path's freshly computed value instead of the prefetched one -- and stored on the way.  Same node
 // arithmetic (node = f32(left + right) of its current children), so the resulting tree is identical.  `lds`: >= 8 KB (7808 bytes used).
 __device__ __forceinline__ void prio_update_block(int n, long long cap2, const long long* __restrict__ idx, const float* __restrict__ td, float eps,
-                                                  float alpha, float* tree, StepState* state, long long* lds, unsigned lds_bytes = 0) {
+                                                  float alpha, float* tree, StepState* state, long long* lds, unsigned lds_bytes = 0, unsigned long long* ktr = nullptr) {
     int L = 0; for (long long w = cap2; w > 1; w >>= 1) L++;
     if (n > 64 || L > 22) {
         const long long used = (long long)((n + 1) / 2) * 16;      // bytes of the index list (padded to 16)
-        prio_update_block_levels(n, cap2, idx, td, eps, alpha, tree, state, lds, (long long)lds_bytes > used ? ((long long)lds_bytes - used) / 4 : 0); return;
+        prio_update_block_levels(n, cap2, idx, td, eps, alpha, tree, state, lds, (long long)lds_bytes > used ? ((long long)lds_bytes - used) / 4 : 0, ktr); return;
     }
     long long* node = lds;                                 // [64]  leaf node id of path i
     float* val = reinterpret_cast<float*>(lds + 64);       // [64]  value of path i's node at the current level
@@ -417,7 +430,7 @@ __device__ __forceinline__ bool prio_block_fast(const PrioArgs& P, StepState* st
 // two-phase form, which needs 8 KB).
 __device__ __forceinline__ void prio_block_run(const PrioArgs& P, StepState* state, long long* sidx, unsigned lds_bytes = 0, unsigned long long* ktr = nullptr) {
     if (lds_bytes && prio_block_fast(P, state, sidx, lds_bytes, ktr)) return;
-    if (P.phase != 2) prio_update_block(P.n, P.cap2, P.idx, P.td, P.eps, P.alpha, P.tree, state, sidx, lds_bytes);
+    if (P.phase != 2) prio_update_block(P.n, P.cap2, P.idx, P.td, P.eps, P.alpha, P.tree, state, sidx, lds_bytes, ktr);
     if (!P.idx_pre || P.phase == 1) return;
     __syncthreads();
     const unsigned long long ctr = state->sample_ctr; const long long size = state->size;

@@ -46,7 +46,7 @@ for grid in sorted(set(bw[:, 0])):
         q = r[r[:, 3] == role]
         life = (q[:, 7] - q[:, 2]) / TPU
         if int(role) == 0 and (q[:, 4] > 0).all():      # priority block (prio_block_fast): words 4..6 = tree top + indices in LDS, siblings / TD / leaves done, ancestors done
-            print("   prio phases (us): indices + tree top in LDS %.2f, siblings + pow + leaves %.2f, ancestors (one wave) %.2f, draws + exit %.2f" % tuple(float(x[0]) / TPU for x in (q[:, 4] - q[:, 2], q[:, 5] - q[:, 4], q[:, 6] - q[:, 5], q[:, 7] - q[:, 6])))
+            print("   prio phases (us; large batches: leaves + duplicate scan / sparse levels / dense top / rest): %.2f, %.2f, %.2f, %.2f" % tuple(float(x[0]) / TPU for x in (q[:, 4] - q[:, 2], q[:, 5] - q[:, 4], q[:, 6] - q[:, 5], q[:, 7] - q[:, 6])))
         if int(role) == 1 and (q[:, 4] > 0).all():      # dX (dx_units_body): words 4..6 = first tile staged, K loop done, unit sums combined
             ph = [(q[:, 4] - q[:, 2]) / TPU, (q[:, 5] - q[:, 4]) / TPU, (q[:, 6] - q[:, 5]) / TPU, (q[:, 7] - q[:, 6]) / TPU]
             print("   dX phases of wave 0 (median / max us): first tile staged %.2f / %.2f, K loop %.2f / %.2f, wait for the other units %.2f / %.2f, combine + store %.2f / %.2f" % tuple(x for p_ in ph for x in (np.median(p_), p_.max())))
