@@ -110,6 +110,7 @@ static int build_layers(const dqn_layer_desc* d, int n, const dqn_hparams* hp, L
 // The default summation-order plan.  Chosen for gfx950 occupancy: long forward contractions
 // are cut into ~512-element chunks, dense dX into 256-element chunks, conv dW into ~256-sample chunks.
 static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out) {
+    bool rec = false; for (int i = 0; i < n; i++) rec = rec || L[i].kind == DQN_LAYER_LSTM;
     for (int i = 0; i < n; i++) {
         out[i].fwd_kc = 0;
         // (small batches only: at B >= 128 the 3 B columns of a step already fill the chip -- 512 workgroups for the 3136 -> 512 layers of config 5 --
@@ -128,10 +129,20 @@ static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out) {
             if (raw < L[i].kh * L[i].kw) out[i].dx_kc = raw;
         }
         out[i].dw_kc = 0;
-        if (L[i].kind == DQN_LAYER_DENSE && L[i].N < 16 && B >= 128) out[i].dw_kc = 64;   // head layers at large batches: 64-sample chains on 8x more threads instead of one B-long chain per output
+        // head layers at large batches, recurrent networks only (their dW is a launch of its own): 64-sample chains on 8x more threads instead of one
+        // B-long chain per output.  Feed-forward networks compute the heads' dW as tail tasks of the widest backward launch, where a 512-deep chain
+        // hides, and unsplit gradients keep the slab sums foldable into the Adam launch (r03: the separate reduce launch cost 12-19 us at config 5)
+        if (L[i].kind == DQN_LAYER_DENSE && L[i].N < 16 && B >= 128 && rec) out[i].dw_kc = 64;
         if (L[i].kind == DQN_LAYER_CONV) {   // positions per chunk so that (K/64 row tiles) x chunks >= ~512 workgroups
             static const int tgt = getenv("DQN_DW_WGS") ? atoi(getenv("DQN_DW_WGS")) : 512;      // experiment knob
             const int st = (tgt + (L[i].K + 63) / 64 - 1) / ((L[i].K + 63) / 64); int ppc = L[i].npos / st; if (ppc < 1) ppc = 1; out[i].dw_kc = ppc * B;
+            // large batches: a position is 4+ K tiles deep, so chunks are cut in SAMPLES (32-aligned, they may start inside a position) to land
+            // on <= 1024 workgroups -- whole positions gave 536 workgroups for the 8x8 conv layer at B = 512, i.e. three on some CUs and two on the rest
+            if (B >= 128 && B % 32 == 0 && !getenv("DQN_DW_POSCHUNK")) {
+                static const int tgt2 = getenv("DQN_DW_WGS") ? atoi(getenv("DQN_DW_WGS")) : 1024;      // measured at config 5: 512 / 768 / 1024 -> conv dW 57 / 52 / 49 us
+                const int mrows = (L[i].K + 63) / 64, KK = L[i].npos * B; int ch = tgt2 / mrows; if (ch < 1) ch = 1;
+                int kc = ((KK + ch - 1) / ch + 31) / 32 * 32; if (kc < KK) out[i].dw_kc = kc; else out[i].dw_kc = 0;
+            }
         }
     }
 }
@@ -172,7 +183,7 @@ static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers
     if (!plan) { default_plan(e->L, e->nl, e->B, defp); plan = defp; }
     for (int i = 0; i < e->nl; i++) {
         e->L[i].fwd_kc = plan[i].fwd_kc; e->L[i].dx_kc = plan[i].dx_kc; e->L[i].dw_kc = plan[i].dw_kc;
-        if (e->L[i].kind == DQN_LAYER_CONV && e->L[i].dw_kc > 0 && e->L[i].dw_kc % e->B) return fail("plan: conv dw_kc must be a multiple of batch_size");
+        if (e->L[i].kind == DQN_LAYER_CONV && e->L[i].dw_kc > 0 && e->L[i].dw_kc % e->B && (e->B % 32 || e->L[i].dw_kc % 32)) return fail("plan: conv dw_kc must be a multiple of batch_size (or, for batch sizes divisible by 32, of 32)");
     }
     HIPCHK(hipSetDevice(device));
     gemm_set_ktrace(nullptr);      // trace builds: (re)reads DQN_PROBE; a no-op otherwise

@@ -70,7 +70,9 @@ int build_program(dqn_engine* e) {
     // ---------------- small batches: the head level (forwards of both nets), the TD kernel and the head layers' dX run as ONE launch with a
     // workgroup per batch column (k_head_td); the heads' dW/db and the loss fold ride as tail tasks of the next backward launch
     int hv_l = -1, ha_l = -1; bool fuse_heads = false;
-    if (!rec && e->B <= 64 && getenv("DQN_NO_HEAD_FUSE") == nullptr) {
+    // (r03: at ANY batch -- at B = 512 the four launches it replaces, head forwards / slab reduce / single-workgroup k_td / head dX, took 40 us)
+    static const int hf_maxB = getenv("DQN_HEAD_FUSE_MAXB") ? atoi(getenv("DQN_HEAD_FUSE_MAXB")) : 1024;      // experiment knob
+    if (!rec && e->B <= hf_maxB && getenv("DQN_NO_HEAD_FUSE") == nullptr) {
         const auto& lv = levels.back();
         if (e->hp.dueling && lv.size() == 2 && lv[0] == e->last_val && lv[1] == e->last_adv) { hv_l = lv[0]; ha_l = lv[1]; }
         else if (!e->hp.dueling && lv.size() == 1 && lv[0] == e->last_base) ha_l = lv[0];
@@ -78,7 +80,7 @@ int build_program(dqn_engine* e) {
             fuse_heads = true; size_t lds = (size_t)(1 + e->nA) * 4;
             for (int l : lv) {
                 const LayerDev& L = e->L[l];
-                fuse_heads = fuse_heads && L.kind == DQN_LAYER_DENSE && dqn_nchunks(B, L.dw_kc) == 1 && dqn_nchunks(L.N, L.dx_kc) == 1 && (L.src < 0 || e->L[L.src].kind != DQN_LAYER_LSTM);
+                fuse_heads = fuse_heads && L.kind == DQN_LAYER_DENSE && dqn_nchunks(L.N, L.dx_kc) == 1 && (L.src < 0 || e->L[L.src].kind != DQN_LAYER_LSTM);
                 lds += ((size_t)3 * L.K + (size_t)3 * L.N * dqn_nchunks(L.K, L.fwd_kc) + (size_t)3 * L.N) * 4;
             }
             fuse_heads = fuse_heads && lds <= 60 * 1024;
@@ -347,8 +349,11 @@ int build_program(dqn_engine* e) {
             // the head layers' dX already ran inside k_head_td; their dW/db (one B-long chain per weight) and the loss fold are tail tasks
             for (int l : lv) {
                 const LayerDev L = e->L[l];
-                VTask t; memset(&t, 0, sizeof t); t.kind = 1; t.L = L; t.X = L.src < 0 ? e->x0 : e->act_on[L.src]; t.ldx = L.src < 0 ? ld0 : ncon; t.dpre = e->dact[l]; t.B = B; t.S = 1; t.kc = B;
-                t.out = e->grad + L.w_off; tail_pend.push_back(t);
+                const int S = dqn_nchunks(B, L.dw_kc);      // large batches: plan chunks of the B-long chains, slabs summed with the other dW slabs
+                float* part = S > 1 ? palloc(e, (size_t)S * (L.K + 1) * L.N) : nullptr;
+                VTask t; memset(&t, 0, sizeof t); t.kind = 1; t.L = L; t.X = L.src < 0 ? e->x0 : e->act_on[L.src]; t.ldx = L.src < 0 ? ld0 : ncon; t.dpre = e->dact[l]; t.B = B; t.S = S; t.kc = dqn_chunk_len(B, L.dw_kc);
+                t.out = S > 1 ? part : e->grad + L.w_off; tail_pend.push_back(t);
+                if (S > 1) { RSeg r; memset(&r, 0, sizeof r); r.part = part; r.S = S; r.elems = (unsigned long long)(L.K + 1) * L.N; r.mode = 2; r.out = e->grad + L.w_off; final_segs.push_back(r); }
             }
             VTask f; memset(&f, 0, sizeof f); f.kind = 3; f.dpre = hl_buf; f.B = B; f.out = &e->state->loss; tail_pend.push_back(f);
             if (early) for (int l : lv) adam_after_tail.push_back(l);

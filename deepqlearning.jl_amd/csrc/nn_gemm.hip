@@ -363,7 +363,7 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
     const GDwProb& p = pr.p[pi];
     const int n0 = ng * NW;
     const int KK = L.npos * B, j0 = s * kc, j1 = min(KK, j0 + kc);
-    const int nsub = B / 32, nkt = (j1 - j0) / 32, pos0 = j0 / B;
+    const int nsub = B / 32, nkt = (j1 - j0) / 32, kt0 = j0 / 32;      // a chunk may start inside a position (kc % 32 == 0, B % 32 == 0: a K tile never straddles two)
     // ---- A tile slice of this thread: rows tid>>3 and +32, float4 (tid & 7)
     const int f4 = tid & 7;
     int koff0, koff1;
@@ -388,7 +388,7 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
     auto cvt = [](const AT& a) { if constexpr (XU8) { const uint32_t w4 = a; return (f32x4){u8_unit(w4 & 0xffu), u8_unit((w4 >> 8) & 0xffu), u8_unit((w4 >> 16) & 0xffu), u8_unit(w4 >> 24)}; } else return a; };
     auto gload = [&](int kt, Stage& r) {
         kt = min(kt, nkt - 1);
-        const int pos = pos0 + kt / nsub, sub = kt % nsub;          // 32-sample block `sub` of position `pos`
+        const int ka = kt0 + kt; const int pos = ka / nsub, sub = ka % nsub;          // 32-sample block `sub` of position `pos`
         const unsigned so = ds.tpr > 0 ? (unsigned)(sub / ds.tpr) * (unsigned)ds.rstride + (unsigned)(sub % ds.tpr) * 32u : (unsigned)sub * 32u;
         const unsigned ao = so, bo = (unsigned)pos * (unsigned)B + so;
         int xb = 0;
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void k_dw_lds(LayerDev L, GDwProbs pr, int npr
 }
 bool gemm_dw_eligible(const LayerDev& L, int B, int ldx) {
     const int KK = L.npos * B, S = dqn_nchunks(KK, L.dw_kc), kc = dqn_chunk_len(KK, L.dw_kc);
-    return !(L.N % 16 || B % 32 || ldx % 4 || L.K < 16 || (S > 1 && kc % B));
+    return !(L.N % 16 || B % 32 || ldx % 4 || L.K < 16 || (S > 1 && kc % 32));
 }
 // nprob (<= 2) sibling layers of identical geometry in one launch; out[i] = gradient base (S == 1) or partial slab base
 void launch_gemm_dw(hipStream_t st, const LayerDev& L, int nprob, const float* const* X, int ldx, const float* const* dpre, int B, float* const* out, int ldd, int tpr, int rstride, GemmTail tail) {

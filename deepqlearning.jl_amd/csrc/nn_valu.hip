@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void k_head_td(const HeadTdArgs* __restrict__ 
     float* const dq = p;                                   // [1 + nA]: head pre-activation gradients of this column (val first)
     if (A.dbg == 9) return;
     if (take_pre && b == 0) {      // the batch in the arena was gathered by the previous step's Adam launch: publish its indices (priority block, parity API)
-        if (tid < B) A.idx[tid] = A.idx_pre[tid];
+        for (int i = tid; i < B; i += 256) A.idx[i] = A.idx_pre[i];
         if (tid == 0 && A.st->pre_valid != 2) A.st->err = 3;
     }
     int act_ = 0; float rew_ = 0.0f, dn_ = 0.0f, w_ = 0.0f;

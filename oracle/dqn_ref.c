@@ -125,7 +125,8 @@ static inline void philox(uint32_t k0, uint32_t k1, uint32_t c[4]) {
 int ref_plan_default(const dqn_layer_desc* d, int n, const dqn_hparams* hp, dqn_layer_plan* out) {
     /* independent restatement of the rule in DESIGN.md section 4 (the tests check it
      * equals dqn_plan_default of the product) */
-    int c = hp->obs_c, h = hp->obs_h, w = hp->obs_w; int bc = c, bh = h, bw = w; int seen_val = 0, seen_adv = 0, has_base = 0;
+    int c = hp->obs_c, h = hp->obs_h, w = hp->obs_w; int bc = c, bh = h, bw = w; int seen_val = 0, seen_adv = 0, has_base = 0, rec = 0;
+    for (int i = 0; i < n; i++) if (d[i].kind == DQN_LAYER_LSTM) rec = 1;
     for (int i = 0; i < n; i++) {
         int join = 0;      /* first layer of a dueling stream: its dX meets the other stream's at the base output */
         if (d[i].stream == DQN_STREAM_VAL && !seen_val) { seen_val = 1; c = bc; h = bh; w = bw; join = has_base; }
@@ -149,8 +150,12 @@ int ref_plan_default(const dqn_layer_desc* d, int n, const dqn_hparams* hp, dqn_
             if (raw < d[i].kh * d[i].kw) out[i].dx_kc = raw;
         }
         out[i].dw_kc = 0;
-        if (d[i].kind == DQN_LAYER_DENSE && d[i].n_out < 16 && B >= 128) out[i].dw_kc = 64;
-        if (posB) { int mrows = (K + 63) / 64; int st = (512 + mrows - 1) / mrows; int ppc = (h * w) / st; if (ppc < 1) ppc = 1; out[i].dw_kc = ppc * B; }
+        if (d[i].kind == DQN_LAYER_DENSE && d[i].n_out < 16 && B >= 128 && rec) out[i].dw_kc = 64;      /* recurrent networks only */
+        if (posB) { int mrows = (K + 63) / 64; int st = (512 + mrows - 1) / mrows; int ppc = (h * w) / st; if (ppc < 1) ppc = 1; out[i].dw_kc = ppc * B;
+            if (B >= 128 && B % 32 == 0) {      /* large batches: sample-granular chunks, <= 1024 workgroups */
+                int KK = h * w * B; int ch = 1024 / mrows; if (ch < 1) ch = 1;
+                int kc = ((KK + ch - 1) / ch + 31) / 32 * 32; out[i].dw_kc = kc < KK ? kc : 0;
+            } }
     }
     return 0;
 }
