@@ -96,15 +96,15 @@ struct GFwdProbs { GFwdProb p[4]; int wg_end[4]; };   // up to 4 problems of one
 #ifndef DQN_F_KT
 #define DQN_F_KT 32
 #endif
-constexpr int F_KT = DQN_F_KT;  // K tile depth (32 or 64)
+constexpr int F_KT_DEF = DQN_F_KT;  // K tile depth of the small-batch launches (32 or 64); launches of >= 1024 workgroups use 16-deep tiles (see launch_gemm_fwd)
 constexpr int F_SA = 80;        // A tile row stride (64 columns + 16 pad): ds_read_b32 of lanes (i, kq) hits banks 16*kq + i
 template <int NT> struct FwdCfg { static constexpr int NW = 16 * NT; static constexpr int SB = (NW % 32 == 0) ? NW + 16 : NW + 32; };
 
 // XU8: the A operand is the BYTE observation arena (u8 replay): a lane fetches 4 bytes = 4 columns and converts them (byte / 255f0, exactly) on
 // the way into the LDS tile -- a quarter of the operand bytes of the float arena, and the gather wrote a quarter as well
-template <int NT, bool XU8 = false>
+template <int NT, bool XU8 = false, int KT = F_KT_DEF>
 __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S, int kc) {
-    constexpr int NW = FwdCfg<NT>::NW, SB = FwdCfg<NT>::SB;
+    constexpr int NW = FwdCfg<NT>::NW, SB = FwdCfg<NT>::SB, F_KT = KT;
     using AT = std::conditional_t<XU8, uint32_t, f32x4>;
     extern __shared__ float lds[];
     float* As = lds;                                   // [2][F_KT][F_SA]
@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     };
     auto stage_wait = [&](auto N, Stage& r) {
         constexpr int n = decltype(N)::value;
-        if constexpr (AQ == 2 && BQ == 1) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.b[0]) : "n"(n) : "memory");
+        if constexpr (AQ == 1 && BQ == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.a[0]), "+v"(r.b[0]) : "n"(n) : "memory");
+        else if constexpr (AQ == 2 && BQ == 1) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.b[0]) : "n"(n) : "memory");
         else if constexpr (AQ == 2 && BQ == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.b[0]), "+v"(r.b[1]) : "n"(n) : "memory");
         else if constexpr (AQ == 4 && BQ == 1) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.b[0]) : "n"(n) : "memory");
         else if constexpr (AQ == 4 && BQ == 2) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.b[0]), "+v"(r.b[1]) : "n"(n) : "memory");
@@ -289,7 +290,7 @@ static int fwd_pick_nt(const LayerDev& L, long mgroups_total, int S) {
 // split-K partial slabs are left for the caller to reduce (k_reduce_multi, or folded into the consumer)
 bool gemm_fwd_eligible(const LayerDev& L, int nprob, const int* ldx, const int* col0, const int* ncols) {
     const int S = dqn_nchunks(L.K, L.fwd_kc), kc = dqn_chunk_len(L.K, L.fwd_kc);
-    if (L.N % 16 || L.K % F_KT || (S > 1 && kc % F_KT) || L.K > 8192 || L.w_off % 4) return false;
+    if (L.N % 16 || L.K % F_KT_DEF || (S > 1 && kc % F_KT_DEF) || L.K > 8192 || L.w_off % 4) return false;
     for (int i = 0; i < nprob; i++) if (ncols[i] % 16 || ldx[i] % 4 || col0[i] % 4) return false;
     return true;
 }
@@ -309,15 +310,19 @@ void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* 
     int end = 0;
     for (int i = 0; i < 4; i++) { if (i < nprob) end += pr.p[i].mgroups * ngroups * S; pr.wg_end[i] = end; }
     const int SB = NT == 4 ? FwdCfg<4>::SB : (NT == 2 ? FwdCfg<2>::SB : FwdCfg<1>::SB);
-    const size_t lds = (size_t)(2 * F_KT * F_SA + 2 * F_KT * SB) * 4 + (L.kind == DQN_LAYER_CONV ? (size_t)L.K * 4 : 0);
-    if (L.xu8) {
-        if (NT == 4) hipLaunchKernelGGL((k_fwd_lds<4, true>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
-        else if (NT == 2) hipLaunchKernelGGL((k_fwd_lds<2, true>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
-        else hipLaunchKernelGGL((k_fwd_lds<1, true>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
-    }
-    else if (NT == 4) hipLaunchKernelGGL((k_fwd_lds<4>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
-    else if (NT == 2) hipLaunchKernelGGL((k_fwd_lds<2>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
-    else hipLaunchKernelGGL((k_fwd_lds<1>), dim3(end), dim3(256), lds, st, L, pr, S, kc);
+    // K tile depth: 32 while a launch is a few hundred workgroups (B = 32: each pays its barriers in full), 16 once it is >= 1024 of them (large
+    // batches): half the LDS per workgroup doubles the resident waves (3-4 -> 6-8 per SIMD), which hides more of the operand latency than the extra
+    // barrier rounds cost -- measured at config 5 (r03): conv forwards 129.7 / 93.4 / 67.0 -> 120.8 / 85.5 / 63.0 us; at config 2 the same tiles LOSE 1.5 us per launch
+    static const int kt16_min = getenv("DQN_FWD_KT16_MIN") ? atoi(getenv("DQN_FWD_KT16_MIN")) : 1024;      // experiment knob
+    const bool k16 = end >= kt16_min && F_KT_DEF == 32;
+    const int kt = k16 ? 16 : F_KT_DEF;
+    const size_t lds = (size_t)(2 * kt * F_SA + 2 * kt * SB) * 4 + (L.kind == DQN_LAYER_CONV ? (size_t)L.K * 4 : 0);
+#define FWD_LAUNCH(NT_, U8_, KT_) hipLaunchKernelGGL((k_fwd_lds<NT_, U8_, KT_>), dim3(end), dim3(256), lds, st, L, pr, S, kc)
+#define FWD_PICK(U8_, KT_) do { if (NT == 4) FWD_LAUNCH(4, U8_, KT_); else if (NT == 2) FWD_LAUNCH(2, U8_, KT_); else FWD_LAUNCH(1, U8_, KT_); } while (0)
+    if (L.xu8) { if (k16) FWD_PICK(true, 16); else FWD_PICK(true, F_KT_DEF); }
+    else { if (k16) FWD_PICK(false, 16); else FWD_PICK(false, F_KT_DEF); }
+#undef FWD_PICK
+#undef FWD_LAUNCH
 }
 
 // =====================================================================================================================
