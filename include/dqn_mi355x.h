@@ -67,7 +67,7 @@ typedef struct {
 typedef struct {
     int32_t fwd_kc; /* forward:  K = n_in            | cin*kh*kw           */
     int32_t dx_kc;  /* dX:       K = n_out           | conv: RAW kernel taps (ky*kw + kx ascending) per chunk; each chunk chains its VALID taps, co innermost */
-    int32_t dw_kc;  /* dW, db:   K = batch           | out_positions*batch  */
+    int32_t dw_kc;  /* dW, db:   K = batch           | out_positions*batch (position-major, sample-minor); conv: a multiple of batch_size, or -- when batch_size % 32 == 0 -- of 32 */
 } dqn_layer_plan;
 
 /* DeepQLearningSolver fields that reach the hot path (src/solver.jl:1-28) plus the
