@@ -338,7 +338,9 @@ __device__ __forceinline__ long long tree_descend_from(const float* __restrict__
 // round trip finishes them.  Same node arithmetic, same comparisons, same Philox draws as prio_update_block + tree_descend: identical tree,
 // identical indices.  r03 ktrace: the two-phase block lived 10-13 us (9 dependent round trips at 0.7-1.5 us) and bounded whichever backward
 // launch carried it.  lds: 7808 bytes of path state + TOPN floats.
-__device__ __forceinline__ bool prio_block_fast(const PrioArgs& P, StepState* state, long long* lds, unsigned lds_bytes, unsigned long long* ktr = nullptr) {
+// ctr_in: the Philox counter of the NEXT sample() when the caller bumped it itself earlier in the SAME kernel (k_tiny_step: a uniform re-read of
+// state->sample_ctr may be served by the scalar cache, which does not see the kernel's own vector stores); ~0: read it from the state
+__device__ __forceinline__ bool prio_block_fast(const PrioArgs& P, StepState* state, long long* lds, unsigned lds_bytes, unsigned long long* ktr = nullptr, unsigned long long ctr_in = ~0ull) {
     int L = 0; for (long long w = P.cap2; w > 1; w >>= 1) L++;
     const int n = P.n, B = P.B;
     if (n < 1 || n > 64 || L > 22 || L < 3 || !P.idx_pre || B > (int)blockDim.x || lds_bytes < 7808 + 64 * 4 || P.cap2 < 64) return false;
@@ -354,7 +356,7 @@ __device__ __forceinline__ bool prio_block_fast(const PrioArgs& P, StepState* st
     // ---- round trip 1: the index list, the TD errors, the step counters, the top of the tree (all independent).  The Float64 pow of the new
     // priorities (~1.7 us of dependent arithmetic per lane) runs while the tree copy is in flight.
     long long my_idx = 0; float my_td = 0.0f; if (t < n && phase != 2) { my_idx = P.idx[t]; my_td = P.td[t]; }
-    const unsigned long long ctr = state->sample_ctr; const long long size = state->size;
+    const unsigned long long ctr = ctr_in != ~0ull ? ctr_in : state->sample_ctr; const long long size = state->size;
     f32x4c tq[8];                                          // <= 8192 nodes at 256 threads
     const int nq = (int)((topn / 4 + blockDim.x - 1) / blockDim.x);
 #pragma unroll
@@ -428,12 +430,12 @@ __device__ __forceinline__ bool prio_block_fast(const PrioArgs& P, StepState* st
 // with its row loads instead of ~5 dependent round trips per workgroup.  Anything that touches the tree, the size or the counters before
 // that gather clears state->pre_valid and the gather descends itself, exactly as before.  lds_bytes: LDS behind `sidx` (0: unknown -- the
 // two-phase form, which needs 8 KB).
-__device__ __forceinline__ void prio_block_run(const PrioArgs& P, StepState* state, long long* sidx, unsigned lds_bytes = 0, unsigned long long* ktr = nullptr) {
-    if (lds_bytes && prio_block_fast(P, state, sidx, lds_bytes, ktr)) return;
+__device__ __forceinline__ void prio_block_run(const PrioArgs& P, StepState* state, long long* sidx, unsigned lds_bytes = 0, unsigned long long* ktr = nullptr, unsigned long long ctr_in = ~0ull) {
+    if (lds_bytes && prio_block_fast(P, state, sidx, lds_bytes, ktr, ctr_in)) return;
     if (P.phase != 2) prio_update_block(P.n, P.cap2, P.idx, P.td, P.eps, P.alpha, P.tree, state, sidx, lds_bytes, ktr);
     if (!P.idx_pre || P.phase == 1) return;
     __syncthreads();
-    const unsigned long long ctr = state->sample_ctr; const long long size = state->size;
+    const unsigned long long ctr = ctr_in != ~0ull ? ctr_in : state->sample_ctr; const long long size = state->size;
     const float seg = P.tree[1] / (float)P.B;
     for (int i = threadIdx.x; i < P.B; i += blockDim.x) P.idx_pre[i] = tree_descend(P.tree, P.cap2, size, P.seed, ctr, i, seg);
     __syncthreads();
@@ -541,6 +543,23 @@ void launch_valu_dw(hipStream_t st, const LayerDev& L, const float* X, int ldx, 
 void launch_valu_dx(hipStream_t st, const LayerDev& L, const float* P, const float* dpre, int B, float* out, float* partials,
                     const float* addend, const float* ysrc, int ldy, int act_src);
 void launch_td(hipStream_t st, const TdArgs& a);
+// the whole train step of a network that fits in LDS as ONE single-workgroup launch (tiny_step.hip; BASELINE config 1)
+#define TINY_MAX_LAYERS 8
+struct TinyArgs {
+    int nl, nlev, B, nA, E, ncon, dueling, double_q, obs_u8;
+    int last_base, last_val, last_adv;
+    float gamma, beta, prio_eps, prio_alpha;
+    long long cap2; unsigned long long seed, P;
+    LayerDev L[TINY_MAX_LAYERS];
+    int lev_n[TINY_MAX_LAYERS], lev_l[TINY_MAX_LAYERS][2];      // level -> its (one or two sibling) layers
+    int on_off[TINY_MAX_LAYERS], tg_off[TINY_MAX_LAYERS], d_off[TINY_MAX_LAYERS];      // LDS float offsets: act_on [N][ncon], act_tg [N][B], dact [N][B]
+    int pon_off, ptg_off, g_off, x0_off, misc_off; unsigned lds_bytes;
+    const float* p_tg; float *p_on, *m, *v, *grad; StepState* state; float* gmax_part; float* tree;
+    long long *idx, *idx_pre; const void *s_rows, *sp_rows; const int* ra; const float* rr; const unsigned char* rdone;
+    float* x0; float *w_is, *td, *q_on_s, *q_on_sp, *q_tg_sp, *ytarget; int* best;
+    int f64mode; float lr; double b1, b2, adam_eps;
+};
+void launch_tiny_step(hipStream_t st, const TinyArgs* a_dev, unsigned lds_bytes, int sample);
 int adam_blocks(size_t P);
 static inline int gmax_slots(size_t) { return 65536; }   // per-block max |g| of every Adam job of a step (each job owns a slot range)
 void launch_adam(hipStream_t st, const AdamJob& job, const PreGather* pg = nullptr /* see PreGather */);

@@ -81,6 +81,8 @@ struct dqn_engine {
     int gmax_used = 0;                    // live slots of gmax_part (per-block max |g| of the step's Adam jobs): what the on-demand fold reads
     StepState* state_host = nullptr;      // pinned landing buffer of fetch_scalars
     bool pg_ok = false, step_pregather = false, step_take_pre = false; PreGather pg; long adam_step = -1;
+    bool no_tiny = false;   // DQN_NO_TINY at dqn_engine_create: always the multi-launch program
+    bool tiny = false;      // the whole step is ONE single-workgroup launch that samples and gathers itself (tiny_step.hip)
     hipGraphExec_t g_pgv[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [take_pre][pregather] variants of the sampled single-device step
     hipGraphExec_t g_mid = nullptr; int mid_group = 4;                          // mid_group consecutive middle steps of dqn_train_steps as one graph
     hipGraphExec_t g_pre1[3] = {nullptr, nullptr, nullptr}, g_pre2 = nullptr;

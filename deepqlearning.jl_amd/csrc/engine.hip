@@ -177,6 +177,7 @@ static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers
     if (build_layers(layers, n_layers, hp, e->L, &e->last_base, &e->last_val, &e->last_adv, &e->P, &e->Pint)) return -1;
     e->nl = n_layers;
     if (const char* am = getenv("DQN_ADAM_MODE")) e->adam_mode = atoi(am);
+    e->no_tiny = getenv("DQN_NO_TINY") != nullptr;
     if (const char* mg = getenv("DQN_MID_GROUP")) e->mid_group = atoi(mg);      // middle steps of dqn_train_steps per graph launch (1 = one step per graph)
     if (const char* sw = getenv("DQN_SIM_WORLD")) { const int k = atoi(sw); if (k >= 1 && !hp->recurrence) { e->sim_world = k; e->world = k; } }   // tests: one process plays k identical ranks
     dqn_layer_plan defp[DQN_MAX_LAYERS];
@@ -529,7 +530,7 @@ void enqueue_step(dqn_engine* e, bool sample, int phase) {
             // the descent is fused into the gather (every workgroup repeats it) while that is cheaper than a launch of its own:
             // small batches.  At B = 512 / 1e6 leaves the repeats cost more than the ~5 us launch, so sample once, then gather.
             const bool fused = sample && e->B <= 64 && !e->hp.sample_distinct;      // distinct indices: one workgroup draws AND dedupes, then the gather reads the list
-            if (e->step_take_pre) {}      // the previous step's Adam launch gathered this batch (PreGather)
+            if (e->step_take_pre || e->tiny) {}      // the previous step's Adam launch gathered this batch (PreGather) / the step's one launch gathers itself (tiny_step.hip)
             else {
             if (sample && !fused) RUN(e, "sample", launch_sample(e->stream, e->B, e->cap2, e->tree, e->hp.seed, e->idx, e->state, 0, e->hp.sample_distinct));    // k_td bumps the Philox counter
             BatchMeta bm; bm.a = e->ra; bm.r = e->rr; bm.done = e->rdone; bm.beta = e->hp.prio_beta; bm.a_out = e->gb_a2; bm.r_out = e->gb_r2; bm.done_out = e->gb_done2; bm.w_out = e->gb_w2;

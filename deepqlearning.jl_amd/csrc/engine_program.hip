@@ -55,6 +55,37 @@ int build_program(dqn_engine* e) {
     std::vector<std::vector<int>> levels; std::vector<int> val, adv;
     for (int i = 0; i < e->nl; i++) { if (e->L[i].stream == DQN_STREAM_BASE) levels.push_back({i}); else if (e->L[i].stream == DQN_STREAM_VAL) val.push_back(i); else adv.push_back(i); }
     for (size_t j = 0; j < std::max(val.size(), adv.size()); j++) { std::vector<int> lv; if (j < val.size()) lv.push_back(val[j]); if (j < adv.size()) lv.push_back(adv[j]); levels.push_back(lv); }
+    // ---------------- networks that fit in LDS: the WHOLE step is one single-workgroup launch (tiny_step.hip; BASELINE config 1)
+    e->tiny = false;
+    if (!rec && !e->comm && !e->sim_world && e->world <= 1 && e->hp.prioritized_replay && !e->hp.sample_distinct && Bb <= 64 && e->nl <= TINY_MAX_LAYERS &&
+        (int)levels.size() <= TINY_MAX_LAYERS && e->Pint <= 16384 && !e->no_tiny) {
+        bool ok = true; size_t fl = 0;
+        TinyArgs a; memset(&a, 0, sizeof a);
+        for (int i = 0; i < e->nl; i++) { const LayerDev& L = e->L[i]; ok = ok && L.kind == DQN_LAYER_DENSE && dqn_nchunks(L.N, L.dx_kc) == 1 && L.src < i; a.L[i] = L; }
+        auto take = [&](size_t n) { const int o = (int)fl; fl += (n + 3) / 4 * 4; return o; };
+        a.pon_off = take(e->Pint); a.ptg_off = take(e->Pint); a.g_off = take(e->Pint); a.x0_off = take((size_t)e->E * ld0); a.misc_off = take((size_t)B * 3 * e->nA);
+        for (int i = 0; i < e->nl; i++) { a.on_off[i] = take((size_t)e->L[i].N * ncon); a.tg_off[i] = take((size_t)e->L[i].N * B); a.d_off[i] = take((size_t)e->L[i].N * B); }
+        if (fl * 4 < 7808 + 64 * 4 + 1024) fl = (7808 + 64 * 4 + 1024) / 4;      // room for the priority block's path state (it reuses the whole region)
+        ok = ok && fl * 4 <= 60 * 1024;
+        if (ok) {
+            a.nl = e->nl; a.nlev = (int)levels.size(); a.B = B; a.nA = e->nA; a.E = e->E; a.ncon = ncon; a.dueling = e->hp.dueling; a.double_q = e->hp.double_q; a.obs_u8 = e->hp.obs_dtype == DQN_OBS_U8 ? 1 : 0;
+            a.last_base = e->last_base; a.last_val = e->last_val; a.last_adv = e->last_adv;
+            a.gamma = e->hp.gamma; a.beta = e->hp.prio_beta; a.prio_eps = e->hp.prio_eps; a.prio_alpha = e->hp.prio_alpha; a.cap2 = e->cap2; a.seed = e->hp.seed; a.P = e->Pint;
+            for (size_t li = 0; li < levels.size(); li++) { a.lev_n[li] = (int)levels[li].size(); a.lev_l[li][0] = levels[li][0]; a.lev_l[li][1] = levels[li].size() > 1 ? levels[li][1] : levels[li][0]; }
+            a.lds_bytes = (unsigned)(fl * 4);
+            a.p_tg = e->p_tg; a.p_on = e->p_on; a.m = e->m; a.v = e->v; a.grad = e->grad; a.state = e->state; a.gmax_part = e->gmax_part; a.tree = e->tree;
+            a.idx = e->idx; a.idx_pre = e->idx_pre; a.s_rows = e->s_rows; a.sp_rows = e->sp_rows; a.ra = e->ra; a.rr = e->rr; a.rdone = e->rdone;
+            a.x0 = e->x0; a.w_is = e->w_is; a.td = e->td; a.q_on_s = e->q_on_s; a.q_on_sp = e->q_on_sp; a.q_tg_sp = e->q_tg_sp; a.ytarget = e->ytarget; a.best = e->best;
+            a.f64mode = e->hp.adam_f64_scalars; a.lr = e->hp.learning_rate; a.b1 = e->hp.adam_beta1; a.b2 = e->hp.adam_beta2; a.adam_eps = e->hp.adam_eps;
+            const TinyArgs* a_dev = upload(e, std::vector<TinyArgs>(1, a)); const unsigned lds = a.lds_bytes;
+            e->prog.push_back({"tiny_step", [=](dqn_engine* en) { launch_tiny_step(en->stream, a_dev, lds, en->step_sampled ? 1 : 0); }});
+            e->tiny = true; e->arena_u8 = false; e->prio_forked = false; e->prio_in_bwd = false; e->dp_gather = false; e->dp_overlap = false; e->prog_pre1_end = 0;
+            e->prog_post_begin = e->prog.size(); e->final_reduce_step = -1; memset(&e->adam_segs, 0, sizeof e->adam_segs); e->gmax_used = 1;
+            for (int i = 0; i < e->nl; i++) e->L[i].xu8 = 0;
+            e->prog_built = true;
+            return 0;
+        }
+    }
     // ---------------- u8 replay: keep the observation arena in BYTES when its only consumers are the LDS-tiled forward and dW launches of ONE
     // first layer (they convert byte / 255 inside their tile loads): the gather writes 1 byte per element instead of 4 and the first layer reads
     // a quarter of the bytes.  Everything else (VALU / direct-MFMA fallbacks, heads fed by the observation, the operand all-gather) needs floats.

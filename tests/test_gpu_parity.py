@@ -4,6 +4,8 @@
   * the torch-autograd-pinned golden fixtures (tests/golden).
 Tolerances are the ones BASELINE.json's north_star states: TD loss and greedy action indices bit-exact,
 Q-values within 1e-5 fp32."""
+import os
+
 import numpy as np
 import pytest
 
@@ -25,11 +27,20 @@ def pkg():
     return p
 
 
-def make_pair(pkg, net, B, cap=128, mfma=1, graph=1, **kw):
+def make_pair(pkg, net, B, cap=128, mfma=1, graph=1, tiny=True, **kw):
+    """tiny=False: networks that fit in LDS take the multi-launch program instead of the single-launch step (tiny_step.hip; DQN_NO_TINY is read at
+    dqn_engine_create) -- both schedules of the same arithmetic stay under test"""
+    tiny = bool(kw.pop("_tiny", tiny))
     hp = ref.hparams_for(net, batch_size=B, buffer_size=cap, use_mfma=mfma, use_graph=graph, **kw)
     layers = ref.layers_from_network(net)
     plan = pkg.default_plan(layers, hp)
-    return pkg.Engine(layers, hp, plan=plan), ref.Twin(layers, hp, plan=plan, threads=8), hp
+    if not tiny:
+        os.environ["DQN_NO_TINY"] = "1"
+    try:
+        eng = pkg.Engine(layers, hp, plan=plan)
+    finally:
+        os.environ.pop("DQN_NO_TINY", None)
+    return eng, ref.Twin(layers, hp, plan=plan, threads=8), hp
 
 
 def fill(handles, net, n, seed=0, u8=False):
@@ -96,13 +107,14 @@ def test_sampler_inclusion_frequencies(pkg):
 @pytest.mark.parametrize("netf,B,kw", [
     (cfg1_mlp_dueling, 32, dict(gamma=0.95)),
     (mlp_tanh_net, 32, dict(gamma=0.99, double_q=0)),
+    (cfg1_mlp_dueling, 6, dict(gamma=0.9)),                               # B % 4 != 0: the scalar item loops of the single-launch step
     (small_conv_dueling, 16, dict(gamma=0.99)),
     (small_conv_plain, 8, dict(gamma=0.9, double_q=0, prioritized_replay=0)),
     (small_conv_dueling, 5, dict(gamma=0.99, adam_f64_scalars=0)),
 ])
 def test_multi_step_bit_exact_vs_twin(pkg, netf, B, kw, mfma):
     net = netf()
-    gpu, cpu, hp = make_pair(pkg, net, B, cap=100, mfma=mfma, learning_rate=1e-3, **kw)
+    gpu, cpu, hp = make_pair(pkg, net, B, cap=100, mfma=mfma, tiny=bool(mfma), learning_rate=1e-3, **kw)      # the MLPs: single-launch step (mfma=1) and multi-launch VALU program (mfma=0)
     fill((gpu, cpu), net, 137)  # > cap: exercises the ring wrap (mod1, ...replay.jl:70)
     set_same_params((gpu, cpu), net)
     np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
@@ -143,10 +155,12 @@ def test_adam_jobs_carried_by_backward_launches(pkg, monkeypatch, netf, B):
     (nature_dueling, 32, dict()),
     (nature_dueling, 32, dict(obs_dtype=1)),                              # u8 replay on the byte arena
     (small_conv_dueling, 16, dict()),
-    (cfg1_mlp_dueling, 32, dict(gamma=0.95)),
+    (cfg1_mlp_dueling, 32, dict(gamma=0.95)),                             # fits in LDS: the single-launch step (tiny_step.hip)
+    (cfg1_mlp_dueling, 32, dict(gamma=0.95, _tiny=0)),                    # ... and its multi-launch program
     (small_conv_plain, 8, dict(double_q=0, prioritized_replay=0)),       # not eligible for the pre-gather: must simply still be right
     (small_conv_dueling, 5, dict(adam_f64_scalars=0)),                    # ragged: 2B = 10 columns, E = 504 features (partial gather tiles)
-    (mlp_tanh_net, 24, dict(double_q=0)),                                 # plain network, VALU-only launches
+    (mlp_tanh_net, 24, dict(double_q=0, _tiny=0)),                        # plain network, VALU-only launches
+    (mlp_tanh_net, 24, dict(double_q=0)),                                 # ... and as ONE launch
     (small_conv_dueling, 16, dict(obs_dtype=1)),                          # u8 rows into the FLOAT arena: no pre-gather, still right
 ])
 def test_train_steps_pipelined_gather_bit_exact(pkg, netf, B, kw, graph):
@@ -154,6 +168,7 @@ def test_train_steps_pipelined_gather_bit_exact(pkg, netf, B, kw, graph):
     schedule of the same arithmetic: after train_steps(n) every piece of state equals the twin stepped n times one call at a time -- and single
     steps, replay writes and explicit-index steps in between must find nothing stale."""
     net = netf()
+    kw = dict(kw)
     gpu, cpu, hp = make_pair(pkg, net, B, cap=128, graph=graph, learning_rate=1e-3, **kw)
     u8 = kw.get("obs_dtype", 0) == 1
     fill((gpu, cpu), net, 100, seed=7, u8=u8)
@@ -192,7 +207,9 @@ def test_train_steps_pipelined_gather_bit_exact(pkg, netf, B, kw, graph):
     names = [n for n, _ in gpu.profile_step(steady=True)]
     cpu.train_step(); cpu.train_step()
     same_state()
-    if kw.get("prioritized_replay", 1) and (kw.get("obs_dtype", 0) == 0 or gpu.batch_arena_elem_bytes() == 1):
+    if names == ["tiny_step"]:
+        assert kw.get("_tiny", 1) and netf in (cfg1_mlp_dueling, mlp_tanh_net), names      # the whole step is one launch that samples and gathers itself
+    elif kw.get("prioritized_replay", 1) and (kw.get("obs_dtype", 0) == 0 or gpu.batch_arena_elem_bytes() == 1):
         assert "adam+gather" in names and not any(n in ("gather", "sample_gather") for n in names), names      # eligible: no gather launch of its own
     else:
         assert "sample_gather" in names and "adam+gather" not in names, names
