@@ -419,9 +419,12 @@ int build_program(dqn_engine* e) {
                 auto emit_dw1 = [&](const LayerDev V, const float* Xv, int ldv, const char* nm) {
                     const int S = dqn_nchunks(B, V.dw_kc);
                     float* part = S > 1 ? palloc(e, (size_t)S * (V.K + 1) * V.N) : nullptr; float* dst = S > 1 ? part : grad + V.w_off;
-                    if (mf && gemm_dw_eligible(V, B, ldv)) { struct A { const float* X[1]; const float* d[1]; float* o[1]; } a; a.X[0] = Xv; a.d[0] = dG; a.o[0] = dst;
+                    // small recurrent layers (config 4: (25+1) x 128 and (32+1) x 128 weights, 256 columns): the two dW contractions as VALU tasks of ONE launch
+                    // (15 us) beat two LDS-tiled MFMA launches of 13 us each (r03: 113.4 -> 102.7 us/step); the MFMA tiles win once the sample chains get long
+                    const bool small_dw = B <= 256 && (size_t)(V.K + 1) * V.N <= 16384 && !getenv("DQN_LSTM_DW_MFMA");
+                    if (mf && !small_dw && gemm_dw_eligible(V, B, ldv)) { struct A { const float* X[1]; const float* d[1]; float* o[1]; } a; a.X[0] = Xv; a.d[0] = dG; a.o[0] = dst;
                         e->prog.push_back({nm, [=](dqn_engine* en) { launch_gemm_dw(en->stream, V, 1, a.X, ldv, a.d, B, a.o); }}); }
-                    else if (mf && mfma_dw_ok(V, B)) e->prog.push_back({nm, [=](dqn_engine* en) { launch_mfma_dw(en->stream, V, Xv, ldv, dG, B, grad, part, false); }});
+                    else if (mf && !small_dw && mfma_dw_ok(V, B)) e->prog.push_back({nm, [=](dqn_engine* en) { launch_mfma_dw(en->stream, V, Xv, ldv, dG, B, grad, part, false); }});
                     else { VTask t; memset(&t, 0, sizeof t); t.kind = 1; t.L = V; t.X = Xv; t.ldx = ldv; t.dpre = dG; t.B = B; t.S = S; t.kc = dqn_chunk_len(B, V.dw_kc); t.out = dst; add_valu(e, pend, t); }
                     if (S > 1) { RSeg r; memset(&r, 0, sizeof r); r.part = part; r.S = S; r.elems = (unsigned long long)(V.K + 1) * V.N; r.mode = 2; r.out = grad + V.w_off; final_segs.push_back(r); }
                 };

@@ -16,6 +16,7 @@ ap.add_argument("--steps", type=int, default=500)
 ap.add_argument("--hidden", type=int, default=32)
 ap.add_argument("--trace", type=int, default=8)
 ap.add_argument("--profile", action="store_true")
+ap.add_argument("--no-mfma", action="store_true")
 args = ap.parse_args()
 pkg = ge.load_package()
 nn = importlib.import_module(pkg.__name__ + ".nn")
@@ -24,7 +25,7 @@ S = importlib.import_module(pkg.__name__ + ".solver")
 model = nn.Chain(nn.flattenbatch, nn.LSTM(25, args.hidden), nn.Dense(args.hidden, 4))
 layers, _ = nn.lower(model)
 hp = pkg.default_hparams(batch_size=32, n_actions=4, obs_c=1, obs_h=5, obs_w=5, gamma=0.99, double_q=1, dueling=0, prioritized_replay=0,
-                         buffer_size=1000, recurrence=1, trace_length=args.trace, learning_rate=1e-3)
+                         buffer_size=1000, recurrence=1, trace_length=args.trace, learning_rate=1e-3, use_mfma=0 if args.no_mfma else 1)
 eng = pkg.Engine(layers, hp)
 eng.set_params(nn.glorot_params(model, seed=1), pkg.NET_ONLINE)
 eng.sync_target()
