@@ -102,7 +102,10 @@ template <int NT> struct FwdCfg { static constexpr int NW = 16 * NT; static cons
 
 // XU8: the A operand is the BYTE observation arena (u8 replay): a lane fetches 4 bytes = 4 columns and converts them (byte / 255f0, exactly) on
 // the way into the LDS tile -- a quarter of the operand bytes of the float arena, and the gather wrote a quarter as well
-template <int NT, bool XU8 = false, int KT = F_KT_DEF>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// M32 (NT == 4 only; experiment, DQN_FWD_M32=1): the 64-column x 64-channel tile as 2 x 2 blocks of v_mfma_f32_32x32x2_f32, one per wave, instead of four
+// 16x16x4 accumulators per wave -- 32 instead of 40 fragment reads and 16 instead of 32 MFMA instructions per wave and K tile
+template <int NT, bool XU8 = false, int KT = F_KT_DEF, bool M32 = false>
 __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S, int kc) {
     constexpr int NW = FwdCfg<NT>::NW, SB = FwdCfg<NT>::SB, F_KT = KT;
     using AT = std::conditional_t<XU8, uint32_t, f32x4>;
@@ -229,6 +232,59 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
 #pragma unroll
             for (int t = 0; t < NT; t++) acc[t] = MFMA(f.a[st], f.b[st][t], acc[t]);
     };
+    if constexpr (M32) {
+        static_assert(NT == 4 || !M32, "M32 needs the 64-channel tile");
+        const int wm = wave & 1, wn = wave >> 1, l31 = lane & 31, kh = lane >> 5;
+        constexpr int NS = F_KT / 2;                   // 32x32x2 steps per K tile
+        struct F32 { float a[NS], b[NS]; };
+        auto fread32 = [&](int buf, F32& f) {
+            const float* Ab = As + (buf * F_KT + kh) * F_SA + 32 * wm + l31;
+            const float* Bb = Bs + (buf * F_KT + kh) * SB + 32 * wn + l31;
+#pragma unroll
+            for (int st = 0; st < NS; st++) { f.a[st] = Ab[2 * st * F_SA]; f.b[st] = Bb[2 * st * SB]; }
+        };
+        f32x16 c16;
+#pragma unroll
+        for (int i = 0; i < 16; i++) c16[i] = 0.0f;
+        auto mma32 = [&](const F32& f, int s0, int s1) {
+#pragma unroll
+            for (int st = s0; st < s1; st++) c16 = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[st], f.b[st], c16, 0, 0, 0);
+        };
+        Stage r0, r1; F32 g0, g1;
+        gload(0, r0); STAGE_WAIT(0, r0); lstore(0, r0); __syncthreads();
+        fread32(0, g0);
+        gload(1, r0);
+        for (int kt = 0; kt < nkt; kt += 2) {
+            gload(kt + 2, r1);
+            mma32(g0, 0, NS / 2);
+            STAGE_WAIT(LPS, r0); lstore(1, r0);
+            __syncthreads();
+            if (kt + 1 < nkt) fread32(1, g1);
+            mma32(g0, NS / 2, NS);
+            gload(kt + 3, r0);
+            if (kt + 1 < nkt) mma32(g1, 0, NS / 2);
+            STAGE_WAIT(LPS, r1); lstore(0, r1);
+            __syncthreads();
+            if (kt + 2 < nkt) fread32(0, g0);
+            if (kt + 1 < nkt) mma32(g1, NS / 2, NS);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // epilogue: lane = channel n0 + 32 wn + l31; register 4g + r = column 32 wm + 8g + 4 kh + r of the workgroup's 64
+        const int n = n0 + 32 * wn + l31;
+        const float bias = S == 1 ? p.bias[n] : 0.0f;
+        const size_t per_s = (size_t)L.N * L.npos * p.ncols;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int cc = 32 * wm + 8 * g + 4 * kh;       // first of 4 consecutive columns, inside M-tile cc >> 4
+            const int mt = mgrp * 4 + (cc >> 4);
+            if (mt >= p.mtiles) continue;
+            const int pos = mt / ctiles, ct = mt % ctiles;
+            f32x4 v = {c16[4 * g], c16[4 * g + 1], c16[4 * g + 2], c16[4 * g + 3]};
+            if (S == 1) { v.x = act_f(v.x + bias, L.act); v.y = act_f(v.y + bias, L.act); v.z = act_f(v.z + bias, L.act); v.w = act_f(v.w + bias, L.act); }
+            *reinterpret_cast<f32x4*>(p.out + (size_t)s * per_s + ((size_t)n * L.npos + pos) * p.ncols + ct * 16 + (cc & 15)) = v;
+        }
+        return;
+    }
     constexpr int HS = F_KT / 8;                       // MFMA steps per half tile
     Stage r0, r1; Frag f0, f1;
     gload(0, r0); STAGE_WAIT(0, r0); lstore(0, r0); __syncthreads();
@@ -270,6 +326,8 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     KTRACE(7); KTRACE_END();
 }
 
+static int g_fwd_m32 = 0;
+void gemm_set_fwd_m32(int on) { g_fwd_m32 = on; }
 static int fwd_pick_nt(const LayerDev& L, long mgroups_total, int S) {
     // widest N tile (most reuse of the im2col'd A tile) that still yields >= ~400 workgroups.  Dense layers at B=32 stream
     // their weights once whatever the tile, so they too prefer more, narrower workgroups (measured: FC1 forward 19.2 -> 16.3 us
@@ -319,7 +377,9 @@ void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* 
     const size_t lds = (size_t)(2 * kt * F_SA + 2 * kt * SB) * 4 + (L.kind == DQN_LAYER_CONV ? (size_t)L.K * 4 : 0);
 #define FWD_LAUNCH(NT_, U8_, KT_) hipLaunchKernelGGL((k_fwd_lds<NT_, U8_, KT_>), dim3(end), dim3(256), lds, st, L, pr, S, kc)
 #define FWD_PICK(U8_, KT_) do { if (NT == 4) FWD_LAUNCH(4, U8_, KT_); else if (NT == 2) FWD_LAUNCH(2, U8_, KT_); else FWD_LAUNCH(1, U8_, KT_); } while (0)
-    if (L.xu8) { if (k16) FWD_PICK(true, 16); else FWD_PICK(true, F_KT_DEF); }
+    const int m32 = g_fwd_m32;      // experiment (DQN_FWD_M32=1 at dqn_engine_create): 32x32x2 MFMA blocks for the 64-channel tiles
+    if (m32 && NT == 4 && !L.xu8) { if (k16) hipLaunchKernelGGL((k_fwd_lds<4, false, 16, true>), dim3(end), dim3(256), lds, st, L, pr, S, kc); else hipLaunchKernelGGL((k_fwd_lds<4, false, F_KT_DEF, true>), dim3(end), dim3(256), lds, st, L, pr, S, kc); }
+    else if (L.xu8) { if (k16) FWD_PICK(true, 16); else FWD_PICK(true, F_KT_DEF); }
     else { if (k16) FWD_PICK(false, 16); else FWD_PICK(false, F_KT_DEF); }
 #undef FWD_PICK
 #undef FWD_LAUNCH
