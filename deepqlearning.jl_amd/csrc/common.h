@@ -569,6 +569,7 @@ void launch_convert_params(hipStream_t st, const LayerDev* layers_dev, int nl, c
 // LDS-tiled MFMA path (nn_gemm.hip): up to two problems (online / target net) of one layer per launch
 bool gemm_fwd_eligible(const LayerDev& L, int nprob, const int* ldx, const int* col0, const int* ncols);
 int gemm_set_ktrace(unsigned long long* p);   // debug (-DDQN_KTRACE builds): per-workgroup timestamps of the LDS-tiled kernels (nullptr = off); -1 = not a trace build
+void gemm_set_fwd_dma(int on);      // DQN_FWD_DMA: LDS-DMA operand loads for the large forward launches with 64-channel tiles (experiment)
 void gemm_set_fwd_m32(int on);      // process-wide experiment switch, set from DQN_FWD_M32 at dqn_engine_create (nn_gemm.hip, k_fwd_lds<.., M32>)
 void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* const* W, const float* const* bias, const float* const* X,
                      const int* ldx, const int* col0, const int* ncols, float* const* out /* Y, or split-K partial slabs */);

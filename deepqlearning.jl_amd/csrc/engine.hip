@@ -179,6 +179,7 @@ static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers
     if (const char* am = getenv("DQN_ADAM_MODE")) e->adam_mode = atoi(am);
     e->no_tiny = getenv("DQN_NO_TINY") != nullptr;
     gemm_set_fwd_m32(getenv("DQN_FWD_M32") ? atoi(getenv("DQN_FWD_M32")) : 0);
+    gemm_set_fwd_dma(getenv("DQN_FWD_DMA") ? atoi(getenv("DQN_FWD_DMA")) : 0);
     if (const char* mg = getenv("DQN_MID_GROUP")) e->mid_group = atoi(mg);      // middle steps of dqn_train_steps per graph launch (1 = one step per graph)
     if (const char* sw = getenv("DQN_SIM_WORLD")) { const int k = atoi(sw); if (k >= 1 && !hp->recurrence) { e->sim_world = k; e->world = k; } }   // tests: one process plays k identical ranks
     dqn_layer_plan defp[DQN_MAX_LAYERS];
