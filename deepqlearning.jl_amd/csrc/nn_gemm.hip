@@ -439,7 +439,8 @@ static int fwd_pick_nt(const LayerDev& L, long mgroups_total, int S) {
         const int nt = cands[c];
         if (L.N % (16 * nt)) continue;
         const long wgs = mgroups_total * (L.N / (16 * nt)) * S;
-        if (wgs >= 400) return nt;
+        static const long min_wgs = getenv("DQN_FWD_MIN_WGS") ? atol(getenv("DQN_FWD_MIN_WGS")) : 400;      // experiment knob
+        if (wgs >= min_wgs) return nt;
         if (wgs > best_wgs) { best_wgs = wgs; best = nt; }
     }
     return best;
