@@ -66,7 +66,7 @@ int build_program(dqn_engine* e) {
         a.pon_off = take(e->Pint); a.ptg_off = take(e->Pint); a.g_off = take(e->Pint); a.x0_off = take((size_t)e->E * ld0); a.misc_off = take((size_t)B * 3 * e->nA);
         for (int i = 0; i < e->nl; i++) { a.on_off[i] = take((size_t)e->L[i].N * ncon); a.tg_off[i] = take((size_t)e->L[i].N * B); a.d_off[i] = take((size_t)e->L[i].N * B); }
         if (fl * 4 < 7808 + 64 * 4 + 1024) fl = (7808 + 64 * 4 + 1024) / 4;      // room for the priority block's path state (it reuses the whole region)
-        ok = ok && fl * 4 <= 60 * 1024;
+        ok = ok && fl * 4 <= 144 * 1024;      // one workgroup may hold up to 160 KB of LDS on gfx950 (beyond 64 KB the launcher raises the function's dynamic-LDS limit)
         if (ok) {
             a.nl = e->nl; a.nlev = (int)levels.size(); a.B = B; a.nA = e->nA; a.E = e->E; a.ncon = ncon; a.dueling = e->hp.dueling; a.double_q = e->hp.double_q; a.obs_u8 = e->hp.obs_dtype == DQN_OBS_U8 ? 1 : 0;
             a.last_base = e->last_base; a.last_val = e->last_val; a.last_adv = e->last_adv;

@@ -375,5 +375,7 @@ __global__ __launch_bounds__(NTH) void k_tiny_step(const TinyArgs* __restrict__ 
 }
 void launch_tiny_step(hipStream_t st, const TinyArgs* a_dev, unsigned lds_bytes, int sample) {
     static const int stop = getenv("DQN_TINY_STOP") ? atoi(getenv("DQN_TINY_STOP")) : 0;      // timing probe: return after phase n (wrong numbers, right schedule)
+    static unsigned lds_attr = 0;      // dynamic LDS beyond 64 KB has to be requested per function
+    if (lds_bytes > 64 * 1024 && lds_bytes > lds_attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tiny_step<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); lds_attr = lds_bytes; }
     hipLaunchKernelGGL((k_tiny_step<1024>), dim3(1), dim3(1024), lds_bytes, st, a_dev, sample, stop);
 }

@@ -328,6 +328,30 @@ def test_wide_sample_dx_tiles_bit_exact(pkg, netf, B):
     np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
 
 
+@pytest.mark.parametrize("netf,B,cap,kw", [
+    (cfg1_mlp_dueling, 8, 40, dict()),                    # sum-tree of 64 leaves: the priority block's general (two-phase) form inside the 1024-thread workgroup
+    (cfg1_mlp_dueling, 4, 20, dict(double_q=0)),          # 32 leaves, no online Q(sp) columns
+    (mlp_tanh_net, 12, 50, dict(obs_dtype=1)),            # u8 rows converted in the kernel's own gather
+    (cfg1_mlp_dueling, 64, 5000, dict()),                 # the largest batch the single-launch step takes
+])
+def test_single_launch_step_edge_cases(pkg, netf, B, cap, kw):
+    """tiny_step.hip at the corners of its eligibility: tiny replay capacities, batches that are not multiples of 4 x 8, byte observations, B = 64; single
+    steps and dqn_train_steps(n) against the twin, priorities included."""
+    net = netf()
+    gpu, cpu, hp = make_pair(pkg, net, B, cap=cap, learning_rate=1e-3, **kw)
+    fill((gpu, cpu), net, cap + 7, seed=3, u8=kw.get("obs_dtype", 0) == 1)
+    set_same_params((gpu, cpu), net, seed=4)
+    for _ in range(4):
+        assert_step_bit_exact(gpu, cpu)
+    lg = gpu.train_steps(6)
+    for _ in range(6):
+        lc = cpu.train_step()
+    assert lg[0] == lc[0] and lg[1] == lc[1]
+    np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
+    np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+    assert [n for n, _ in gpu.profile_step()] == ["tiny_step"]
+
+
 @pytest.mark.parametrize("knob", ["DQN_FWD_M32", "DQN_FWD_DMA"])
 def test_forward_32x32_mfma_blocks_bit_exact(pkg, monkeypatch, knob):
     """DQN_FWD_M32=1 (read at dqn_engine_create): the forward launches with 64-channel tiles use 2 x 2 blocks of v_mfma_f32_32x32x2_f32 per workgroup instead of
