@@ -58,7 +58,7 @@ int build_program(dqn_engine* e) {
     // ---------------- networks that fit in LDS: the WHOLE step is one single-workgroup launch (tiny_step.hip; BASELINE config 1)
     e->tiny = false;
     if (!rec && !e->comm && !e->sim_world && e->world <= 1 && e->hp.prioritized_replay && !e->hp.sample_distinct && Bb <= 64 && e->nl <= TINY_MAX_LAYERS &&
-        (int)levels.size() <= TINY_MAX_LAYERS && e->Pint <= 16384 && !e->no_tiny) {
+        (int)levels.size() <= TINY_MAX_LAYERS && e->Pint <= 16384 && (size_t)e->Pint * B <= 262144 /* ~5 MACs per parameter and column on ONE CU: <= ~9 us of arithmetic */ && !e->no_tiny) {
         bool ok = true; size_t fl = 0;
         TinyArgs a; memset(&a, 0, sizeof a);
         for (int i = 0; i < e->nl; i++) { const LayerDev& L = e->L[i]; ok = ok && L.kind == DQN_LAYER_DENSE && dqn_nchunks(L.N, L.dx_kc) == 1 && L.src < i; a.L[i] = L; }
