@@ -20,3 +20,13 @@ for n, (u, c) in zip(ns, us): print(f"train_steps({n:3d}): {u:9.1f} us = {u / n:
 A = np.vstack([np.array(ns[6:], float), np.ones(len(ns) - 6)]).T
 slope, icpt = np.linalg.lstsq(A, np.array([u for u, _ in us[6:]]), rcond=None)[0]
 print(f"fit over n >= 10: {slope:.2f} us/step + {icpt:.1f} us per call   (HSA_ENABLE_INTERRUPT={os.environ.get('HSA_ENABLE_INTERRUPT', 'unset')})")
+# where the per-call cost sits: the same calls without fetching the scalars (null loss / grad_norm pointers: no fold launch, no D2H copy, no sync inside)
+import ctypes as C
+def t0(n, reps=30):
+    v = []
+    for _ in range(reps):
+        eng.sync(); a = time.perf_counter(); eng._check(eng.f["train_steps"](eng._h, n, None, None)); eng.sync(); v.append(time.perf_counter() - a)
+    v.sort(); return v[len(v) // 2] * 1e6
+us0 = [t0(n) for n in ns[6:]]
+s0, i0 = np.linalg.lstsq(A, np.array(us0), rcond=None)[0]
+print(f"without the scalar fetch: {s0:.2f} us/step + {i0:.1f} us per call")
