@@ -181,6 +181,7 @@ static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers
     gemm_set_fwd_m32(getenv("DQN_FWD_M32") ? atoi(getenv("DQN_FWD_M32")) : 0);
     gemm_set_fwd_dma(getenv("DQN_FWD_DMA") ? atoi(getenv("DQN_FWD_DMA")) : 0);
     if (const char* mg = getenv("DQN_MID_GROUP")) e->mid_group = atoi(mg);      // middle steps of dqn_train_steps per graph launch (1 = one step per graph)
+    if (const char* mb = getenv("DQN_MID_BIG")) e->mid_big = atoi(mb);
     if (const char* sw = getenv("DQN_SIM_WORLD")) { const int k = atoi(sw); if (k >= 1 && !hp->recurrence) { e->sim_world = k; e->world = k; } }   // tests: one process plays k identical ranks
     dqn_layer_plan defp[DQN_MAX_LAYERS];
     if (!plan) { default_plan(e->L, e->nl, e->B, defp); plan = defp; }
@@ -263,6 +264,7 @@ void drop_graphs(dqn_engine* e) {
     if (e->g_post) { hipGraphExecDestroy(e->g_post); e->g_post = nullptr; }
     if (e->g_post_pg) { hipGraphExecDestroy(e->g_post_pg); e->g_post_pg = nullptr; }
     if (e->g_mid) { hipGraphExecDestroy(e->g_mid); e->g_mid = nullptr; }
+    if (e->g_mid_big) { hipGraphExecDestroy(e->g_mid_big); e->g_mid_big = nullptr; }
     if (e->g_pre_tp) { hipGraphExecDestroy(e->g_pre_tp); e->g_pre_tp = nullptr; }
     for (int i = 0; i < 3; i++) if (e->g_pre1[i]) { hipGraphExecDestroy(e->g_pre1[i]); e->g_pre1[i] = nullptr; }
     for (int i = 0; i < 4; i++) if (e->g_dp_one[i]) { hipGraphExecDestroy(e->g_dp_one[i]); e->g_dp_one[i] = nullptr; }
@@ -751,9 +753,15 @@ extern "C" int dqn_train_steps(dqn_engine_t* e, int n, float* loss, float* grad_
                                                                          e->step_take_pre = e->step_pregather = false; return rc; };
         if (pg) { if (cap1(false, true, &e->g_pgv[0][1], 1) || cap1(true, true, &e->g_pgv[1][1], 1) || cap1(true, false, &e->g_pgv[1][0], 1)) return -1; }
         if (MID_GROUP > 1 && cap1(pg, pg, &e->g_mid, MID_GROUP)) return -1;
+        if (e->mid_big > MID_GROUP && cap1(pg, pg, &e->g_mid_big, e->mid_big)) return -1;
     }
     for (int i = 0; i < n;) {
         // a run of identical steps: middle steps (pipelined gather) or, where that does not apply, any steps
+        const int BIG = e->mid_big;
+        if (single && BIG > MID_GROUP && e->g_mid_big && (pg ? (i >= 1 && i + BIG <= n - 1) : (i + BIG <= n))) {
+            HIPCHK(hipGraphLaunch(e->g_mid_big, e->stream));
+            i += BIG; continue;
+        }
         if (single && MID_GROUP > 1 && (pg ? (i >= 1 && i + MID_GROUP <= n - 1) : (i + MID_GROUP <= n))) {
             HIPCHK(hipGraphLaunch(e->g_mid, e->stream));
             i += MID_GROUP; continue;
