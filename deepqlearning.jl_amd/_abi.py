@@ -360,8 +360,9 @@ class Handle:
 
     # ---- DRQN
     def episode_add(self, s, a, r, sp, done):
-        s = self._obs_rows(s, "episode_add")
-        sp = self._obs_rows(sp, "episode_add")
+        # the episode replay always stores Float32 rows (dqn_episode_add copies E*4 bytes per observation; recurrence with a u8 replay is refused at creation)
+        s = _as(s, np.float32).reshape(-1, self.obs_elems)
+        sp = _as(sp, np.float32).reshape(-1, self.obs_elems)
         n = s.shape[0]
         a, r, done = _as(np.atleast_1d(a), np.int32), _as(np.atleast_1d(r), np.float32), _as(np.atleast_1d(done), np.uint8)
         self._check(self.f["episode_add"](self._h, s.ctypes.data_as(_vp), _ptr(a, _i32p), _ptr(r, _f32p), sp.ctypes.data_as(_vp), _ptr(done, _u8p), n))
@@ -392,6 +393,28 @@ class Handle:
 
     def reset_state(self):
         self._check(self.f["reset_state"](self._h))
+
+    def hidden_size(self, streams=1):
+        """floats in the flat Recur state: per LSTM layer h then c, each [out][streams] (src/helpers.jl:61-63)"""
+        return sum(2 * int(l.n_out) * streams for l in self.layers[:self.n_layers] if l.kind == LAYER_LSTM)
+
+    def get_hidden(self, streams=1):
+        """hiddenstates(m) (src/helpers.jl:61-63): list of (h, c) per LSTM layer, each [out, streams]"""
+        buf = np.empty(self.hidden_size(streams), np.float32)
+        self._check(self.f["get_hidden"](self._h, _ptr(buf, _f32p), buf.size))
+        out, off = [], 0
+        for l in self.layers[:self.n_layers]:
+            if l.kind == LAYER_LSTM:
+                m = int(l.n_out) * streams
+                out.append((buf[off:off + m].reshape(int(l.n_out), streams).copy(), buf[off + m:off + 2 * m].reshape(int(l.n_out), streams).copy()))
+                off += 2 * m
+        return out
+
+    def set_hidden(self, hs):
+        """sethiddenstates!(m, hs) (src/helpers.jl:71-79)"""
+        buf = np.concatenate([np.concatenate([_as(h, np.float32).ravel(), _as(c, np.float32).ravel()]) for h, c in hs]) if hs else np.empty(0, np.float32)
+        buf = np.ascontiguousarray(buf, np.float32)
+        self._check(self.f["set_hidden"](self._h, _ptr(buf, _f32p), buf.size))
 
     # ---- vectorised environments on the device (SURVEY.md 8f-1)
     def envs_create(self, env, n_envs=None, max_episode_length=100, seed=0):

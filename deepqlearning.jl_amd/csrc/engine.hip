@@ -208,6 +208,7 @@ static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers
     const int B = e->B;
     e->T = hp->recurrence ? hp->trace_length : 1;
     if (hp->recurrence && (e->T < 1 || (long long)e->T * B > 65536)) return fail("trace_length %d unsupported", e->T);
+    if (hp->recurrence && hp->obs_dtype == DQN_OBS_U8) return fail("DeepQLearningError: obs_dtype = u8 is not supported with recurrence = true (the episode replay stores Float32 rows, src/episode_replay.jl:3-20)");
     const int Bc = e->Bc = e->T * B;            // columns per sequence set: B, or T*B time-major columns for DRQN
     e->ncon = hp->double_q ? 2 * Bc : Bc;
     DM(e->L_dev, e->nl); HIPCHK(hipMemcpy(e->L_dev, e->L, sizeof(LayerDev) * e->nl, hipMemcpyHostToDevice));

@@ -134,6 +134,7 @@ extern "C" int dqn_reset_state(dqn_engine_t* e) { if (!e) return fail("null engi
 }
 extern "C" int dqn_get_hidden(dqn_engine_t* e, float* hc, size_t n) { if (!e) return fail("null engine handle");   // hiddenstates(m) (src/helpers.jl:61-63): per LSTM layer h then c, [out][streams]
     HIPCHK(hipSetDevice(e->device)); size_t off = 0;
+    if (e->hp.recurrence && e->pol_state_n == 0 && policy_state(e, 1, true)) return -1;      // no forward yet: one stream at state0
     for (int i = 0; i < e->nl; i++) if (e->L[i].kind == DQN_LAYER_LSTM) {
         const size_t m = (size_t)e->L[i].H * e->pol_state_n; if (off + 2 * m > n) return fail("get_hidden: buffer too small");
         HIPCHK(hipMemcpyAsync(hc + off, e->pol_h[i][e->pol_flip], m * 4, hipMemcpyDeviceToHost, e->stream)); off += m;
@@ -143,6 +144,7 @@ extern "C" int dqn_get_hidden(dqn_engine_t* e, float* hc, size_t n) { if (!e) re
 }
 extern "C" int dqn_set_hidden(dqn_engine_t* e, const float* hc, size_t n) { if (!e) return fail("null engine handle");   // sethiddenstates!(m, hs) (src/helpers.jl:71-79)
     HIPCHK(hipSetDevice(e->device)); size_t off = 0;
+    if (e->hp.recurrence && e->pol_state_n == 0 && policy_state(e, 1, true)) return -1;
     for (int i = 0; i < e->nl; i++) if (e->L[i].kind == DQN_LAYER_LSTM) {
         const size_t m = (size_t)e->L[i].H * e->pol_state_n; if (off + 2 * m > n) return fail("set_hidden: buffer too small");
         HIPCHK(hipMemcpyAsync(e->pol_h[i][e->pol_flip], hc + off, m * 4, hipMemcpyHostToDevice, e->stream)); off += m;

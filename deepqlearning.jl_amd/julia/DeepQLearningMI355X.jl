@@ -85,8 +85,10 @@ mutable struct Engine
     B::Int; nA::Int; obs_dims::Tuple
     obs_u8::Bool      # replay rows are BYTES (hp.obs_dtype = DQN_OBS_U8): training reads byte / 255f0 (test/test_env.jl:59)
 end
-# observation rows in the replay's storage type.  dqn_replay_add / dqn_episode_add read the void* as bytes for a u8 replay: a Float32 buffer there
-# would be cut to its first E bytes, so only UInt8 arrays are accepted (the Python mirror's _obs_rows does the same)
+# observation rows in the replay's storage type.  dqn_replay_add reads the void* as bytes for a u8 replay: a Float32 buffer there
+# would be cut to its first E bytes, so only UInt8 arrays are accepted (the Python mirror's _obs_rows does the same).  The EPISODE replay
+# always stores Float32 rows (dqn_episode_add copies E*4 bytes per observation): dqn_engine_create refuses recurrence with obs_u8, so
+# obs_rows never returns bytes for a HIPEpisodeReplayBuffer.
 function obs_rows(e::Engine, x, what)
     e.obs_u8 || return Float32.(vec(x))
     eltype(x) == UInt8 || error("$what: this replay stores UInt8 observations (obs_u8 = true); got $(eltype(x)) -- pass the raw bytes")

@@ -163,6 +163,7 @@ int ref_plan_default(const dqn_layer_desc* d, int n, const dqn_hparams* hp, dqn_
 /* ---------------------------------------------------------------- create */
 int ref_create(const dqn_layer_desc* d, int n, const dqn_hparams* hp, const dqn_layer_plan* plan, ref_engine** out) {
     if (n <= 0 || n > MAXL) FAIL("bad layer count %d", n);
+    if (hp->recurrence && hp->obs_dtype == DQN_OBS_U8) FAIL("DeepQLearningError: obs_dtype = u8 is not supported with recurrence = true (the episode replay stores Float32 rows, src/episode_replay.jl:3-20)");
     ref_engine* e = (ref_engine*)calloc(1, sizeof *e);
     e->nl = n; e->hp = *hp; e->B = hp->batch_size; e->nA = hp->n_actions;
     e->obs_elems = hp->obs_c * hp->obs_h * hp->obs_w;
@@ -688,6 +689,26 @@ static void policy_state(ref_engine* e, int n, int force_reset) {
     }
 }
 int ref_reset_state(ref_engine* e) { policy_state(e, e->pol_n > 0 ? e->pol_n : 1, 1); return 0; }      /* resetstate!(policy) */
+/* hiddenstates(m) / sethiddenstates!(m, hs) (src/helpers.jl:61-79; used around batch_train!, src/solver.jl:137-139): per LSTM layer h then c,
+   each [out][streams]; the same flat layout as dqn_get_hidden / dqn_set_hidden */
+int ref_get_hidden(ref_engine* e, float* hc, size_t n) {
+    if (e->hp.recurrence && e->pol_n == 0) policy_state(e, 1, 1);
+    size_t off = 0;
+    for (int i = 0; i < e->nl; i++) if (e->L[i].kind == DQN_LAYER_LSTM) {
+        const size_t m = (size_t)e->L[i].H * e->pol_n; if (off + 2 * m > n) FAIL("get_hidden: buffer too small");
+        memcpy(hc + off, e->pol_h[i], m * 4); off += m; memcpy(hc + off, e->pol_c[i], m * 4); off += m;
+    }
+    return 0;
+}
+int ref_set_hidden(ref_engine* e, const float* hc, size_t n) {
+    if (e->hp.recurrence && e->pol_n == 0) policy_state(e, 1, 1);
+    size_t off = 0;
+    for (int i = 0; i < e->nl; i++) if (e->L[i].kind == DQN_LAYER_LSTM) {
+        const size_t m = (size_t)e->L[i].H * e->pol_n; if (off + 2 * m > n) FAIL("set_hidden: buffer too small");
+        memcpy(e->pol_h[i], hc + off, m * 4); off += m; memcpy(e->pol_c[i], hc + off, m * 4); off += m;
+    }
+    return 0;
+}
 int ref_forward(ref_engine* e, int which, const float* obs, int n, float* q_out) {
     const float* P = which == DQN_NET_TARGET ? e->p_tg : e->p_on; int E = e->obs_elems;
     float* x = (float*)malloc((size_t)E * n * 4); float* act[MAXL];
@@ -736,6 +757,33 @@ int ref_greedy_action(ref_engine* e, const float* obs, int n, int32_t* a_out) {
 static inline float sigm_f(float x) { return (float)(1.0 / (1.0 + exp(-(double)x))); }
 static inline float tanh_f(float x) { return (float)tanh((double)x); }
 
+/* checkpoint seam of the episode replay (the twin of dqn_episode_export / dqn_episode_import): episodes as [n][T] slots + their true lengths */
+int ref_episode_export(ref_engine* e, int64_t first, int64_t n, float* s, float* sp, int32_t* a, float* r, uint8_t* done, int32_t* len) {
+    if (!e->hp.recurrence) FAIL("this engine was created with recurrence = false");
+    if (first < 0 || n < 0 || first + n > e->ep_size) FAIL("BoundsError: episodes %lld..%lld outside 0..%lld", (long long)first, (long long)(first + n - 1), (long long)e->ep_size - 1);
+    const size_t T = (size_t)e->T, E = (size_t)e->obs_elems, off = (size_t)first * T, cnt = (size_t)n * T;
+    if (s) memcpy(s, e->ep_s + off * E, cnt * E * 4);
+    if (sp) memcpy(sp, e->ep_sp + off * E, cnt * E * 4);
+    if (a) memcpy(a, e->ep_a + off, cnt * 4);
+    if (r) memcpy(r, e->ep_r + off, cnt * 4);
+    if (done) memcpy(done, e->ep_done + off, cnt);
+    if (len) memcpy(len, e->ep_len + first, (size_t)n * 4);
+    return 0;
+}
+int ref_episode_import(ref_engine* e, int64_t n, const float* s, const float* sp, const int32_t* a, const float* r, const uint8_t* done, const int32_t* len) {
+    if (!e->hp.recurrence) FAIL("this engine was created with recurrence = false");
+    if (n < 0 || n > e->ep_cap) FAIL("import of %lld episodes into an episode replay of capacity %lld", (long long)n, (long long)e->ep_cap);
+    const size_t T = (size_t)e->T, E = (size_t)e->obs_elems, cnt = (size_t)n * T;
+    for (int64_t i = 0; i < n; i++) {
+        if (len[i] < 1) FAIL("episode %lld: length %d < 1", (long long)i, len[i]);
+        const int m = len[i] < e->T ? len[i] : e->T;
+        for (int t = 0; t < m; t++) if (a[(size_t)i * T + t] < 0 || a[(size_t)i * T + t] >= e->nA) FAIL("action index %d out of range 0..%d", a[(size_t)i * T + t], e->nA - 1);
+    }
+    memcpy(e->ep_s, s, cnt * E * 4); memcpy(e->ep_sp, sp, cnt * E * 4); memcpy(e->ep_a, a, cnt * 4); memcpy(e->ep_r, r, cnt * 4); memcpy(e->ep_done, done, cnt);
+    memcpy(e->ep_len, len, (size_t)n * 4);
+    e->ep_size = n; e->ep_widx = n % e->ep_cap; e->ep_cur_len = 0;
+    return 0;
+}
 int ref_episode_count(ref_engine* e, int64_t* cur, int64_t* cap) { if (cur) *cur = e->ep_size; if (cap) *cap = e->ep_cap; return 0; }
 int ref_episode_commit(ref_engine* e) {          /* add_episode! (:54-60) */
     if (!e->hp.recurrence) FAIL("engine was created with recurrence = false");

@@ -104,7 +104,19 @@ def make_case(name, net, B, seed, gamma, double_q, lr=1e-4, store_params=True, o
     a = rng.integers(0, net.n_actions, B).astype(np.int32)
     r = rng.standard_normal(B).astype(np.float32) * 3  # large enough to hit the linear Huber branch
     done = (rng.random(B) < 0.25).astype(np.float32)
-    w = (0.5 + rng.random(B)).astype(np.float32)
+    rng.random(B)   # (round <= 3 drew random IS weights here; the draw is kept so that every later draw -- there is none -- and the seeds stay put)
+    # IS weights as get_batch computes them (src/prioritized_experience_replay.jl:93-102) for a replay that holds exactly these B transitions,
+    # each added the way dqn_train! adds them: add_exp!(replay, exp, abs(exp.r)) (src/solver.jl:91-94) -> priority (|r| + eps)^alpha
+    # (...replay.jl:67, eps = 1e-3, alpha = 0.6, beta = 0.4: :43-45).  An engine fed the same way returns the SAME w from get_batch(0..B-1),
+    # so its loss / td / gradients / Adam step can be compared with the torch values below directly.
+    prio = np.array([np.float32(float(np.float32(abs(float(x))) + np.float32(1e-3)) ** float(np.float32(0.6))) for x in r], np.float32)   # Float32^Float32 through Float64
+    tot = np.float32(0)
+    for q in prio:
+        tot = np.float32(tot + q)
+    w = np.array([np.float32(float(np.float32(B) * np.float32(q / tot)) ** (-float(np.float32(0.4)))) for q in prio], np.float32)
+    np.testing.assert_array_equal(prio, O.priority_from_td(np.abs(r), np.float32(1e-3), np.float32(0.6)))
+    np.testing.assert_allclose(w, O.is_weights(prio, prio, 0.4), rtol=3e-7)
+    assert w.max() / w.min() > 1.5, "IS weights too uniform to pin anything"
     batch = (s, a, r, sp, done, w)
 
     adam = O.AdamState([np.asarray(p, np.float64) for p in p_on], lr)
@@ -121,7 +133,7 @@ def make_case(name, net, B, seed, gamma, double_q, lr=1e-4, store_params=True, o
     assert max(errs.values()) < 1e-9, errs
 
     out = dict(B=B, seed=seed, gamma=gamma, double_q=int(double_q), lr=lr,
-               s=s, a=a, r=r, sp=sp, done=done, w=w,
+               s=s, a=a, r=r, sp=sp, done=done, w=w, prio=prio, w_from_priorities=1,
                loss=np.float64(t["loss"]), td=t["td"], q=t["q"], grad_norm=np.float64(max(np.abs(g).max() for g in t["grads"])),
                grad_sums=np.array([g.sum() for g in t["grads"]]),
                grad_abs_sums=np.array([np.abs(g).sum() for g in t["grads"]]),

@@ -68,3 +68,88 @@ def check_against_oracle(h, net, eps_ring, B, T, kw, rng, params):
     diff = np.abs(newp - O.Network.flatten(o["new_params"]))
     assert diff.max() <= 2.1e-3 and (diff > 5e-6).mean() < 1e-3     # Adam at |g| ~ eps, see test_twin_vs_oracle.py
     return idx, start, loss, gn
+
+
+def oracle_recur_state(net, p_on, xs):
+    """(h, c) of every LSTM layer after running the policy network over xs from the reset state: the fp64 oracle's Recur state
+    (what hiddenstates(m), src/helpers.jl:61-63, returns after len(xs) calls of the policy, src/policy.jl:38-46), each [out, streams]."""
+    qs, caches = O._seq_forward(net, [p.astype(np.float64) for p in net.unflatten(p_on)], [x.astype(np.float64) for x in xs])
+    out = []
+    for c in caches[-1]:
+        if c[0] == "lstm":
+            _, _, _, hp, cp, i, f, gc, o, tc = c
+            out.append(((o * tc).T, (f * cp + i * gc).T))
+    return qs, out
+
+
+def check_hidden_state_protocol(h, net, p_on, rng, twin=None):
+    """hiddenstates / sethiddenstates! / resetstate! (src/helpers.jl:61-79, src/policy.jl:32-34) and their use around batch_train!
+    (src/solver.jl:137-139: hs = hiddenstates(active_q); batch_train!; sethiddenstates!(active_q, hs)).
+    h: engine or twin handle with episodes in its replay; twin: optional second handle in the same state, compared bit for bit."""
+    hs_all = [h] + ([twin] if twin is not None else [])
+    xs = [rng.random((1,) + net.obs_shape).astype(np.float32) for _ in range(5)]
+    lstm = [l for l in net.base if l.kind == "lstm"]
+    for g in hs_all:
+        g.reset_state()
+    # fresh state == state0 of the online network (Flux.reset!)
+    sl = net.param_slices(); ps = net.unflatten(p_on)
+    st0 = [(ps[sl[li][0] + 3], ps[sl[li][0] + 4]) for li, l in enumerate(net.base) if l.kind == "lstm"]
+    for (hh, cc), (h0, c0) in zip(h.get_hidden(), st0):
+        np.testing.assert_array_equal(hh[:, 0], h0); np.testing.assert_array_equal(cc[:, 0], c0)
+    # after k policy forwards the state equals the oracle's to 1e-5 (and the twin's bit for bit)
+    for k in range(3):
+        for g in hs_all:
+            g.forward(xs[k])
+    _, want = oracle_recur_state(net, p_on, xs[:3])
+    saved = h.get_hidden()
+    assert len(saved) == len(lstm) == len(want)
+    for (hh, cc), (ho, co) in zip(saved, want):
+        np.testing.assert_allclose(hh, ho, atol=1e-5, rtol=1e-5); np.testing.assert_allclose(cc, co, atol=1e-5, rtol=1e-5)
+    if twin is not None:
+        for (a, b), (c, d) in zip(saved, twin.get_hidden()):
+            np.testing.assert_array_equal(a, c); np.testing.assert_array_equal(b, d)
+    # the policy's Recur state survives a train step (the reference saves and restores it around batch_train!, src/solver.jl:137-139;
+    # the engine keeps it apart from the train step's sequences)
+    for g in hs_all:
+        g.train_step_drqn()
+    for (a, b), (c, d) in zip(saved, h.get_hidden()):
+        np.testing.assert_array_equal(a, c); np.testing.assert_array_equal(b, d)
+    # ... so the next forward continues the sequence -- with the UPDATED parameters, exactly what the reference computes after sethiddenstates!
+    p_new = h.get_params(0)
+    q3 = h.forward(xs[3])
+    st3 = h.get_hidden()
+    # set -> forward reproduces: restore the saved state, the same observation gives the same Q and the same next state, bit for bit
+    h.forward(xs[4])
+    h.set_hidden(saved)
+    for (a, b), (c, d) in zip(saved, h.get_hidden()):
+        np.testing.assert_array_equal(a, c); np.testing.assert_array_equal(b, d)
+    np.testing.assert_array_equal(h.forward(xs[3]), q3)
+    for (a, b), (c, d) in zip(st3, h.get_hidden()):
+        np.testing.assert_array_equal(a, c); np.testing.assert_array_equal(b, d)
+    # and that forward is the oracle's step from the saved state with the new parameters (1e-5)
+    psn = [p.astype(np.float64) for p in net.unflatten(p_new)]
+    x = xs[3].astype(np.float64)
+    k = 0
+    for li, l in enumerate(net.base):
+        a, b_ = sl[li]
+        if l.kind == "lstm":
+            Wi, Wh, b, _, _ = psn[a:b_]
+            hp, cp = saved[k][0].T.astype(np.float64), saved[k][1].T.astype(np.float64)
+            g = x.reshape(1, -1) @ Wi + hp @ Wh + b
+            H = l.n_out
+            i, f, gc, o = O._sigm(g[:, :H]), O._sigm(g[:, H:2 * H]), np.tanh(g[:, 2 * H:3 * H]), O._sigm(g[:, 3 * H:])
+            c = f * cp + i * gc
+            x = o * np.tanh(c)
+            np.testing.assert_allclose(st3[k][0], x.T, atol=1e-5, rtol=1e-5); np.testing.assert_allclose(st3[k][1], c.T, atol=1e-5, rtol=1e-5)
+            k += 1
+        else:
+            x, _ = O.layer_forward(l, x, *psn[a:b_])
+    if twin is not None:
+        np.testing.assert_array_equal(twin.forward(xs[3]), q3)
+        for (a, b), (c, d) in zip(st3, twin.get_hidden()):
+            np.testing.assert_array_equal(a, c); np.testing.assert_array_equal(b, d)
+    # a wrong-sized buffer is refused
+    import pytest
+    with pytest.raises(Exception, match="buffer too small"):
+        buf = np.zeros(max(1, h.hidden_size() - 1), np.float32)
+        h._check(h.f["get_hidden"](h._h, buf.ctypes.data_as(ref.abi._f32p), buf.size))

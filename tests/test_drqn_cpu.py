@@ -33,3 +33,25 @@ def test_recurrent_model_without_recurrence_is_rejected():
     hp = ref.hparams_for(net, batch_size=B, buffer_size=8, recurrence=0)
     with pytest.raises(ref.abi.DQNError, match="recurrent model but recurrence is set to false"):   # src/solver.jl:45-47
         ref.Twin(ref.layers_from_network(net), hp)
+
+
+@pytest.mark.parametrize("name", ["cfg4_lstm_plain", "dense_lstm_dueling"])
+def test_twin_hidden_state_save_restore(name):
+    """hiddenstates / sethiddenstates! (src/helpers.jl:61-79) around batch_train! (src/solver.jl:137-139)"""
+    from drqn_common import check_hidden_state_protocol
+    net, B, T, kw = drqn_nets()[name]
+    rng = np.random.default_rng(17)
+    h, hp, layers = make_handle(ref.Twin, net, B, T, kw, cap=B + 4, threads=2)
+    feed(h, make_episodes(net, B + 4, T, rng))
+    p_on = (O.Network.flatten(O.init_params_recurrent(net, 3)) + 0.05 * rng.standard_normal(net.n_params())).astype(np.float32)
+    h.set_params(p_on, 0); h.set_params(p_on * 0.9, 1)
+    check_hidden_state_protocol(h, net, p_on, rng)
+    h.close()
+
+
+def test_recurrence_with_u8_replay_is_rejected():
+    """the episode replay stores Float32 rows; a u8 replay would make dqn_episode_add read 4x past the caller's byte buffer"""
+    net, B, T, kw = drqn_nets()["lstm_single_q"]
+    hp = ref.hparams_for(net, batch_size=B, buffer_size=8, recurrence=1, trace_length=T, obs_dtype=ref.abi.OBS_U8)
+    with pytest.raises(ref.abi.DQNError, match="u8 is not supported with recurrence"):
+        ref.Twin(ref.layers_from_network(net), hp)

@@ -133,3 +133,38 @@ def test_drqn_checkpoint_resume_is_bit_exact(pkg, tmp_path):
         z = np.zeros((cap + 1, T) + net.obs_shape, np.float32)
         b.episode_import(z, z, np.zeros((cap + 1, T), np.int32), np.zeros((cap + 1, T), np.float32), np.zeros((cap + 1, T), np.uint8), np.ones(cap + 1, np.int32))
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("name", ["cfg4_lstm_plain", "dense_lstm_dueling", "lstm16_dueling_b16"])
+def test_hidden_state_save_restore_vs_oracle_and_twin(pkg, name):
+    """dqn_get_hidden / dqn_set_hidden == hiddenstates / sethiddenstates! (src/helpers.jl:61-79): the policy's Recur state after k forwards equals the fp64
+    oracle's to 1e-5 and the twin's bit for bit, survives a recurrent train step (src/solver.jl:137-139), and set -> forward reproduces."""
+    from drqn_common import check_hidden_state_protocol
+    net, B, T, kw, rng, gpu, cpu, ring, (p_on, p_tg) = setup(pkg, name)
+    check_hidden_state_protocol(gpu, net, p_on, np.random.default_rng(23), twin=cpu)
+    gpu.close(); cpu.close()
+
+
+def test_recurrence_with_u8_replay_is_rejected(pkg):
+    net, B, T, kw = drqn_nets()["lstm_single_q"]
+    hp = ref.hparams_for(net, batch_size=B, buffer_size=8, recurrence=1, trace_length=T, obs_dtype=pkg.OBS_U8)
+    with pytest.raises(pkg.DQNError, match="u8 is not supported with recurrence"):
+        pkg.Engine(ref.layers_from_network(net), hp, device=0)
+
+
+@pytest.mark.parametrize("mfma", [0, 1])
+@pytest.mark.parametrize("name", ["drqn_cfg4_lstm_plain", "drqn_dense_lstm_dueling", "drqn_lstm_single_q"])
+def test_drqn_golden_fixture_torch_values(pkg, name, mfma, golden_dir):
+    """the three committed DRQN fixtures (torch float64 autograd of src/solver.jl:239-287): loss, gradients, Adam step DIRECTLY, and the twin bit for bit"""
+    from golden_common import load, run_drqn_fixture
+    g = load(golden_dir, name)
+    outs = []
+    class Eng(pkg.Engine):
+        def __init__(self, layers, hp, **kw):
+            hp.use_mfma = mfma
+            super().__init__(layers, hp, device=0, **kw)
+            outs.append(self.plan())
+    a = run_drqn_fixture(Eng, name, g)
+    b = run_drqn_fixture(ref.Twin, name, g, plan=outs[0], threads=4)
+    assert a["loss"] == b["loss"] and a["gn"] == b["gn"]
+    np.testing.assert_array_equal(a["grads"], b["grads"]); np.testing.assert_array_equal(a["newp"], b["newp"])

@@ -72,11 +72,14 @@ def run_case(name, golden_dir, Engine, tol_q=1e-5, prioritized=1, **engine_kw):
     diff = np.abs(newp - O.Network.flatten(o["new_params"]))
     assert diff.max() <= 2.1 * float(g["lr"])
     assert (diff > 2e-6).mean() < 1e-5
-    # golden (torch autograd, with the FIXTURE's IS weights): only meaningful pieces that do not
-    # depend on w: Q(s) and shapes
+    # golden (torch float64 autograd): with prioritized replay on, get_batch's IS weights ARE the fixture's (oracle/make_golden.py derives them from
+    # the priorities this replay holds), so every stored torch output is compared directly
     np.testing.assert_allclose(q["q_on_s"], g["q"], atol=tol_q, rtol=1e-5)
+    if prioritized:
+        from golden_common import engine_vs_ff_fixture
+        engine_vs_ff_fixture(h, name, g, dict(w=w, loss=loss, gn=gn, td=td, q=q["q_on_s"], grads=grads, newp=newp), tol_q=tol_q)
     h.close()
-    return dict(loss=loss, td=td, q=q, grads=grads, newp=newp)
+    return dict(loss=loss, td=td, q=q["q_on_s"], q_all=q, grads=grads, newp=newp, w=w, gn=gn)
 
 
 @pytest.mark.parametrize("name", list(GOLDEN_CASES))
