@@ -141,7 +141,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--profile-steps", type=int, default=20)
-    ap.add_argument("--sustained-steps", type=int, default=5000, help="steps of the long-run twin of the timed region (0 = skip)")
+    ap.add_argument("--sustained-steps", type=int, default=-1, help="steps of the long-run twin of the timed region (0 = skip; -1 = as many as --sustained-seconds needs at the measured rate)")
+    ap.add_argument("--sustained-seconds", type=float, default=10.0, help="GPU time of the sustained region (longer than any SMI sampler's period; runs BEFORE the CPU baseline)")
+    ap.add_argument("--per-call-steps", type=int, default=-1, help="calls of the per-call seam measurement (dqn_train_step with scalars returned, and its async form); -1 = --steps, 0 = skip")
+    ap.add_argument("--dp-overlap", type=int, default=-1, choices=[-1, 0, 1], help="replicas: 1 = exchange the wide dense layers' operands on a third stream under the conv backward (DESIGN.md 8); -1 = engine default")
     ap.add_argument("--device-fill", action="store_true", help="fill the replay with the device-resident env loop (uniform-random policy, eps = 1) instead of host rollouts + PCIe; needed for config 5's 1e6-transition replay")
     ap.add_argument("--env-steps", type=int, default=200, help="vector steps of the device-resident env loop timed after the main metric (0 = skip)")
     ap.add_argument("--conv-kc", type=int, default=0, help="experiment: forward split-K chunk of the conv layers")
@@ -166,6 +169,10 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
 
+    if args.dp_overlap == 1:
+        os.environ["DQN_DP_OVERLAP"] = "1"
+    elif args.dp_overlap == 0:
+        os.environ.pop("DQN_DP_OVERLAP", None)
     import torch
     if not torch.cuda.is_available():
         print("bench.py: no HIP device visible; the engine has no CPU fallback", file=sys.stderr)
@@ -247,6 +254,8 @@ def main():
     # ---- the same measurement over a LONG region (the driver's --steps 20 region is ~3 ms, shorter than its SMI sampler's period): K2 >= 5000
     # steps of the identical call, same barriers, same max-over-ranks clock.  Reported beside `value`, never instead of it.
     sustained = None
+    if args.sustained_steps < 0:
+        args.sustained_steps = int(max(1000, args.sustained_seconds * value / world)) if args.sustained_seconds > 0 else 0
     if args.sustained_steps > 0:
         barrier()
         t0 = time.perf_counter()
@@ -257,6 +266,37 @@ def main():
         el2 = group.max_over_ranks(t1 - t0)
         group.barrier()
         sustained = {"steps": args.sustained_steps, "seconds": el2, "value": world * args.sustained_steps / el2, "unit": "steps/s", "ms_per_step": el2 / args.sustained_steps * 1e3}
+
+    # ---- the drop-in seam as the reference's loop drives it: ONE call per train step with (loss, grad_norm) returned every time (src/solver.jl:138,235).
+    # `sync`: K calls of dqn_train_step(e, NULL, &loss, &gn, NULL) -- the host waits for every step's scalars (published by the step's last launch into a
+    # mapped host ring).  `async`: K calls of dqn_train_step_async (returns once enqueued) and ONE dqn_step_scalars at the end -- what the shim's dqn_train! does
+    # between two log_freq prints (src/solver.jl:154-167).  Both include the step's own sample + gather launch (nothing is pre-gathered across calls).
+    per_call = None
+    kpc = args.steps if args.per_call_steps < 0 else args.per_call_steps
+    if kpc > 0 and world == 1:
+        per_call = {}
+        for _ in range(3):
+            eng.train_step(want_td=False); eng.step_scalars(eng.train_step_async())
+        for mode in ("sync", "async"):
+            barrier()
+            t0 = time.perf_counter()
+            if mode == "sync":
+                for _ in range(kpc):
+                    lv = eng.train_step(want_td=False)
+            else:
+                for _ in range(kpc):
+                    tk = eng.train_step_async()
+                lv = eng.step_scalars(tk, wait=True)
+            eng.sync()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            per_call[mode] = {"calls": kpc, "value": kpc / (t1 - t0), "unit": "steps/s", "us_per_call": (t1 - t0) / kpc * 1e6,
+                              "us_over_batched_step": (t1 - t0) / kpc * 1e6 - ms_per_step * 1e3, "last_loss": lv[0]}
+        per_call["note"] = ("sync = dqn_train_step(e, NULL, &loss, &gn, NULL) per step (what the shim's batch_train! method does); async = dqn_train_step_async per step + one "
+                            "dqn_step_scalars (what the shim's dqn_train! loop does between log_freq prints); `value` above is dqn_train_steps(K), one call for K steps")
+    comm_info = eng.comm_info()
+    if world > 1 and not sim_comm:
+        assert comm_info["rccl_nranks"] == world and comm_info["rccl_rank"] == rank, (comm_info, rank, world)     # the communicator itself saw WORLD_SIZE ranks
 
     out = None
     if rank == 0:
@@ -314,8 +354,11 @@ def main():
         gemm = [r for r in table if r.get("bound") == "mfma"]
         if gemm:
             roof["gemm_launches_frac"] = round(sum(r["mflop"] for r in gemm) * 1e6 / (sum(r["avg_us"] for r in gemm) * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
-            dom = max(gemm, key=lambda r: r["avg_us"])
-            roof["dominant_kernel"] = dict(dom)          # the longest GEMM launch, per-launch roofline: algorithmic FLOP / HIP-event duration
+            roof["longest_gemm_launch"] = dict(max(gemm, key=lambda r: r["avg_us"]))      # per-launch roofline: algorithmic FLOP / HIP-event duration
+            # what the event brackets add per launch: (sum of the bracketed launches - the graph-replayed step) / launches.  rocprofv3's begin/end stamps carry none of it
+            ev_over = max(0.0, (sum(kern.values()) * 1e3 - ms_per_step * 1e3) / max(1, len(kern)))
+            roof["event_overhead_us_per_launch"] = round(ev_over, 2)
+            roof["dominant_kernel"] = dominant_kernel(table, args.batch == 32 and not args.u8 and world == 1, ev_over)
         gk = dict(kern); gk.update({k: v[0] / v[1] for k, v in single_gather.items()})
         gname = "sample_gather" if "sample_gather" in gk else ("gather" if "gather" in gk else None)
         if gname:
@@ -343,9 +386,12 @@ def main():
                        "replay_dtype": "u8" if args.u8 else "f32", "envs_per_rank": args.envs_per_rank, "n_params": int(P),
                        "parallelism": f"dp{world} (per-rank envs + replay; one RCCL all-gather per step: wide-dense operands + small gradients)" if world > 1 else "single GPU",
                        "hip_graph": not args.no_graph, "mfma": not args.no_mfma, "last_loss": loss, "last_grad_norm": gnorm,
+                       "rccl_nranks": comm_info["rccl_nranks"], "rccl_rank": comm_info["rccl_rank"], "rccl_device": comm_info["rccl_device"],
+                       "exchange": {0: "none", 1: "all-gather (wide-dense operands + small gradients)", 2: "all-reduce (flat gradient)", -1: "undecided"}[comm_info["exchange"]],
+                       "dp_overlap": bool(comm_info["dp_overlap"]),
                        **({"sim_comm": "SELF-TEST: all ranks share GPU 0, the all-gather is replaced by local copies (DQN_SIM_WORLD); not a scaling measurement"} if sim_comm else {})},
             "samples_per_s": value * args.batch,
-            "roofline": roof, "cpu_baseline": cpu, "env_loop": env_loop, "sustained": sustained,
+            "roofline": roof, "cpu_baseline": cpu, "env_loop": env_loop, "sustained": sustained, "per_call": per_call,
         }
         print(json.dumps(out))
     group.barrier()
@@ -427,6 +473,78 @@ def cpu_baseline(pkg, layers, hp, params, env, args):
 
 PMC_OK = [True]
 
+# kernel-symbol family of a launch of the step program (names: DESIGN.md section 6 / op_cost above)
+KERNEL_FAMILIES = (("k_dwdx_lds", lambda n: "dx" in n and n.startswith("dw")), ("k_fwd_lds", lambda n: n.startswith("fwd_") and "reduce" not in n and "valu" not in n),
+                   ("k_dw_lds", lambda n: n.startswith("dw") and "dx" not in n), ("k_adam", lambda n: n.startswith("adam")), ("k_head_td", lambda n: n == "head_td"),
+                   ("k_reduce_multi", lambda n: "reduce" in n))
+
+
+def dominant_kernel(table, use_profile, ev_over=0.0):
+    """The dominant kernel = the kernel symbol with the largest TOTAL time in the newest committed rocprofv3 --kernel-trace summary of this bench
+    (profiles/*_kernel_trace_summary.txt; config 2, single GPU), priced on its launches' algorithmic FLOPs (or bytes) over their LIVE HIP-event durations; the
+    committed profile's average duration of the same symbol stands beside it (HIP events read ~1.2-2 us longer per launch than rocprofv3's begin/end stamps).
+    Without a usable profile (other configs): the family with the largest live total."""
+    import glob
+    import hashlib
+    fam_rows = {}
+    for fam, pred in KERNEL_FAMILIES:
+        rows = [r for r in table if pred(r["launch"])]
+        if rows:
+            fam_rows[fam] = rows
+    prof = None
+    if use_profile:
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_trace_summary.txt")), reverse=True):
+            if "cfg5" in path or "drqn" in path:
+                continue
+            rows = []
+            for line in open(path):
+                f = line.rsplit(None, 6)
+                try:
+                    if len(f) == 7:
+                        rows.append((f[0].strip(), int(f[1]), float(f[2]), float(f[5])))
+                except ValueError:
+                    pass      # header / footer lines
+            if rows:
+                prof = (path, rows)
+                break
+    if prof:
+        # the top SYMBOL of the profile (rows are sorted by total time); its family's launches are the ones priced (template instances of one family that the
+        # launch names cannot tell apart -- the forward tiles' NT -- are priced together)
+        by_fam, symbol = {}, None
+        for name, calls, avg, tot in sorted(prof[1], key=lambda r: -r[3]):
+            fam0 = next((f for f in fam_rows if f in name), None)
+            if fam0 is not None:
+                by_fam[fam0] = [calls, tot]; symbol = name
+                break
+        fam = next(iter(by_fam), None)
+    else:
+        fam = None
+    if fam is None:
+        fam = max(fam_rows, key=lambda k: sum(r["avg_us"] for r in fam_rows[k]))
+    rows = fam_rows[fam]
+    us = sum(r["avg_us"] for r in rows)
+    d = {"kernel": fam, "launches_per_step": len(rows), "launches": [r["launch"] for r in rows], "avg_us": round(us / len(rows), 2), "step_us": round(us, 2),
+         "timing": "HIP events on the engine stream, live in this run (eager launches of the steady-state step)"}
+    if all(r.get("bound") == "mfma" for r in rows):
+        fl = sum(r["mflop"] for r in rows) * 1e6
+        d.update(bound="mfma", mflop_per_step=round(fl / 1e6, 1), tflops=round(fl / (us * 1e-6) / 1e12, 2), frac=round(fl / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
+    elif all(r.get("bound") == "hbm" for r in rows):
+        by = sum(r["mbytes"] for r in rows) * 1e6
+        d.update(bound="hbm", mbytes_per_step=round(by / 1e6, 2), gbs=round(by / (us * 1e-6) / 1e9, 1), frac=round(by / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4))
+    if ev_over > 0 and d.get("bound") == "mfma":
+        net = us - ev_over * len(rows)
+        d.update(avg_us_net_of_event_overhead=round(net / len(rows), 2), frac_net_of_event_overhead=round(d["mflop_per_step"] * 1e6 / (net * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
+    if prof:
+        calls, tot = by_fam[fam]
+        d.update(rocprof_symbol=symbol, rocprof_file="profiles/" + os.path.basename(prof[0]), rocprof_sha1=hashlib.sha1(open(prof[0], "rb").read()).hexdigest()[:12],
+                 rocprof_avg_us=round(tot * 1e3 / calls, 2), rocprof_share_of_kernel_time=round(tot / sum(r[3] for r in prof[1]), 4),
+                 chosen_by="largest total time in the committed rocprofv3 kernel-trace summary")
+        if d.get("bound") == "mfma":
+            d["frac_at_rocprof_duration"] = round(d["mflop_per_step"] * 1e6 / (d["rocprof_avg_us"] * len(rows) * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+    else:
+        d["chosen_by"] = "largest live total (no committed rocprofv3 summary for this configuration)"
+    return d
+
 
 def pmc_traffic(op):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_fetch.txt / *_pmc_write.txt: separate
@@ -451,8 +569,10 @@ def pmc_traffic(op):
     write, pw = last("*_pmc_write.txt")
     if fetch is None or write is None:
         return {}
+    import hashlib
+    sha = lambda f: hashlib.sha1(open(os.path.join(ROOT, "profiles", f), "rb").read()).hexdigest()[:12]
     return {"traffic": (2.0 * fetch + write) * 1024.0, "traffic_unit": "bytes/launch",
-            "traffic_source": f"profiles/{pf} (FETCH_SIZE x2) + profiles/{pw} (WRITE_SIZE), separate rocprofv3 --pmc passes of this bench"}
+            "traffic_source": f"profiles/{pf} [sha1 {sha(pf)}] (FETCH_SIZE x2) + profiles/{pw} [sha1 {sha(pw)}] (WRITE_SIZE), separate rocprofv3 --pmc passes of this bench (committed files, NOT measured by this run)"}
 
 
 def torch_cpu_line(hp, seconds):

@@ -97,6 +97,10 @@ _P = C.POINTER
 _f32p, _i32p, _i64p, _u8p, _f64p = _P(C.c_float), _P(C.c_int32), _P(C.c_int64), _P(C.c_uint8), _P(C.c_double)
 _vp, _sz = C.c_void_p, C.c_size_t
 
+class CommInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("rccl_nranks", "rccl_rank", "rccl_device", "engine_world", "engine_rank", "sim_world", "exchange", "dp_overlap")]
+
+
 # name -> argtypes (without prefix).  All return int unless listed in _RESTYPE.
 PROTOS = {
     "plan_default": [_P(LayerDesc), C.c_int, _P(HParams), _P(LayerPlan)],
@@ -118,6 +122,8 @@ PROTOS = {
     "update_priorities": [_vp, _i64p, _f32p, C.c_int],
     "train_step": [_vp, _i64p, _f32p, _f32p, _f32p],
     "train_steps": [_vp, C.c_int, _f32p, _f32p],
+    "train_step_async": [_vp, _i64p, _P(C.c_uint64)],
+    "step_scalars": [_vp, C.c_uint64, C.c_int, _f32p, _f32p, _P(C.c_uint64)],
     "get_last_q": [_vp, _f32p, _f32p, _f32p, _i32p, _f32p],
     "get_last_indices": [_vp, _i64p],
     "get_grads": [_vp, _f32p, _sz],
@@ -125,6 +131,7 @@ PROTOS = {
     "greedy_action": [_vp, _f32p, C.c_int, _i32p],
     "comm_unique_id": [_vp],
     "comm_init": [_vp, _vp, C.c_int, C.c_int],
+    "comm_info": [_vp, _P(CommInfo)],
     "sim_ranks_step": [_vp, _i64p, _f32p, _f32p, _f32p],
     "debug_ktrace": [_vp, _P(C.c_uint64), _sz],
     "stream_sync": [_vp],
@@ -327,6 +334,25 @@ class Handle:
         td = np.empty(self.B, np.float32) if want_td else None
         self._check(self.f["train_step"](self._h, _ptr(idx, _i64p), C.byref(loss), C.byref(gn), _ptr(td, _f32p)))
         return (loss.value, gn.value, td) if want_td else (loss.value, gn.value)
+
+    def comm_info(self):
+        """what the engine's RCCL communicator itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice) beside what the engine was told"""
+        ci = CommInfo()
+        self._check(self.f["comm_info"](self._h, C.byref(ci)))
+        return {n: int(getattr(ci, n)) for n, _ in ci._fields_}
+
+    def train_step_async(self, idx=None):
+        """enqueue one batch_train! and return at once; the ticket names the (loss, grad_norm) record the step's last launch publishes to the host mailbox"""
+        idx = _as(idx, np.int64)
+        t = C.c_uint64()
+        self._check(self.f["train_step_async"](self._h, _ptr(idx, _i64p), C.byref(t)))
+        return t.value
+
+    def step_scalars(self, ticket, wait=True):
+        """(loss, grad_norm) of the step that returned `ticket`; wait=False returns None while the step is still running"""
+        loss, gn, pub = C.c_float(), C.c_float(), C.c_uint64()
+        self._check(self.f["step_scalars"](self._h, int(ticket), 1 if wait else 0, C.byref(loss), C.byref(gn), C.byref(pub)))
+        return (loss.value, gn.value) if pub.value == ticket else None
 
     def train_steps(self, n):
         loss, gn = C.c_float(), C.c_float()

@@ -45,6 +45,15 @@ struct StepState {
                                        // 2: ... and their rows, batch scalars and IS weights are already in the batch arena (PreGather)
 };
 
+// (loss, grad_norm) of a train step as the step's LAST launch publishes them into mapped pinned HOST memory (k_publish_scalars): the host reads
+// them without a fold launch, a D2H copy or a stream synchronize.  A ring of DQN_MAIL_SLOTS records indexed by the publish sequence number.
+#define DQN_MAIL_SLOTS 64
+struct StepMail {
+    float loss, gnorm; int err, pad;
+    unsigned long long step;           // StepState::step when published (train steps started so far)
+    unsigned long long seq;            // publish sequence number, written LAST (release, system scope): seq == ticket <=> the record is complete
+};
+
 static inline __host__ __device__ int dqn_nchunks(int K, int kc) { return (kc <= 0 || kc >= K) ? 1 : (K + kc - 1) / kc; }
 static inline __host__ __device__ int dqn_chunk_len(int K, int kc) { return (kc <= 0 || kc >= K) ? K : kc; }
 // conv dX: RAW kernel taps (index ky*kw + kx, ascending) per summation chunk (plan.dx_kc; 0 / >= kh*kw = one chunk)
@@ -537,6 +546,8 @@ void launch_batch_meta(hipStream_t st, int B, long long cap2, const long long* i
 void launch_update_priorities(hipStream_t st, int n, long long cap2, const long long* idx, const float* td, float eps, float alpha,
                               float* tree, StepState* state, int tick_adam, double beta1, double beta2, const float* gmax_part, int n_gmax,
                               long long* idx_pre = nullptr /* also draw the NEXT sample()'s pre_B indices (prio_block_run's second half) */, unsigned long long seed = 0, int pre_B = 0);
+
+void launch_publish_scalars(hipStream_t st, StepState* state, const float* gmax_part, int n_gmax, unsigned long long* pub_ctr, StepMail* mail /* device view of the mapped host ring */);
 
 void launch_valu_fwd(hipStream_t st, const LayerDev& L, const float* P, const float* X, int ldx, int col0, int ncols, float* Y, float* partials);
 void launch_valu_dw(hipStream_t st, const LayerDev& L, const float* X, int ldx, const float* dpre, int B, float* G, float* partials);

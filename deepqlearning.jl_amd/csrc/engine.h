@@ -80,6 +80,10 @@ struct dqn_engine {
     // the next batch; step_take_pre = this step runs without its gather launch
     int gmax_used = 0;                    // live slots of gmax_part (per-block max |g| of the step's Adam jobs): what the on-demand fold reads
     StepState* state_host = nullptr;      // pinned landing buffer of fetch_scalars
+    // scalar mailbox (StepMail, common.h): mapped pinned host ring the step's last launch writes (loss, grad_norm) into; pub_issued = publishes enqueued by the host,
+    // pub_ctr = publishes executed by the device (the record of ticket t sits in slot t % DQN_MAIL_SLOTS once its seq == t)
+    StepMail *mail_host = nullptr, *mail_dev = nullptr; unsigned long long* pub_ctr = nullptr; unsigned long long pub_issued = 0; bool step_publish = false;
+    hipGraphExec_t g_full_pub[2] = {nullptr, nullptr};      // g_full + the publish launch
     bool pg_ok = false, step_pregather = false, step_take_pre = false; PreGather pg; long adam_step = -1;
     bool no_tiny = false;   // DQN_NO_TINY at dqn_engine_create: always the multi-launch program
     bool tiny = false;      // the whole step is ONE single-workgroup launch that samples and gathers itself (tiny_step.hip)

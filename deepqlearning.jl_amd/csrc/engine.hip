@@ -22,6 +22,7 @@ struct Rccl {
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr; int (*CommUserRank)(void*, int*) = nullptr; int (*CommCuDevice)(void*, int*) = nullptr;
 };
 static Rccl g_rccl;
 static int rccl_load() {
@@ -35,6 +36,8 @@ static int rccl_load() {
     g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(g_rccl.lib, "ncclAllGather");
     g_rccl.CommDestroy = (int (*)(void*))dlsym(g_rccl.lib, "ncclCommDestroy");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
+    g_rccl.CommCount = (int (*)(void*, int*))dlsym(g_rccl.lib, "ncclCommCount"); g_rccl.CommUserRank = (int (*)(void*, int*))dlsym(g_rccl.lib, "ncclCommUserRank");
+    g_rccl.CommCuDevice = (int (*)(void*, int*))dlsym(g_rccl.lib, "ncclCommCuDevice");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather) return fail("librccl is missing nccl symbols");
     return 0;
 }
@@ -216,6 +219,13 @@ static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers
     HIPCHK(hipMemset(e->p_on, 0, e->Pint * 4)); HIPCHK(hipMemset(e->p_tg, 0, e->Pint * 4)); HIPCHK(hipMemset(e->grad, 0, e->Pint * 4));
     HIPCHK(hipMemset(e->m, 0, e->Pint * 4)); HIPCHK(hipMemset(e->v, 0, e->Pint * 4));
     DM(e->state, 1);
+    // scalar mailbox: a coherent, mapped pinned ring the publish launch writes and the host polls (a failure here only disables the fast path)
+    DM(e->pub_ctr, 1); HIPCHK(hipMemset(e->pub_ctr, 0, sizeof(unsigned long long)));
+    if (hipHostMalloc((void**)&e->mail_host, sizeof(StepMail) * DQN_MAIL_SLOTS, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+        memset(e->mail_host, 0, sizeof(StepMail) * DQN_MAIL_SLOTS);
+        if (hipHostGetDevicePointer((void**)&e->mail_dev, e->mail_host, 0) != hipSuccess) { hipHostFree(e->mail_host); e->mail_host = nullptr; e->mail_dev = nullptr; }
+    } else { e->mail_host = nullptr; }
+    (void)hipGetLastError();
     StepState s0; memset(&s0, 0, sizeof s0); s0.bp[0][0] = s0.bp[1][0] = hp->adam_beta1; s0.bp[0][1] = s0.bp[1][1] = hp->adam_beta2;
     HIPCHK(hipMemcpy(e->state, &s0, sizeof s0, hipMemcpyHostToDevice));
     e->cap = hp->recurrence ? B : hp->buffer_size; while (e->cap2 < e->cap) e->cap2 <<= 1;   // DRQN keeps episodes instead (below)
@@ -259,6 +269,7 @@ static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers
 void drop_graphs(dqn_engine* e) {
     for (int i = 0; i < 2; i++) {
         if (e->g_full[i]) { hipGraphExecDestroy(e->g_full[i]); e->g_full[i] = nullptr; }
+        if (e->g_full_pub[i]) { hipGraphExecDestroy(e->g_full_pub[i]); e->g_full_pub[i] = nullptr; }
         if (e->g_pre[i]) { hipGraphExecDestroy(e->g_pre[i]); e->g_pre[i] = nullptr; }
         for (int j = 0; j < 2; j++) if (e->g_pgv[i][j]) { hipGraphExecDestroy(e->g_pgv[i][j]); e->g_pgv[i][j] = nullptr; }
     }
@@ -294,6 +305,8 @@ extern "C" int dqn_engine_destroy(dqn_engine_t* e) {
     hipFree(e->L_dev); hipFree(e->p_on); hipFree(e->p_tg); hipFree(e->grad); hipFree(e->m); hipFree(e->v); hipFree(e->io_tmp); hipFree(e->state);
     hipFree(e->s_rows); hipFree(e->sp_rows); hipFree(e->ra); hipFree(e->rr); hipFree(e->rdone); hipFree(e->tree);
     if (e->state_host) hipHostFree(e->state_host);
+    if (e->mail_host) hipHostFree(e->mail_host);
+    hipFree(e->pub_ctr);
     hipFree(e->st_a); hipFree(e->st_r); hipFree(e->st_done); hipFree(e->st_td); hipFree(e->idx); hipFree(e->idx_pre); hipFree(e->x0);
     for (int i = 0; i < e->nl; i++) { hipFree(e->act_on[i]); hipFree(e->act_tg[i]); hipFree(e->dact[i]); }
     hipFree(e->join_tmp); hipFree(e->partials); hipFree(e->gmax_part); hipFree(e->w_is); hipFree(e->td); hipFree(e->q_on_s); hipFree(e->q_on_sp); hipFree(e->q_tg_sp);
@@ -549,6 +562,8 @@ void enqueue_step(dqn_engine* e, bool sample, int phase) {
         }
     }
     if (phase != PH_PRE && phase != PH_PRE1) for (size_t i = e->prog_post_begin; i < e->prog.size(); i++) RUN(e, (e->step_pregather && (long)i == e->adam_step) ? "adam+gather" : e->prog[i].name, e->prog[i].fn(e));
+    if (e->step_publish && phase == PH_ALL)
+        RUN(e, "publish", launch_publish_scalars(e->stream, e->state, e->gmax_part, (e->gmax_used > 0 && e->gmax_used <= gmax_slots(e->Pint)) ? e->gmax_used : gmax_slots(e->Pint), e->pub_ctr, e->mail_dev));
 }
 int exchange_grads(dqn_engine* e);
 int exchange_segment(dqn_engine* e, int seg);
@@ -663,12 +678,42 @@ int run_step(dqn_engine* e, bool sample, bool take_pre, bool pregather) {
         e->step_take_pre = e->step_pregather = false;
         return rc;
     }
+    // publish (dqn_train_step with scalar outputs, dqn_train_step_async): the step's last launch also writes (loss, grad_norm) into the host mailbox
+    const bool pub = e->step_publish && e->mail_dev != nullptr; e->step_publish = pub;
+    int rc = 0;
     if (e->hp.use_graph && !e->profiling) {
-        if (!e->g_full[gi] && capture(e, sample, PH_ALL, &e->g_full[gi])) return -1;
-        HIPCHK(hipGraphLaunch(e->g_full[gi], e->stream));
-    } else { enqueue_step(e, sample, PH_ALL); HIPCHK(hipGetLastError()); }      // eager launches: a refused launch (bad LDS size, bad grid) is an error, not a silent no-op
+        hipGraphExec_t& g = pub ? e->g_full_pub[gi] : e->g_full[gi];
+        if (!g && capture(e, sample, PH_ALL, &g)) rc = -1;
+        else { const hipError_t le = hipGraphLaunch(g, e->stream); if (le != hipSuccess) rc = fail("HIP error %s launching the train-step graph", hipGetErrorString(le)); }
+    } else { enqueue_step(e, sample, PH_ALL); const hipError_t le = hipGetLastError(); if (le != hipSuccess) rc = fail("HIP error %s enqueuing the train step", hipGetErrorString(le)); }      // eager launches: a refused launch (bad LDS size, bad grid) is an error, not a silent no-op
+    e->step_publish = false;
+    if (!rc && pub) e->pub_issued++;
+    return rc;
+}
+// the record of publish `ticket`: spin on the mapped host ring (the GPU writes it with a system-scope release), falling back to a stream synchronize
+static int wait_mail(dqn_engine* e, unsigned long long ticket, bool wait, float* loss, float* gn, unsigned long long* published) {
+    volatile StepMail* m = e->mail_host + (ticket & (DQN_MAIL_SLOTS - 1));
+    auto seq_now = [&]() { return __atomic_load_n(&m->seq, __ATOMIC_ACQUIRE); };
+    if (ticket == 0 || ticket > e->pub_issued) return fail("step scalars: ticket %llu was never issued (newest %llu)", ticket, e->pub_issued);
+    if (ticket + DQN_MAIL_SLOTS <= e->pub_issued) return fail("step scalars: ticket %llu is older than the %d newest publishes (newest %llu)", ticket, DQN_MAIL_SLOTS, e->pub_issued);
+    unsigned long long s = seq_now();
+    if (s != ticket && wait) {
+        for (long spin = 0; (s = seq_now()) != ticket; spin++) {
+            __builtin_ia32_pause();
+            if (spin == (1L << 22)) { HIPCHK(hipStreamSynchronize(e->stream)); s = seq_now(); break; }      // ~tens of ms of spinning: stop burning the core
+        }
+    }
+    if (published) *published = (s == ticket) ? ticket : 0;
+    if (s != ticket) { if (wait) return fail("step scalars: publish %llu did not arrive (slot holds %llu)", ticket, s); return 0; }
+    const int err = m->err;
+    if (err) { HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&e->state->err, 0, 1, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); }      // reported once, not on every later call
+    if (err == 2) return fail("AssertionError: all(new_priorities .> 0f0)");
+    if (err == 3) return fail("internal error: a pre-gathered batch was consumed after the replay changed (StepState::pre_valid != 2)");
+    if (loss) *loss = m->loss;
+    if (gn) *gn = m->gnorm;
     return 0;
 }
+static bool mailbox_ok(dqn_engine* e) { return e->mail_dev && e->world <= 1 && !(e->comm && e->force_comm) && !e->profiling && !e->hp.recurrence; }
 int fetch_scalars(dqn_engine* e, float* loss, float* gn) {
     // globalnorm (helpers.jl:38-46): fold the Adam kernel's per-block maxima only when the host asks for the scalar
     if (gn) launch_update_priorities(e->stream, 0, e->cap2, e->idx, e->td, e->hp.prio_eps, e->hp.prio_alpha, e->tree, e->state, 1, 1.0, 1.0, e->gmax_part, (e->gmax_used > 0 && e->gmax_used <= gmax_slots(e->Pint)) ? e->gmax_used : gmax_slots(e->Pint));
@@ -688,10 +733,36 @@ extern "C" int dqn_train_step(dqn_engine_t* e, const int64_t* idx, float* loss, 
     if (e->hp.recurrence) return fail("recurrence = true: use dqn_train_step_drqn (src/solver.jl:239-287)");
     if (e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
     if (idx) { if (check_idx(e, idx, e->B)) return -1; HIPCHK(hipMemcpyAsync(e->idx, idx, (size_t)e->B * 8, hipMemcpyHostToDevice, e->stream)); }
+    // scalars only (what batch_train! returns, src/solver.jl:235): the step's last launch publishes them to the host mailbox -- no fold launch, no D2H copy,
+    // no stream synchronize; the host spins on the record
+    const bool mail = (loss || grad_norm) && !td_out && mailbox_ok(e);
+    e->step_publish = mail;
     if (run_step(e, idx == nullptr)) return -1;
+    if (mail) return wait_mail(e, e->pub_issued, true, loss, grad_norm, nullptr);
     if (td_out) HIPCHK(hipMemcpyAsync(td_out, e->td, (size_t)e->B * 4, hipMemcpyDeviceToHost, e->stream));
     if (loss || grad_norm || td_out) return fetch_scalars(e, loss, grad_norm);
     return 0;
+}
+// the same step WITHOUT waiting: returns as soon as the step is enqueued; *ticket names the (loss, grad_norm) record its last launch will publish.
+// The reference only looks at batch_train!'s return values every log_freq env steps (src/solver.jl:154-167): the shim's loop fetches them there.
+extern "C" int dqn_train_step_async(dqn_engine_t* e, const int64_t* idx, uint64_t* ticket) { if (!e) return fail("null engine handle");
+    HIPCHK(hipSetDevice(e->device));
+    if (e->hp.recurrence) return fail("recurrence = true: use dqn_train_step_drqn (src/solver.jl:239-287)");
+    if (!mailbox_ok(e)) return fail("dqn_train_step_async: single-device feed-forward engines only");
+    if (e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
+    if (idx) { if (check_idx(e, idx, e->B)) return -1; HIPCHK(hipMemcpyAsync(e->idx, idx, (size_t)e->B * 8, hipMemcpyHostToDevice, e->stream)); }
+    e->step_publish = true;
+    if (run_step(e, idx == nullptr)) return -1;
+    if (ticket) *ticket = e->pub_issued;
+    return 0;
+}
+// (loss, grad_norm) of the step that returned `ticket` (one of the DQN_MAIL_SLOTS newest).  wait != 0: blocks until the record has arrived.  wait == 0: returns at
+// once; *published = ticket if the record was there (outputs written), 0 if the step has not finished yet (outputs untouched).
+extern "C" int dqn_step_scalars(dqn_engine_t* e, uint64_t ticket, int wait, float* loss, float* grad_norm, uint64_t* published) { if (!e) return fail("null engine handle");
+    if (!e->mail_host) return fail("dqn_step_scalars: no mailbox on this engine");
+    unsigned long long pub = 0; const int rc = wait_mail(e, ticket, wait != 0, loss, grad_norm, &pub);
+    if (published) *published = pub;
+    return rc;
 }
 // TEST HOOK (DQN_SIM_WORLD = k): one data-parallel step in which this process plays k ranks with k DISTINCT batches.  Each simulated rank runs
 // the first half of the step (gather .. backward .. dp_pack) on its own index list and its packed block lands in ITS slot of the gathered
@@ -871,6 +942,21 @@ extern "C" int dqn_comm_init(dqn_engine_t* e, const void* id128, int rank, int w
     for (void* p : e->prog_allocs) hipFree(p);
     e->prog_allocs.clear(); e->prog.clear(); e->prog_built = false; e->prog_post_begin = 0; e->final_reduce_step = -1; memset(&e->adam_segs, 0, sizeof e->adam_segs);
     hipFree(e->dp_send); hipFree(e->dp_recv); e->dp_send = e->dp_recv = nullptr; e->dp_gather = e->dp_pack_folds = e->dp_adam_folds = false; e->dp_count = 0;
+    return 0;
+}
+
+// what the COMMUNICATOR itself says (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), so that a bench line can prove how many ranks RCCL saw;
+// without a communicator: nranks = 0 (sim_world engines report it in `sim_world`).  exchange: 0 none, 1 all-gather of operands + small gradients, 2 all-reduce
+extern "C" int dqn_comm_info(dqn_engine_t* e, dqn_comm_info_t* out) { if (!e || !out) return fail("null argument");
+    memset(out, 0, sizeof *out); out->rccl_rank = -1; out->rccl_device = -1;
+    out->engine_world = e->world; out->engine_rank = e->rank; out->sim_world = e->sim_world; out->dp_overlap = e->dp_overlap ? 1 : 0;
+    out->exchange = (e->comm || e->sim_world) ? (e->prog_built ? (e->dp_gather ? 1 : 2) : -1) : 0;      // -1: decided when the step program is built (first train step)
+    if (e->comm) {
+        if (!g_rccl.CommCount || !g_rccl.CommUserRank) return fail("librccl has no ncclCommCount / ncclCommUserRank");
+        int rc = g_rccl.CommCount(e->comm, &out->rccl_nranks); if (!rc) rc = g_rccl.CommUserRank(e->comm, &out->rccl_rank);
+        if (!rc && g_rccl.CommCuDevice) rc = g_rccl.CommCuDevice(e->comm, &out->rccl_device);
+        if (rc) return fail("ncclCommCount / ncclCommUserRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    }
     return 0;
 }
 

@@ -238,6 +238,30 @@ void launch_update_priorities(hipStream_t st, int n, long long cap2, const long 
     hipLaunchKernelGGL(k_update_priorities, dim3(1), dim3(bs), 0, st, n, cap2, idx, td, eps, alpha, tree, state, tick_adam, beta1, beta2, gmax_part, n_gmax, idx_pre, seed, pre_B);
 }
 
+// ------------------------------------------------------------------ (loss, grad_norm) -> host mailbox: the last launch of a dqn_train_step that returns scalars
+// globalnorm (helpers.jl:38-46) is the max over the Adam jobs' per-block maxima (exact: max is order-independent); the record goes straight into mapped
+// pinned host memory, payload first, then -- after a system-scope fence -- its sequence number
+__global__ __launch_bounds__(1024) void k_publish_scalars(StepState* state, const float* __restrict__ gmax_part, int n_gmax, unsigned long long* pub_ctr, StepMail* mail) {
+    __shared__ float smax[16];
+    float g = 0.0f;
+    for (int j = threadIdx.x; j < n_gmax; j += blockDim.x) g = fmaxf(g, gmax_part[j]);
+    for (int off = 32; off > 0; off >>= 1) g = fmaxf(g, __shfl_xor(g, off));
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = g;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) g = fmaxf(g, smax[w]);
+        state->gnorm_bits = __float_as_uint(g);
+        const unsigned long long seq = *pub_ctr + 1; *pub_ctr = seq;
+        StepMail* m = mail + (seq & (DQN_MAIL_SLOTS - 1));
+        m->loss = state->loss; m->gnorm = g; m->err = state->err; m->step = state->step;
+        __threadfence_system();
+        __hip_atomic_store(&m->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+void launch_publish_scalars(hipStream_t st, StepState* state, const float* gmax_part, int n_gmax, unsigned long long* pub_ctr, StepMail* mail) {
+    hipLaunchKernelGGL(k_publish_scalars, dim3(1), dim3(1024), 0, st, state, gmax_part, n_gmax, pub_ctr, mail);
+}
+
 // ------------------------------------------------------------------ checkpoint import: rebuild every internal node of the sum-tree from the leaves
 __global__ void k_tree_level(float* tree, long long width) {      // width = number of nodes on the PARENT level
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

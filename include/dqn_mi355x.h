@@ -156,6 +156,15 @@ int dqn_update_priorities(dqn_engine_t* e, const int64_t* idx, const float* td, 
  * enqueues work on the engine's stream (no host sync). */
 int dqn_train_step(dqn_engine_t* e, const int64_t* idx_or_null, float* loss, float* grad_norm,
                    float* td_out /* B */);
+/* The same step without waiting for it: returns as soon as the step is enqueued on the engine's stream.  *ticket names the (loss, grad_norm) record the step's
+ * last launch publishes into a mapped pinned host ring (no fold launch, no D2H copy, no stream synchronize).  The reference reads batch_train!'s return values
+ * only every log_freq env steps (src/solver.jl:154-167); the shim's dqn_train! loop fetches them there.  dqn_train_step(e, idx, &loss, &gn, NULL) itself is
+ * this call followed by dqn_step_scalars(e, ticket, 1, ...).  Single-device feed-forward engines. */
+int dqn_train_step_async(dqn_engine_t* e, const int64_t* idx_or_null, uint64_t* ticket);
+/* (loss, grad_norm) of the step that returned `ticket` -- one of the 64 newest.  wait != 0: blocks (host spin on the record, stream synchronize as a fallback)
+ * until it has arrived.  wait == 0: returns at once; *published = ticket and the outputs are written if the record was there, *published = 0 otherwise.
+ * Device-side assertion failures of that step (AssertionError: all(new_priorities .> 0f0)) are reported here. */
+int dqn_step_scalars(dqn_engine_t* e, uint64_t ticket, int wait, float* loss, float* grad_norm, uint64_t* published);
 /* run `n_steps` sampled train steps back to back; returns the last step's scalars.  Bit-identical to n_steps calls of dqn_train_step(e, NULL, ...)
  * (tests/test_gpu_parity.py::test_train_steps_pipelined_gather_bit_exact), but inside the call nothing else can touch the replay, so step i's last
  * launch already gathers step i+1's batch and steps 2..n run without a sample / gather launch (prioritized replay; f32 observations, or u8
@@ -255,6 +264,11 @@ int dqn_set_counters(dqn_engine_t* e, const dqn_counters* in);   /* size must eq
  * Every rank must issue the same sequence of train steps. */
 int dqn_comm_unique_id(void* id128);
 int dqn_comm_init(dqn_engine_t* e, const void* id128, int rank, int world);
+/* what the communicator ITSELF reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice) next to what the engine was told: a bench line can prove how
+ * many ranks RCCL saw.  No communicator: rccl_nranks = 0, rccl_rank = rccl_device = -1.  exchange: 0 none, 1 all-gather of the wide dense layers' operands +
+ * small gradients, 2 all-reduce of the flat gradient, -1 not decided yet (the step program is built at the first train step). */
+typedef struct dqn_comm_info_t { int32_t rccl_nranks, rccl_rank, rccl_device, engine_world, engine_rank, sim_world, exchange, dp_overlap; } dqn_comm_info_t;
+int dqn_comm_info(dqn_engine_t* e, dqn_comm_info_t* out);
 
 /* TEST HOOK for the exchange above on ONE GPU: an engine created with the environment variable DQN_SIM_WORLD=k plays k ranks; this call runs
  * one data-parallel step with k DISTINCT batches idx[k][B] (rank r's packed block lands in slot r of the gathered buffer, as ncclAllGather

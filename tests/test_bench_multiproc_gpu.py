@@ -40,3 +40,21 @@ def test_bench_two_ranks_script_path():
     assert d["cpu_baseline"] is not None and d["cpu_baseline"]["value"] > 0          # rank 0 keeps the CPU baseline at N > 1
     assert d["sustained"]["steps"] == 40 and d["sustained"]["value"] > 0
     assert d["env_loop"]["act_only_env_steps_per_s"] > 0
+    # the line says what the communicator saw: here (self-test, no ncclCommInitRank) nothing -- on a real N-GPU launch bench.py asserts rccl_nranks == WORLD_SIZE
+    assert d["config"]["rccl_nranks"] == 0 and d["config"]["rccl_rank"] == -1 and d["config"]["exchange"].startswith("all-gather") and d["config"]["dp_overlap"] is False
+    assert d["per_call"] is None                              # the per-call seam is a single-device measurement
+
+
+def test_bench_single_gpu_line_fields():
+    """the default single-GPU line carries per_call (sync + async seam), a sustained region sized in seconds and a dominant kernel named from the committed profile"""
+    cmd = [sys.executable, os.path.join(ge.ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--replay", "2048", "--env-steps", "0", "--profile-steps", "2",
+           "--sustained-seconds", "0.5", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ge.ROOT)
+    assert p.returncode == 0, p.stderr[-4000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    pc = d["per_call"]
+    assert pc["sync"]["calls"] == pc["async"]["calls"] == 20 and pc["sync"]["value"] > 0 and pc["async"]["value"] >= 0.9 * pc["sync"]["value"]
+    assert 0.3 < d["sustained"]["seconds"] < 2.0 and d["sustained"]["steps"] >= 1000
+    dk = d["roofline"]["dominant_kernel"]
+    assert dk["rocprof_file"].startswith("profiles/") and dk["kernel"] in dk["rocprof_symbol"] and dk["bound"] in ("mfma", "hbm") and 0 < dk["frac"] < 1
+    assert d["config"]["rccl_nranks"] == 0 and d["config"]["exchange"] == "none"

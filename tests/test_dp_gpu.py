@@ -164,7 +164,10 @@ def test_rccl_allgather_world1_matches_plain(pkg, monkeypatch):
     a, cpu, rng = setup(pkg, net, 32, 32, seed=1)
     b, _, _ = setup(pkg, net, 32, 32, seed=1)
     monkeypatch.setenv("DQN_FORCE_ALLREDUCE", "1")                         # run the communicator path although world_size == 1
+    assert b.comm_info()["rccl_nranks"] == 0 and b.comm_info()["exchange"] == 0           # no communicator: nothing to report
     a.comm_init(pkg.comm_unique_id(), 0, 1)
+    ci = a.comm_info()                                                                   # what the communicator ITSELF says (ncclCommCount / ncclCommUserRank / ncclCommCuDevice)
+    assert (ci["rccl_nranks"], ci["rccl_rank"], ci["rccl_device"], ci["engine_world"], ci["engine_rank"]) == (1, 0, 0, 1, 0) and ci["exchange"] == -1
     for _ in range(4):
         ra, rb, rc = a.train_step(), b.train_step(), cpu.train_step()
         assert ra[0] == rb[0] == rc[0] and ra[1] == rb[1]
@@ -172,6 +175,7 @@ def test_rccl_allgather_world1_matches_plain(pkg, monkeypatch):
     np.testing.assert_array_equal(a.get_params(0), b.get_params(0))
     np.testing.assert_array_equal(a.get_params(0), cpu.get_params(0))
     np.testing.assert_array_equal(a.get_grads(), b.get_grads())
+    assert a.comm_info()["exchange"] == 1                                                # the all-gather of the wide dense layers' operands + small gradients
 
 
 def test_rccl_world1_train_steps_pipelined_gather(pkg, monkeypatch):

@@ -625,3 +625,38 @@ def test_train_steps_with_distinct_sampling_bit_exact(pkg, B, cap):
     np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
     np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
     gpu.close(); cpu.close()
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+@pytest.mark.parametrize("netf,B", [(small_conv_dueling, 16), (cfg1_mlp_dueling, 32), (mid_conv_dueling, 32)])
+def test_scalar_mailbox_and_async_step_bit_exact(pkg, netf, B, graph):
+    """dqn_train_step with scalar outputs publishes (loss, grad_norm) from the step's last launch into a mapped host ring (no fold launch / D2H copy / stream
+    synchronize), dqn_train_step_async returns before the step has run and dqn_step_scalars fetches a ticket's record later: every record equals what the
+    twin's batch_train! returns (src/solver.jl:235), bit for bit, in any interleaving with the other entry points."""
+    net = netf()
+    gpu, cpu, hp = make_pair(pkg, net, B, cap=128, graph=graph, learning_rate=1e-3)
+    fill((gpu, cpu), net, 100, seed=3)
+    set_same_params((gpu, cpu), net, seed=2)
+    for _ in range(3):                                    # synchronous, scalars only: the mailbox path
+        assert gpu.train_step(want_td=False) == cpu.train_step(want_td=False)
+    assert_step_bit_exact(gpu, cpu)                       # with td: the copy path, still the same numbers
+    rng = np.random.default_rng(4)
+    tickets, want = [], []
+    for k in range(70):                                   # more than the ring holds
+        idx = None if k % 3 else rng.integers(0, 100, B)
+        tickets.append(gpu.train_step_async(idx)); want.append(cpu.train_step(idx, want_td=False))
+    assert tickets == list(range(tickets[0], tickets[0] + 70))
+    for t, w in list(zip(tickets, want))[-60:]:           # any of the 64 newest, in any order, more than once
+        assert gpu.step_scalars(t) == w
+    assert gpu.step_scalars(tickets[-1], wait=False) == want[-1]
+    with pytest.raises(pkg.DQNError, match="older than"):
+        gpu.step_scalars(tickets[0])
+    with pytest.raises(pkg.DQNError, match="never issued"):
+        gpu.step_scalars(tickets[-1] + 1)
+    np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+    np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
+    lg = gpu.train_steps(4)                               # the batched entry point afterwards
+    for _ in range(4):
+        lc = cpu.train_step(want_td=False)
+    assert lg == lc
+    gpu.close(); cpu.close()
