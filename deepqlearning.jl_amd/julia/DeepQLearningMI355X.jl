@@ -176,6 +176,20 @@ function batch_train!(solver::DeepQLearningSolver, env::AbstractEnv, policy::Abs
     return loss[], gn[]
 end
 
+# The same step WITHOUT waiting for it (feed-forward engines): returns once the step is enqueued; the ticket names the (loss, grad_norm) record the
+# step's last launch publishes into a mapped host ring.  The reference looks at batch_train!'s return values only every log_freq env steps
+# (src/solver.jl:154-167), so the shim's dqn_train! loop below trains with this call and fetches the scalars of the newest step when it logs.
+function batch_train_async!(replay::HIPReplayBuffer)
+    ticket = Ref{UInt64}(0)
+    check(ccall((:dqn_train_step_async, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ref{UInt64}), replay.e.h, C_NULL, ticket))
+    return ticket[]
+end
+function step_scalars(e::Engine, ticket::UInt64; wait::Bool = true)
+    loss = Ref{Float32}(0); gn = Ref{Float32}(0); pub = Ref{UInt64}(0)
+    check(ccall((:dqn_step_scalars, LIB), Cint, (Ptr{Cvoid}, UInt64, Cint, Ref{Float32}, Ref{Float32}, Ref{UInt64}), e.h, ticket, wait ? 1 : 0, loss, gn, pub))
+    return pub[] == ticket ? (loss[], gn[]) : nothing
+end
+
 # n sampled batch_train! steps back to back with nothing in between (no reference equivalent: offline / catch-up training on a filled replay).
 # Bit-identical to n batch_train! calls; inside the call step i's last launch already gathers step i+1's batch (dqn_train_steps).
 function train_steps!(e::Engine, n::Integer)
@@ -234,6 +248,16 @@ function getnetwork(p::HIPNNPolicy)                    # Flux.params(active_q) <
     p.qnetwork
 end
 resetstate!(p::HIPNNPolicy) = check(ccall((:dqn_reset_state, LIB), Cint, (Ptr{Cvoid},), p.e.h))   # Flux.reset!: Recur state <- state0
+# hiddenstates(m) / sethiddenstates!(m, hs) (src/helpers.jl:61-79) for the policy's Recur state, which lives in the engine: flat Float32 vector, per LSTM
+# layer h then c.  The engine keeps it apart from the train step's sequences, so the save / restore the reference does around batch_train! (:137-139) is a no-op
+# here; these exist for callers that checkpoint or transplant the state themselves.
+function hiddenstates(p::HIPNNPolicy)
+    n = sum(Int[2 * size(l.cell.Wh, 2) for l in filter(l -> l isa Flux.Recur, collect(p.qnetwork))])      # Wh: (4h, h)
+    hc = zeros(Float32, n)
+    check(ccall((:dqn_get_hidden, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), p.e.h, hc, n))
+    hc
+end
+sethiddenstates!(p::HIPNNPolicy, hc::Vector{Float32}) = check(ccall((:dqn_set_hidden, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), p.e.h, hc, length(hc)))
 actionmap(p::HIPNNPolicy) = p.action_map
 function _q(p::HIPNNPolicy, o)
     ndims(o) == p.n_input_dims || throw("NNPolicyError: was expecting an array with $(p.n_input_dims) dimensions, got $(ndims(o))")
@@ -297,7 +321,7 @@ function dqn_train!(solver::DeepQLearningSolver, env::AbstractEnv, policy::HIPNN
     action_indices = Dict(a => i for (i, a) in enumerate(actionmap(policy)))
     ep_rewards = Float64[0.0]; ep_steps = Int64[]; step = 0
     best_eval = -Inf; scores_eval = -Inf; model_saved = false; eval_next = false; save_next = false
-    loss_val = NaN32; grad_val = NaN32
+    loss_val = NaN32; grad_val = NaN32; ticket = UInt64(0)
     for t in 1:solver.max_steps
         act = action(solver.exploration_policy, policy, t, obs)
         rew = act!(env, act); op = observe(env); done = terminated(env)
@@ -325,8 +349,12 @@ function dqn_train!(solver::DeepQLearningSolver, env::AbstractEnv, policy::HIPNN
             reset!(env); obs = observe(env); resetstate!(policy)
             push!(ep_steps, step); push!(ep_rewards, 0.0); step = 0
         end
-        if t % solver.train_freq == 0
-            loss_val, grad_val = batch_train!(solver, env, policy, nothing, nothing, replay)      # ONE ccall, :136-140
+        if t % solver.train_freq == 0                                                            # ONE ccall, :136-140
+            if replay isa HIPReplayBuffer
+                ticket = batch_train_async!(replay)          # returns once enqueued: the env loop runs on while the GPU trains
+            else
+                loss_val, grad_val = batch_train!(solver, env, policy, nothing, nothing, replay)
+            end
         end
         t % solver.target_update_freq == 0 && sync_target!(policy)                             # :142-145 inside the engine
         t % solver.eval_freq == 0 && (eval_next = true)
@@ -335,6 +363,7 @@ function dqn_train!(solver::DeepQLearningSolver, env::AbstractEnv, policy::HIPNN
             nt = POMDPTools.loginfo(solver.exploration_policy, t)
             for (k, v) in pairs(nt); log_value(logger, String(k), v, step = t); end
             avg100 = mean(ep_rewards[max(1, length(ep_rewards) - 101):end])
+            ticket != 0 && ((loss_val, grad_val) = step_scalars(policy.e, ticket))      # (loss, grad_norm) of the newest train step: the values :154-167 print
             solver.verbose && @printf("%5d / %5d eps %0.3f |  avgR %1.3f | Loss %2.3e | Grad %2.3e | EvalR %1.3f \n",
                                       t, solver.max_steps, nt[1], avg100, loss_val, grad_val, scores_eval)
             log_value(logger, "avg_reward", avg100, step = t); log_value(logger, "loss", loss_val, step = t); log_value(logger, "grad_val", grad_val, step = t)

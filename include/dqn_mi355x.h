@@ -196,7 +196,8 @@ int dqn_train_step_drqn(dqn_engine_t* e, const int64_t* ep_idx, const int32_t* e
 /* Recur state of the POLICY network (src/policy.jl:32-34 resetstate!, src/helpers.jl:61-79 hiddenstates/sethiddenstates!):
  * dqn_forward / dqn_greedy_action advance it for recurrent networks (n streams, one per observation row). */
 int dqn_reset_state(dqn_engine_t* e);
-int dqn_get_hidden(dqn_engine_t* e, float* hc, size_t n /* sum over LSTM layers of 2*out*streams */);
+/* n = sum over LSTM layers of 2 x out x streams floats: per layer h then c, each [out][streams] (streams = observations per dqn_forward call, 1 before the first) */
+int dqn_get_hidden(dqn_engine_t* e, float* hc, size_t n);
 int dqn_set_hidden(dqn_engine_t* e, const float* hc, size_t n);
 
 /* NNPolicy: actionvalues / action / value (src/policy.jl:38-64) for n observations
