@@ -30,7 +30,7 @@ __device__ __forceinline__ float adam_upd(float gi, float& mi, float& vi, float&
 }
 // workgroup `bid` (256 threads) of job J.  sidx: 1024 long longs of LDS for the priority block (unused when the job has none or it runs
 // elsewhere); wmax: 4 floats of LDS.
-__device__ __forceinline__ void adam_job_run(const AdamJob& J, int bid, long long* sidx, float* wmax, bool prio_elsewhere = false, unsigned sidx_bytes = 0) {
+__device__ __forceinline__ void adam_job_run(const AdamJob& J, int bid, long long* sidx, float* wmax, bool prio_elsewhere = false, unsigned sidx_bytes = 0, float* fold_buf = nullptr) {
     if (J.prio.n > 0 && !prio_elsewhere) {
         // update_priorities!(replay, indices, td): one DEDICATED workgroup walks the sum-tree while the others stream -- its latency-bound
         // levels ride inside a longer launch instead of costing one of their own; the tree is next read by the following step's sampler
@@ -43,6 +43,39 @@ __device__ __forceinline__ void adam_job_run(const AdamJob& J, int bid, long lon
     const double bp1 = J.state->bp[slot][0], bp2 = J.state->bp[slot][1];
     const bool rblock = bid < (int)J.segs.blocks;
     if (J.tick && bid == (int)J.segs.blocks && threadIdx.x == 0) { J.state->bp[slot ^ 1][0] = bp1 * J.b1; J.state->bp[slot ^ 1][1] = bp2 * J.b2; }
+    if (J.tick && J.fold_hl && fold_buf && bid == (int)J.segs.blocks) {      // recurrent fused step: loss fold in the twin's order (t outer, b inner, / B per step, / T at the end)
+        // rows of B terms come in through LDS (all loads of a round in flight at once); one thread per row adds its B terms in order, thread 0 then adds the
+        // rows' lsum / B in row order -- the association of oracle/dqn_ref.c, with the T rows advancing side by side
+        const int B = J.fold_B, T = J.fold_T; float loss = 0.0f;
+        if (B <= 128) {
+            const int rpc = 256 / B;                                   // rows per round
+            for (int t0 = 0; t0 < T; t0 += rpc) {
+                const int nr = T - t0 < rpc ? T - t0 : rpc;
+                if ((int)threadIdx.x < nr * B) fold_buf[threadIdx.x] = J.fold_hl[t0 * B + threadIdx.x];
+                __syncthreads();
+                float lsum = 0.0f;
+                if ((int)threadIdx.x < nr) {
+                    const float* r = fold_buf + threadIdx.x * B;
+                    for (int b = 0; b < B; b += 8) {
+                        float v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) v[q] = b + q < B ? r[b + q] : 0.0f;
+#pragma unroll
+                        for (int q = 0; q < 8; q++) if (b + q < B) lsum = lsum + v[q];
+                    }
+                    lsum = lsum / (float)B;
+                }
+                __syncthreads();
+                if ((int)threadIdx.x < nr) fold_buf[threadIdx.x] = lsum;
+                __syncthreads();
+                if (threadIdx.x == 0) for (int r = 0; r < nr; r++) loss = loss + fold_buf[r];
+                __syncthreads();
+            }
+        } else if (threadIdx.x == 0) {
+            for (int t = 0; t < T; t++) { float lsum = 0.0f; for (int b = 0; b < B; b++) lsum = lsum + J.fold_hl[t * B + b]; loss = loss + lsum / (float)B; }
+        }
+        if (threadIdx.x == 0) { J.state->loss = loss / (float)T; if (J.bump_ctr) *J.bump_ctr = *J.bump_ctr + 1; }
+    }
     float gmax = 0.0f;
     if (rblock) {
         size_t e = (size_t)bid * blockDim.x + threadIdx.x;      // index into the concatenation of the segments

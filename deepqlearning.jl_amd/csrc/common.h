@@ -48,6 +48,7 @@ struct StepState {
 // (loss, grad_norm) of a train step as the step's LAST launch publishes them into mapped pinned HOST memory (k_publish_scalars): the host reads
 // them without a fold launch, a D2H copy or a stream synchronize.  A ring of DQN_MAIL_SLOTS records indexed by the publish sequence number.
 #define DQN_MAIL_SLOTS 64
+#define DQN_DRAW_SLOTS 64      /* episode-draw ring of the fused recurrent step (DrqnColsArgs) */
 struct StepMail {
     float loss, gnorm; int err, pad;
     unsigned long long step;           // StepState::step when published (train steps started so far)
@@ -461,6 +462,8 @@ struct AdamJob {
     int f64mode; float lr; double b1, b2, eps; float gscale;
     int nr; unsigned long long beg[4], end[4];
     AdamSegs segs; PrioArgs prio; int tick; unsigned sblocks;
+    // recurrent fused step: the tick thread also folds the loss from the per-column Huber terms, loss = (sum_t (sum_b hl[t*B + b]) / B) / T (src/solver.jl:276-281)
+    const float* fold_hl; int fold_T, fold_B; unsigned long long* bump_ctr;      // bump_ctr: the draw-ring sequence number of the fused recurrent step, +1 per step
 };
 static inline __host__ __device__ unsigned adam_job_blocks(const AdamJob& j) { return (j.prio.n > 0 ? 1u : 0u) + j.segs.blocks + j.sblocks; }
 
@@ -571,6 +574,49 @@ struct TinyArgs {
     int f64mode; float lr; double b1, b2, adam_eps;
 };
 void launch_tiny_step(hipStream_t st, const TinyArgs* a_dev, unsigned lds_bytes, int sample);
+
+// ---- the recurrent train step (batch_train!(..., ::EpisodeReplayBuffer), src/solver.jl:239-287) as a COLUMN-PARALLEL launch (drqn_cols.hip; BASELINE config 4):
+// batch columns never interact before the gradient sum, so workgroup g owns the batch columns [g*cg, (g+1)*cg) for the WHOLE step -- episode gather (prefix quirk),
+// both target passes and the online pass of the LSTM, heads, TD / masked Huber, BPTT, and its chunk of every dW / db (the column-group chunks of the summation plan,
+// dw_kc = -cg) -- with the parameters of both networks and all of its columns' activations in LDS; the step's second launch (the Adam launch) adds the G = B / cg
+// slabs in ascending order, folds the loss and updates.  Networks: Chain(flattenbatch, LSTM(E, H), Dense(H, nA)) with or without the dueling split of the head.
+struct DrqnColsArgs {
+    int B, T, H, E, nA, dueling, double_q, cg, nset; float gamma;
+    unsigned Pint;                                              // floats of the internal parameter vector (a multiple of 4)
+    unsigned wi_off, b_off, wh_off, h0_off, c0_off;             // LSTM block [Wi E x 4H][b 4H][Wh H x 4H][junk 4H][h0 H][c0 H][zeros 4H]
+    unsigned hw_off[2], hb_off[2]; int hN[2], hact[2], h_S[2], h_kc[2];      // heads: [0] = advantage stream (or the plain Q head), [1] = value stream; forward plan chunks of K = H
+    const float *p_on, *p_tg;
+    const float *ep_s, *ep_sp; const int* ep_a; const float* ep_r; const unsigned char* ep_done; const int* ep_len;
+    // the step's episode draws: slot (*draw_seq % draw_slots) of a mapped pinned HOST ring written by dqn_train_step_drqn (no H2D copy launch per step; the Adam launch
+    // of the step bumps *draw_seq)
+    const long long* ring_idx; const int* ring_np; const unsigned long long* draw_seq; int draw_slots;      // ring_np: rows the prefix copy delivers = max(0, min(len, T) - start)
+    float* slabs;                                               // [B / cg][Pint] per-workgroup gradient chunks
+    float *hl, *td;                                             // [T*B] Huber terms (folded by the Adam launch), TD errors
+    StepState* st;
+    int probe;                                                  // TIMING PROBES (DQN_DRQN_PROBE at creation; wrong numbers, right schedule): bit 0 = single-precision hardware exp instead of the Float64 sigm / tanh
+    unsigned long long* stamps;                                 // timing probe (DQN_DRQN_STAMPS at creation, tools/drqn_phases.py): 100 MHz s_memrealtime at the phase boundaries of workgroup 0, else null
+};
+// the column-group size of the fused recurrent step for this network, 0 = not covered (the twin restates this rule: oracle/dqn_ref.c fused_cg)
+static inline int drqn_fused_cg(const LayerDev* L, int nl, int E, int B, int T, int nA, int dueling, int double_q, int recurrence) {
+    if (!recurrence) return 0;
+    const int duel = dueling ? 1 : 0;
+    if (nl != (duel ? 3 : 2) || L[0].kind != DQN_LAYER_LSTM || L[0].stream != DQN_STREAM_BASE || L[0].src >= 0) return 0;
+    const int H = L[0].H, N = 4 * H;
+    if (L[0].K != E || H < 8 || H > 64 || H % 8 || T < 1 || T > 64 || nA > 16 || E > 512) return 0;
+    if (!duel) { if (L[1].kind != DQN_LAYER_DENSE || L[1].stream != DQN_STREAM_BASE || L[1].K != H || L[1].N != nA) return 0; }
+    else if (L[1].kind != DQN_LAYER_DENSE || L[1].stream != DQN_STREAM_VAL || L[1].K != H || L[1].N != 1 ||
+             L[2].kind != DQN_LAYER_DENSE || L[2].stream != DQN_STREAM_ADV || L[2].K != H || L[2].N != nA) return 0;
+    const int nset = double_q ? 3 : 2, Ep = (E + 3) / 4 * 4, no = nA + duel;
+    const long pp = (long)(E + 1) * N + (long)(H + 1) * N + 2 * H + N + (long)(H + 1) * no + 32;
+    for (int c = 4; c >= 1; c >>= 1) {
+        if (B % c || nset * 4 * H * c > 1024) continue;
+        const long lds = 2 * pp + 2L * T * c * Ep + 4L * T * c + (long)nset * T * H * c + (long)nset * 7 * H * c + (long)T * N * c + 3L * T * H * c +
+                         (long)(nset + 1) * T * c * (no + 1) + (long)T * H * c + 2L * H * c + (long)H * (N + 4) + 64;
+        if (lds <= 36000) return c;
+    }
+    return 0;
+}
+int launch_drqn_cols(hipStream_t st, const DrqnColsArgs& a, const DrqnColsArgs* a_dev);      // 0 = launched; -1 = the LDS attribute could not be raised
 int adam_blocks(size_t P);
 static inline int gmax_slots(size_t) { return 65536; }   // per-block max |g| of every Adam job of a step (each job owns a slot range)
 void launch_adam(hipStream_t st, const AdamJob& job, const PreGather* pg = nullptr /* see PreGather */);
@@ -637,13 +683,13 @@ __device__ __forceinline__ float slab_sum(const float* __restrict__ p, size_t st
 #pragma unroll
         for (int u = 0; u < 32; u++) tot = tot + v[u];
     }
-    for (; s < S; s += 8) {
-        const int m = S - s < 8 ? S - s : 8;
-        float v[8];
+    for (; s < S; s += 16) {      // (r04: rounds of 16 -- the 16 column-group slabs of the fused recurrent step are ONE round trip instead of three)
+        const int m = S - s < 16 ? S - s : 16;
+        float v[16];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = u < m ? p[(size_t)(s + u) * stride] : 0.0f;
+        for (int u = 0; u < 16; u++) v[u] = u < m ? p[(size_t)(s + u) * stride] : 0.0f;
 #pragma unroll
-        for (int u = 0; u < 8; u++) if (u < m) tot = tot + v[u];
+        for (int u = 0; u < 16; u++) if (u < m) tot = tot + v[u];
     }
     return tot;
 }

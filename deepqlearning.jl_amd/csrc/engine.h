@@ -65,7 +65,7 @@ struct dqn_engine {
     float *gx_on[DQN_MAX_LAYERS] = {}, *gx_tg[DQN_MAX_LAYERS] = {}, *cst_on[DQN_MAX_LAYERS] = {}, *cst_tg[DQN_MAX_LAYERS] = {}, *gates[DQN_MAX_LAYERS] = {}, *tcb[DQN_MAX_LAYERS] = {},
           *hprev_buf[DQN_MAX_LAYERS] = {}, *cprev_buf[DQN_MAX_LAYERS] = {}, *dG[DQN_MAX_LAYERS] = {}, *dhn[DQN_MAX_LAYERS] = {}, *dcn[DQN_MAX_LAYERS] = {};
     float *pol_h[DQN_MAX_LAYERS][2] = {}, *pol_c[DQN_MAX_LAYERS][2] = {}, *pol_gx[DQN_MAX_LAYERS] = {}; int pol_flip = 0, pol_state_n = 0; uint64_t drqn_draws = 0;
-    hipGraphExec_t g_drqn = nullptr;
+    hipGraphExec_t g_drqn = nullptr, g_drqn_k = nullptr;      // g_drqn_k: a run of fused recurrent steps as one graph (engine_drqn.hip drqn_train_steps)
     // static launch program
     struct Step { const char* name; std::function<void(dqn_engine*)> fn; };
     // acting programs (forward on n columns + env kernels), one for the training envs and one for the evaluation envs
@@ -87,6 +87,11 @@ struct dqn_engine {
     bool pg_ok = false, step_pregather = false, step_take_pre = false; PreGather pg; long adam_step = -1;
     bool no_tiny = false;   // DQN_NO_TINY at dqn_engine_create: always the multi-launch program
     bool tiny = false;      // the whole step is ONE single-workgroup launch that samples and gathers itself (tiny_step.hip)
+    // fused recurrent step: episode draws travel through a mapped pinned host ring (slot = step % DQN_DRAW_SLOTS) the kernel reads directly
+    long long *draw_idx_h = nullptr, *draw_idx_d = nullptr; int *draw_start_h = nullptr, *draw_start_d = nullptr; unsigned long long* draw_seq = nullptr; unsigned long long draw_issued = 0;
+    hipEvent_t draw_ev[2] = {nullptr, nullptr};
+    unsigned long long* drqn_stamps = nullptr;      // timing probe of the fused recurrent step (DQN_DRQN_STAMPS)
+    bool drqn_fused = false;      // recurrent step = the column-parallel launch (which gathers its own episode rows) + the Adam launch (drqn_cols.hip)
     hipGraphExec_t g_pgv[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [take_pre][pregather] variants of the sampled single-device step
     hipGraphExec_t g_mid = nullptr; int mid_group = 4;                          // mid_group consecutive middle steps of dqn_train_steps as one graph
     hipGraphExec_t g_mid_big = nullptr; int mid_big = 16;                       // ... and runs of mid_big of them (DQN_MID_BIG; 0 = off): 20 steps = first + 16 + 2 single + last
@@ -122,6 +127,8 @@ int run_step(dqn_engine* e, bool sample, bool take_pre = false, bool pregather =
 int fetch_scalars(dqn_engine* e, float* loss, float* gn);
 int policy_ws(dqn_engine* e, int n);
 int policy_state(dqn_engine* e, int n, bool force_reset);
+// engine_drqn.hip
+int drqn_train_steps(dqn_engine* e, int n, float* loss, float* grad_norm);
 // engine_program.hip
 template <class T> static T* upload(dqn_engine* e, const std::vector<T>& v) {
     T* d = nullptr; hipMalloc((void**)&d, sizeof(T) * v.size()); hipMemcpy(d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice);

@@ -112,7 +112,7 @@ static int build_layers(const dqn_layer_desc* d, int n, const dqn_hparams* hp, L
 }
 // The default summation-order plan.  Chosen for gfx950 occupancy: long forward contractions
 // are cut into ~512-element chunks, dense dX into 256-element chunks, conv dW into ~256-sample chunks.
-static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out) {
+static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out, const dqn_hparams* hp) {
     bool rec = false; for (int i = 0; i < n; i++) rec = rec || L[i].kind == DQN_LAYER_LSTM;
     for (int i = 0; i < n; i++) {
         out[i].fwd_kc = 0;
@@ -148,11 +148,14 @@ static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out) {
             }
         }
     }
+    // recurrent networks the fused column-parallel step covers (drqn_cols.hip): dW / db chunks = groups of cg batch columns, one workgroup each
+    const int cg = drqn_fused_cg(L, n, hp->obs_c * hp->obs_h * hp->obs_w, B, hp->trace_length, hp->n_actions, hp->dueling, hp->double_q, hp->recurrence);
+    if (cg) for (int i = 0; i < n; i++) out[i].dw_kc = -cg;
 }
 extern "C" int dqn_plan_default(const dqn_layer_desc* layers, int n_layers, const dqn_hparams* hp, dqn_layer_plan* plan_out) {
     LayerDev L[DQN_MAX_LAYERS]; int lb, lv, la; size_t P, Pi;
     if (build_layers(layers, n_layers, hp, L, &lb, &lv, &la, &P, &Pi)) return -1;
-    default_plan(L, n_layers, hp->batch_size, plan_out); return 0;
+    default_plan(L, n_layers, hp->batch_size, plan_out, hp); return 0;
 }
 
 
@@ -187,10 +190,11 @@ static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers
     if (const char* mb = getenv("DQN_MID_BIG")) e->mid_big = atoi(mb);
     if (const char* sw = getenv("DQN_SIM_WORLD")) { const int k = atoi(sw); if (k >= 1 && !hp->recurrence) { e->sim_world = k; e->world = k; } }   // tests: one process plays k identical ranks
     dqn_layer_plan defp[DQN_MAX_LAYERS];
-    if (!plan) { default_plan(e->L, e->nl, e->B, defp); plan = defp; }
+    if (!plan) { default_plan(e->L, e->nl, e->B, defp, hp); plan = defp; }
     for (int i = 0; i < e->nl; i++) {
         e->L[i].fwd_kc = plan[i].fwd_kc; e->L[i].dx_kc = plan[i].dx_kc; e->L[i].dw_kc = plan[i].dw_kc;
         if (e->L[i].kind == DQN_LAYER_CONV && e->L[i].dw_kc > 0 && e->L[i].dw_kc % e->B && (e->B % 32 || e->L[i].dw_kc % 32)) return fail("plan: conv dw_kc must be a multiple of batch_size (or, for batch sizes divisible by 32, of 32)");
+        if (e->L[i].dw_kc < 0 && (!hp->recurrence || e->B % (-e->L[i].dw_kc))) return fail("plan: dw_kc < 0 (column-group chunks of %d batch columns) needs recurrence = true and a group size that divides batch_size", -e->L[i].dw_kc);
     }
     HIPCHK(hipSetDevice(device));
     gemm_set_ktrace(nullptr);      // trace builds: (re)reads DQN_PROBE; a no-op otherwise
@@ -276,6 +280,8 @@ void drop_graphs(dqn_engine* e) {
     if (e->g_post) { hipGraphExecDestroy(e->g_post); e->g_post = nullptr; }
     if (e->g_post_pg) { hipGraphExecDestroy(e->g_post_pg); e->g_post_pg = nullptr; }
     if (e->g_mid) { hipGraphExecDestroy(e->g_mid); e->g_mid = nullptr; }
+    if (e->g_drqn_k) { hipGraphExecDestroy(e->g_drqn_k); e->g_drqn_k = nullptr; }
+    if (e->g_drqn) { hipGraphExecDestroy(e->g_drqn); e->g_drqn = nullptr; }
     if (e->g_mid_big) { hipGraphExecDestroy(e->g_mid_big); e->g_mid_big = nullptr; }
     if (e->g_pre_tp) { hipGraphExecDestroy(e->g_pre_tp); e->g_pre_tp = nullptr; }
     for (int i = 0; i < 3; i++) if (e->g_pre1[i]) { hipGraphExecDestroy(e->g_pre1[i]); e->g_pre1[i] = nullptr; }
@@ -306,6 +312,9 @@ extern "C" int dqn_engine_destroy(dqn_engine_t* e) {
     hipFree(e->s_rows); hipFree(e->sp_rows); hipFree(e->ra); hipFree(e->rr); hipFree(e->rdone); hipFree(e->tree);
     if (e->state_host) hipHostFree(e->state_host);
     if (e->mail_host) hipHostFree(e->mail_host);
+    if (e->draw_idx_h) hipHostFree(e->draw_idx_h);
+    if (e->draw_start_h) hipHostFree(e->draw_start_h);
+    hipFree(e->draw_seq); for (int k = 0; k < 2; k++) if (e->draw_ev[k]) hipEventDestroy(e->draw_ev[k]);
     hipFree(e->pub_ctr);
     hipFree(e->st_a); hipFree(e->st_r); hipFree(e->st_done); hipFree(e->st_td); hipFree(e->idx); hipFree(e->idx_pre); hipFree(e->x0);
     for (int i = 0; i < e->nl; i++) { hipFree(e->act_on[i]); hipFree(e->act_tg[i]); hipFree(e->dact[i]); }
@@ -318,7 +327,6 @@ extern "C" int dqn_engine_destroy(dqn_engine_t* e) {
     hipFree(e->r_a); hipFree(e->r_r); hipFree(e->r_done); hipFree(e->r_mask);
     for (int i = 0; i < e->nl; i++) { hipFree(e->gx_on[i]); hipFree(e->gx_tg[i]); hipFree(e->cst_on[i]); hipFree(e->cst_tg[i]); hipFree(e->gates[i]); hipFree(e->tcb[i]); hipFree(e->hprev_buf[i]);
         hipFree(e->cprev_buf[i]); hipFree(e->dG[i]); hipFree(e->dhn[i]); hipFree(e->dcn[i]); for (int k = 0; k < 2; k++) { hipFree(e->pol_h[i][k]); hipFree(e->pol_c[i][k]); } hipFree(e->pol_gx[i]); }
-    if (e->g_drqn) hipGraphExecDestroy(e->g_drqn);
     if (e->stream) hipStreamDestroy(e->stream);
     if (e->stream2) hipStreamDestroy(e->stream2);
     if (e->stream3) hipStreamDestroy(e->stream3);
@@ -543,7 +551,7 @@ void enqueue_step(dqn_engine* e, bool sample, int phase) {
         if (e->hp.recurrence) {
             EpGatherArgs g; g.ep_s = e->ep_s; g.ep_sp = e->ep_sp; g.ep_a = e->ep_a; g.ep_r = e->ep_r; g.ep_done = e->ep_done; g.ep_len = e->ep_len; g.ep_idx = e->ep_idx; g.ep_start = e->ep_start;
             g.E = e->E; g.B = e->B; g.T = e->T; g.x0 = e->x0; g.a_out = e->r_a; g.r_out = e->r_r; g.done_out = e->r_done; g.mask_out = e->r_mask;
-            RUN(e, "gather_episodes", launch_gather_episodes(e->stream, g));
+            if (!e->drqn_fused) RUN(e, "gather_episodes", launch_gather_episodes(e->stream, g));      // the fused recurrent step gathers its own columns (drqn_cols.hip)
         } else {
             // the descent is fused into the gather (every workgroup repeats it) while that is cheaper than a launch of its own:
             // small batches.  At B = 512 / 1e6 leaves the repeats cost more than the ~5 us launch, so sample once, then gather.
@@ -810,7 +818,7 @@ extern "C" int dqn_sim_ranks_step(dqn_engine_t* e, const int64_t* idx, float* lo
 }
 extern "C" int dqn_train_steps(dqn_engine_t* e, int n, float* loss, float* grad_norm) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device));
-    if (e->hp.recurrence) { for (int i = 0; i < n; i++) if (dqn_train_step_drqn(e, nullptr, nullptr, i + 1 == n ? loss : nullptr, i + 1 == n ? grad_norm : nullptr)) return -1; return 0; }
+    if (e->hp.recurrence) return drqn_train_steps(e, n, loss, grad_norm);
     if (e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
     if (build_program(e)) return -1;
     // between the steps of this call nothing else touches the replay: step i's Adam launch gathers step i+1's batch (PreGather)

@@ -101,29 +101,74 @@ extern "C" int dqn_episode_get_batch(dqn_engine_t* e, const int64_t* ep_idx, con
     }
     return 0;
 }
+// sample(rng, 1:n, B, replace=false); ep_start = rand(rng, 1:length(ep))  (src/episode_replay.jl:75,81) -- host-side SplitMix draws
+static int drqn_host_draws(dqn_engine* e, std::vector<int64_t>& di, std::vector<int32_t>& ds) {
+    if (e->ep_size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
+    auto next = [&]() { uint64_t z = (e->drqn_draws += 0x9E3779B97F4A7C15ull) ^ e->hp.seed; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+    // partial Fisher-Yates on a persistent identity permutation: B swaps, read the prefix, undo the swaps (O(B) per step, same
+    // draws as shuffling a fresh 0..n-1 vector)
+    std::vector<int64_t>& perm = e->ep_perm;
+    if ((long long)perm.size() != e->ep_size) { perm.resize((size_t)e->ep_size); for (size_t i = 0; i < perm.size(); i++) perm[i] = (int64_t)i; }
+    std::vector<size_t> js((size_t)e->B);
+    for (int b = 0; b < e->B; b++) { js[b] = b + (size_t)(next() % (perm.size() - b)); std::swap(perm[b], perm[js[b]]); }
+    di.assign(perm.begin(), perm.begin() + e->B); ds.resize(e->B);
+    for (int b = e->B - 1; b >= 0; b--) std::swap(perm[b], perm[js[b]]);
+    for (int b = 0; b < e->B; b++) { const int len = e->ep_len_host[(size_t)di[b]]; ds[b] = len > 0 ? (int32_t)(next() % (uint64_t)len) : 0; }
+    return 0;
+}
+// fused recurrent step: the draws of the next step go into slot (step % DQN_DRAW_SLOTS) of the mapped host ring the step's kernel reads -- no H2D copy launch, the
+// host never waits for the GPU (before a half of the ring is reused, the event recorded behind the steps that last read it must have passed)
+static int drqn_ring_put(dqn_engine* e, unsigned long long s, const int64_t* ep_idx, const int32_t* ep_start) {
+    const int half = DQN_DRAW_SLOTS / 2;
+    if (s >= (unsigned long long)DQN_DRAW_SLOTS && s % half == 0) HIPCHK(hipEventSynchronize(e->draw_ev[(s / half) & 1]));
+    const size_t slot = (size_t)(s % DQN_DRAW_SLOTS) * e->B;
+    memcpy(e->draw_idx_h + slot, ep_idx, (size_t)e->B * 8);
+    for (int b = 0; b < e->B; b++) {      // what the kernel needs of (length, start): the number of rows the prefix copy delivers (src/episode_replay.jl:82-92)
+        const int len = e->ep_len_host[(size_t)ep_idx[b]]; int np = (len < e->T ? len : e->T) - ep_start[b]; e->draw_start_h[slot + b] = np < 0 ? 0 : np;
+    }
+    return 0;
+}
+static int drqn_ring_done(dqn_engine* e, int nsteps) {      // nsteps fused steps were enqueued (nsteps divides the half ring, or is 1)
+    const int half = DQN_DRAW_SLOTS / 2; const unsigned long long before = e->draw_issued / half;
+    e->draw_issued += (unsigned long long)nsteps;
+    if (e->draw_issued / half != before) HIPCHK(hipEventRecord(e->draw_ev[((e->draw_issued / half) - 1) & 1], e->stream));
+    return 0;
+}
 extern "C" int dqn_train_step_drqn(dqn_engine_t* e, const int64_t* ep_idx, const int32_t* ep_start, float* loss, float* grad_norm) { if (!e) return fail("null engine handle");
     NEED_REC(e); HIPCHK(hipSetDevice(e->device));
     std::vector<int64_t> di; std::vector<int32_t> ds;
-    if (!ep_idx) {   // sample(rng, 1:n, B, replace=false); ep_start = rand(rng, 1:length(ep))  (src/episode_replay.jl:75,81) -- host-side SplitMix draws
-        if (e->ep_size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
-        auto next = [&]() { uint64_t z = (e->drqn_draws += 0x9E3779B97F4A7C15ull) ^ e->hp.seed; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
-        // partial Fisher-Yates on a persistent identity permutation: B swaps, read the prefix, undo the swaps (O(B) per step, same
-        // draws as shuffling a fresh 0..n-1 vector)
-        std::vector<int64_t>& perm = e->ep_perm;
-        if ((long long)perm.size() != e->ep_size) { perm.resize((size_t)e->ep_size); for (size_t i = 0; i < perm.size(); i++) perm[i] = (int64_t)i; }
-        std::vector<size_t> js((size_t)e->B);
-        for (int b = 0; b < e->B; b++) { js[b] = b + (size_t)(next() % (perm.size() - b)); std::swap(perm[b], perm[js[b]]); }
-        di.assign(perm.begin(), perm.begin() + e->B); ds.resize(e->B);
-        for (int b = e->B - 1; b >= 0; b--) std::swap(perm[b], perm[js[b]]);
-        for (int b = 0; b < e->B; b++) { const int len = e->ep_len_host[(size_t)di[b]]; ds[b] = len > 0 ? (int32_t)(next() % (uint64_t)len) : 0; }
-        ep_idx = di.data(); ep_start = ds.data();
-    }
-    if (drqn_check(e, ep_idx, ep_start) || drqn_upload_draws(e, ep_idx, ep_start)) return -1;
+    if (!ep_idx) { if (drqn_host_draws(e, di, ds)) return -1; ep_idx = di.data(); ep_start = ds.data(); }
+    if (drqn_check(e, ep_idx, ep_start)) return -1;
     if (build_program(e)) return -1;
+    if (e->drqn_fused) { if (drqn_ring_put(e, e->draw_issued, ep_idx, ep_start)) return -1; __atomic_thread_fence(__ATOMIC_RELEASE); }
+    else if (drqn_upload_draws(e, ep_idx, ep_start)) return -1;
     if (e->hp.use_graph && !e->profiling && e->world == 1) {
         if (!e->g_drqn && capture(e, false, PH_ALL, &e->g_drqn)) return -1;
         HIPCHK(hipGraphLaunch(e->g_drqn, e->stream));
     } else { enqueue_step(e, false, PH_PRE); if (e->world > 1 && exchange_grads(e)) return -1; enqueue_step(e, false, PH_POST); }
+    if (e->drqn_fused && drqn_ring_done(e, 1)) return -1;
+    if (loss || grad_norm) return fetch_scalars(e, loss, grad_norm);
+    return 0;
+}
+// n sampled recurrent steps back to back (dqn_train_steps on a recurrent engine).  Fused step: every step reads ITS slot of the draw ring (the device-side sequence
+// number advances per step), so runs of DRQN_GROUP steps replay as ONE graph -- the draws of the whole run are written first, then one hipGraphLaunch.
+int drqn_train_steps(dqn_engine* e, int n, float* loss, float* grad_norm) {
+    enum { DRQN_GROUP = 8 };      // divides DQN_DRAW_SLOTS / 2
+    if (build_program(e)) return -1;
+    const bool grouped = e->drqn_fused && e->hp.use_graph && !e->profiling && e->world == 1;
+    std::vector<int64_t> di; std::vector<int32_t> ds;
+    for (int i = 0; i < n;) {
+        if (grouped && n - i >= DRQN_GROUP && e->draw_issued % DRQN_GROUP == 0) {
+            if (!e->g_drqn_k && capture(e, false, PH_ALL, &e->g_drqn_k, DRQN_GROUP)) return -1;
+            for (int k = 0; k < DRQN_GROUP; k++) { if (drqn_host_draws(e, di, ds) || drqn_check(e, di.data(), ds.data()) || drqn_ring_put(e, e->draw_issued + k, di.data(), ds.data())) return -1; }
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+            HIPCHK(hipGraphLaunch(e->g_drqn_k, e->stream));
+            if (drqn_ring_done(e, DRQN_GROUP)) return -1;
+            i += DRQN_GROUP; continue;
+        }
+        if (dqn_train_step_drqn(e, nullptr, nullptr, nullptr, nullptr)) return -1;
+        i++;
+    }
     if (loss || grad_norm) return fetch_scalars(e, loss, grad_norm);
     return 0;
 }
@@ -153,3 +198,10 @@ extern "C" int dqn_set_hidden(dqn_engine_t* e, const float* hc, size_t n) { if (
     HIPCHK(hipStreamSynchronize(e->stream)); return 0;
 }
 
+// TIMING PROBE (tools/drqn_phases.py; not part of the public header): s_memrealtime stamps (100 MHz) of workgroup 0 at the phase boundaries of the fused recurrent
+// step, recorded when the engine was created under DQN_DRQN_STAMPS=1
+extern "C" __attribute__((visibility("default"))) int dqn_debug_drqn_stamps(dqn_engine_t* e, uint64_t* out, size_t n) { if (!e) return fail("null engine handle");
+    if (!e->drqn_stamps) return fail("no stamps: create the engine under DQN_DRQN_STAMPS=1 and run a fused recurrent step first");
+    HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(out, e->drqn_stamps, std::min<size_t>(n, 32) * 8, hipMemcpyDeviceToHost)); return 0;
+}

@@ -55,6 +55,55 @@ int build_program(dqn_engine* e) {
     std::vector<std::vector<int>> levels; std::vector<int> val, adv;
     for (int i = 0; i < e->nl; i++) { if (e->L[i].stream == DQN_STREAM_BASE) levels.push_back({i}); else if (e->L[i].stream == DQN_STREAM_VAL) val.push_back(i); else adv.push_back(i); }
     for (size_t j = 0; j < std::max(val.size(), adv.size()); j++) { std::vector<int> lv; if (j < val.size()) lv.push_back(val[j]); if (j < adv.size()) lv.push_back(adv[j]); levels.push_back(lv); }
+    // ---------------- recurrent networks with column-group dW chunks (plan dw_kc = -cg): the step is ONE column-parallel launch + the Adam launch (drqn_cols.hip; BASELINE config 4)
+    {
+        int cgm = 0; bool all_same = true;
+        for (int i = 0; i < e->nl; i++) { if (e->L[i].dw_kc < 0) cgm = -e->L[i].dw_kc; all_same = all_same && e->L[i].dw_kc == e->L[0].dw_kc; }
+        if (cgm) {
+            if (!rec || !all_same) return fail("plan: column-group dW chunks (dw_kc < 0) need recurrence = true and the same dw_kc on every layer");
+            const int nset = e->hp.double_q ? 3 : 2; const LayerDev& L0 = e->L[0];
+            bool ok = drqn_fused_cg(e->L, e->nl, e->E, Bb, T, e->nA, e->hp.dueling, e->hp.double_q, 1) > 0 && Bb % cgm == 0 && nset * 4 * L0.H * cgm <= 1024 && !e->comm && !e->sim_world && e->world <= 1;
+            if (ok) { ok = dqn_nchunks(L0.K, L0.fwd_kc) == 1; for (int i = 1; i < e->nl; i++) ok = ok && dqn_nchunks(e->L[i].N, e->L[i].dx_kc) == 1; }
+            if (!ok) return fail("plan: column-group dW chunks (dw_kc = %d) need a network the fused recurrent step covers -- Chain(flattenbatch, LSTM, Dense) with or without the dueling split, "
+                                 "H a multiple of 8 up to 64, unsplit input projection and head dX, a single device -- use the default plan or dw_kc >= 0", -cgm);
+            DrqnColsArgs a; memset(&a, 0, sizeof a);
+            a.B = Bb; a.T = T; a.H = L0.H; a.E = e->E; a.nA = e->nA; a.dueling = e->hp.dueling; a.double_q = e->hp.double_q; a.cg = cgm; a.nset = nset; a.gamma = e->hp.gamma; a.Pint = (unsigned)e->Pint;
+            a.wi_off = (unsigned)L0.w_off; a.b_off = (unsigned)L0.b_off; a.wh_off = (unsigned)L0.wh_off; a.h0_off = (unsigned)L0.h0_off; a.c0_off = (unsigned)L0.c0_off;
+            const int ha = e->hp.dueling ? e->last_adv : e->last_base, hv = e->hp.dueling ? e->last_val : -1;
+            for (int hd = 0; hd < 2; hd++) { const int l = hd == 0 ? ha : hv; if (l < 0) continue; const LayerDev& L = e->L[l];
+                a.hw_off[hd] = (unsigned)L.w_off; a.hb_off[hd] = (unsigned)L.b_off; a.hN[hd] = L.N; a.hact[hd] = L.act; a.h_S[hd] = dqn_nchunks(L.K, L.fwd_kc); a.h_kc[hd] = dqn_chunk_len(L.K, L.fwd_kc); }
+            a.p_on = e->p_on; a.p_tg = e->p_tg; a.ep_s = e->ep_s; a.ep_sp = e->ep_sp; a.ep_a = e->ep_a; a.ep_r = e->ep_r; a.ep_done = e->ep_done; a.ep_len = e->ep_len;
+            if (!e->draw_idx_h) {      // the draw ring: mapped, coherent pinned host memory (survives program rebuilds; freed with the engine)
+                HIPCHK(hipHostMalloc((void**)&e->draw_idx_h, sizeof(long long) * DQN_DRAW_SLOTS * Bb, hipHostMallocMapped | hipHostMallocCoherent));
+                HIPCHK(hipHostMalloc((void**)&e->draw_start_h, sizeof(int) * DQN_DRAW_SLOTS * Bb, hipHostMallocMapped | hipHostMallocCoherent));
+                memset(e->draw_idx_h, 0, sizeof(long long) * DQN_DRAW_SLOTS * Bb); memset(e->draw_start_h, 0, sizeof(int) * DQN_DRAW_SLOTS * Bb);
+                HIPCHK(hipHostGetDevicePointer((void**)&e->draw_idx_d, e->draw_idx_h, 0)); HIPCHK(hipHostGetDevicePointer((void**)&e->draw_start_d, e->draw_start_h, 0));
+                HIPCHK(hipMalloc((void**)&e->draw_seq, sizeof(unsigned long long))); HIPCHK(hipMemset(e->draw_seq, 0, sizeof(unsigned long long))); e->draw_issued = 0;
+                for (int k = 0; k < 2; k++) HIPCHK(hipEventCreateWithFlags(&e->draw_ev[k], hipEventDisableTiming));
+            }
+            a.ring_idx = e->draw_idx_d; a.ring_np = e->draw_start_d; a.draw_seq = e->draw_seq; a.draw_slots = DQN_DRAW_SLOTS;
+            const int G = Bb / cgm;
+            a.slabs = palloc(e, (size_t)G * e->Pint); a.hl = palloc(e, (size_t)B); a.td = e->td; a.st = e->state;
+            if (const char* pv = getenv("DQN_DRQN_PROBE")) a.probe = atoi(pv);
+            if (getenv("DQN_DRQN_STAMPS")) { a.stamps = (unsigned long long*)palloc(e, 64); e->drqn_stamps = a.stamps; }
+            const DrqnColsArgs* a_dev = upload(e, std::vector<DrqnColsArgs>(1, a));
+            e->prog.push_back({"drqn_cols", [=](dqn_engine* en) { launch_drqn_cols(en->stream, a, a_dev); }});
+            e->prog_post_begin = e->prog.size();
+            AdamJob J; memset(&J, 0, sizeof J);
+            J.p = e->p_on; J.m = e->m; J.v = e->v; J.g = e->grad; J.g_out = e->grad; J.state = e->state; J.gmax_part = e->gmax_part;
+            J.f64mode = e->hp.adam_f64_scalars; J.lr = e->hp.learning_rate; J.b1 = e->hp.adam_beta1; J.b2 = e->hp.adam_beta2; J.eps = e->hp.adam_eps; J.gscale = 1.0f;
+            J.segs.n = 1; J.segs.beg[0] = 0; J.segs.end[0] = e->Pint; J.segs.part[0] = a.slabs; J.segs.S[0] = G; J.segs.stride[0] = e->Pint; J.segs.blocks = (unsigned)((e->Pint + 255) / 256);
+            J.nr = 0; J.sblocks = 1; J.tick = 1; J.slot0 = 0; J.fold_hl = a.hl; J.fold_T = T; J.fold_B = Bb; J.bump_ctr = e->draw_seq;
+            e->adam_step = (long)e->prog.size();
+            e->prog.push_back({"adam", [=](dqn_engine* en) { launch_adam(en->stream, J); }});
+            e->gmax_used = (int)(J.segs.blocks + J.sblocks);
+            e->tiny = false; e->drqn_fused = true; e->arena_u8 = false; e->prio_forked = false; e->prio_in_bwd = false; e->dp_gather = false; e->dp_overlap = false; e->prog_pre1_end = 0;
+            e->final_reduce_step = -1; memset(&e->adam_segs, 0, sizeof e->adam_segs);
+            e->prog_built = true;
+            return 0;
+        }
+        e->drqn_fused = false;
+    }
     // ---------------- networks that fit in LDS: the WHOLE step is one single-workgroup launch (tiny_step.hip; BASELINE config 1)
     e->tiny = false;
     if (!rec && !e->comm && !e->sim_world && e->world <= 1 && e->hp.prioritized_replay && !e->hp.sample_distinct && Bb <= 64 && e->nl <= TINY_MAX_LAYERS &&
@@ -130,7 +179,9 @@ int build_program(dqn_engine* e) {
         if (fuse_heads && li + 1 == levels.size()) continue;      // computed inside k_head_td
         struct Prob { int l, net; const float *P, *X; int ldx, col0, ncols; float *Y, *part; int S; };
         std::vector<Prob> pr;
+        static const bool probe_no_tg = getenv("DQN_PROBE_NO_TG") != nullptr;      // TIMING PROBE (wrong numbers, right schedule): the forward launches without the target network's problems
         for (int l : lv) for (int net = 0; net < 2; net++) {
+            if (net == 1 && probe_no_tg) { if (wantT[l]) actT[l][1] = palloc(e, (size_t)LV[l].out_feat * B); continue; }
             const LayerDev& L = LV[l]; Prob q; q.l = l; q.net = net; q.P = net ? e->p_tg : e->p_on;
             float** act = net ? e->act_tg : e->act_on;
             q.X = L.src < 0 ? e->x0 : act[L.src]; q.ldx = L.src < 0 ? ld0 : (net ? B : ncon); q.col0 = (L.src < 0 && net) ? B : 0; q.ncols = net ? B : ncon;

@@ -503,8 +503,8 @@ __global__ __launch_bounds__(256) void k_adam(AdamJob J) {
 }
 // jobs without a priority block: no LDS to speak of, so their workgroups fit beside the LDS-heavy GEMM workgroups of a concurrent launch
 __global__ __launch_bounds__(256) void k_adam_stream(AdamJob J) {
-    __shared__ float wmax[4];
-    adam_job_run(J, (int)blockIdx.x, nullptr, wmax);
+    __shared__ float wmax[4]; __shared__ float fold_buf[256];      // fold_buf: the loss fold of the fused recurrent step (J.fold_hl)
+    adam_job_run(J, (int)blockIdx.x, nullptr, wmax, false, 0, fold_buf);
 }
 // the Adam launch of a step that is followed by another sampled step: its FIRST workgroups gather the next batch (PreGather); their dependent
 // round trips (row index -> 256-B row segments -> LDS -> arena lines) hide under the parameter stream of the remaining workgroups

@@ -122,6 +122,29 @@ static inline void philox(uint32_t k0, uint32_t k1, uint32_t c[4]) {
 }
 
 /* ---------------------------------------------------------------- plan */
+/* Column-group dW chunks of recurrent networks (plan.dw_kc = -cg): the T*B sample columns of a dW / db contraction are cut by
+ * BATCH column -- chunk g = columns {t*B + b : b in [g*cg, (g+1)*cg), t = 0..T-1} chained in ascending column order -- instead of into contiguous column
+ * ranges: batch columns never interact before the gradient sum, so a group of cg columns is what ONE workgroup of the fused recurrent step owns.
+ * This is the independent restatement of drqn_fused_cg (deepqlearning.jl_amd/csrc/common.h): the group size the default plan picks, 0 = not eligible. */
+static int fused_cg(const dqn_layer_desc* d, int n, const dqn_hparams* hp) {
+    if (!hp->recurrence) return 0;
+    const int duel = hp->dueling ? 1 : 0;
+    if (n != (duel ? 3 : 2) || d[0].kind != DQN_LAYER_LSTM || d[0].stream != DQN_STREAM_BASE) return 0;
+    const int E = hp->obs_c * hp->obs_h * hp->obs_w, H = d[0].n_out, N = 4 * H, T = hp->trace_length, B = hp->batch_size, nA = hp->n_actions;
+    if (d[0].n_in != E || H < 8 || H > 64 || H % 8 || T < 1 || T > 64 || nA > 16 || E > 512) return 0;
+    if (!duel) { if (d[1].kind != DQN_LAYER_DENSE || d[1].stream != DQN_STREAM_BASE || d[1].n_in != H || d[1].n_out != nA) return 0; }
+    else if (d[1].kind != DQN_LAYER_DENSE || d[1].stream != DQN_STREAM_VAL || d[1].n_in != H || d[1].n_out != 1 ||
+             d[2].kind != DQN_LAYER_DENSE || d[2].stream != DQN_STREAM_ADV || d[2].n_in != H || d[2].n_out != nA) return 0;
+    const int nset = hp->double_q ? 3 : 2, Ep = (E + 3) / 4 * 4, no = nA + duel;
+    const long pp = (long)(E + 1) * N + (long)(H + 1) * N + 2 * H + N + (long)(H + 1) * no + 32;
+    for (int c = 4; c >= 1; c >>= 1) {
+        if (B % c || nset * 4 * H * c > 1024) continue;
+        const long lds = 2 * pp + 2L * T * c * Ep + 4L * T * c + (long)nset * T * H * c + (long)nset * 7 * H * c + (long)T * N * c + 3L * T * H * c +
+                         (long)(nset + 1) * T * c * (no + 1) + (long)T * H * c + 2L * H * c + (long)H * (N + 4) + 64;
+        if (lds <= 36000) return c;
+    }
+    return 0;
+}
 int ref_plan_default(const dqn_layer_desc* d, int n, const dqn_hparams* hp, dqn_layer_plan* out) {
     /* independent restatement of the rule in DESIGN.md section 4 (the tests check it
      * equals dqn_plan_default of the product) */
@@ -157,6 +180,8 @@ int ref_plan_default(const dqn_layer_desc* d, int n, const dqn_hparams* hp, dqn_
                 int kc = ((KK + ch - 1) / ch + 31) / 32 * 32; out[i].dw_kc = kc < KK ? kc : 0;
             } }
     }
+    const int cg = fused_cg(d, n, hp);      /* recurrent networks the fused column-parallel step covers: column-group dW chunks */
+    if (cg) for (int i = 0; i < n; i++) out[i].dw_kc = -cg;
     return 0;
 }
 
@@ -170,6 +195,12 @@ int ref_create(const dqn_layer_desc* d, int n, const dqn_hparams* hp, const dqn_
     e->last_base = e->last_val = e->last_adv = -1;
     dqn_layer_plan defp[MAXL];
     if (!plan) { ref_plan_default(d, n, hp, defp); plan = defp; }
+    /* column-group dW chunks (dw_kc = -cg): recurrent engines only, every layer alike, cg divides the batch */
+    for (int i = 0; i < n; i++) if (plan[i].dw_kc < 0) {
+        if (!hp->recurrence) { free(e); FAIL("plan: dw_kc < 0 (column-group chunks) needs recurrence = true"); }
+        for (int j = 0; j < n; j++) if (plan[j].dw_kc != plan[i].dw_kc) { free(e); FAIL("plan: column-group dw_kc must be the same for every layer"); }
+        if (hp->batch_size % (-plan[i].dw_kc)) { free(e); FAIL("plan: column group %d does not divide batch_size %d", -plan[i].dw_kc, hp->batch_size); }
+    }
     size_t off = 0;
     for (int i = 0; i < n; i++) {
         RLayer* L = &e->L[i];
@@ -490,6 +521,31 @@ static void layer_backward_w(const RLayer* L, const float* X, int ldx, const flo
             float acc = 0.0f; int j1 = (s + 1) * kc < KK ? (s + 1) * kc : KK;
             for (int j = s * kc; j < j1; j++) { int pos = j / B, b = j % B; acc = acc + dpre[((size_t)n * npos + pos) * B + b]; }
             tot = s == 0 ? acc : tot + acc;
+        }
+        db[n] = tot;
+    }
+}
+/* the same contraction with COLUMN-GROUP chunks (plan.dw_kc = -cg, recurrent networks, dense views only): TB = T*Bb columns j = t*Bb + b; chunk g holds the
+ * columns of batch columns [g*cg, (g+1)*cg) for all t, chained in ascending j; chunk sums are added in ascending g */
+static void layer_backward_w_cg(const RLayer* L, const float* X, int ldx, const float* dpre, int T, int Bb, int cg, float* G) {
+    float* dW = G + L->w_off; float* db = G + L->b_off;
+    const int K = L->K, N = L->N, TB = T * Bb, S = Bb / cg;
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < K; k++) for (int n = 0; n < N; n++) {
+        float tot = 0.0f;
+        for (int g = 0; g < S; g++) {
+            float acc = 0.0f;
+            for (int t = 0; t < T; t++) for (int b = g * cg; b < (g + 1) * cg; b++) { const int j = t * Bb + b; acc = fmaf(X[(size_t)k * ldx + j], dpre[(size_t)n * TB + j], acc); }
+            tot = g == 0 ? acc : tot + acc;
+        }
+        dW[(size_t)k * N + n] = tot;
+    }
+    for (int n = 0; n < N; n++) {
+        float tot = 0.0f;
+        for (int g = 0; g < S; g++) {
+            float acc = 0.0f;
+            for (int t = 0; t < T; t++) for (int b = g * cg; b < (g + 1) * cg; b++) acc = acc + dpre[(size_t)n * TB + t * Bb + b];
+            tot = g == 0 ? acc : tot + acc;
         }
         db[n] = tot;
     }
@@ -947,6 +1003,7 @@ int ref_train_step_drqn(ref_engine* e, const int64_t* ep_idx_in, const int32_t* 
     /* backward over the s-sequence columns 0..TB-1 */
     memset(e->grad, 0, e->P * 4);
     int joined = 0;
+    const int cgm = e->L[0].plan.dw_kc < 0 ? -e->L[0].plan.dw_kc : 0;      /* column-group dW chunks (validated at creation: all layers alike, B % cg == 0) */
     for (int i = e->nl - 1; i >= 0; i--) {
         const RLayer* L = &e->L[i];
         float* d = e->rdact[i]; const float* y = e->racc_on[i];
@@ -976,23 +1033,29 @@ int ref_train_step_drqn(ref_engine* e, const int64_t* ep_idx_in, const int32_t* 
                 }
             }
             for (int u = 0; u < H; u++) {                                          /* trainable initial state: sum over the batch, ascending b */
-                float sh = 0.0f, sc = 0.0f; for (int b = 0; b < B; b++) { sh = sh + dhn[u * B + b]; sc = sc + dcn[u * B + b]; }
+                float sh = 0.0f, sc = 0.0f;
+                if (cgm) {                                                           /* column-group plan: per-group sums (from +0, ascending b), groups added ascending */
+                    for (int g = 0; g < B / cgm; g++) {
+                        float ah = 0.0f, ac = 0.0f; for (int b = g * cgm; b < (g + 1) * cgm; b++) { ah = ah + dhn[u * B + b]; ac = ac + dcn[u * B + b]; }
+                        sh = g == 0 ? ah : sh + ah; sc = g == 0 ? ac : sc + ac;
+                    }
+                } else for (int b = 0; b < B; b++) { sh = sh + dhn[u * B + b]; sc = sc + dcn[u * B + b]; }
                 e->grad[L->h0_off + u] = sh; e->grad[L->c0_off + u] = sc;
             }
             free(dhn); free(dcn);
             RLayer wi = dense_view(L, L->K, L->N, L->w_off, L->b_off);             /* dWi and db over all T*B columns (t-major, b-minor) */
             /* layer_backward_w writes db right after dW: stage into a scratch (K+1) x N block */
             float* scratch = (float*)calloc(((size_t)(L->K > H ? L->K : H) + 1) * L->N, 4);
-            wi.w_off = 0; wi.b_off = (size_t)L->K * L->N; layer_backward_w(&wi, X, ldx, dG, TB, scratch);
+            wi.w_off = 0; wi.b_off = (size_t)L->K * L->N; if (cgm) layer_backward_w_cg(&wi, X, ldx, dG, T, B, cgm, scratch); else layer_backward_w(&wi, X, ldx, dG, TB, scratch);
             memcpy(e->grad + L->w_off, scratch, (size_t)L->K * L->N * 4); memcpy(e->grad + L->b_off, scratch + (size_t)L->K * L->N, (size_t)L->N * 4);
             RLayer wh = dense_view(L, H, L->N, 0, (size_t)H * L->N);               /* dWh: X = h_{t-1} (h0 broadcast at t = 0) */
-            layer_backward_w(&wh, HP, TB, dG, TB, scratch);
+            if (cgm) layer_backward_w_cg(&wh, HP, TB, dG, T, B, cgm, scratch); else layer_backward_w(&wh, HP, TB, dG, TB, scratch);
             memcpy(e->grad + L->wh_off, scratch, (size_t)H * L->N * 4);
             free(scratch);
             xv = dense_view(L, L->K, L->N, L->w_off, L->b_off); dpre_for_dx = dG;
         } else {
             for (size_t t = 0; t < (size_t)L->out_feat; t++) for (int k = 0; k < TB; k++) d[t * TB + k] = dact_f(d[t * TB + k], y[t * ncon + k], L->act);
-            layer_backward_w(L, X, ldx, d, TB, e->grad);
+            if (cgm) layer_backward_w_cg(L, X, ldx, d, T, B, cgm, e->grad); else layer_backward_w(L, X, ldx, d, TB, e->grad);
             xv = *L;
         }
         if (L->src >= 0) {

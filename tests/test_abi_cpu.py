@@ -50,6 +50,23 @@ def test_default_plan_product_equals_twin(pkg, name, B):
     assert pkg.default_plan(layers, hp) == ref.default_plan(layers, hp)
 
 
+@pytest.mark.parametrize("B,T,dq", [(32, 8, 1), (4, 3, 0), (16, 10, 1), (32, 40, 1), (6, 5, 1), (33, 8, 1)])
+def test_default_plan_recurrent_column_groups_product_equals_twin(pkg, B, T, dq):
+    """recurrent networks: the default plan of the networks the fused column-parallel step covers cuts dW / db by batch-column groups (dw_kc = -cg);
+    the product's rule (common.h drqn_fused_cg) and the twin's restatement must agree, covered or not"""
+    from drqn_common import drqn_nets
+    seen = set()
+    for name, (net, _, _, kw) in drqn_nets().items():
+        hp = ref.hparams_for(net, batch_size=B, buffer_size=64, recurrence=1, trace_length=T, prioritized_replay=0, gamma=0.9, double_q=dq)
+        layers = ref.layers_from_network(net)
+        a, b = pkg.default_plan(layers, hp), ref.default_plan(layers, hp)
+        assert a == b, (name, a, b)
+        seen.add((name, a[0][2]))
+    if (B, T, dq) == (32, 8, 1):
+        assert ("cfg4_lstm_plain", -2) in seen and ("lstm16_dueling_b16", -2) in seen      # BASELINE config 4: groups of 2 columns, 16 workgroups
+        assert ("dense_lstm_dueling", 0) in seen                                            # a Dense layer in front of the LSTM: the multi-launch program
+
+
 def test_hparams_default_matches_reference_defaults(pkg):
     hp = pkg.HParams()
     pkg.fns()["hparams_default"](ctypes.byref(hp))

@@ -168,3 +168,48 @@ def test_drqn_golden_fixture_torch_values(pkg, name, mfma, golden_dir):
     b = run_drqn_fixture(ref.Twin, name, g, plan=outs[0], threads=4)
     assert a["loss"] == b["loss"] and a["gn"] == b["gn"]
     np.testing.assert_array_equal(a["grads"], b["grads"]); np.testing.assert_array_equal(a["newp"], b["newp"])
+
+
+@pytest.mark.parametrize("name", ["cfg4_lstm_plain", "lstm16_dueling_b16", "lstm_single_q"])
+def test_drqn_multilaunch_program_with_contiguous_dw_plan(pkg, name):
+    """the networks the fused column-parallel step covers still run the multi-launch recurrent program when the plan asks for contiguous dW chunks
+    (dw_kc >= 0): both schedules stay under test, each bit-exact against the twin handed the same plan -- and they differ from each other only in rounding"""
+    net, B, T, kw = drqn_nets()[name]
+    rng = np.random.default_rng(5)
+    cap = max(12, B + 4)
+    hp = ref.hparams_for(net, batch_size=B, buffer_size=cap, recurrence=1, trace_length=T, learning_rate=1e-3, prioritized_replay=0, **kw)
+    layers = ref.layers_from_network(net)
+    dplan = pkg.default_plan(layers, hp)
+    assert all(p[2] < 0 for p in dplan)                                  # covered: column-group chunks by default
+    plan0 = [(p[0], p[1], 0) for p in dplan]
+    eps = make_episodes(net, cap + 3, T, rng)
+    p_on = (O.Network.flatten(O.init_params_recurrent(net, 3)) + 0.05 * rng.standard_normal(net.n_params())).astype(np.float32)
+    outs = []
+    for plan in (plan0, dplan):
+        gpu = pkg.Engine(layers, hp, plan=plan, device=0); cpu = ref.Twin(layers, hp, plan=plan, threads=4)
+        assert gpu.plan() == plan
+        for h in (gpu, cpu):
+            feed(h, eps); h.set_params(p_on, 0); h.set_params(p_on * np.float32(0.9), 1)
+        r = np.random.default_rng(3)
+        ring = [None] * cap
+        for i, ep in enumerate(eps):
+            ring[i % cap] = ep
+        for step in range(3):
+            idx, start = draws(ring, B, r)
+            assert gpu.train_step_drqn(idx, start) == cpu.train_step_drqn(idx, start)
+        np.testing.assert_array_equal(gpu.get_grads(), cpu.get_grads())
+        np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+        outs.append(gpu.get_params(0)); gpu.close(); cpu.close()
+    np.testing.assert_allclose(outs[0], outs[1], atol=3e-3, rtol=0)     # same math, different summation order (Adam at |g| ~ eps moves a parameter by up to lr per step)
+
+
+def test_drqn_column_group_plan_on_uncovered_network_is_refused(pkg):
+    net, B, T, kw = drqn_nets()["dense_lstm_dueling"]
+    hp = ref.hparams_for(net, batch_size=B, buffer_size=12, recurrence=1, trace_length=T, prioritized_replay=0, **kw)
+    layers = ref.layers_from_network(net)
+    plan = [(p[0], p[1], -2) for p in pkg.default_plan(layers, hp)]
+    gpu = pkg.Engine(layers, hp, plan=plan, device=0)
+    feed(gpu, make_episodes(net, 12, T, np.random.default_rng(0)))
+    with pytest.raises(pkg.DQNError, match="column-group dW chunks"):
+        gpu.train_step_drqn()
+    gpu.close()
