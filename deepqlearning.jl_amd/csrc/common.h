@@ -27,6 +27,7 @@ struct LayerDev {
     // LSTM (Flux Recur(LSTMCell)): K = n_in, N = 4H.  internal block [Wi K x 4H][b 4H][Wh H x 4H][junk 4H][h0 H][c0 H][zeros 4H]:
     // Wi|b and Wh|junk are (K+1) x N blocks for the dW kernels; `zeros` is the bias of the bias-free input projection.
     int H; unsigned long long wh_off, h0_off, c0_off, z_off, ewh_off, eh0_off, ec0_off;
+    int opt;                           // per-ENGINE experiment switches the kernel launchers look at (DQN_LOPT_*, set at dqn_engine_create from EngineOpts): no process-wide state
     int xu8;                           // this layer reads the observation arena and the arena holds BYTES (u8 replay): value = byte / 255f0, converted in the tile load
 };
 
@@ -573,7 +574,7 @@ struct TinyArgs {
     float* x0; float *w_is, *td, *q_on_s, *q_on_sp, *q_tg_sp, *ytarget; int* best;
     int f64mode; float lr; double b1, b2, adam_eps;
 };
-void launch_tiny_step(hipStream_t st, const TinyArgs* a_dev, unsigned lds_bytes, int sample);
+int launch_tiny_step(hipStream_t st, const TinyArgs* a_dev, unsigned lds_bytes, int sample, int stop /* timing probe: return after phase n */);      // -1: the LDS attribute was refused
 
 // ---- the recurrent train step (batch_train!(..., ::EpisodeReplayBuffer), src/solver.jl:239-287) as a COLUMN-PARALLEL launch (drqn_cols.hip; BASELINE config 4):
 // batch columns never interact before the gradient sum, so workgroup g owns the batch columns [g*cg, (g+1)*cg) for the WHOLE step -- episode gather (prefix quirk),
@@ -626,8 +627,10 @@ void launch_convert_params(hipStream_t st, const LayerDev* layers_dev, int nl, c
 // LDS-tiled MFMA path (nn_gemm.hip): up to two problems (online / target net) of one layer per launch
 bool gemm_fwd_eligible(const LayerDev& L, int nprob, const int* ldx, const int* col0, const int* ncols);
 int gemm_set_ktrace(unsigned long long* p);   // debug (-DDQN_KTRACE builds): per-workgroup timestamps of the LDS-tiled kernels (nullptr = off); -1 = not a trace build
-void gemm_set_fwd_dma(int on);      // DQN_FWD_DMA: LDS-DMA operand loads for the large forward launches with 64-channel tiles (experiment)
-void gemm_set_fwd_m32(int on);      // process-wide experiment switch, set from DQN_FWD_M32 at dqn_engine_create (nn_gemm.hip, k_fwd_lds<.., M32>)
+// LayerDev::opt bits
+#define DQN_LOPT_FWD_M32 1      /* DQN_FWD_M32: 32x32x2 MFMA blocks for the 64-channel forward tiles (measured no faster; kept parity-tested) */
+#define DQN_LOPT_FWD_DMA 2      /* DQN_FWD_DMA: LDS-DMA operand loads for the large forward launches with 64-channel tiles (measured no faster) */
+#define DQN_LOPT_NO_DX_WIDE 4   /* DQN_NO_DX_WIDE: large batches take the 32-sample dX tiles instead of the 128-sample ones */
 void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* const* W, const float* const* bias, const float* const* X,
                      const int* ldx, const int* col0, const int* ncols, float* const* out /* Y, or split-K partial slabs */);
 

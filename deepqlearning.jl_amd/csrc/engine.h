@@ -19,7 +19,26 @@ int fail(const char* fmt, ...);      // records the message for dqn_last_error()
 // ---------------------------------------------------------------- engine
 struct ProfEntry { const char* name; hipEvent_t a, b; };
 
+// Experiment / test switches.  Read ONCE from the environment of the call that creates the engine (read_opts, engine.hip -- the only getenv site of the
+// library besides trace builds), kept in the engine: no function-local statics, nothing process-wide, a second engine in the same process never inherits the
+// first one's switches.  The communicator switches (force_allreduce, dp_*) are re-read by dqn_comm_init, the call that makes them meaningful.
+struct EngineOpts {
+    int adam_mode = 0;            // DQN_ADAM_MODE=1: Adam jobs carried by the backward launches (measured slower; parity-tested)
+    int no_tiny = 0;              // DQN_NO_TINY: networks that fit in LDS take the multi-launch program
+    int fwd_m32 = 0, fwd_dma = 0, no_dx_wide = 0;      // DQN_FWD_M32 / DQN_FWD_DMA / DQN_NO_DX_WIDE -> LayerDev::opt bits
+    int mid_group = 4, mid_big = 16;                   // DQN_MID_GROUP / DQN_MID_BIG: middle steps of dqn_train_steps per graph (mid_big also needs mid_group > 1)
+    int sim_world = 0;            // DQN_SIM_WORLD=k: one process plays k ranks (tests)
+    int no_graph_upload = 0;      // DQN_NO_GRAPH_UPLOAD
+    int no_rollout_cycle = 0;     // DQN_NO_ROLLOUT_CYCLE
+    int no_u8_arena = 0, head_fuse_maxb = 1024, no_head_fuse = 0, head_dbg = 0, prio_fork = 0, prio_level = 0, prio_nosplit = 0, no_pregather = 0, lstm_dw_mfma = 0;
+    int force_allreduce = 0, dp_allreduce = 0, dp_overlap = 0, dp_no_one_graph = 0;      // DQN_FORCE_ALLREDUCE / DQN_DP_ALLREDUCE / DQN_DP_OVERLAP / DQN_DP_NO_ONE_GRAPH
+    // timing probes (wrong numbers, right schedule) and stamps
+    int probe_no_tg = 0, drqn_probe = 0, drqn_stamps = 0, tiny_stop = 0;
+};
+void read_opts(EngineOpts& o, bool comm_only = false);
+
 struct dqn_engine {
+    EngineOpts opt;
     int device = 0; hipStream_t stream = nullptr, stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream3 = nullptr; hipEvent_t ev_xa = nullptr, ev_xb = nullptr, ev_xc = nullptr;      // replicas: the exchange runs on its own stream (dp_overlap)
     int nl = 0; LayerDev L[DQN_MAX_LAYERS]; LayerDev* L_dev = nullptr;
@@ -91,6 +110,7 @@ struct dqn_engine {
     long long *draw_idx_h = nullptr, *draw_idx_d = nullptr; int *draw_start_h = nullptr, *draw_start_d = nullptr; unsigned long long* draw_seq = nullptr; unsigned long long draw_issued = 0;
     hipEvent_t draw_ev[2] = {nullptr, nullptr};
     unsigned long long* drqn_stamps = nullptr;      // timing probe of the fused recurrent step (DQN_DRQN_STAMPS)
+    bool launch_failed = false;      // a launcher refused (an LDS attribute the device would not grant): reported by the entry point that enqueued the step
     bool drqn_fused = false;      // recurrent step = the column-parallel launch (which gathers its own episode rows) + the Adam launch (drqn_cols.hip)
     hipGraphExec_t g_pgv[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [take_pre][pregather] variants of the sampled single-device step
     hipGraphExec_t g_mid = nullptr; int mid_group = 4;                          // mid_group consecutive middle steps of dqn_train_steps as one graph

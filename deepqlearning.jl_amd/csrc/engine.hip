@@ -112,6 +112,18 @@ static int build_layers(const dqn_layer_desc* d, int n, const dqn_hparams* hp, L
 }
 // The default summation-order plan.  Chosen for gfx950 occupancy: long forward contractions
 // are cut into ~512-element chunks, dense dX into 256-element chunks, conv dW into ~256-sample chunks.
+// the ONE place the library reads its environment (besides trace builds): at dqn_engine_create, and -- the communicator switches only -- at dqn_comm_init
+void read_opts(EngineOpts& o, bool comm_only) {
+    auto I = [](const char* k, int dflt) { const char* v = getenv(k); return v ? atoi(v) : dflt; };
+    auto F = [](const char* k) { return getenv(k) != nullptr ? 1 : 0; };
+    o.force_allreduce = F("DQN_FORCE_ALLREDUCE"); o.dp_allreduce = F("DQN_DP_ALLREDUCE"); o.dp_overlap = F("DQN_DP_OVERLAP"); o.dp_no_one_graph = F("DQN_DP_NO_ONE_GRAPH");
+    if (comm_only) return;
+    o.adam_mode = I("DQN_ADAM_MODE", 0); o.no_tiny = F("DQN_NO_TINY"); o.fwd_m32 = I("DQN_FWD_M32", 0); o.fwd_dma = I("DQN_FWD_DMA", 0); o.no_dx_wide = F("DQN_NO_DX_WIDE");
+    o.mid_group = I("DQN_MID_GROUP", 4); o.mid_big = I("DQN_MID_BIG", 16); o.sim_world = I("DQN_SIM_WORLD", 0); o.no_graph_upload = F("DQN_NO_GRAPH_UPLOAD");
+    o.no_rollout_cycle = F("DQN_NO_ROLLOUT_CYCLE"); o.no_u8_arena = F("DQN_NO_U8_ARENA"); o.head_fuse_maxb = I("DQN_HEAD_FUSE_MAXB", 1024); o.no_head_fuse = F("DQN_NO_HEAD_FUSE");
+    o.head_dbg = I("DQN_HEAD_DBG", 0); o.prio_fork = F("DQN_PRIO_FORK"); o.prio_level = I("DQN_PRIO_LEVEL", 0); o.prio_nosplit = F("DQN_PRIO_NOSPLIT"); o.no_pregather = F("DQN_NO_PREGATHER");
+    o.lstm_dw_mfma = F("DQN_LSTM_DW_MFMA"); o.probe_no_tg = F("DQN_PROBE_NO_TG"); o.drqn_probe = I("DQN_DRQN_PROBE", 0); o.drqn_stamps = F("DQN_DRQN_STAMPS"); o.tiny_stop = I("DQN_TINY_STOP", 0);
+}
 static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out, const dqn_hparams* hp) {
     bool rec = false; for (int i = 0; i < n; i++) rec = rec || L[i].kind == DQN_LAYER_LSTM;
     for (int i = 0; i < n; i++) {
@@ -137,12 +149,12 @@ static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out, c
         // hides, and unsplit gradients keep the slab sums foldable into the Adam launch (r03: the separate reduce launch cost 12-19 us at config 5)
         if (L[i].kind == DQN_LAYER_DENSE && L[i].N < 16 && B >= 128 && rec) out[i].dw_kc = 64;
         if (L[i].kind == DQN_LAYER_CONV) {   // positions per chunk so that (K/64 row tiles) x chunks >= ~512 workgroups
-            static const int tgt = getenv("DQN_DW_WGS") ? atoi(getenv("DQN_DW_WGS")) : 512;      // experiment knob
+            const int tgt = 512;      // (r03: 256 / 128 workgroups measured no faster)
             const int st = (tgt + (L[i].K + 63) / 64 - 1) / ((L[i].K + 63) / 64); int ppc = L[i].npos / st; if (ppc < 1) ppc = 1; out[i].dw_kc = ppc * B;
             // large batches: a position is 4+ K tiles deep, so chunks are cut in SAMPLES (32-aligned, they may start inside a position) to land
             // on <= 1024 workgroups -- whole positions gave 536 workgroups for the 8x8 conv layer at B = 512, i.e. three on some CUs and two on the rest
-            if (B >= 128 && B % 32 == 0 && !getenv("DQN_DW_POSCHUNK")) {
-                static const int tgt2 = getenv("DQN_DW_WGS") ? atoi(getenv("DQN_DW_WGS")) : 1024;      // measured at config 5: 512 / 768 / 1024 -> conv dW 57 / 52 / 49 us
+            if (B >= 128 && B % 32 == 0) {
+                const int tgt2 = 1024;      // measured at config 5: 512 / 768 / 1024 -> conv dW 57 / 52 / 49 us
                 const int mrows = (L[i].K + 63) / 64, KK = L[i].npos * B; int ch = tgt2 / mrows; if (ch < 1) ch = 1;
                 int kc = ((KK + ch - 1) / ch + 31) / 32 * 32; if (kc < KK) out[i].dw_kc = kc; else out[i].dw_kc = 0;
             }
@@ -182,13 +194,12 @@ static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers
     e->device = device; e->hp = *hp; e->B = hp->batch_size; e->nA = hp->n_actions; e->E = hp->obs_c * hp->obs_h * hp->obs_w;
     if (build_layers(layers, n_layers, hp, e->L, &e->last_base, &e->last_val, &e->last_adv, &e->P, &e->Pint)) return -1;
     e->nl = n_layers;
-    if (const char* am = getenv("DQN_ADAM_MODE")) e->adam_mode = atoi(am);
-    e->no_tiny = getenv("DQN_NO_TINY") != nullptr;
-    gemm_set_fwd_m32(getenv("DQN_FWD_M32") ? atoi(getenv("DQN_FWD_M32")) : 0);
-    gemm_set_fwd_dma(getenv("DQN_FWD_DMA") ? atoi(getenv("DQN_FWD_DMA")) : 0);
-    if (const char* mg = getenv("DQN_MID_GROUP")) e->mid_group = atoi(mg);      // middle steps of dqn_train_steps per graph launch (1 = one step per graph)
-    if (const char* mb = getenv("DQN_MID_BIG")) e->mid_big = atoi(mb);
-    if (const char* sw = getenv("DQN_SIM_WORLD")) { const int k = atoi(sw); if (k >= 1 && !hp->recurrence) { e->sim_world = k; e->world = k; } }   // tests: one process plays k identical ranks
+    read_opts(e->opt);      // every experiment / test switch, once; nothing below (or later) looks at the environment
+    e->adam_mode = e->opt.adam_mode; e->no_tiny = e->opt.no_tiny != 0;
+    e->mid_group = e->opt.mid_group;      // middle steps of dqn_train_steps per graph launch (1 = one step per graph: no grouped graphs at all)
+    e->mid_big = e->opt.mid_group > 1 ? e->opt.mid_big : 0;
+    { const int lopt = (e->opt.fwd_m32 ? DQN_LOPT_FWD_M32 : 0) | (e->opt.fwd_dma ? DQN_LOPT_FWD_DMA : 0) | (e->opt.no_dx_wide ? DQN_LOPT_NO_DX_WIDE : 0); for (int i = 0; i < e->nl; i++) e->L[i].opt = lopt; }
+    if (e->opt.sim_world >= 1 && !hp->recurrence) { e->sim_world = e->opt.sim_world; e->world = e->opt.sim_world; }   // tests: one process plays k identical ranks
     dqn_layer_plan defp[DQN_MAX_LAYERS];
     if (!plan) { default_plan(e->L, e->nl, e->B, defp, hp); plan = defp; }
     for (int i = 0; i < e->nl; i++) {
@@ -593,13 +604,14 @@ int capture(dqn_engine* e, bool sample, int phase, hipGraphExec_t* out, int repe
         } else { enqueue_step(e, sample, PH_PRE); xrc |= exchange_grads(e); enqueue_step(e, sample, PH_POST); }
     } else
     for (int r = 0; r < repeat; r++) enqueue_step(e, sample, phase);
-    const hipError_t lerr = hipGetLastError();          // a launch refused during capture never becomes a graph node
+    hipError_t lerr = hipGetLastError();          // a launch refused during capture never becomes a graph node
+    if (e->launch_failed) { e->launch_failed = false; if (lerr == hipSuccess) lerr = hipErrorInvalidValue; }      // a launcher could not get the dynamic LDS it needs on this device
     { const hipError_t ce = hipStreamEndCapture(e->stream, &g); if (ce != hipSuccess || xrc) { (void)hipGetLastError(); if (ce == hipSuccess) hipGraphDestroy(g); return fail("capturing the train step failed (%s%s)", hipGetErrorString(ce), xrc ? "; collective refused" : ""); } }
     if (lerr != hipSuccess) { hipGraphDestroy(g); return fail("HIP error %s while capturing the train step", hipGetErrorString(lerr)); }
     HIPCHK(hipGraphInstantiate(out, g, nullptr, nullptr, 0));
     // the FIRST launch of an executable graph prepares its packets on the device side; done here instead, a short timed call (the driver's 20 steps
     // launch the 4-step middle graph for the first time inside the timed region: its warm-up of 5 steps is too short to reach it) does not pay it
-    if (!getenv("DQN_NO_GRAPH_UPLOAD")) (void)hipGraphUpload(*out, e->stream);
+    if (!e->opt.no_graph_upload) (void)hipGraphUpload(*out, e->stream);
     (void)hipGetLastError();
     HIPCHK(hipGraphDestroy(g)); return 0;
 }
@@ -647,8 +659,7 @@ int run_step(dqn_engine* e, bool sample, bool take_pre, bool pregather) {
         const bool tp = sample && e->pg_ok && take_pre, pgth = sample && e->pg_ok && pregather;
         e->step_take_pre = tp; e->step_pregather = pgth;
         int rc = 0;
-        static const bool one_graph_ok = getenv("DQN_DP_NO_ONE_GRAPH") == nullptr;
-        if (one_graph_ok && e->hp.use_graph && !e->profiling && !e->sim_world && e->comm && e->dp_one_state >= 0) {
+        if (!e->opt.dp_no_one_graph && e->hp.use_graph && !e->profiling && !e->sim_world && e->comm && e->dp_one_state >= 0) {
             hipGraphExec_t& g = e->g_dp_one[(tp ? 2 : 0) + (pgth ? 1 : 0) + 0];
             if (!g && gi == 0) { if (capture(e, sample, PH_DP_ONE, &g)) { e->dp_one_state = -1; g = nullptr; } else e->dp_one_state = 1; }
             if (g && gi == 0) { HIPCHK(hipGraphLaunch(g, e->stream)); e->step_take_pre = e->step_pregather = false; return 0; }
@@ -693,7 +704,7 @@ int run_step(dqn_engine* e, bool sample, bool take_pre, bool pregather) {
         hipGraphExec_t& g = pub ? e->g_full_pub[gi] : e->g_full[gi];
         if (!g && capture(e, sample, PH_ALL, &g)) rc = -1;
         else { const hipError_t le = hipGraphLaunch(g, e->stream); if (le != hipSuccess) rc = fail("HIP error %s launching the train-step graph", hipGetErrorString(le)); }
-    } else { enqueue_step(e, sample, PH_ALL); const hipError_t le = hipGetLastError(); if (le != hipSuccess) rc = fail("HIP error %s enqueuing the train step", hipGetErrorString(le)); }      // eager launches: a refused launch (bad LDS size, bad grid) is an error, not a silent no-op
+    } else { enqueue_step(e, sample, PH_ALL); const hipError_t le = hipGetLastError(); if (le != hipSuccess || e->launch_failed) { e->launch_failed = false; rc = fail("HIP error %s enqueuing the train step", hipGetErrorString(le)); } }      // eager launches: a refused launch (bad LDS size, bad grid) is an error, not a silent no-op
     e->step_publish = false;
     if (!rc && pub) e->pub_issued++;
     return rc;
@@ -832,8 +843,8 @@ extern "C" int dqn_train_steps(dqn_engine_t* e, int n, float* loss, float* grad_
         auto cap1 = [&](bool tp, bool pgth, hipGraphExec_t* g, int rep) { if (*g) return 0; e->step_take_pre = tp; e->step_pregather = pgth; const int rc = capture(e, true, PH_ALL, g, rep);
                                                                          e->step_take_pre = e->step_pregather = false; return rc; };
         if (pg) { if (cap1(false, true, &e->g_pgv[0][1], 1) || cap1(true, true, &e->g_pgv[1][1], 1) || cap1(true, false, &e->g_pgv[1][0], 1)) return -1; }
-        if (MID_GROUP > 1 && cap1(pg, pg, &e->g_mid, MID_GROUP)) return -1;
-        if (e->mid_big > MID_GROUP && cap1(pg, pg, &e->g_mid_big, e->mid_big)) return -1;
+        if (MID_GROUP > 1 && n >= MID_GROUP + (pg ? 2 : 0) && cap1(pg, pg, &e->g_mid, MID_GROUP)) return -1;
+        if (e->mid_big > MID_GROUP && n >= e->mid_big + (pg ? 2 : 0) && cap1(pg, pg, &e->g_mid_big, e->mid_big)) return -1;      // only calls long enough to use it pay its capture
     }
     for (int i = 0; i < n;) {
         // a run of identical steps: middle steps (pipelined gather) or, where that does not apply, any steps
@@ -842,7 +853,7 @@ extern "C" int dqn_train_steps(dqn_engine_t* e, int n, float* loss, float* grad_
             HIPCHK(hipGraphLaunch(e->g_mid_big, e->stream));
             i += BIG; continue;
         }
-        if (single && MID_GROUP > 1 && (pg ? (i >= 1 && i + MID_GROUP <= n - 1) : (i + MID_GROUP <= n))) {
+        if (single && MID_GROUP > 1 && e->g_mid && (pg ? (i >= 1 && i + MID_GROUP <= n - 1) : (i + MID_GROUP <= n))) {
             HIPCHK(hipGraphLaunch(e->g_mid, e->stream));
             i += MID_GROUP; continue;
         }
@@ -944,7 +955,8 @@ extern "C" int dqn_comm_init(dqn_engine_t* e, const void* id128, int rank, int w
     Id128 id; memcpy(id.b, id128, 128);
     const int rc = g_rccl.CommInitRank(&e->comm, world, id, rank);
     if (rc) return fail("ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
-    e->rank = rank; e->world = world; e->sim_world = 0; e->force_comm = getenv("DQN_FORCE_ALLREDUCE") != nullptr;
+    read_opts(e->opt, /*comm_only*/ true);      // the communicator switches, as of this call
+    e->rank = rank; e->world = world; e->sim_world = 0; e->force_comm = e->opt.force_allreduce != 0; e->dp_one_state = 0;
     // the launch program depends on the exchange mode and the world size: rebuild it on the next step
     drop_graphs(e); HIPCHK(hipStreamSynchronize(e->stream));
     for (void* p : e->prog_allocs) hipFree(p);
@@ -973,7 +985,8 @@ extern "C" int dqn_stream_sync(dqn_engine_t* e) { if (!e) return fail("null engi
 extern "C" int dqn_stream_handle(dqn_engine_t* e, void** s) { if (!e) return fail("null engine handle"); *s = (void*)e->stream; return 0; }
 // debug aid: per-workgroup s_memtime records of the forward GEMM kernels (nn_gemm.hip, KTRACE).  out == NULL: start recording (room for 65536
 // records); out != NULL: stop and copy counter + records (n 64-bit words) to the host.  Process-wide (one engine at a time).
-extern "C" int dqn_debug_ktrace(dqn_engine_t* e, uint64_t* out, size_t n) { if (!e) return fail("null engine handle");
+// (not declared in the public header: a development hook of trace builds, bound by tools/ktrace*.py only)
+extern "C" __attribute__((visibility("default"))) int dqn_debug_ktrace(dqn_engine_t* e, uint64_t* out, size_t n) { if (!e) return fail("null engine handle");
     const size_t words = 1 + 8 * 65536ull;
     HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream));
     if (!out) {

@@ -163,7 +163,7 @@ extern "C" int dqn_rollout(dqn_engine_t* e, int n_steps, const dqn_rollout_cfg* 
     // before the cycle's last step
     const bool single = e->world <= 1 && !(e->comm && e->force_comm);
     const int F = cfg->train_freq > 0 ? cfg->train_freq : 4;
-    const bool cyc = graph && single && F >= 2 && F <= 16 && getenv("DQN_NO_ROLLOUT_CYCLE") == nullptr;
+    const bool cyc = graph && single && F >= 2 && F <= 16 && !e->opt.no_rollout_cycle;
     for (int k = 0; k < n_steps; k++) {
         const long long t = cfg->t0 + k;
         if (cyc && k + F <= n_steps) {

@@ -84,10 +84,10 @@ int build_program(dqn_engine* e) {
             a.ring_idx = e->draw_idx_d; a.ring_np = e->draw_start_d; a.draw_seq = e->draw_seq; a.draw_slots = DQN_DRAW_SLOTS;
             const int G = Bb / cgm;
             a.slabs = palloc(e, (size_t)G * e->Pint); a.hl = palloc(e, (size_t)B); a.td = e->td; a.st = e->state;
-            if (const char* pv = getenv("DQN_DRQN_PROBE")) a.probe = atoi(pv);
-            if (getenv("DQN_DRQN_STAMPS")) { a.stamps = (unsigned long long*)palloc(e, 64); e->drqn_stamps = a.stamps; }
+            a.probe = e->opt.drqn_probe;
+            if (e->opt.drqn_stamps) { a.stamps = (unsigned long long*)palloc(e, 64); e->drqn_stamps = a.stamps; }
             const DrqnColsArgs* a_dev = upload(e, std::vector<DrqnColsArgs>(1, a));
-            e->prog.push_back({"drqn_cols", [=](dqn_engine* en) { launch_drqn_cols(en->stream, a, a_dev); }});
+            e->prog.push_back({"drqn_cols", [=](dqn_engine* en) { if (launch_drqn_cols(en->stream, a, a_dev)) en->launch_failed = true; }});
             e->prog_post_begin = e->prog.size();
             AdamJob J; memset(&J, 0, sizeof J);
             J.p = e->p_on; J.m = e->m; J.v = e->v; J.g = e->grad; J.g_out = e->grad; J.state = e->state; J.gmax_part = e->gmax_part;
@@ -127,7 +127,7 @@ int build_program(dqn_engine* e) {
             a.x0 = e->x0; a.w_is = e->w_is; a.td = e->td; a.q_on_s = e->q_on_s; a.q_on_sp = e->q_on_sp; a.q_tg_sp = e->q_tg_sp; a.ytarget = e->ytarget; a.best = e->best;
             a.f64mode = e->hp.adam_f64_scalars; a.lr = e->hp.learning_rate; a.b1 = e->hp.adam_beta1; a.b2 = e->hp.adam_beta2; a.adam_eps = e->hp.adam_eps;
             const TinyArgs* a_dev = upload(e, std::vector<TinyArgs>(1, a)); const unsigned lds = a.lds_bytes;
-            e->prog.push_back({"tiny_step", [=](dqn_engine* en) { launch_tiny_step(en->stream, a_dev, lds, en->step_sampled ? 1 : 0); }});
+            e->prog.push_back({"tiny_step", [=](dqn_engine* en) { if (launch_tiny_step(en->stream, a_dev, lds, en->step_sampled ? 1 : 0, en->opt.tiny_stop)) en->launch_failed = true; }});
             e->tiny = true; e->arena_u8 = false; e->prio_forked = false; e->prio_in_bwd = false; e->dp_gather = false; e->dp_overlap = false; e->prog_pre1_end = 0;
             e->prog_post_begin = e->prog.size(); e->final_reduce_step = -1; memset(&e->adam_segs, 0, sizeof e->adam_segs); e->gmax_used = 1;
             for (int i = 0; i < e->nl; i++) e->L[i].xu8 = 0;
@@ -140,7 +140,7 @@ int build_program(dqn_engine* e) {
     // a quarter of the bytes.  Everything else (VALU / direct-MFMA fallbacks, heads fed by the observation, the operand all-gather) needs floats.
     e->arena_u8 = false;
     for (int i = 0; i < e->nl; i++) { e->L[i].xu8 = 0; LV[i].xu8 = 0; }
-    if (e->hp.obs_dtype == DQN_OBS_U8 && !rec && mf && B % 4 == 0 && e->E % 4 == 0 && levels.size() > 1 && getenv("DQN_NO_U8_ARENA") == nullptr) {
+    if (e->hp.obs_dtype == DQN_OBS_U8 && !rec && mf && B % 4 == 0 && e->E % 4 == 0 && levels.size() > 1 && !e->opt.no_u8_arena) {
         int n_src = 0; for (int i = 0; i < e->nl; i++) if (e->L[i].src < 0) n_src++;
         const int l0 = levels[0][0];
         int ldx2[2] = {ld0, ld0}, c02[2] = {0, B}, nc2[2] = {ncon, B};
@@ -151,8 +151,7 @@ int build_program(dqn_engine* e) {
     // workgroup per batch column (k_head_td); the heads' dW/db and the loss fold ride as tail tasks of the next backward launch
     int hv_l = -1, ha_l = -1; bool fuse_heads = false;
     // (r03: at ANY batch -- at B = 512 the four launches it replaces, head forwards / slab reduce / single-workgroup k_td / head dX, took 40 us)
-    static const int hf_maxB = getenv("DQN_HEAD_FUSE_MAXB") ? atoi(getenv("DQN_HEAD_FUSE_MAXB")) : 1024;      // experiment knob
-    if (!rec && e->B <= hf_maxB && getenv("DQN_NO_HEAD_FUSE") == nullptr) {
+    if (!rec && e->B <= e->opt.head_fuse_maxb && !e->opt.no_head_fuse) {
         const auto& lv = levels.back();
         if (e->hp.dueling && lv.size() == 2 && lv[0] == e->last_val && lv[1] == e->last_adv) { hv_l = lv[0]; ha_l = lv[1]; }
         else if (!e->hp.dueling && lv.size() == 1 && lv[0] == e->last_base) ha_l = lv[0];
@@ -179,7 +178,7 @@ int build_program(dqn_engine* e) {
         if (fuse_heads && li + 1 == levels.size()) continue;      // computed inside k_head_td
         struct Prob { int l, net; const float *P, *X; int ldx, col0, ncols; float *Y, *part; int S; };
         std::vector<Prob> pr;
-        static const bool probe_no_tg = getenv("DQN_PROBE_NO_TG") != nullptr;      // TIMING PROBE (wrong numbers, right schedule): the forward launches without the target network's problems
+        const bool probe_no_tg = e->opt.probe_no_tg != 0;      // TIMING PROBE (wrong numbers, right schedule): the forward launches without the target network's problems
         for (int l : lv) for (int net = 0; net < 2; net++) {
             if (net == 1 && probe_no_tg) { if (wantT[l]) actT[l][1] = palloc(e, (size_t)LV[l].out_feat * B); continue; }
             const LayerDev& L = LV[l]; Prob q; q.l = l; q.net = net; q.P = net ? e->p_tg : e->p_on;
@@ -297,7 +296,7 @@ int build_program(dqn_engine* e) {
                 if (ok) { h.stage_w = 1; if (head_td_lds_bytes(h) > 60 * 1024) h.stage_w = 0; }
                 (void)wb;
             }
-            if (const char* dv = getenv("DQN_HEAD_DBG")) h.dbg = atoi(dv);
+            h.dbg = e->opt.head_dbg;
             const HeadTdArgs* h_dev = upload(e, std::vector<HeadTdArgs>(1, h));
             e->prog.push_back({"head_td", [=](dqn_engine* en) { launch_head_td(en->stream, h, h_dev, en->step_sampled ? 1 : 0, en->step_take_pre ? 1 : 0); }});
         }
@@ -316,7 +315,7 @@ int build_program(dqn_engine* e) {
         // ... unless a backward launch can carry it as a workgroup of its own (r03: the fork + join nodes themselves cost 12 + 10 us of the main
         // stream at config 5, and the block -- split in two, update then draws -- is shorter than the 57-87 us launches it rides in)
         bool big_in_bwd = false;
-        if (!rec && e->hp.prioritized_replay && Bb > 64 && Bb <= 1024 && mf && !e->comm && !e->sim_world && !getenv("DQN_PRIO_FORK")) {
+        if (!rec && e->hp.prioritized_replay && Bb > 64 && Bb <= 1024 && mf && !e->comm && !e->sim_world && !e->opt.prio_fork) {
             int carriers = 0;
             for (const auto& lvq : levels) for (int l2 : lvq) { const LayerDev& L2 = e->L[l2]; if (L2.kind != DQN_LAYER_LSTM && gemm_dw_eligible(L2, B, L2.src < 0 ? ld0 : ncon)) { carriers++; break; } }
             big_in_bwd = carriers >= 2;
@@ -333,7 +332,7 @@ int build_program(dqn_engine* e) {
     }
     // ---------------- data-parallel replicas: which layers' dW is computed AFTER the exchange from gathered operands (dp.hip)
     const int W = e->sim_world ? e->sim_world : e->world;
-    const bool dp_on = (e->comm || e->sim_world) && !rec && getenv("DQN_DP_ALLREDUCE") == nullptr;
+    const bool dp_on = (e->comm || e->sim_world) && !rec && !e->opt.dp_allreduce;
     bool dp_layer[DQN_MAX_LAYERS] = {}; int n_dp = 0;
     if (dp_on) for (int i = 0; i < e->nl; i++) {
         const LayerDev& L = e->L[i];
@@ -358,7 +357,7 @@ int build_program(dqn_engine* e) {
     const bool early = !rec && !e->comm && !e->sim_world && segs_ok && adam_mode == 1;
     struct PItem { unsigned long long beg, end; const float* part; int S; };      // part != nullptr: split-K slabs to reduce; else a streamable range
     std::vector<PItem> adam_pending; std::vector<int> adam_after_tail; int gmax_next = 0; bool prio_placed = false, prio_draw_pending = false;
-    int prio_skip = getenv("DQN_PRIO_LEVEL") ? atoi(getenv("DQN_PRIO_LEVEL")) : 0;      // experiment knob: which LDS-tiled backward launch carries the priority block (0 = the first)
+    int prio_skip = e->opt.prio_level;      // experiment knob: which LDS-tiled backward launch carries the priority block (0 = the first)
     auto base_job = [&]() {
         AdamJob J; memset(&J, 0, sizeof J);
         J.p = e->p_on; J.m = e->m; J.v = e->v; J.g = e->grad; J.g_out = e->grad; J.state = e->state; J.gmax_part = e->gmax_part;
@@ -373,7 +372,7 @@ int build_program(dqn_engine* e) {
     // workgroup 0 of the first LDS-tiled backward launch instead
     // large batches: the priority update runs on the side stream (prio_fork) and draws the next indices there; k_td takes the pre-drawn batch
     const bool pg_want = e->hp.prioritized_replay && !rec && (prio_in_adam ? (fuse_heads || e->prio_in_bwd) : e->prio_forked) && !early && !e->sim_world &&
-                         (e->hp.obs_dtype != DQN_OBS_U8 || e->arena_u8) && !getenv("DQN_NO_PREGATHER") && !e->hp.sample_distinct;      // distinct mode: sample launch + gather launch every step      // u8 rows: only onto the byte arena
+                         (e->hp.obs_dtype != DQN_OBS_U8 || e->arena_u8) && !e->opt.no_pregather && !e->hp.sample_distinct;      // distinct mode: sample launch + gather launch every step      // u8 rows: only onto the byte arena
     // layer l's gradient is final: queue its parameter range (split-K layers: as a slab segment)
     auto adam_queue = [&](int l, const std::vector<RSeg>& segs_known) {
         const LayerDev& L = e->L[l]; PItem it; it.beg = L.w_off; it.end = l + 1 < e->nl ? e->L[l + 1].w_off : e->Pint; it.part = nullptr; it.S = 0;
@@ -420,7 +419,7 @@ int build_program(dqn_engine* e) {
     // backward launch: pack and exchange them now, on the exchange stream, while the conv backward runs (SURVEY 8e "overlapped with backward")
     // OPT-IN (DQN_DP_OVERLAP=1): measured at world 1, where there is nothing to hide, the fork + join of the exchange stream cost 26 us per step (one-graph
     // replica step 155.8 -> 181.9 us) -- it pays once the first all-gather takes longer than that, which only a multi-GPU box can tell
-    bool overlap_cand = dp_on && n_dp > 0 && fuse_heads && levels.size() >= 2 && getenv("DQN_DP_OVERLAP") != nullptr;
+    bool overlap_cand = dp_on && n_dp > 0 && fuse_heads && levels.size() >= 2 && e->opt.dp_overlap;
     if (overlap_cand) for (int i = 0; i < e->nl; i++) if (dp_layer[i]) { bool in_lvl = false; for (int l : levels[levels.size() - 2]) in_lvl = in_lvl || l == i; overlap_cand = overlap_cand && in_lvl; }
     e->dp_overlap = false; e->prog_pre1_end = 0;
     if (overlap_cand) { e->prog.push_back({"dp_pack_wide", [](dqn_engine* en) { if (en->dp_overlap) launch_dp_pack(en->stream, en->dp_pk_a); }}); e->prog_pre1_end = e->prog.size(); }
@@ -472,7 +471,7 @@ int build_program(dqn_engine* e) {
                     float* part = S > 1 ? palloc(e, (size_t)S * (V.K + 1) * V.N) : nullptr; float* dst = S > 1 ? part : grad + V.w_off;
                     // small recurrent layers (config 4: (25+1) x 128 and (32+1) x 128 weights, 256 columns): the two dW contractions as VALU tasks of ONE launch
                     // (15 us) beat two LDS-tiled MFMA launches of 13 us each (r03: 113.4 -> 102.7 us/step); the MFMA tiles win once the sample chains get long
-                    const bool small_dw = B <= 256 && (size_t)(V.K + 1) * V.N <= 16384 && !getenv("DQN_LSTM_DW_MFMA");
+                    const bool small_dw = B <= 256 && (size_t)(V.K + 1) * V.N <= 16384 && !e->opt.lstm_dw_mfma;
                     if (mf && !small_dw && gemm_dw_eligible(V, B, ldv)) { struct A { const float* X[1]; const float* d[1]; float* o[1]; } a; a.X[0] = Xv; a.d[0] = dG; a.o[0] = dst;
                         e->prog.push_back({nm, [=](dqn_engine* en) { launch_gemm_dw(en->stream, V, 1, a.X, ldv, a.d, B, a.o); }}); }
                     else if (mf && !small_dw && mfma_dw_ok(V, B)) e->prog.push_back({nm, [=](dqn_engine* en) { launch_mfma_dw(en->stream, V, Xv, ldv, dG, B, grad, part, false); }});
@@ -567,7 +566,7 @@ int build_program(dqn_engine* e) {
             // the block rides as workgroup 0 of this launch.  When a LATER backward launch can carry a workgroup too, the block is SPLIT: update_priorities!
             // here, the draws there -- each half shorter than the dX chains it hides under (r03 ktrace: the whole block lived 11 us, longer than any)
             bool later = false;
-            static const bool no_split = getenv("DQN_PRIO_NOSPLIT") != nullptr;
+            const bool no_split = e->opt.prio_nosplit != 0;
             for (int lj = li - 1; lj >= 0 && !later && !no_split; lj--) for (int l2 : levels[lj]) {
                 const LayerDev& L2 = e->L[l2]; const int ldx2 = L2.src < 0 ? ld0 : ncon;
                 if (mf && L2.kind != DQN_LAYER_LSTM && !dp_layer[l2] && gemm_dw_eligible(L2, B, ldx2)) later = true;

@@ -425,10 +425,6 @@ __global__ __launch_bounds__(256) void k_fwd_dma(LayerDev L, GFwdProbs pr, int S
         *reinterpret_cast<f32x4*>(p.out + (size_t)s * per_s + ((size_t)n * L.npos + pos) * p.ncols + ct * 16 + 4 * kq) = v;
     }
 }
-static int g_fwd_dma = 0;
-void gemm_set_fwd_dma(int on) { g_fwd_dma = on; }
-static int g_fwd_m32 = 0;
-void gemm_set_fwd_m32(int on) { g_fwd_m32 = on; }
 static int fwd_pick_nt(const LayerDev& L, long mgroups_total, int S) {
     // widest N tile (most reuse of the im2col'd A tile) that still yields >= ~400 workgroups.  Dense layers at B=32 stream
     // their weights once whatever the tile, so they too prefer more, narrower workgroups (measured: FC1 forward 19.2 -> 16.3 us
@@ -439,7 +435,7 @@ static int fwd_pick_nt(const LayerDev& L, long mgroups_total, int S) {
         const int nt = cands[c];
         if (L.N % (16 * nt)) continue;
         const long wgs = mgroups_total * (L.N / (16 * nt)) * S;
-        static const long min_wgs = getenv("DQN_FWD_MIN_WGS") ? atol(getenv("DQN_FWD_MIN_WGS")) : 400;      // experiment knob
+        const long min_wgs = 400;      // (r03: 1024-2048 measured slower -- the A tile is re-read more often)
         if (wgs >= min_wgs) return nt;
         if (wgs > best_wgs) { best_wgs = wgs; best = nt; }
     }
@@ -473,18 +469,18 @@ void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* 
     // K tile depth: 32 while a launch is a few hundred workgroups (B = 32: each pays its barriers in full), 16 once it is >= 1024 of them (large
     // batches): half the LDS per workgroup doubles the resident waves (3-4 -> 6-8 per SIMD), which hides more of the operand latency than the extra
     // barrier rounds cost -- measured at config 5 (r03): conv forwards 129.7 / 93.4 / 67.0 -> 120.8 / 85.5 / 63.0 us; at config 2 the same tiles LOSE 1.5 us per launch
-    static const int kt16_min = getenv("DQN_FWD_KT16_MIN") ? atoi(getenv("DQN_FWD_KT16_MIN")) : 1024;      // experiment knob
+    const int kt16_min = 1024;
     const bool k16 = end >= kt16_min && F_KT_DEF == 32;
     const int kt = k16 ? 16 : F_KT_DEF;
     const size_t lds = (size_t)(2 * kt * F_SA + 2 * kt * SB) * 4 + (L.kind == DQN_LAYER_CONV ? (size_t)L.K * 4 : 0);
 #define FWD_LAUNCH(NT_, U8_, KT_) hipLaunchKernelGGL((k_fwd_lds<NT_, U8_, KT_>), dim3(end), dim3(256), lds, st, L, pr, S, kc)
 #define FWD_PICK(U8_, KT_) do { if (NT == 4) FWD_LAUNCH(4, U8_, KT_); else if (NT == 2) FWD_LAUNCH(2, U8_, KT_); else FWD_LAUNCH(1, U8_, KT_); } while (0)
-    if (g_fwd_dma && NT == 4 && !L.xu8 && L.K % DMA_KT == 0 && (S == 1 || kc % DMA_KT == 0) && end >= kt16_min) {
+    if ((L.opt & DQN_LOPT_FWD_DMA) && NT == 4 && !L.xu8 && L.K % DMA_KT == 0 && (S == 1 || kc % DMA_KT == 0) && end >= kt16_min) {
         const size_t ldsd = (size_t)(2 * DMA_D * DMA_KT * 64) * 4 + (L.kind == DQN_LAYER_CONV ? (size_t)L.K * 4 : 0);
         hipLaunchKernelGGL(k_fwd_dma, dim3(end), dim3(256), ldsd, st, L, pr, S, kc);
         return;
     }
-    const int m32 = g_fwd_m32;      // experiment (DQN_FWD_M32=1 at dqn_engine_create): 32x32x2 MFMA blocks for the 64-channel tiles
+    const int m32 = (L.opt & DQN_LOPT_FWD_M32) ? 1 : 0;      // experiment (DQN_FWD_M32=1 at dqn_engine_create): 32x32x2 MFMA blocks for the 64-channel tiles
     if (m32 && NT == 4 && !L.xu8) { if (k16) hipLaunchKernelGGL((k_fwd_lds<4, false, 16, true>), dim3(end), dim3(256), lds, st, L, pr, S, kc); else hipLaunchKernelGGL((k_fwd_lds<4, false, F_KT_DEF, true>), dim3(end), dim3(256), lds, st, L, pr, S, kc); }
     else if (L.xu8) { if (k16) FWD_PICK(true, 16); else FWD_PICK(true, F_KT_DEF); }
     else { if (k16) FWD_PICK(false, 16); else FWD_PICK(false, F_KT_DEF); }
@@ -1030,7 +1026,7 @@ static int conv_max_chunks(const LayerDev& L) {
 // dX body of a launch: 2 = 32 features x 128 samples per workgroup (large batches; dense plan chunks go through slabs, conv taps unchunked),
 // 3 = 32 x 32 tiles with one wave per (source, chunk) unit (dx_units_body; chunks combined in the workgroup), -1 = not covered by the LDS kernels
 static int dx_mode(const LayerDev& L, int nsrc, int B, int ldy) {
-    static const bool no_wide = getenv("DQN_NO_DX_WIDE") != nullptr;
+    const bool no_wide = (L.opt & DQN_LOPT_NO_DX_WIDE) != 0;
     const bool dense = L.kind == DQN_LAYER_DENSE;
     const int S = dense ? dqn_nchunks(L.N, L.dx_kc) : 1, kc = dqn_chunk_len(L.N, L.dx_kc);
     if (B % 32 || ldy % 4 || L.N % 32 || (S > 1 && kc % 32) || L.w_off % 4) return -1;

@@ -373,9 +373,13 @@ __global__ __launch_bounds__(NTH) void k_tiny_step(const TinyArgs* __restrict__ 
     pa.idx_pre = A.idx_pre; pa.seed = A.seed; pa.B = B; pa.phase = 0;
     prio_block_run(pa, st, reinterpret_cast<long long*>(sm), A.lds_bytes, nullptr, sample ? ctr0 + 1 : ctr0);
 }
-void launch_tiny_step(hipStream_t st, const TinyArgs* a_dev, unsigned lds_bytes, int sample) {
-    static const int stop = getenv("DQN_TINY_STOP") ? atoi(getenv("DQN_TINY_STOP")) : 0;      // timing probe: return after phase n (wrong numbers, right schedule)
-    static unsigned lds_attr = 0;      // dynamic LDS beyond 64 KB has to be requested per function
-    if (lds_bytes > 64 * 1024 && lds_bytes > lds_attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tiny_step<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); lds_attr = lds_bytes; }
+int launch_tiny_step(hipStream_t st, const TinyArgs* a_dev, unsigned lds_bytes, int sample, int stop) {
+    // dynamic LDS beyond 64 KB has to be requested per function AND per device: asked for on every enqueue that needs it (an enqueue is a graph capture or an eager
+    // launch, never the replay path), and a refusal is reported instead of leaving a launch that cannot run
+    if (lds_bytes > 64 * 1024) {
+        const hipError_t le = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tiny_step<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (le != hipSuccess) { (void)hipGetLastError(); return -1; }
+    }
     hipLaunchKernelGGL((k_tiny_step<1024>), dim3(1), dim3(1024), lds_bytes, st, a_dev, sample, stop);
+    return 0;
 }

@@ -287,10 +287,6 @@ int dqn_profile_step(dqn_engine_t* e, int max_entries, const char** names, float
  * otherwise both steps are plain ones).  Results of dqn_train_steps(n) are bit-identical to n dqn_train_step calls either way. */
 int dqn_profile_steady_step(dqn_engine_t* e, int max_entries, const char** names, float* ms, int* n_entries);
 
-/* debug aid, TRACE BUILDS ONLY (library compiled with -DDQN_KTRACE; the product build returns an error): per-workgroup timestamps of the
- * LDS-tiled GEMM kernels (tools/ktrace.py, tools/ktrace_bwd.py).  out == NULL starts recording; otherwise stops and copies n 64-bit words:
- * [0] = record count, then 8-word records {grid, block, s_memtime x 6}.  The buffer belongs to the engine. */
-int dqn_debug_ktrace(dqn_engine_t* e, uint64_t* out, size_t n);
 
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop

@@ -660,3 +660,24 @@ def test_scalar_mailbox_and_async_step_bit_exact(pkg, netf, B, graph):
         lc = cpu.train_step(want_td=False)
     assert lg == lc
     gpu.close(); cpu.close()
+
+
+def test_engine_switches_are_read_at_creation_and_stay_per_engine(pkg, monkeypatch):
+    """experiment / test switches are read ONCE, in dqn_engine_create, into the engine (EngineOpts, csrc/engine.h): a second engine in the same process does
+    not inherit the first one's, and changing the environment afterwards changes nothing for an existing engine"""
+    net = cfg1_mlp_dueling()
+    hp = ref.hparams_for(net, batch_size=32, buffer_size=64)
+    layers = ref.layers_from_network(net)
+    monkeypatch.setenv("DQN_NO_TINY", "1")
+    a = pkg.Engine(layers, hp)                       # created under DQN_NO_TINY: the multi-launch program
+    monkeypatch.delenv("DQN_NO_TINY")
+    b = pkg.Engine(layers, hp)                       # created without: the single-launch step
+    monkeypatch.setenv("DQN_NO_TINY", "1")           # ... and setting it again must not reach b
+    fill((a, b), net, 40, seed=1); set_same_params((a, b), net, seed=1)
+    na = [n for n, _ in a.profile_step()]; nb = [n for n, _ in b.profile_step()]
+    assert "tiny_step" not in na and len(na) > 3, na
+    assert nb == ["tiny_step"], nb
+    for _ in range(3):                               # two schedules of the same arithmetic
+        ra, rb = a.train_step(), b.train_step()
+        assert ra[0] == rb[0] and ra[1] == rb[1]; np.testing.assert_array_equal(ra[2], rb[2])
+    a.close(); b.close()
