@@ -103,6 +103,7 @@ class CommInfo(C.Structure):
 
 # name -> argtypes (without prefix).  All return int unless listed in _RESTYPE.
 PROTOS = {
+    "plan_version": [],
     "plan_default": [_P(LayerDesc), C.c_int, _P(HParams), _P(LayerPlan)],
     "engine_create": [_P(LayerDesc), C.c_int, _P(HParams), _P(LayerPlan), C.c_int, _P(_vp)],
     "engine_destroy": [_vp],
@@ -524,14 +525,21 @@ class Handle:
             m, v, bp = self.get_adam_state()
             c = self.get_counters()
             return dict(p_on=self.get_params(NET_ONLINE), p_tg=self.get_params(NET_TARGET), adam_m=m, adam_v=v, adam_bp=np.asarray(bp, np.float64),
-                        s=s, sp=sp, a=a, r=r, done=d, ep_len=ln, counters=np.array([c["size"], c["widx"], c["sample_ctr"], c["train_steps"]], np.uint64))      # the draw counter uses all 64 bits
+                        s=s, sp=sp, a=a, r=r, done=d, ep_len=ln, counters=np.array([c["size"], c["widx"], c["sample_ctr"], c["train_steps"]], np.uint64),      # the draw counter uses all 64 bits
+                        plan=np.array(self.plan(), np.int32), plan_version=np.int32(self.f["plan_version"]()))
         s, sp, a, r, d, pr = self.replay_export()
         m, v, bp = self.get_adam_state()
         c = self.get_counters()
         return dict(p_on=self.get_params(NET_ONLINE), p_tg=self.get_params(NET_TARGET), adam_m=m, adam_v=v, adam_bp=np.asarray(bp, np.float64),
-                    s=s, sp=sp, a=a, r=r, done=d, priorities=pr, counters=np.array([c["size"], c["widx"], c["sample_ctr"], c["train_steps"]], np.int64))
+                    s=s, sp=sp, a=a, r=r, done=d, priorities=pr, counters=np.array([c["size"], c["widx"], c["sample_ctr"], c["train_steps"]], np.int64),
+                    plan=np.array(self.plan(), np.int32), plan_version=np.int32(self.f["plan_version"]()))
 
     def restore(self, ck):
+        # a run continues bit for bit only under the plan (rounding order) and the plan semantics it was saved with
+        if "plan_version" in ck and int(ck["plan_version"]) != self.f["plan_version"]():
+            raise DQNError(f"checkpoint was written under plan version {int(ck['plan_version'])}, this library is version {self.f['plan_version']()}: the rounding order differs, a bit-exact resume is impossible")
+        if "plan" in ck and [tuple(int(x) for x in r) for r in np.asarray(ck["plan"]).reshape(-1, 3)] != [tuple(p) for p in self.plan()]:
+            raise DQNError("checkpoint was written under a different summation plan: create the engine with plan=checkpoint['plan']")
         self.set_params(ck["p_on"], NET_ONLINE); self.set_params(ck["p_tg"], NET_TARGET)
         if self.hp.recurrence:
             self.episode_import(ck["s"], ck["sp"], ck["a"], ck["r"], ck["done"], ck["ep_len"])

@@ -164,6 +164,7 @@ static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out, c
     const int cg = drqn_fused_cg(L, n, hp->obs_c * hp->obs_h * hp->obs_w, B, hp->trace_length, hp->n_actions, hp->dueling, hp->double_q, hp->recurrence);
     if (cg) for (int i = 0; i < n; i++) out[i].dw_kc = -cg;
 }
+extern "C" int dqn_plan_version(void) { return DQN_PLAN_VERSION; }
 extern "C" int dqn_plan_default(const dqn_layer_desc* layers, int n_layers, const dqn_hparams* hp, dqn_layer_plan* plan_out) {
     LayerDev L[DQN_MAX_LAYERS]; int lb, lv, la; size_t P, Pi;
     if (build_layers(layers, n_layers, hp, L, &lb, &lv, &la, &P, &Pi)) return -1;

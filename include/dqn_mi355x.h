@@ -106,6 +106,12 @@ int dqn_hparams_default(dqn_hparams* hp);
 
 /* Host-only (no GPU needed): the default summation-order plan the engine would use
  * for this network, one entry per layer. */
+/* Version of the plan SEMANTICS (what a dqn_layer_plan value means for the rounding order) and of dqn_plan_default's choices.  Results are bit-identical only
+ * between builds of the same version under the same plan; a checkpoint records both and a resume across versions is refused.
+ *   1  rounds 1-2      2  round 3: conv dx_kc = RAW taps per chunk, conv dw_kc may be sample-granular      3  round 4: dw_kc < 0 = column-group chunks
+ *   (recurrent networks; the default for the networks the fused recurrent step covers) */
+#define DQN_PLAN_VERSION 3
+int dqn_plan_version(void);
 int dqn_plan_default(const dqn_layer_desc* layers, int n_layers, const dqn_hparams* hp,
                      dqn_layer_plan* plan_out);
 

@@ -145,6 +145,7 @@ static int fused_cg(const dqn_layer_desc* d, int n, const dqn_hparams* hp) {
     }
     return 0;
 }
+int ref_plan_version(void) { return DQN_PLAN_VERSION; }
 int ref_plan_default(const dqn_layer_desc* d, int n, const dqn_hparams* hp, dqn_layer_plan* out) {
     /* independent restatement of the rule in DESIGN.md section 4 (the tests check it
      * equals dqn_plan_default of the product) */

@@ -591,6 +591,16 @@ def test_checkpoint_resume_is_bit_exact(pkg, u8, tmp_path):
     z = np.zeros((101,) + net.obs_shape, b.obs_np)
     with pytest.raises(pkg.DQNError, match="capacity"):
         b.replay_import(z, z, np.zeros(101, np.int32), np.zeros(101, np.float32), np.zeros(101, np.uint8), np.ones(101, np.float32))
+    # the checkpoint records the summation plan and the version of its semantics (include/dqn_mi355x.h DQN_PLAN_VERSION): a resume that could not be bit-exact is refused
+    assert int(ck["plan_version"]) == pkg.fns()["plan_version"]() == 3 and [tuple(r) for r in ck["plan"]] == a.plan()
+    with pytest.raises(pkg.DQNError, match="plan version"):
+        b.restore(dict(ck, plan_version=np.int32(2)))
+    other = [(p[0], p[1], 64 if p[2] else p[2]) for p in a.plan()]
+    if other != a.plan():
+        c = pkg.Engine(ref.layers_from_network(net), hp, plan=other)
+        with pytest.raises(pkg.DQNError, match="different summation plan"):
+            c.restore(ck)
+        c.close()
 
 
 def test_sampler_distinct_gpu_equals_twin(pkg):
