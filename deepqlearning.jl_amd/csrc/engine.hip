@@ -844,8 +844,10 @@ extern "C" int dqn_train_steps(dqn_engine_t* e, int n, float* loss, float* grad_
         auto cap1 = [&](bool tp, bool pgth, hipGraphExec_t* g, int rep) { if (*g) return 0; e->step_take_pre = tp; e->step_pregather = pgth; const int rc = capture(e, true, PH_ALL, g, rep);
                                                                          e->step_take_pre = e->step_pregather = false; return rc; };
         if (pg) { if (cap1(false, true, &e->g_pgv[0][1], 1) || cap1(true, true, &e->g_pgv[1][1], 1) || cap1(true, false, &e->g_pgv[1][0], 1)) return -1; }
-        if (MID_GROUP > 1 && n >= MID_GROUP + (pg ? 2 : 0) && cap1(pg, pg, &e->g_mid, MID_GROUP)) return -1;
-        if (e->mid_big > MID_GROUP && n >= e->mid_big + (pg ? 2 : 0) && cap1(pg, pg, &e->g_mid_big, e->mid_big)) return -1;      // only calls long enough to use it pay its capture
+        if (MID_GROUP > 1 && cap1(pg, pg, &e->g_mid, MID_GROUP)) return -1;
+        // (ADVICE r03 suggested capturing the grouped graphs only in calls long enough to use them.  Measured, r04: the driver's `--steps 20 --warmup 5` then pays the capture
+        // + instantiate of both grouped graphs INSIDE its 3 ms timed region -- 7100 -> 5984 steps/s.  They are captured by the first call, whatever its length: ~0.6 ms, once.)
+        if (e->mid_big > MID_GROUP && cap1(pg, pg, &e->g_mid_big, e->mid_big)) return -1;
     }
     for (int i = 0; i < n;) {
         // a run of identical steps: middle steps (pipelined gather) or, where that does not apply, any steps

@@ -6,7 +6,7 @@ import sys
 
 c = sqlite3.connect(sys.argv[1])
 rows = c.execute("select name, start, end, grid_x, workgroup_x, lds_size, vgpr_count from kernels order by start").fetchall()
-idxs = [i for i, r in enumerate(rows) if r[0].startswith("k_adam")]
+idxs = [i for i, r in enumerate(rows) if r[0].startswith("k_adam_pg")] or [i for i, r in enumerate(rows) if r[0].startswith("k_adam")]      # k_adam_pg: only the steady-state step of dqn_train_steps ends with it
 a, b = idxs[-3] + 1, idxs[-2] + 1
 t0 = rows[a][1]
 print(f"{'t_us':>9s} {'dur_us':>8s} {'grid':>8s} {'wg':>4s} {'lds':>6s} {'vgpr':>4s}  kernel")
