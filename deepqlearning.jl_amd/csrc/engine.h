@@ -103,6 +103,7 @@ struct dqn_engine {
     // pub_ctr = publishes executed by the device (the record of ticket t sits in slot t % DQN_MAIL_SLOTS once its seq == t)
     StepMail *mail_host = nullptr, *mail_dev = nullptr; unsigned long long* pub_ctr = nullptr; unsigned long long pub_issued = 0; bool step_publish = false;
     hipGraphExec_t g_full_pub[2] = {nullptr, nullptr};      // g_full + the publish launch
+    hipGraphExec_t g_pgv_pub = nullptr;                      // the LAST step of dqn_train_steps (takes the pre-gathered batch, gathers nothing) + the publish launch
     bool pg_ok = false, step_pregather = false, step_take_pre = false; PreGather pg; long adam_step = -1;
     bool no_tiny = false;   // DQN_NO_TINY at dqn_engine_create: always the multi-launch program
     bool tiny = false;      // the whole step is ONE single-workgroup launch that samples and gathers itself (tiny_step.hip)

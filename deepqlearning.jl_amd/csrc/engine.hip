@@ -289,6 +289,7 @@ void drop_graphs(dqn_engine* e) {
         if (e->g_pre[i]) { hipGraphExecDestroy(e->g_pre[i]); e->g_pre[i] = nullptr; }
         for (int j = 0; j < 2; j++) if (e->g_pgv[i][j]) { hipGraphExecDestroy(e->g_pgv[i][j]); e->g_pgv[i][j] = nullptr; }
     }
+    if (e->g_pgv_pub) { hipGraphExecDestroy(e->g_pgv_pub); e->g_pgv_pub = nullptr; }
     if (e->g_post) { hipGraphExecDestroy(e->g_post); e->g_post = nullptr; }
     if (e->g_post_pg) { hipGraphExecDestroy(e->g_post_pg); e->g_post_pg = nullptr; }
     if (e->g_mid) { hipGraphExecDestroy(e->g_mid); e->g_mid = nullptr; }
@@ -646,14 +647,17 @@ int run_step(dqn_engine* e, bool sample, bool take_pre, bool pregather) {
     e->step_take_pre = e->step_pregather = false;
     if (sample && e->pg_ok && (take_pre || pregather) && e->world <= 1 && !(e->comm && e->force_comm)) {
         e->step_take_pre = take_pre; e->step_pregather = pregather;
+        const bool pub = e->step_publish && e->mail_dev != nullptr && take_pre && !pregather; e->step_publish = pub;      // the LAST step of a dqn_train_steps call may publish its scalars
         int rc = 0;
         if (e->hp.use_graph && !e->profiling) {
-            hipGraphExec_t& g = e->g_pgv[take_pre ? 1 : 0][pregather ? 1 : 0];
+            hipGraphExec_t& g = pub ? e->g_pgv_pub : e->g_pgv[take_pre ? 1 : 0][pregather ? 1 : 0];
             if (!g && capture(e, true, PH_ALL, &g)) rc = -1; else HIPCHK(hipGraphLaunch(g, e->stream));
         } else { enqueue_step(e, true, PH_ALL); HIPCHK(hipGetLastError()); }
-        e->step_take_pre = e->step_pregather = false;
+        e->step_take_pre = e->step_pregather = false; e->step_publish = false;
+        if (!rc && pub) e->pub_issued++;
         return rc;
     }
+    if (e->world > 1 || (e->comm && e->force_comm)) e->step_publish = false;
     if (e->world > 1 || (e->comm && e->force_comm)) {      // data-parallel replicas (also DQN_SIM_WORLD: world = k without a communicator)
         // the pre-gather is rank-local (own replay, own arena), so it works on replicas too: first half without the gather launch, the Adam
         // launch of the second half gathers the next batch.  Every rank takes the same variant (same configuration, same call).
@@ -844,6 +848,7 @@ extern "C" int dqn_train_steps(dqn_engine_t* e, int n, float* loss, float* grad_
         auto cap1 = [&](bool tp, bool pgth, hipGraphExec_t* g, int rep) { if (*g) return 0; e->step_take_pre = tp; e->step_pregather = pgth; const int rc = capture(e, true, PH_ALL, g, rep);
                                                                          e->step_take_pre = e->step_pregather = false; return rc; };
         if (pg) { if (cap1(false, true, &e->g_pgv[0][1], 1) || cap1(true, true, &e->g_pgv[1][1], 1) || cap1(true, false, &e->g_pgv[1][0], 1)) return -1; }
+        if (pg && mailbox_ok(e) && !e->g_pgv_pub) { e->step_publish = true; const int rc = cap1(true, false, &e->g_pgv_pub, 1); e->step_publish = false; if (rc) return -1; }      // last step + publish
         if (MID_GROUP > 1 && cap1(pg, pg, &e->g_mid, MID_GROUP)) return -1;
         // (ADVICE r03 suggested capturing the grouped graphs only in calls long enough to use them.  Measured, r04: the driver's `--steps 20 --warmup 5` then pays the capture
         // + instantiate of both grouped graphs INSIDE its 3 ms timed region -- 7100 -> 5984 steps/s.  They are captured by the first call, whatever its length: ~0.6 ms, once.)
@@ -860,8 +865,12 @@ extern "C" int dqn_train_steps(dqn_engine_t* e, int n, float* loss, float* grad_
             HIPCHK(hipGraphLaunch(e->g_mid, e->stream));
             i += MID_GROUP; continue;
         }
+        // the last step of a call that returns scalars publishes them from its own last launch into the host mailbox (no fold launch / D2H copy / stream synchronize)
+        const unsigned long long pub0 = e->pub_issued;
+        e->step_publish = (loss || grad_norm) && i + 1 == n && mailbox_ok(e);
         if (run_step(e, true, pg && i > 0, pg && i + 1 < n)) return -1;
         i++;
+        if (i == n && e->pub_issued != pub0) return wait_mail(e, e->pub_issued, true, loss, grad_norm, nullptr);
     }
     if (loss || grad_norm) return fetch_scalars(e, loss, grad_norm);
     return 0;

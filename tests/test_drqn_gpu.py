@@ -213,3 +213,25 @@ def test_drqn_column_group_plan_on_uncovered_network_is_refused(pkg):
     with pytest.raises(pkg.DQNError, match="column-group dW chunks"):
         gpu.train_step_drqn()
     gpu.close()
+
+
+def test_drqn_fused_step_long_run_wraps_the_draw_ring(pkg):
+    """the fused recurrent step takes its episode draws from a 64-slot mapped host ring (slot = a device-side sequence number): 300 steps -- single calls with the engine's own
+    sampler, explicit draws, and dqn_train_steps runs of 8-step graphs, in every alignment -- wrap it several times and must leave the twin's parameters bit for bit"""
+    net, B, T, kw, rng, gpu, cpu, ring, params = setup(pkg, "cfg4_lstm_plain")
+    assert all(p[2] < 0 for p in gpu.plan())                        # the fused path
+    done = 0
+    for n in (1, 7, 8, 9, 30, 64, 3, 65, 16, 40):
+        lg = gpu.train_steps(n)
+        for _ in range(n):
+            lc = cpu.train_step_drqn()
+        assert lg == lc, (done, n, lg, lc)
+        done += n
+        idx, start = draws(ring, B, rng)                              # an explicit-draw step in between shifts the alignment of the next run
+        assert gpu.train_step_drqn(idx, start) == cpu.train_step_drqn(idx, start)
+        done += 1
+    assert done > 3 * 64
+    np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+    mg, vg, bg = gpu.get_adam_state(); mc, vc, bc = cpu.get_adam_state()
+    np.testing.assert_array_equal(mg, mc); np.testing.assert_array_equal(vg, vc); np.testing.assert_array_equal(bg, bc)
+    gpu.close(); cpu.close()
