@@ -594,9 +594,11 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
 #pragma unroll
             for (int t = 0; t < NT; t++) acc[t] = MFMA(af[st], bf[st][t], acc[t]);
         if (do_bias) {
+            // two samples per read: ds_read_b64 banks are (dword address) mod 64 per 32-lane group and 34 * lane takes 32 distinct even values there -- conflict-free, where the
+            // one-dword reads put lanes l and l + 16 on one bank (r04; the additions stay in ascending sample order)
             const float* br = Bs + (buf * NW + tid) * W_ST;
 #pragma unroll
-            for (int b = 0; b < 32; b++) dbacc = dbacc + br[b];
+            for (int b = 0; b < 32; b += 2) { const f32x2 v2 = *reinterpret_cast<const f32x2*>(br + b); dbacc = dbacc + v2.x; dbacc = dbacc + v2.y; }
         }
     };
     Stage r0, r1;
@@ -624,25 +626,35 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
     const size_t per_s = (size_t)(L.K + 1) * L.N;
     float* out = p.out + (size_t)s * per_s;
     if (probe & 4) return;
-    if ((((size_t)out) & 15) == 0) {
-        // epilogue through LDS: the accumulators hold 4 rows x 1 column per lane (16 scattered 64-byte pieces per wave and N tile); transposed through the
-        // wave's OWN rows of the A tile (no other wave reads them, every staging store is behind the last barrier) each store instruction writes whole
-        // 16*NT-float row segments -- NT instead of 4*NT store instructions per wave, full lines instead of halves (r03_i PMC: the non-temporal
+    if ((((size_t)out) & 15) == 0 && NT >= 2) {
+        // epilogue through LDS: the accumulators hold 4 rows x 1 column per lane (16 scattered 64-byte pieces per wave and N tile); transposed through LDS each store
+        // instruction writes whole 16*NT-float row segments -- NT instead of 4*NT store instructions per wave, full lines instead of halves (r03_i PMC: the non-temporal
         // half-line stores moved 21.7 MB for the 12.8 MB dense gradient).  Non-temporal: the gradient is read once, by the Adam launch.
-        float* T0 = As + (16 * wave) * W_ST;           // rows 16w.. of buffer 0: N tiles 0, 1;   buffer 1 (+ 64 rows): N tiles 2, 3
+        // r04: the transposed tile is [64 rows][NW] with NO padding and the 16-column tiles of rows 4..7 (mod 8) swapped pairwise (column ^ 16 for odd kq):
+        //   stores  (ds_write_b32: banks mod 32 per 32-lane group): lanes (i, kq = 0 | 1) hit banks (16 t + i) and (16 (t ^ 1) + i) -- disjoint;
+        //   reads   (ds_read_b128: banks mod 64 per 16-lane group {0-3,12-15,20-27} / {4-11,16-19,28-31} / +32): each group reads 64 CONTIGUOUS floats
+        //           (one row of NW = 64, two adjacent rows of NW = 32) -- every bank once.
+        // The round-3 layout (the wave's own rows of the A tile, stride 34) needed no barrier but conflicted 2-way on both sides: 12-14 % of the backward
+        // launches' LDS cycles (profiles/r03_q_pmc_sq.txt).  One barrier: every wave is past its last fragment read before the tile is overwritten.
+        __syncthreads();
+        float* T = lds;
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-            float* Tt = T0 + (t >> 1) * 64 * W_ST + 16 * (t & 1) + l15;
-            Tt[(4 * kq + 0) * W_ST] = acc[t].x; Tt[(4 * kq + 1) * W_ST] = acc[t].y; Tt[(4 * kq + 2) * W_ST] = acc[t].z; Tt[(4 * kq + 3) * W_ST] = acc[t].w;
+            float* Tt = T + (16 * wave + 4 * kq) * NW + ((16 * t + l15) ^ ((kq & 1) << 4));
+            Tt[0] = acc[t].x; Tt[NW] = acc[t].y; Tt[2 * NW] = acc[t].z; Tt[3 * NW] = acc[t].w;
         }
-        constexpr int F = 4 * NT, RPI = 64 / F;        // float4 per row segment, rows per store instruction
-        const int rl = lane / F, n4 = lane % F;
+        // lane -> (16-lane hardware group g, index j in the group): rows of this wave only (LDS operations of a wave execute in order: no second barrier)
+        const int l5 = lane & 31; int g, j;
+        if (l5 < 4) { g = 0; j = l5; } else if (l5 < 12) { g = 1; j = l5 - 4; } else if (l5 < 16) { g = 0; j = l5 - 8; } else if (l5 < 20) { g = 1; j = l5 - 8; } else if (l5 < 28) { g = 0; j = l5 - 12; } else { g = 1; j = l5 - 16; }
+        g += (lane >> 5) << 1;
+        constexpr int F = 4 * NT, RPG = 16 / F, RPI = 4 * RPG;      // float4 per row, rows per 16-lane group (1 or 2), rows per store instruction (4 or 8)
+        const int rg = g * RPG + j / F, p4 = j % F;                  // row within the instruction, PHYSICAL float4 slot of that row
 #pragma unroll
-        for (int i = 0; i < NT; i++) {
-            const int row = i * RPI + rl, k = mr * 64 + 16 * wave + row;
-            const float* src = T0 + (n4 >> 3) * 64 * W_ST + row * W_ST + 4 * (n4 & 7);
-            const f32x2 lo = *reinterpret_cast<const f32x2*>(src), hi = *reinterpret_cast<const f32x2*>(src + 2);
-            if (k < L.K) __builtin_nontemporal_store((f32x4){lo.x, lo.y, hi.x, hi.y}, reinterpret_cast<f32x4*>(out + (size_t)k * L.N + n0 + 4 * n4));
+        for (int i = 0; i < 16 / RPI; i++) {
+            const int row = i * RPI + rg, k = mr * 64 + 16 * wave + row;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(T + (16 * wave + row) * NW + 4 * p4);
+            const int n4 = p4 ^ (((row >> 2) & 1) << 2);            // the logical float4 this slot holds (rows 4kq + r: tiles swapped where kq is odd)
+            if (k < L.K) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + (size_t)k * L.N + n0 + 4 * n4));
         }
     } else {
 #pragma unroll
