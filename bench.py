@@ -50,6 +50,7 @@ def build_workload(pkg, args, rank, device):
     env.rng = np.random.default_rng(1000 + rank)
     filled = 0
     o = env.observe()
+    t_fill, n_host = time.perf_counter(), 0
     if args.device_fill:
         n_fill = min(1024, args.replay)
         eng.envs_create(env, n_envs=n_fill, max_episode_length=100, seed=1000 + rank)
@@ -62,10 +63,20 @@ def build_workload(pkg, args, rank, device):
         op = env.observe()
         d = env.terminated()
         eng.replay_add(o, a.astype(np.int32), r, op, d.astype(np.uint8))   # priority (|r|+eps)^alpha (...replay.jl:122)
-        filled += env.n
+        filled += env.n; n_host += env.n
         env.reset(d)
         o = env.observe()
+    eng.sync()
+    # what the boundary costs when the caller hands over HOST observation buffers (dqn_replay_add: rows copied over PCIe straight into their ring slots; the host env
+    # mirror's own stepping is inside this time too).  Never part of `value`: the train step starts with everything resident in HBM.
+    fill_s = time.perf_counter() - t_fill
+    row_b = 2 * 4 * 84 * 84 * (1 if args.u8 else 4)
+    HOST_FILL.update({"transitions_from_host": n_host, "seconds": fill_s, "transitions_per_s": n_host / fill_s if n_host else None,
+                      "pcie_GBps_incl_host_env": n_host * row_b / fill_s / 1e9 if n_host else None, "bytes_per_transition": row_b})
     return eng, layers, hp, net, params, env
+
+
+HOST_FILL = {}
 
 
 ADAM_SLAB_BYTES = [0.0]     # the engine's OWN overhead inside k_adam (conv dW split-K slabs it reduces): reported beside, never inside, the 8(d) floor
@@ -391,7 +402,7 @@ def main():
                        "dp_overlap": bool(comm_info["dp_overlap"]),
                        **({"sim_comm": "SELF-TEST: all ranks share GPU 0, the all-gather is replaced by local copies (DQN_SIM_WORLD); not a scaling measurement"} if sim_comm else {})},
             "samples_per_s": value * args.batch,
-            "roofline": roof, "cpu_baseline": cpu, "env_loop": env_loop, "sustained": sustained, "per_call": per_call,
+            "roofline": roof, "cpu_baseline": cpu, "env_loop": env_loop, "sustained": sustained, "per_call": per_call, "host_fill": dict(HOST_FILL),
         }
         print(json.dumps(out))
     group.barrier()

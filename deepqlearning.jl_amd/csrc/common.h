@@ -612,7 +612,7 @@ static inline int drqn_fused_cg(const LayerDev* L, int nl, int E, int B, int T, 
     for (int c = 4; c >= 1; c >>= 1) {
         if (B % c || nset * 4 * H * c > 1024) continue;
         const long lds = 2 * pp + 2L * T * c * Ep + 4L * T * c + (long)nset * T * H * c + (long)nset * 7 * H * c + (long)T * N * c + 3L * T * H * c +
-                         (long)(nset + 1) * T * c * (no + 1) + (long)T * H * c + 2L * H * c + (long)H * (N + 4) + 64;
+                         (long)(nset + 1) * T * c * (no + 1) + (long)T * H * c + 2L * H * c + (long)H * (N + 4) + (long)nset * ((T * c + 15) / 16 * 16) * N + 64;
         if (lds <= 36000) return c;
     }
     return 0;

@@ -72,6 +72,8 @@ __global__ __launch_bounds__(1024) void k_drqn_cols(const DrqnColsArgs* __restri
     float* dhn = dH + T * per;                  // [cg][H]
     float* dcn = dhn + per;                     // [cg][H]
     float* WhP = dcn + per;                     // [H][4H + 4]        online Wh, padded rows (BPTT reads row u 16 B at a time: stride 4H would put every lane on one bank)
+    const int MT = (T * cg + 15) / 16;          // 16-row M tiles of the input-projection GEMM (rows = the group's columns j = t * cg + c)
+    float* GX = WhP + H * (N + 4);              // [nset][16 MT][4H]  input projections of every (set, column, gate output); the 16-column tiles of odd-kq rows swapped (conflict-free stores)
     // ---- thread role in the recurrence: (set, gate q, column c, unit u); sets: 0 = online net on s (kept for BPTT), [1 = online net on sp (double-Q)], last = target net on sp
     const bool on = tid < nset * 4 * per;
     const int set = on ? tid / (4 * per) : 0, rr = tid - set * 4 * per, q = rr / per, ee = rr - q * per, c = ee / H, u = ee - c * H, n = q * H + u;
@@ -83,14 +85,11 @@ __global__ __launch_bounds__(1024) void k_drqn_cols(const DrqnColsArgs* __restri
         const size_t slot = (size_t)(*A.draw_seq & (unsigned long long)(A.draw_slots - 1)) * B;
         ep_v = A.ring_idx[slot + b0 + tid]; np_v = A.ring_np[slot + b0 + tid];
     }
-    // this thread's Wh column, Wi column (small observations) and bias go straight from L2 into registers: the serial path of the recurrence reads no weight from LDS
+    // this thread's Wh column and bias go straight from L2 into registers: the serial path of the recurrence reads no weight from LDS
     const float* Pg = tgt ? A.p_tg : A.p_on;
-    float gx[TT], wh[HH], wir[WK];
-    const bool wi_regs = E <= WK;
+    float gx[TT], wh[HH];
 #pragma unroll
     for (int j = 0; j < HH; j++) wh[j] = (on && j < H) ? Pg[A.wh_off + (size_t)j * N + n] : 0.0f;
-#pragma unroll
-    for (int k = 0; k < WK; k++) wir[k] = (on && wi_regs && k < E) ? Pg[A.wi_off + (size_t)k * N + n] : 0.0f;
     const float bias_n = on ? Pg[A.b_off + n] : 0.0f;
     if (tid < cg) { ep_s4[tid] = ep_v; np_s[tid] = np_v; }          // waits for the draws only (the oldest loads of these lanes); everything above stays in flight
     ldsb();
@@ -109,11 +108,11 @@ __global__ __launch_bounds__(1024) void k_drqn_cols(const DrqnColsArgs* __restri
         a_s[i] = ok ? A.ep_a[slot] : 0;                              // CartesianIndex(1,1) on masked rows: harmless, the mask multiplies inside huber
         r_s[i] = ok ? A.ep_r[slot] : 0.0f; dn_s[i] = ok ? (float)A.ep_done[slot] : 0.0f; m_s[i] = ok ? 1.0f : 0.0f;
     }
-    {   // parameters of both networks into LDS -- without the Wi and Wh blocks when every thread holds its columns of them in registers (93 % of the vector)
+    {   // parameters of both networks into LDS -- without the Wh blocks: every thread holds its column of Wh in registers and BPTT reads the padded copy WhP
         const float4* po = reinterpret_cast<const float4*>(A.p_on); const float4* pt = reinterpret_cast<const float4*>(A.p_tg);
-        const int s0 = (int)A.wi_off / 4, s1 = (int)(A.wi_off + (unsigned)(E * N)) / 4, s2 = (int)A.wh_off / 4, s3 = (int)(A.wh_off + (unsigned)(H * N)) / 4;
+        const int s2 = (int)A.wh_off / 4, s3 = (int)(A.wh_off + (unsigned)(H * N)) / 4;
         for (int i = tid; i < Pint / 4; i += NT) {
-            if (wi_regs && ((i >= s0 && i < s1) || (i >= s2 && i < s3))) continue;
+            if (i >= s2 && i < s3) continue;
             reinterpret_cast<float4*>(Pon)[i] = po[i]; reinterpret_cast<float4*>(Ptg)[i] = pt[i];
         }
     }
@@ -121,43 +120,48 @@ __global__ __launch_bounds__(1024) void k_drqn_cols(const DrqnColsArgs* __restri
     if (g == 0 && tid == 0) A.st->step = A.st->step + 1;            // read by the Adam launch (beta-power slot)
     __syncthreads();
     stamp();
-    const float* P = tgt ? Ptg : Pon; const float* X = set == 0 ? Xs : Xsp;
+    const float* P = tgt ? Ptg : Pon;
 
-    // ---- phase 1: input projections of ALL time steps into registers (they do not depend on the recurrence)
+    // ---- phase 1: input projections of ALL time steps (they do not depend on the recurrence) as fp32 MFMA tiles: rows = the group's 16 MT columns j = t * cg + c, 16 gate
+    // outputs per tile, K = E in steps of 4 -- v_mfma_f32_16x16x4_f32 accumulates its four products in k order, one rounding each, so every element is the twin's chain
+    // fma(x[k], Wi[k][n], .) over k ascending from +0 (padded k and padded rows contribute fma(0, 0, acc) = acc).  As VALU chains this phase was bound by
+    // the LDS return path: 56 broadcast ds_read_b128 per thread for 200 fma (3.8 us); here a wave reads E/4 x 2 dwords per tile (r04).
+    if (A.probe & 2) {      // A/B switch (DQN_DRQN_PROBE=2): the VALU form of the same chains (same bits), kept for same-box comparisons
 #pragma unroll
-    for (int t = 0; t < TT; t++) gx[t] = 0.0f;
-    if (on) {
-        const float* wi = P + A.wi_off + n; const float* xc = X + c * Ep;
-        const int E4 = E & ~3;
-        if (wi_regs) {
-#pragma unroll
-            for (int k = 0; k < WK; k += 4) if (k < E4) {
-#pragma unroll
-                for (int t = 0; t < TT; t++) if (t < T) {
-                    const float4 x4 = *reinterpret_cast<const float4*>(xc + t * cg * Ep + k);
-                    gx[t] = fmaf(x4.x, wir[k], gx[t]); gx[t] = fmaf(x4.y, wir[k + 1], gx[t]); gx[t] = fmaf(x4.z, wir[k + 2], gx[t]); gx[t] = fmaf(x4.w, wir[k + 3], gx[t]);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < WK; k++) if (k >= E4 && k < E) {
-#pragma unroll
-                for (int t = 0; t < TT; t++) if (t < T) gx[t] = fmaf(xc[t * cg * Ep + k], wir[k], gx[t]);
-            }
-        } else {
-            for (int k = 0; k < E4; k += 4) {
-                const float w0 = wi[(size_t)k * N], w1 = wi[(size_t)(k + 1) * N], w2 = wi[(size_t)(k + 2) * N], w3 = wi[(size_t)(k + 3) * N];
-#pragma unroll
-                for (int t = 0; t < TT; t++) if (t < T) {
-                    const float4 x4 = *reinterpret_cast<const float4*>(xc + t * cg * Ep + k);
-                    gx[t] = fmaf(x4.x, w0, gx[t]); gx[t] = fmaf(x4.y, w1, gx[t]); gx[t] = fmaf(x4.z, w2, gx[t]); gx[t] = fmaf(x4.w, w3, gx[t]);
-                }
-            }
-            for (int k = E4; k < E; k++) {
+        for (int t = 0; t < TT; t++) gx[t] = 0.0f;
+        if (on) {
+            const float* wi = P + A.wi_off + n; const float* xc = (set == 0 ? Xs : Xsp) + c * Ep;
+            for (int k = 0; k < E; k++) {
                 const float w0 = wi[(size_t)k * N];
 #pragma unroll
                 for (int t = 0; t < TT; t++) if (t < T) gx[t] = fmaf(xc[t * cg * Ep + k], w0, gx[t]);
             }
         }
+    } else {
+    {
+        typedef float f32x4v __attribute__((ext_vector_type(4)));
+        const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4, nwaves = NT >> 6;
+        const int NTn = N / 16, ntiles = nset * MT * NTn, KS = Ep / 4, NJ1 = T * cg;
+        for (int tile = wave; tile < ntiles; tile += nwaves) {
+            const int st = tile / (MT * NTn), rem = tile - st * MT * NTn, mt = rem / NTn, nt = rem - mt * NTn;
+            const float* Pn = (st == nset - 1 ? Ptg : Pon) + A.wi_off + 16 * nt + l15; const float* Xn = st == 0 ? Xs : Xsp;
+            const int j = 16 * mt + l15;
+            f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < KS; ks++) {
+                const int k = 4 * ks + kq;
+                const float a = j < NJ1 ? Xn[j * Ep + k] : 0.0f;      // the rows are zero-padded to Ep
+                const float b = k < E ? Pn[(size_t)k * N] : 0.0f;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+            }
+            float* G = GX + (size_t)(st * MT * 16 + 16 * mt + 4 * kq) * N + ((16 * nt + l15) ^ ((kq & 1) << 4));      // D: rows 4 kq + i, column l15
+            G[0] = acc.x; G[N] = acc.y; G[2 * N] = acc.z; G[3 * N] = acc.w;
+        }
+    }
+    ldsb();
+    if (on) {
+#pragma unroll
+        for (int t = 0; t < TT; t++) { gx[t] = 0.0f; if (t < T) { const int j = t * cg + c; gx[t] = GX[(size_t)(set * MT * 16 + j) * N + (n ^ ((((j & 15) >> 2) & 1) << 4))]; } }
+    }
     }
     stamp();
     // ---- phase 2: the recurrence, all sequence sets side by side
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(1024) void k_drqn_cols(const DrqnColsArgs* __restri
 
 static size_t drqn_cols_lds_floats(const DrqnColsArgs& a) {
     const size_t T = a.T, cg = a.cg, H = a.H, N = 4 * H, per = H * cg, Ep = (a.E + 3) & ~3, no = a.nA + (a.dueling ? 1 : 0), ns = a.nset;
-    return 2 * (size_t)a.Pint + 2 * T * cg * Ep + 4 * T * cg + ns * T * per + ns * per + ns * 4 * per + T * cg * N + 2 * T * per + ns * T * cg * no + T * cg * no + T * per + 2 * per + H * (N + 4);
+    return 2 * (size_t)a.Pint + 2 * T * cg * Ep + 4 * T * cg + ns * T * per + ns * per + ns * 4 * per + T * cg * N + 2 * T * per + ns * T * cg * no + T * cg * no + T * per + 2 * per + H * (N + 4) + ns * ((T * cg + 15) / 16 * 16) * N;
 }
 int launch_drqn_cols(hipStream_t st, const DrqnColsArgs& a, const DrqnColsArgs* a_dev) {
     const size_t lds = drqn_cols_lds_floats(a) * sizeof(float);

@@ -82,6 +82,12 @@ int build_program(dqn_engine* e) {
                 for (int k = 0; k < 2; k++) HIPCHK(hipEventCreateWithFlags(&e->draw_ev[k], hipEventDisableTiming));
             }
             a.ring_idx = e->draw_idx_d; a.ring_np = e->draw_start_d; a.draw_seq = e->draw_seq; a.draw_slots = DQN_DRAW_SLOTS;
+            if (e->opt.drqn_probe & 4) {      // TIMING PROBE: the draws come from DEVICE memory (episode 0, one row, for every column -- wrong numbers, right schedule): what the PCIe read of the host ring costs
+                long long* di = (long long*)palloc(e, (size_t)DQN_DRAW_SLOTS * Bb * 2); int* dn = (int*)palloc(e, (size_t)DQN_DRAW_SLOTS * Bb);
+                std::vector<long long> zi((size_t)DQN_DRAW_SLOTS * Bb, 0); std::vector<int> zn((size_t)DQN_DRAW_SLOTS * Bb, 1);
+                HIPCHK(hipMemcpy(di, zi.data(), zi.size() * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dn, zn.data(), zn.size() * 4, hipMemcpyHostToDevice));
+                a.ring_idx = di; a.ring_np = dn;
+            }
             const int G = Bb / cgm;
             a.slabs = palloc(e, (size_t)G * e->Pint); a.hl = palloc(e, (size_t)B); a.td = e->td; a.st = e->state;
             a.probe = e->opt.drqn_probe;
