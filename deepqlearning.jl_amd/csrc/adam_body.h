@@ -74,7 +74,7 @@ __device__ __forceinline__ void adam_job_run(const AdamJob& J, int bid, long lon
         } else if (threadIdx.x == 0) {
             for (int t = 0; t < T; t++) { float lsum = 0.0f; for (int b = 0; b < B; b++) lsum = lsum + J.fold_hl[t * B + b]; loss = loss + lsum / (float)B; }
         }
-        if (threadIdx.x == 0) { J.state->loss = loss / (float)T; if (J.bump_ctr) *J.bump_ctr = *J.bump_ctr + 1; }
+        if (threadIdx.x == 0) J.state->loss = loss / (float)T;
     }
     float gmax = 0.0f;
     if (rblock) {

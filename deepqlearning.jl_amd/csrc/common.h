@@ -49,7 +49,7 @@ struct StepState {
 // (loss, grad_norm) of a train step as the step's LAST launch publishes them into mapped pinned HOST memory (k_publish_scalars): the host reads
 // them without a fold launch, a D2H copy or a stream synchronize.  A ring of DQN_MAIL_SLOTS records indexed by the publish sequence number.
 #define DQN_MAIL_SLOTS 64
-#define DQN_DRAW_SLOTS 64      /* episode-draw ring of the fused recurrent step (DrqnColsArgs) */
+#define DQN_DRAW_SLOTS 32      /* episode-draw slots of the fused recurrent step (DrqnColsArgs): [0,8) / [8,16) the two alternating 8-step graphs, 16 / 17 the two alternating single-step graphs */
 struct StepMail {
     float loss, gnorm; int err, pad;
     unsigned long long step;           // StepState::step when published (train steps started so far)
@@ -464,7 +464,7 @@ struct AdamJob {
     int nr; unsigned long long beg[4], end[4];
     AdamSegs segs; PrioArgs prio; int tick; unsigned sblocks;
     // recurrent fused step: the tick thread also folds the loss from the per-column Huber terms, loss = (sum_t (sum_b hl[t*B + b]) / B) / T (src/solver.jl:276-281)
-    const float* fold_hl; int fold_T, fold_B; unsigned long long* bump_ctr;      // bump_ctr: the draw-ring sequence number of the fused recurrent step, +1 per step
+    const float* fold_hl; int fold_T, fold_B;
 };
 static inline __host__ __device__ unsigned adam_job_blocks(const AdamJob& j) { return (j.prio.n > 0 ? 1u : 0u) + j.segs.blocks + j.sblocks; }
 
@@ -588,9 +588,9 @@ struct DrqnColsArgs {
     unsigned hw_off[2], hb_off[2]; int hN[2], hact[2], h_S[2], h_kc[2];      // heads: [0] = advantage stream (or the plain Q head), [1] = value stream; forward plan chunks of K = H
     const float *p_on, *p_tg;
     const float *ep_s, *ep_sp; const int* ep_a; const float* ep_r; const unsigned char* ep_done; const int* ep_len;
-    // the step's episode draws: slot (*draw_seq % draw_slots) of a mapped pinned HOST ring written by dqn_train_step_drqn (no H2D copy launch per step; the Adam launch
-    // of the step bumps *draw_seq)
-    const long long* ring_idx; const int* ring_np; const unsigned long long* draw_seq; int draw_slots;      // ring_np: rows the prefix copy delivers = max(0, min(len, T) - start)
+    // the step's episode draws: slot `slot` (a launch parameter, fixed per graph node) of a mapped pinned HOST buffer written by dqn_train_step_drqn -- no H2D copy
+    // launch per step, no device-side sequence number to chase
+    const long long* ring_idx; const int* ring_np;              // ring_np: rows the prefix copy delivers = max(0, min(len, T) - start)
     float* slabs;                                               // [B / cg][Pint] per-workgroup gradient chunks
     float *hl, *td;                                             // [T*B] Huber terms (folded by the Adam launch), TD errors
     StepState* st;
@@ -617,7 +617,7 @@ static inline int drqn_fused_cg(const LayerDev* L, int nl, int E, int B, int T, 
     }
     return 0;
 }
-int launch_drqn_cols(hipStream_t st, const DrqnColsArgs& a, const DrqnColsArgs* a_dev);      // 0 = launched; -1 = the LDS attribute could not be raised
+int launch_drqn_cols(hipStream_t st, const DrqnColsArgs& a, int slot);      // 0 = launched; -1 = the LDS attribute could not be raised
 int adam_blocks(size_t P);
 static inline int gmax_slots(size_t) { return 65536; }   // per-block max |g| of every Adam job of a step (each job owns a slot range)
 void launch_adam(hipStream_t st, const AdamJob& job, const PreGather* pg = nullptr /* see PreGather */);

@@ -43,10 +43,9 @@ __device__ __forceinline__ void ldsb() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts
 
 // TT: compile-time bound on the trace length (the input projections of all time steps live in registers); HH: bound on H (a thread keeps its Wh column in registers)
 template <int TT, int HH, int WK>
-__global__ __launch_bounds__(1024) void k_drqn_cols(const DrqnColsArgs* __restrict__ Ap) {
+__global__ __launch_bounds__(1024) void k_drqn_cols(const DrqnColsArgs A, const int slot_i) {
     extern __shared__ __align__(16) float sm[];
     __shared__ int np_s[4]; __shared__ long long ep_s4[4];
-    const DrqnColsArgs& A = *Ap;
     const int tid = threadIdx.x, NT = blockDim.x;
     const int B = A.B, T = A.T, H = A.H, E = A.E, nA = A.nA, cg = A.cg, nset = A.nset, N = 4 * H, per = H * cg, Ep = (E + 3) & ~3;
     const int duel = A.dueling ? 1 : 0, no = nA + duel, Pint = (int)A.Pint;
@@ -82,7 +81,7 @@ __global__ __launch_bounds__(1024) void k_drqn_cols(const DrqnColsArgs* __restri
     // this thread's Wh column, Wi column and bias (registers, straight from L2), the parameters of both networks (LDS)
     long long ep_v = 0; int np_v = 0;
     if (tid < cg) {                                                  // np: rows the prefix copy delivers (episode_replay.jl:82-92), computed by the host from (length, start)
-        const size_t slot = (size_t)(*A.draw_seq & (unsigned long long)(A.draw_slots - 1)) * B;
+        const size_t slot = (size_t)slot_i * B;
         ep_v = A.ring_idx[slot + b0 + tid]; np_v = A.ring_np[slot + b0 + tid];
     }
     // this thread's Wh column and bias go straight from L2 into registers: the serial path of the recurrence reads no weight from LDS
@@ -147,11 +146,14 @@ __global__ __launch_bounds__(1024) void k_drqn_cols(const DrqnColsArgs* __restri
             const float* Pn = (st == nset - 1 ? Ptg : Pon) + A.wi_off + 16 * nt + l15; const float* Xn = st == 0 ? Xs : Xsp;
             const int j = 16 * mt + l15;
             f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-            for (int ks = 0; ks < KS; ks++) {
-                const int k = 4 * ks + kq;
-                const float a = j < NJ1 ? Xn[j * Ep + k] : 0.0f;      // the rows are zero-padded to Ep
-                const float b = k < E ? Pn[(size_t)k * N] : 0.0f;
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+            for (int ks0 = 0; ks0 < KS; ks0 += 8) {               // operands of eight k-steps requested before the first MFMA (E <= 32: all of them)
+                float av[8], bv[8];
+#pragma unroll
+                for (int q8 = 0; q8 < 8; q8++) { const int k = 4 * (ks0 + q8) + kq; const bool okk = ks0 + q8 < KS;
+                    av[q8] = (okk && j < NJ1) ? Xn[j * Ep + k] : 0.0f;      // the rows are zero-padded to Ep
+                    bv[q8] = (okk && k < E) ? Pn[(size_t)k * N] : 0.0f; }
+#pragma unroll
+                for (int q8 = 0; q8 < 8; q8++) if (ks0 + q8 < KS) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q8], bv[q8], acc, 0, 0, 0);
             }
             float* G = GX + (size_t)(st * MT * 16 + 16 * mt + 4 * kq) * N + ((16 * nt + l15) ^ ((kq & 1) << 4));      // D: rows 4 kq + i, column l15
             G[0] = acc.x; G[N] = acc.y; G[2 * N] = acc.z; G[3 * N] = acc.w;
@@ -373,13 +375,13 @@ static size_t drqn_cols_lds_floats(const DrqnColsArgs& a) {
     const size_t T = a.T, cg = a.cg, H = a.H, N = 4 * H, per = H * cg, Ep = (a.E + 3) & ~3, no = a.nA + (a.dueling ? 1 : 0), ns = a.nset;
     return 2 * (size_t)a.Pint + 2 * T * cg * Ep + 4 * T * cg + ns * T * per + ns * per + ns * 4 * per + T * cg * N + 2 * T * per + ns * T * cg * no + T * cg * no + T * per + 2 * per + H * (N + 4) + ns * ((T * cg + 15) / 16 * 16) * N;
 }
-int launch_drqn_cols(hipStream_t st, const DrqnColsArgs& a, const DrqnColsArgs* a_dev) {
+int launch_drqn_cols(hipStream_t st, const DrqnColsArgs& a, int slot) {
     const size_t lds = drqn_cols_lds_floats(a) * sizeof(float);
     int nt = a.nset * 4 * a.H * a.cg; nt = (nt + 63) / 64 * 64; if (nt < a.H * a.cg) nt = a.H * a.cg; if (nt < 256) nt = 256;
     const int G = a.B / a.cg;
 #define DRQN_COLS_LAUNCH(TTv, HHv) do { \
         if (lds > 64 * 1024) { const hipError_t le = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_drqn_cols<TTv, HHv, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (le != hipSuccess) { (void)hipGetLastError(); return -1; } } \
-        hipLaunchKernelGGL((k_drqn_cols<TTv, HHv, 32>), dim3(G), dim3(nt), lds, st, a_dev); } while (0)
+        hipLaunchKernelGGL((k_drqn_cols<TTv, HHv, 32>), dim3(G), dim3(nt), lds, st, a, slot); } while (0)
     if (a.H <= 32) { if (a.T <= 8) DRQN_COLS_LAUNCH(8, 32); else if (a.T <= 16) DRQN_COLS_LAUNCH(16, 32); else DRQN_COLS_LAUNCH(64, 32); }
     else { if (a.T <= 8) DRQN_COLS_LAUNCH(8, 64); else if (a.T <= 16) DRQN_COLS_LAUNCH(16, 64); else DRQN_COLS_LAUNCH(64, 64); }
 #undef DRQN_COLS_LAUNCH

@@ -84,7 +84,7 @@ struct dqn_engine {
     float *gx_on[DQN_MAX_LAYERS] = {}, *gx_tg[DQN_MAX_LAYERS] = {}, *cst_on[DQN_MAX_LAYERS] = {}, *cst_tg[DQN_MAX_LAYERS] = {}, *gates[DQN_MAX_LAYERS] = {}, *tcb[DQN_MAX_LAYERS] = {},
           *hprev_buf[DQN_MAX_LAYERS] = {}, *cprev_buf[DQN_MAX_LAYERS] = {}, *dG[DQN_MAX_LAYERS] = {}, *dhn[DQN_MAX_LAYERS] = {}, *dcn[DQN_MAX_LAYERS] = {};
     float *pol_h[DQN_MAX_LAYERS][2] = {}, *pol_c[DQN_MAX_LAYERS][2] = {}, *pol_gx[DQN_MAX_LAYERS] = {}; int pol_flip = 0, pol_state_n = 0; uint64_t drqn_draws = 0;
-    hipGraphExec_t g_drqn = nullptr, g_drqn_k = nullptr;      // g_drqn_k: a run of fused recurrent steps as one graph (engine_drqn.hip drqn_train_steps)
+    hipGraphExec_t g_drqn[2] = {nullptr, nullptr}, g_drqn_k[2] = {nullptr, nullptr};      // the recurrent step as a graph (fused step: two alternating instances, see draw_ev); g_drqn_k: runs of 8 fused steps
     // static launch program
     struct Step { const char* name; std::function<void(dqn_engine*)> fn; };
     // acting programs (forward on n columns + env kernels), one for the training envs and one for the evaluation envs
@@ -107,9 +107,11 @@ struct dqn_engine {
     bool pg_ok = false, step_pregather = false, step_take_pre = false; PreGather pg; long adam_step = -1;
     bool no_tiny = false;   // DQN_NO_TINY at dqn_engine_create: always the multi-launch program
     bool tiny = false;      // the whole step is ONE single-workgroup launch that samples and gathers itself (tiny_step.hip)
-    // fused recurrent step: episode draws travel through a mapped pinned host ring (slot = step % DQN_DRAW_SLOTS) the kernel reads directly
-    long long *draw_idx_h = nullptr, *draw_idx_d = nullptr; int *draw_start_h = nullptr, *draw_start_d = nullptr; unsigned long long* draw_seq = nullptr; unsigned long long draw_issued = 0;
-    hipEvent_t draw_ev[2] = {nullptr, nullptr};
+    // fused recurrent step: episode draws travel through a mapped pinned host buffer of DQN_DRAW_SLOTS slots the kernel reads directly.  A slot is a LAUNCH PARAMETER, fixed per graph
+    // node: two 8-step graphs (slots 0-7 / 8-15) and two single-step graphs (16 / 17) alternate, and before the host rewrites the slots of one it waits for the event recorded
+    // behind that graph's previous launch
+    long long *draw_idx_h = nullptr, *draw_idx_d = nullptr; int *draw_start_h = nullptr, *draw_start_d = nullptr;
+    hipEvent_t draw_ev[4] = {nullptr, nullptr, nullptr, nullptr}; bool draw_ev_used[4] = {false, false, false, false}; int drqn_grp_par = 0, drqn_one_par = 0, drqn_slot_next = 0;
     unsigned long long* drqn_stamps = nullptr;      // timing probe of the fused recurrent step (DQN_DRQN_STAMPS)
     bool launch_failed = false;      // a launcher refused (an LDS attribute the device would not grant): reported by the entry point that enqueued the step
     bool drqn_fused = false;      // recurrent step = the column-parallel launch (which gathers its own episode rows) + the Adam launch (drqn_cols.hip)

@@ -293,8 +293,7 @@ void drop_graphs(dqn_engine* e) {
     if (e->g_post) { hipGraphExecDestroy(e->g_post); e->g_post = nullptr; }
     if (e->g_post_pg) { hipGraphExecDestroy(e->g_post_pg); e->g_post_pg = nullptr; }
     if (e->g_mid) { hipGraphExecDestroy(e->g_mid); e->g_mid = nullptr; }
-    if (e->g_drqn_k) { hipGraphExecDestroy(e->g_drqn_k); e->g_drqn_k = nullptr; }
-    if (e->g_drqn) { hipGraphExecDestroy(e->g_drqn); e->g_drqn = nullptr; }
+    for (int k = 0; k < 2; k++) { if (e->g_drqn_k[k]) { hipGraphExecDestroy(e->g_drqn_k[k]); e->g_drqn_k[k] = nullptr; } if (e->g_drqn[k]) { hipGraphExecDestroy(e->g_drqn[k]); e->g_drqn[k] = nullptr; } }
     if (e->g_mid_big) { hipGraphExecDestroy(e->g_mid_big); e->g_mid_big = nullptr; }
     if (e->g_pre_tp) { hipGraphExecDestroy(e->g_pre_tp); e->g_pre_tp = nullptr; }
     for (int i = 0; i < 3; i++) if (e->g_pre1[i]) { hipGraphExecDestroy(e->g_pre1[i]); e->g_pre1[i] = nullptr; }
@@ -327,7 +326,7 @@ extern "C" int dqn_engine_destroy(dqn_engine_t* e) {
     if (e->mail_host) hipHostFree(e->mail_host);
     if (e->draw_idx_h) hipHostFree(e->draw_idx_h);
     if (e->draw_start_h) hipHostFree(e->draw_start_h);
-    hipFree(e->draw_seq); for (int k = 0; k < 2; k++) if (e->draw_ev[k]) hipEventDestroy(e->draw_ev[k]);
+    for (int k = 0; k < 4; k++) if (e->draw_ev[k]) hipEventDestroy(e->draw_ev[k]);
     hipFree(e->pub_ctr);
     hipFree(e->st_a); hipFree(e->st_r); hipFree(e->st_done); hipFree(e->st_td); hipFree(e->idx); hipFree(e->idx_pre); hipFree(e->x0);
     for (int i = 0; i < e->nl; i++) { hipFree(e->act_on[i]); hipFree(e->act_tg[i]); hipFree(e->dact[i]); }

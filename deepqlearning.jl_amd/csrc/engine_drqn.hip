@@ -116,23 +116,14 @@ static int drqn_host_draws(dqn_engine* e, std::vector<int64_t>& di, std::vector<
     for (int b = 0; b < e->B; b++) { const int len = e->ep_len_host[(size_t)di[b]]; ds[b] = len > 0 ? (int32_t)(next() % (uint64_t)len) : 0; }
     return 0;
 }
-// fused recurrent step: the draws of the next step go into slot (step % DQN_DRAW_SLOTS) of the mapped host ring the step's kernel reads -- no H2D copy launch, the
-// host never waits for the GPU (before a half of the ring is reused, the event recorded behind the steps that last read it must have passed)
-static int drqn_ring_put(dqn_engine* e, unsigned long long s, const int64_t* ep_idx, const int32_t* ep_start) {
-    const int half = DQN_DRAW_SLOTS / 2;
-    if (s >= (unsigned long long)DQN_DRAW_SLOTS && s % half == 0) HIPCHK(hipEventSynchronize(e->draw_ev[(s / half) & 1]));
-    const size_t slot = (size_t)(s % DQN_DRAW_SLOTS) * e->B;
-    memcpy(e->draw_idx_h + slot, ep_idx, (size_t)e->B * 8);
+// fused recurrent step: the draws of a step go into ITS slot of the mapped host buffer (the slot is a launch parameter of the step's kernel, fixed per graph node): no H2D
+// copy launch, no device-side counter, and the host never waits for the GPU except for the previous launch of the same graph instance (two instances alternate)
+static void drqn_ring_put(dqn_engine* e, int slot, const int64_t* ep_idx, const int32_t* ep_start) {
+    const size_t o = (size_t)slot * e->B;
+    memcpy(e->draw_idx_h + o, ep_idx, (size_t)e->B * 8);
     for (int b = 0; b < e->B; b++) {      // what the kernel needs of (length, start): the number of rows the prefix copy delivers (src/episode_replay.jl:82-92)
-        const int len = e->ep_len_host[(size_t)ep_idx[b]]; int np = (len < e->T ? len : e->T) - ep_start[b]; e->draw_start_h[slot + b] = np < 0 ? 0 : np;
+        const int len = e->ep_len_host[(size_t)ep_idx[b]]; int np = (len < e->T ? len : e->T) - ep_start[b]; e->draw_start_h[o + b] = np < 0 ? 0 : np;
     }
-    return 0;
-}
-static int drqn_ring_done(dqn_engine* e, int nsteps) {      // nsteps fused steps were enqueued (nsteps divides the half ring, or is 1)
-    const int half = DQN_DRAW_SLOTS / 2; const unsigned long long before = e->draw_issued / half;
-    e->draw_issued += (unsigned long long)nsteps;
-    if (e->draw_issued / half != before) HIPCHK(hipEventRecord(e->draw_ev[((e->draw_issued / half) - 1) & 1], e->stream));
-    return 0;
 }
 extern "C" int dqn_train_step_drqn(dqn_engine_t* e, const int64_t* ep_idx, const int32_t* ep_start, float* loss, float* grad_norm) { if (!e) return fail("null engine handle");
     NEED_REC(e); HIPCHK(hipSetDevice(e->device));
@@ -140,30 +131,36 @@ extern "C" int dqn_train_step_drqn(dqn_engine_t* e, const int64_t* ep_idx, const
     if (!ep_idx) { if (drqn_host_draws(e, di, ds)) return -1; ep_idx = di.data(); ep_start = ds.data(); }
     if (drqn_check(e, ep_idx, ep_start)) return -1;
     if (build_program(e)) return -1;
-    if (e->drqn_fused) { if (drqn_ring_put(e, e->draw_issued, ep_idx, ep_start)) return -1; __atomic_thread_fence(__ATOMIC_RELEASE); }
-    else if (drqn_upload_draws(e, ep_idx, ep_start)) return -1;
+    const int par = e->drqn_fused ? e->drqn_one_par : 0, evi = 2 + par;
+    if (e->drqn_fused) {
+        if (e->draw_ev_used[evi]) HIPCHK(hipEventSynchronize(e->draw_ev[evi]));      // the previous launch of THIS instance has read its slot
+        drqn_ring_put(e, 16 + par, ep_idx, ep_start); __atomic_thread_fence(__ATOMIC_RELEASE);
+        e->drqn_slot_next = 16 + par;
+    } else if (drqn_upload_draws(e, ep_idx, ep_start)) return -1;
     if (e->hp.use_graph && !e->profiling && e->world == 1) {
-        if (!e->g_drqn && capture(e, false, PH_ALL, &e->g_drqn)) return -1;
-        HIPCHK(hipGraphLaunch(e->g_drqn, e->stream));
-    } else { enqueue_step(e, false, PH_PRE); if (e->world > 1 && exchange_grads(e)) return -1; enqueue_step(e, false, PH_POST); }
-    if (e->drqn_fused && drqn_ring_done(e, 1)) return -1;
+        if (!e->g_drqn[par] && capture(e, false, PH_ALL, &e->g_drqn[par])) return -1;
+        HIPCHK(hipGraphLaunch(e->g_drqn[par], e->stream));
+    } else { enqueue_step(e, false, PH_PRE); if (e->world > 1 && exchange_grads(e)) return -1; enqueue_step(e, false, PH_POST); if (e->launch_failed) { e->launch_failed = false; return fail("the recurrent step could not be enqueued (dynamic LDS refused)"); } }
+    if (e->drqn_fused) { HIPCHK(hipEventRecord(e->draw_ev[evi], e->stream)); e->draw_ev_used[evi] = true; e->drqn_one_par ^= 1; }
     if (loss || grad_norm) return fetch_scalars(e, loss, grad_norm);
     return 0;
 }
-// n sampled recurrent steps back to back (dqn_train_steps on a recurrent engine).  Fused step: every step reads ITS slot of the draw ring (the device-side sequence
-// number advances per step), so runs of DRQN_GROUP steps replay as ONE graph -- the draws of the whole run are written first, then one hipGraphLaunch.
+// n sampled recurrent steps back to back (dqn_train_steps on a recurrent engine).  Fused step: runs of DRQN_GROUP steps replay as ONE graph whose k-th step reads slot
+// (instance * 8 + k) -- the draws of the whole run are written first, then one hipGraphLaunch.
 int drqn_train_steps(dqn_engine* e, int n, float* loss, float* grad_norm) {
-    enum { DRQN_GROUP = 8 };      // divides DQN_DRAW_SLOTS / 2
+    enum { DRQN_GROUP = 8 };
     if (build_program(e)) return -1;
     const bool grouped = e->drqn_fused && e->hp.use_graph && !e->profiling && e->world == 1;
     std::vector<int64_t> di; std::vector<int32_t> ds;
     for (int i = 0; i < n;) {
-        if (grouped && n - i >= DRQN_GROUP && e->draw_issued % DRQN_GROUP == 0) {
-            if (!e->g_drqn_k && capture(e, false, PH_ALL, &e->g_drqn_k, DRQN_GROUP)) return -1;
-            for (int k = 0; k < DRQN_GROUP; k++) { if (drqn_host_draws(e, di, ds) || drqn_check(e, di.data(), ds.data()) || drqn_ring_put(e, e->draw_issued + k, di.data(), ds.data())) return -1; }
+        if (grouped && n - i >= DRQN_GROUP) {
+            const int par = e->drqn_grp_par;
+            if (e->draw_ev_used[par]) HIPCHK(hipEventSynchronize(e->draw_ev[par]));
+            for (int k = 0; k < DRQN_GROUP; k++) { if (drqn_host_draws(e, di, ds) || drqn_check(e, di.data(), ds.data())) return -1; drqn_ring_put(e, par * DRQN_GROUP + k, di.data(), ds.data()); }
             __atomic_thread_fence(__ATOMIC_RELEASE);
-            HIPCHK(hipGraphLaunch(e->g_drqn_k, e->stream));
-            if (drqn_ring_done(e, DRQN_GROUP)) return -1;
+            if (!e->g_drqn_k[par]) { e->drqn_slot_next = par * DRQN_GROUP; if (capture(e, false, PH_ALL, &e->g_drqn_k[par], DRQN_GROUP)) return -1; }
+            HIPCHK(hipGraphLaunch(e->g_drqn_k[par], e->stream));
+            HIPCHK(hipEventRecord(e->draw_ev[par], e->stream)); e->draw_ev_used[par] = true; e->drqn_grp_par ^= 1;
             i += DRQN_GROUP; continue;
         }
         if (dqn_train_step_drqn(e, nullptr, nullptr, nullptr, nullptr)) return -1;

@@ -78,10 +78,9 @@ int build_program(dqn_engine* e) {
                 HIPCHK(hipHostMalloc((void**)&e->draw_start_h, sizeof(int) * DQN_DRAW_SLOTS * Bb, hipHostMallocMapped | hipHostMallocCoherent));
                 memset(e->draw_idx_h, 0, sizeof(long long) * DQN_DRAW_SLOTS * Bb); memset(e->draw_start_h, 0, sizeof(int) * DQN_DRAW_SLOTS * Bb);
                 HIPCHK(hipHostGetDevicePointer((void**)&e->draw_idx_d, e->draw_idx_h, 0)); HIPCHK(hipHostGetDevicePointer((void**)&e->draw_start_d, e->draw_start_h, 0));
-                HIPCHK(hipMalloc((void**)&e->draw_seq, sizeof(unsigned long long))); HIPCHK(hipMemset(e->draw_seq, 0, sizeof(unsigned long long))); e->draw_issued = 0;
-                for (int k = 0; k < 2; k++) HIPCHK(hipEventCreateWithFlags(&e->draw_ev[k], hipEventDisableTiming));
+                for (int k = 0; k < 4; k++) { HIPCHK(hipEventCreateWithFlags(&e->draw_ev[k], hipEventDisableTiming)); e->draw_ev_used[k] = false; }
             }
-            a.ring_idx = e->draw_idx_d; a.ring_np = e->draw_start_d; a.draw_seq = e->draw_seq; a.draw_slots = DQN_DRAW_SLOTS;
+            a.ring_idx = e->draw_idx_d; a.ring_np = e->draw_start_d;
             if (e->opt.drqn_probe & 4) {      // TIMING PROBE: the draws come from DEVICE memory (episode 0, one row, for every column -- wrong numbers, right schedule): what the PCIe read of the host ring costs
                 long long* di = (long long*)palloc(e, (size_t)DQN_DRAW_SLOTS * Bb * 2); int* dn = (int*)palloc(e, (size_t)DQN_DRAW_SLOTS * Bb);
                 std::vector<long long> zi((size_t)DQN_DRAW_SLOTS * Bb, 0); std::vector<int> zn((size_t)DQN_DRAW_SLOTS * Bb, 1);
@@ -92,14 +91,13 @@ int build_program(dqn_engine* e) {
             a.slabs = palloc(e, (size_t)G * e->Pint); a.hl = palloc(e, (size_t)B); a.td = e->td; a.st = e->state;
             a.probe = e->opt.drqn_probe;
             if (e->opt.drqn_stamps) { a.stamps = (unsigned long long*)palloc(e, 64); e->drqn_stamps = a.stamps; }
-            const DrqnColsArgs* a_dev = upload(e, std::vector<DrqnColsArgs>(1, a));
-            e->prog.push_back({"drqn_cols", [=](dqn_engine* en) { if (launch_drqn_cols(en->stream, a, a_dev)) en->launch_failed = true; }});
+            e->prog.push_back({"drqn_cols", [=](dqn_engine* en) { if (launch_drqn_cols(en->stream, a, en->drqn_slot_next++)) en->launch_failed = true; }});      // the slot is baked into the captured node
             e->prog_post_begin = e->prog.size();
             AdamJob J; memset(&J, 0, sizeof J);
             J.p = e->p_on; J.m = e->m; J.v = e->v; J.g = e->grad; J.g_out = e->grad; J.state = e->state; J.gmax_part = e->gmax_part;
             J.f64mode = e->hp.adam_f64_scalars; J.lr = e->hp.learning_rate; J.b1 = e->hp.adam_beta1; J.b2 = e->hp.adam_beta2; J.eps = e->hp.adam_eps; J.gscale = 1.0f;
             J.segs.n = 1; J.segs.beg[0] = 0; J.segs.end[0] = e->Pint; J.segs.part[0] = a.slabs; J.segs.S[0] = G; J.segs.stride[0] = e->Pint; J.segs.blocks = (unsigned)((e->Pint + 255) / 256);
-            J.nr = 0; J.sblocks = 1; J.tick = 1; J.slot0 = 0; J.fold_hl = a.hl; J.fold_T = T; J.fold_B = Bb; J.bump_ctr = e->draw_seq;
+            J.nr = 0; J.sblocks = 1; J.tick = 1; J.slot0 = 0; J.fold_hl = a.hl; J.fold_T = T; J.fold_B = Bb;
             e->adam_step = (long)e->prog.size();
             e->prog.push_back({"adam", [=](dqn_engine* en) { launch_adam(en->stream, J); }});
             e->gmax_used = (int)(J.segs.blocks + J.sblocks);
