@@ -49,10 +49,15 @@ __device__ __forceinline__ void gather_fb_body(const void* __restrict__ s_rows, 
             v[p] = (gb_f32x4){0.f, 0.f, 0.f, 0.f};
             if (c < ld && f < E) v[p] = *reinterpret_cast<const gb_f32x4*>((const float*)(c < B ? s_rows : sp_rows) + rows[cl] * E + f);
         }
+        // LDS transpose without bank conflicts (r04): ds_write_b32 / ds_read_b32 are serviced per 32-lane group on banks (dword address) mod 32; with the 65-word pitch the 16 float4
+        // columns of a row (and the 16 column quads of the read-back) repeat every 8 lanes, so lanes 8 apart rotate which of their four words goes out in a given instruction
+        // (stores: by column half + row parity; reads: by 2, the two feature rows of a group being 1 bank apart) -- every instruction then touches 32 distinct banks (PMC r03: 112 896 conflict cycles per launch)
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            const int q = threadIdx.x + 256 * p, cl = q >> 4, fl = 4 * (q & 15);
-            tile[cl][fl] = v[p].x; tile[cl][fl + 1] = v[p].y; tile[cl][fl + 2] = v[p].z; tile[cl][fl + 3] = v[p].w;
+            const int q = threadIdx.x + 256 * p, cl = q >> 4, m = q & 15, fl = 4 * m, rot = (m >> 3) + (cl & 1);      // the four (row parity, column half) classes of a 32-lane group land on the four word offsets
+            const float vv[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const int ii = (i + rot) & 3; tile[cl][fl + ii] = ii == 0 ? vv[0] : ii == 1 ? vv[1] : ii == 2 ? vv[2] : vv[3]; }
         }
     } else {
 #pragma unroll 4
@@ -75,7 +80,12 @@ __device__ __forceinline__ void gather_fb_body(const void* __restrict__ s_rows, 
     for (int p = 0; p < 4; p++) {
         const int fl = p * 16 + r16, f = f0 + fl, c = c0 + 4 * l16;
         if (f >= E) continue;
-        if (c + 3 < ld) *reinterpret_cast<gb_f32x4*>(x0 + (size_t)f * ld + c) = (gb_f32x4){tile[4 * l16][fl], tile[4 * l16 + 1][fl], tile[4 * l16 + 2][fl], tile[4 * l16 + 3][fl]};
+        if (c + 3 < ld) {
+            float o4[4]; const int rot = (l16 >> 3) << 1;
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int uu = (u + rot) & 3; const float t = tile[4 * l16 + uu][fl]; if (uu == 0) o4[0] = t; else if (uu == 1) o4[1] = t; else if (uu == 2) o4[2] = t; else o4[3] = t; }
+            *reinterpret_cast<gb_f32x4*>(x0 + (size_t)f * ld + c) = (gb_f32x4){o4[0], o4[1], o4[2], o4[3]};
+        }
         else for (int u = 0; u < 4; u++) if (c + u < ld) x0[(size_t)f * ld + c + u] = tile[4 * l16 + u][fl];
     }
     if (bx == 0) gather_batch_meta(meta, rows, c0, B, cap2, tree, state);
@@ -117,7 +127,12 @@ __device__ __forceinline__ void gather_u8b_body(const unsigned char* __restrict_
         }
     }
 #pragma unroll
-    for (int p = 0; p < 8; p++) { const int q = threadIdx.x + 256 * p; uint32_t* d = tile32 + (q >> 4) * 65 + 4 * (q & 15); d[0] = v[p].x; d[1] = v[p].y; d[2] = v[p].z; d[3] = v[p].w; }
+    for (int p = 0; p < 8; p++) {      // rotated word order per 8-lane block: conflict-free like gather_fb_body's stores (r04; PMC r03: 67 % of this kernel's LDS cycles were conflicts)
+        const int q = threadIdx.x + 256 * p, m = q & 15, rot = (m >> 3) + ((q >> 4) & 1); uint32_t* d = tile32 + (q >> 4) * 65 + 4 * m;
+        const uint32_t vv[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int ii = (i + rot) & 3; d[ii] = ii == 0 ? vv[0] : ii == 1 ? vv[1] : ii == 2 ? vv[2] : vv[3]; }
+    }
     __syncthreads();
     // 32 lanes x 4 columns = one 128-byte segment of a feature row of the arena; a wave writes 2 feature rows per instruction
     const int c4 = threadIdx.x & 31, r8 = threadIdx.x >> 5;
@@ -125,9 +140,9 @@ __device__ __forceinline__ void gather_u8b_body(const unsigned char* __restrict_
     for (int p = 0; p < 32; p++) {
         const int fl = p * 8 + r8, f = f0 + fl, c = c0 + 4 * c4, sh = 8 * (fl & 3), w = fl >> 2;
         if (f >= E) continue;
-        uint32_t o = 0;
+        uint32_t o = 0; const int rot = c4 >> 3;       // lanes 8 apart sit on the same bank (4 c4 mod 32): each reads a different one of its four columns per instruction
 #pragma unroll
-        for (int u = 0; u < 4; u++) o |= ((tile32[(4 * c4 + u) * 65 + w] >> sh) & 0xffu) << (8 * u);
+        for (int u = 0; u < 4; u++) { const int uu = (u + rot) & 3; o |= ((tile32[(4 * c4 + uu) * 65 + w] >> sh) & 0xffu) << (8 * uu); }
         if (c + 3 < ld) *reinterpret_cast<uint32_t*>(x0b + (size_t)f * ld + c) = o;
         else for (int u = 0; u < 4; u++) if (c + u < ld) x0b[(size_t)f * ld + c + u] = (unsigned char)(o >> (8 * u));
     }
