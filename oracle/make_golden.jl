@@ -45,7 +45,7 @@ function feedforward_case(name, mdp, model; B, double_q, dueling, prioritized, l
     action_map = collect(RL.actions(env)); action_indices = Dict(a => i for (i, a) in enumerate(action_map))
     replay = initialize_replay_buffer(solver, env, action_indices)                     # :180-189 (populate with |r| priorities)
     active_q = dueling ? create_dueling_network(solver.qnetwork) : solver.qnetwork     # :48-52
-    policy = NNPolicy(env, active_q, action_map, length(RL.obs_dimensions(env)))
+    policy = NNPolicy(env, active_q, action_map, length(DeepQLearning.obs_dimensions(env)))
     target_q = deepcopy(active_q)
     for w in Flux.params(target_q); w .*= 0.9f0; end                                    # a target that differs from the online network
     optimizer = Adam(solver.learning_rate)                                             # :66
@@ -88,7 +88,7 @@ function feedforward_case(name, mdp, model; B, double_q, dueling, prioritized, l
             bson(joinpath(outdir, "julia_qnetwork.bson"), qnetwork=[w for w in Flux.params(active_q)])
         end
     end
-    println("wrote julia_", name, ".dqnvec  loss=", "n=", n)
+    println("wrote julia_", name, ".dqnvec  (n = ", n, " transitions)")
 end
 
 function drqn_case(name, mdp, model; B, T, double_q, lr=1f-3, n_ep=24, seed=2)
@@ -99,7 +99,7 @@ function drqn_case(name, mdp, model; B, T, double_q, lr=1f-3, n_ep=24, seed=2)
     action_map = collect(RL.actions(env)); action_indices = Dict(a => i for (i, a) in enumerate(action_map))
     replay = initialize_replay_buffer(solver, env, action_indices)
     active_q = solver.qnetwork
-    policy = NNPolicy(env, active_q, action_map, length(RL.obs_dimensions(env)))
+    policy = NNPolicy(env, active_q, action_map, length(DeepQLearning.obs_dimensions(env)))
     target_q = deepcopy(active_q)
     for w in Flux.params(target_q); w .*= 0.9f0; end
     optimizer = Adam(solver.learning_rate)
