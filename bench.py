@@ -250,6 +250,8 @@ def main():
     # ---- the headline: W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize.  It runs AFTER the secondary sections
     # above (real train steps and env steps, all untimed): the GPU needs ~10 ms of activity to reach its clocks, and with --steps 20 --warmup 5
     # the timed region is 3 ms -- measured straight after the idle build phase it read 160 us/step instead of 152 (tools/first_call.py).
+    # (r04, measured and rejected: running the 10-second sustained region BEFORE it.  Five alternating runs with the driver's flags: 6201 / 6396 / 6931 / 7164 / 5909 steps/s
+    # after the sustained region vs 7004 / 7057 / 7084 / 7048 / 6944 in this order -- the first short call after ten seconds of load is slower and far noisier.)
     eng.train_steps(max(3, args.warmup))      # >= 3 so that the three step graphs of dqn_train_steps (first / middle / last) are all captured untimed
     barrier()
     t0 = time.perf_counter()
@@ -262,8 +264,8 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps / elapsed            # whole-job train steps/s (each rank runs its own B=32 step)
 
-    # ---- the same measurement over a LONG region (the driver's --steps 20 region is ~3 ms, shorter than its SMI sampler's period): K2 >= 5000
-    # steps of the identical call, same barriers, same max-over-ranks clock.  Reported beside `value`, never instead of it.
+    # ---- the same measurement over a LONG region (the driver's --steps 20 region is ~3 ms, shorter than its SMI sampler's period): `--sustained-seconds` of GPU time
+    # (default 10 s) of the identical call, same barriers, same max-over-ranks clock, BEFORE the CPU baseline.  Reported beside `value`, never instead of it.
     sustained = None
     if args.sustained_steps < 0:
         args.sustained_steps = int(max(1000, args.sustained_seconds * value / world)) if args.sustained_seconds > 0 else 0
