@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--sustained-steps", type=int, default=-1, help="steps of the long-run twin of the timed region (0 = skip; -1 = as many as --sustained-seconds needs at the measured rate)")
     ap.add_argument("--sustained-seconds", type=float, default=10.0, help="GPU time of the sustained region (longer than any SMI sampler's period; runs BEFORE the CPU baseline)")
+    ap.add_argument("--order", default="profile-first", choices=["profile-first", "env-first"], help="order of the two untimed secondary sections before the headline (A/B)")
     ap.add_argument("--per-call-steps", type=int, default=-1, help="calls of the per-call seam measurement (dqn_train_step with scalars returned, and its async form); -1 = --steps, 0 = skip")
     ap.add_argument("--dp-overlap", type=int, default=-1, choices=[-1, 0, 1], help="replicas: 1 = exchange the wide dense layers' operands on a third stream under the conv backward (DESIGN.md 8); -1 = engine default")
     ap.add_argument("--device-fill", action="store_true", help="fill the replay with the device-resident env loop (uniform-random policy, eps = 1) instead of host rollouts + PCIe; needed for config 5's 1e6-transition replay")
@@ -210,42 +211,53 @@ def main():
         torch.cuda.synchronize()
         eng.sync()
 
-    # ---- secondary: the device-resident env loop of config 3 (envs_per_rank copies of the image MDP per rank, eps-greedy + add_exp! in HBM)
     env_loop = None
-    if args.env_steps > 0:
-        eng.envs_create(env, n_envs=args.envs_per_rank, max_episode_length=100, seed=1234 + rank)
-        eng.rollout(20, t0=1, train_freq=0, target_update_freq=0, stats=False)
-        eng.sync()
-        ta = time.perf_counter()
-        eng.rollout(args.env_steps, t0=21, train_freq=0, target_update_freq=0, stats=False)      # acting only: no collective, safe on every rank
-        eng.sync()
-        tb = time.perf_counter()
-        act_s = group.max_over_ranks(tb - ta)
-        env_loop = {"envs_per_rank": args.envs_per_rank, "vector_steps": args.env_steps, "act_only_env_steps_per_s": world * args.envs_per_rank * args.env_steps / act_s,
-                    "act_only_ms_per_vector_step": act_s / args.env_steps * 1e3}
-        if world == 1:
+    prof_acc, single_gather = {}, {}
+
+    def section_env_loop():
+        nonlocal env_loop
+        # ---- secondary: the device-resident env loop of config 3 (envs_per_rank copies of the image MDP per rank, eps-greedy + add_exp! in HBM)
+        if args.env_steps > 0:
+            eng.envs_create(env, n_envs=args.envs_per_rank, max_episode_length=100, seed=1234 + rank)
+            eng.rollout(20, t0=1, train_freq=0, target_update_freq=0, stats=False)
+            eng.sync()
             ta = time.perf_counter()
-            st = eng.rollout(args.env_steps, t0=21 + args.env_steps, train_freq=4, target_update_freq=500)
+            eng.rollout(args.env_steps, t0=21, train_freq=0, target_update_freq=0, stats=False)      # acting only: no collective, safe on every rank
+            eng.sync()
             tb = time.perf_counter()
-            env_loop.update({"train_freq": 4, "loop_env_steps_per_s": args.envs_per_rank * args.env_steps / (tb - ta),
-                             "loop_train_steps_per_s": st["train_steps"] / (tb - ta), "loop_ms_per_vector_step": (tb - ta) / args.env_steps * 1e3})
+            act_s = group.max_over_ranks(tb - ta)
+            env_loop = {"envs_per_rank": args.envs_per_rank, "vector_steps": args.env_steps, "act_only_env_steps_per_s": world * args.envs_per_rank * args.env_steps / act_s,
+                        "act_only_ms_per_vector_step": act_s / args.env_steps * 1e3}
+            if world == 1:
+                ta = time.perf_counter()
+                st = eng.rollout(args.env_steps, t0=21 + args.env_steps, train_freq=4, target_update_freq=500)
+                tb = time.perf_counter()
+                env_loop.update({"train_freq": 4, "loop_env_steps_per_s": args.envs_per_rank * args.env_steps / (tb - ta),
+                                 "loop_train_steps_per_s": st["train_steps"] / (tb - ta), "loop_ms_per_vector_step": (tb - ta) / args.env_steps * 1e3})
+            group.barrier()
+
+
+    def section_profile():
+        # per-launch durations (HIP events on the engine stream, eager launches).  A profiled step is a full train step -- with its collective when
+        # world > 1 -- so EVERY rank runs the same number of them; only rank 0 uses the numbers.
+        for _ in range(args.profile_steps):
+            for name, ms in eng.profile_step(steady=True):      # the step dqn_train_steps(n) repeats (its timed loop below runs exactly that)
+                a = prof_acc.setdefault(name, [0.0, 0])
+                a[0] += ms
+                a[1] += 1
+        # the gather launch of a SINGLE dqn_train_step (inside dqn_train_steps the previous step's Adam launch carries it: "adam+gather" above)
+        for _ in range(min(5, args.profile_steps)):
+            for name, ms in eng.profile_step():
+                if name in ("gather", "sample_gather"):
+                    a = single_gather.setdefault(name, [0.0, 0]); a[0] += ms; a[1] += 1
         group.barrier()
 
-    # per-launch durations (HIP events on the engine stream, eager launches).  A profiled step is a full train step -- with its collective when
-    # world > 1 -- so EVERY rank runs the same number of them; only rank 0 uses the numbers.
-    prof_acc = {}
-    for _ in range(args.profile_steps):
-        for name, ms in eng.profile_step(steady=True):      # the step dqn_train_steps(n) repeats (its timed loop below runs exactly that)
-            a = prof_acc.setdefault(name, [0.0, 0])
-            a[0] += ms
-            a[1] += 1
-    # the gather launch of a SINGLE dqn_train_step (inside dqn_train_steps the previous step's Adam launch carries it: "adam+gather" above)
-    single_gather = {}
-    for _ in range(min(5, args.profile_steps)):
-        for name, ms in eng.profile_step():
-            if name in ("gather", "sample_gather"):
-                a = single_gather.setdefault(name, [0.0, 0]); a[0] += ms; a[1] += 1
-    group.barrier()
+
+    # the HOST-paced per-launch profile first, the GPU-paced device env loop (~35 ms of dense work) last: what runs right before the 3 ms timed region decides the clocks it sees
+    if args.order == "env-first":
+        section_env_loop(); section_profile()
+    else:
+        section_profile(); section_env_loop()
 
     # ---- the headline: W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize.  It runs AFTER the secondary sections
     # above (real train steps and env steps, all untimed): the GPU needs ~10 ms of activity to reach its clocks, and with --steps 20 --warmup 5
