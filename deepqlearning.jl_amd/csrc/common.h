@@ -79,12 +79,14 @@ __device__ __forceinline__ float dact_f(float dy, float y, int act) {
     default: return dy;
     }
 }
-// (float)b / 255.0f for a byte b (u8 observations, test/test_env.jl:59) without the ~10-instruction IEEE division: one Newton step on b * fl(1/255) is
-// exact for all 256 byte values (checked exhaustively on the host, and by the u8 parity tests against the twin's plain division)
+// (float)b / 255.0f for a byte b (u8 observations, test/test_env.jl:59) in TWO operations beside the conversion instead of the ~10-instruction IEEE division:
+// 1/255 = r_hi + r_lo with r_hi = 0x1.01p-8 (9 significant bits: b * r_hi is exact for b < 256) and r_lo = fl(1/255 - r_hi), so fma(b, r_lo, b * r_hi) rounds
+// b / 255 (1 + 2^-40) once -- and b / 255 = 0.bbb... in base 256 is never that close to a rounding boundary.  Equal to the division for all 256 bytes
+// (tests/test_abi_cpu.py checks the identity in numpy; the u8 parity tests compare with the twin's plain division).  On gfx950 fp32 MFMA and VALU work do
+// not overlap (tools/micro/mfma_mix.cpp), so every instruction of this conversion is paid in matrix time: r03's multiply + Newton step was one more.
 __device__ __forceinline__ float u8_unit(unsigned b) {
-    const float x = (float)b, r = 1.0f / 255.0f;
-    const float q = x * r; const float rem = fmaf(-q, 255.0f, x);
-    return fmaf(rem, r, q);
+    const float x = (float)b;
+    return fmaf(x, 0x1.010102p-24f, x * 0x1.01p-8f);
 }
 __device__ __forceinline__ float prio_f(float td_abs, float eps, float alpha) {
     float base = td_abs + eps;  // (td + eps)^alpha through Float64 (prioritized_experience_replay.jl:67,77)
@@ -631,6 +633,7 @@ int gemm_set_ktrace(unsigned long long* p);   // debug (-DDQN_KTRACE builds): pe
 #define DQN_LOPT_FWD_M32 1      /* DQN_FWD_M32: 32x32x2 MFMA blocks for the 64-channel forward tiles (measured no faster; kept parity-tested) */
 #define DQN_LOPT_FWD_DMA 2      /* DQN_FWD_DMA: LDS-DMA operand loads for the large forward launches with 64-channel tiles (measured no faster) */
 #define DQN_LOPT_NO_DX_WIDE 4   /* DQN_NO_DX_WIDE: large batches take the 32-sample dX tiles instead of the 128-sample ones */
+#define DQN_LOPT_NO_FWD_WRES 8  /* DQN_NO_FWD_WRES: large-batch forwards of a narrow layer take the per-tile kernel instead of the weights-resident persistent one (A/B) */
 void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* const* W, const float* const* bias, const float* const* X,
                      const int* ldx, const int* col0, const int* ncols, float* const* out /* Y, or split-K partial slabs */);
 

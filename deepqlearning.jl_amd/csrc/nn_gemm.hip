@@ -327,6 +327,214 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
 }
 
 // =====================================================================================================================
+// forward with the layer's WEIGHTS RESIDENT in LDS (r04; large-batch launches of a narrow layer whose [K][N] block fits beside the A tiles -- the first
+// convolution of the Nature net at B = 512: 256 x 32 floats = 32 KB).  Long-lived workgroups (2-3 per CU) fetch the weights ONCE and then walk their share of
+// the output in ONE continuous software pipeline.  Each WAVE owns MT adjacent 16-column M-tiles of one output position and stages ITS OWN A rows (16 MT columns
+// per input row, through registers into a wave-private LDS tile): the stream has no workgroup barrier, the waves of a SIMD drift apart and fill each other's
+// LDS / conversion / wait phases with MFMA work, and a wave carries MT x NT independent accumulator chains through every latency of its own.
+// D register stages keep D - 1 tiles of loads in flight; the first tiles of the next macro-tile are requested while the last MFMA steps of the current one issue.
+// Same chains as k_fwd_lds (k ascending per accumulator, one chunk): bit-identical outputs.
+// =====================================================================================================================
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int NT, int MT, bool XU8>
+__global__ __launch_bounds__(256) void k_fwd_wres(LayerDev L, GFwdProbs pr) {
+    constexpr int NW = 16 * NT, F_KT = 32, AQ = F_KT / 16, HS = F_KT / 8, SWZ = NW >= 32 ? 16 : 0, D = 4;
+    constexpr int ASTR = F_KT * 16 + 4;                // floats per M-tile region [32 k][16 columns]; the + 4 rotates the banks of the regions a lane quad writes in one instruction
+    constexpr unsigned ESZ = XU8 ? 1u : 4u;            // bytes per arena element
+    constexpr int NLD = XU8 ? 1 : MT;                  // load instructions per row slice: u8 = one load of MT dwords, f32 = MT loads of 16 bytes
+    using UT = std::conditional_t<MT == 1, uint32_t, std::conditional_t<MT == 2, u32x2, u32x4>>;
+    static_assert(AQ == 2 && (MT == 1 || MT == 2 || MT == 4), "the counted waits name these registers");
+    extern __shared__ float lds[];
+    float* As = lds;                                   // [4 waves][MT][ASTR]: every wave stages its own columns -- no workgroup barrier in the stream
+    float* Bres = lds + 4 * MT * ASTR;                 // [K][NW]; element (k, c) at column c ^ 16 (k & 1): the 16-lane fragment reads of rows k, k + 1 hit disjoint banks without padding
+    int* koff_lds = (int*)(Bres + L.K * NW);           // [K]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    karg_warm<sizeof(LayerDev) + sizeof(GFwdProbs)>();
+    const bool conv = L.kind == DQN_LAYER_CONV;
+    int pi = 0;
+    while (pi < 3 && (int)blockIdx.x >= pr.wg_end[pi]) pi++;
+    const GFwdProb& p = pr.p[pi];
+    const unsigned ldb = (unsigned)p.ldx * ESZ;        // bytes per input row
+    // BYTE offset of contraction index k's input row, tabulated once per workgroup (dense: k itself, so that the stream below has no layer-kind branch)
+    if (conv) {
+        const float r_khw = 1.0f / (float)(L.kh * L.kw), r_kw = 1.0f / (float)L.kw; const int khw = L.kh * L.kw;
+        for (int k = tid; k < L.K; k += 256) { const int ci = (int)(((float)k + 0.5f) * r_khw); const int rem = k - ci * khw; const int ky = (int)(((float)rem + 0.5f) * r_kw); koff_lds[k] = (int)((unsigned)((ci * L.ih + ky) * L.iw + (rem - ky * L.kw)) * ldb); }
+    } else for (int k = tid; k < L.K; k += 256) koff_lds[k] = (int)((unsigned)k * ldb);
+    const int wg_begin = pi == 0 ? 0 : pr.wg_end[pi - 1];
+    const int cnt = pr.wg_end[pi] - wg_begin;          // workgroups of this problem; this one walks workgroup tiles li, li + cnt, ...  (at any time an XCD works on one contiguous band)
+    const int li = xcd_remap(blockIdx.x - wg_begin, cnt);
+    const int ctiles = p.ncols >> 4, nkt = L.K / F_KT;
+    const int wgt = (p.mtiles + 4 * MT - 1) / (4 * MT);        // workgroup tiles: 4 waves x MT M-tiles (ctiles % MT == 0: a wave's M-tiles share their output position)
+    const int ngm = li < wgt ? (wgt - li + cnt - 1) / cnt : 0;
+    {
+        constexpr int BF4 = NW / 4;
+        for (int q = tid; q < L.K * BF4; q += 256) {
+            const int k = q / BF4, c4 = q % BF4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p.W + (size_t)k * L.N + 4 * c4);
+            *reinterpret_cast<f32x4*>(Bres + k * NW + ((4 * c4) ^ (SWZ * (k & 1)))) = v;
+        }
+    }
+    float bias_r[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) bias_r[t] = p.bias[16 * t + l15];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the counted waits below assume only staging loads in flight
+    __syncthreads();
+    if (ngm == 0) return;
+    // ---- this lane's slice of the wave's A tile (32 k x 16 MT columns): rows lane >> 2 and + 16, columns 4 MT (lane & 3) .. + 4 MT - 1
+    const int arow = lane >> 2, aq3 = lane & 3;
+    float* Aw = As + wave * (MT * ASTR);
+    // operand address = scalar base (arena + col0) + 32-bit byte offset {row offset from the table + this lane's column bytes (kn) + the wave's tile offset (scalar)}:
+    // one VALU add per load, no 64-bit address arithmetic in the stream (the arena is < 4 GB)
+    const unsigned char* Xbase = reinterpret_cast<const unsigned char*>(p.X) + (size_t)p.col0 * ESZ;
+    const unsigned lane_b = (unsigned)(aq3 * 4 * MT) * ESZ;
+    auto tile_of = [&](int gi, unsigned& go) {         // byte offset of this wave's macro-tile of the gi-th workgroup tile: input-row base + column (a missing one re-reads tile 0: never stored)
+        const int amt = __builtin_amdgcn_readfirstlane(((li + gi * cnt) * 4 + wave) * MT);
+        go = 0;
+        if (amt < p.mtiles) {
+            const int pos = amt / ctiles; go = (unsigned)(amt - pos * ctiles) * 16u * ESZ;
+            if (conv) { const int oy = pos / L.ow, ox = pos - oy * L.ow; go += (unsigned)(oy * L.sh * L.iw + ox * L.sw) * ldb; }
+        }
+    };
+    struct Stage { UT u[AQ]; f32x4 v[AQ][MT]; };      // (one of the two is live)
+    // the input-row offsets of a tile are fetched from the table ONE STEP AHEAD of the loads that use them (kn): no LDS round trip in front of a load issue
+    unsigned kn[AQ];
+    auto koff_of = [&](int kt) {
+#pragma unroll
+        for (int q = 0; q < AQ; q++) kn[q] = (unsigned)koff_lds[kt * F_KT + arow + 16 * q] + lane_b;
+    };
+    auto gload = [&](unsigned go, Stage& r) {             // ALWAYS AQ * NLD loads (hand-counted waits, see k_fwd_lds); rows from kn
+#pragma unroll
+        for (int q = 0; q < AQ; q++) {
+            const unsigned off = kn[q] + go;
+            if constexpr (XU8) {
+                if constexpr (MT == 1) asm volatile("global_load_dword %0, %1, %2" : "=v"(r.u[q]) : "v"(off), "s"(Xbase) : "memory");
+                else if constexpr (MT == 2) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r.u[q]) : "v"(off), "s"(Xbase) : "memory");
+                else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r.u[q]) : "v"(off), "s"(Xbase) : "memory");
+            } else {
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r.v[q][0]) : "v"(off), "s"(Xbase) : "memory");
+                if constexpr (MT >= 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(r.v[q][1]) : "v"(off), "s"(Xbase) : "memory");
+                if constexpr (MT == 4) { asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=v"(r.v[q][2]) : "v"(off), "s"(Xbase) : "memory");
+                                         asm volatile("global_load_dwordx4 %0, %1, %2 offset:48" : "=v"(r.v[q][3]) : "v"(off), "s"(Xbase) : "memory"); }
+            }
+        }
+    };
+    auto lstore = [&](const Stage& r) {
+#pragma unroll
+        for (int q = 0; q < AQ; q++)
+#pragma unroll
+            for (int u = 0; u < MT; u++) {
+                f32x4 av;
+                if constexpr (XU8) {
+                    uint32_t w4;
+                    if constexpr (MT == 1) w4 = r.u[q]; else w4 = r.u[q][u];
+                    av = (f32x4){u8_unit(w4 & 0xffu), u8_unit((w4 >> 8) & 0xffu), u8_unit((w4 >> 16) & 0xffu), u8_unit(w4 >> 24)};
+                } else av = r.v[q][u];
+                const int idx = aq3 * MT + u;          // column quad idx of the wave's 4 MT: M-tile idx >> 2, columns 4 (idx & 3) ..
+                *reinterpret_cast<f32x4*>(Aw + (idx >> 2) * ASTR + (arow + 16 * q) * 16 + (idx & 3) * 4) = av;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();      // the wave's LDS operations execute in order: its own later fragment reads see these stores
+    };
+    // everything older than the newest N operations has landed: the stage `r`, and an epilogue's stores issued after it (loads and stores retire in order)
+    auto stage_wait = [&](auto N, Stage& r) {
+        constexpr int n = decltype(N)::value;
+        if constexpr (XU8) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.u[0]), "+v"(r.u[1]) : "n"(n) : "memory");
+        else if constexpr (MT == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.v[0][0]), "+v"(r.v[1][0]) : "n"(n) : "memory");
+        else if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r.v[0][0]), "+v"(r.v[0][1]), "+v"(r.v[1][0]), "+v"(r.v[1][1]) : "n"(n) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r.v[0][0]), "+v"(r.v[0][1]), "+v"(r.v[0][2]), "+v"(r.v[0][3]), "+v"(r.v[1][0]), "+v"(r.v[1][1]), "+v"(r.v[1][2]), "+v"(r.v[1][3]) : "n"(n) : "memory");
+    };
+#define WRES_WAIT(N, r) stage_wait(std::integral_constant<int, (N)>{}, r)
+    constexpr int LPS = AQ * NLD;                      // loads per stage
+    struct Frag { float a[F_KT / 4][MT]; float b[F_KT / 4][NT]; };
+    const float* Afr = Aw + kq * 16 + l15;             // rows kq = 0, 1 of a 32-lane group: banks 0-15 / 16-31 (+ the region's rotation)
+    const float* Bfr[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) Bfr[t] = Bres + kq * NW + ((16 * t) ^ (SWZ * (kq & 1))) + l15;
+    auto fread = [&](int kt, Frag& f) {                // per-lane bases + compile-time offsets: no address arithmetic per read
+#pragma unroll
+        for (int st = 0; st < F_KT / 4; st++) {
+#pragma unroll
+            for (int m = 0; m < MT; m++) f.a[st][m] = Afr[m * ASTR + 4 * st * 16];
+#pragma unroll
+            for (int t = 0; t < NT; t++) f.b[st][t] = (Bfr[t] + kt * F_KT * NW)[4 * st * NW];
+        }
+    };
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](const Frag& f, int s0, int s1) {
+#pragma unroll
+        for (int st = s0; st < s1; st++)
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[m][t] = MFMA(f.a[st][m], f.b[st][t], acc[m][t]);
+    };
+    unsigned go0, go1;
+    tile_of(0, go0); tile_of(1, go1);
+    // The A tile has ONE LDS buffer: its fragments are read into the second register set a full step before they are used, and a wave's LDS operations
+    // execute in order, so the stores of tile t + 1 may follow the reads of tile t directly.
+    Stage r[D]; Frag f[2];
+#pragma unroll
+    for (int j = 0; j < D; j++) { koff_of(j); gload(go0, r[j]); }
+    koff_of(D % nkt);
+    WRES_WAIT((D - 1) * LPS, r[0]); lstore(r[0]);
+    fread(0, f[0]);
+    // one tile step; invariant at its top: tile kt + J in f[J & 1], its stage r[J] free, tiles kt + J + 1 .. kt + J + D - 1 in flight.  Straight-line code: selects, no branches
+#define WRES_STEP(J, XTRA)                                                                                                                   \
+    {                                                                                                                                  \
+        const int tn = kt + (J) + D, tn2 = tn + 1;                                                                                     \
+        const bool nx = tn >= nkt && more;          /* past the macro-tile's last tile the stream continues with the NEXT one's */     \
+        gload(nx ? go1 : go0, r[J]);                                                                                                   \
+        koff_of(tn2 < nkt ? tn2 : (more ? tn2 - nkt : nkt - 1));                                                                       \
+        mma(f[(J) & 1], 0, HS);                                                                                                        \
+        WRES_WAIT((D - 1) * LPS + (XTRA), r[((J) + 1) % D]); lstore(r[((J) + 1) % D]);                                                 \
+        fread(kt + (J) + 1 < nkt ? kt + (J) + 1 : 0, f[((J) + 1) & 1]);                                                                \
+        mma(f[(J) & 1], HS, 2 * HS);                                                                                                   \
+    }
+    bool stored = false;                                // the previous epilogue issued its stores (a ragged macro-tile does not)
+    for (int gi = 0; gi < ngm; gi++) {
+        const bool more = gi + 1 < ngm;
+        // (an epilogue's MT * NT stores sit in the memory queue between the stages in flight and the loads issued after it: the first three steps of the next
+        // macro-tile count them in, so that a wave never waits for a store to be acknowledged; the fourth wait is three steps later)
+        { const int kt = 0; if (stored) { WRES_STEP(0, MT * NT) WRES_STEP(1, MT * NT) WRES_STEP(2, MT * NT) WRES_STEP(3, 0) } else { WRES_STEP(0, 0) WRES_STEP(1, 0) WRES_STEP(2, 0) WRES_STEP(3, 0) } }
+        for (int kt = D; kt < nkt; kt += D) { WRES_STEP(0, 0) WRES_STEP(1, 0) WRES_STEP(2, 0) WRES_STEP(3, 0) }      // nkt % D == 0
+        // ---- epilogue of workgroup tile gi: this wave's MT M-tiles
+        const int mt0 = ((li + gi * cnt) * 4 + wave) * MT;
+        stored = mt0 < p.mtiles;
+        if (stored) {
+            const int pos = mt0 / ctiles, ct0 = mt0 - pos * ctiles;
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const int n = 16 * t + l15;
+                    const float bias = bias_r[t];
+                    f32x4 v = acc[m][t];
+                    v.x = act_f(v.x + bias, L.act); v.y = act_f(v.y + bias, L.act); v.z = act_f(v.z + bias, L.act); v.w = act_f(v.w + bias, L.act);
+                    *reinterpret_cast<f32x4*>(p.out + ((size_t)n * L.npos + pos) * p.ncols + (ct0 + m) * 16 + 4 * kq) = v;
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        go0 = go1; tile_of(gi + 2, go1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the dummy tail loads
+#undef WRES_WAIT
+#undef WRES_STEP
+}
+// launch_gemm_fwd takes this form for: one chunk, all N channels in one tile of 16 or 32, a multiple of four K tiles, weights + A tiles within half of a CU's LDS, and >= 2048 M-groups
+static size_t fwd_wres_lds(const LayerDev& L, int MT) { return (size_t)(4 * MT * (32 * 16 + 4) + L.K * L.N + L.K) * 4; }
+static bool fwd_wres_ok(const LayerDev& L, long mg_total, int S) {
+    if ((L.opt & DQN_LOPT_NO_FWD_WRES) || S != 1 || (L.N != 16 && L.N != 32) || L.K % 128 || mg_total < 2048) return false;
+    return fwd_wres_lds(L, 1) <= (size_t)(160 * 1024 / 3 - 256);
+}
+
+// =====================================================================================================================
 // forward, LDS-DMA form (experiment, DQN_FWD_DMA=1; 64-channel tiles, float operands): the tiles are written by
 // global_load_lds_dwordx4 -- global memory straight into LDS, no register staging, no ds_write -- into UNPADDED [16][64] tiles; the bank
 // conflict padding used to avoid (rows k and k+1 on the same banks for the 16-lane fragment reads) is removed by swizzling on the GLOBAL
@@ -460,6 +668,30 @@ void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* 
         q.W = W[j]; q.bias = bias[j]; q.X = X[j]; q.ldx = ldx[j]; q.col0 = col0[j]; q.ncols = ncols[j]; q.out = out[j];
         q.mtiles = L.npos * (ncols[j] / 16); q.mgroups = (q.mtiles + 3) / 4;
         if (i < nprob) mg_total += q.mgroups;
+    }
+    if (fwd_wres_ok(L, mg_total, S)) {
+        // M-tiles per wave: 4 (64-column row slices: a quarter of the L1 line visits, weight fragments shared by four accumulators; two workgroups per CU) when every
+        // problem's column count allows and the LDS holds it, else 2, else 1
+        int MT = L.xu8 ? 4 : 2;                          // (float operands: 4 would need > 256 registers)
+        for (int i = 0; i < nprob; i++) while (MT > 1 && (ncols[i] / 16) % MT) MT >>= 1;
+        while (MT > 1 && fwd_wres_lds(L, MT) > (size_t)(160 * 1024 / 2 - 256)) MT >>= 1;
+        const size_t lds_b = fwd_wres_lds(L, MT);
+        // persistent workgroups, shared out between the problems in proportion to their tiles
+        const int per_cu = (int)((size_t)(160 * 1024) / (lds_b + 256)) < 3 ? (int)((size_t)(160 * 1024) / (lds_b + 256)) : 3;
+        const int slots = 256 * per_cu; int end = 0; long wgt[4], wgt_total = 0;
+        for (int i = 0; i < nprob; i++) { wgt[i] = (pr.p[i].mtiles + 4 * MT - 1) / (4 * MT); wgt_total += wgt[i]; }
+        for (int i = 0; i < 4; i++) {
+            if (i < nprob) { long w = (slots * wgt[i] + wgt_total / 2) / wgt_total; if (w < 1) w = 1; if (w > wgt[i]) w = wgt[i]; end += (int)w; }
+            pr.wg_end[i] = end;
+        }
+#define WRES_LAUNCH(NT_, MT_, U8_) do { if (lds_b > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_fwd_wres<NT_, MT_, U8_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b); \
+        hipLaunchKernelGGL((k_fwd_wres<NT_, MT_, U8_>), dim3(end), dim3(256), lds_b, st, L, pr); } while (0)
+#define WRES_PICK(NT_) do { if (L.xu8) { if (MT == 4) WRES_LAUNCH(NT_, 4, true); else if (MT == 2) WRES_LAUNCH(NT_, 2, true); else WRES_LAUNCH(NT_, 1, true); } \
+                            else { if (MT == 4) WRES_LAUNCH(NT_, 4, false); else if (MT == 2) WRES_LAUNCH(NT_, 2, false); else WRES_LAUNCH(NT_, 1, false); } } while (0)
+        if (L.N == 32) WRES_PICK(2); else WRES_PICK(1);
+#undef WRES_PICK
+#undef WRES_LAUNCH
+        return;
     }
     const int NT = fwd_pick_nt(L, mg_total, S);
     const int ngroups = L.N / (16 * NT);

@@ -1,6 +1,7 @@
 """CPU: the C-ABI library loads, exports every symbol include/dqn_mi355x.h declares, and its host-only entry points
 work without a GPU.  No compute call is made here (there is no CPU fallback to call)."""
 import ctypes
+import numpy as np
 import os
 import re
 
@@ -106,3 +107,15 @@ def test_null_handle_is_an_error_not_a_crash():
         assert f(None) == -1 and b"null engine handle" in lib.dqn_last_error()
     lib.dqn_engine_destroy.argtypes = [C.c_void_p]; lib.dqn_engine_destroy.restype = C.c_int
     assert lib.dqn_engine_destroy(None) == 0
+
+
+def test_u8_unit_two_operation_form_equals_the_division_for_every_byte():
+    """common.h u8_unit: fma(b, r_lo, b * r_hi) == (float)b / 255f0 (test/test_env.jl:59) for all 256 bytes; b * r_hi is exact."""
+    b = np.arange(256, dtype=np.float64)
+    ref = (b.astype(np.float32) / np.float32(255.0)).astype(np.float32)
+    r_hi, r_lo = float.fromhex("0x1.01p-8"), float.fromhex("0x1.010102p-24")
+    assert np.float32(r_hi) == r_hi and np.float32(r_lo) == r_lo
+    q = b * r_hi
+    assert np.array_equal(q.astype(np.float32).astype(np.float64), q)          # the product is exact in fp32
+    y = (b * r_lo + q).astype(np.float32)                                      # exact in fp64, rounded once == fmaf
+    assert np.array_equal(y, ref)

@@ -452,6 +452,25 @@ def test_config5_nature_b512_u8_bit_exact(pkg):
     np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
 
 
+@pytest.mark.parametrize("B,u8,off", [(128, True, False), (160, True, False), (144, True, False), (128, False, False), (144, False, False), (128, True, True)])
+def test_weights_resident_first_conv_forward_bit_exact(pkg, monkeypatch, B, u8, off):
+    """k_fwd_wres (csrc/nn_gemm.hip): from 2048 M-groups up the forward of a layer of <= 32 channels keeps its weights in LDS and walks the output with
+    long-lived workgroups, a wave owning 4 / 2 / 1 adjacent M-tiles (B = 128 / 160 / 144: the column tiles of [s;sp] and sp divide by 4 / 2 / 1), byte or
+    float operands.  Another schedule of the same chains: bit-identical to the twin; off = DQN_NO_FWD_WRES keeps the per-tile kernel's large-launch
+    form (16-deep K tiles) under test at the same shape."""
+    net = nature_dueling()
+    if off:
+        monkeypatch.setenv("DQN_NO_FWD_WRES", "1")
+    gpu, cpu, hp = make_pair(pkg, net, B, cap=1024, obs_dtype=1 if u8 else 0, gamma=0.99)
+    monkeypatch.delenv("DQN_NO_FWD_WRES", raising=False)
+    cpu.set_threads(64)
+    fill((gpu, cpu), net, 700, seed=B, u8=u8)
+    set_same_params((gpu, cpu), net, seed=3)
+    assert_step_bit_exact(gpu, cpu)
+    assert_step_bit_exact(gpu, cpu)
+    np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+
+
 def test_large_batch_train_steps_pipelined(pkg):
     """B > 64: the priority update runs on the side stream and also draws the next step's indices; inside dqn_train_steps the Adam launch gathers
     the next batch (byte arena) and the next step starts without its sample and gather launches (k_td publishes the indices).  Mid-size network at

@@ -1,0 +1,78 @@
+// mfma_mix.cpp -- what the forward tile loop loses to each kind of work beside the MFMAs (MI355X, fp32 16x16x4; peak 157.3 TFLOP/s at 2.4 GHz).
+// Base: 4 waves per workgroup; per K tile of 32 a wave reads its fragments from LDS (8 A + 8 NT B, ds_read_b32) and issues 8 NT MFMAs (NT = 2: the first-convolution shape).
+// Variants add, per K tile and wave: V independent VALU fmas; W ds_write_b128 of register data (wave-private region); G global dword loads (L2-resident buffer).
+// r04: the LDS-tiled forward kernels all plateau at 53-58 % MFMA busy with every other unit < 25 % busy; this isolates which neighbour costs MFMA issue slots.
+//   hipcc --offload-arch=gfx950 -O3 mfma_mix.cpp -o mfma_mix.bin
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+template <int NT, int V, int W, int G>
+__global__ __launch_bounds__(256) void k(float* out, const unsigned* gbuf, int iters) {
+    constexpr int SB = 16 * NT;
+    extern __shared__ float lds[];
+    float* Bs = lds;                       // [32][SB], swizzled like the resident block
+    float* As = lds + 32 * SB;             // [4 waves][32][16]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    for (int i = tid; i < 32 * SB + 4 * 512; i += 256) lds[i] = 1.0f + 1e-6f * (float)i;
+    __syncthreads();
+    f32x4 acc[NT];
+    for (int t = 0; t < NT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float* Aw = As + wave * 512;
+    const float* Ab = Aw + kq * 16 + l15;
+    const float* Bb[NT];
+    for (int t = 0; t < NT; t++) Bb[t] = Bs + kq * SB + ((16 * t) ^ (NT >= 2 ? 16 * (kq & 1) : 0)) + l15;
+    float x[8] = {1.f + lane, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
+    const float c1 = 1.0000001f, c2 = 1e-9f;
+    unsigned g[G > 0 ? G : 1]; for (int i = 0; i < (G > 0 ? G : 1); i++) g[i] = 0;
+    const unsigned* gp = gbuf + (blockIdx.x * 256 + tid) * 4 % (1 << 20);
+    for (int it = 0; it < iters; it++) {
+        float a[8], b[8][NT];
+#pragma unroll
+        for (int st = 0; st < 8; st++) { a[st] = Ab[4 * st * 16];
+#pragma unroll
+            for (int t = 0; t < NT; t++) b[st][t] = Bb[t][4 * st * SB]; }
+        if (G > 0) {
+#pragma unroll
+            for (int i = 0; i < G; i++) g[i] += gp[((it * G + i) * 4096) & ((1 << 20) - 1)];
+        }
+#pragma unroll
+        for (int st = 0; st < 8; st++) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = MFMA(a[st], b[st][t], acc[t]);
+#pragma unroll
+            for (int v = 0; v < V / 8; v++) x[(st + v) & 7] = __builtin_fmaf(x[(st + v) & 7], c1, c2);      // V independent-ish VALU ops spread between the MFMAs
+        }
+        if (W > 0) {
+#pragma unroll
+            for (int w = 0; w < W; w++) *reinterpret_cast<f32x4*>(Aw + ((lane >> 2) + 16 * (w & 1)) * 16 + (lane & 3) * 4) = (f32x4){x[0], x[1], x[2], x[3]};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        }
+        asm volatile("" ::: "memory");
+    }
+    float s = 0; for (int t = 0; t < NT; t++) s += acc[t].x + acc[t].y + acc[t].z + acc[t].w;
+    for (int i = 0; i < 8; i++) s += x[i];
+    for (int i = 0; i < (G > 0 ? G : 1); i++) s += (float)g[i];
+    if (s == 12345.678f) out[tid] = s;
+}
+template <int NT, int V, int W, int G> void run(float* out, unsigned* gbuf) {
+    const int iters = 4000; const size_t lds = (32 * 16 * NT + 4 * 512) * 4 + 40 * 1024;      // + 40 KB: bounds residency at 3 workgroups per CU like the real kernel
+    printf("NT=%d VALU=%2d dswrite=%d gload=%d :", NT, V, W, G);
+    for (int wg_per_cu : {1, 2, 3}) {
+        const int grid = 256 * wg_per_cu;
+        hipLaunchKernelGGL((k<NT, V, W, G>), dim3(grid), dim3(256), lds, 0, out, gbuf, 10); hipDeviceSynchronize();
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        hipEventRecord(a, 0); hipLaunchKernelGGL((k<NT, V, W, G>), dim3(grid), dim3(256), lds, 0, out, gbuf, iters); hipEventRecord(b, 0); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        const double flop = (double)grid * 4 * iters * 8 * NT * 2048.0;
+        printf("  %d/CU %5.1f TF (%3.0f %%)", wg_per_cu, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 157.3 * 100);
+    }
+    printf("\n");
+}
+int main() {
+    float* out; hipMalloc(&out, 4096); unsigned* gbuf; hipMalloc(&gbuf, 16 << 20); hipMemset(gbuf, 0, 16 << 20);
+    run<2, 0, 0, 0>(out, gbuf); run<2, 8, 0, 0>(out, gbuf); run<2, 16, 0, 0>(out, gbuf); run<2, 32, 0, 0>(out, gbuf); run<2, 64, 0, 0>(out, gbuf);
+    run<2, 0, 2, 0>(out, gbuf); run<2, 0, 0, 2>(out, gbuf); run<2, 32, 2, 2>(out, gbuf);
+    run<4, 0, 0, 0>(out, gbuf); run<4, 32, 0, 0>(out, gbuf); run<4, 64, 0, 0>(out, gbuf); run<4, 32, 2, 2>(out, gbuf);
+    return 0;
+}
