@@ -1174,34 +1174,50 @@ __device__ __forceinline__ void dx_lds_body_wide(const LayerDev& L, const GDxArg
     const int arow = tid >> 5, af4 = tid & 31, brow = tid >> 3, bf4 = tid & 7;
     const int frow = min(f0 + brow, nfeat - 1);
     struct Stage { f32x4 a[4]; f32x4 b; };
-    auto gld = [](const float* ptr) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory"); return v; };
-    auto gload = [&](int kt, Stage& r) {
-        kt = min(kt, total - 1);
-        const int si = kt >= nkt ? 1 : 0; const int k = kt - si * nkt;
-        const GDxSrc& sr = A.src[si];
-        if (dense) {
-            const int nb = s * kc + k * 32;
+    // r04: operand address = SCALAR base of the tile (source pointer + tile offset, scalar ALU) + a 32-bit per-thread byte offset fixed for the whole workgroup -- the
+    // loads cost no VALU instruction (they used to: five 64-bit multiply-adds per stage, 80 v_mul_lo / v_mad_u64 per four K tiles, and on gfx950 every VALU
+    // instruction is paid in fp32 MFMA time, tools/micro/mfma_mix.cpp).  The activations / weights of one layer are < 4 GB.
+    unsigned a_off[4];
 #pragma unroll
-            for (int p = 0; p < 4; p++) r.a[p] = gld(sr.dpre + (size_t)(nb + arow + 8 * p) * B + b0 + 4 * af4);
-            r.b = gld(sr.W + (size_t)frow * L.N + nb + 4 * bf4);
-        } else {
-            const int cot = L.N / 32; const int tp = taps[k / cot]; const int cob = (k % cot) * 32;
-            const int tap = tp >> 16, pos = tp & 0xffff;
+    for (int q = 0; q < 4; q++) a_off[q] = 4u * ((unsigned)(arow + 8 * q) * (unsigned)(dense ? B : L.npos * B) + (unsigned)(b0 + 4 * af4));
+    const unsigned b_off = 4u * ((unsigned)frow * (unsigned)(dense ? L.N : khw * L.N) + (unsigned)(4 * bf4));
+    auto gld_s = [](unsigned off, const float* base) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); return v; };
+    // cursor of the staging loads: gload is called for tiles 0, 1, 2, ... in order (past the last tile it stays there); the tap of the NEXT tile is read from the
+    // table one call ahead, so no LDS round trip or division sits in front of a load issue
+    const int cot = dense ? 1 : L.N / 32;
+    int g_kt = 0, g_si = 0, g_k = 0, g_ci = 0, g_ti = 0;
+    int g_tp = dense ? 0 : taps[0];
+    auto gload = [&](Stage& r) {
+        const GDxSrc& sr = A.src[g_si];
+        size_t sa, sb;
+        if (dense) { const int nb = s * kc + g_k * 32; sa = (size_t)nb * B; sb = (size_t)nb; }
+        else {
+            const int tp = __builtin_amdgcn_readfirstlane(g_tp); const int tap = tp >> 16, pos = tp & 0xffff, cob = g_ci * 32;
+            sa = ((size_t)cob * L.npos + pos) * B; sb = (size_t)tap * L.N + cob;
+        }
+        const float* pa = sr.dpre + sa; const float* pb = sr.W + sb;
 #pragma unroll
-            for (int p = 0; p < 4; p++) r.a[p] = gld(sr.dpre + ((size_t)(cob + arow + 8 * p) * L.npos + pos) * B + b0 + 4 * af4);
-            r.b = gld(sr.W + ((size_t)frow * khw + tap) * L.N + cob + 4 * bf4);
+        for (int q = 0; q < 4; q++) r.a[q] = gld_s(a_off[q], pa);
+        r.b = gld_s(b_off, pb);
+        if (g_kt + 1 < total) {
+            g_kt++; g_k++; g_ci++;
+            if (g_ci == cot) { g_ci = 0; g_ti++; }
+            if (g_k == nkt) { g_k = 0; g_ci = 0; g_ti = 0; g_si = 1; }
+            if (!dense) g_tp = taps[g_ti];
         }
     };
     auto lstore = [&](int buf, const Stage& r) {
 #pragma unroll
-        for (int p = 0; p < 4; p++) *reinterpret_cast<f32x4*>(As + (buf * 32 + arow + 8 * p) * X_SAW + 4 * af4) = r.a[p];
+        for (int q = 0; q < 4; q++) *reinterpret_cast<f32x4*>(As + (buf * 32 + arow + 8 * q) * X_SAW + 4 * af4) = r.a[q];
         lds_st4(Bs + (buf * 32 + brow) * X_SB + 4 * bf4, r.b);
     };
 #define STAGE_WAITW(N, r) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.b) : "n"(N) : "memory")
     f32x4 acc[2][2][2];                               // [source][feature tile][sample tile]
 #pragma unroll
     for (int i = 0; i < 8; i++) (&acc[0][0][0])[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](int buf, int si) {
+    // SI = the source's accumulator set, a COMPILE-TIME choice (r04: as a run-time select per MFMA it compiled to a branch and two accumulator moves per MFMA)
+    auto compute = [&](int buf, auto SI) {
+        constexpr int si = decltype(SI)::value;
         const float* Ab = As + buf * 32 * X_SAW + 32 * wave + l15;
         const float* Bb = Bs + (buf * 32 + l15) * X_SB + kq;
         float af[2][8], bf[2][8];
@@ -1215,25 +1231,28 @@ __device__ __forceinline__ void dx_lds_body_wide(const LayerDev& L, const GDxArg
 #pragma unroll
             for (int ft = 0; ft < 2; ft++)
 #pragma unroll
-                for (int ml = 0; ml < 2; ml++) {
-                    if (si == 0) acc[0][ft][ml] = MFMA(af[ml][st], bf[ft][st], acc[0][ft][ml]);
-                    else acc[1][ft][ml] = MFMA(af[ml][st], bf[ft][st], acc[1][ft][ml]);
-                }
+                for (int ml = 0; ml < 2; ml++) acc[si][ft][ml] = MFMA(af[ml][st], bf[ft][st], acc[si][ft][ml]);
     };
     if (total > 0) {
         Stage r0, r1;
-        gload(0, r0); STAGE_WAITW(0, r0); lstore(0, r0); __syncthreads();
-        gload(1, r0);
-        for (int kt = 0; kt < total; kt += 2) {
-            gload(kt + 2, r1);
-            compute(0, kt >= nkt ? 1 : 0);
+        gload(r0); STAGE_WAITW(0, r0); lstore(0, r0); __syncthreads();
+        gload(r0);
+        // two K tiles per round; the rounds of source 0, the round that straddles the sources when nkt is odd (or holds the last tile alone), the rounds of source 1
+        auto round = [&](int kt, auto S0, auto S1) {
+            gload(r1);
+            compute(0, S0);
             STAGE_WAITW(5, r0); lstore(1, r0);
             __syncthreads();
-            gload(kt + 3, r0);
-            if (kt + 1 < total) compute(1, kt + 1 >= nkt ? 1 : 0);
+            gload(r0);
+            if (kt + 1 < total) compute(1, S1);
             STAGE_WAITW(5, r1); lstore(0, r1);
             __syncthreads();
-        }
+        };
+        std::integral_constant<int, 0> s0; std::integral_constant<int, 1> s1;
+        int kt = 0;
+        for (; kt + 1 < nkt; kt += 2) round(kt, s0, s0);
+        if (kt < nkt) { round(kt, s0, s1); kt += 2; }
+        for (; kt < total; kt += 2) round(kt, s1, s1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 #undef STAGE_WAITW

@@ -7,7 +7,7 @@
 #include <stdio.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
-template <int NT, int V, int W, int G>
+template <int NT, int V, int W, int G, int SA = 0>
 __global__ __launch_bounds__(256) void k(float* out, const unsigned* gbuf, int iters) {
     constexpr int SB = 16 * NT;
     extern __shared__ float lds[];
@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void k(float* out, const unsigned* gbuf, int i
     const float c1 = 1.0000001f, c2 = 1e-9f;
     unsigned g[G > 0 ? G : 1]; for (int i = 0; i < (G > 0 ? G : 1); i++) g[i] = 0;
     const unsigned* gp = gbuf + (blockIdx.x * 256 + tid) * 4 % (1 << 20);
+    int sreg = __builtin_amdgcn_readfirstlane(iters);
     for (int it = 0; it < iters; it++) {
         float a[8], b[8][NT];
 #pragma unroll
@@ -42,6 +43,8 @@ __global__ __launch_bounds__(256) void k(float* out, const unsigned* gbuf, int i
             for (int t = 0; t < NT; t++) acc[t] = MFMA(a[st], b[st][t], acc[t]);
 #pragma unroll
             for (int v = 0; v < V / 8; v++) x[(st + v) & 7] = __builtin_fmaf(x[(st + v) & 7], c1, c2);      // V independent-ish VALU ops spread between the MFMAs
+#pragma unroll
+            for (int v = 0; v < SA / 8; v++) asm volatile("s_mul_i32 %0, %0, 3" : "+s"(sreg));                 // SA scalar ALU ops spread likewise
         }
         if (W > 0) {
 #pragma unroll
@@ -52,17 +55,18 @@ __global__ __launch_bounds__(256) void k(float* out, const unsigned* gbuf, int i
     }
     float s = 0; for (int t = 0; t < NT; t++) s += acc[t].x + acc[t].y + acc[t].z + acc[t].w;
     for (int i = 0; i < 8; i++) s += x[i];
+    s += (float)sreg;
     for (int i = 0; i < (G > 0 ? G : 1); i++) s += (float)g[i];
     if (s == 12345.678f) out[tid] = s;
 }
-template <int NT, int V, int W, int G> void run(float* out, unsigned* gbuf) {
+template <int NT, int V, int W, int G, int SA = 0> void run(float* out, unsigned* gbuf) {
     const int iters = 4000; const size_t lds = (32 * 16 * NT + 4 * 512) * 4 + 40 * 1024;      // + 40 KB: bounds residency at 3 workgroups per CU like the real kernel
-    printf("NT=%d VALU=%2d dswrite=%d gload=%d :", NT, V, W, G);
+    printf("NT=%d VALU=%2d dswrite=%d gload=%d SALU=%3d :", NT, V, W, G, SA);
     for (int wg_per_cu : {1, 2, 3}) {
         const int grid = 256 * wg_per_cu;
-        hipLaunchKernelGGL((k<NT, V, W, G>), dim3(grid), dim3(256), lds, 0, out, gbuf, 10); hipDeviceSynchronize();
+        hipLaunchKernelGGL((k<NT, V, W, G, SA>), dim3(grid), dim3(256), lds, 0, out, gbuf, 10); hipDeviceSynchronize();
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-        hipEventRecord(a, 0); hipLaunchKernelGGL((k<NT, V, W, G>), dim3(grid), dim3(256), lds, 0, out, gbuf, iters); hipEventRecord(b, 0); hipEventSynchronize(b);
+        hipEventRecord(a, 0); hipLaunchKernelGGL((k<NT, V, W, G, SA>), dim3(grid), dim3(256), lds, 0, out, gbuf, iters); hipEventRecord(b, 0); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         const double flop = (double)grid * 4 * iters * 8 * NT * 2048.0;
         printf("  %d/CU %5.1f TF (%3.0f %%)", wg_per_cu, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 157.3 * 100);
@@ -73,6 +77,7 @@ int main() {
     float* out; hipMalloc(&out, 4096); unsigned* gbuf; hipMalloc(&gbuf, 16 << 20); hipMemset(gbuf, 0, 16 << 20);
     run<2, 0, 0, 0>(out, gbuf); run<2, 8, 0, 0>(out, gbuf); run<2, 16, 0, 0>(out, gbuf); run<2, 32, 0, 0>(out, gbuf); run<2, 64, 0, 0>(out, gbuf);
     run<2, 0, 2, 0>(out, gbuf); run<2, 0, 0, 2>(out, gbuf); run<2, 32, 2, 2>(out, gbuf);
+    run<2, 0, 0, 0, 32>(out, gbuf); run<2, 0, 0, 0, 64>(out, gbuf); run<2, 0, 0, 0, 128>(out, gbuf); run<4, 0, 0, 0, 64>(out, gbuf); run<4, 0, 0, 0, 128>(out, gbuf);
     run<4, 0, 0, 0>(out, gbuf); run<4, 32, 0, 0>(out, gbuf); run<4, 64, 0, 0>(out, gbuf); run<4, 32, 2, 2>(out, gbuf);
     return 0;
 }
