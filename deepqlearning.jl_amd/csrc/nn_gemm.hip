@@ -117,16 +117,18 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     karg_warm<sizeof(LayerDev) + sizeof(GFwdProbs) + 8>();
     KTRACE_BEGIN()
     const bool conv = L.kind == DQN_LAYER_CONV;
-    if (conv) {
-        // input-row offset of contraction index k = (ci, ky, kx), tabulated once per workgroup.  The two divisions go through reciprocals
-        // (floor((x + 0.5) / d) is exact for these small ints): with integer divisions this table cost 0.85-2.0 us at the head of every conv
-        // launch (ktrace, r02) before the first operand load could be issued.
-        const float r_khw = 1.0f / (float)(L.kh * L.kw), r_kw = 1.0f / (float)L.kw; const int khw = L.kh * L.kw;
-        for (int k = tid; k < L.K; k += 256) { const int ci = (int)(((float)k + 0.5f) * r_khw); const int rem = k - ci * khw; const int ky = (int)(((float)rem + 0.5f) * r_kw); koff_lds[k] = (ci * L.ih + ky) * L.iw + (rem - ky * L.kw); }
-    }
     int pi = 0;
     while (pi < 3 && (int)blockIdx.x >= pr.wg_end[pi]) pi++;
     const GFwdProb& p = pr.p[pi];
+    constexpr unsigned ESZ = XU8 ? 1u : 4u;            // bytes per arena element
+    const unsigned ldb = (unsigned)p.ldx * ESZ;        // bytes per input row
+    if (conv) {
+        // BYTE offset of contraction index k = (ci, ky, kx)'s input row, tabulated once per workgroup.  The two divisions go through reciprocals
+        // (floor((x + 0.5) / d) is exact for these small ints): with integer divisions this table cost 0.85-2.0 us at the head of every conv
+        // launch (ktrace, r02) before the first operand load could be issued.
+        const float r_khw = 1.0f / (float)(L.kh * L.kw), r_kw = 1.0f / (float)L.kw; const int khw = L.kh * L.kw;
+        for (int k = tid; k < L.K; k += 256) { const int ci = (int)(((float)k + 0.5f) * r_khw); const int rem = k - ci * khw; const int ky = (int)(((float)rem + 0.5f) * r_kw); koff_lds[k] = (int)((unsigned)((ci * L.ih + ky) * L.iw + (rem - ky * L.kw)) * ldb); }
+    }
     const int wg_begin = pi == 0 ? 0 : pr.wg_end[pi - 1];
     int w = xcd_remap(blockIdx.x - wg_begin, pr.wg_end[pi] - wg_begin);
     const int ngroups = L.N / NW;
@@ -144,10 +146,12 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
         const int pos = amt / ctiles; a_ct = amt % ctiles;
         if (conv) { const int oy = pos / L.ow, ox = pos % L.ow; a_xb = oy * L.sh * L.iw + ox * L.sw; }
     }
-    const float* Xa = p.X + p.col0 + a_ct * 16 + (tid & 3) * 4;
-    const unsigned char* Xb = reinterpret_cast<const unsigned char*>(p.X) + p.col0 + a_ct * 16 + (tid & 3) * 4;      // XU8 view of the same arena
     const int arow = tid >> 4;                         // 0..15 (second float4: +16)
-    const unsigned ldx = (unsigned)p.ldx;
+    // r04: operand address = SCALAR base (+ the K tile's offset where it is uniform: dense rows, weight rows) + a 32-bit per-thread byte offset fixed for the whole
+    // workgroup (+ the row offset from the table for conv): at most one VALU add per load -- every VALU instruction is paid in fp32 MFMA time on gfx950
+    // (tools/micro/mfma_mix.cpp).  One layer's operands are < 4 GB.
+    const unsigned char* Xbase = reinterpret_cast<const unsigned char*>(p.X) + (size_t)p.col0 * ESZ;
+    const unsigned a_fix = (unsigned)a_xb * ldb + (unsigned)(a_ct * 16 + (tid & 3) * 4) * ESZ;
     // ---- B tile slice: NW/4 float4 per row
     constexpr int BF4 = NW / 4;                        // float4 per B row
     constexpr int BQ = (F_KT * BF4 + 255) / 256;       // float4 per thread (1 or 2)
@@ -163,25 +167,36 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     constexpr int AQ = F_KT / 16;                      // A float4 per thread
     constexpr int LPS = AQ + BQ;                       // loads per stage
     struct Stage { AT a[AQ]; f32x4 b[BQ]; };
-    const float* Wb[BQ]; bool bok[BQ]; int brow[BQ], bc4[BQ];
+    bool bok[BQ]; int brow[BQ], bc4[BQ]; unsigned b_fix[BQ];
 #pragma unroll
     for (int i = 0; i < BQ; i++) {                                   // clamped B slots (threads beyond the tile re-load the last one)
         const int q = tid + 256 * i; bok[i] = q < F_KT * BF4; const int qc = bok[i] ? q : F_KT * BF4 - 1;
-        brow[i] = qc / BF4; bc4[i] = qc % BF4; Wb[i] = Wp + (unsigned)brow[i] * (unsigned)L.N + 4 * bc4[i];
+        brow[i] = qc / BF4; bc4[i] = qc % BF4; b_fix[i] = 4u * ((unsigned)brow[i] * (unsigned)L.N + 4u * bc4[i]);
     }
-    auto gld = [](const float* ptr) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory"); return v; };
-    auto gld1 = [](const unsigned char* ptr) { uint32_t v; asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr) : "memory"); return v; };
+    unsigned a_den[AQ];                                                // dense: the thread's rows of a K tile
+#pragma unroll
+    for (int q = 0; q < AQ; q++) a_den[q] = a_fix + (unsigned)(arow + 16 * q) * ldb;
+    auto gld = [](unsigned off, const void* base) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); return v; };
+    auto gld1 = [](unsigned off, const void* base) { uint32_t v; asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); return v; };
+    // conv: the row offsets of a tile are read from the table one call AHEAD of the loads that use them (gload is called for tiles 0, 1, 2, ... in order, clamped
+    // at the last): no LDS round trip -- and no drain of the fragment reads in flight -- in front of a load issue
+    unsigned kn[AQ];
+#pragma unroll
+    for (int q = 0; q < AQ; q++) kn[q] = conv ? a_fix + (unsigned)koff_lds[k0 + arow + 16 * q] : a_den[q];
     auto gload = [&](int kt, Stage& r) {
         kt = min(kt, nkt - 1);
         const int kb = k0 + kt * F_KT;
+        const unsigned char* pa = conv ? Xbase : Xbase + (size_t)((unsigned)kb * ldb);
 #pragma unroll
-        for (int q = 0; q < AQ; q++) {
-            const int ka = kb + arow + 16 * q;
-            const int ko = conv ? koff_lds[ka] : ka;
-            if constexpr (XU8) r.a[q] = gld1(Xb + (unsigned)(a_xb + ko) * ldx); else r.a[q] = gld(Xa + (unsigned)(a_xb + ko) * ldx);
+        for (int q = 0; q < AQ; q++) { if constexpr (XU8) r.a[q] = gld1(kn[q], pa); else r.a[q] = gld(kn[q], pa); }
+        const float* pb = Wp + (size_t)((unsigned)kb * (unsigned)L.N);
+#pragma unroll
+        for (int i = 0; i < BQ; i++) r.b[i] = gld(b_fix[i], pb);
+        if (conv) {
+            const int kbn = k0 + min(kt + 1, nkt - 1) * F_KT;
+#pragma unroll
+            for (int q = 0; q < AQ; q++) kn[q] = a_fix + (unsigned)koff_lds[kbn + arow + 16 * q];
         }
-#pragma unroll
-        for (int i = 0; i < BQ; i++) r.b[i] = gld(Wb[i] + (unsigned)kb * (unsigned)L.N);
     };
     auto lstore = [&](int buf, const Stage& r) {
 #pragma unroll
@@ -775,16 +790,19 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
             koff1 = ((k1r / khw) * L.ih + (k1r / L.kw) % L.kh) * L.iw + k1r % L.kw;
         } else { koff0 = k0r; koff1 = k1r; }
     }
-    const float* Xa = p.X + 4 * f4;
-    const unsigned char* Xb = reinterpret_cast<const unsigned char*>(p.X) + 4 * f4;      // XU8 view (the byte observation arena)
+    // r04: operand address = SCALAR base of the K tile (arena / dpre + tile offset, scalar ALU) + a 32-bit per-thread byte offset fixed for the whole workgroup: no VALU
+    // address arithmetic in the loop (every VALU instruction is paid in fp32 MFMA time on gfx950, tools/micro/mfma_mix.cpp).  One layer's operands are < 4 GB.
+    constexpr unsigned ESZ = XU8 ? 1u : 4u;
+    const unsigned char* Xbytes = reinterpret_cast<const unsigned char*>(p.X);
+    const unsigned a_off0 = ((unsigned)koff0 * (unsigned)ldx + 4u * f4) * ESZ, a_off1 = ((unsigned)koff1 * (unsigned)ldx + 4u * f4) * ESZ;
     // ---- B tile slice: channel rows q>>3 (clamped), float4 (q & 7)
     const int bq0 = tid < NW * 8 ? tid : NW * 8 - 1, bq1 = tid + 256 < NW * 8 ? tid + 256 : NW * 8 - 1;
-    const float* Db0 = p.dpre + (size_t)(n0 + (bq0 >> 3)) * ds.ldd + 4 * (bq0 & 7);
-    const float* Db1 = p.dpre + (size_t)(n0 + (bq1 >> 3)) * ds.ldd + 4 * (bq1 & 7);
+    const unsigned b_off0 = 4u * ((unsigned)(n0 + (bq0 >> 3)) * (unsigned)ds.ldd + 4u * (bq0 & 7));
+    const unsigned b_off1 = 4u * ((unsigned)(n0 + (bq1 >> 3)) * (unsigned)ds.ldd + 4u * (bq1 & 7));
     constexpr int LPS = 2 + BQ;
     struct Stage { AT a0, a1; f32x4 b0, b1; };
-    auto gld = [](const float* ptr) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory"); return v; };
-    auto gld1 = [](const unsigned char* ptr) { uint32_t v; asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr) : "memory"); return v; };
+    auto gld = [](unsigned off, const void* base) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); return v; };
+    auto gld1 = [](unsigned off, const void* base) { uint32_t v; asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); return v; };
     auto cvt = [](const AT& a) { if constexpr (XU8) { const uint32_t w4 = a; return (f32x4){u8_unit(w4 & 0xffu), u8_unit((w4 >> 8) & 0xffu), u8_unit((w4 >> 16) & 0xffu), u8_unit(w4 >> 24)}; } else return a; };
     auto gload = [&](int kt, Stage& r) {
         kt = min(kt, nkt - 1);
@@ -793,10 +811,12 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
         const unsigned ao = so, bo = (unsigned)pos * (unsigned)B + so;
         int xb = 0;
         if (conv) { const int oy = pos / L.ow, ox = pos % L.ow; xb = oy * L.sh * L.iw + ox * L.sw; }
-        if constexpr (XU8) { r.a0 = gld1(Xb + (unsigned)(xb + koff0) * (unsigned)ldx + ao); r.a1 = gld1(Xb + (unsigned)(xb + koff1) * (unsigned)ldx + ao); }
-        else { r.a0 = gld(Xa + (unsigned)(xb + koff0) * (unsigned)ldx + ao); r.a1 = gld(Xa + (unsigned)(xb + koff1) * (unsigned)ldx + ao); }
-        r.b0 = gld(Db0 + bo);
-        if (BQ > 1) r.b1 = gld(Db1 + bo);
+        const unsigned char* pa = Xbytes + (size_t)((unsigned)xb * (unsigned)ldx + ao) * ESZ;
+        const float* pb = p.dpre + bo;
+        if constexpr (XU8) { r.a0 = gld1(a_off0, pa); r.a1 = gld1(a_off1, pa); }
+        else { r.a0 = gld(a_off0, pa); r.a1 = gld(a_off1, pa); }
+        r.b0 = gld(b_off0, pb);
+        if (BQ > 1) r.b1 = gld(b_off1, pb);
     };
     auto lstore = [&](int buf, const Stage& r) {
         lds_st4(As + (buf * 64 + (tid >> 3)) * W_ST + 4 * f4, cvt(r.a0));
