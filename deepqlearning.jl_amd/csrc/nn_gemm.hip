@@ -804,13 +804,21 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
     auto gld = [](unsigned off, const void* base) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); return v; };
     auto gld1 = [](unsigned off, const void* base) { uint32_t v; asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); return v; };
     auto cvt = [](const AT& a) { if constexpr (XU8) { const uint32_t w4 = a; return (f32x4){u8_unit(w4 & 0xffu), u8_unit((w4 >> 8) & 0xffu), u8_unit((w4 >> 16) & 0xffu), u8_unit(w4 >> 24)}; } else return a; };
-    auto gload = [&](int kt, Stage& r) {
-        kt = min(kt, nkt - 1);
-        const int ka = kt0 + kt; const int pos = ka / nsub, sub = ka % nsub;          // 32-sample block `sub` of position `pos`
-        const unsigned so = ds.tpr > 0 ? (unsigned)(sub / ds.tpr) * (unsigned)ds.rstride + (unsigned)(sub % ds.tpr) * 32u : (unsigned)sub * 32u;
-        const unsigned ao = so, bo = (unsigned)pos * (unsigned)B + so;
-        int xb = 0;
-        if (conv) { const int oy = pos / L.ow, ox = pos % L.ow; xb = oy * L.sh * L.iw + ox * L.sw; }
+    // cursor of the staging loads (r04): gload is called for K tiles 0, 1, 2, ... in order (clamped at the last), so the 32-sample block `sub` of position
+    // `pos` = (oy, ox) and the block's place in a gathered rank layout advance by carries -- the five integer divisions per tile this replaces were ~5 scalar
+    // instructions per MFMA in the first convolution's dW launch (PMC r04_o)
+    int g_kt = 0, g_pos = kt0 / nsub, g_sub = kt0 % nsub, g_oy = 0, g_ox = 0, g_rk = 0, g_st = g_sub;
+    if (conv) { g_oy = g_pos / L.ow; g_ox = g_pos % L.ow; }
+    if (ds.tpr > 0) { g_rk = g_sub / ds.tpr; g_st = g_sub % ds.tpr; }
+    auto gload = [&](int, Stage& r) {
+        const unsigned so = ds.tpr > 0 ? (unsigned)g_rk * (unsigned)ds.rstride + (unsigned)g_st * 32u : (unsigned)g_sub * 32u;
+        const unsigned ao = so, bo = (unsigned)g_pos * (unsigned)B + so;
+        const int xb = conv ? g_oy * L.sh * L.iw + g_ox * L.sw : 0;
+        if (g_kt + 1 < nkt) {
+            g_kt++; g_sub++; g_st++;
+            if (ds.tpr > 0 && g_st == ds.tpr) { g_st = 0; g_rk++; }
+            if (g_sub == nsub) { g_sub = 0; g_st = 0; g_rk = 0; g_pos++; g_ox++; if (g_ox == L.ow) { g_ox = 0; g_oy++; } }
+        }
         const unsigned char* pa = Xbytes + (size_t)((unsigned)xb * (unsigned)ldx + ao) * ESZ;
         const float* pb = p.dpre + bo;
         if constexpr (XU8) { r.a0 = gld1(a_off0, pa); r.a1 = gld1(a_off1, pa); }
