@@ -72,6 +72,12 @@ template <int NBYTES> __device__ __forceinline__ void karg_warm() {
     asm volatile("" ::"s"(x));
 #endif
 }
+// a wave-uniform pointer the compiler cannot prove uniform (derived from threadIdx >> 6), moved to scalar registers for the scalar-base form of global loads
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const float*)(((unsigned long long)hi << 32) | lo);
+}
 // tail workgroups of a backward launch: VALU tasks first, then the Adam stream (blk counts from the first tail workgroup)
 __device__ __forceinline__ void gemm_tail_run(const GemmTail& tail, unsigned blk) {
     if (blk < tail.blocks) { valu_task_run<false>(tail.tasks, tail.n, blk); return; }
@@ -1052,7 +1058,8 @@ __device__ __forceinline__ void dx_units_body(const LayerDev& L, const GDxArgs& 
 #pragma unroll
     for (int j = 0; j < 2 * FT; j++) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (active) {
-        const int si = wave / nch, cj = wave - si * nch;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);      // the unit index in a SCALAR register: everything derived from it (tile counts, cursor, bases) is scalar arithmetic and uniform branches
+        const int si = wv / nch, cj = wv - si * nch;
         const GDxSrc& sr = A.src[si];
         const int cot = L.N / 32;
         int nt, n0 = 0, t0 = 0;
@@ -1060,27 +1067,36 @@ __device__ __forceinline__ void dx_units_body(const LayerDev& L, const GDxArgs& 
         else { t0 = cst[cj]; nt = (cst[cj + 1] - t0) * cot; }
         // staging slices of this lane: rows (lane >> 3) + 8p, float4 (lane & 7) of both tiles
         const int row0 = lane >> 3, f4 = lane & 7;
-        const float* Ap = sr.dpre + b0 + 4 * f4;
-        unsigned boff[2 * FT];
+        // r04: operand address = SCALAR base of the tile (scalar ALU; the unit and its tile cursor are wave-uniform) + a 32-bit per-lane byte offset fixed for the whole
+        // unit: no VALU address arithmetic per load (every VALU instruction is paid in fp32 MFMA time on gfx950, and a wave is alone on its SIMD here)
+        unsigned aoff[4], boff[2 * FT];
 #pragma unroll
-        for (int p = 0; p < 2 * FT; p++) { const unsigned frow = (unsigned)min(f0 + row0 + 8 * p, nfeat - 1); boff[p] = dense ? frow * (unsigned)L.N + 4u * f4 : frow * (unsigned)(khw * L.N) + 4u * f4; }
-        const float* Wp = sr.W;
-        const float r_cot = 1.0f / (float)cot;
+        for (int p = 0; p < 4; p++) aoff[p] = 4u * ((unsigned)(row0 + 8 * p) * (unsigned)(dense ? B : L.npos * B) + (unsigned)(b0 + 4 * f4));
+#pragma unroll
+        for (int p = 0; p < 2 * FT; p++) { const unsigned frow = (unsigned)min(f0 + row0 + 8 * p, nfeat - 1); boff[p] = 4u * (dense ? frow * (unsigned)L.N + 4u * f4 : frow * (unsigned)(khw * L.N) + 4u * f4); }
         struct Stage { f32x4 a[4], b[2 * FT]; };
-        auto gld = [](const float* ptr) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory"); return v; };
-        auto gload = [&](int t, Stage& r) {
-            t = min(t, nt - 1);
-            unsigned ao, astep, bo;
-            if (dense) { const unsigned nb = (unsigned)(n0 + 32 * t); ao = (nb + row0) * (unsigned)B; astep = 8u * (unsigned)B; bo = nb; }
+        auto gld = [](unsigned off, const float* base) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); return v; };
+        // tile cursor: gload is called for tiles 0, 1, 2, ... in order (clamped at the last): tile = (tap g_ti of the chunk, channel tile g_ci); the tap of the NEXT
+        // tile is read from the table one call ahead
+        int g_t = 0, g_ti = 0, g_ci = 0;
+        int g_tp = dense ? 0 : taps[t0];
+        auto gload = [&](int, Stage& r) {
+            size_t sa, sb;
+            if (dense) { const unsigned nb = (unsigned)(n0 + 32 * g_t); sa = (size_t)nb * (unsigned)B; sb = nb; }
             else {
-                const int ti = (int)(((float)t + 0.5f) * r_cot); const int cob = (t - ti * cot) * 32;     // tile t = (tap ti of the chunk, channel tile)
-                const int tp = taps[t0 + ti]; const unsigned tap = (unsigned)tp >> 16, pos = (unsigned)tp & 0xffffu;
-                ao = ((unsigned)(cob + row0) * (unsigned)L.npos + pos) * (unsigned)B; astep = 8u * (unsigned)L.npos * (unsigned)B; bo = tap * (unsigned)L.N + (unsigned)cob;
+                const int tp = __builtin_amdgcn_readfirstlane(g_tp); const unsigned tap = (unsigned)tp >> 16, pos = (unsigned)tp & 0xffffu, cob = (unsigned)g_ci * 32u;
+                sa = ((size_t)cob * (unsigned)L.npos + pos) * (unsigned)B; sb = (size_t)tap * (unsigned)L.N + cob;
             }
+            const float* pa = uniform_ptr(sr.dpre + sa); const float* pb = uniform_ptr(sr.W + sb);      // (the unit is the wave: uniform, which the compiler cannot see)
 #pragma unroll
-            for (int p = 0; p < 4; p++) r.a[p] = gld(Ap + ao + p * astep);
+            for (int p = 0; p < 4; p++) r.a[p] = gld(aoff[p], pa);
 #pragma unroll
-            for (int p = 0; p < 2 * FT; p++) r.b[p] = gld(Wp + boff[p] + bo);
+            for (int p = 0; p < 2 * FT; p++) r.b[p] = gld(boff[p], pb);
+            if (g_t + 1 < nt) {
+                g_t++; g_ci++;
+                if (g_ci == cot) { g_ci = 0; g_ti++; }
+                if (!dense) g_tp = taps[t0 + g_ti];
+            }
         };
         const int aswz = ((row0 & 1) << 2) ^ f4;     // float4 column of this lane's A rows (all of one parity: row0 + 8p)
         auto lstore = [&](const Stage& r) {
