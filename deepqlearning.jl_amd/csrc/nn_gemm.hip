@@ -186,22 +186,24 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     auto gld1 = [](unsigned off, const void* base) { uint32_t v; asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); return v; };
     // conv: the row offsets of a tile are read from the table one call AHEAD of the loads that use them (gload is called for tiles 0, 1, 2, ... in order, clamped
     // at the last): no LDS round trip -- and no drain of the fragment reads in flight -- in front of a load issue
+    // (kn holds the RAW table value until the call that uses it: the empty asm pins the wait for the table read there, a whole tile after its issue -- with the
+    // add written next to the read the compiler waits for the LDS round trip on the spot, once per tile of a lone wave)
     unsigned kn[AQ];
 #pragma unroll
-    for (int q = 0; q < AQ; q++) kn[q] = conv ? a_fix + (unsigned)koff_lds[k0 + arow + 16 * q] : a_den[q];
+    for (int q = 0; q < AQ; q++) kn[q] = conv ? (unsigned)koff_lds[k0 + arow + 16 * q] : a_den[q] - a_fix;
     auto gload = [&](int kt, Stage& r) {
         kt = min(kt, nkt - 1);
         const int kb = k0 + kt * F_KT;
         const unsigned char* pa = conv ? Xbase : Xbase + (size_t)((unsigned)kb * ldb);
 #pragma unroll
-        for (int q = 0; q < AQ; q++) { if constexpr (XU8) r.a[q] = gld1(kn[q], pa); else r.a[q] = gld(kn[q], pa); }
+        for (int q = 0; q < AQ; q++) { asm volatile("" : "+v"(kn[q])); const unsigned off = a_fix + kn[q]; if constexpr (XU8) r.a[q] = gld1(off, pa); else r.a[q] = gld(off, pa); }
         const float* pb = Wp + (size_t)((unsigned)kb * (unsigned)L.N);
 #pragma unroll
         for (int i = 0; i < BQ; i++) r.b[i] = gld(b_fix[i], pb);
         if (conv) {
             const int kbn = k0 + min(kt + 1, nkt - 1) * F_KT;
 #pragma unroll
-            for (int q = 0; q < AQ; q++) kn[q] = a_fix + (unsigned)koff_lds[kbn + arow + 16 * q];
+            for (int q = 0; q < AQ; q++) kn[q] = (unsigned)koff_lds[kbn + arow + 16 * q];
         }
     };
     auto lstore = [&](int buf, const Stage& r) {
@@ -422,12 +424,13 @@ __global__ __launch_bounds__(256) void k_fwd_wres(LayerDev L, GFwdProbs pr) {
     unsigned kn[AQ];
     auto koff_of = [&](int kt) {
 #pragma unroll
-        for (int q = 0; q < AQ; q++) kn[q] = (unsigned)koff_lds[kt * F_KT + arow + 16 * q] + lane_b;
+        for (int q = 0; q < AQ; q++) kn[q] = (unsigned)koff_lds[kt * F_KT + arow + 16 * q];      // RAW: the adds wait for the read where it is USED (next step)
     };
     auto gload = [&](unsigned go, Stage& r) {             // ALWAYS AQ * NLD loads (hand-counted waits, see k_fwd_lds); rows from kn
 #pragma unroll
         for (int q = 0; q < AQ; q++) {
-            const unsigned off = kn[q] + go;
+            asm volatile("" : "+v"(kn[q]));
+            const unsigned off = kn[q] + (go + lane_b);
             if constexpr (XU8) {
                 if constexpr (MT == 1) asm volatile("global_load_dword %0, %1, %2" : "=v"(r.u[q]) : "v"(off), "s"(Xbase) : "memory");
                 else if constexpr (MT == 2) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r.u[q]) : "v"(off), "s"(Xbase) : "memory");
