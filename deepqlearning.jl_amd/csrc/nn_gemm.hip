@@ -137,9 +137,9 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     }
     const int wg_begin = pi == 0 ? 0 : pr.wg_end[pi - 1];
     int w = xcd_remap(blockIdx.x - wg_begin, pr.wg_end[pi] - wg_begin);
-    const int ngroups = L.N / NW;
-    const int ng = w % ngroups; w /= ngroups;
-    const int mgrp = w % p.mgroups; const int s = w / p.mgroups;
+    const int ngroups = L.N / NW;                      // (NW is a power of two; the decodes below go through reciprocals: fdiv_*, common.h)
+    int ng, mgrp, s;
+    { int w2; fdiv_qr(w, fdiv_of(ngroups), w2, ng); fdiv_qr(w2, fdiv_of(p.mgroups), s, mgrp); }
     const int n0 = ng * NW, ctiles = p.ncols >> 4;
     const int k0 = s * kc, k1 = min(L.K, k0 + kc), nkt = (k1 - k0) / F_KT;
 
@@ -149,8 +149,8 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     const bool a_ok = amt < p.mtiles;
     int a_xb = 0, a_ct = 0;
     if (a_ok) {
-        const int pos = amt / ctiles; a_ct = amt % ctiles;
-        if (conv) { const int oy = pos / L.ow, ox = pos % L.ow; a_xb = oy * L.sh * L.iw + ox * L.sw; }
+        int pos; fdiv_qr(amt, fdiv_of(ctiles), pos, a_ct);
+        if (conv) { int oy, ox; fdiv_qr(pos, fdiv_of(L.ow), oy, ox); a_xb = oy * L.sh * L.iw + ox * L.sw; }
     }
     const int arow = tid >> 4;                         // 0..15 (second float4: +16)
     // r04: operand address = SCALAR base (+ the K tile's offset where it is uniform: dense rows, weight rows) + a 32-bit per-thread byte offset fixed for the whole
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     // ---- epilogue: wave w's M-tile
     const int mt = mgrp * 4 + wave;
     if (mt >= p.mtiles) return;
-    const int pos = mt / ctiles, ct = mt % ctiles;
+    int pos, ct; fdiv_qr(mt, fdiv_of(ctiles), pos, ct);
     const size_t per_s = (size_t)L.N * L.npos * p.ncols;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
@@ -781,9 +781,8 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
     const bool conv = L.kind == DQN_LAYER_CONV;
     const int mrows = (L.K + 63) / 64, ngroups = L.N / NW;
     int w = xcd_remap(bid, nblocks);
-    const int pi = w % nprob; w /= nprob;
-    const int ng = w % ngroups; w /= ngroups;
-    const int mr = w % mrows; const int s = w / mrows;
+    int pi, ng, mr, s;                                 // (decodes through reciprocals: fdiv_*, common.h)
+    { int w2, w3; fdiv_qr(w, fdiv_of(nprob), w2, pi); fdiv_qr(w2, fdiv_of(ngroups), w3, ng); fdiv_qr(w3, fdiv_of(mrows), s, mr); }
     const GDwProb& p = pr.p[pi];
     const int n0 = ng * NW;
     const int KK = L.npos * B, j0 = s * kc, j1 = min(KK, j0 + kc);
@@ -794,9 +793,10 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
     {
         const int k0r = min(mr * 64 + (tid >> 3), L.K - 1), k1r = min(mr * 64 + (tid >> 3) + 32, L.K - 1);
         if (conv) {
-            const int khw = L.kh * L.kw;
-            koff0 = ((k0r / khw) * L.ih + (k0r / L.kw) % L.kh) * L.iw + k0r % L.kw;
-            koff1 = ((k1r / khw) * L.ih + (k1r / L.kw) % L.kh) * L.iw + k1r % L.kw;
+            const FDiv fkhw = fdiv_of(L.kh * L.kw), fkw = fdiv_of(L.kw);
+            int ci, rem, ky, kx;
+            fdiv_qr(k0r, fkhw, ci, rem); fdiv_qr(rem, fkw, ky, kx); koff0 = (ci * L.ih + ky) * L.iw + kx;
+            fdiv_qr(k1r, fkhw, ci, rem); fdiv_qr(rem, fkw, ky, kx); koff1 = (ci * L.ih + ky) * L.iw + kx;
         } else { koff0 = k0r; koff1 = k1r; }
     }
     // r04: operand address = SCALAR base of the K tile (arena / dpre + tile offset, scalar ALU) + a 32-bit per-thread byte offset fixed for the whole workgroup: no VALU
@@ -816,9 +816,10 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
     // cursor of the staging loads (r04): gload is called for K tiles 0, 1, 2, ... in order (clamped at the last), so the 32-sample block `sub` of position
     // `pos` = (oy, ox) and the block's place in a gathered rank layout advance by carries -- the five integer divisions per tile this replaces were ~5 scalar
     // instructions per MFMA in the first convolution's dW launch (PMC r04_o)
-    int g_kt = 0, g_pos = kt0 / nsub, g_sub = kt0 % nsub, g_oy = 0, g_ox = 0, g_rk = 0, g_st = g_sub;
-    if (conv) { g_oy = g_pos / L.ow; g_ox = g_pos % L.ow; }
-    if (ds.tpr > 0) { g_rk = g_sub / ds.tpr; g_st = g_sub % ds.tpr; }
+    int g_kt = 0, g_pos, g_sub, g_oy = 0, g_ox = 0, g_rk = 0, g_st;
+    fdiv_qr(kt0, fdiv_of(nsub), g_pos, g_sub); g_st = g_sub;
+    if (conv) fdiv_qr(g_pos, fdiv_of(L.ow), g_oy, g_ox);
+    if (ds.tpr > 0) fdiv_qr(g_sub, fdiv_of(ds.tpr), g_rk, g_st);
     auto gload = [&](int, Stage& r) {
         const unsigned so = ds.tpr > 0 ? (unsigned)g_rk * (unsigned)ds.rstride + (unsigned)g_st * 32u : (unsigned)g_sub * 32u;
         const unsigned ao = so, bo = (unsigned)g_pos * (unsigned)B + so;
