@@ -1023,22 +1023,23 @@ __device__ __forceinline__ void dx_units_body(const LayerDev& L, const GDxArgs& 
     const int w = xcd_remap(bid, nblocks);
     const int nfeat = dense ? L.K : L.cin, khw = L.kh * L.kw;
     int f0, ip = 0, nch;
-    if (dense) { const int ftiles = (L.K + FW - 1) / FW; f0 = (w % ftiles) * FW; nch = S; }
+    if (dense) { const int ftiles = (L.K + FW - 1) / FW; int q, r; fdiv_qr(w, fdiv_of(ftiles), q, r); f0 = r * FW; nch = S; }
     else {
-        const int ctiles = L.cin / FW; f0 = (w % ctiles) * FW; ip = w / ctiles;
+        const int ctiles = L.cin / FW; int r; fdiv_qr(w, fdiv_of(ctiles), ip, r); f0 = r * FW;
         if (tid < 64) {
             // lane (ky*kw + kx) tests its own tap; ballots compact the valid ones in raw-tap order and mark the first valid tap of every chunk
-            const int iy = ip / L.iw, ix = ip % L.iw; bool ok = false; int val = 0;
+            int iy, ix; fdiv_qr(ip, fdiv_of(L.iw), iy, ix); bool ok = false; int val = 0;      // (reciprocal decodes: fdiv_*, common.h)
             if (tid < khw) {
-                const int ky = tid / L.kw, kx = tid % L.kw, ty = iy - ky, tx = ix - kx;
-                if (ty >= 0 && tx >= 0 && ty % L.sh == 0 && tx % L.sw == 0) {
-                    const int oy = ty / L.sh, ox = tx / L.sw;
-                    if (oy < L.oh && ox < L.ow) { ok = true; val = (tid << 16) | (oy * L.ow + ox); }
+                int ky, kx; fdiv_qr(tid, fdiv_of(L.kw), ky, kx);
+                const int ty = iy - ky, tx = ix - kx;
+                if (ty >= 0 && tx >= 0) {
+                    int oy, ry, ox, rx; fdiv_qr(ty, fdiv_of(L.sh), oy, ry); fdiv_qr(tx, fdiv_of(L.sw), ox, rx);
+                    if (ry == 0 && rx == 0 && oy < L.oh && ox < L.ow) { ok = true; val = (tid << 16) | (oy * L.ow + ox); }
                 }
             }
-            const int tcr = DQN_CONV_TAP_CHUNK(L);
+            const int tcr = DQN_CONV_TAP_CHUNK(L); const FDiv ftcr = fdiv_of(tcr);
             const unsigned long long m = __ballot(ok), below = (1ull << tid) - 1ull, mb = m & below;
-            const bool first = ok && (mb == 0 || (63 - __clzll(mb)) / tcr != tid / tcr);
+            const bool first = ok && (mb == 0 || fdiv_q(63 - __clzll(mb), ftcr) != fdiv_q(tid, ftcr));
             const unsigned long long fm = __ballot(first);
             if (ok) taps[__popcll(mb)] = val;
             if (first) cst[__popcll(fm & below)] = __popcll(mb);
@@ -1063,7 +1064,7 @@ __device__ __forceinline__ void dx_units_body(const LayerDev& L, const GDxArgs& 
     for (int j = 0; j < 2 * FT; j++) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (active) {
         const int wv = __builtin_amdgcn_readfirstlane(wave);      // the unit index in a SCALAR register: everything derived from it (tile counts, cursor, bases) is scalar arithmetic and uniform branches
-        const int si = wv / nch, cj = wv - si * nch;
+        const int si = fdiv_q(wv, fdiv_of(nch)), cj = wv - si * nch;
         const GDxSrc& sr = A.src[si];
         const int cot = L.N / 32;
         int nt, n0 = 0, t0 = 0;
@@ -1195,19 +1196,20 @@ __device__ __forceinline__ void dx_lds_body_wide(const LayerDev& L, const GDxArg
     int w = xcd_remap(bid, nblocks);
     int f0, s = 0, ip = 0;
     const int nfeat = dense ? L.K : L.cin;
-    if (dense) { const int ftiles = (L.K + 31) / 32; f0 = (w % ftiles) * 32; s = w / ftiles; }
-    else { const int ctiles = L.cin / 32; f0 = (w % ctiles) * 32; ip = w / ctiles; }
+    if (dense) { const int ftiles = (L.K + 31) / 32; int r; fdiv_qr(w, fdiv_of(ftiles), s, r); f0 = r * 32; }
+    else { const int ctiles = L.cin / 32; int r; fdiv_qr(w, fdiv_of(ctiles), ip, r); f0 = r * 32; }
     int nkt;
     const int khw = L.kh * L.kw;
     if (dense) { const int n0 = s * kc, n1 = min(L.N, n0 + kc); nkt = (n1 - n0) / 32; }
     else {
         if (tid < 64) {
-            const int iy = ip / L.iw, ix = ip % L.iw; bool ok = false; int val = 0;
+            int iy, ix; fdiv_qr(ip, fdiv_of(L.iw), iy, ix); bool ok = false; int val = 0;
             if (tid < L.kh * L.kw) {
-                const int ky = tid / L.kw, kx = tid % L.kw, ty = iy - ky, tx = ix - kx;
-                if (ty >= 0 && tx >= 0 && ty % L.sh == 0 && tx % L.sw == 0) {
-                    const int oy = ty / L.sh, ox = tx / L.sw;
-                    if (oy < L.oh && ox < L.ow) { ok = true; val = (tid << 16) | (oy * L.ow + ox); }
+                int ky, kx; fdiv_qr(tid, fdiv_of(L.kw), ky, kx);
+                const int ty = iy - ky, tx = ix - kx;
+                if (ty >= 0 && tx >= 0) {
+                    int oy, ry, ox, rx; fdiv_qr(ty, fdiv_of(L.sh), oy, ry); fdiv_qr(tx, fdiv_of(L.sw), ox, rx);
+                    if (ry == 0 && rx == 0 && oy < L.oh && ox < L.ow) { ok = true; val = (tid << 16) | (oy * L.ow + ox); }
                 }
             }
             const unsigned long long m = __ballot(ok);
