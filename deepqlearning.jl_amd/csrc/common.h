@@ -79,6 +79,18 @@ __device__ __forceinline__ float dact_f(float dy, float y, int act) {
     default: return dy;
     }
 }
+// four values at once: ONE decode of the activation code per vector (the element-wise helpers above cost a switch -- three or four scalar branches -- per element, and a
+// lone wave pays every branch: r04).  V = any 4-component vector type with .x .y .z .w
+template <class V> __device__ __forceinline__ void act_v4(V& v, float bias, int act) {
+    const float a = v.x + bias, b = v.y + bias, c = v.z + bias, d = v.w + bias;
+    if (act == DQN_ACT_RELU) { v.x = a > 0.0f ? a : 0.0f; v.y = b > 0.0f ? b : 0.0f; v.z = c > 0.0f ? c : 0.0f; v.w = d > 0.0f ? d : 0.0f; }
+    else if (act == DQN_ACT_TANH || act == DQN_ACT_SIGMOID) { v.x = act_f(a, act); v.y = act_f(b, act); v.z = act_f(c, act); v.w = act_f(d, act); }
+    else { v.x = a; v.y = b; v.z = c; v.w = d; }
+}
+template <class V> __device__ __forceinline__ void dact_v4(V& v, const V& y, int act) {
+    if (act == DQN_ACT_RELU) { v.x = y.x > 0.0f ? v.x : 0.0f; v.y = y.y > 0.0f ? v.y : 0.0f; v.z = y.z > 0.0f ? v.z : 0.0f; v.w = y.w > 0.0f ? v.w : 0.0f; }
+    else if (act == DQN_ACT_TANH || act == DQN_ACT_SIGMOID) { v.x = dact_f(v.x, y.x, act); v.y = dact_f(v.y, y.y, act); v.z = dact_f(v.z, y.z, act); v.w = dact_f(v.w, y.w, act); }
+}
 // (float)b / 255.0f for a byte b (u8 observations, test/test_env.jl:59) in TWO operations beside the conversion instead of the ~10-instruction IEEE division:
 // 1/255 = r_hi + r_lo with r_hi = 0x1.01p-8 (9 significant bits: b * r_hi is exact for b < 256) and r_lo = fl(1/255 - r_hi), so fma(b, r_lo, b * r_hi) rounds
 // b / 255 (1 + 2^-40) once -- and b / 255 = 0.bbb... in base 256 is never that close to a rounding boundary.  Equal to the division for all 256 bytes

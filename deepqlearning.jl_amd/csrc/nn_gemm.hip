@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
             if (mt >= p.mtiles) continue;
             const int pos = mt / ctiles, ct = mt % ctiles;
             f32x4 v = {c16[4 * g], c16[4 * g + 1], c16[4 * g + 2], c16[4 * g + 3]};
-            if (S == 1) { v.x = act_f(v.x + bias, L.act); v.y = act_f(v.y + bias, L.act); v.z = act_f(v.z + bias, L.act); v.w = act_f(v.w + bias, L.act); }
+            if (S == 1) { act_v4(v, bias, L.act); }
             *reinterpret_cast<f32x4*>(p.out + (size_t)s * per_s + ((size_t)n * L.npos + pos) * p.ncols + ct * 16 + (cc & 15)) = v;
         }
         return;
@@ -342,7 +342,8 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
         f32x4 v = acc[t];
         if (S == 1) {
             const float bias = bias_r[t];
-            v.x = act_f(v.x + bias, L.act); v.y = act_f(v.y + bias, L.act); v.z = act_f(v.z + bias, L.act); v.w = act_f(v.w + bias, L.act);
+            if constexpr (KT == 16) act_v4(v, bias, L.act);      // (large launches; for the lone waves of the 32-deep form the per-element switch measures 1.9 % FASTER per step, same box)
+            else { v.x = act_f(v.x + bias, L.act); v.y = act_f(v.y + bias, L.act); v.z = act_f(v.z + bias, L.act); v.w = act_f(v.w + bias, L.act); }
         }
         *reinterpret_cast<f32x4*>(p.out + (size_t)s * per_s + ((size_t)n * L.npos + pos) * p.ncols + ct * 16 + 4 * kq) = v;
     }
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(256) void k_fwd_wres(LayerDev L, GFwdProbs pr) {
                     const int n = 16 * t + l15;
                     const float bias = bias_r[t];
                     f32x4 v = acc[m][t];
-                    v.x = act_f(v.x + bias, L.act); v.y = act_f(v.y + bias, L.act); v.z = act_f(v.z + bias, L.act); v.w = act_f(v.w + bias, L.act);
+                    act_v4(v, bias, L.act);
                     *reinterpret_cast<f32x4*>(p.out + ((size_t)n * L.npos + pos) * p.ncols + (ct0 + m) * 16 + 4 * kq) = v;
                 }
         }
@@ -653,7 +654,7 @@ __global__ __launch_bounds__(256) void k_fwd_dma(LayerDev L, GFwdProbs pr, int S
     for (int t = 0; t < NT; t++) {
         const int n = n0 + 16 * t + l15;
         f32x4 v = acc[t];
-        if (S == 1) { const float bias = bias_r[t]; v.x = act_f(v.x + bias, L.act); v.y = act_f(v.y + bias, L.act); v.z = act_f(v.z + bias, L.act); v.w = act_f(v.w + bias, L.act); }
+        if (S == 1) { const float bias = bias_r[t]; act_v4(v, bias, L.act); }
         *reinterpret_cast<f32x4*>(p.out + (size_t)s * per_s + ((size_t)n * L.npos + pos) * p.ncols + ct * 16 + 4 * kq) = v;
     }
 }
@@ -1319,7 +1320,7 @@ __device__ __forceinline__ void dx_lds_body_wide(const LayerDev& L, const GDxArg
             if (A.nsrc > 1) { const f32x4 o = acc[1][ft][ml]; v.x = v.x + o.x; v.y = v.y + o.y; v.z = v.z + o.z; v.w = v.w + o.w; }
             if (S == 1 && A.ysrc) {
                 const f32x4 y = *reinterpret_cast<const f32x4*>(A.ysrc + feat * A.ldy + bcol);
-                v.x = dact_f(v.x, y.x, A.act_src); v.y = dact_f(v.y, y.y, A.act_src); v.z = dact_f(v.z, y.z, A.act_src); v.w = dact_f(v.w, y.w, A.act_src);
+                dact_v4(v, y, A.act_src);
             }
             *reinterpret_cast<f32x4*>(A.out + (size_t)s * per_s + feat * B + bcol) = v;
         }
