@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
         // BYTE offset of contraction index k = (ci, ky, kx)'s input row, tabulated once per workgroup.  The two divisions go through reciprocals
         // (floor((x + 0.5) / d) is exact for these small ints): with integer divisions this table cost 0.85-2.0 us at the head of every conv
         // launch (ktrace, r02) before the first operand load could be issued.
-        const float r_khw = 1.0f / (float)(L.kh * L.kw), r_kw = 1.0f / (float)L.kw; const int khw = L.kh * L.kw;
+        const float r_khw = __builtin_amdgcn_rcpf((float)(L.kh * L.kw)), r_kw = __builtin_amdgcn_rcpf((float)L.kw); const int khw = L.kh * L.kw;      // (1-ulp reciprocals: exact for these ranges, fdiv_of in common.h)
         for (int k = tid; k < L.K; k += 256) { const int ci = (int)(((float)k + 0.5f) * r_khw); const int rem = k - ci * khw; const int ky = (int)(((float)rem + 0.5f) * r_kw); koff_lds[k] = (int)((unsigned)((ci * L.ih + ky) * L.iw + (rem - ky * L.kw)) * ldb); }
     }
     const int wg_begin = pi == 0 ? 0 : pr.wg_end[pi - 1];
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void k_fwd_wres(LayerDev L, GFwdProbs pr) {
     const unsigned ldb = (unsigned)p.ldx * ESZ;        // bytes per input row
     // BYTE offset of contraction index k's input row, tabulated once per workgroup (dense: k itself, so that the stream below has no layer-kind branch)
     if (conv) {
-        const float r_khw = 1.0f / (float)(L.kh * L.kw), r_kw = 1.0f / (float)L.kw; const int khw = L.kh * L.kw;
+        const float r_khw = __builtin_amdgcn_rcpf((float)(L.kh * L.kw)), r_kw = __builtin_amdgcn_rcpf((float)L.kw); const int khw = L.kh * L.kw;      // (1-ulp reciprocals: exact for these ranges, fdiv_of in common.h)
         for (int k = tid; k < L.K; k += 256) { const int ci = (int)(((float)k + 0.5f) * r_khw); const int rem = k - ci * khw; const int ky = (int)(((float)rem + 0.5f) * r_kw); koff_lds[k] = (int)((unsigned)((ci * L.ih + ky) * L.iw + (rem - ky * L.kw)) * ldb); }
     } else for (int k = tid; k < L.K; k += 256) koff_lds[k] = (int)((unsigned)k * ldb);
     const int wg_begin = pi == 0 ? 0 : pr.wg_end[pi - 1];
@@ -412,12 +412,13 @@ __global__ __launch_bounds__(256) void k_fwd_wres(LayerDev L, GFwdProbs pr) {
     // one VALU add per load, no 64-bit address arithmetic in the stream (the arena is < 4 GB)
     const unsigned char* Xbase = reinterpret_cast<const unsigned char*>(p.X) + (size_t)p.col0 * ESZ;
     const unsigned lane_b = (unsigned)(aq3 * 4 * MT) * ESZ;
+    const FDiv fct = fdiv_of(ctiles), fow = fdiv_of(conv ? L.ow : 1);
     auto tile_of = [&](int gi, unsigned& go) {         // byte offset of this wave's macro-tile of the gi-th workgroup tile: input-row base + column (a missing one re-reads tile 0: never stored)
         const int amt = __builtin_amdgcn_readfirstlane(((li + gi * cnt) * 4 + wave) * MT);
         go = 0;
         if (amt < p.mtiles) {
-            const int pos = amt / ctiles; go = (unsigned)(amt - pos * ctiles) * 16u * ESZ;
-            if (conv) { const int oy = pos / L.ow, ox = pos - oy * L.ow; go += (unsigned)(oy * L.sh * L.iw + ox * L.sw) * ldb; }
+            int pos, ct; fdiv_qr(amt, fct, pos, ct); go = (unsigned)ct * 16u * ESZ;
+            if (conv) { int oy, ox; fdiv_qr(pos, fow, oy, ox); go += (unsigned)(oy * L.sh * L.iw + ox * L.sw) * ldb; }
         }
     };
     struct Stage { UT u[AQ]; f32x4 v[AQ][MT]; };      // (one of the two is live)
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(256) void k_fwd_wres(LayerDev L, GFwdProbs pr) {
         const int mt0 = ((li + gi * cnt) * 4 + wave) * MT;
         stored = mt0 < p.mtiles;
         if (stored) {
-            const int pos = mt0 / ctiles, ct0 = mt0 - pos * ctiles;
+            int pos, ct0; fdiv_qr(mt0, fct, pos, ct0);
 #pragma unroll
             for (int m = 0; m < MT; m++)
 #pragma unroll
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(256) void k_fwd_dma(LayerDev L, GFwdProbs pr, int S
     karg_warm<sizeof(LayerDev) + sizeof(GFwdProbs) + 8>();
     const bool conv = L.kind == DQN_LAYER_CONV;
     if (conv) {
-        const float r_khw = 1.0f / (float)(L.kh * L.kw), r_kw = 1.0f / (float)L.kw; const int khw = L.kh * L.kw;
+        const float r_khw = __builtin_amdgcn_rcpf((float)(L.kh * L.kw)), r_kw = __builtin_amdgcn_rcpf((float)L.kw); const int khw = L.kh * L.kw;      // (1-ulp reciprocals: exact for these ranges, fdiv_of in common.h)
         for (int k = tid; k < L.K; k += 256) { const int ci = (int)(((float)k + 0.5f) * r_khw); const int rem = k - ci * khw; const int ky = (int)(((float)rem + 0.5f) * r_kw); koff_lds[k] = (ci * L.ih + ky) * L.iw + (rem - ky * L.kw); }
     }
     int pi = 0;
@@ -1362,8 +1363,9 @@ template <bool WIDE>
 __global__ __launch_bounds__(256) void k_dx_lds(LayerDev L, GDxArgs A, int B, int S, int kc, int gx, GemmTail tail) {
     karg_warm<sizeof(LayerDev) + sizeof(GDxArgs) + 32 + sizeof(GemmTail)>();
     GEMM_TAIL_PROLOGUE(tail, bid, main_blocks)
-    if constexpr (WIDE) dx_lds_body_wide(L, A, B, S, kc, bid % gx, gx, bid / gx);
-    else dx_units_body<U_FT>(L, A, B, S, kc, bid % gx, gx, bid / gx);
+    int bq, br; fdiv_qr(bid, fdiv_of(gx), bq, br);
+    if constexpr (WIDE) dx_lds_body_wide(L, A, B, S, kc, br, gx, bq);
+    else dx_units_body<U_FT>(L, A, B, S, kc, br, gx, bq);
 }
 // dW and dX of one layer are independent given dpre: ONE launch runs both (blocks [0, dw_blocks) do dW, the rest dX), which
 // saves a dispatch and lets the latency-bound dX workgroups share the machine with the dW ones.
@@ -1383,8 +1385,8 @@ __global__ __launch_bounds__(256) void k_dwdx_lds(LayerDev Lw, GDwProbs pr, int 
     const int dx_blocks = (int)gridDim.x - pre_ - ntail - dw_blocks;
     if (bid < dx_blocks) {
         if (probe & 8) {}      // timing probe: dX workgroups return at once
-        else if constexpr (WIDE) dx_lds_body_wide(Lx, A, B, Sx, kcx, bid % dx_gx, dx_gx, bid / dx_gx);
-        else dx_units_body<U_FT>(Lx, A, B, Sx, kcx, bid % dx_gx, dx_gx, bid / dx_gx, KTRACE_REC());
+        else if constexpr (WIDE) { int bq, br; fdiv_qr(bid, fdiv_of(dx_gx), bq, br); dx_lds_body_wide(Lx, A, B, Sx, kcx, br, dx_gx, bq); }
+        else { int bq, br; fdiv_qr(bid, fdiv_of(dx_gx), bq, br); dx_units_body<U_FT>(Lx, A, B, Sx, kcx, br, dx_gx, bq, KTRACE_REC()); }
         KTRACE_SET(3, 1);
     }
     else if (bid < dx_blocks + ntail) { gemm_tail_run(tail, (unsigned)(bid - dx_blocks)); KTRACE_SET(3, 2); }

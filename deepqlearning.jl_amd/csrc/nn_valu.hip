@@ -38,13 +38,17 @@ __global__ __launch_bounds__(256) void k_reduce_multi(const RSeg* __restrict__ s
         const float t2 = slab_sum(R.part + (size_t)R.S * R.elems + e, (size_t)R.elems, R.S2);
         tot = tot + t2;
     }
-    if (R.mode == 0) tot = act_f(tot + R.bias[e / R.per_n], R.act);
+    // element-index decodes: through reciprocals while the segment is small (fdiv_*, common.h: exact below 2^21 -- the 64-bit divisions written here before cost
+    // ~100 instructions each, three per element of a launch that is all prologue), plain 64-bit division otherwise
+    const bool small = R.elems < (1ull << 21);
+    auto dv = [&](size_t x, int d, size_t& q, size_t& r) { if (small) { int qi, ri; fdiv_qr((int)x, fdiv_of(d), qi, ri); q = (size_t)qi; r = (size_t)ri; } else { q = x / (size_t)d; r = x - q * (size_t)d; } };
+    if (R.mode == 0) { size_t q, r; dv(e, R.per_n, q, r); tot = act_f(tot + R.bias[q], R.act); }
     else if (R.mode == 1) {
         if (R.addend) tot = R.addend[e] + tot;
-        if (R.ysrc) tot = dact_f(tot, R.ysrc[(e / R.B) * R.ldy + (e % R.B)], R.act);
+        if (R.ysrc) { size_t q, r; dv(e, R.B, q, r); tot = dact_f(tot, R.ysrc[q * R.ldy + r], R.act); }
     }
     R.out[e] = tot;
-    if (R.outT) { const size_t feat = e / R.ncolsT, col = e % R.ncolsT; R.outT[col * (R.elems / R.ncolsT) + feat] = tot; }
+    if (R.outT) { size_t feat, col; dv(e, R.ncolsT, feat, col); size_t nf, rr; dv((size_t)R.elems, R.ncolsT, nf, rr); R.outT[col * nf + feat] = tot; }
 }
 void launch_reduce_multi(hipStream_t st, const RSeg* segs_dev, int nseg, unsigned total_blocks) {
     hipLaunchKernelGGL(k_reduce_multi, dim3(total_blocks), dim3(256), 0, st, segs_dev, nseg);
