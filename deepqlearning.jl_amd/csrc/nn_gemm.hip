@@ -1426,7 +1426,10 @@ void launch_gemm_dwdx(hipStream_t st, const LayerDev& Lw, int nprob, const float
     const int fw = pj == 3 ? 16 * U_FT : 32;
     const int gx = dense ? ((Lx.K + fw - 1) / fw) * (pj == 2 ? Sx : 1) : (Lx.cin / fw) * Lx.ih * Lx.iw;
     const size_t lds_w = (size_t)(2 * 64 * W_ST + 2 * 16 * NT * W_ST) * 4, lds_x = dx_lds_bytes(pj);
-    const size_t lds = lds_w > lds_x ? lds_w : lds_x;
+    size_t lds = lds_w > lds_x ? lds_w : lds_x;
+    // the dense pair at B >= 512 runs better with TWO workgroups per CU than with the three its 46.6 KB allow (measured r04, config 5, same box, alternating: 81.7 -> 76.8 us;
+    // the conv launches lose 8-11 % the same way and keep three): the request is raised past a third of the CU's LDS
+    if (pj == 2 && dense && B >= 512 && lds < (size_t)(160 * 1024 / 3 + 1024)) lds = (size_t)(160 * 1024 / 3 + 1024);
     tail.lds_bytes = (unsigned)lds; tail.probe = HOST_PROBE();
     const int grid = dw_blocks + gx * (B / dx_cols(pj)) + (int)gemm_tail_blocks(tail);
 #define DWDX_LAUNCH(NTv, Wv) hipLaunchKernelGGL((k_dwdx_lds<NTv, Wv>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, tail)
