@@ -649,7 +649,9 @@ void launch_convert_params(hipStream_t st, const LayerDev* layers_dev, int nl, c
 bool gemm_fwd_eligible(const LayerDev& L, int nprob, const int* ldx, const int* col0, const int* ncols);
 int gemm_set_ktrace(unsigned long long* p);   // debug (-DDQN_KTRACE builds): per-workgroup timestamps of the LDS-tiled kernels (nullptr = off); -1 = not a trace build
 // LayerDev::opt bits
-#define DQN_LOPT_FWD_M32 1      /* DQN_FWD_M32: 32x32x2 MFMA blocks for the 64-channel forward tiles (measured no faster; kept parity-tested) */
+#define DQN_LOPT_FWD_M32 1      /* DQN_FWD_M32=1: 32x32x2 MFMA blocks for the 64-channel forward tiles in EVERY launch (default: only the large ones, >= 1024 workgroups, where they measure
+                                   conv3 forward 58.3 -> 55.7 us at config 5 since the r04 instruction diet; no faster before it) */
+#define DQN_LOPT_NO_FWD_M32 32  /* DQN_FWD_M32=0: never */
 #define DQN_LOPT_FWD_DMA 2      /* DQN_FWD_DMA: LDS-DMA operand loads for the large forward launches with 64-channel tiles (measured no faster) */
 #define DQN_LOPT_NO_DX_WIDE 4   /* DQN_NO_DX_WIDE: large batches take the 32-sample dX tiles instead of the 128-sample ones */
 #define DQN_LOPT_NO_FWD_WRES 8  /* DQN_NO_FWD_WRES: large-batch forwards of a narrow layer take the per-tile kernel instead of the weights-resident persistent one (A/B) */

@@ -25,7 +25,7 @@ struct ProfEntry { const char* name; hipEvent_t a, b; };
 struct EngineOpts {
     int adam_mode = 0;            // DQN_ADAM_MODE=1: Adam jobs carried by the backward launches (measured slower; parity-tested)
     int no_tiny = 0;              // DQN_NO_TINY: networks that fit in LDS take the multi-launch program
-    int fwd_m32 = 0, fwd_dma = 0, no_dx_wide = 0, no_fwd_wres = 0;      // DQN_FWD_M32 / DQN_FWD_DMA / DQN_NO_DX_WIDE / DQN_NO_FWD_WRES -> LayerDev::opt bits
+    int fwd_m32 = -1 /* -1: large launches only */, fwd_dma = 0, no_dx_wide = 0, no_fwd_wres = 0;      // DQN_FWD_M32 / DQN_FWD_DMA / DQN_NO_DX_WIDE / DQN_NO_FWD_WRES -> LayerDev::opt bits
     int mid_group = 4, mid_big = 16;                   // DQN_MID_GROUP / DQN_MID_BIG: middle steps of dqn_train_steps per graph (mid_big also needs mid_group > 1)
     int sim_world = 0;            // DQN_SIM_WORLD=k: one process plays k ranks (tests)
     int no_graph_upload = 0;      // DQN_NO_GRAPH_UPLOAD

@@ -738,7 +738,8 @@ void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* 
         hipLaunchKernelGGL(k_fwd_dma, dim3(end), dim3(256), ldsd, st, L, pr, S, kc);
         return;
     }
-    const int m32 = (L.opt & DQN_LOPT_FWD_M32) ? 1 : 0;      // experiment (DQN_FWD_M32=1 at dqn_engine_create): 32x32x2 MFMA blocks for the 64-channel tiles
+    // 32x32x2 MFMA blocks for the 64-channel tiles: large launches by default (r04), everywhere with DQN_FWD_M32=1, nowhere with =0 (read at dqn_engine_create)
+    const int m32 = (L.opt & DQN_LOPT_NO_FWD_M32) ? 0 : ((L.opt & DQN_LOPT_FWD_M32) || k16) ? 1 : 0;
     if (m32 && NT == 4 && !L.xu8) { if (k16) hipLaunchKernelGGL((k_fwd_lds<4, false, 16, true>), dim3(end), dim3(256), lds, st, L, pr, S, kc); else hipLaunchKernelGGL((k_fwd_lds<4, false, F_KT_DEF, true>), dim3(end), dim3(256), lds, st, L, pr, S, kc); }
     else if (L.xu8) { if (k16) FWD_PICK(true, 16); else FWD_PICK(true, F_KT_DEF); }
     else { if (k16) FWD_PICK(false, 16); else FWD_PICK(false, F_KT_DEF); }

@@ -352,16 +352,17 @@ def test_single_launch_step_edge_cases(pkg, netf, B, cap, kw):
     assert [n for n, _ in gpu.profile_step()] == ["tiny_step"]
 
 
-@pytest.mark.parametrize("knob", ["DQN_FWD_M32", "DQN_FWD_DMA"])
-def test_forward_32x32_mfma_blocks_bit_exact(pkg, monkeypatch, knob):
-    """DQN_FWD_M32=1 (read at dqn_engine_create): the forward launches with 64-channel tiles use 2 x 2 blocks of v_mfma_f32_32x32x2_f32 per workgroup instead of
-    four 16x16x4 accumulators per wave.  The 32x32x2 instruction accumulates its two k steps in order like the 16x16x4 one accumulates its four: the same
-    k-ascending chain, bit-identical to the twin (measured: no faster, hence opt-in).
+@pytest.mark.parametrize("knob,val,B", [("DQN_FWD_M32", "1", 128), ("DQN_FWD_M32", "0", 384), ("DQN_FWD_DMA", "1", 384)])
+def test_forward_32x32_mfma_blocks_bit_exact(pkg, monkeypatch, knob, val, B):
+    """DQN_FWD_M32 (read at dqn_engine_create): the forward launches with 64-channel tiles use 2 x 2 blocks of v_mfma_f32_32x32x2_f32 per workgroup instead of
+    four 16x16x4 accumulators per wave -- by default in the large launches (>= 1024 workgroups, r04: B = 384 here and in the config-5 tests), with =1 in every
+    launch (B = 128), with =0 in none (the 16x16x4 form of the large launches stays under test).  The 32x32x2 instruction accumulates its two k steps in order like
+    the 16x16x4 one accumulates its four: the same k-ascending chain, bit-identical to the twin (DESIGN.md sections 6.6, 6.10).
     DQN_FWD_DMA=1: the large forward launches with 64-channel tiles fetch their operands with global_load_lds_dwordx4 into unpadded, globally swizzled
     tiles (k_fwd_dma; engaged from 1024 workgroups: B = 384 here, 1458 for the 4x4 conv layer) -- same chains, same verdict."""
-    monkeypatch.setenv(knob, "1")
+    monkeypatch.setenv(knob, val)
     net = nature_dueling()
-    gpu, cpu, _ = make_pair(pkg, net, 384 if knob == "DQN_FWD_DMA" else 128, cap=512, learning_rate=1e-3, gamma=0.99)
+    gpu, cpu, _ = make_pair(pkg, net, B, cap=512, learning_rate=1e-3, gamma=0.99)
     monkeypatch.delenv(knob)
     fill((gpu, cpu), net, 400, seed=21)
     set_same_params((gpu, cpu), net, seed=22)
