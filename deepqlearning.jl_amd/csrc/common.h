@@ -121,7 +121,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t
 // logical workgroups == a contiguous band of output positions, whose activations then stay in that XCD's private 4 MB L2
 // instead of being re-fetched over the fabric by all eight.
 // x / d and x % d for the small non-negative ints of the workgroup prologues (tile / position / tap decodes): floor((x + 0.5) * (1 / d)) is exact while
-// x < 2^21 even with the 1-ulp hardware reciprocal (error x / d * 2^-22 against the 0.5 / d margin).  An integer division compiles to ~25-40 instructions; a
+// x < 2^21 even with the 1-ulp hardware reciprocal (error x / d * 2^-22 against the 0.5 / d margin; tests/test_abi_cpu.py checks every multiple +-1 for the divisors in use).  An integer division compiles to ~25-40 instructions; a
 // forward workgroup issued ~500 instructions before its first operand load, most of them these (r04), and at B = 32 a wave is alone on its SIMD and pays each.
 struct FDiv { int d; float r; };
 __device__ __forceinline__ FDiv fdiv_of(int d) { FDiv f; f.d = d; f.r = __builtin_amdgcn_rcpf((float)d); return f; }

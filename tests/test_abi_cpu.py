@@ -119,3 +119,17 @@ def test_u8_unit_two_operation_form_equals_the_division_for_every_byte():
     assert np.array_equal(q.astype(np.float32).astype(np.float64), q)          # the product is exact in fp32
     y = (b * r_lo + q).astype(np.float32)                                      # exact in fp64, rounded once == fmaf
     assert np.array_equal(y, ref)
+
+
+def test_reciprocal_division_of_the_prologues_is_exact_below_2_to_21():
+    """common.h fdiv_q: floor((x + 0.5) * rcp(d)) == x // d for 0 <= x < 2^21 and the divisors the kernels use (tile counts, kernel extents, strides, widths),
+    with the reciprocal off by up to one ulp either way (v_rcp_f32 is a 1-ulp instruction).  Checked at the risky points: x = k d - 1, k d, k d + 1."""
+    f32 = np.float32
+    for d in list(range(1, 130)) + [144, 196, 256, 400, 441, 512, 784, 1000, 1536, 2401, 3136, 4096, 7056, 65535]:
+        k = np.arange(0, (1 << 21) // d + 1, dtype=np.int64)
+        x = np.unique(np.concatenate([k * d - 1, k * d, k * d + 1]))
+        x = x[(x >= 0) & (x < (1 << 21))]
+        r0 = f32(1.0) / f32(d)
+        for r in (np.nextafter(r0, f32(0)), r0, np.nextafter(r0, f32(2))):
+            q = ((x.astype(np.float32) + f32(0.5)) * r).astype(np.int64)      # float32 arithmetic, truncation == floor for non-negative values
+            assert np.array_equal(q, x // d), d
