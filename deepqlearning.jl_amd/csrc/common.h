@@ -656,7 +656,8 @@ int gemm_set_ktrace(unsigned long long* p);   // debug (-DDQN_KTRACE builds): pe
 #define DQN_LOPT_NO_DX_WIDE 4   /* DQN_NO_DX_WIDE: large batches take the 32-sample dX tiles instead of the 128-sample ones */
 #define DQN_LOPT_NO_FWD_WRES 8  /* DQN_NO_FWD_WRES: large-batch forwards of a narrow layer take the per-tile kernel instead of the weights-resident persistent one (A/B) */
 void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* const* W, const float* const* bias, const float* const* X,
-                     const int* ldx, const int* col0, const int* ncols, float* const* out /* Y, or split-K partial slabs */);
+                     const int* ldx, const int* col0, const int* ncols, float* const* out /* Y, or split-K partial slabs */,
+                     float* const* outT = nullptr /* optional, dense unsplit layers: a TRANSPOSED copy [column][feature] of Y per problem (k_head_td's input columns) */);
 
 // ---- DRQN (drqn.hip): EpisodeReplayBuffer gather, LSTM recurrence / BPTT steps, recurrent TD
 struct LstmSeq {          // one sequence set advancing one time step: B columns starting at column c0 (+ t*B) of [*][ld] arrays

@@ -195,9 +195,17 @@ int build_program(dqn_engine* e) {
         std::vector<bool> done(pr.size(), false);
         auto emit_gemm = [&](const std::vector<int>& ids, const char* name) {
             const LayerDev L = LV[pr[ids[0]].l]; const int n = (int)ids.size();
-            struct A { const float *W[4], *bias[4], *X[4]; int ldx[4], col0[4], ncols[4]; float* out[4]; } a;
-            for (int i = 0; i < n; i++) { const Prob& q = pr[ids[i]]; const LayerDev& Lq = LV[q.l]; a.W[i] = q.P + Lq.w_off; a.bias[i] = q.P + Lq.b_off; a.X[i] = q.X; a.ldx[i] = q.ldx; a.col0[i] = q.col0; a.ncols[i] = q.ncols; a.out[i] = q.S > 1 ? q.part : q.Y; }
-            e->prog.push_back({name, [=](dqn_engine* en) { launch_gemm_fwd(en->stream, L, n, a.W, a.bias, a.X, a.ldx, a.col0, a.ncols, a.out); }});
+            struct A { const float *W[4], *bias[4], *X[4]; int ldx[4], col0[4], ncols[4]; float* out[4]; float* outT[4]; } a;
+            bool any_t = false;
+            for (int i = 0; i < n; i++) {
+                const Prob& q = pr[ids[i]]; const LayerDev& Lq = LV[q.l]; a.W[i] = q.P + Lq.w_off; a.bias[i] = q.P + Lq.b_off; a.X[i] = q.X; a.ldx[i] = q.ldx; a.col0[i] = q.col0; a.ncols[i] = q.ncols; a.out[i] = q.S > 1 ? q.part : q.Y;
+                // an UNSPLIT dense layer that feeds k_head_td writes the transposed copy of its output itself (r04: without it the head kernel read its columns one 64-byte
+                // sector per element at B = 512 -- 11 us of its 25); split-K layers get theirs from the reduce launch below
+                a.outT[i] = nullptr;
+                if (wantT[q.l] && q.S == 1 && Lq.kind == DQN_LAYER_DENSE) { a.outT[i] = actT[q.l][q.net] = palloc(e, (size_t)Lq.out_feat * q.ncols); any_t = true; }
+            }
+            if (any_t) for (int i = 0; i < n; i++) if (!a.outT[i]) { any_t = false; for (int j = 0; j < n; j++) { if (a.outT[j]) actT[pr[ids[j]].l][pr[ids[j]].net] = nullptr; a.outT[j] = nullptr; } break; }      // all problems of the launch or none
+            e->prog.push_back({name, [=](dqn_engine* en) { launch_gemm_fwd(en->stream, L, n, a.W, a.bias, a.X, a.ldx, a.col0, a.ncols, a.out, any_t ? a.outT : nullptr); }});
             for (int id : ids) done[id] = true;
         };
         if (mf) {

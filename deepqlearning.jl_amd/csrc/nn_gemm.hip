@@ -96,7 +96,7 @@ __device__ __forceinline__ void gemm_tail_run(const GemmTail& tail, unsigned blk
 // workgroup tile = 4 M-tiles (16 columns each, drawn from consecutive (pos, column-tile) pairs; wave w owns M-tile w)
 //                  x NT N-tiles (16*NT output channels), K walked in tiles of 32.
 // =====================================================================================================================
-struct GFwdProb { const float* W; const float* bias; const float* X; int ldx, col0, ncols; float* out; int mtiles, mgroups; };
+struct GFwdProb { const float* W; const float* bias; const float* X; int ldx, col0, ncols; float* out; int mtiles, mgroups; float* outT; };      // outT: optional transposed copy [column][N] (dense, one chunk)
 struct GFwdProbs { GFwdProb p[4]; int wg_end[4]; };   // up to 4 problems of one geometry per launch: {val,adv} x {online,target}
 
 #ifndef DQN_F_KT
@@ -346,6 +346,10 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
             else { v.x = act_f(v.x + bias, L.act); v.y = act_f(v.y + bias, L.act); v.z = act_f(v.z + bias, L.act); v.w = act_f(v.w + bias, L.act); }
         }
         *reinterpret_cast<f32x4*>(p.out + (size_t)s * per_s + ((size_t)n * L.npos + pos) * p.ncols + ct * 16 + 4 * kq) = v;
+        if (p.outT) {      // (dense, one chunk) the same activations with a batch column's features contiguous: k_head_td reads its columns as runs instead of one 64-byte sector per element
+            float* o = p.outT + (size_t)(ct * 16 + 4 * kq) * L.N + n;
+            o[0] = v.x; o[L.N] = v.y; o[2 * (size_t)L.N] = v.z; o[3 * (size_t)L.N] = v.w;
+        }
     }
     KTRACE(7); KTRACE_END();
 }
@@ -685,17 +689,18 @@ bool gemm_fwd_eligible(const LayerDev& L, int nprob, const int* ldx, const int* 
     return true;
 }
 void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* const* W, const float* const* bias, const float* const* X,
-                     const int* ldx, const int* col0, const int* ncols, float* const* out) {
+                     const int* ldx, const int* col0, const int* ncols, float* const* out, float* const* outT) {
     const int S = dqn_nchunks(L.K, L.fwd_kc), kc = dqn_chunk_len(L.K, L.fwd_kc);
     GFwdProbs pr; long mg_total = 0;
     for (int i = 0; i < 4; i++) {
         const int j = i < nprob ? i : 0;
         GFwdProb& q = pr.p[i];
-        q.W = W[j]; q.bias = bias[j]; q.X = X[j]; q.ldx = ldx[j]; q.col0 = col0[j]; q.ncols = ncols[j]; q.out = out[j];
+        q.W = W[j]; q.bias = bias[j]; q.X = X[j]; q.ldx = ldx[j]; q.col0 = col0[j]; q.ncols = ncols[j]; q.out = out[j]; q.outT = (outT && S == 1 && L.kind == DQN_LAYER_DENSE) ? outT[j] : nullptr;
         q.mtiles = L.npos * (ncols[j] / 16); q.mgroups = (q.mtiles + 3) / 4;
         if (i < nprob) mg_total += q.mgroups;
     }
-    if (fwd_wres_ok(L, mg_total, S)) {
+    const bool want_t = pr.p[0].outT != nullptr;
+    if (!want_t && fwd_wres_ok(L, mg_total, S)) {
         // M-tiles per wave: 4 (64-column row slices: a quarter of the L1 line visits, weight fragments shared by four accumulators; two workgroups per CU) when every
         // problem's column count allows and the LDS holds it, else 2, else 1
         int MT = L.xu8 ? 4 : 2;                          // (float operands: 4 would need > 256 registers)
@@ -733,13 +738,13 @@ void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* 
     const size_t lds = (size_t)(2 * kt * F_SA + 2 * kt * SB) * 4 + (L.kind == DQN_LAYER_CONV ? (size_t)L.K * 4 : 0);
 #define FWD_LAUNCH(NT_, U8_, KT_) hipLaunchKernelGGL((k_fwd_lds<NT_, U8_, KT_>), dim3(end), dim3(256), lds, st, L, pr, S, kc)
 #define FWD_PICK(U8_, KT_) do { if (NT == 4) FWD_LAUNCH(4, U8_, KT_); else if (NT == 2) FWD_LAUNCH(2, U8_, KT_); else FWD_LAUNCH(1, U8_, KT_); } while (0)
-    if ((L.opt & DQN_LOPT_FWD_DMA) && NT == 4 && !L.xu8 && L.K % DMA_KT == 0 && (S == 1 || kc % DMA_KT == 0) && end >= kt16_min) {
+    if ((L.opt & DQN_LOPT_FWD_DMA) && !want_t && NT == 4 && !L.xu8 && L.K % DMA_KT == 0 && (S == 1 || kc % DMA_KT == 0) && end >= kt16_min) {
         const size_t ldsd = (size_t)(2 * DMA_D * DMA_KT * 64) * 4 + (L.kind == DQN_LAYER_CONV ? (size_t)L.K * 4 : 0);
         hipLaunchKernelGGL(k_fwd_dma, dim3(end), dim3(256), ldsd, st, L, pr, S, kc);
         return;
     }
     // 32x32x2 MFMA blocks for the 64-channel tiles: large launches by default (r04), everywhere with DQN_FWD_M32=1, nowhere with =0 (read at dqn_engine_create)
-    const int m32 = (L.opt & DQN_LOPT_NO_FWD_M32) ? 0 : ((L.opt & DQN_LOPT_FWD_M32) || k16) ? 1 : 0;
+    const int m32 = ((L.opt & DQN_LOPT_NO_FWD_M32) || want_t) ? 0 : ((L.opt & DQN_LOPT_FWD_M32) || k16) ? 1 : 0;
     if (m32 && NT == 4 && !L.xu8) { if (k16) hipLaunchKernelGGL((k_fwd_lds<4, false, 16, true>), dim3(end), dim3(256), lds, st, L, pr, S, kc); else hipLaunchKernelGGL((k_fwd_lds<4, false, F_KT_DEF, true>), dim3(end), dim3(256), lds, st, L, pr, S, kc); }
     else if (L.xu8) { if (k16) FWD_PICK(true, 16); else FWD_PICK(true, F_KT_DEF); }
     else { if (k16) FWD_PICK(false, 16); else FWD_PICK(false, F_KT_DEF); }
