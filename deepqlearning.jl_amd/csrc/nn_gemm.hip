@@ -128,13 +128,6 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     const GFwdProb& p = pr.p[pi];
     constexpr unsigned ESZ = XU8 ? 1u : 4u;            // bytes per arena element
     const unsigned ldb = (unsigned)p.ldx * ESZ;        // bytes per input row
-    if (conv) {
-        // BYTE offset of contraction index k = (ci, ky, kx)'s input row, tabulated once per workgroup.  The two divisions go through reciprocals
-        // (floor((x + 0.5) / d) is exact for these small ints): with integer divisions this table cost 0.85-2.0 us at the head of every conv
-        // launch (ktrace, r02) before the first operand load could be issued.
-        const float r_khw = __builtin_amdgcn_rcpf((float)(L.kh * L.kw)), r_kw = __builtin_amdgcn_rcpf((float)L.kw); const int khw = L.kh * L.kw;      // (1-ulp reciprocals: exact for these ranges, fdiv_of in common.h)
-        for (int k = tid; k < L.K; k += 256) { const int ci = (int)(((float)k + 0.5f) * r_khw); const int rem = k - ci * khw; const int ky = (int)(((float)rem + 0.5f) * r_kw); koff_lds[k] = (int)((unsigned)((ci * L.ih + ky) * L.iw + (rem - ky * L.kw)) * ldb); }
-    }
     const int wg_begin = pi == 0 ? 0 : pr.wg_end[pi - 1];
     int w = xcd_remap(blockIdx.x - wg_begin, pr.wg_end[pi] - wg_begin);
     const int ngroups = L.N / NW;                      // (NW is a power of two; the decodes below go through reciprocals: fdiv_*, common.h)
@@ -163,8 +156,6 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     constexpr int BQ = (F_KT * BF4 + 255) / 256;       // float4 per thread (1 or 2)
     const float* Wp = p.W + n0;
 
-    if (conv) __syncthreads();                         // koff table ready
-    KTRACE(3);
     // Register staging with HAND-COUNTED waits.  hipcc's waitcnt pass drains vmcnt(0) before every prefetch issue in a
     // pipelined loop with conditional loads (seen in the ISA), which exposes the full L2/HBM latency once per K tile.
     // So the staging loads are inline asm (invisible to that pass), ALWAYS issued (tile index clamped, so the number of
@@ -188,11 +179,26 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     // at the last): no LDS round trip -- and no drain of the fragment reads in flight -- in front of a load issue
     // (kn holds the RAW table value until the call that uses it: the empty asm pins the wait for the table read there, a whole tile after its issue -- with the
     // add written next to the read the compiler waits for the LDS round trip on the spot, once per tile of a lone wave)
+    // The FIRST tile's row offsets are computed by each thread for itself (two values), its loads go out, and only then is the table built: the table's ~100 instructions
+    // and its barrier ride under the first tile's global latency instead of standing in front of it (ktrace r04, B = 32: 1400-1640 cycles from entry to the table, 1700-1950
+    // more to the first tile in LDS, of workgroup lifetimes of 16-18 k cycles).
     unsigned kn[AQ];
+    {
+        const FDiv fkhw = fdiv_of(conv ? L.kh * L.kw : 1), fkw = fdiv_of(conv ? L.kw : 1);
 #pragma unroll
-    for (int q = 0; q < AQ; q++) kn[q] = conv ? (unsigned)koff_lds[k0 + arow + 16 * q] : a_den[q] - a_fix;
-    auto gload = [&](int kt, Stage& r) {
-        kt = min(kt, nkt - 1);
+        for (int q = 0; q < AQ; q++) {
+            if (conv) { const int k = k0 + arow + 16 * q; int ci, rem, ky, kx; fdiv_qr(k, fkhw, ci, rem); fdiv_qr(rem, fkw, ky, kx); kn[q] = (unsigned)((ci * L.ih + ky) * L.iw + kx) * ldb; }
+            else kn[q] = a_den[q] - a_fix;
+        }
+    }
+    auto kn_next = [&](int kt) {                          // (kt already clamped) the NEXT tile's row offsets, from the table
+        if (conv) {
+            const int kbn = k0 + min(kt + 1, nkt - 1) * F_KT;
+#pragma unroll
+            for (int q = 0; q < AQ; q++) kn[q] = (unsigned)koff_lds[kbn + arow + 16 * q];
+        }
+    };
+    auto gissue = [&](int kt, Stage& r) {
         const int kb = k0 + kt * F_KT;
         const unsigned char* pa = conv ? Xbase : Xbase + (size_t)((unsigned)kb * ldb);
 #pragma unroll
@@ -200,11 +206,20 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
         const float* pb = Wp + (size_t)((unsigned)kb * (unsigned)L.N);
 #pragma unroll
         for (int i = 0; i < BQ; i++) r.b[i] = gld(b_fix[i], pb);
+    };
+    auto gload = [&](int kt, Stage& r) { kt = min(kt, nkt - 1); gissue(kt, r); kn_next(kt); };
+    auto gload_first = [&](Stage& r) {
+        gissue(0, r);
         if (conv) {
-            const int kbn = k0 + min(kt + 1, nkt - 1) * F_KT;
-#pragma unroll
-            for (int q = 0; q < AQ; q++) kn[q] = (unsigned)koff_lds[kbn + arow + 16 * q];
+        // BYTE offset of contraction index k = (ci, ky, kx)'s input row, tabulated once per workgroup.  The two divisions go through reciprocals
+        // (floor((x + 0.5) / d) is exact for these small ints): with integer divisions this table cost 0.85-2.0 us at the head of every conv
+        // launch (ktrace, r02) before the first operand load could be issued.
+        const float r_khw = __builtin_amdgcn_rcpf((float)(L.kh * L.kw)), r_kw = __builtin_amdgcn_rcpf((float)L.kw); const int khw = L.kh * L.kw;      // (1-ulp reciprocals: exact for these ranges, fdiv_of in common.h)
+        for (int k = tid; k < L.K; k += 256) { const int ci = (int)(((float)k + 0.5f) * r_khw); const int rem = k - ci * khw; const int ky = (int)(((float)rem + 0.5f) * r_kw); koff_lds[k] = (int)((unsigned)((ci * L.ih + ky) * L.iw + (rem - ky * L.kw)) * ldb); }
         }
+        if (conv) __syncthreads();                     // koff table ready
+        KTRACE(3);
+        kn_next(0);
     };
     auto lstore = [&](int buf, const Stage& r) {
 #pragma unroll
@@ -274,7 +289,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
             for (int st = s0; st < s1; st++) c16 = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[st], f.b[st], c16, 0, 0, 0);
         };
         Stage r0, r1; F32 g0, g1;
-        gload(0, r0); STAGE_WAIT(0, r0); lstore(0, r0); __syncthreads();
+        gload_first(r0); STAGE_WAIT(0, r0); lstore(0, r0); __syncthreads();
         fread32(0, g0);
         gload(1, r0);
         for (int kt = 0; kt < nkt; kt += 2) {
@@ -310,7 +325,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     }
     constexpr int HS = F_KT / 8;                       // MFMA steps per half tile
     Stage r0, r1; Frag f0, f1;
-    gload(0, r0); STAGE_WAIT(0, r0); lstore(0, r0); __syncthreads();
+    gload_first(r0); STAGE_WAIT(0, r0); lstore(0, r0); __syncthreads();
     KTRACE(4);
     fread(0, f0);
     gload(1, r0);

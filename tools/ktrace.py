@@ -23,8 +23,10 @@ eng.train_step()
 n = 1 + 8 * 65536
 buf = np.zeros(n, np.uint64)
 assert f(eng._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), n) == 0
-cnt = int(buf[0]); rec = buf[1:1 + 8 * cnt].reshape(cnt, 8).astype(np.int64)
-print("records", cnt)
+cnt = int(buf[0]); raw = buf[1:1 + 8 * cnt].reshape(cnt, 8)
+rec = raw.astype(np.int64); rec[:, 0] &= 0xffffffff; rec[:, 1] &= 0xffffffff      # words 0 / 1 carry s_memrealtime in their upper halves (r03); low halves: grid size, block id
+rec = rec[rec[:, 3] > 16]                                                            # forward records only: the backward kernels put a ROLE (0..3) in word 3 (tools/ktrace_bwd.py reads those)
+print("records", cnt, "forward records", len(rec))
 names = ["entry->tables", "tables->tile0", "tile0->loop end", "loop end->combined", "combined->stores"]
 for grid in sorted(set(rec[:, 0])):
     r = rec[rec[:, 0] == grid]
