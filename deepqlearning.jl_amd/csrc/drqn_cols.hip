@@ -66,8 +66,10 @@ __global__ __launch_bounds__(1024) void k_drqn_cols(const DrqnColsArgs A, const 
     float* TC = GD + T * cg * N;                // [T][cg][H]         tanh(c_t)
     float* CP = TC + T * per;                   // [T][cg][H]         c_{t-1}
     float* QO = CP + T * per;                   // [nset][T][cg][no]  head outputs (advantage / plain Q first, the value stream last)
-    float* DQ = QO + nset * T * cg * no;        // [T][cg][no]        dpre of the heads
-    float* dH = DQ + T * cg * no;               // [T][cg][H]
+    // (QO and DQ are the only arrays whose extent need not be a multiple of 4 floats -- odd T x odd n_out: everything behind them is read 16 bytes at a time (WhP by BPTT), so
+    // both extents are rounded up; a misaligned ds_read_b128 is replayed at 64 cycles or worse, MI355X guide / Guideline 17)
+    float* DQ = QO + ((nset * T * cg * no + 3) & ~3);        // [T][cg][no]        dpre of the heads
+    float* dH = DQ + ((T * cg * no + 3) & ~3);               // [T][cg][H]
     float* dhn = dH + T * per;                  // [cg][H]
     float* dcn = dhn + per;                     // [cg][H]
     float* WhP = dcn + per;                     // [H][4H + 4]        online Wh, padded rows (BPTT reads row u 16 B at a time: stride 4H would put every lane on one bank)
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(1024) void k_drqn_cols(const DrqnColsArgs A, const 
 
 static size_t drqn_cols_lds_floats(const DrqnColsArgs& a) {
     const size_t T = a.T, cg = a.cg, H = a.H, N = 4 * H, per = H * cg, Ep = (a.E + 3) & ~3, no = a.nA + (a.dueling ? 1 : 0), ns = a.nset;
-    return 2 * (size_t)a.Pint + 2 * T * cg * Ep + 4 * T * cg + ns * T * per + ns * per + ns * 4 * per + T * cg * N + 2 * T * per + ns * T * cg * no + T * cg * no + T * per + 2 * per + H * (N + 4) + ns * ((T * cg + 15) / 16 * 16) * N;
+    return 2 * (size_t)a.Pint + 2 * T * cg * Ep + 4 * T * cg + ns * T * per + ns * per + ns * 4 * per + T * cg * N + 2 * T * per + ((ns * T * cg * no + 3) & ~(size_t)3) + ((T * cg * no + 3) & ~(size_t)3) + T * per + 2 * per + H * (N + 4) + ns * ((T * cg + 15) / 16 * 16) * N;
 }
 int launch_drqn_cols(hipStream_t st, const DrqnColsArgs& a, int slot) {
     const size_t lds = drqn_cols_lds_floats(a) * sizeof(float);

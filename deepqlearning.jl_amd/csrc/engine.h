@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
+#include <time.h>
 #include <algorithm>
 #include <functional>
 #include <string>
@@ -41,7 +42,7 @@ struct dqn_engine {
     EngineOpts opt;
     int device = 0; hipStream_t stream = nullptr, stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream3 = nullptr; hipEvent_t ev_xa = nullptr, ev_xb = nullptr, ev_xc = nullptr;      // replicas: the exchange runs on its own stream (dp_overlap)
-    int nl = 0; LayerDev L[DQN_MAX_LAYERS]; LayerDev* L_dev = nullptr;
+    int nl = 0; LayerDev L[DQN_MAX_LAYERS]; LayerDev* L_dev = nullptr; bool plan_defaulted = false;      // plan == NULL at dqn_engine_create (dqn_comm_init may re-derive it for replicas)
     dqn_hparams hp; int B = 0, nA = 0, E = 0, ncon = 0;
     int last_base = -1, last_val = -1, last_adv = -1;
     size_t P = 0, Pint = 0;   // external (Flux.params) and internal (16-B aligned arrays) parameter counts
@@ -76,6 +77,7 @@ struct dqn_engine {
     bool dp_gather = false, dp_pack_folds = false, dp_adam_folds = false; AdamSegs dp_adam_segs; int sim_world = 0; float *dp_send = nullptr, *dp_recv = nullptr; size_t dp_count = 0;
     // dp_overlap: the block is exchanged in TWO collectives -- [0, dp_count_a): X | dpre of the wide dense layers, final right after the head level, gathered (into dp_recv) on
     // stream3 WHILE the conv backward runs; [dp_count_a, dp_count): the small gradients, gathered (into dp_recv_b) after the backward pass
+    long long* sim_idx = nullptr; float* sim_td = nullptr;      // dqn_sim_ranks_step (test hook): per-rank copies of the index lists and TD errors
     bool dp_overlap = false; size_t dp_count_a = 0; float* dp_recv_b = nullptr; DpPackArgs dp_pk_a;   // force_comm: run the all-reduce path even at world == 1 (tests)
     // DRQN (recurrence = true): column count per sequence set Bc = T*B (B otherwise); EpisodeReplayBuffer storage; LSTM workspaces
     int Bc = 0, T = 1; long long ep_cap = 0, ep_size = 0, ep_widx = 0, ep_cur_len = 0; std::vector<int> ep_len_host; std::vector<int64_t> ep_perm;
@@ -102,6 +104,7 @@ struct dqn_engine {
     // scalar mailbox (StepMail, common.h): mapped pinned host ring the step's last launch writes (loss, grad_norm) into; pub_issued = publishes enqueued by the host,
     // pub_ctr = publishes executed by the device (the record of ticket t sits in slot t % DQN_MAIL_SLOTS once its seq == t)
     StepMail *mail_host = nullptr, *mail_dev = nullptr; unsigned long long* pub_ctr = nullptr; unsigned long long pub_issued = 0; bool step_publish = false;
+    unsigned long long mail_swept = 0; bool mail_plain = false;      // mail_swept: records [1, mail_swept] have been checked for device-side errors (mail_sweep); mail_plain: the ring is ordinary host memory (mapped allocation refused)
     hipGraphExec_t g_full_pub[2] = {nullptr, nullptr};      // g_full + the publish launch
     hipGraphExec_t g_pgv_pub = nullptr;                      // the LAST step of dqn_train_steps (takes the pre-gathered batch, gathers nothing) + the publish launch
     bool pg_ok = false, step_pregather = false, step_take_pre = false; PreGather pg; long adam_step = -1;

@@ -124,7 +124,7 @@ void read_opts(EngineOpts& o, bool comm_only) {
     o.head_dbg = I("DQN_HEAD_DBG", 0); o.prio_fork = F("DQN_PRIO_FORK"); o.prio_level = I("DQN_PRIO_LEVEL", 0); o.prio_nosplit = F("DQN_PRIO_NOSPLIT"); o.no_pregather = F("DQN_NO_PREGATHER");
     o.lstm_dw_mfma = F("DQN_LSTM_DW_MFMA"); o.probe_no_tg = F("DQN_PROBE_NO_TG"); o.drqn_probe = I("DQN_DRQN_PROBE", 0); o.drqn_stamps = F("DQN_DRQN_STAMPS"); o.tiny_stop = I("DQN_TINY_STOP", 0);
 }
-static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out, const dqn_hparams* hp) {
+static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out, const dqn_hparams* hp, bool allow_cg = true) {
     bool rec = false; for (int i = 0; i < n; i++) rec = rec || L[i].kind == DQN_LAYER_LSTM;
     for (int i = 0; i < n; i++) {
         out[i].fwd_kc = 0;
@@ -161,7 +161,9 @@ static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out, c
         }
     }
     // recurrent networks the fused column-parallel step covers (drqn_cols.hip): dW / db chunks = groups of cg batch columns, one workgroup each
-    const int cg = drqn_fused_cg(L, n, hp->obs_c * hp->obs_h * hp->obs_w, B, hp->trace_length, hp->n_actions, hp->dueling, hp->double_q, hp->recurrence);
+    // (allow_cg = false: replicas -- the fused step has no exchange point between its gradient chunks and Adam, so an engine that is given a communicator takes the
+    // multi-launch recurrent program, whose gradient is materialised before the all-reduce: dqn_comm_init)
+    const int cg = allow_cg ? drqn_fused_cg(L, n, hp->obs_c * hp->obs_h * hp->obs_w, B, hp->trace_length, hp->n_actions, hp->dueling, hp->double_q, hp->recurrence) : 0;
     if (cg) for (int i = 0; i < n; i++) out[i].dw_kc = -cg;
 }
 extern "C" int dqn_plan_version(void) { return DQN_PLAN_VERSION; }
@@ -202,6 +204,7 @@ static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers
     { const int lopt = (e->opt.fwd_m32 > 0 ? DQN_LOPT_FWD_M32 : 0) | (e->opt.fwd_m32 == 0 ? DQN_LOPT_NO_FWD_M32 : 0) | (e->opt.fwd_dma ? DQN_LOPT_FWD_DMA : 0) | (e->opt.no_dx_wide ? DQN_LOPT_NO_DX_WIDE : 0) | (e->opt.no_fwd_wres ? DQN_LOPT_NO_FWD_WRES : 0); for (int i = 0; i < e->nl; i++) e->L[i].opt = lopt; }
     if (e->opt.sim_world >= 1 && !hp->recurrence) { e->sim_world = e->opt.sim_world; e->world = e->opt.sim_world; }   // tests: one process plays k identical ranks
     dqn_layer_plan defp[DQN_MAX_LAYERS];
+    e->plan_defaulted = plan == nullptr;
     if (!plan) { default_plan(e->L, e->nl, e->B, defp, hp); plan = defp; }
     for (int i = 0; i < e->nl; i++) {
         e->L[i].fwd_kc = plan[i].fwd_kc; e->L[i].dx_kc = plan[i].dx_kc; e->L[i].dw_kc = plan[i].dw_kc;
@@ -242,6 +245,7 @@ static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers
         if (hipHostGetDevicePointer((void**)&e->mail_dev, e->mail_host, 0) != hipSuccess) { hipHostFree(e->mail_host); e->mail_host = nullptr; e->mail_dev = nullptr; }
     } else { e->mail_host = nullptr; }
     (void)hipGetLastError();
+    if (!e->mail_host) { e->mail_host = (StepMail*)calloc(DQN_MAIL_SLOTS, sizeof(StepMail)); e->mail_dev = nullptr; e->mail_plain = true; }      // no device-side publish: dqn_train_step_async degrades to synchronous steps recorded by the host
     StepState s0; memset(&s0, 0, sizeof s0); s0.bp[0][0] = s0.bp[1][0] = hp->adam_beta1; s0.bp[0][1] = s0.bp[1][1] = hp->adam_beta2;
     HIPCHK(hipMemcpy(e->state, &s0, sizeof s0, hipMemcpyHostToDevice));
     e->cap = hp->recurrence ? B : hp->buffer_size; while (e->cap2 < e->cap) e->cap2 <<= 1;   // DRQN keeps episodes instead (below)
@@ -323,7 +327,7 @@ extern "C" int dqn_engine_destroy(dqn_engine_t* e) {
     hipFree(e->L_dev); hipFree(e->p_on); hipFree(e->p_tg); hipFree(e->grad); hipFree(e->m); hipFree(e->v); hipFree(e->io_tmp); hipFree(e->state);
     hipFree(e->s_rows); hipFree(e->sp_rows); hipFree(e->ra); hipFree(e->rr); hipFree(e->rdone); hipFree(e->tree);
     if (e->state_host) hipHostFree(e->state_host);
-    if (e->mail_host) hipHostFree(e->mail_host);
+    if (e->mail_host) { if (e->mail_plain) free(e->mail_host); else hipHostFree(e->mail_host); }
     if (e->draw_idx_h) hipHostFree(e->draw_idx_h);
     if (e->draw_start_h) hipHostFree(e->draw_start_h);
     for (int k = 0; k < 4; k++) if (e->draw_ev[k]) hipEventDestroy(e->draw_ev[k]);
@@ -343,7 +347,7 @@ extern "C" int dqn_engine_destroy(dqn_engine_t* e) {
     if (e->stream2) hipStreamDestroy(e->stream2);
     if (e->stream3) hipStreamDestroy(e->stream3);
     if (e->ev_xa) hipEventDestroy(e->ev_xa); if (e->ev_xb) hipEventDestroy(e->ev_xb); if (e->ev_xc) hipEventDestroy(e->ev_xc);
-    hipFree(e->dp_recv_b);
+    hipFree(e->dp_recv_b); hipFree(e->sim_idx); hipFree(e->sim_td);
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_join) hipEventDestroy(e->ev_join);
 
@@ -656,8 +660,11 @@ int run_step(dqn_engine* e, bool sample, bool take_pre, bool pregather) {
         if (!rc && pub) e->pub_issued++;
         return rc;
     }
-    if (e->world > 1 || (e->comm && e->force_comm)) e->step_publish = false;
     if (e->world > 1 || (e->comm && e->force_comm)) {      // data-parallel replicas (also DQN_SIM_WORLD: world = k without a communicator)
+        // scalars on replicas (r05): the publish launch is enqueued EAGERLY behind the step (behind the exchange and the Adam launch that takes grad_norm after it), outside the
+        // step's graphs -- one kernel boundary, no fold launch / D2H copy / stream synchronize, so the drop-in seam costs a replica what it costs a single device
+        const bool pub_dp = e->step_publish && e->mail_dev != nullptr && !e->profiling; e->step_publish = false;
+        auto publish_dp = [&]() { if (!pub_dp) return; launch_publish_scalars(e->stream, e->state, e->gmax_part, (e->gmax_used > 0 && e->gmax_used <= gmax_slots(e->Pint)) ? e->gmax_used : gmax_slots(e->Pint), e->pub_ctr, e->mail_dev); e->pub_issued++; };
         // the pre-gather is rank-local (own replay, own arena), so it works on replicas too: first half without the gather launch, the Adam
         // launch of the second half gathers the next batch.  Every rank takes the same variant (same configuration, same call).
         const bool tp = sample && e->pg_ok && take_pre, pgth = sample && e->pg_ok && pregather;
@@ -666,7 +673,7 @@ int run_step(dqn_engine* e, bool sample, bool take_pre, bool pregather) {
         if (!e->opt.dp_no_one_graph && e->hp.use_graph && !e->profiling && !e->sim_world && e->comm && e->dp_one_state >= 0) {
             hipGraphExec_t& g = e->g_dp_one[(tp ? 2 : 0) + (pgth ? 1 : 0) + 0];
             if (!g && gi == 0) { if (capture(e, sample, PH_DP_ONE, &g)) { e->dp_one_state = -1; g = nullptr; } else e->dp_one_state = 1; }
-            if (g && gi == 0) { HIPCHK(hipGraphLaunch(g, e->stream)); e->step_take_pre = e->step_pregather = false; return 0; }
+            if (g && gi == 0) { HIPCHK(hipGraphLaunch(g, e->stream)); e->step_take_pre = e->step_pregather = false; publish_dp(); return 0; }
         }
         if (e->dp_gather && e->dp_overlap) {
             // three segments: [.. head level, pack of the wide operands] | all-gather A on stream3, concurrently: [rest of the backward pass, pack of the small
@@ -699,6 +706,7 @@ int run_step(dqn_engine* e, bool sample, bool take_pre, bool pregather) {
             }
         } else { enqueue_step(e, sample, PH_PRE); HIPCHK(hipGetLastError()); if (exchange_grads(e)) rc = -1; else { enqueue_step(e, sample, PH_POST); HIPCHK(hipGetLastError()); } }
         e->step_take_pre = e->step_pregather = false;
+        if (!rc) publish_dp();
         return rc;
     }
     // publish (dqn_train_step with scalar outputs, dqn_train_step_async): the step's last launch also writes (loss, grad_norm) into the host mailbox
@@ -713,30 +721,83 @@ int run_step(dqn_engine* e, bool sample, bool take_pre, bool pregather) {
     if (!rc && pub) e->pub_issued++;
     return rc;
 }
-// the record of publish `ticket`: spin on the mapped host ring (the GPU writes it with a system-scope release), falling back to a stream synchronize
-static int wait_mail(dqn_engine* e, unsigned long long ticket, bool wait, float* loss, float* gn, unsigned long long* published) {
+// ---- the scalar mailbox, host side
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__) || defined(__arm__)
+    asm volatile("yield" ::: "memory");
+#elif defined(__powerpc64__)
+    asm volatile("or 27,27,27" ::: "memory");
+#else
+    asm volatile("" ::: "memory");
+#endif
+}
+#define DQN_MAIL_SPIN_US 20000       /* spin on the mapped record this long (a step is 25 us - 1 ms), then stop burning the core and poll the stream */
+#define DQN_MAIL_TIMEOUT_S 30        /* a publish that has not arrived after this long while the stream is still busy: a kernel of the step is hung -- say so */
+static inline double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+static int mail_err_msg(int err, unsigned long long step) {
+    if (err == 2) return fail("AssertionError: all(new_priorities .> 0f0) (train step %llu)", step);
+    if (err == 3) return fail("internal error: a pre-gathered batch was consumed after the replay changed (StepState::pre_valid != 2; train step %llu)", step);
+    return fail("device-side error %d in train step %llu", err, step);
+}
+// wait until publish `ticket` has arrived (its record holds seq == ticket).  Returns 0 = arrived, 1 = not yet (wait == false), -1 = error (message set)
+static int mail_arrive(dqn_engine* e, unsigned long long ticket, bool wait) {
     volatile StepMail* m = e->mail_host + (ticket & (DQN_MAIL_SLOTS - 1));
     auto seq_now = [&]() { return __atomic_load_n(&m->seq, __ATOMIC_ACQUIRE); };
+    if (seq_now() == ticket) return 0;
+    if (!wait) return 1;
+    const double t0 = now_s();
+    for (unsigned spin = 0;; spin++) {
+        if (seq_now() == ticket) return 0;
+        cpu_relax();
+        if ((spin & 1023) == 1023 && now_s() - t0 > 1e-6 * DQN_MAIL_SPIN_US) break;
+    }
+    for (;;) {      // the step is long (or stuck): poll the stream instead of the record
+        const hipError_t q = hipStreamQuery(e->stream);
+        if (seq_now() == ticket) return 0;
+        if (q == hipSuccess) { (void)hipGetLastError(); return seq_now() == ticket ? 0 : fail("step scalars: the stream is idle but publish %llu did not arrive (slot holds %llu): the step's publish launch was refused", ticket, (unsigned long long)seq_now()); }
+        if (q != hipErrorNotReady) { (void)hipGetLastError(); return fail("step scalars: HIP error %s while waiting for publish %llu", hipGetErrorString(q), ticket); }
+        (void)hipGetLastError();
+        if (now_s() - t0 > (double)DQN_MAIL_TIMEOUT_S) return fail("step scalars: publish %llu did not arrive within %d s and the stream is still busy -- a kernel of the train step is hung (DQN_MAIL_TIMEOUT_S)", ticket, DQN_MAIL_TIMEOUT_S);
+        struct timespec ts = {0, 50000}; nanosleep(&ts, nullptr);
+    }
+}
+// device-side assertion failures travel in the records (k_publish_scalars consumes StepState::err, so each failure sits in exactly ONE record): every arrived record is
+// looked at once, in publish order (publishes execute in stream order, so arrival is in order too); the first error found is reported -- by whichever call sweeps first:
+// a step-scalars fetch or the next dqn_train_step / dqn_train_step_async -- naming the step that failed
+static int mail_sweep(dqn_engine* e) {
+    while (e->mail_swept < e->pub_issued) {
+        const unsigned long long t = e->mail_swept + 1;
+        volatile StepMail* m = e->mail_host + (t & (DQN_MAIL_SLOTS - 1));
+        if (__atomic_load_n(&m->seq, __ATOMIC_ACQUIRE) != t) break;      // not yet arrived (or already overwritten: mail_reserve keeps that from happening)
+        e->mail_swept = t;
+        const int err = m->err; if (err) return mail_err_msg(err, m->step);
+    }
+    return 0;
+}
+// before publish number pub_issued + 1 is enqueued: the record it will overwrite (ticket pub_issued + 1 - DQN_MAIL_SLOTS) must have been swept -- the host never runs more
+// than DQN_MAIL_SLOTS publishes ahead of the device, so no error record is ever lost unseen.  Also surfaces errors of earlier steps promptly
+static int mail_reserve(dqn_engine* e) {
+    if (!e->mail_dev) return 0;
+    if (e->pub_issued + 1 > DQN_MAIL_SLOTS) { const unsigned long long need = e->pub_issued + 1 - DQN_MAIL_SLOTS; if (e->mail_swept < need && mail_arrive(e, need, true)) return -1; }
+    return mail_sweep(e);
+}
+// the record of publish `ticket`
+static int wait_mail(dqn_engine* e, unsigned long long ticket, bool wait, float* loss, float* gn, unsigned long long* published) {
     if (ticket == 0 || ticket > e->pub_issued) return fail("step scalars: ticket %llu was never issued (newest %llu)", ticket, e->pub_issued);
     if (ticket + DQN_MAIL_SLOTS <= e->pub_issued) return fail("step scalars: ticket %llu is older than the %d newest publishes (newest %llu)", ticket, DQN_MAIL_SLOTS, e->pub_issued);
-    unsigned long long s = seq_now();
-    if (s != ticket && wait) {
-        for (long spin = 0; (s = seq_now()) != ticket; spin++) {
-            __builtin_ia32_pause();
-            if (spin == (1L << 22)) { HIPCHK(hipStreamSynchronize(e->stream)); s = seq_now(); break; }      // ~tens of ms of spinning: stop burning the core
-        }
-    }
-    if (published) *published = (s == ticket) ? ticket : 0;
-    if (s != ticket) { if (wait) return fail("step scalars: publish %llu did not arrive (slot holds %llu)", ticket, s); return 0; }
-    const int err = m->err;
-    if (err) { HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&e->state->err, 0, 1, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); }      // reported once, not on every later call
-    if (err == 2) return fail("AssertionError: all(new_priorities .> 0f0)");
-    if (err == 3) return fail("internal error: a pre-gathered batch was consumed after the replay changed (StepState::pre_valid != 2)");
+    const int a = mail_arrive(e, ticket, wait);
+    if (a < 0) return -1;
+    if (published) *published = a == 0 ? ticket : 0;
+    if (mail_sweep(e)) return -1;      // an assertion failure of this or an earlier step (reported once)
+    if (a) return 0;
+    volatile StepMail* m = e->mail_host + (ticket & (DQN_MAIL_SLOTS - 1));
     if (loss) *loss = m->loss;
     if (gn) *gn = m->gnorm;
     return 0;
 }
-static bool mailbox_ok(dqn_engine* e) { return e->mail_dev && e->world <= 1 && !(e->comm && e->force_comm) && !e->profiling && !e->hp.recurrence; }
+static bool mailbox_ok(dqn_engine* e) { return e->mail_dev && !e->sim_world && !e->profiling && !e->hp.recurrence; }      // replicas included (r05: published eagerly behind the step, run_step)
 int fetch_scalars(dqn_engine* e, float* loss, float* gn) {
     // globalnorm (helpers.jl:38-46): fold the Adam kernel's per-block maxima only when the host asks for the scalar
     if (gn) launch_update_priorities(e->stream, 0, e->cap2, e->idx, e->td, e->hp.prio_eps, e->hp.prio_alpha, e->tree, e->state, 1, 1.0, 1.0, e->gmax_part, (e->gmax_used > 0 && e->gmax_used <= gmax_slots(e->Pint)) ? e->gmax_used : gmax_slots(e->Pint));
@@ -759,6 +820,7 @@ extern "C" int dqn_train_step(dqn_engine_t* e, const int64_t* idx, float* loss, 
     // scalars only (what batch_train! returns, src/solver.jl:235): the step's last launch publishes them to the host mailbox -- no fold launch, no D2H copy,
     // no stream synchronize; the host spins on the record
     const bool mail = (loss || grad_norm) && !td_out && mailbox_ok(e);
+    if (mail && mail_reserve(e)) return -1;
     e->step_publish = mail;
     if (run_step(e, idx == nullptr)) return -1;
     if (mail) return wait_mail(e, e->pub_issued, true, loss, grad_norm, nullptr);
@@ -771,9 +833,24 @@ extern "C" int dqn_train_step(dqn_engine_t* e, const int64_t* idx, float* loss, 
 extern "C" int dqn_train_step_async(dqn_engine_t* e, const int64_t* idx, uint64_t* ticket) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device));
     if (e->hp.recurrence) return fail("recurrence = true: use dqn_train_step_drqn (src/solver.jl:239-287)");
-    if (!mailbox_ok(e)) return fail("dqn_train_step_async: single-device feed-forward engines only");
     if (e->size < e->B) return fail("AssertionError: r._curr_size >= r.batch_size");
+    if (!e->mail_host) return fail("dqn_train_step_async: no mailbox on this engine");
     if (idx) { if (check_idx(e, idx, e->B)) return -1; HIPCHK(hipMemcpyAsync(e->idx, idx, (size_t)e->B * 8, hipMemcpyHostToDevice, e->stream)); }
+    if (!mailbox_ok(e)) {
+        // no device-side publish here (replicas, a profiled step, or the mapped-host allocation failed at create): the call DEGRADES to a synchronous step whose scalars are
+        // recorded under the ticket by the host, so that a caller written against the async seam -- the shim's dqn_train! -- runs unchanged
+        if (mail_sweep(e)) return -1;
+        float l = 0.0f, g = 0.0f;
+        if (run_step(e, idx == nullptr)) return -1;
+        if (fetch_scalars(e, &l, &g)) return -1;
+        const unsigned long long t = ++e->pub_issued; e->mail_swept = t;
+        StepMail* m = e->mail_host + (t & (DQN_MAIL_SLOTS - 1));
+        m->loss = l; m->gnorm = g; m->err = 0; m->step = 0; __atomic_store_n(&m->seq, t, __ATOMIC_RELEASE);
+        if (e->pub_ctr) HIPCHK(hipMemcpy(e->pub_ctr, &t, sizeof t, hipMemcpyHostToDevice));      // the device-side publish counter follows (a later mailbox publish continues the sequence)
+        if (ticket) *ticket = t;
+        return 0;
+    }
+    if (mail_reserve(e)) return -1;
     e->step_publish = true;
     if (run_step(e, idx == nullptr)) return -1;
     if (ticket) *ticket = e->pub_issued;
@@ -801,7 +878,8 @@ extern "C" int dqn_sim_ranks_step(dqn_engine_t* e, const int64_t* idx, float* lo
     if (check_idx(e, idx, k * B)) return -1;
     if (build_program(e)) return -1;
     if (!e->dp_gather) return fail("DQN_SIM_WORLD needs the gather exchange (no wide dense layer in this network, or DQN_DP_ALLREDUCE is set)");
-    long long* s_idx = nullptr; float* s_td = nullptr; DM(s_idx, (size_t)k * B); DM(s_td, (size_t)k * B);
+    if (!e->sim_idx) { DM(e->sim_idx, (size_t)k * B); DM(e->sim_td, (size_t)k * B); }      // per-rank index / TD copies: owned by the engine, allocated once (sim_world and B are fixed at create)
+    long long* s_idx = e->sim_idx; float* s_td = e->sim_td;
     int rc = 0;
     for (int r = 0; r < k && !rc; r++) {
         HIPCHK(hipMemcpyAsync(e->idx, idx + (size_t)r * B, (size_t)B * 8, hipMemcpyHostToDevice, e->stream));
@@ -828,7 +906,7 @@ extern "C" int dqn_sim_ranks_step(dqn_engine_t* e, const int64_t* idx, float* lo
         for (int r = 0; r + 1 < k; r++) launch_update_priorities(e->stream, B, e->cap2, s_idx + (size_t)r * B, s_td + (size_t)r * B, e->hp.prio_eps, e->hp.prio_alpha, e->tree, e->state, 0, 1.0, 1.0, nullptr, 0);
     if (!rc && td_out) HIPCHK(hipMemcpyAsync(td_out, s_td, (size_t)k * B * 4, hipMemcpyDeviceToHost, e->stream));
     if (!rc) rc = fetch_scalars(e, nullptr, grad_norm);
-    hipStreamSynchronize(e->stream); hipFree(s_idx); hipFree(s_td);
+    hipStreamSynchronize(e->stream);
     return rc;
 }
 extern "C" int dqn_train_steps(dqn_engine_t* e, int n, float* loss, float* grad_norm) { if (!e) return fail("null engine handle");
@@ -867,6 +945,7 @@ extern "C" int dqn_train_steps(dqn_engine_t* e, int n, float* loss, float* grad_
         // the last step of a call that returns scalars publishes them from its own last launch into the host mailbox (no fold launch / D2H copy / stream synchronize)
         const unsigned long long pub0 = e->pub_issued;
         e->step_publish = (loss || grad_norm) && i + 1 == n && mailbox_ok(e);
+        if (e->step_publish && mail_reserve(e)) return -1;
         if (run_step(e, true, pg && i > 0, pg && i + 1 < n)) return -1;
         i++;
         if (i == n && e->pub_issued != pub0) return wait_mail(e, e->pub_issued, true, loss, grad_norm, nullptr);
@@ -963,6 +1042,26 @@ extern "C" int dqn_comm_unique_id(void* id128) { if (rccl_load()) return -1; con
 extern "C" int dqn_comm_init(dqn_engine_t* e, const void* id128, int rank, int world) { if (!e) return fail("null engine handle");
     if (rccl_load()) return -1;
     HIPCHK(hipSetDevice(e->device));
+    // Recurrent engines on the fused column-parallel step (plan dw_kc = -cg, drqn_cols.hip): that step has no point at which a gradient could be exchanged.  A DEFAULTED
+    // plan is recomputed without the column-group rule (the multi-launch recurrent program, all-reduce between backward and Adam); a plan the CALLER wrote is refused here,
+    // with the reason, instead of at the first train step.
+    bool cgp = false; for (int i = 0; i < e->nl; i++) cgp = cgp || e->L[i].dw_kc < 0;
+    if (cgp && !e->plan_defaulted)
+        return fail("dqn_comm_init: this engine was created with a column-group dW plan (dw_kc < 0: the fused single-device recurrent step); replicas need dw_kc >= 0 -- "
+                    "create the engine with plan = NULL (the default plan is then re-derived for replicas here) or with contiguous dW chunks");
+    if (cgp) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        dqn_layer_plan defp[DQN_MAX_LAYERS]; default_plan(e->L, e->nl, e->B, defp, &e->hp, /*allow_cg*/ false);
+        size_t pmax = e->partials_elems;
+        for (int i = 0; i < e->nl; i++) {
+            LayerDev& l = e->L[i]; l.fwd_kc = defp[i].fwd_kc; l.dx_kc = defp[i].dx_kc; l.dw_kc = defp[i].dw_kc;
+            const size_t sf = dqn_nchunks(l.K, l.fwd_kc); if (sf > 1) pmax = std::max(pmax, sf * (size_t)l.out_feat * e->ncon);
+            const size_t sw = dqn_nchunks(l.npos * e->Bc, l.dw_kc); if (sw > 1) pmax = std::max(pmax, sw * (size_t)(l.K + 1) * l.N);
+            const size_t sx = l.kind != DQN_LAYER_CONV ? dqn_nchunks(l.N, l.dx_kc) : 1; if (sx > 1) pmax = std::max(pmax, sx * (size_t)l.in_feat * e->Bc);
+        }
+        HIPCHK(hipMemcpy(e->L_dev, e->L, sizeof(LayerDev) * e->nl, hipMemcpyHostToDevice));
+        if (pmax > e->partials_elems) { hipFree(e->partials); e->partials = nullptr; DM(e->partials, 2 * pmax); e->partials_elems = pmax; }
+    }
     Id128 id; memcpy(id.b, id128, 128);
     const int rc = g_rccl.CommInitRank(&e->comm, world, id, rank);
     if (rc) return fail("ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");

@@ -137,10 +137,11 @@ extern "C" int dqn_train_step_drqn(dqn_engine_t* e, const int64_t* ep_idx, const
         drqn_ring_put(e, 16 + par, ep_idx, ep_start); __atomic_thread_fence(__ATOMIC_RELEASE);
         e->drqn_slot_next = 16 + par;
     } else if (drqn_upload_draws(e, ep_idx, ep_start)) return -1;
-    if (e->hp.use_graph && !e->profiling && e->world == 1) {
+    const bool xch = e->world > 1 || (e->comm && e->force_comm);      // replicas (or DQN_FORCE_ALLREDUCE at world 1, tests): all-reduce of the materialised gradient between backward and Adam
+    if (e->hp.use_graph && !e->profiling && !xch) {
         if (!e->g_drqn[par] && capture(e, false, PH_ALL, &e->g_drqn[par])) return -1;
         HIPCHK(hipGraphLaunch(e->g_drqn[par], e->stream));
-    } else { enqueue_step(e, false, PH_PRE); if (e->world > 1 && exchange_grads(e)) return -1; enqueue_step(e, false, PH_POST); if (e->launch_failed) { e->launch_failed = false; return fail("the recurrent step could not be enqueued (dynamic LDS refused)"); } }
+    } else { enqueue_step(e, false, PH_PRE); if (xch && exchange_grads(e)) return -1; enqueue_step(e, false, PH_POST); if (e->launch_failed) { e->launch_failed = false; return fail("the recurrent step could not be enqueued (dynamic LDS refused)"); } }
     if (e->drqn_fused) { HIPCHK(hipEventRecord(e->draw_ev[evi], e->stream)); e->draw_ev_used[evi] = true; e->drqn_one_par ^= 1; }
     if (loss || grad_norm) return fetch_scalars(e, loss, grad_norm);
     return 0;
@@ -150,7 +151,7 @@ extern "C" int dqn_train_step_drqn(dqn_engine_t* e, const int64_t* ep_idx, const
 int drqn_train_steps(dqn_engine* e, int n, float* loss, float* grad_norm) {
     enum { DRQN_GROUP = 8 };
     if (build_program(e)) return -1;
-    const bool grouped = e->drqn_fused && e->hp.use_graph && !e->profiling && e->world == 1;
+    const bool grouped = e->drqn_fused && e->hp.use_graph && !e->profiling && e->world == 1 && !(e->comm && e->force_comm);
     std::vector<int64_t> di; std::vector<int32_t> ds;
     for (int i = 0; i < n;) {
         if (grouped && n - i >= DRQN_GROUP) {

@@ -65,7 +65,7 @@ int build_program(dqn_engine* e) {
             bool ok = drqn_fused_cg(e->L, e->nl, e->E, Bb, T, e->nA, e->hp.dueling, e->hp.double_q, 1) > 0 && Bb % cgm == 0 && nset * 4 * L0.H * cgm <= 1024 && !e->comm && !e->sim_world && e->world <= 1;
             if (ok) { ok = dqn_nchunks(L0.K, L0.fwd_kc) == 1; for (int i = 1; i < e->nl; i++) ok = ok && dqn_nchunks(e->L[i].N, e->L[i].dx_kc) == 1; }
             if (!ok) return fail("plan: column-group dW chunks (dw_kc = %d) need a network the fused recurrent step covers -- Chain(flattenbatch, LSTM, Dense) with or without the dueling split, "
-                                 "H a multiple of 8 up to 64, unsplit input projection and head dX, a single device -- use the default plan or dw_kc >= 0", -cgm);
+                                 "H a multiple of 8 up to 64, unsplit input projection and head dX, ONE device without a communicator -- use dw_kc >= 0 (plan = NULL picks a plan that fits; with a communicator dqn_comm_init re-derives it)", -cgm);
             DrqnColsArgs a; memset(&a, 0, sizeof a);
             a.B = Bb; a.T = T; a.H = L0.H; a.E = e->E; a.nA = e->nA; a.dueling = e->hp.dueling; a.double_q = e->hp.double_q; a.cg = cgm; a.nset = nset; a.gamma = e->hp.gamma; a.Pint = (unsigned)e->Pint;
             a.wi_off = (unsigned)L0.w_off; a.b_off = (unsigned)L0.b_off; a.wh_off = (unsigned)L0.wh_off; a.h0_off = (unsigned)L0.h0_off; a.c0_off = (unsigned)L0.c0_off;
@@ -89,7 +89,7 @@ int build_program(dqn_engine* e) {
             }
             const int G = Bb / cgm;
             a.slabs = palloc(e, (size_t)G * e->Pint); a.hl = palloc(e, (size_t)B); a.td = e->td; a.st = e->state;
-            a.probe = e->opt.drqn_probe;
+            a.probe = e->opt.drqn_probe | (mf ? 0 : 2);      // hp.use_mfma = 0: the VALU form of the input projection (the same chains, the same bits)
             if (e->opt.drqn_stamps) { a.stamps = (unsigned long long*)palloc(e, 64); e->drqn_stamps = a.stamps; }
             e->prog.push_back({"drqn_cols", [=](dqn_engine* en) { if (launch_drqn_cols(en->stream, a, en->drqn_slot_next++)) en->launch_failed = true; }});      // the slot is baked into the captured node
             e->prog_post_begin = e->prog.size();

@@ -266,7 +266,9 @@ __global__ __launch_bounds__(1024) void k_publish_scalars(StepState* state, cons
         state->gnorm_bits = __float_as_uint(g);
         const unsigned long long seq = *pub_ctr + 1; *pub_ctr = seq;
         StepMail* m = mail + (seq & (DQN_MAIL_SLOTS - 1));
-        m->loss = state->loss; m->gnorm = g; m->err = state->err; m->step = state->step;
+        // a device-side assertion failure is CONSUMED here (delivered in exactly one record): left sticky, every step already enqueued behind the failing one would
+        // publish it again and the host would report it once per outstanding ticket; the host sweeps every arrived record in order (mail_sweep, engine.hip)
+        m->loss = state->loss; m->gnorm = g; m->err = atomicExch(&state->err, 0); m->step = state->step;
         __threadfence_system();
         __hip_atomic_store(&m->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

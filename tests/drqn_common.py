@@ -12,6 +12,10 @@ def drqn_nets():
         "cfg4_lstm_plain": (O.RecurrentNetwork((1, 5, 5), [O.LSTM(25, 32), O.Dense(32, 4, I)]), 32, 8, dict(gamma=0.99, double_q=1)),   # benchmark/flux_dqn.jl:35-36
         "dense_lstm_dueling": (O.RecurrentNetwork((6,), [O.Dense(6, 12, O.ACT_RELU), O.LSTM(12, 16)], [O.Dense(16, 1, I)], [O.Dense(16, 5, I)]), 6, 5, dict(gamma=0.95, double_q=1)),
         "lstm_single_q": (O.RecurrentNetwork((6,), [O.LSTM(6, 8), O.Dense(8, 3, I)]), 4, 3, dict(gamma=0.9, double_q=0)),
+        # (nset + 1) * T * cg * n_out NOT a multiple of 4 (single-Q, odd T, 3 actions; B = 6 -> column groups of 2, B = 5 -> of 1): the fused step's LDS arrays behind the
+        # head outputs (the padded Wh copy BPTT reads 16 bytes at a time) must stay 16-byte aligned
+        "lstm_q3_b6_t5": (O.RecurrentNetwork((6,), [O.LSTM(6, 8), O.Dense(8, 3, I)]), 6, 5, dict(gamma=0.9, double_q=0)),
+        "lstm_q3_b5_t3": (O.RecurrentNetwork((7,), [O.LSTM(7, 16), O.Dense(16, 3, I)]), 5, 3, dict(gamma=0.9, double_q=0)),
         "lstm16_dueling_b16": (O.RecurrentNetwork((16,), [O.LSTM(16, 32)], [O.Dense(32, 1, I)], [O.Dense(32, 4, I)]), 16, 10, dict(gamma=0.95, double_q=1)),   # test/runtests.jl:131-147 shape
     }
 

@@ -216,8 +216,10 @@ def test_drqn_column_group_plan_on_uncovered_network_is_refused(pkg):
 
 
 def test_drqn_fused_step_long_run_wraps_the_draw_ring(pkg):
-    """the fused recurrent step takes its episode draws from a 64-slot mapped host ring (slot = a device-side sequence number): 300 steps -- single calls with the engine's own
-    sampler, explicit draws, and dqn_train_steps runs of 8-step graphs, in every alignment -- wrap it several times and must leave the twin's parameters bit for bit"""
+    """the fused recurrent step takes its episode draws from DQN_DRAW_SLOTS = 32 mapped host slots; a slot is a LAUNCH PARAMETER fixed per graph node (two alternating 8-step
+    graphs own slots 0-7 / 8-15, two alternating single-step graphs 16 / 17) and the host waits for the event behind a graph's previous launch before rewriting its slots:
+    300 steps -- single calls with the engine's own sampler, explicit draws, and dqn_train_steps runs of 8-step graphs, in every alignment -- reuse every slot many times and
+    must leave the twin's parameters bit for bit"""
     net, B, T, kw, rng, gpu, cpu, ring, params = setup(pkg, "cfg4_lstm_plain")
     assert all(p[2] < 0 for p in gpu.plan())                        # the fused path
     done = 0
@@ -235,3 +237,40 @@ def test_drqn_fused_step_long_run_wraps_the_draw_ring(pkg):
     mg, vg, bg = gpu.get_adam_state(); mc, vc, bc = cpu.get_adam_state()
     np.testing.assert_array_equal(mg, mc); np.testing.assert_array_equal(vg, vc); np.testing.assert_array_equal(bg, bc)
     gpu.close(); cpu.close()
+
+
+@pytest.mark.parametrize("name", ["cfg4_lstm_plain", "lstm16_dueling_b16"])
+def test_drqn_default_plan_with_communicator(pkg, monkeypatch, name):
+    """a recurrent engine created with the DEFAULT plan (column-group dW chunks: the fused single-device step) and then given a communicator must keep
+    training: dqn_comm_init re-derives the default plan without the column-group rule, the step runs the multi-launch program with the all-reduce between backward and
+    Adam (a real RCCL communicator at world 1, forced on), bit-exact against the twin handed the engine's plan; a caller-written column-group plan is refused AT
+    dqn_comm_init with the reason"""
+    net, B, T, kw = drqn_nets()[name]
+    rng = np.random.default_rng(5); cap = max(12, B + 4)
+    monkeypatch.setenv("DQN_FORCE_ALLREDUCE", "1")
+    gpu, hp, layers = make_handle(pkg.Engine, net, B, T, kw, cap=cap)
+    assert all(p[2] < 0 for p in gpu.plan())
+    gpu.comm_init(pkg.comm_unique_id(), 0, 1)
+    plan = gpu.plan()
+    assert all(p[2] >= 0 for p in plan), plan
+    cpu = ref.Twin(layers, hp, plan=plan, threads=4)
+    eps = make_episodes(net, cap + 3, T, rng)
+    ring = [None] * cap
+    for i, ep in enumerate(eps):
+        ring[i % cap] = ep
+    p_on = (O.Network.flatten(O.init_params_recurrent(net, 3)) + 0.05 * rng.standard_normal(net.n_params())).astype(np.float32)
+    for h in (gpu, cpu):
+        feed(h, eps); h.set_params(p_on, 0); h.set_params(p_on * np.float32(0.9), 1)
+    for step in range(3):
+        idx, start = draws(ring, B, rng)
+        assert gpu.train_step_drqn(idx, start) == cpu.train_step_drqn(idx, start)
+    assert gpu.train_steps(3) == [cpu.train_step_drqn() for _ in range(3)][-1]
+    info = gpu.comm_info()
+    assert info["rccl_nranks"] == 1 and info["exchange"] == 2      # all-reduce of the flat gradient
+    np.testing.assert_array_equal(gpu.get_grads(), cpu.get_grads())
+    np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+    gpu.close(); cpu.close()
+    g2 = pkg.Engine(layers, hp, plan=pkg.default_plan(layers, hp), device=0)      # the same plan, but WRITTEN by the caller
+    with pytest.raises(pkg.DQNError, match="column-group dW plan"):
+        g2.comm_init(pkg.comm_unique_id(), 0, 1)
+    g2.close()
