@@ -583,11 +583,11 @@ def cpu_worker(args):
             if r["value"] > best_v:
                 best_t, best_v = th, r["value"]
         torch.set_num_threads(best_t)
-        for _ in range(3):
-            runs.append(torch_cpu_line(hp, min(3.0, args.cpu_seconds / 4)))
-        top = max(runs, key=lambda r: r["value"])
+        for _ in range(5):
+            runs.append(torch_cpu_line(hp, min(2.0, args.cpu_seconds / 6)))
+        top = sorted(runs, key=lambda r: r["value"])[2]
         top.update(threads=best_t, runs_steps_per_s=[round(r["value"], 2) for r in runs], spread=round(max(r["value"] for r in runs) / min(r["value"] for r in runs), 3),
-                   protocol="fresh process pinned to one NUMA node's physical cores; thread count = best of 16/32/all by a short probe; value = best of 3 runs")
+                   protocol="fresh process pinned to one NUMA node's physical cores; thread count = best of 16/32/all by a short probe; value = MEDIAN of 5 runs")
         print(json.dumps(top))
         return 0
     # ---- the canonical-order C twin (oracle/dqn_ref.c, kind "port") on a bounded sample of the same workload: same network, batch and step, a 512-transition replay
@@ -678,7 +678,7 @@ def cpu_baseline(pkg, layers, hp, params, env, args):
             "timed_steps": tw.get("timed_steps"), "twin": tw, "torch_cpu": tc,
             "sample": f"value = the faster of two CPU ports of the same train step (B={hp.batch_size}, Nature-DQN dueling, double-Q, IS-weighted Huber, backward, Adam), each in a fresh process "
                       f"pinned to the {len(plan['cores'])} physical cores of NUMA node {plan['node']} of this {ncpu}-CPU host (OMP_PROC_BIND=close, OMP_PLACES=cores): "
-                      f"(a) eager PyTorch CPU / oneDNN, random batch, best of 3 runs (library-class proxy for Flux's im2col + OpenBLAS path); "
+                      f"(a) eager PyTorch CPU / oneDNN, random batch, median of 5 runs (library-class proxy for Flux's im2col + OpenBLAS path); "
                       f"(b) port_value: oracle/dqn_ref.c (the canonical-order twin the parity tests use) on a 512-transition replay, thread count = fastest of 1/8/16/32/all by a 5-step probe, "
                       f"then 3 x (10 warm-up + >= 30 individually timed steps), 1 / smallest median.  The Julia/Flux reference itself cannot run in this image"}
 
@@ -755,7 +755,7 @@ def dominant_kernel(table, use_profile, ev_over=0.0):
         d.update(rocprof_symbol=symbol, rocprof_file="profiles/" + os.path.basename(prof[0]), rocprof_sha1=hashlib.sha1(open(prof[0], "rb").read()).hexdigest()[:12],
                  rocprof_avg_us=round(tot * 1e3 / calls, 2), rocprof_share_of_kernel_time=round(tot / sum(r[3] for r in prof[1]), 4),
                  chosen_by="largest total time in the committed rocprofv3 kernel-trace summary")
-        if d.get("bound") == "mfma":
+        if d.get("bound") == "mfma" and use_profile != "cfg5":      # (config 5: the family's launches are several template instances, the profile's average is ONE symbol's)
             # live FLOPs over the COMMITTED profile's duration: not a measurement of this run (the profile may predate the code that is running)
             d["frac_at_committed_profile_duration"] = round(d["mflop_per_step"] * 1e6 / (d["rocprof_avg_us"] * len(rows) * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
     else:

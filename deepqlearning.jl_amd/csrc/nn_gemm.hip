@@ -270,6 +270,27 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
 #pragma unroll
             for (int t = 0; t < NT; t++) acc[t] = MFMA(f.a[st], f.b[st][t], acc[t]);
     };
+    if constexpr (!M32) {
+        // r05: a wave whose M-tile lies beyond the problem -- the target net's 32 columns are 2 of a dense workgroup's 4 M-tiles, so waves 2 and 3 of those workgroups
+        // contracted padding: 4/3 of the algorithmic MFMAs in the FC forward (SQ_VALU_MFMA_BUSY_CYCLES 12.85 M vs 9.6 M, profiles/r04_y_pmc_sq.txt), issued on SIMDs the
+        // co-resident workgroup's waves need.  Such a wave still moves its share of both operand tiles -- the loads, LDS stores and barriers of the pipeline below, in the same
+        // order -- but reads no fragments and issues no MFMAs.  The productive waves' instruction stream is unchanged (a separate path, not a predicate in the loop).
+        if (!__builtin_amdgcn_readfirstlane((int)(mgrp * 4 + wave < p.mtiles))) {
+            Stage r0, r1;
+            gload_first(r0); STAGE_WAIT(0, r0); lstore(0, r0); __syncthreads();
+            gload(1, r0);
+            for (int kt = 0; kt < nkt; kt += 2) {
+                gload(kt + 2, r1);
+                STAGE_WAIT(LPS, r0); lstore(1, r0);
+                __syncthreads();
+                gload(kt + 3, r0);
+                STAGE_WAIT(LPS, r1); lstore(0, r1);
+                __syncthreads();
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
+    }
     if constexpr (M32) {
         static_assert(NT == 4 || !M32, "M32 needs the 64-channel tile");
         const int wm = wave & 1, wn = wave >> 1, l31 = lane & 31, kh = lane >> 5;

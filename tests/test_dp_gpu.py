@@ -172,6 +172,14 @@ def test_rccl_allgather_world1_matches_plain(pkg, monkeypatch):
         ra, rb, rc = a.train_step(), b.train_step(), cpu.train_step()
         assert ra[0] == rb[0] == rc[0] and ra[1] == rb[1]
         np.testing.assert_array_equal(ra[2], rb[2])
+    # r05: the scalar mailbox on replicas -- the publish launch is enqueued behind the exchange + Adam, so batch_train!'s (loss, grad_norm) cost no fold launch / D2H copy /
+    # stream synchronize there either; synchronous and asynchronous forms, same records as the plain engine and the twin
+    for _ in range(2):
+        assert a.train_step(want_td=False) == b.train_step(want_td=False) == cpu.train_step(want_td=False)
+    tk = [a.train_step_async() for _ in range(3)]
+    want = [cpu.train_step(want_td=False) for _ in range(3)]
+    assert [b.train_step(want_td=False) for _ in range(3)] == want
+    assert [a.step_scalars(t) for t in tk] == want
     np.testing.assert_array_equal(a.get_params(0), b.get_params(0))
     np.testing.assert_array_equal(a.get_params(0), cpu.get_params(0))
     np.testing.assert_array_equal(a.get_grads(), b.get_grads())

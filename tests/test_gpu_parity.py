@@ -692,6 +692,26 @@ def test_scalar_mailbox_and_async_step_bit_exact(pkg, netf, B, graph):
     gpu.close(); cpu.close()
 
 
+def test_device_assertion_travels_in_the_mailbox_once(pkg):
+    """assert all(new_priorities .> 0) (...replay.jl:78) fails on the DEVICE when a TD error is NaN.  The failure is consumed into exactly one mailbox record
+    (k_publish_scalars), and the host reports it once, naming the step, at the first call that sweeps that record -- not once per outstanding ticket"""
+    net = cfg1_mlp_dueling()
+    gpu, cpu, hp = make_pair(pkg, net, 32, cap=128, learning_rate=1e-3)
+    fill((gpu, cpu), net, 100, seed=3)
+    set_same_params((gpu, cpu), net, seed=2)
+    assert gpu.train_step(want_td=False) == cpu.train_step(want_td=False)
+    rng = np.random.default_rng(0)
+    s = rng.random((1,) + net.obs_shape, dtype=np.float32)
+    gpu.replay_add(s, np.zeros(1, np.int32), np.full(1, np.nan, np.float32), s, np.zeros(1, np.uint8), td_err=np.ones(1, np.float32))      # a transition with a NaN reward at slot 100
+    idx = np.arange(69, 101).astype(np.int64)
+    t1 = gpu.train_step_async(idx)                        # its TD error is NaN -> a NaN priority -> the device-side assertion
+    with pytest.raises(pkg.DQNError, match="new_priorities"):
+        gpu.step_scalars(t1)
+    l, g = gpu.step_scalars(t1)                           # reported once: the record itself stays readable
+    assert np.isnan(l)
+    gpu.close(); cpu.close()
+
+
 def test_engine_switches_are_read_at_creation_and_stay_per_engine(pkg, monkeypatch):
     """experiment / test switches are read ONCE, in dqn_engine_create, into the engine (EngineOpts, csrc/engine.h): a second engine in the same process does
     not inherit the first one's, and changing the environment afterwards changes nothing for an existing engine"""
