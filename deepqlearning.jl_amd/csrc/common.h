@@ -63,13 +63,21 @@ static inline __host__ __device__ int dqn_chunk_len(int K, int kc) { return (kc 
 
 // ---- device math shared by VALU and MFMA epilogues (compiled with -ffp-contract=off: every fused
 //      multiply-add is an explicit fmaf / MFMA, never a compiler contraction)
+// tanh / sigmoid through Float64 (Flux's Float32 activations round once): OUT OF LINE.  Inlined at every use -- four per epilogue vector, in every kernel -- these two bodies
+// were most of the code of the forward kernels (k_fwd_lds<2>: 1185 instructions without them, ~10 000 with) and stood, as branch targets nobody takes at relu / identity
+// layers, between the instructions that run (r05: same-box A/B of a build without them: +1.4 % steps/s at config 2).  Same arithmetic, same bits.
+__device__ __attribute__((noinline)) static float act_slow(float y, int act) {
+    if (act == DQN_ACT_TANH) return (float)tanh((double)y);
+    return (float)(1.0 / (1.0 + exp(-(double)y)));
+}
 __device__ __forceinline__ float act_f(float y, int act) {
-    switch (act) {
-    case DQN_ACT_RELU: return y > 0.0f ? y : 0.0f;
-    case DQN_ACT_TANH: return (float)tanh((double)y);
-    case DQN_ACT_SIGMOID: return (float)(1.0 / (1.0 + exp(-(double)y)));
-    default: return y;
-    }
+#ifdef DQN_PROBE_NO_TRANS      /* TIMING PROBE (r05): tanh / sigmoid compiled out */
+    return act == DQN_ACT_RELU ? (y > 0.0f ? y : 0.0f) : y;
+#else
+    if (act == DQN_ACT_RELU) return y > 0.0f ? y : 0.0f;
+    if (act == DQN_ACT_TANH || act == DQN_ACT_SIGMOID) return act_slow(y, act);
+    return y;
+#endif
 }
 __device__ __forceinline__ float dact_f(float dy, float y, int act) {
     switch (act) {
@@ -528,6 +536,31 @@ struct HeadTdArgs {
 };
 size_t head_td_lds_bytes(const HeadTdArgs& a);
 void launch_head_td(hipStream_t st, const HeadTdArgs& a, const HeadTdArgs* a_dev, int bump_sample_ctr, int take_pre = 0);   // a_dev: the same record in device memory
+
+// ---- split-K reduce of the last hidden layer + the head level in ONE chip-filling launch (red_head.hip, r05): workgroup = (4 batch columns, stream, plan chunk of 32 hidden
+// rows); the last arriver of a column group does the TD arithmetic and the heads' dX.  Stream 0 = advantage / plain Q head, stream 1 = value head.
+struct RedHeadStream {
+    const float* part[2];              // [net] split-K slabs [S][K][ncols(net)] of the hidden layer's forward (net 0: ncon columns, net 1: B columns)
+    const float* pbias[2]; int pact;   // [net] hidden layer bias [K], its activation
+    const float* W[2]; const float* hbias[2]; int N, hact;      // [net] head weights [K][N], bias [N]; head activation
+    float* y_on;                       // online hidden activations [K][ncon]: columns 0..B-1 (the s columns) are written -- what the backward pass reads
+    float* dpre;                       // [N][B]  dL/d(pre-activation) of the head
+    float* dsrc;                       // [K][B]  dL/d(pre-activation) of the hidden layer
+};
+struct RedHeadArgs {
+    int B, nA, K, S, ncon, nstream, NO, double_q;      // K hidden rows (= head inputs), S slabs, NO = head outputs of both streams (nA, + 1 with a value stream)
+    float gamma;
+    RedHeadStream st[2];
+    const int* bm_a; const float *bm_r, *bm_done, *bm_w;      // batch scalars of the B columns (written by the gather launch)
+    float *w_is, *td, *q_on_s, *q_on_sp, *q_tg_sp, *ytarget, *hl; int* best;
+    StepState* stt; long long* idx; const long long* idx_pre;
+    float* partials;                   // [B/4][3 slots][4 columns][NO][K/32] chunk sums of the head outputs
+    unsigned* tickets;                 // [B/4] arrival counters (zero between launches: the last arriver re-arms its group's)
+    unsigned long long* stamps;        // timing probe (DQN_DRQN_STAMPS at create, tools/red_head_phases.py), else null
+};
+size_t red_head_lds_bytes(const RedHeadArgs& a);
+bool red_head_ok(int B, int K, int S, int nA, int nstream, int N0, int N1);
+void launch_red_head(hipStream_t st, const RedHeadArgs& a, const RedHeadArgs* a_dev, int bump_sample_ctr, int take_pre = 0);
 
 // task / segment tables of the batched small kernels (device-resident, built once per engine)
 struct VTask {

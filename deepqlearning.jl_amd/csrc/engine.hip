@@ -122,6 +122,7 @@ void read_opts(EngineOpts& o, bool comm_only) {
     o.mid_group = I("DQN_MID_GROUP", 4); o.mid_big = I("DQN_MID_BIG", 16); o.sim_world = I("DQN_SIM_WORLD", 0); o.no_graph_upload = F("DQN_NO_GRAPH_UPLOAD");
     o.no_rollout_cycle = F("DQN_NO_ROLLOUT_CYCLE"); o.no_u8_arena = F("DQN_NO_U8_ARENA"); o.head_fuse_maxb = I("DQN_HEAD_FUSE_MAXB", 1024); o.no_head_fuse = F("DQN_NO_HEAD_FUSE");
     o.head_dbg = I("DQN_HEAD_DBG", 0); o.prio_fork = F("DQN_PRIO_FORK"); o.prio_level = I("DQN_PRIO_LEVEL", 0); o.prio_nosplit = F("DQN_PRIO_NOSPLIT"); o.no_pregather = F("DQN_NO_PREGATHER");
+    o.no_red_head = F("DQN_NO_RED_HEAD");
     o.lstm_dw_mfma = F("DQN_LSTM_DW_MFMA"); o.probe_no_tg = F("DQN_PROBE_NO_TG"); o.drqn_probe = I("DQN_DRQN_PROBE", 0); o.drqn_stamps = F("DQN_DRQN_STAMPS"); o.tiny_stop = I("DQN_TINY_STOP", 0);
 }
 static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out, const dqn_hparams* hp, bool allow_cg = true) {

@@ -173,6 +173,25 @@ int build_program(dqn_engine* e) {
     float* actT[DQN_MAX_LAYERS][2] = {};                             // transposed copies [column][feature] of the head layers' inputs (written by the split-K reduce)
     bool wantT[DQN_MAX_LAYERS] = {};
     if (fuse_heads) for (int l : levels.back()) if (e->L[l].src >= 0) wantT[e->L[l].src] = true;
+    // ---------------- r05: when the head layers sit on dense hidden layers whose forward ran split-K, the split-K reduce AND the head level are ONE chip-filling launch
+    // (red_head.hip: workgroup = 4 batch columns x stream x plan chunk of 32 hidden rows, the last arriver of a column group does TD + the heads' dX) instead of
+    // k_reduce_multi (384 workgroups) + k_head_td (B workgroups)
+    bool fuse_rh = false; int rh_pa = -1, rh_pv = -1; const float* rh_part[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [stream][net]
+    if (fuse_heads && levels.size() >= 2 && !e->opt.no_red_head && !e->opt.probe_no_tg && !e->opt.head_dbg) {
+        const LayerDev& La = e->L[ha_l]; rh_pa = La.src; rh_pv = hv_l >= 0 ? e->L[hv_l].src : -1;
+        bool ok = rh_pa >= 0 && (hv_l < 0 || (rh_pv >= 0 && rh_pv != rh_pa));
+        const auto& pl = levels[levels.size() - 2];
+        auto in_pl = [&](int l) { for (int x : pl) if (x == l) return true; return false; };
+        if (ok) ok = in_pl(rh_pa) && (hv_l < 0 || in_pl(rh_pv)) && (int)pl.size() == (hv_l >= 0 ? 2 : 1);
+        if (ok) {
+            const LayerDev& Pa = e->L[rh_pa]; const int S = dqn_nchunks(Pa.K, Pa.fwd_kc);
+            ok = Pa.kind == DQN_LAYER_DENSE && S > 1 && dqn_chunk_len(La.K, La.fwd_kc) == 32 && dqn_nchunks(La.K, La.fwd_kc) * 32 == La.K;
+            if (ok && hv_l >= 0) { const LayerDev& Pv = e->L[rh_pv]; const LayerDev& Lv = e->L[hv_l];
+                ok = Pv.kind == DQN_LAYER_DENSE && Pv.N == Pa.N && dqn_nchunks(Pv.K, Pv.fwd_kc) == S && dqn_chunk_len(Lv.K, Lv.fwd_kc) == 32 && Lv.K == La.K; }
+            if (ok) ok = red_head_ok(B, La.K, S, e->nA, hv_l >= 0 ? 2 : 1, La.N, hv_l >= 0 ? e->L[hv_l].N : 0);
+        }
+        fuse_rh = ok;
+    }
     HeadSrc head[DQN_MAX_LAYERS][2];   // per (layer, net): where k_td finds the layer's output
     // ---------------- forward: online net on [s ; sp] (src/solver.jl:210,220), target net on sp (:211)
     for (size_t li = 0; li < levels.size(); li++) {
@@ -233,7 +252,8 @@ int build_program(dqn_engine* e) {
         for (const Prob& q : pr) {
             const LayerDev& L = LV[q.l];
             HeadSrc h; h.p = q.Y; h.ld = q.ncols; h.S = 1; h.per_s = 0; h.bias = q.P + L.b_off; h.act = L.act;
-            if (q.S > 1) {
+            if (q.S > 1 && fuse_rh && (q.l == rh_pa || q.l == rh_pv)) rh_part[q.l == rh_pa ? 0 : 1][q.net] = q.part;      // reduced inside k_red_head
+            else if (q.S > 1) {
                 if (last) { h.p = q.part; h.S = q.S; h.per_s = (unsigned long long)L.out_feat * q.ncols; }   // reduced on the fly by k_td
                 else { RSeg r; memset(&r, 0, sizeof r); r.part = q.part; r.S = q.S; r.elems = (unsigned long long)L.out_feat * q.ncols; r.mode = 0; r.bias = q.P + L.b_off; r.per_n = L.npos * q.ncols; r.act = L.act; r.out = q.Y;
                        if (wantT[q.l]) { r.outT = actT[q.l][q.net] = palloc(e, (size_t)L.out_feat * q.ncols); r.ncolsT = q.ncols; }
@@ -284,7 +304,29 @@ int build_program(dqn_engine* e) {
         t.on_adv = head[lq][0]; t.tg_adv = head[lq][1]; t.d_adv = e->dact[lq];
         if (e->hp.dueling) { t.on_val = head[e->last_val][0]; t.tg_val = head[e->last_val][1]; t.d_val = e->dact[e->last_val]; }
         t.idx_mut = e->idx; t.idx_pre = e->idx_pre; t.w_is = e->w_is; t.td = e->td; t.q_on_s = e->q_on_s; t.q_on_sp = e->q_on_sp; t.q_tg_sp = e->q_tg_sp; t.ytarget = e->ytarget; t.best = e->best; t.st = e->state;
-        if (fuse_heads) {
+        if (fuse_rh) {
+            RedHeadArgs h; memset(&h, 0, sizeof h);
+            const LayerDev& La = e->L[ha_l];
+            h.B = B; h.nA = e->nA; h.K = La.K; h.S = dqn_nchunks(e->L[rh_pa].K, e->L[rh_pa].fwd_kc); h.ncon = ncon; h.nstream = hv_l >= 0 ? 2 : 1; h.NO = e->nA + (hv_l >= 0 ? 1 : 0); h.double_q = e->hp.double_q;
+            h.gamma = e->hp.gamma;
+            for (int st = 0; st < h.nstream; st++) {
+                const int hl_ = st == 0 ? ha_l : hv_l, pl_ = st == 0 ? rh_pa : rh_pv; const LayerDev& H = e->L[hl_]; const LayerDev& P = e->L[pl_]; RedHeadStream& T = h.st[st];
+                T.part[0] = rh_part[st][0]; T.part[1] = rh_part[st][1]; T.pbias[0] = e->p_on + P.b_off; T.pbias[1] = e->p_tg + P.b_off; T.pact = P.act;
+                T.W[0] = e->p_on + H.w_off; T.W[1] = e->p_tg + H.w_off; T.hbias[0] = e->p_on + H.b_off; T.hbias[1] = e->p_tg + H.b_off; T.N = H.N; T.hact = H.act;
+                T.y_on = e->act_on[pl_]; T.dpre = e->dact[hl_]; T.dsrc = e->dact[pl_];
+            }
+            if (h.nstream == 1) h.st[1] = h.st[0];      // (never read: keeps every pointer of the record valid)
+            h.bm_a = e->gb_a2; h.bm_r = e->gb_r2; h.bm_done = e->gb_done2; h.bm_w = e->gb_w2;
+            h.w_is = e->w_is; h.td = e->td; h.q_on_s = e->q_on_s; h.q_on_sp = e->q_on_sp; h.q_tg_sp = e->q_tg_sp; h.ytarget = e->ytarget; h.best = e->best; h.hl = hl_buf; h.stt = e->state;
+            h.idx = e->idx; h.idx_pre = e->idx_pre;
+            const int Gc = B / 4, NC = h.K / 32;
+            h.partials = palloc(e, (size_t)Gc * 12 * h.NO * NC); h.tickets = (unsigned*)palloc(e, (size_t)Gc);
+            HIPCHK(hipMemset(h.tickets, 0, (size_t)Gc * 4));      // armed once; every launch's last arrivers re-arm their groups
+            if (e->opt.drqn_stamps) { h.stamps = (unsigned long long*)palloc(e, 64); HIPCHK(hipMemset(h.stamps, 0, 256)); e->drqn_stamps = h.stamps; }
+            const RedHeadArgs* h_dev = upload(e, std::vector<RedHeadArgs>(1, h));
+            e->prog.push_back({"red_head", [=](dqn_engine* en) { launch_red_head(en->stream, h, h_dev, en->step_sampled ? 1 : 0, en->step_take_pre ? 1 : 0); }});
+        }
+        else if (fuse_heads) {
             HeadTdArgs h; memset(&h, 0, sizeof h);
             h.B = B; h.nA = e->nA; h.dueling = e->hp.dueling; h.double_q = e->hp.double_q; h.gamma = e->hp.gamma; h.prio_beta = e->hp.prio_beta; h.cap2 = e->cap2;
             h.bm_a = e->gb_a2; h.bm_r = e->gb_r2; h.bm_done = e->gb_done2; h.bm_w = e->gb_w2;

@@ -424,6 +424,50 @@ def test_nature_dqn_b32_full_size_bit_exact(pkg):
     check_priorities_after_step(gpu, hp, idx, pr_before, td, o["td"], batch[5])
 
 
+def _wide_fc_plain():
+    """a plain (non-dueling) Q network whose last hidden layer is wide enough for a split-K forward (K > 1024): one stream for the fused reduce + head launch"""
+    return O.Network((4, 20, 20), [O.Conv(4, 4, 32, O.ACT_RELU, 2), O.Conv(3, 32, 32, O.ACT_RELU, 1), O.Dense(32 * 7 * 7, 128, O.ACT_RELU), O.Dense(128, 3, O.ACT_IDENTITY)])
+
+
+def _wide_fc_dueling_tanh():
+    b, v, a = O.create_dueling_network([O.Conv(4, 4, 32, O.ACT_RELU, 2), O.Conv(3, 32, 32, O.ACT_RELU, 1), O.Dense(32 * 7 * 7, 160, O.ACT_TANH), O.Dense(160, 5, O.ACT_IDENTITY)])
+    return O.Network((4, 20, 20), b, v, a)
+
+
+@pytest.mark.parametrize("netf,B,kw", [(nature_dueling, 32, dict(gamma=0.99)), (_wide_fc_plain, 16, dict(gamma=0.9)), (_wide_fc_plain, 8, dict(gamma=0.9, double_q=0)),
+                                       (_wide_fc_dueling_tanh, 24, dict(gamma=0.95)), (_wide_fc_dueling_tanh, 4, dict(gamma=0.95, double_q=0, prioritized_replay=0))])
+def test_fused_reduce_head_launch_both_schedules(pkg, monkeypatch, netf, B, kw):
+    """r05: where the head layers sit on split-K dense hidden layers, k_reduce_multi + k_head_td are ONE launch (red_head.hip: workgroup = 4 batch columns x stream x chunk
+    of 32 hidden rows, write-through hand-off to the column group's last arriver).  Both schedules (DQN_NO_RED_HEAD, read at dqn_engine_create) run the same chains: each
+    bit-exact against the twin -- single steps, explicit indices, the pipelined dqn_train_steps -- and against each other."""
+    net = netf()
+    outs = []
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("DQN_NO_RED_HEAD", "1")
+        gpu, cpu, hp = make_pair(pkg, net, B, cap=128, **kw)
+        monkeypatch.delenv("DQN_NO_RED_HEAD", raising=False)
+        fill((gpu, cpu), net, 100, seed=5)
+        set_same_params((gpu, cpu), net, seed=3)
+        for _ in range(2):
+            assert_step_bit_exact(gpu, cpu)
+        assert_step_bit_exact(gpu, cpu, np.random.default_rng(1).integers(0, 100, B))      # duplicates allowed
+        lg = gpu.train_steps(5)
+        for _ in range(5):
+            lc = cpu.train_step(want_td=False)
+        assert lg == lc
+        np.testing.assert_array_equal(gpu.get_grads(), cpu.get_grads())
+        np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+        np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
+        names = [n for n, _ in gpu.profile_step()]
+        assert ("red_head" in names) == fused and ("head_td" in names) == (not fused), names
+        if fused:
+            assert not any("fwd_reduce" in n for n in names), names
+        outs.append((gpu.get_params(0), gpu.get_adam_state()[0]))
+        gpu.close(); cpu.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0]); np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
 def test_nature_u8_b32_byte_arena_bit_exact(pkg):
     """u8 replay with the Nature-DQN first layer: the observation arena stays in BYTES (gather writes 1 byte per element, conv1's forward and dW
     tile loads convert byte / 255f0 exactly) -- every one of the 256 byte values occurs in the random rows; bit-exact vs the twin's plain

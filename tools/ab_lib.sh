@@ -5,7 +5,7 @@
 other=$1
 for i in 1 2 3; do
 for so in "" "$other"; do
-  DQN_MI355X_LIB=${so:+$PWD/$so} python bench.py --no-cpu-baseline --sustained-seconds 2 --per-call-steps 0 2>/dev/null | python tools/bench_summary.py /dev/stdin | head -1 | sed "s|^|${so:-in-tree} |"
+  DQN_MI355X_LIB=${so:+$PWD/$so} python bench.py --no-cpu-baseline --sustained-seconds 2 --per-call-steps 0 --no-secondary 2>/dev/null | python tools/bench_summary.py /dev/stdin | head -1 | sed "s|^|${so:-in-tree} |"
 done; done
 for so in "" "$other"; do
   DQN_MI355X_LIB=${so:+$PWD/$so} python bench.py --batch 512 --u8 --replay 200000 --device-fill --steps 100 --warmup 10 --no-cpu-baseline --env-steps 0 --sustained-seconds 0 2>/dev/null | python tools/bench_summary.py /dev/stdin | head -1 | sed "s|^|cfg5 ${so:-in-tree} |"
