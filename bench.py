@@ -41,6 +41,17 @@ def build_workload(pkg, args, rank, device):
         plan = [(args.conv_kc if (d.kind == pkg._abi.LAYER_CONV and d.cin * d.kh * d.kw > args.conv_kc) else p[0], p[1], p[2]) for d, p in zip(layers, pkg.default_plan(layers, hp))]
     if args.fc_kc:      # experiment knob: forward split-K chunk of the 3136-wide dense layers (the plan only fixes rounding order)
         plan = [(args.fc_kc if (d.kind == pkg._abi.LAYER_DENSE and d.n_in > 1024) else p[0], p[1], p[2]) for d, p in zip(layers, pkg.default_plan(layers, hp))]
+    if getattr(args, "dw_wgs", 0):      # experiment knob: conv dW split -- whole positions per chunk so that (K/64 row tiles) x chunks ~ dw_wgs workgroups (default plan: 512)
+        base = plan if plan is not None else pkg.default_plan(layers, hp)
+        plan = []
+        h = w = 84
+        for d, p in zip(layers, base):
+            if d.kind == pkg._abi.LAYER_CONV:
+                h, w = (h - d.kh) // d.sh + 1, (w - d.kw) // d.sw + 1
+                mrows = -(-(d.cin * d.kh * d.kw) // 64); st = max(1, -(-args.dw_wgs // mrows)); ppc = max(1, (h * w) // st)
+                plan.append((p[0], p[1], ppc * args.batch))
+            else:
+                plan.append(p)
     eng = pkg.Engine(layers, hp, plan=plan, device=device)
     params = nn.glorot_params(net, seed=1)           # identical replicas on every rank
     eng.set_params(params, pkg.NET_ONLINE)
@@ -324,6 +335,7 @@ def main():
     ap.add_argument("--env-steps", type=int, default=200, help="vector steps of the device-resident env loop timed after the main metric (0 = skip)")
     ap.add_argument("--conv-kc", type=int, default=0, help="experiment: forward split-K chunk of the conv layers")
     ap.add_argument("--fc-kc", type=int, default=0, help="experiment: override fwd_kc of the wide dense layers")
+    ap.add_argument("--dw-wgs", type=int, default=0, help="experiment: target workgroup count of the conv dW split (plan dw_kc)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` block (BASELINE configs[0], [3], [4] timed like `value`; default run at N = 1 on the headline workload only)")
     ap.add_argument("--distinct", action="store_true", help="hp.sample_distinct = 1 for the headline engine (the reference's replace=false draws, ...replay.jl:85)")
     ap.add_argument("--cpu-worker", default="", choices=["", "twin", "torch"], help=argparse.SUPPRESS)      # internal: the CPU-baseline subprocess (cpu_worker below)
