@@ -294,6 +294,22 @@ def secondary_block(pkg, args, device):
         e5.close(); out["config5"] = r
     except Exception as ex:
         out["config5"] = {"error": repr(ex)}
+    # ---- the headline configuration with the REFERENCE's sampling semantics: B distinct indices per batch (sample(...; replace=false), ...replay.jl:85; hp.sample_distinct)
+    try:
+        a2 = _ap.Namespace(**vars(args)); a2.distinct = True; a2.device_fill = True
+        e2, _, _, _, _, _ = build_workload(pkg, a2, 0, device)
+        r = timed_steps(e2, 300, 30)
+        for _ in range(3):
+            e2.train_step(want_td=False)
+        e2.sync(); t0 = time.perf_counter()
+        for _ in range(300):
+            e2.train_step(want_td=False)
+        e2.sync(); dt = time.perf_counter() - t0
+        r.update(workload="configs[1] with hp.sample_distinct = 1 (the reference's replace=false draws): " + workload_name(a2, 1), per_call_sync_us=dt / 300 * 1e6, per_call_sync_steps_per_s=300 / dt,
+                 parity_gate="tests/test_gpu_parity.py::test_train_steps_with_distinct_sampling_bit_exact + test_sampler_distinct_gpu_equals_twin")
+        e2.close(); out["config2_distinct"] = r
+    except Exception as ex:
+        out["config2_distinct"] = {"error": repr(ex)}
     out["seconds"] = time.perf_counter() - t_all
     return out
 
@@ -535,6 +551,7 @@ def main():
             "samples_per_s": value * args.batch,
             "roofline": roof, "cpu_baseline": cpu, "env_loop": env_loop, "sustained": sustained, "per_call": per_call, "host_fill": dict(HOST_FILL),
             "secondary": secondary,
+            "value_distinct": (secondary or {}).get("config2_distinct", {}).get("steps_per_s"),      # the same step with distinct sampling (secondary.config2_distinct)
         }
         print(json.dumps(out))
     group.barrier()

@@ -334,9 +334,30 @@ __device__ __forceinline__ void sample_distinct_fix(const float* __restrict__ tr
     }
 }
 #endif
+#ifdef __HIPCC__
+// hp.sample_distinct, by a whole workgroup: `list` holds the B stratified draws; every lane tests its draws against the ones before them (out of `taken`, O(B) per lane) and
+// only when some draw repeats an earlier one does ONE lane run the sequential redraw -- without a duplicate it would change nothing.  Every thread of the workgroup calls;
+// taken: B long longs, tp: B floats, any: one int of scratch (LDS).  k_sample, the priority block's pre-draw and the fused sample + gather workgroups all go through here:
+// the same list whichever of them draws it (r05: the reference's replace=false semantics on the fast path, ...replay.jl:85).
+__device__ __forceinline__ void sample_distinct_block(const float* __restrict__ tree, long long cap2, long long size, unsigned long long seed, unsigned long long ctr,
+                                                      int B, long long* list, long long* taken, float* tp, int* any) {
+    if (threadIdx.x == 0) *any = 0;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) taken[i] = list[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        const long long v = taken[i]; bool d = false;
+        for (int j = 0; j < i; j++) d = d || taken[j] == v;
+        if (d) *any = 1;
+    }
+    __syncthreads();
+    if (*any && threadIdx.x == 0) sample_distinct_fix(tree, cap2, size, seed, ctr, B, list, taken, tp);
+    __syncthreads();
+}
+#endif
 struct PrioArgs { int n; long long cap2; const long long* idx; const float* td; float eps, alpha; float* tree;
                   long long* idx_pre; unsigned long long seed; int B;       // idx_pre != nullptr: also draw the next step's B indices (see prio_block_run)
-                  int phase; };                                          // prio_block_fast only: 0 = update + draw, 1 = update, 2 = draw (split over two launches of one step)
+                  int phase;                                             // prio_block_fast only: 0 = update + draw, 1 = update, 2 = draw (split over two launches of one step)
+                  int distinct; };                                       // hp.sample_distinct: the pre-drawn list is deduped like sample()'s (sample_distinct_block)
 #ifdef __HIPCC__
 // the priority workgroup of a step: update_priorities!(replay, idx, td), then -- the tree is final and the Philox counter of the next sample()
 // is known (k_td / k_head_td bumped it earlier in this step) -- the NEXT step's B stratified descents, so that the next gather launch starts
@@ -459,9 +480,14 @@ __device__ __forceinline__ bool prio_block_fast(const PrioArgs& P, StepState* st
         }
         nd = tree_descend_from(tree, P.cap2, nd, m);
         long long leaf = nd - P.cap2; if (leaf >= size) leaf = size - 1;
-        P.idx_pre[t] = leaf;
+        if (P.distinct) node[t] = leaf; else P.idx_pre[t] = leaf;      // (the path state is free by now: the draws of a distinct list stay in LDS until they are deduped)
     }
     __syncthreads();
+    if (P.distinct) {
+        sample_distinct_block(tree, P.cap2, size, P.seed, ctr, B, node, lds + 64, reinterpret_cast<float*>(lds + 128), reinterpret_cast<int*>(lds + 160));
+        if (t < B) P.idx_pre[t] = node[t];
+        __syncthreads();
+    }
     if (threadIdx.x == 0) state->pre_valid = 1;
     return true;
 }
@@ -477,6 +503,15 @@ __device__ __forceinline__ void prio_block_run(const PrioArgs& P, StepState* sta
     __syncthreads();
     const unsigned long long ctr = ctr_in != ~0ull ? ctr_in : state->sample_ctr; const long long size = state->size;
     const float seg = P.tree[1] / (float)P.B;
+    if (P.distinct) {      // draws -> LDS, dedupe, publish; without room for the scratch (20 bytes per draw) nothing is pre-drawn: the next sample() draws itself
+        const unsigned have = lds_bytes ? lds_bytes : 8192u;
+        if ((unsigned)P.B * 20u + 8u > have) return;
+        long long* list = sidx; long long* taken = sidx + P.B; float* tp = reinterpret_cast<float*>(sidx + 2 * P.B); int* any = reinterpret_cast<int*>(tp + P.B);
+        for (int i = threadIdx.x; i < P.B; i += blockDim.x) list[i] = tree_descend(P.tree, P.cap2, size, P.seed, ctr, i, seg);
+        __syncthreads();
+        sample_distinct_block(P.tree, P.cap2, size, P.seed, ctr, P.B, list, taken, tp, any);
+        for (int i = threadIdx.x; i < P.B; i += blockDim.x) P.idx_pre[i] = list[i];
+    } else
     for (int i = threadIdx.x; i < P.B; i += blockDim.x) P.idx_pre[i] = tree_descend(P.tree, P.cap2, size, P.seed, ctr, i, seg);
     __syncthreads();
     if (threadIdx.x == 0) state->pre_valid = 1;
@@ -580,7 +615,8 @@ void launch_reduce_multi(hipStream_t st, const RSeg* segs_dev, int nseg, unsigne
 
 // get_batch scalars of the sampled transitions (a, r, done, IS weight: ...replay.jl:93-102), written by ONE workgroup of the gather launch
 // for the fused head kernel (a_out == nullptr: not wanted)
-struct BatchMeta { const int* a; const float* r; const unsigned char* done; float beta; int* a_out; float* r_out; float* done_out; float* w_out; };
+struct BatchMeta { const int* a; const float* r; const unsigned char* done; float beta; int* a_out; float* r_out; float* done_out; float* w_out;
+                   int distinct; /* hp.sample_distinct (B <= 64): a gather workgroup that draws the indices itself dedupes the list like sample() does */ };
 // The NEXT step's get_batch, run by the first workgroups of this step's Adam launch (inside dqn_train_steps(n): the host knows that a sampled
 // step follows and that nothing touches the replay in between).  By then every reader of the arena, of the batch scalars and of the index list
 // in this step is done, the tree is final (the priority block ran in an earlier backward launch and drew idx_pre), and the Philox counter of
@@ -615,7 +651,7 @@ void launch_td(hipStream_t st, const TdArgs& a);
 // the whole train step of a network that fits in LDS as ONE single-workgroup launch (tiny_step.hip; BASELINE config 1)
 #define TINY_MAX_LAYERS 8
 struct TinyArgs {
-    int nl, nlev, B, nA, E, ncon, dueling, double_q, obs_u8;
+    int nl, nlev, B, nA, E, ncon, dueling, double_q, obs_u8, distinct;
     int last_base, last_val, last_adv;
     float gamma, beta, prio_eps, prio_alpha;
     long long cap2; unsigned long long seed, P;

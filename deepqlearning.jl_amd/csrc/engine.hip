@@ -572,13 +572,16 @@ void enqueue_step(dqn_engine* e, bool sample, int phase) {
         } else {
             // the descent is fused into the gather (every workgroup repeats it) while that is cheaper than a launch of its own:
             // small batches.  At B = 512 / 1e6 leaves the repeats cost more than the ~5 us launch, so sample once, then gather.
-            const bool fused = sample && e->B <= 64 && !e->hp.sample_distinct;      // distinct indices: one workgroup draws AND dedupes, then the gather reads the list
+            // hp.sample_distinct (r05): the fused launch's workgroups dedupe the list themselves (gather_distinct_list) -- except on the u8-rows-to-float-arena kernel,
+            // which keeps its own index code: there one workgroup draws AND dedupes (k_sample), then the gather reads the list
+            const bool dist_fused_ok = !(e->hp.obs_dtype == DQN_OBS_U8 && !e->arena_u8 && (e->E & 3) == 0);
+            const bool fused = sample && e->B <= 64 && (!e->hp.sample_distinct || dist_fused_ok);
             if (e->step_take_pre || e->tiny) {}      // the previous step's Adam launch gathered this batch (PreGather) / the step's one launch gathers itself (tiny_step.hip)
             else {
             if (sample && !fused) RUN(e, "sample", launch_sample(e->stream, e->B, e->cap2, e->tree, e->hp.seed, e->idx, e->state, 0, e->hp.sample_distinct));    // k_td bumps the Philox counter
-            BatchMeta bm; bm.a = e->ra; bm.r = e->rr; bm.done = e->rdone; bm.beta = e->hp.prio_beta; bm.a_out = e->gb_a2; bm.r_out = e->gb_r2; bm.done_out = e->gb_done2; bm.w_out = e->gb_w2;
+            BatchMeta bm; bm.a = e->ra; bm.r = e->rr; bm.done = e->rdone; bm.beta = e->hp.prio_beta; bm.a_out = e->gb_a2; bm.r_out = e->gb_r2; bm.done_out = e->gb_done2; bm.w_out = e->gb_w2; bm.distinct = e->hp.sample_distinct ? 1 : 0;
             RUN(e, fused ? "sample_gather" : "gather", launch_gather_fb(e->stream, e->s_rows, e->sp_rows, e->hp.obs_dtype == DQN_OBS_U8, e->E, e->B, e->idx, e->x0,
-                                                                        fused ? 1 : 0, e->cap2, e->tree, e->hp.seed, e->state, bm, e->hp.sample_distinct ? nullptr : e->idx_pre, e->arena_u8 ? 1 : 0));
+                                                                        fused ? 1 : 0, e->cap2, e->tree, e->hp.seed, e->state, bm, (e->hp.sample_distinct && !fused) ? nullptr : e->idx_pre, e->arena_u8 ? 1 : 0));
             }
         }
         for (size_t i = 0; i < (phase == PH_PRE1 ? e->prog_pre1_end : e->prog_post_begin); i++) {

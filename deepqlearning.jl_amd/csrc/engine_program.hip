@@ -110,7 +110,7 @@ int build_program(dqn_engine* e) {
     }
     // ---------------- networks that fit in LDS: the WHOLE step is one single-workgroup launch (tiny_step.hip; BASELINE config 1)
     e->tiny = false;
-    if (!rec && !e->comm && !e->sim_world && e->world <= 1 && e->hp.prioritized_replay && !e->hp.sample_distinct && Bb <= 64 && e->nl <= TINY_MAX_LAYERS &&
+    if (!rec && !e->comm && !e->sim_world && e->world <= 1 && e->hp.prioritized_replay && Bb <= 64 && e->nl <= TINY_MAX_LAYERS &&
         (int)levels.size() <= TINY_MAX_LAYERS && e->Pint <= 16384 && (size_t)e->Pint * B <= 262144 /* ~5 MACs per parameter and column on ONE CU: <= ~9 us of arithmetic */ && !e->no_tiny) {
         bool ok = true; size_t fl = 0;
         TinyArgs a; memset(&a, 0, sizeof a);
@@ -121,7 +121,7 @@ int build_program(dqn_engine* e) {
         if (fl * 4 < 7808 + 64 * 4 + 1024) fl = (7808 + 64 * 4 + 1024) / 4;      // room for the priority block's path state (it reuses the whole region)
         ok = ok && fl * 4 <= 144 * 1024;      // one workgroup may hold up to 160 KB of LDS on gfx950 (beyond 64 KB the launcher raises the function's dynamic-LDS limit)
         if (ok) {
-            a.nl = e->nl; a.nlev = (int)levels.size(); a.B = B; a.nA = e->nA; a.E = e->E; a.ncon = ncon; a.dueling = e->hp.dueling; a.double_q = e->hp.double_q; a.obs_u8 = e->hp.obs_dtype == DQN_OBS_U8 ? 1 : 0;
+            a.nl = e->nl; a.nlev = (int)levels.size(); a.B = B; a.nA = e->nA; a.E = e->E; a.ncon = ncon; a.dueling = e->hp.dueling; a.double_q = e->hp.double_q; a.obs_u8 = e->hp.obs_dtype == DQN_OBS_U8 ? 1 : 0; a.distinct = e->hp.sample_distinct ? 1 : 0;
             a.last_base = e->last_base; a.last_val = e->last_val; a.last_adv = e->last_adv;
             a.gamma = e->hp.gamma; a.beta = e->hp.prio_beta; a.prio_eps = e->hp.prio_eps; a.prio_alpha = e->hp.prio_alpha; a.cap2 = e->cap2; a.seed = e->hp.seed; a.P = e->Pint;
             for (size_t li = 0; li < levels.size(); li++) { a.lev_n[li] = (int)levels[li].size(); a.lev_l[li][0] = levels[li][0]; a.lev_l[li][1] = levels[li].size() > 1 ? levels[li][1] : levels[li][0]; }
@@ -419,14 +419,16 @@ int build_program(dqn_engine* e) {
         return J;
     };
     auto prio_args = [&]() { PrioArgs pa; memset(&pa, 0, sizeof pa); pa.n = B; pa.cap2 = e->cap2; pa.idx = e->idx; pa.td = e->td; pa.eps = e->hp.prio_eps; pa.alpha = e->hp.prio_alpha; pa.tree = e->tree;
-                              if ((Bb <= 64 || e->prio_in_bwd) && !e->hp.sample_distinct) { pa.idx_pre = e->idx_pre; pa.seed = e->hp.seed; pa.B = Bb; }      // the fused sample+gather launch (B <= 64) consumes them
+                              // hp.sample_distinct: pre-drawn (and deduped by the priority block) for the small batches whose fused sample + gather launch understands the list
+                              const bool dist_ok = !e->hp.sample_distinct || (Bb <= 64 && !(e->hp.obs_dtype == DQN_OBS_U8 && !e->arena_u8 && (e->E & 3) == 0));
+                              if ((Bb <= 64 || e->prio_in_bwd) && dist_ok) { pa.idx_pre = e->idx_pre; pa.seed = e->hp.seed; pa.B = Bb; pa.distinct = e->hp.sample_distinct ? 1 : 0; }      // the fused sample+gather launch (B <= 64) consumes them
                               return pa; };
     const bool prio_in_adam = e->hp.prioritized_replay && !rec && (Bb <= 64 || e->prio_in_bwd);      // larger batches: a backward launch's workgroup, or the side stream (prio_fork)
     // pre-gather (common.h PreGather): needs the priority block (which also draws the next indices) OUT of the Adam launch -- it rides as
     // workgroup 0 of the first LDS-tiled backward launch instead
     // large batches: the priority update runs on the side stream (prio_fork) and draws the next indices there; k_td takes the pre-drawn batch
     const bool pg_want = e->hp.prioritized_replay && !rec && (prio_in_adam ? (fuse_heads || e->prio_in_bwd) : e->prio_forked) && !early && !e->sim_world &&
-                         (e->hp.obs_dtype != DQN_OBS_U8 || e->arena_u8) && !e->opt.no_pregather && !e->hp.sample_distinct;      // distinct mode: sample launch + gather launch every step      // u8 rows: only onto the byte arena
+                         (e->hp.obs_dtype != DQN_OBS_U8 || e->arena_u8) && !e->opt.no_pregather && (!e->hp.sample_distinct || Bb <= 64);      // distinct mode at B > 64: sample launch + gather launch every step      // u8 rows: only onto the byte arena
     // layer l's gradient is final: queue its parameter range (split-K layers: as a slab segment)
     auto adam_queue = [&](int l, const std::vector<RSeg>& segs_known) {
         const LayerDev& L = e->L[l]; PItem it; it.beg = L.w_off; it.end = l + 1 < e->nl ? e->L[l + 1].w_off : e->Pint; it.part = nullptr; it.S = 0;
@@ -756,6 +758,7 @@ int build_program(dqn_engine* e) {
         memset(&e->pg, 0, sizeof e->pg); e->pg_ok = pg_want && (prio_placed || e->prio_forked);
         if (e->pg_ok) {
             PreGather& G = e->pg; G.on = 1; G.s_rows = e->s_rows; G.sp_rows = e->sp_rows; G.E = e->E; G.B = B; G.idx_pre = e->idx_pre; G.x0 = e->x0; G.cap2 = e->cap2; G.tree = e->tree; G.seed = e->hp.seed;
+            G.meta.distinct = e->hp.sample_distinct ? 1 : 0;
             G.meta.a = e->ra; G.meta.r = e->rr; G.meta.done = e->rdone; G.meta.beta = e->hp.prio_beta; G.meta.a_out = e->gb_a2; G.meta.r_out = e->gb_r2; G.meta.done_out = e->gb_done2; G.meta.w_out = e->gb_w2;
             G.u8b = e->arena_u8 ? 1 : 0;
             if (G.u8b) { G.gx = (e->E + 255) / 256; G.gy = (2 * B + 127) / 128; } else { G.gx = (e->E + 63) / 64; G.gy = (2 * B + 63) / 64; }

@@ -19,18 +19,33 @@ __device__ __forceinline__ void gather_batch_meta(const BatchMeta& M, const long
     const float x = (float)state->size * p;                     // n .* p
     M.w_out[c] = (float)pow((double)x, -(double)M.beta);        // .^ (-beta), :102
 }
+// hp.sample_distinct on the fused sample + gather path (B <= 64): the workgroup reproduces the WHOLE list -- the pre-drawn, already deduped one when it is valid, else the B
+// stratified draws followed by sample()'s dedupe (sample_distinct_block: deterministic, so every workgroup of the launch arrives at the same list) -- into `dl`
+__device__ __forceinline__ void gather_distinct_list(long long* dl, int B, long long cap2, const float* __restrict__ tree, unsigned long long seed, const StepState* __restrict__ state,
+                                                     const long long* __restrict__ idx_pre) {
+    __shared__ long long gd_taken[64]; __shared__ float gd_tp[64]; __shared__ int gd_any;
+    const bool pre = idx_pre && state->pre_valid;
+    const long long size = state->size; const unsigned long long ctr = state->sample_ctr;
+    if ((int)threadIdx.x < B) dl[threadIdx.x] = pre ? idx_pre[threadIdx.x] : tree_descend(tree, cap2, size, seed, ctr, (int)threadIdx.x, tree[1] / (float)B);
+    __syncthreads();
+    if (!pre) sample_distinct_block(tree, cap2, size, seed, ctr, B, dl, gd_taken, gd_tp, &gd_any);
+}
 // (bx, by): the 64-feature x 64-column tile; tile: 64 x 65 floats of LDS; rows: 64 long longs of LDS
 __device__ __forceinline__ void gather_fb_body(const void* __restrict__ s_rows, const void* __restrict__ sp_rows, int u8, int E, int B,
                                                long long* __restrict__ idx, float* __restrict__ x0, int do_sample, long long cap2,
                                                const float* __restrict__ tree, unsigned long long seed, const StepState* __restrict__ state, const BatchMeta& meta,
                                                const long long* __restrict__ idx_pre, int bx, int by, float (*tile)[65], long long* rows) {
     const int f0 = bx * 64, c0 = by * 64, lane = threadIdx.x & 63, w = threadIdx.x >> 6, ld = 2 * B;
+    __shared__ long long gd_list[64];
+    const bool dist = do_sample && meta.distinct && B <= 64;
+    if (dist) gather_distinct_list(gd_list, B, cap2, tree, seed, state, idx_pre);
     if (threadIdx.x < 64) {
         const int c = c0 + threadIdx.x;
         long long r = 0;
         if (c < ld) {
             const int i = c < B ? c : c - B;
-            if (do_sample) {
+            if (dist) { r = gd_list[i]; if (bx == 0 && c < B) idx[i] = r; }
+            else if (do_sample) {
                 // the indices of this sample() were drawn in the tail of the previous step's priority block unless something changed the tree since
                 r = (idx_pre && state->pre_valid) ? idx_pre[i] : tree_descend(tree, cap2, state->size, seed, state->sample_ctr, i, tree[1] / (float)B);
                 if (bx == 0 && c < B) idx[i] = r;
@@ -100,12 +115,16 @@ __device__ __forceinline__ void gather_u8b_body(const unsigned char* __restrict_
                                                 const float* __restrict__ tree, unsigned long long seed, const StepState* __restrict__ state, const BatchMeta& meta,
                                                 const long long* __restrict__ idx_pre, int bx, int by, uint32_t* tile32, long long* rows) {
     const int f0 = bx * 256, c0 = by * 128, ld = 2 * B;
+    __shared__ long long gd_list[64];
+    const bool dist = do_sample && meta.distinct && B <= 64;
+    if (dist) gather_distinct_list(gd_list, B, cap2, tree, seed, state, idx_pre);
     if (threadIdx.x < 128) {
         const int c = c0 + threadIdx.x;
         long long r = 0;
         if (c < ld) {
             const int i = c < B ? c : c - B;
-            if (do_sample) {
+            if (dist) { r = gd_list[i]; if (bx == 0 && c < B) idx[i] = r; }
+            else if (do_sample) {
                 r = (idx_pre && state->pre_valid) ? idx_pre[i] : tree_descend(tree, cap2, state->size, seed, state->sample_ctr, i, tree[1] / (float)B);
                 if (bx == 0 && c < B) idx[i] = r;
             } else r = idx[i];

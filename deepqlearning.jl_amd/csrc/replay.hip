@@ -176,22 +176,10 @@ __global__ __launch_bounds__(1024) void k_sample(int B, long long cap2, const fl
     const long long size = state->size;
     const float total = tree[1], seg = total / (float)B;
     for (int i = threadIdx.x; i < B; i += blockDim.x) idx[i] = tree_descend(tree, cap2, size, seed, ctr, i, seg);
-    if (distinct && B <= 1024) {      // hp.sample_distinct: redraw later duplicates on the residual priorities (see sample_distinct_fix)
-        // the duplicate test of the UNTOUCHED draws runs on all lanes (lane i against the draws before it, out of LDS: O(B) per lane); only when some draw repeats an earlier
-        // one does the sequential fix run at all -- without a duplicate it changes nothing, so the common case costs microseconds instead of lane 0's O(B^2) scan
-        // (~0.5 ms at B = 512)
+    if (distinct && B <= 1024) {      // hp.sample_distinct: redraw later duplicates on the residual priorities (sample_distinct_block / sample_distinct_fix, common.h)
         __shared__ int any_dup;
-        if (threadIdx.x == 0) any_dup = 0;
         __syncthreads();
-        for (int i = threadIdx.x; i < B; i += blockDim.x) taken[i] = idx[i];
-        __syncthreads();
-        for (int i = threadIdx.x; i < B; i += blockDim.x) {
-            const long long v = taken[i]; bool d = false;
-            for (int j = 0; j < i; j++) d = d || taken[j] == v;
-            if (d) any_dup = 1;
-        }
-        __syncthreads();
-        if (any_dup && threadIdx.x == 0) sample_distinct_fix(tree, cap2, size, seed, ctr, B, idx, taken, tp);
+        sample_distinct_block(tree, cap2, size, seed, ctr, B, idx, taken, tp, &any_dup);
     }
     __syncthreads();
     if (threadIdx.x == 0 && bump) { state->sample_ctr = ctr + 1; state->pre_valid = 0; }      // pre-drawn indices belonged to the counter just consumed

@@ -57,11 +57,20 @@ __global__ __launch_bounds__(NTH) void k_tiny_step(const TinyArgs* __restrict__ 
     }
     if (tid >= 64 && tid < 64 + nlev) { const int v = tid - 64; LEV[v][0] = A.lev_n[v]; LEV[v][1] = A.lev_l[v][0]; LEV[v][2] = A.lev_l[v][1]; }
     for (int i = tid; i < P; i += NTH) { Pon[i] = A.p_on[i]; Ptg[i] = A.p_tg[i]; Gs[i] = 0.0f; }
+    // hp.sample_distinct (r05): a sample() that is not pre-drawn is deduped like k_sample's (sample_distinct_block; the pre-drawn list already is) -- a uniform branch
+    const bool draw_distinct = A.distinct && sample && !(A.idx_pre && pv);
+    if (draw_distinct) {
+        __shared__ long long t_list[64], t_taken[64]; __shared__ float t_tp[64]; __shared__ int t_any;
+        if (tid < B) t_list[tid] = tree_descend(A.tree, A.cap2, size, A.seed, ctr0, tid, A.tree[1] / (float)B);
+        __syncthreads();
+        sample_distinct_block(A.tree, A.cap2, size, A.seed, ctr0, B, t_list, t_taken, t_tp, &t_any);
+        if (tid < ld0) r_pre = t_list[bcol];
+    }
     // ---- sample() + get_batch (...replay.jl:82-102): thread c < 2B owns arena column c; the first B also fetch the batch scalars and the IS weight
     if (tid < ld0) {
         long long r = r_pre;
         // the indices of this sample() were drawn in the tail of the previous step's priority block unless something changed the tree since
-        if (sample && !(A.idx_pre && pv)) r = tree_descend(A.tree, A.cap2, size, A.seed, ctr0, bcol, A.tree[1] / (float)B);
+        if (sample && !(A.idx_pre && pv) && !draw_distinct) r = tree_descend(A.tree, A.cap2, size, A.seed, ctr0, bcol, A.tree[1] / (float)B);
         const bool first = tid < B;
         int a_ = 0; float rw_ = 0.0f, dn_ = 0.0f, leaf_ = 0.0f, tot_ = 1.0f;
         if (first) { a_ = A.ra[r]; rw_ = A.rr[r]; dn_ = (float)A.rdone[r]; leaf_ = A.tree[A.cap2 + r]; tot_ = A.tree[1]; if (sample) A.idx[tid] = r; }
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(NTH) void k_tiny_step(const TinyArgs* __restrict__ 
     if (stop == 6) return;
     // ---- phase 5: update_priorities!(replay, idx, td) + the next sample()'s stratified draws (the tree is final, the Philox counter is known)
     PrioArgs pa; pa.n = B; pa.cap2 = A.cap2; pa.idx = A.idx; pa.td = A.td; pa.eps = A.prio_eps; pa.alpha = A.prio_alpha; pa.tree = A.tree;
-    pa.idx_pre = A.idx_pre; pa.seed = A.seed; pa.B = B; pa.phase = 0;
+    pa.idx_pre = A.idx_pre; pa.seed = A.seed; pa.B = B; pa.phase = 0; pa.distinct = A.distinct;
     prio_block_run(pa, st, reinterpret_cast<long long*>(sm), A.lds_bytes, nullptr, sample ? ctr0 + 1 : ctr0);
 }
 int launch_tiny_step(hipStream_t st, const TinyArgs* a_dev, unsigned lds_bytes, int sample, int stop) {

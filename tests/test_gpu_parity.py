@@ -675,13 +675,18 @@ def test_sampler_distinct_gpu_equals_twin(pkg):
     np.testing.assert_array_equal(g, c)
 
 
-@pytest.mark.parametrize("B,cap", [(32, 64), (128, 200)], ids=["B32_fused_heads", "B128_large_batch_path"])
-def test_train_steps_with_distinct_sampling_bit_exact(pkg, B, cap):
-    """train steps in distinct mode (sample launch + gather launch, no pre-drawn indices, no pre-gather): sampled indices never repeat inside a
-    batch even with a dominant priority, and indices / TD errors / loss / parameters equal the twin's bit for bit, single steps and train_steps(n)."""
-    net = small_conv_dueling()
-    gpu, cpu, hp = make_pair(pkg, net, B, cap=cap, sample_distinct=1, learning_rate=1e-3)
-    fill((gpu, cpu), net, cap, seed=4)
+@pytest.mark.parametrize("netf,B,cap,kw", [(small_conv_dueling, 32, 64, {}), (small_conv_dueling, 128, 200, {}), (cfg1_mlp_dueling, 32, 64, {}), (cfg1_mlp_dueling, 32, 64, dict(_tiny=False)),
+                                           (mid_conv_dueling, 16, 64, dict(obs_dtype=1))],
+                         ids=["B32_fused_heads", "B128_large_batch_path", "cfg1_single_launch_step", "cfg1_multi_launch", "u8_byte_arena"])
+def test_train_steps_with_distinct_sampling_bit_exact(pkg, netf, B, cap, kw):
+    """train steps in distinct mode (...replay.jl:85, replace=false): sampled indices never repeat inside a batch even with a dominant priority, and indices / TD errors /
+    loss / parameters equal the twin's bit for bit, single steps and train_steps(n).  r05: at B <= 64 the mode keeps the fast path -- the priority block dedupes the list
+    it pre-draws, the fused sample + gather workgroups (and the single-launch step) dedupe a list they draw themselves, dqn_train_steps pre-gathers as in the default
+    mode; larger batches keep the sample launch + gather launch."""
+    net = netf()
+    u8 = kw.get("obs_dtype", 0) == 1
+    gpu, cpu, hp = make_pair(pkg, net, B, cap=cap, sample_distinct=1, learning_rate=1e-3, **kw)
+    fill((gpu, cpu), net, cap, seed=4, u8=u8)
     set_same_params((gpu, cpu), net)
     big = np.full(cap, 0.01, np.float32); big[5] = 50.0                 # one transition dominates: the stratified default would repeat it
     for h in (gpu, cpu):
@@ -698,6 +703,25 @@ def test_train_steps_with_distinct_sampling_bit_exact(pkg, B, cap):
     assert len(set(gpu.last_indices().tolist())) == B
     np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
     np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
+    # a long pipelined run with replay writes in between (they invalidate the pre-drawn list: the next gather draws and dedupes itself)
+    rng = np.random.default_rng(2)
+    for n in (5, 1, 7):
+        lg = gpu.train_steps(n)
+        for _ in range(n):
+            lc = cpu.train_step(want_td=False)
+        assert lg == lc, (n, lg, lc)
+        assert len(set(gpu.last_indices().tolist())) == B
+        if u8:
+            s = rng.integers(0, 256, (3,) + net.obs_shape).astype(np.uint8)
+        else:
+            s = rng.random((3,) + net.obs_shape, dtype=np.float32)
+        for h in (gpu, cpu):
+            h.replay_add(s, np.zeros(3, np.int32), np.full(3, 30.0, np.float32), s, np.zeros(3, np.uint8))      # heavy new transitions: duplicates likely among the stratified draws
+    np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+    np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
+    names = [n for n, _ in gpu.profile_step()]
+    if B <= 64 and (not u8 or gpu.batch_arena_elem_bytes() == 1):
+        assert "sample" not in names, names          # no separate sample launch on the small-batch path (u8 rows into a FLOAT arena keep it: that gather kernel has its own index code)
     gpu.close(); cpu.close()
 
 
