@@ -79,7 +79,7 @@ class EnvSpec(C.Structure):
 
 class RolloutCfg(C.Structure):
     _fields_ = [("train_freq", C.c_int32), ("target_update_freq", C.c_int32),
-                ("eps_start", C.c_float), ("eps_stop", C.c_float), ("eps_steps", C.c_float), ("t0", C.c_int64)]
+                ("eps_start", C.c_float), ("eps_stop", C.c_float), ("eps_steps", C.c_float), ("cadence_env_steps", C.c_int32), ("t0", C.c_int64)]
 
 
 class RolloutStats(C.Structure):
@@ -464,8 +464,9 @@ class Handle:
     def envs_reset(self):
         self._check(self.f["envs_reset"](self._h))
 
-    def rollout(self, n_steps, t0=1, train_freq=4, target_update_freq=500, eps=(1.0, 0.01, 5000.0), stats=True):
-        cfg = RolloutCfg(int(train_freq), int(target_update_freq), float(eps[0]), float(eps[1]), float(eps[2]), int(t0))
+    def rollout(self, n_steps, t0=1, train_freq=4, target_update_freq=500, eps=(1.0, 0.01, 5000.0), stats=True, env_step_cadence=False):
+        """env_step_cadence: train_freq / target_update_freq count ENV steps as in the reference's loop (src/solver.jl:136-145) instead of vector steps"""
+        cfg = RolloutCfg(int(train_freq), int(target_update_freq), float(eps[0]), float(eps[1]), float(eps[2]), 1 if env_step_cadence else 0, int(t0))
         st = RolloutStats()
         self._check(self.f["rollout"](self._h, int(n_steps), C.byref(cfg), C.byref(st) if stats else None))
         return dict(episodes=st.episodes, reward_sum=st.reward_sum, train_steps=st.train_steps, loss=st.last_loss, grad_norm=st.last_grad_norm) if stats else None

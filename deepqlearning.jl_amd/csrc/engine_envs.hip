@@ -163,9 +163,19 @@ extern "C" int dqn_rollout(dqn_engine_t* e, int n_steps, const dqn_rollout_cfg* 
     // before the cycle's last step
     const bool single = e->world <= 1 && !(e->comm && e->force_comm);
     const int F = cfg->train_freq > 0 ? cfg->train_freq : 4;
-    const bool cyc = graph && single && F >= 2 && F <= 16 && !e->opt.no_rollout_cycle;
+    const bool envc = cfg->cadence_env_steps != 0;      // train_freq / target_update_freq count ENV steps (src/solver.jl:136-145): n / train_freq train steps per vector step
+    const bool cyc = graph && single && F >= 2 && F <= 16 && !e->opt.no_rollout_cycle && !envc;
     for (int k = 0; k < n_steps; k++) {
         const long long t = cfg->t0 + k;
+        if (envc) {
+            if (graph) HIPCHK(hipGraphLaunch(e->act.graph, e->stream));
+            else for (auto& s : e->act.steps) { prof_begin(e, s.name); s.fn(e); prof_end(e); }
+            e->widx = (e->widx + n) % e->cap; e->size = std::min(e->cap, e->size + n);
+            const long long due = cfg->train_freq > 0 ? (t * n) / cfg->train_freq - ((t - 1) * n) / cfg->train_freq : 0;
+            if (due > 0 && e->size >= e->B) { if (dqn_train_steps(e, (int)due, nullptr, nullptr)) return -1; trained += due; }      // back to back: the pipelined gather applies
+            if (cfg->target_update_freq > 0 && (t * n) / cfg->target_update_freq != ((t - 1) * n) / cfg->target_update_freq) { if (dqn_sync_target(e)) return -1; }
+            continue;
+        }
         if (cyc && k + F <= n_steps) {
             const long long tl = t + F - 1;      // the cycle's last step
             bool ok = cfg->train_freq > 0 ? (tl % cfg->train_freq == 0 && std::min(e->cap, e->size + (long long)F * n) >= e->B) : true;

@@ -387,7 +387,7 @@ struct EnvSpec
     reward_xy::NTuple{16,Int32}; reward_val::NTuple{8,Float32}                # SimpleGridWorld reward cells (x1,y1,x2,y2,...)
 end
 struct RolloutCfg
-    train_freq::Int32; target_update_freq::Int32; eps_start::Float32; eps_stop::Float32; eps_steps::Float32; t0::Int64
+    train_freq::Int32; target_update_freq::Int32; eps_start::Float32; eps_stop::Float32; eps_steps::Float32; cadence_env_steps::Int32; t0::Int64
 end
 mutable struct RolloutStats
     episodes::Int64; reward_sum::Float64; train_steps::Int64; last_loss::Float32; last_grad_norm::Float32
@@ -410,10 +410,11 @@ function evaluate(e::Engine, n_eval, max_episode_length; seed = 0)              
     check(ccall((:dqn_evaluate, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, UInt64, Ref{Float64}, Ref{Float64}), e.h, n_eval, max_episode_length, seed, r, st))
     r[], st[]
 end
-function rollout!(e::Engine, n_steps; t0 = 1, train_freq = 4, target_update_freq = 500, eps = (1f0, 0.01f0, 5000f0))
+# env_step_cadence = true: train_freq / target_update_freq count ENV steps as dqn_train! does (src/solver.jl:136-145) -- n / train_freq train steps per vector step
+function rollout!(e::Engine, n_steps; t0 = 1, train_freq = 4, target_update_freq = 500, eps = (1f0, 0.01f0, 5000f0), env_step_cadence = false)
     st = RolloutStats()
     check(ccall((:dqn_rollout, LIB), Cint, (Ptr{Cvoid}, Cint, Ref{RolloutCfg}, Ref{RolloutStats}), e.h, n_steps,
-                RolloutCfg(train_freq, target_update_freq, eps[1], eps[2], eps[3], t0), st))
+                RolloutCfg(train_freq, target_update_freq, eps[1], eps[2], eps[3], env_step_cadence ? 1 : 0, t0), st))
     st
 end
 

@@ -235,6 +235,11 @@ typedef struct {
 typedef struct {
     int32_t train_freq, target_update_freq;     /* solver.train_freq (4), solver.target_update_freq (500); 0 = never */
     float eps_start, eps_stop, eps_steps;       /* LinearDecaySchedule(start, stop, steps) of the exploration policy */
+    int32_t cadence_env_steps;                  /* (r05; occupies what was padding: offsets and size unchanged)  0: train_freq / target_update_freq count VECTOR steps -- one
+                                                 * train step per train_freq steps of all n copies.  1: they count ENV steps as the reference's loop does (src/solver.jl:136-145):
+                                                 * after vector step t, floor(t*n / train_freq) - floor((t-1)*n / train_freq) train steps run back to back (8 per vector step
+                                                 * for 32 copies at train_freq = 4) and the target network is synced whenever a multiple of target_update_freq env steps
+                                                 * was crossed.  The n transitions of a vector step are added BEFORE its train steps (the reference interleaves them). */
     int64_t t0;                                 /* global index of the first vector step of this call (t counts from 1) */
 } dqn_rollout_cfg;
 typedef struct { int64_t episodes; double reward_sum; int64_t train_steps; float last_loss, last_grad_norm; } dqn_rollout_stats;

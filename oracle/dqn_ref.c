@@ -1200,6 +1200,12 @@ int ref_rollout(ref_engine* e, int n_steps, const dqn_rollout_cfg* cfg, dqn_roll
         for (int i = 0; i < n; i++) if (v->dones[i] || v->ep_step[i] >= v->sp.max_episode_length) {
             v->fin_eps[i] += 1; v->fin_reward[i] += (double)v->ep_reward[i]; envs_reset_one(v, i, (uint64_t)t);
         }
+        if (cfg->cadence_env_steps) {      /* train_freq / target_update_freq count ENV steps (src/solver.jl:136-145); the n transitions of the vector step are already in the replay */
+            int64_t due = cfg->train_freq > 0 ? (t * n) / cfg->train_freq - ((t - 1) * n) / cfg->train_freq : 0;
+            if (e->size >= e->B) for (int64_t q = 0; q < due; q++) { if (ref_train_step(e, NULL, &loss, &gn, NULL)) return -1; trained++; }
+            if (cfg->target_update_freq > 0 && (t * n) / cfg->target_update_freq != ((t - 1) * n) / cfg->target_update_freq) ref_sync_target(e);
+            continue;
+        }
         if (cfg->train_freq > 0 && t % cfg->train_freq == 0 && e->size >= e->B) { if (ref_train_step(e, NULL, &loss, &gn, NULL)) return -1; trained++; }
         if (cfg->target_update_freq > 0 && t % cfg->target_update_freq == 0) ref_sync_target(e);
     }

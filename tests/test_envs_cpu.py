@@ -129,6 +129,23 @@ def test_training_cadence_and_target_sync():
     assert not np.array_equal(tw.get_params(0), p0)
 
 
+def test_env_step_cadence_counts_env_steps_like_the_reference():
+    """cadence_env_steps = 1: train_freq / target_update_freq count ENV steps (src/solver.jl:136-145): with n = 6 copies and train_freq = 4 a vector step t
+    is followed by floor(6t / 4) - floor(6(t-1) / 4) train steps (1, 2, 1, 2, ...), and the target net syncs when a multiple of target_update_freq is crossed"""
+    net = EC.testmdp_conv_dueling()
+    tw, hp = make_twin(net, B=6, cap=128)
+    p0 = EC.same_params([tw], net)
+    tw.envs_create(envs.TestMDP((14, 12), 4, 6, n=6, seed=1), seed=1)
+    st = tw.rollout(4, t0=1, train_freq=4, target_update_freq=0, env_step_cadence=True)      # 24 env steps -> 6 train steps
+    assert st["train_steps"] == 6
+    np.testing.assert_array_equal(tw.get_params(1), p0)
+    st = tw.rollout(1, t0=5, train_freq=4, target_update_freq=30, env_step_cadence=True)     # env steps 25..30: one train step (28), sync at 30
+    assert st["train_steps"] == 1
+    np.testing.assert_array_equal(tw.get_params(1), tw.get_params(0))
+    st = tw.rollout(2, t0=6, train_freq=0, target_update_freq=0, env_step_cadence=True)      # train_freq = 0: acting only
+    assert st["train_steps"] == 0
+
+
 def test_evaluate_matches_host_rollout():
     """ref_evaluate = basic_evaluation (src/evaluation_policy.jl:17-42): greedy episodes, undiscounted Float64 return, step count;
     `while !done && step <= max_episode_length` runs max_episode_length + 1 steps when the episode does not end."""
