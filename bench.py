@@ -90,6 +90,7 @@ def build_workload(pkg, args, rank, device):
 HOST_FILL = {}
 
 
+args_ms_plain = [None]      # ms per step of the headline run (read by secondary_block's dp_model)
 ADAM_SLAB_BYTES = [0.0]     # the engine's OWN overhead inside k_adam (conv dW split-K slabs it reduces): reported beside, never inside, the 8(d) floor
 
 
@@ -294,6 +295,35 @@ def secondary_block(pkg, args, device):
         e5.close(); out["config5"] = r
     except Exception as ex:
         out["config5"] = {"error": repr(ex)}
+    # ---- what a replica step costs BEFORE any wire time, measured at world 1 through a real RCCL communicator (ncclCommInitRank + ncclAllGather of one rank inside the step
+    # graph): the numbers a future multi-GPU SCALE line can be checked against.  Nothing here is a scaling measurement.
+    try:
+        os.environ["DQN_FORCE_ALLREDUCE"] = "1"
+        a3 = _ap.Namespace(**vars(args)); a3.distinct = False; a3.device_fill = True
+        e3, _, _, _, _, _ = build_workload(pkg, a3, 0, device)
+        e3.comm_init(pkg.comm_unique_id(), 0, 1)
+        os.environ.pop("DQN_FORCE_ALLREDUCE", None)
+        r = timed_steps(e3, 300, 30)
+        prof = launch_profile(e3, 10)
+        L = {k: v[0] / v[1] * 1e3 for k, v in prof.items()}
+        xb = e3.comm_exchange_bytes()
+        plain_us = 1e3 * args_ms_plain[0] if args_ms_plain[0] else None
+        link = 153e9      # one xGMI link, bytes/s (MI355X guide)
+        def model(N):      # replica step at N ranks = measured world-1 replica step + (N - 1) x the wide dW's per-rank-block K tiles + the all-gather over point-to-point links
+            wide = sum(v for k, v in L.items() if k.startswith("dp_dw"))
+            ag_direct = xb / link * 1e6 if N > 1 else 0.0; ag_ring = (N - 1) * xb / link * 1e6
+            return {"wide_dw_us": round(wide * N, 1), "allgather_direct_us": round(ag_direct, 1), "allgather_ring_us": round(ag_ring, 1), "rccl_latency_us": "10-20 (not measurable at world 1)",
+                    "predicted_step_us_direct": round(r["ms_per_step"] * 1e3 + wide * (N - 1) + ag_direct + 15.0, 1), "predicted_step_us_ring": round(r["ms_per_step"] * 1e3 + wide * (N - 1) + ag_ring + 15.0, 1)}
+        out["dp_model"] = {"measured_world1": {"replica_step_us": round(r["ms_per_step"] * 1e3, 2), "plain_step_us": plain_us, "steps_per_s": r["steps_per_s"],
+                                                "pack_us": round(sum(v for k, v in L.items() if k.startswith("dp_pack")), 2), "wide_dw_us": round(sum(v for k, v in L.items() if k.startswith("dp_dw")), 2),
+                                                "unpack_sum_us": round(L.get("dp_sum_ranks", 0.0), 2), "launches": {k: round(v, 2) for k, v in L.items()}},
+                           "exchange_bytes_per_rank": xb, "rccl_nranks": e3.comm_info()["rccl_nranks"],
+                           "model": {f"N={N}": model(N) for N in (2, 4, 8)},
+                           "note": "world-1 measurement through a real communicator + a point-to-point xGMI model (153 GB/s per link, one link per peer pair); predicted_step_us = replica step + (N-1) x wide dW K tiles + all-gather + 15 us RCCL latency; UNMEASURED beyond world 1"}
+        e3.close()
+    except Exception as ex:
+        os.environ.pop("DQN_FORCE_ALLREDUCE", None)
+        out["dp_model"] = {"error": repr(ex)}
     # ---- the headline configuration with the REFERENCE's sampling semantics: B distinct indices per batch (sample(...; replace=false), ...replay.jl:85; hp.sample_distinct)
     try:
         a2 = _ap.Namespace(**vars(args)); a2.distinct = True; a2.device_fill = True
@@ -537,6 +567,7 @@ def main():
         secondary = None
         if world == 1 and not args.no_secondary and args.batch == 32 and not args.u8 and not args.distinct:
             eng.close()
+            args_ms_plain[0] = ms_per_step
             secondary = secondary_block(pkg, args, local_rank)
         cpu = None
         if not args.no_cpu_baseline:           # rank 0 only (this block), at any world size

@@ -133,6 +133,7 @@ PROTOS = {
     "comm_unique_id": [_vp],
     "comm_init": [_vp, _vp, C.c_int, C.c_int],
     "comm_info": [_vp, _P(CommInfo)],
+    "comm_exchange_bytes": [_vp, _P(C.c_int64)],
     "sim_ranks_step": [_vp, _i64p, _f32p, _f32p, _f32p],
     "debug_ktrace": [_vp, _P(C.c_uint64), _sz],
     "stream_sync": [_vp],
@@ -341,6 +342,11 @@ class Handle:
         ci = CommInfo()
         self._check(self.f["comm_info"](self._h, C.byref(ci)))
         return {n: int(getattr(ci, n)) for n, _ in ci._fields_}
+
+    def comm_exchange_bytes(self):
+        n = C.c_int64()
+        self._check(self.f["comm_exchange_bytes"](self._h, C.byref(n)))
+        return n.value
 
     def train_step_async(self, idx=None):
         """enqueue one batch_train! and return at once; the ticket names the (loss, grad_norm) record the step's last launch publishes to the host mailbox"""

@@ -1094,6 +1094,12 @@ extern "C" int dqn_comm_info(dqn_engine_t* e, dqn_comm_info_t* out) { if (!e || 
     return 0;
 }
 
+extern "C" int dqn_comm_exchange_bytes(dqn_engine_t* e, int64_t* bytes) { if (!e || !bytes) return fail("null argument");
+    *bytes = 0;
+    if ((e->comm || e->sim_world) && e->prog_built) *bytes = (int64_t)(e->dp_gather ? e->dp_count : e->Pint) * 4;
+    return 0;
+}
+
 // ---------------------------------------------------------------- misc
 extern "C" int dqn_stream_sync(dqn_engine_t* e) { if (!e) return fail("null engine handle"); HIPCHK(hipSetDevice(e->device)); HIPCHK(hipStreamSynchronize(e->stream)); return 0; }
 extern "C" int dqn_stream_handle(dqn_engine_t* e, void** s) { if (!e) return fail("null engine handle"); *s = (void*)e->stream; return 0; }

@@ -172,7 +172,6 @@ int build_program(dqn_engine* e) {
     float* hl_buf = fuse_heads ? palloc(e, (size_t)B) : nullptr;      // per-column Huber terms (folded into the loss by a tail task)
     float* actT[DQN_MAX_LAYERS][2] = {};                             // transposed copies [column][feature] of the head layers' inputs (written by the split-K reduce)
     bool wantT[DQN_MAX_LAYERS] = {};
-    if (fuse_heads) for (int l : levels.back()) if (e->L[l].src >= 0) wantT[e->L[l].src] = true;
     // ---------------- r05: when the head layers sit on dense hidden layers whose forward ran split-K, the split-K reduce AND the head level are ONE chip-filling launch
     // (red_head.hip: workgroup = 4 batch columns x stream x plan chunk of 32 hidden rows, the last arriver of a column group does TD + the heads' dX) instead of
     // k_reduce_multi (384 workgroups) + k_head_td (B workgroups)
@@ -185,6 +184,8 @@ int build_program(dqn_engine* e) {
         if (ok) ok = in_pl(rh_pa) && (hv_l < 0 || in_pl(rh_pv)) && (int)pl.size() == (hv_l >= 0 ? 2 : 1);
         if (ok) {
             const LayerDev& Pa = e->L[rh_pa]; const int S = dqn_nchunks(Pa.K, Pa.fwd_kc);
+            // (the kernel also takes S == 1 -- finished activations of an unsplit forward, i.e. large batches -- bit-exact at config 5, and SLOWER there: 27.4 vs 21.3 us for
+            // k_head_td at B = 512 (profiles/r05_k_cfg5_red_head_ab.txt): 4096 workgroups each staging both streams' head weights; so only split-K producers take it)
             ok = Pa.kind == DQN_LAYER_DENSE && S > 1 && dqn_chunk_len(La.K, La.fwd_kc) == 32 && dqn_nchunks(La.K, La.fwd_kc) * 32 == La.K;
             if (ok && hv_l >= 0) { const LayerDev& Pv = e->L[rh_pv]; const LayerDev& Lv = e->L[hv_l];
                 ok = Pv.kind == DQN_LAYER_DENSE && Pv.N == Pa.N && dqn_nchunks(Pv.K, Pv.fwd_kc) == S && dqn_chunk_len(Lv.K, Lv.fwd_kc) == 32 && Lv.K == La.K; }
@@ -192,6 +193,7 @@ int build_program(dqn_engine* e) {
         }
         fuse_rh = ok;
     }
+    if (fuse_heads && !fuse_rh) for (int l : levels.back()) if (e->L[l].src >= 0) wantT[e->L[l].src] = true;      // k_head_td reads its input columns out of transposed copies
     HeadSrc head[DQN_MAX_LAYERS][2];   // per (layer, net): where k_td finds the layer's output
     // ---------------- forward: online net on [s ; sp] (src/solver.jl:210,220), target net on sp (:211)
     for (size_t li = 0; li < levels.size(); li++) {
@@ -252,7 +254,7 @@ int build_program(dqn_engine* e) {
         for (const Prob& q : pr) {
             const LayerDev& L = LV[q.l];
             HeadSrc h; h.p = q.Y; h.ld = q.ncols; h.S = 1; h.per_s = 0; h.bias = q.P + L.b_off; h.act = L.act;
-            if (q.S > 1 && fuse_rh && (q.l == rh_pa || q.l == rh_pv)) rh_part[q.l == rh_pa ? 0 : 1][q.net] = q.part;      // reduced inside k_red_head
+            if (fuse_rh && (q.l == rh_pa || q.l == rh_pv)) rh_part[q.l == rh_pa ? 0 : 1][q.net] = q.S > 1 ? q.part : q.Y;      // reduced inside k_red_head (S == 1: the finished activation)
             else if (q.S > 1) {
                 if (last) { h.p = q.part; h.S = q.S; h.per_s = (unsigned long long)L.out_feat * q.ncols; }   // reduced on the fly by k_td
                 else { RSeg r; memset(&r, 0, sizeof r); r.part = q.part; r.S = q.S; r.elems = (unsigned long long)L.out_feat * q.ncols; r.mode = 0; r.bias = q.P + L.b_off; r.per_n = L.npos * q.ncols; r.act = L.act; r.out = q.Y;

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_red_head(const RedHeadArgs A, int bump_
     long long idx_v = 0; unsigned long long step_v = 0, sctr_v = 0; int pv_v = 2;
     const bool bk = blockIdx.x == 0 && tid >= 192;
     if (bk) {
-        if (take_pre && tid - 192 < B) idx_v = *gptr(A.idx_pre + (tid - 192));
+        if (take_pre && tid - 192 < B) idx_v = *gptr(A.idx_pre + (tid - 192));      // (B > 64: the rest of the list follows in a loop below, off the critical path of group 0)
         if (tid == 255) { step_v = *gptr(&A.stt->step); sctr_v = *gptr(&A.stt->sample_ctr); if (take_pre) pv_v = *gptr(&A.stt->pre_valid); }
     }
     f32x4r sl[SMAX]; float pb = 0.0f;
@@ -128,13 +128,15 @@ __global__ __launch_bounds__(256) void k_red_head(const RedHeadArgs A, int bump_
         f32x4r tot = sl[0];
 #pragma unroll
         for (int s = 1; s < SMAX; s++) if (s < S) { tot.x = tot.x + sl[s].x; tot.y = tot.y + sl[s].y; tot.z = tot.z + sl[s].z; tot.w = tot.w + sl[s].w; }
-        tot.x = rh_act<TRANS>(tot.x + pb, T.pact); tot.y = rh_act<TRANS>(tot.y + pb, T.pact); tot.z = rh_act<TRANS>(tot.z + pb, T.pact); tot.w = rh_act<TRANS>(tot.w + pb, T.pact);
+        if (S > 1) { tot.x = rh_act<TRANS>(tot.x + pb, T.pact); tot.y = rh_act<TRANS>(tot.y + pb, T.pact); tot.z = rh_act<TRANS>(tot.z + pb, T.pact); tot.w = rh_act<TRANS>(tot.w + pb, T.pact); }
+        // (S == 1: `part` IS the hidden layer's finished activation -- an unsplit forward, large batches -- and the online s columns are already where the backward pass reads them)
         if (slot == 1 && !double_q) tot = (f32x4r){0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4r*>(act + (slot * 32 + f) * 4) = tot;
-        if (slot == 0) st_sc1_x4(T.y_on + (size_t)(32 * c + f) * ncon + 4 * g, tot);      // the backward pass (head dW) and the group's last arriver (act') read it
+        if (slot == 0 && S > 1) st_sc1_x4(T.y_on + (size_t)(32 * c + f) * ncon + 4 * g, tot);      // the backward pass (head dW) and the group's last arriver (act') read it
     }
     if (bk) {
         if (take_pre && tid - 192 < B) *gptr(A.idx + (tid - 192)) = idx_v;
+        if (take_pre) for (int i = tid - 192 + 64; i < B; i += 64) A.idx[i] = A.idx_pre[i];
         if (tid == 255) { *gptr(&A.stt->step) = step_v + 1; if (bump_sample_ctr) *gptr(&A.stt->sample_ctr) = sctr_v + 1; if (take_pre && pv_v != 2) *gptr(&A.stt->err) = 3; }
     }
     // LDS-only hand-over: s_waitcnt lgkmcnt(0) + s_barrier -- __syncthreads() also drains vmcnt, i.e. would wait here for the write-through store's acknowledgement
@@ -312,7 +314,7 @@ size_t red_head_lds_bytes(const RedHeadArgs& a) {
 // chunks (one round of loads per head output), <= 16 slabs
 bool red_head_ok(int B, int K, int S, int nA, int nstream, int N0, int N1) {
     const int NO = N0 + (nstream > 1 ? N1 : 0);
-    return B % 4 == 0 && B >= 4 && B <= 64 && K % 32 == 0 && K <= 512 && K * nstream <= 1024 && K * NO <= 4096 && S >= 2 && S <= 16 && nA >= 1 && nA <= 8 && N0 == nA && (nstream == 1 || N1 == 1) &&
+    return B % 4 == 0 && B >= 4 && B <= 1024 && K % 32 == 0 && K <= 512 && K * nstream <= 1024 && K * NO <= 4096 && S >= 1 && S <= 16 && nA >= 1 && nA <= 8 && N0 == nA && (nstream == 1 || N1 == 1) &&
            12 * std::max(N0, N1) <= 256 && 32 * std::max(N0, N1) <= 256 && 12 * NO <= 256;
 }
 void launch_red_head(hipStream_t st, const RedHeadArgs& a, const RedHeadArgs* a_dev, int bump_sample_ctr, int take_pre) {
@@ -321,6 +323,7 @@ void launch_red_head(hipStream_t st, const RedHeadArgs& a, const RedHeadArgs* a_
     (void)a_dev;
     auto tr = [](int x) { return x == DQN_ACT_TANH || x == DQN_ACT_SIGMOID; };
     const bool trans = tr(a.st[0].pact) || tr(a.st[0].hact) || (a.nstream > 1 && (tr(a.st[1].pact) || tr(a.st[1].hact)));
-    if (a.S <= 8) { if (trans) hipLaunchKernelGGL((k_red_head<8, true>), dim3(grid), dim3(256), lds, st, a, bump_sample_ctr, take_pre); else hipLaunchKernelGGL((k_red_head<8, false>), dim3(grid), dim3(256), lds, st, a, bump_sample_ctr, take_pre); }
+    if (a.S == 1) { if (trans) hipLaunchKernelGGL((k_red_head<1, true>), dim3(grid), dim3(256), lds, st, a, bump_sample_ctr, take_pre); else hipLaunchKernelGGL((k_red_head<1, false>), dim3(grid), dim3(256), lds, st, a, bump_sample_ctr, take_pre); }
+    else if (a.S <= 8) { if (trans) hipLaunchKernelGGL((k_red_head<8, true>), dim3(grid), dim3(256), lds, st, a, bump_sample_ctr, take_pre); else hipLaunchKernelGGL((k_red_head<8, false>), dim3(grid), dim3(256), lds, st, a, bump_sample_ctr, take_pre); }
     else { if (trans) hipLaunchKernelGGL((k_red_head<16, true>), dim3(grid), dim3(256), lds, st, a, bump_sample_ctr, take_pre); else hipLaunchKernelGGL((k_red_head<16, false>), dim3(grid), dim3(256), lds, st, a, bump_sample_ctr, take_pre); }
 }

@@ -281,6 +281,9 @@ int dqn_comm_init(dqn_engine_t* e, const void* id128, int rank, int world);
  * small gradients, 2 all-reduce of the flat gradient, -1 not decided yet (the step program is built at the first train step). */
 typedef struct dqn_comm_info_t { int32_t rccl_nranks, rccl_rank, rccl_device, engine_world, engine_rank, sim_world, exchange, dp_overlap; } dqn_comm_info_t;
 int dqn_comm_info(dqn_engine_t* e, dqn_comm_info_t* out);
+/* bytes ONE rank contributes to the step's collective (the packed block of the all-gather: X | dpre of the wide dense layers + every other gradient range; or the flat
+ * gradient of the all-reduce); 0 without a communicator / before the step program exists (it is built by the first train step) */
+int dqn_comm_exchange_bytes(dqn_engine_t* e, int64_t* bytes_per_rank);
 
 /* TEST HOOK for the exchange above on ONE GPU: an engine created with the environment variable DQN_SIM_WORLD=k plays k ranks; this call runs
  * one data-parallel step with k DISTINCT batches idx[k][B] (rank r's packed block lands in slot r of the gathered buffer, as ncclAllGather

@@ -435,7 +435,7 @@ def _wide_fc_dueling_tanh():
 
 
 @pytest.mark.parametrize("netf,B,kw", [(nature_dueling, 32, dict(gamma=0.99)), (_wide_fc_plain, 16, dict(gamma=0.9)), (_wide_fc_plain, 8, dict(gamma=0.9, double_q=0)),
-                                       (_wide_fc_dueling_tanh, 24, dict(gamma=0.95)), (_wide_fc_dueling_tanh, 4, dict(gamma=0.95, double_q=0, prioritized_replay=0))])
+                                       (_wide_fc_dueling_tanh, 24, dict(gamma=0.95)), (_wide_fc_dueling_tanh, 4, dict(gamma=0.95, double_q=0, prioritized_replay=0)), (_wide_fc_plain, 96, dict(gamma=0.9))])
 def test_fused_reduce_head_launch_both_schedules(pkg, monkeypatch, netf, B, kw):
     """r05: where the head layers sit on split-K dense hidden layers, k_reduce_multi + k_head_td are ONE launch (red_head.hip: workgroup = 4 batch columns x stream x chunk
     of 32 hidden rows, write-through hand-off to the column group's last arriver).  Both schedules (DQN_NO_RED_HEAD, read at dqn_engine_create) run the same chains: each
@@ -445,9 +445,9 @@ def test_fused_reduce_head_launch_both_schedules(pkg, monkeypatch, netf, B, kw):
     for fused in (True, False):
         if not fused:
             monkeypatch.setenv("DQN_NO_RED_HEAD", "1")
-        gpu, cpu, hp = make_pair(pkg, net, B, cap=128, **kw)
+        gpu, cpu, hp = make_pair(pkg, net, B, cap=max(128, B + 40), **kw)
         monkeypatch.delenv("DQN_NO_RED_HEAD", raising=False)
-        fill((gpu, cpu), net, 100, seed=5)
+        fill((gpu, cpu), net, max(100, B + 20), seed=5)
         set_same_params((gpu, cpu), net, seed=3)
         for _ in range(2):
             assert_step_bit_exact(gpu, cpu)
