@@ -7,6 +7,14 @@
 #pragma once
 #include "common.h"
 
+#ifndef DQN_ADAM_ST
+#define DQN_ADAM_ST 0      /* experiment (r05): bit 0 = m, v stored write-through (sc1), bit 1 = p too */
+#endif
+__device__ __forceinline__ void adam_st4(float4* p, const float4& v, int wt) {
+    typedef float adam_f4 __attribute__((ext_vector_type(4)));
+    if (wt) { const adam_f4 x = {v.x, v.y, v.z, v.w}; asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory"); }
+    else *p = v;
+}
 // one element: Flux 0.14 Optimise.Adam with Float64 scalars (f64mode) or plain fp32; returns |g| for the max-abs norm
 __device__ __forceinline__ float adam_upd(float gi, float& mi, float& vi, float& pi, int f64mode, float lr, double b1, double b2, double eps, double bp1, double bp2, float gscale) {
     if (gscale != 1.0f) gi = gi * gscale;
@@ -103,7 +111,8 @@ __device__ __forceinline__ void adam_job_run(const AdamJob& J, int bid, long lon
                 gmax = fmaxf(gmax, adam_upd(g4.y, m4.y, v4.y, p4.y, J.f64mode, J.lr, J.b1, J.b2, J.eps, bp1, bp2, J.gscale));
                 gmax = fmaxf(gmax, adam_upd(g4.z, m4.z, v4.z, p4.z, J.f64mode, J.lr, J.b1, J.b2, J.eps, bp1, bp2, J.gscale));
                 gmax = fmaxf(gmax, adam_upd(g4.w, m4.w, v4.w, p4.w, J.f64mode, J.lr, J.b1, J.b2, J.eps, bp1, bp2, J.gscale));
-                reinterpret_cast<float4*>(J.m)[i] = m4; reinterpret_cast<float4*>(J.v)[i] = v4; reinterpret_cast<float4*>(J.p)[i] = p4;
+                // m and v are next read a whole step later: small-batch engines store them write-through (J.wt; r05 same-box A/B, profiles/r05_m_store_ab.txt: +0.5 %; p too: -0.2 %)
+                adam_st4(reinterpret_cast<float4*>(J.m) + i, m4, J.wt | (DQN_ADAM_ST & 1)); adam_st4(reinterpret_cast<float4*>(J.v) + i, v4, J.wt | (DQN_ADAM_ST & 1)); adam_st4(reinterpret_cast<float4*>(J.p) + i, p4, DQN_ADAM_ST & 2);
             }
         }
     }

@@ -529,6 +529,7 @@ struct AdamJob {
     AdamSegs segs; PrioArgs prio; int tick; unsigned sblocks;
     // recurrent fused step: the tick thread also folds the loss from the per-column Huber terms, loss = (sum_t (sum_b hl[t*B + b]) / B) / T (src/solver.jl:276-281)
     const float* fold_hl; int fold_T, fold_B;
+    int wt;      // m, v stored write-through (small-batch engines: DQN_LOPT_ST_WT)
 };
 static inline __host__ __device__ unsigned adam_job_blocks(const AdamJob& j) { return (j.prio.n > 0 ? 1u : 0u) + j.segs.blocks + j.sblocks; }
 
@@ -723,6 +724,7 @@ int gemm_set_ktrace(unsigned long long* p);   // debug (-DDQN_KTRACE builds): pe
 #define DQN_LOPT_NO_FWD_M32 32  /* DQN_FWD_M32=0: never */
 #define DQN_LOPT_FWD_DMA 2      /* DQN_FWD_DMA: LDS-DMA operand loads for the large forward launches with 64-channel tiles (measured no faster) */
 #define DQN_LOPT_NO_DX_WIDE 4   /* DQN_NO_DX_WIDE: large batches take the 32-sample dX tiles instead of the 128-sample ones */
+#define DQN_LOPT_ST_WT 64       /* small-batch engines (<= 64 columns per sequence set; DQN_NO_ST_WT=1 turns it off): the GEMM launches store their outputs write-through, nn_gemm.hip st_out4 */
 #define DQN_LOPT_NO_FWD_WRES 8  /* DQN_NO_FWD_WRES: large-batch forwards of a narrow layer take the per-tile kernel instead of the weights-resident persistent one (A/B) */
 void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* const* W, const float* const* bias, const float* const* X,
                      const int* ldx, const int* col0, const int* ncols, float* const* out /* Y, or split-K partial slabs */,

@@ -31,6 +31,7 @@ struct EngineOpts {
     int sim_world = 0;            // DQN_SIM_WORLD=k: one process plays k ranks (tests)
     int no_graph_upload = 0;      // DQN_NO_GRAPH_UPLOAD
     int no_rollout_cycle = 0;     // DQN_NO_ROLLOUT_CYCLE
+    int no_st_wt = 0;             // DQN_NO_ST_WT: small-batch engines keep plain / non-temporal output stores in the GEMM launches (A/B)
     int no_red_head = 0;          // DQN_NO_RED_HEAD: keep k_reduce_multi + k_head_td where the fused reduce + head launch (red_head.hip) would apply (A/B, both schedules under test)
     int no_u8_arena = 0, head_fuse_maxb = 1024, no_head_fuse = 0, head_dbg = 0, prio_fork = 0, prio_level = 0, prio_nosplit = 0, no_pregather = 0, lstm_dw_mfma = 0;
     int force_allreduce = 0, dp_allreduce = 0, dp_overlap = 0, dp_no_one_graph = 0;      // DQN_FORCE_ALLREDUCE / DQN_DP_ALLREDUCE / DQN_DP_OVERLAP / DQN_DP_NO_ONE_GRAPH

@@ -99,7 +99,11 @@ __device__ __forceinline__ void gather_fb_body(const void* __restrict__ s_rows, 
             float o4[4]; const int rot = (l16 >> 3) << 1;
 #pragma unroll
             for (int u = 0; u < 4; u++) { const int uu = (u + rot) & 3; const float t = tile[4 * l16 + uu][fl]; if (uu == 0) o4[0] = t; else if (uu == 1) o4[1] = t; else if (uu == 2) o4[2] = t; else o4[3] = t; }
+#if defined(DQN_ADAM_ST) && (DQN_ADAM_ST & 4)
+            { const gb_f32x4 ov = {o4[0], o4[1], o4[2], o4[3]}; asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(x0 + (size_t)f * ld + c), "v"(ov) : "memory"); }
+#else
             *reinterpret_cast<gb_f32x4*>(x0 + (size_t)f * ld + c) = (gb_f32x4){o4[0], o4[1], o4[2], o4[3]};
+#endif
         }
         else for (int u = 0; u < 4; u++) if (c + u < ld) x0[(size_t)f * ld + c + u] = tile[4 * l16 + u][fl];
     }

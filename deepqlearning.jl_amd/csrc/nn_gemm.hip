@@ -54,6 +54,20 @@ int gemm_set_ktrace(unsigned long long*) { return -1; }     // not a trace build
 #define KTRACE_PROBE() 0
 #endif
 
+// Output tiles of the GEMM launches (activations, split-K slabs, dX tiles, dW slabs / gradients) are stored WRITE-THROUGH (sc1) by the small-batch engines
+// (LayerDev::opt & DQN_LOPT_ST_WT, set at dqn_engine_create for <= 64 columns per sequence set).  A kernel boundary writes back what its launch left dirty in the eight L2s
+// (MI355X guide, "boundary" row: + B / 6 TB/s behind B dirty bytes) and at B = 32 the step is ten short launches that each leave 1-13 MB behind; write-through stores
+// stream out while the launch still runs.  r05, same box, alternating (profiles/r05_l_store_ab.txt): config 2 7960 -> 8115 steps/s with every output write-through (dW only:
+// 8050; activations / slabs / dX only: 7970); config 5 (B = 512: launches of 45-105 us) 1642 -> 1632, so large batches keep plain / non-temporal stores.
+// (inline asm: invisible to hipcc's wait counting -- nothing in a kernel reads these back, and a wave's stores complete before it ends)
+__device__ __forceinline__ void st_out4(f32x4* p, const f32x4& v, int wt) {
+    if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else *p = v;
+}
+__device__ __forceinline__ void st_grad4(f32x4* p, const f32x4& v, int wt) {      // dW slabs / gradients: read once, by the Adam launch
+    if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else __builtin_nontemporal_store(v, p);
+}
 void launch_reduce_pub(hipStream_t st, const float* part, int S, size_t elems, int mode, const float* bias, int per_n, int act,
                        const float* addend, const float* ysrc, int B, int ldy, float* out);
 
@@ -340,7 +354,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
             const int pos = mt / ctiles, ct = mt % ctiles;
             f32x4 v = {c16[4 * g], c16[4 * g + 1], c16[4 * g + 2], c16[4 * g + 3]};
             if (S == 1) { act_v4(v, bias, L.act); }
-            *reinterpret_cast<f32x4*>(p.out + (size_t)s * per_s + ((size_t)n * L.npos + pos) * p.ncols + ct * 16 + (cc & 15)) = v;
+            st_out4(reinterpret_cast<f32x4*>(p.out + (size_t)s * per_s + ((size_t)n * L.npos + pos) * p.ncols + ct * 16 + (cc & 15)), v, L.opt & DQN_LOPT_ST_WT);
         }
         return;
     }
@@ -381,7 +395,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
             if constexpr (KT == 16) act_v4(v, bias, L.act);      // (large launches; for the lone waves of the 32-deep form the per-element switch measures 1.9 % FASTER per step, same box)
             else { v.x = act_f(v.x + bias, L.act); v.y = act_f(v.y + bias, L.act); v.z = act_f(v.z + bias, L.act); v.w = act_f(v.w + bias, L.act); }
         }
-        *reinterpret_cast<f32x4*>(p.out + (size_t)s * per_s + ((size_t)n * L.npos + pos) * p.ncols + ct * 16 + 4 * kq) = v;
+        st_out4(reinterpret_cast<f32x4*>(p.out + (size_t)s * per_s + ((size_t)n * L.npos + pos) * p.ncols + ct * 16 + 4 * kq), v, L.opt & DQN_LOPT_ST_WT);
         if (p.outT) {      // (dense, one chunk) the same activations with a batch column's features contiguous: k_head_td reads its columns as runs instead of one 64-byte sector per element
             float* o = p.outT + (size_t)(ct * 16 + 4 * kq) * L.N + n;
             o[0] = v.x; o[L.N] = v.y; o[2 * (size_t)L.N] = v.z; o[3 * (size_t)L.N] = v.w;
@@ -696,7 +710,7 @@ __global__ __launch_bounds__(256) void k_fwd_dma(LayerDev L, GFwdProbs pr, int S
         const int n = n0 + 16 * t + l15;
         f32x4 v = acc[t];
         if (S == 1) { const float bias = bias_r[t]; act_v4(v, bias, L.act); }
-        *reinterpret_cast<f32x4*>(p.out + (size_t)s * per_s + ((size_t)n * L.npos + pos) * p.ncols + ct * 16 + 4 * kq) = v;
+        st_out4(reinterpret_cast<f32x4*>(p.out + (size_t)s * per_s + ((size_t)n * L.npos + pos) * p.ncols + ct * 16 + 4 * kq), v, L.opt & DQN_LOPT_ST_WT);
     }
 }
 static int fwd_pick_nt(const LayerDev& L, long mgroups_total, int S) {
@@ -968,7 +982,7 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
             const int row = i * RPI + rg, k = mr * 64 + 16 * wave + row;
             const f32x4 v = *reinterpret_cast<const f32x4*>(T + (16 * wave + row) * NW + 4 * p4);
             const int n4 = p4 ^ (((row >> 2) & 1) << 2);            // the logical float4 this slot holds (rows 4kq + r: tiles swapped where kq is odd)
-            if (k < L.K) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + (size_t)k * L.N + n0 + 4 * n4));
+            if (k < L.K) st_grad4(reinterpret_cast<f32x4*>(out + (size_t)k * L.N + n0 + 4 * n4), v, L.opt & DQN_LOPT_ST_WT);
         }
     } else {
 #pragma unroll
@@ -1223,7 +1237,7 @@ __device__ __forceinline__ void dx_units_body(const LayerDev& L, const GDxArgs& 
     }
     if (A.ysrc) { v.x = dact_f(v.x, y_e.x, A.act_src); v.y = dact_f(v.y, y_e.y, A.act_src); v.z = dact_f(v.z, y_e.z, A.act_src); v.w = dact_f(v.w, y_e.w, A.act_src); }
     const size_t featx = dense ? (size_t)fl : (size_t)fl * L.ih * L.iw + ip;
-    *reinterpret_cast<f32x4*>(A.out + featx * B + b0 + 16 * mt + 4 * kq) = v;
+    st_out4(reinterpret_cast<f32x4*>(A.out + featx * B + b0 + 16 * mt + 4 * kq), v, L.opt & DQN_LOPT_ST_WT);
 }
 // Large batches (B % 128 == 0): 32 features x 128 SAMPLES per workgroup.  Wave w owns samples 32w..32w+31 and both 16-feature tiles: four
 // accumulator tiles per source, 32 MFMAs per K tile and wave between two barriers instead of 8, and the conv prologue (tap list) is paid once
@@ -1365,7 +1379,7 @@ __device__ __forceinline__ void dx_lds_body_wide(const LayerDev& L, const GDxArg
                 const f32x4 y = *reinterpret_cast<const f32x4*>(A.ysrc + feat * A.ldy + bcol);
                 dact_v4(v, y, A.act_src);
             }
-            *reinterpret_cast<f32x4*>(A.out + (size_t)s * per_s + feat * B + bcol) = v;
+            st_out4(reinterpret_cast<f32x4*>(A.out + (size_t)s * per_s + feat * B + bcol), v, L.opt & DQN_LOPT_ST_WT);
         }
     }
 }
