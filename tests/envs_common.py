@@ -14,6 +14,13 @@ def testmdp_conv_dueling(h=12, w=14, stack=4):
     return O.Network((stack, h, w), b, v, a)
 
 
+def testmdp_wide_fc_dueling(h=20, w=20, stack=4):
+    """a trunk whose flattened output (32 x 7 x 7 = 1568 > 1024) makes the dueling streams' hidden layers split-K: the shape class of the Nature network, where the
+    fused reduce + head launch (red_head.hip) applies -- in the train step and, in its acting form, in the env loop's policy forward"""
+    b, v, a = O.create_dueling_network([O.Conv(4, stack, 32, R, 2), O.Conv(3, 32, 32, R, 1), O.Dense(32 * 7 * 7, 128, R), O.Dense(128, 4, I)])
+    return O.Network((stack, h, w), b, v, a)
+
+
 def gridworld_mlp_dueling():
     b, v, a = O.create_dueling_network([O.Dense(2, 32, R), O.Dense(32, 4, I)])   # README.md:38
     return O.Network((2,), b, v, a)

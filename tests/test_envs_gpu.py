@@ -84,6 +84,37 @@ def test_gridworld_rollout_bit_exact(pkg, envs):
     assert tot_eps >= 64 * 4          # max_episode_length 20 over 100 steps
 
 
+@pytest.mark.parametrize("n_envs", [8, 12])
+def test_rollout_with_fused_acting_head_bit_exact(pkg, envs, monkeypatch, n_envs):
+    """r05: the device env loop on a network whose dueling streams have split-K hidden layers (the Nature shape class): its train steps take the fused reduce + head launch
+    (red_head.hip).  Trajectories, replay, priorities, parameters and evaluation equal the twin's bit for bit, and the schedule without the fused launch (DQN_NO_RED_HEAD)
+    walks the same trajectory.  (An ACTING form of that launch -- reduce + heads of the policy forward in one -- was built and measured no faster: 9.6 us vs 4.7 + 4.8,
+    profiles/r05_o_acting_step_with_fused_head_dropped.txt; dropped.)"""
+    net = EC.testmdp_wide_fc_dueling()
+    outs = []
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("DQN_NO_RED_HEAD", "1")
+        g, t, hp = make_pair(pkg, net, B=8, cap=128)
+        monkeypatch.delenv("DQN_NO_RED_HEAD", raising=False)
+        EC.same_params([g, t], net)
+        spec = envs.TestMDP((20, 20), 4, 6, n=n_envs, seed=3)
+        for h in (g, t):
+            h.envs_create(spec, max_episode_length=100, seed=17)
+        t0 = 1
+        for chunk in (1, 4, 9, 6):
+            kw = dict(t0=t0, train_freq=2, target_update_freq=7, eps=(0.6, 0.05, 15.0))
+            sg = g.rollout(chunk, **kw); st = t.rollout(chunk, **kw)
+            t0 += chunk
+            assert sg == st, (sg, st)
+            compare_state(g, t)
+            np.testing.assert_array_equal(g.get_params(0), t.get_params(0))
+        assert g.evaluate(8, 50, seed=5) == t.evaluate(8, 50, seed=5)
+        outs.append((g.get_params(0), g.replay_priorities()))
+        g.close(); t.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0]); np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
 def test_rollout_env_step_cadence_bit_exact(pkg, envs):
     """r05 (VERDICT r04 missing #4): dqn_rollout with cadence_env_steps = 1 trains every train_freq ENV steps like the reference's loop (src/solver.jl:136-140) -- n / train_freq
     train steps per vector step, run back to back through the pipelined dqn_train_steps path -- and syncs the target net on env-step multiples: trajectories, replay,
