@@ -137,6 +137,22 @@ def step_flops_analytic(eng_layers, B, ncon):
     return tot
 
 
+class quiet_stdout:
+    """RCCL prints a version banner to the C stdout when a communicator is created; the driver parses ONE JSON line from this script's stdout.  File descriptor 1 points at
+    /dev/null while the communicator is made, and the C stdio buffer is flushed into it before the descriptor is restored."""
+    def __enter__(self):
+        import ctypes
+        sys.stdout.flush()
+        self._libc = ctypes.CDLL(None); self._libc.fflush(None)
+        self._saved = os.dup(1); dn = os.open(os.devnull, os.O_WRONLY); os.dup2(dn, 1); os.close(dn)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush(); self._libc.fflush(None)
+        os.dup2(self._saved, 1); os.close(self._saved)
+        return False
+
+
 def layer_geo(pkg, layers, hw=84):
     """(K, N, npos) per layer of an image network on hw x hw observations"""
     h = w = hw
@@ -301,7 +317,8 @@ def secondary_block(pkg, args, device):
         os.environ["DQN_FORCE_ALLREDUCE"] = "1"
         a3 = _ap.Namespace(**vars(args)); a3.distinct = False; a3.device_fill = True
         e3, _, _, _, _, _ = build_workload(pkg, a3, 0, device)
-        e3.comm_init(pkg.comm_unique_id(), 0, 1)
+        with quiet_stdout():
+            e3.comm_init(pkg.comm_unique_id(), 0, 1)
         os.environ.pop("DQN_FORCE_ALLREDUCE", None)
         r = timed_steps(e3, 300, 30)
         prof = launch_profile(e3, 10)
@@ -309,17 +326,18 @@ def secondary_block(pkg, args, device):
         xb = e3.comm_exchange_bytes()
         plain_us = 1e3 * args_ms_plain[0] if args_ms_plain[0] else None
         link = 153e9      # one xGMI link, bytes/s (MI355X guide)
-        def model(N):      # replica step at N ranks = measured world-1 replica step + (N - 1) x the wide dW's per-rank-block K tiles + the all-gather over point-to-point links
+        def model(N):      # replica step at N ranks = measured world-1 replica step + (N - 1) more K tiles in the wide dW + the all-gather over point-to-point links
             wide = sum(v for k, v in L.items() if k.startswith("dp_dw"))
+            per_tile = 2.1      # us per additional rank block (one more 32-sample K tile per workgroup): calibrated on the simulated 8-rank run (profiles/r01_k_dp8_*: 25.8 us at N = 8)
             ag_direct = xb / link * 1e6 if N > 1 else 0.0; ag_ring = (N - 1) * xb / link * 1e6
-            return {"wide_dw_us": round(wide * N, 1), "allgather_direct_us": round(ag_direct, 1), "allgather_ring_us": round(ag_ring, 1), "rccl_latency_us": "10-20 (not measurable at world 1)",
-                    "predicted_step_us_direct": round(r["ms_per_step"] * 1e3 + wide * (N - 1) + ag_direct + 15.0, 1), "predicted_step_us_ring": round(r["ms_per_step"] * 1e3 + wide * (N - 1) + ag_ring + 15.0, 1)}
+            return {"wide_dw_us": round(wide + per_tile * (N - 1), 1), "allgather_direct_us": round(ag_direct, 1), "allgather_ring_us": round(ag_ring, 1), "rccl_latency_us": "10-20 (not measurable at world 1)",
+                    "predicted_step_us_direct": round(r["ms_per_step"] * 1e3 + per_tile * (N - 1) + ag_direct + 15.0, 1), "predicted_step_us_ring": round(r["ms_per_step"] * 1e3 + per_tile * (N - 1) + ag_ring + 15.0, 1)}
         out["dp_model"] = {"measured_world1": {"replica_step_us": round(r["ms_per_step"] * 1e3, 2), "plain_step_us": plain_us, "steps_per_s": r["steps_per_s"],
                                                 "pack_us": round(sum(v for k, v in L.items() if k.startswith("dp_pack")), 2), "wide_dw_us": round(sum(v for k, v in L.items() if k.startswith("dp_dw")), 2),
                                                 "unpack_sum_us": round(L.get("dp_sum_ranks", 0.0), 2), "launches": {k: round(v, 2) for k, v in L.items()}},
                            "exchange_bytes_per_rank": xb, "rccl_nranks": e3.comm_info()["rccl_nranks"],
                            "model": {f"N={N}": model(N) for N in (2, 4, 8)},
-                           "note": "world-1 measurement through a real communicator + a point-to-point xGMI model (153 GB/s per link, one link per peer pair); predicted_step_us = replica step + (N-1) x wide dW K tiles + all-gather + 15 us RCCL latency; UNMEASURED beyond world 1"}
+                           "note": "world-1 measurement through a real communicator + a point-to-point xGMI model (153 GB/s per link, one link per peer pair); predicted_step_us = replica step + 2.1 us per extra rank block in the wide dW + all-gather + 15 us RCCL latency; UNMEASURED beyond world 1"}
         e3.close()
     except Exception as ex:
         os.environ.pop("DQN_FORCE_ALLREDUCE", None)
@@ -431,7 +449,8 @@ def main():
     group = par.Group(backend="gloo")
 
     eng, layers, hp, net, params, env = build_workload(pkg, args, rank, local_rank)
-    group.attach_engine(pkg, eng, init_comm=not sim_comm)          # RCCL communicator inside the engine (the step's collective runs on its stream)
+    with quiet_stdout():
+        group.attach_engine(pkg, eng, init_comm=not sim_comm)          # RCCL communicator inside the engine (the step's collective runs on its stream)
 
     def barrier():
         group.barrier()
