@@ -468,6 +468,37 @@ def test_fused_reduce_head_launch_both_schedules(pkg, monkeypatch, netf, B, kw):
     np.testing.assert_array_equal(outs[0][0], outs[1][0]); np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
 
+def test_fused_reduce_head_hand_off_soak(pkg, monkeypatch):
+    """the fused reduce + head launch hands data between workgroups INSIDE a launch (write-through stores, a drained ticket, L1-bypassing loads on the last arriver: MI355X guide,
+    Guideline 16).  A stale or torn hand-off would not crash, it would change a number: 4000 train steps at the full Nature-DQN shape (B = 32, 256 workgroups per launch, 8 column
+    groups) on the fused schedule and on the two-launch schedule must leave IDENTICAL parameters, Adam state and priorities -- 32 000 hand-offs checked through every bit they feed."""
+    net = nature_dueling()
+    hp = ref.hparams_for(net, batch_size=32, buffer_size=512, gamma=0.99, learning_rate=1e-4)
+    layers = ref.layers_from_network(net)
+    plan = pkg.default_plan(layers, hp)
+    rng = np.random.default_rng(11)
+    s = rng.random((512,) + net.obs_shape, dtype=np.float32); sp = rng.random((512,) + net.obs_shape, dtype=np.float32)
+    a = rng.integers(0, net.n_actions, 512).astype(np.int32); r = rng.standard_normal(512).astype(np.float32); d = (rng.random(512) < 0.1).astype(np.uint8)
+    p = O.Network.flatten(O.init_params(net, seed=3))
+    outs = []
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("DQN_NO_RED_HEAD", "1")
+        g = pkg.Engine(layers, hp, plan=plan)
+        monkeypatch.delenv("DQN_NO_RED_HEAD", raising=False)
+        g.set_params(p, 0); g.set_params(p * np.float32(0.95), 1); g.replay_add(s, a, r, sp, d)
+        for chunk in (1, 37, 962, 3000):
+            loss, gn = g.train_steps(chunk)
+            assert np.isfinite(loss) and np.isfinite(gn)
+        outs.append((g.get_params(0), g.get_adam_state(), g.replay_priorities(), (loss, gn)))
+        g.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    for x, y in zip(outs[0][1], outs[1][1]):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(outs[0][2], outs[1][2])
+    assert outs[0][3] == outs[1][3]
+
+
 def test_nature_u8_b32_byte_arena_bit_exact(pkg):
     """u8 replay with the Nature-DQN first layer: the observation arena stays in BYTES (gather writes 1 byte per element, conv1's forward and dW
     tile loads convert byte / 255f0 exactly) -- every one of the 256 byte values occurs in the random rows; bit-exact vs the twin's plain
