@@ -773,7 +773,7 @@ PMC_OK = [True]
 
 # kernel-symbol family of a launch of the step program (names: DESIGN.md section 6 / op_cost above)
 KERNEL_FAMILIES = (("k_dwdx_lds", lambda n: "dx" in n and n.startswith("dw")), ("k_fwd_lds", lambda n: n.startswith("fwd_") and "reduce" not in n and "valu" not in n),
-                   ("k_dw_lds", lambda n: n.startswith("dw") and "dx" not in n), ("k_adam", lambda n: n.startswith("adam")), ("k_head_td", lambda n: n == "head_td"), ("k_red_head", lambda n: n == "red_head"),
+                   ("k_dw_lds", lambda n: n.startswith("dw") and "dx" not in n), ("k_adam", lambda n: n.startswith("adam")), ("k_head_td", lambda n: n == "head_td"), ("k_red_head", lambda n: n == "red_head"), ("k_head_cols4", lambda n: n == "head_cols4"),
                    ("k_reduce_multi", lambda n: "reduce" in n))
 
 

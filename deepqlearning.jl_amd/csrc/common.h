@@ -579,6 +579,7 @@ struct RedHeadStream {
     const float* part[2];              // [net] split-K slabs [S][K][ncols(net)] of the hidden layer's forward (net 0: ncon columns, net 1: B columns)
     const float* pbias[2]; int pact;   // [net] hidden layer bias [K], its activation
     const float* W[2]; const float* hbias[2]; int N, hact;      // [net] head weights [K][N], bias [N]; head activation
+    const float* partT[2];             // [net] S == 1 only, optional: the transposed copy [column][K] of the finished activation (written by the dense forward's epilogue)
     float* y_on;                       // online hidden activations [K][ncon]: columns 0..B-1 (the s columns) are written -- what the backward pass reads
     float* dpre;                       // [N][B]  dL/d(pre-activation) of the head
     float* dsrc;                       // [K][B]  dL/d(pre-activation) of the hidden layer
@@ -722,7 +723,6 @@ int gemm_set_ktrace(unsigned long long* p);   // debug (-DDQN_KTRACE builds): pe
 #define DQN_LOPT_FWD_M32 1      /* DQN_FWD_M32=1: 32x32x2 MFMA blocks for the 64-channel forward tiles in EVERY launch (default: only the large ones, >= 1024 workgroups, where they measure
                                    conv3 forward 58.3 -> 55.7 us at config 5 since the r04 instruction diet; no faster before it) */
 #define DQN_LOPT_NO_FWD_M32 32  /* DQN_FWD_M32=0: never */
-#define DQN_LOPT_FWD_DMA 2      /* DQN_FWD_DMA: LDS-DMA operand loads for the large forward launches with 64-channel tiles (measured no faster) */
 #define DQN_LOPT_NO_DX_WIDE 4   /* DQN_NO_DX_WIDE: large batches take the 32-sample dX tiles instead of the 128-sample ones */
 #define DQN_LOPT_ST_WT 64       /* small-batch engines (<= 64 columns per sequence set; DQN_NO_ST_WT=1 turns it off): the GEMM launches store their outputs write-through, nn_gemm.hip st_out4 */
 #define DQN_LOPT_NO_FWD_WRES 8  /* DQN_NO_FWD_WRES: large-batch forwards of a narrow layer take the per-tile kernel instead of the weights-resident persistent one (A/B) */

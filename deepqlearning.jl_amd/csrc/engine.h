@@ -26,12 +26,13 @@ struct ProfEntry { const char* name; hipEvent_t a, b; };
 struct EngineOpts {
     int adam_mode = 0;            // DQN_ADAM_MODE=1: Adam jobs carried by the backward launches (measured slower; parity-tested)
     int no_tiny = 0;              // DQN_NO_TINY: networks that fit in LDS take the multi-launch program
-    int fwd_m32 = -1 /* -1: large launches only */, fwd_dma = 0, no_dx_wide = 0, no_fwd_wres = 0;      // DQN_FWD_M32 / DQN_FWD_DMA / DQN_NO_DX_WIDE / DQN_NO_FWD_WRES -> LayerDev::opt bits
+    int fwd_m32 = -1 /* -1: large launches only */, no_dx_wide = 0, no_fwd_wres = 0;      // DQN_FWD_M32 / DQN_NO_DX_WIDE / DQN_NO_FWD_WRES -> LayerDev::opt bits
     int mid_group = 4, mid_big = 16;                   // DQN_MID_GROUP / DQN_MID_BIG: middle steps of dqn_train_steps per graph (mid_big also needs mid_group > 1)
     int sim_world = 0;            // DQN_SIM_WORLD=k: one process plays k ranks (tests)
     int no_graph_upload = 0;      // DQN_NO_GRAPH_UPLOAD
     int no_rollout_cycle = 0;     // DQN_NO_ROLLOUT_CYCLE
     int no_st_wt = 0;             // DQN_NO_ST_WT: small-batch engines keep plain / non-temporal output stores in the GEMM launches (A/B)
+    int no_head_cols4 = 0;        // DQN_NO_HEAD_COLS4=1: keep k_head_td (one workgroup per column) at large batches where k_head_cols4 (red_head.hip) would apply (A/B); =2: k_head_cols4 without the transposed copies (its fallback loader, under test)
     int no_red_head = 0;          // DQN_NO_RED_HEAD: keep k_reduce_multi + k_head_td where the fused reduce + head launch (red_head.hip) would apply (A/B, both schedules under test)
     int no_u8_arena = 0, head_fuse_maxb = 1024, no_head_fuse = 0, head_dbg = 0, prio_fork = 0, prio_level = 0, prio_nosplit = 0, no_pregather = 0, lstm_dw_mfma = 0;
     int force_allreduce = 0, dp_allreduce = 0, dp_overlap = 0, dp_no_one_graph = 0;      // DQN_FORCE_ALLREDUCE / DQN_DP_ALLREDUCE / DQN_DP_OVERLAP / DQN_DP_NO_ONE_GRAPH

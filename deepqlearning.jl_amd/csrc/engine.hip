@@ -118,11 +118,11 @@ void read_opts(EngineOpts& o, bool comm_only) {
     auto F = [](const char* k) { return getenv(k) != nullptr ? 1 : 0; };
     o.force_allreduce = F("DQN_FORCE_ALLREDUCE"); o.dp_allreduce = F("DQN_DP_ALLREDUCE"); o.dp_overlap = F("DQN_DP_OVERLAP"); o.dp_no_one_graph = F("DQN_DP_NO_ONE_GRAPH");
     if (comm_only) return;
-    o.adam_mode = I("DQN_ADAM_MODE", 0); o.no_tiny = F("DQN_NO_TINY"); o.fwd_m32 = I("DQN_FWD_M32", -1); o.fwd_dma = I("DQN_FWD_DMA", 0); o.no_dx_wide = F("DQN_NO_DX_WIDE"); o.no_fwd_wres = F("DQN_NO_FWD_WRES");
+    o.adam_mode = I("DQN_ADAM_MODE", 0); o.no_tiny = F("DQN_NO_TINY"); o.fwd_m32 = I("DQN_FWD_M32", -1); o.no_dx_wide = F("DQN_NO_DX_WIDE"); o.no_fwd_wres = F("DQN_NO_FWD_WRES");
     o.mid_group = I("DQN_MID_GROUP", 4); o.mid_big = I("DQN_MID_BIG", 16); o.sim_world = I("DQN_SIM_WORLD", 0); o.no_graph_upload = F("DQN_NO_GRAPH_UPLOAD");
     o.no_rollout_cycle = F("DQN_NO_ROLLOUT_CYCLE"); o.no_u8_arena = F("DQN_NO_U8_ARENA"); o.head_fuse_maxb = I("DQN_HEAD_FUSE_MAXB", 1024); o.no_head_fuse = F("DQN_NO_HEAD_FUSE");
     o.head_dbg = I("DQN_HEAD_DBG", 0); o.prio_fork = F("DQN_PRIO_FORK"); o.prio_level = I("DQN_PRIO_LEVEL", 0); o.prio_nosplit = F("DQN_PRIO_NOSPLIT"); o.no_pregather = F("DQN_NO_PREGATHER");
-    o.no_red_head = F("DQN_NO_RED_HEAD"); o.no_st_wt = F("DQN_NO_ST_WT");
+    o.no_red_head = F("DQN_NO_RED_HEAD"); o.no_head_cols4 = I("DQN_NO_HEAD_COLS4", 0); o.no_st_wt = F("DQN_NO_ST_WT");
     o.lstm_dw_mfma = F("DQN_LSTM_DW_MFMA"); o.probe_no_tg = F("DQN_PROBE_NO_TG"); o.drqn_probe = I("DQN_DRQN_PROBE", 0); o.drqn_stamps = F("DQN_DRQN_STAMPS"); o.tiny_stop = I("DQN_TINY_STOP", 0);
 }
 static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out, const dqn_hparams* hp, bool allow_cg = true) {
@@ -202,7 +202,7 @@ static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers
     e->adam_mode = e->opt.adam_mode; e->no_tiny = e->opt.no_tiny != 0;
     e->mid_group = e->opt.mid_group;      // middle steps of dqn_train_steps per graph launch (1 = one step per graph: no grouped graphs at all)
     e->mid_big = e->opt.mid_group > 1 ? e->opt.mid_big : 0;
-    { const int lopt = (e->opt.fwd_m32 > 0 ? DQN_LOPT_FWD_M32 : 0) | (e->opt.fwd_m32 == 0 ? DQN_LOPT_NO_FWD_M32 : 0) | (e->opt.fwd_dma ? DQN_LOPT_FWD_DMA : 0) | (e->opt.no_dx_wide ? DQN_LOPT_NO_DX_WIDE : 0) | (e->opt.no_fwd_wres ? DQN_LOPT_NO_FWD_WRES : 0) |
+    { const int lopt = (e->opt.fwd_m32 > 0 ? DQN_LOPT_FWD_M32 : 0) | (e->opt.fwd_m32 == 0 ? DQN_LOPT_NO_FWD_M32 : 0) | (e->opt.no_dx_wide ? DQN_LOPT_NO_DX_WIDE : 0) | (e->opt.no_fwd_wres ? DQN_LOPT_NO_FWD_WRES : 0) |
                        ((!e->opt.no_st_wt && (long long)hp->batch_size * (hp->recurrence ? hp->trace_length : 1) <= 64) ? DQN_LOPT_ST_WT : 0); for (int i = 0; i < e->nl; i++) e->L[i].opt = lopt; }
     if (e->opt.sim_world >= 1 && !hp->recurrence) { e->sim_world = e->opt.sim_world; e->world = e->opt.sim_world; }   // tests: one process plays k identical ranks
     dqn_layer_plan defp[DQN_MAX_LAYERS];

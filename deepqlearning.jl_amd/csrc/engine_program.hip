@@ -175,7 +175,8 @@ int build_program(dqn_engine* e) {
     // ---------------- r05: when the head layers sit on dense hidden layers whose forward ran split-K, the split-K reduce AND the head level are ONE chip-filling launch
     // (red_head.hip: workgroup = 4 batch columns x stream x plan chunk of 32 hidden rows, the last arriver of a column group does TD + the heads' dX) instead of
     // k_reduce_multi (384 workgroups) + k_head_td (B workgroups)
-    bool fuse_rh = false; int rh_pa = -1, rh_pv = -1; const float* rh_part[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [stream][net]
+    bool fuse_rh = false; int rh_pa = -1, rh_pv = -1, rh_S = 0; const float* rh_part[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [stream][net]
+    const float* rh_partT[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     if (fuse_heads && levels.size() >= 2 && !e->opt.no_red_head && !e->opt.probe_no_tg && !e->opt.head_dbg) {
         const LayerDev& La = e->L[ha_l]; rh_pa = La.src; rh_pv = hv_l >= 0 ? e->L[hv_l].src : -1;
         bool ok = rh_pa >= 0 && (hv_l < 0 || (rh_pv >= 0 && rh_pv != rh_pa));
@@ -183,17 +184,19 @@ int build_program(dqn_engine* e) {
         auto in_pl = [&](int l) { for (int x : pl) if (x == l) return true; return false; };
         if (ok) ok = in_pl(rh_pa) && (hv_l < 0 || in_pl(rh_pv)) && (int)pl.size() == (hv_l >= 0 ? 2 : 1);
         if (ok) {
-            const LayerDev& Pa = e->L[rh_pa]; const int S = dqn_nchunks(Pa.K, Pa.fwd_kc);
-            // (the kernel also takes S == 1 -- finished activations of an unsplit forward, i.e. large batches -- bit-exact at config 5, and SLOWER there: 27.4 vs 21.3 us for
-            // k_head_td at B = 512 (profiles/r05_k_cfg5_red_head_ab.txt): 4096 workgroups each staging both streams' head weights; so only split-K producers take it)
-            ok = Pa.kind == DQN_LAYER_DENSE && S > 1 && dqn_chunk_len(La.K, La.fwd_kc) == 32 && dqn_nchunks(La.K, La.fwd_kc) * 32 == La.K;
+            const LayerDev& Pa = e->L[rh_pa]; const int S = dqn_nchunks(Pa.K, Pa.fwd_kc); rh_S = S;
+            // S > 1: k_red_head (split-K producers, small batches).  S == 1 -- finished activations of an unsplit forward, i.e. large batches: k_head_cols4, one workgroup per
+            // column group (k_red_head's (group, stream, chunk) decomposition is SLOWER there: 27.4 vs 21.3 us for k_head_td at B = 512, profiles/r05_k_cfg5_red_head_ab.txt --
+            // 4096 workgroups each staging both streams' head weights)
+            ok = Pa.kind == DQN_LAYER_DENSE && (S > 1 || e->opt.no_head_cols4 != 1) && dqn_chunk_len(La.K, La.fwd_kc) == 32 && dqn_nchunks(La.K, La.fwd_kc) * 32 == La.K;
             if (ok && hv_l >= 0) { const LayerDev& Pv = e->L[rh_pv]; const LayerDev& Lv = e->L[hv_l];
                 ok = Pv.kind == DQN_LAYER_DENSE && Pv.N == Pa.N && dqn_nchunks(Pv.K, Pv.fwd_kc) == S && dqn_chunk_len(Lv.K, Lv.fwd_kc) == 32 && Lv.K == La.K; }
             if (ok) ok = red_head_ok(B, La.K, S, e->nA, hv_l >= 0 ? 2 : 1, La.N, hv_l >= 0 ? e->L[hv_l].N : 0);
         }
         fuse_rh = ok;
     }
-    if (fuse_heads && !fuse_rh) for (int l : levels.back()) if (e->L[l].src >= 0) wantT[e->L[l].src] = true;      // k_head_td reads its input columns out of transposed copies
+    // k_head_td and k_head_cols4 (unsplit producers) read their input columns out of transposed copies
+    if (fuse_heads && (!fuse_rh || rh_S == 1)) for (int l : levels.back()) if (e->L[l].src >= 0) wantT[e->L[l].src] = true;
     HeadSrc head[DQN_MAX_LAYERS][2];   // per (layer, net): where k_td finds the layer's output
     // ---------------- forward: online net on [s ; sp] (src/solver.jl:210,220), target net on sp (:211)
     for (size_t li = 0; li < levels.size(); li++) {
@@ -254,7 +257,8 @@ int build_program(dqn_engine* e) {
         for (const Prob& q : pr) {
             const LayerDev& L = LV[q.l];
             HeadSrc h; h.p = q.Y; h.ld = q.ncols; h.S = 1; h.per_s = 0; h.bias = q.P + L.b_off; h.act = L.act;
-            if (fuse_rh && (q.l == rh_pa || q.l == rh_pv)) rh_part[q.l == rh_pa ? 0 : 1][q.net] = q.S > 1 ? q.part : q.Y;      // reduced inside k_red_head (S == 1: the finished activation)
+            if (fuse_rh && (q.l == rh_pa || q.l == rh_pv)) { rh_part[q.l == rh_pa ? 0 : 1][q.net] = q.S > 1 ? q.part : q.Y;      // reduced inside k_red_head (S == 1: the finished activation)
+                                                             rh_partT[q.l == rh_pa ? 0 : 1][q.net] = q.S > 1 ? nullptr : actT[q.l][q.net]; }
             else if (q.S > 1) {
                 if (last) { h.p = q.part; h.S = q.S; h.per_s = (unsigned long long)L.out_feat * q.ncols; }   // reduced on the fly by k_td
                 else { RSeg r; memset(&r, 0, sizeof r); r.part = q.part; r.S = q.S; r.elems = (unsigned long long)L.out_feat * q.ncols; r.mode = 0; r.bias = q.P + L.b_off; r.per_n = L.npos * q.ncols; r.act = L.act; r.out = q.Y;
@@ -313,11 +317,13 @@ int build_program(dqn_engine* e) {
             h.gamma = e->hp.gamma;
             for (int st = 0; st < h.nstream; st++) {
                 const int hl_ = st == 0 ? ha_l : hv_l, pl_ = st == 0 ? rh_pa : rh_pv; const LayerDev& H = e->L[hl_]; const LayerDev& P = e->L[pl_]; RedHeadStream& T = h.st[st];
-                T.part[0] = rh_part[st][0]; T.part[1] = rh_part[st][1]; T.pbias[0] = e->p_on + P.b_off; T.pbias[1] = e->p_tg + P.b_off; T.pact = P.act;
+                T.part[0] = rh_part[st][0]; T.part[1] = rh_part[st][1]; T.partT[0] = rh_partT[st][0]; T.partT[1] = rh_partT[st][1]; T.pbias[0] = e->p_on + P.b_off; T.pbias[1] = e->p_tg + P.b_off; T.pact = P.act;
                 T.W[0] = e->p_on + H.w_off; T.W[1] = e->p_tg + H.w_off; T.hbias[0] = e->p_on + H.b_off; T.hbias[1] = e->p_tg + H.b_off; T.N = H.N; T.hact = H.act;
                 T.y_on = e->act_on[pl_]; T.dpre = e->dact[hl_]; T.dsrc = e->dact[pl_];
             }
             if (h.nstream == 1) h.st[1] = h.st[0];      // (never read: keeps every pointer of the record valid)
+            { bool allT = true; for (int st = 0; st < h.nstream; st++) allT = allT && h.st[st].partT[0] && h.st[st].partT[1];      // transposed copies: all four or none
+              if (!allT || e->opt.no_head_cols4 == 2) for (int st = 0; st < 2; st++) h.st[st].partT[0] = h.st[st].partT[1] = nullptr; }
             h.bm_a = e->gb_a2; h.bm_r = e->gb_r2; h.bm_done = e->gb_done2; h.bm_w = e->gb_w2;
             h.w_is = e->w_is; h.td = e->td; h.q_on_s = e->q_on_s; h.q_on_sp = e->q_on_sp; h.q_tg_sp = e->q_tg_sp; h.ytarget = e->ytarget; h.best = e->best; h.hl = hl_buf; h.stt = e->state;
             h.idx = e->idx; h.idx_pre = e->idx_pre;
@@ -326,7 +332,7 @@ int build_program(dqn_engine* e) {
             HIPCHK(hipMemset(h.tickets, 0, (size_t)Gc * 4));      // armed once; every launch's last arrivers re-arm their groups
             if (e->opt.drqn_stamps) { h.stamps = (unsigned long long*)palloc(e, 64); HIPCHK(hipMemset(h.stamps, 0, 256)); e->drqn_stamps = h.stamps; }
             const RedHeadArgs* h_dev = upload(e, std::vector<RedHeadArgs>(1, h));
-            e->prog.push_back({"red_head", [=](dqn_engine* en) { launch_red_head(en->stream, h, h_dev, en->step_sampled ? 1 : 0, en->step_take_pre ? 1 : 0); }});
+            e->prog.push_back({h.S == 1 ? "head_cols4" : "red_head", [=](dqn_engine* en) { launch_red_head(en->stream, h, h_dev, en->step_sampled ? 1 : 0, en->step_take_pre ? 1 : 0); }});
         }
         else if (fuse_heads) {
             HeadTdArgs h; memset(&h, 0, sizeof h);

@@ -113,10 +113,7 @@ __device__ __forceinline__ void gemm_tail_run(const GemmTail& tail, unsigned blk
 struct GFwdProb { const float* W; const float* bias; const float* X; int ldx, col0, ncols; float* out; int mtiles, mgroups; float* outT; };      // outT: optional transposed copy [column][N] (dense, one chunk)
 struct GFwdProbs { GFwdProb p[4]; int wg_end[4]; };   // up to 4 problems of one geometry per launch: {val,adv} x {online,target}
 
-#ifndef DQN_F_KT
-#define DQN_F_KT 32
-#endif
-constexpr int F_KT_DEF = DQN_F_KT;  // K tile depth of the small-batch launches (32 or 64); launches of >= 1024 workgroups use 16-deep tiles (see launch_gemm_fwd)
+constexpr int F_KT_DEF = 32;    // K tile depth of the small-batch launches; launches of >= 1024 workgroups use 16-deep tiles (see launch_gemm_fwd).  64-deep tiles measured slower (r03) and were removed
 constexpr int F_SA = 80;        // A tile row stride (64 columns + 16 pad): ds_read_b32 of lanes (i, kq) hits banks 16*kq + i
 template <int NT> struct FwdCfg { static constexpr int NW = 16 * NT; static constexpr int SB = (NW % 32 == 0) ? NW + 16 : NW + 32; };
 
@@ -614,105 +611,8 @@ static bool fwd_wres_ok(const LayerDev& L, long mg_total, int S) {
     return fwd_wres_lds(L, 1) <= (size_t)(160 * 1024 / 3 - 256);
 }
 
-// =====================================================================================================================
-// forward, LDS-DMA form (experiment, DQN_FWD_DMA=1; 64-channel tiles, float operands): the tiles are written by
-// global_load_lds_dwordx4 -- global memory straight into LDS, no register staging, no ds_write -- into UNPADDED [16][64] tiles; the bank
-// conflict padding used to avoid (rows k and k+1 on the same banks for the 16-lane fragment reads) is removed by swizzling on the GLOBAL
-// side instead: the lane that fills chunk c of an odd row fetches chunk c ^ 4, so element (k, col) lives at col ^ 16*(k & 1).
-// A ring of DMA_D tiles keeps DMA_D - 1 tiles of loads in flight; one barrier per K tile.  Same chains as k_fwd_lds (k ascending per accumulator).
-// MEASURED (r03, config 5): bit-exact, and no faster -- conv2 / conv3 forward 88.4 / 63.3 us at ring depth 3 vs 86.1 / 63.7 us for the register-staged kernel
-// (depth 4: 90.8 / 70.0, its 32 KB cost occupancy).  Opt-in so that the measurement can be repeated.
-// =====================================================================================================================
-#ifndef DQN_DMA_D
-#define DQN_DMA_D 3
-#endif
-constexpr int DMA_KT = 16, DMA_D = DQN_DMA_D;      // 16-row tiles (a wave's DMA instruction fills 4 rows, the 4 waves one tile); ring depth 3: 24 KB, six workgroups per CU
-__global__ __launch_bounds__(256) void k_fwd_dma(LayerDev L, GFwdProbs pr, int S, int kc) {
-    constexpr int NT = 4, NW = 64, KT = DMA_KT, D = DMA_D;
-    extern __shared__ __align__(16) float lds[];
-    float* As = lds;                                   // [D][KT][64]
-    float* Bs = lds + D * KT * 64;                     // [D][KT][64]
-    int* koff_lds = (int*)(Bs + D * KT * 64);          // [K] (conv only)
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
-    karg_warm<sizeof(LayerDev) + sizeof(GFwdProbs) + 8>();
-    const bool conv = L.kind == DQN_LAYER_CONV;
-    if (conv) {
-        const float r_khw = __builtin_amdgcn_rcpf((float)(L.kh * L.kw)), r_kw = __builtin_amdgcn_rcpf((float)L.kw); const int khw = L.kh * L.kw;      // (1-ulp reciprocals: exact for these ranges, fdiv_of in common.h)
-        for (int k = tid; k < L.K; k += 256) { const int ci = (int)(((float)k + 0.5f) * r_khw); const int rem = k - ci * khw; const int ky = (int)(((float)rem + 0.5f) * r_kw); koff_lds[k] = (ci * L.ih + ky) * L.iw + (rem - ky * L.kw); }
-    }
-    int pi = 0;
-    while (pi < 3 && (int)blockIdx.x >= pr.wg_end[pi]) pi++;
-    const GFwdProb& p = pr.p[pi];
-    const int wg_begin = pi == 0 ? 0 : pr.wg_end[pi - 1];
-    int w = xcd_remap(blockIdx.x - wg_begin, pr.wg_end[pi] - wg_begin);
-    const int ngroups = L.N / NW;
-    const int ng = w % ngroups; w /= ngroups;
-    const int mgrp = w % p.mgroups; const int s = w / p.mgroups;
-    const int n0 = ng * NW, ctiles = p.ncols >> 4;
-    const int k0 = s * kc, k1 = min(L.K, k0 + kc), nkt = (k1 - k0) / KT;
-    // ---- this lane's part of a tile: row 4*wave + (lane >> 4) of the 16, LDS chunk c = lane & 15; it FETCHES chunk c ^ 4 on odd rows
-    const int rw = lane >> 4, krow = 4 * wave + rw;
-    const int cg = l15 ^ (4 * (rw & 1));               // global chunk (4 columns / channels) of this lane
-    int amt = mgrp * 4 + (cg >> 2); if (amt >= p.mtiles) amt = p.mtiles - 1;      // ragged last group: re-fetch a valid tile (its results are not stored)
-    int a_xb = 0; const int a_pos = amt / ctiles, a_ct = amt % ctiles;
-    if (conv) { const int oy = a_pos / L.ow, ox = a_pos % L.ow; a_xb = oy * L.sh * L.iw + ox * L.sw; }
-    const float* Xa = p.X + p.col0 + a_ct * 16 + (cg & 3) * 4;
-    const float* Wb = p.W + n0 + 4 * cg;
-    const unsigned ldx = (unsigned)p.ldx;
-    if (conv) __syncthreads();
-    typedef __attribute__((address_space(3))) void lds_void;
-    auto dma = [&](int kt) {                           // the two 16-byte loads of this lane for tile kt into ring slot kt % D (clamped: always issued)
-        kt = min(kt, nkt - 1);
-        const int slot = kt % D, k = k0 + kt * KT + krow;
-        const int ko = conv ? koff_lds[k] : k;
-        __builtin_amdgcn_global_load_lds(Xa + (unsigned)(a_xb + ko) * ldx, (lds_void*)(As + (slot * KT + 4 * wave) * 64), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(Wb + (unsigned)k * (unsigned)L.N, (lds_void*)(Bs + (slot * KT + 4 * wave) * 64), 16, 0, 0);
-    };
-    f32x4 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float bias_r[NT];
-#pragma unroll
-    for (int t = 0; t < NT; t++) bias_r[t] = S == 1 ? p.bias[n0 + 16 * t + l15] : 0.0f;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the bias loads: the counted waits below assume only DMA loads are in flight)
-    const int sw = 16 * (kq & 1);                      // fragment rows 4*st + kq have the parity of kq
-    auto compute = [&](int slot) {
-        const float* Ab = As + (slot * KT + kq) * 64 + ((16 * wave + l15) ^ sw);
-        const float* Bb = Bs + (slot * KT + kq) * 64 + l15;
-        float af[KT / 4], bf[KT / 4][NT];
-#pragma unroll
-        for (int st = 0; st < KT / 4; st++) {
-            af[st] = Ab[4 * st * 64];
-#pragma unroll
-            for (int t = 0; t < NT; t++) bf[st][t] = Bb[4 * st * 64 + ((16 * t) ^ sw)];      // channel 16 t + l15 of an odd row sits at 16 (t ^ 1) + l15
-        }
-#pragma unroll
-        for (int st = 0; st < KT / 4; st++)
-#pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = MFMA(af[st], bf[st][t], acc[t]);
-    };
-#pragma unroll
-    for (int d = 0; d < D - 1; d++) dma(d);
-    for (int kt = 0; kt < nkt; kt++) {
-        // tile kt's loads are the oldest in flight; 2 loads per tile and lane, D - 2 newer tiles behind them
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 2)) : "memory");
-        __syncthreads();                               // every lane's part of tile kt has landed; every wave is done with tile kt - 1
-        dma(kt + D - 1);                               // into the slot tile kt - 1 just left
-        compute(kt % D);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int mt = mgrp * 4 + wave;
-    if (mt >= p.mtiles) return;
-    const int pos = mt / ctiles, ct = mt % ctiles;
-    const size_t per_s = (size_t)L.N * L.npos * p.ncols;
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-        const int n = n0 + 16 * t + l15;
-        f32x4 v = acc[t];
-        if (S == 1) { const float bias = bias_r[t]; act_v4(v, bias, L.act); }
-        st_out4(reinterpret_cast<f32x4*>(p.out + (size_t)s * per_s + ((size_t)n * L.npos + pos) * p.ncols + ct * 16 + 4 * kq), v, L.opt & DQN_LOPT_ST_WT);
-    }
-}
+// (r03 experiment, removed in r05: an LDS-DMA form of the forward -- global_load_lds_dwordx4 into unpadded, globally swizzled tiles, ring depth 3 -- was bit-exact and no faster:
+//  conv2 / conv3 forward at config 5 88.4 / 63.3 us vs 86.1 / 63.7 us for the register-staged kernel; DESIGN.md section 8.1 keeps the numbers)
 static int fwd_pick_nt(const LayerDev& L, long mgroups_total, int S) {
     // widest N tile (most reuse of the im2col'd A tile) that still yields >= ~400 workgroups.  Dense layers at B=32 stream
     // their weights once whatever the tile, so they too prefer more, narrower workgroups (measured: FC1 forward 19.2 -> 16.3 us
@@ -783,16 +683,11 @@ void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* 
     // batches): half the LDS per workgroup doubles the resident waves (3-4 -> 6-8 per SIMD), which hides more of the operand latency than the extra
     // barrier rounds cost -- measured at config 5 (r03): conv forwards 129.7 / 93.4 / 67.0 -> 120.8 / 85.5 / 63.0 us; at config 2 the same tiles LOSE 1.5 us per launch
     const int kt16_min = 1024;
-    const bool k16 = end >= kt16_min && F_KT_DEF == 32;
+    const bool k16 = end >= kt16_min;
     const int kt = k16 ? 16 : F_KT_DEF;
     const size_t lds = (size_t)(2 * kt * F_SA + 2 * kt * SB) * 4 + (L.kind == DQN_LAYER_CONV ? (size_t)L.K * 4 : 0);
 #define FWD_LAUNCH(NT_, U8_, KT_) hipLaunchKernelGGL((k_fwd_lds<NT_, U8_, KT_>), dim3(end), dim3(256), lds, st, L, pr, S, kc)
 #define FWD_PICK(U8_, KT_) do { if (NT == 4) FWD_LAUNCH(4, U8_, KT_); else if (NT == 2) FWD_LAUNCH(2, U8_, KT_); else FWD_LAUNCH(1, U8_, KT_); } while (0)
-    if ((L.opt & DQN_LOPT_FWD_DMA) && !want_t && NT == 4 && !L.xu8 && L.K % DMA_KT == 0 && (S == 1 || kc % DMA_KT == 0) && end >= kt16_min) {
-        const size_t ldsd = (size_t)(2 * DMA_D * DMA_KT * 64) * 4 + (L.kind == DQN_LAYER_CONV ? (size_t)L.K * 4 : 0);
-        hipLaunchKernelGGL(k_fwd_dma, dim3(end), dim3(256), ldsd, st, L, pr, S, kc);
-        return;
-    }
     // 32x32x2 MFMA blocks for the 64-channel tiles: large launches by default (r04), everywhere with DQN_FWD_M32=1, nowhere with =0 (read at dqn_engine_create)
     const int m32 = ((L.opt & DQN_LOPT_NO_FWD_M32) || want_t) ? 0 : ((L.opt & DQN_LOPT_FWD_M32) || k16) ? 1 : 0;
     if (m32 && NT == 4 && !L.xu8) { if (k16) hipLaunchKernelGGL((k_fwd_lds<4, false, 16, true>), dim3(end), dim3(256), lds, st, L, pr, S, kc); else hipLaunchKernelGGL((k_fwd_lds<4, false, F_KT_DEF, true>), dim3(end), dim3(256), lds, st, L, pr, S, kc); }

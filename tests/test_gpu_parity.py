@@ -352,14 +352,12 @@ def test_single_launch_step_edge_cases(pkg, netf, B, cap, kw):
     assert [n for n, _ in gpu.profile_step()] == ["tiny_step"]
 
 
-@pytest.mark.parametrize("knob,val,B", [("DQN_FWD_M32", "1", 128), ("DQN_FWD_M32", "0", 384), ("DQN_FWD_DMA", "1", 384)])
+@pytest.mark.parametrize("knob,val,B", [("DQN_FWD_M32", "1", 128), ("DQN_FWD_M32", "0", 384)])
 def test_forward_32x32_mfma_blocks_bit_exact(pkg, monkeypatch, knob, val, B):
     """DQN_FWD_M32 (read at dqn_engine_create): the forward launches with 64-channel tiles use 2 x 2 blocks of v_mfma_f32_32x32x2_f32 per workgroup instead of
     four 16x16x4 accumulators per wave -- by default in the large launches (>= 1024 workgroups, r04: B = 384 here and in the config-5 tests), with =1 in every
     launch (B = 128), with =0 in none (the 16x16x4 form of the large launches stays under test).  The 32x32x2 instruction accumulates its two k steps in order like
-    the 16x16x4 one accumulates its four: the same k-ascending chain, bit-identical to the twin (DESIGN.md sections 6.6, 6.10).
-    DQN_FWD_DMA=1: the large forward launches with 64-channel tiles fetch their operands with global_load_lds_dwordx4 into unpadded, globally swizzled
-    tiles (k_fwd_dma; engaged from 1024 workgroups: B = 384 here, 1458 for the 4x4 conv layer) -- same chains, same verdict."""
+    the 16x16x4 one accumulates its four: the same k-ascending chain, bit-identical to the twin (DESIGN.md sections 6.6, 6.10)."""
     monkeypatch.setenv(knob, val)
     net = nature_dueling()
     gpu, cpu, _ = make_pair(pkg, net, B, cap=512, learning_rate=1e-3, gamma=0.99)
@@ -466,6 +464,43 @@ def test_fused_reduce_head_launch_both_schedules(pkg, monkeypatch, netf, B, kw):
         outs.append((gpu.get_params(0), gpu.get_adam_state()[0]))
         gpu.close(); cpu.close()
     np.testing.assert_array_equal(outs[0][0], outs[1][0]); np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("netf,B,kw", [(nature_dueling, 128, dict(gamma=0.99)), (nature_dueling, 132, dict(gamma=0.99, double_q=0)), (_wide_fc_dueling_tanh, 160, dict(gamma=0.95)),
+                                       (_wide_fc_plain, 256, dict(gamma=0.9, prioritized_replay=0))])
+def test_head_level_four_columns_per_workgroup_both_schedules(pkg, monkeypatch, netf, B, kw):
+    """r05: at batches whose hidden-layer forwards are NOT split-K the head level is k_head_cols4 (red_head.hip): one workgroup per group of four batch columns pulls its 12
+    columns of the hidden layers as 16-byte pieces, runs the chunk chains, the TD arithmetic and the heads' dX (16-byte stores) -- instead of k_head_td's one workgroup per
+    column reading a transposed copy.  Same chains in the same order: both schedules (DQN_NO_HEAD_COLS4=1 keeps k_head_td) bit-exact against the twin and each other."""
+    net = netf()
+    outs = []
+    for fused in (True, 2, False):      # (2: k_head_cols4 reading the [K][columns] activations themselves -- its loader when no transposed copy exists)
+        if fused is not True:
+            monkeypatch.setenv("DQN_NO_HEAD_COLS4", "2" if fused else "1")
+        gpu, cpu, hp = make_pair(pkg, net, B, cap=B + 72, **kw)
+        monkeypatch.delenv("DQN_NO_HEAD_COLS4", raising=False)
+        fill((gpu, cpu), net, B + 40, seed=5)
+        set_same_params((gpu, cpu), net, seed=3)
+        for _ in range(2):
+            assert_step_bit_exact(gpu, cpu)
+        assert_step_bit_exact(gpu, cpu, np.random.default_rng(1).integers(0, B + 40, B))
+        lg = gpu.train_steps(3)
+        for _ in range(3):
+            lc = cpu.train_step(want_td=False)
+        assert lg == lc
+        np.testing.assert_array_equal(gpu.get_grads(), cpu.get_grads())
+        np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+        np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
+        names = [n for n, _ in gpu.profile_step()]
+        if fused:
+            assert "head_cols4" in names or "red_head" in names, names      # (a plan that splits the hidden layer's forward at this batch takes k_red_head)
+            assert netf is not nature_dueling or "head_cols4" in names, names
+        else:
+            assert "head_cols4" not in names, names
+        outs.append((gpu.get_params(0), gpu.get_adam_state()[0]))
+        gpu.close(); cpu.close()
+    for o in outs[1:]:
+        np.testing.assert_array_equal(outs[0][0], o[0]); np.testing.assert_array_equal(outs[0][1], o[1])
 
 
 def test_fused_reduce_head_hand_off_soak(pkg, monkeypatch):
