@@ -2,7 +2,7 @@
 # r05_u: TIMING PROBES (wrong numbers, right schedule) of the dW body at config 5: build variants -DDQN_DWP=bits (1 no MFMA, 2 no byte conversion, 4 every tile re-reads tile 0,
 # 8 no bias sums, 16 no LDS stores, 32 no barriers); per-launch HIP-event durations of the launches that run dw_lds_body
 mkdir -p gpurun_out
-for v in 0 1 2 4 8 16 48 6 0; do
+for v in ${DWPS:-0 1 2 4 8 16 48 6 0}; do
   DQN_MI355X_LIB=$PWD/deepqlearning.jl_amd/build/dwp$v.so timeout 200 python bench.py --batch 512 --u8 --replay 100000 --device-fill --steps 30 --warmup 5 --no-cpu-baseline --env-steps 0 --sustained-seconds 0 --no-secondary 2>/dev/null > gpurun_out/dwp$v.json
   python - <<PY
 import json
