@@ -522,9 +522,13 @@ def main():
     barrier()
     t0 = time.perf_counter()
     loss, gnorm = eng.train_steps(args.steps)       # K graph replays back to back; one host sync at the end
+    t_call = time.perf_counter()
     eng.sync()
+    t_sync = time.perf_counter()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    region_split = {"dqn_train_steps_call": (t_call - t0) * 1e6, "engine_stream_sync": (t_sync - t_call) * 1e6, "torch_cuda_synchronize": (t1 - t_sync) * 1e6,
+                    "note": "rank 0's split of the timed region (us): the K-step call (returns when the last step's scalars are in the host mailbox), then the two synchronisations the contract asks for"}
     elapsed = group.max_over_ranks(t1 - t0)
     group.barrier()
     ms_per_step = elapsed / args.steps * 1e3
@@ -596,6 +600,7 @@ def main():
         out = {
             "metric": f"train steps/sec (batch={args.batch}, 84x84x4 obs)", "value": value, "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "timed_region_us": region_split,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_name(args, world), "sampling": "distinct (replace=false, ...replay.jl:85)" if args.distinct else "stratified sum-tree (with replacement)",
                        "batch_per_rank": args.batch, "global_batch": args.batch * world, "replay_per_rank": args.replay,
