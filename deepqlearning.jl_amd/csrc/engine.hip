@@ -813,6 +813,7 @@ int fetch_scalars(dqn_engine* e, float* loss, float* gn) {
     if (s.err) { HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&e->state->err, 0, 1, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); }      // reported once, not on every later call
     if (s.err == 2) return fail("AssertionError: all(new_priorities .> 0f0)");
     if (s.err == 3) return fail("internal error: a pre-gathered batch was consumed after the replay changed (StepState::pre_valid != 2)");
+    if (s.err) return mail_err_msg(s.err, (unsigned long long)s.step);
     if (loss) *loss = s.loss;
     if (gn) { float g; memcpy(&g, &s.gnorm_bits, 4); *gn = g; }
     return 0;
