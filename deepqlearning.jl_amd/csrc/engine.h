@@ -123,6 +123,7 @@ struct dqn_engine {
     bool drqn_fused = false;      // recurrent step = the column-parallel launch (which gathers its own episode rows) + the Adam launch (drqn_cols.hip)
     hipGraphExec_t g_pgv[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [take_pre][pregather] variants of the sampled single-device step
     hipGraphExec_t g_mid = nullptr; int mid_group = 4;                          // mid_group consecutive middle steps of dqn_train_steps as one graph
+    bool mid_big_warm = false;                                                  // g_mid_big has been launched at least once (its first launch is the expensive one)
     hipGraphExec_t g_mid_big = nullptr; int mid_big = 16;                       // ... and runs of mid_big of them (DQN_MID_BIG; 0 = off): 20 steps = first + 16 + 2 single + last
     hipGraphExec_t g_pre1[3] = {nullptr, nullptr, nullptr}, g_pre2 = nullptr;
     hipGraphExec_t g_dp_one[4] = {nullptr, nullptr, nullptr, nullptr}; int dp_one_state = 0;      // replicas: the WHOLE step incl. its collective(s) as ONE graph ([take_pre][pregather]); state 0 untried, 1 works, -1 RCCL refused the capture      // dp_overlap: first half cut in two ([0] sampled, [1] given indices, [2] without the gather launch)

@@ -300,7 +300,7 @@ void drop_graphs(dqn_engine* e) {
     if (e->g_post_pg) { hipGraphExecDestroy(e->g_post_pg); e->g_post_pg = nullptr; }
     if (e->g_mid) { hipGraphExecDestroy(e->g_mid); e->g_mid = nullptr; }
     for (int k = 0; k < 2; k++) { if (e->g_drqn_k[k]) { hipGraphExecDestroy(e->g_drqn_k[k]); e->g_drqn_k[k] = nullptr; } if (e->g_drqn[k]) { hipGraphExecDestroy(e->g_drqn[k]); e->g_drqn[k] = nullptr; } }
-    if (e->g_mid_big) { hipGraphExecDestroy(e->g_mid_big); e->g_mid_big = nullptr; }
+    if (e->g_mid_big) { hipGraphExecDestroy(e->g_mid_big); e->g_mid_big = nullptr; } e->mid_big_warm = false;
     if (e->g_pre_tp) { hipGraphExecDestroy(e->g_pre_tp); e->g_pre_tp = nullptr; }
     for (int i = 0; i < 3; i++) if (e->g_pre1[i]) { hipGraphExecDestroy(e->g_pre1[i]); e->g_pre1[i] = nullptr; }
     for (int i = 0; i < 4; i++) if (e->g_dp_one[i]) { hipGraphExecDestroy(e->g_dp_one[i]); e->g_dp_one[i] = nullptr; }
@@ -940,8 +940,11 @@ extern "C" int dqn_train_steps(dqn_engine_t* e, int n, float* loss, float* grad_
     for (int i = 0; i < n;) {
         // a run of identical steps: middle steps (pipelined gather) or, where that does not apply, any steps
         const int BIG = e->mid_big;
-        if (single && BIG > MID_GROUP && e->g_mid_big && (pg ? (i >= 1 && i + BIG <= n - 1) : (i + BIG <= n))) {
-            HIPCHK(hipGraphLaunch(e->g_mid_big, e->stream));
+        // (the FIRST launch of a graph exec costs more than the later ones, uploaded or not, and the more the bigger the graph -- tools/r05_run_y2.sh: a 20-step call that is the
+        //  first to use the 16-step group reads 129.5 us/step, with the 4-step group only 128.1.  So a short call stays with the small group until some long call -- which
+        //  amortises the ~28 us -- has launched the big one)
+        if (single && BIG > MID_GROUP && e->g_mid_big && (e->mid_big_warm || n >= 4 * BIG) && (pg ? (i >= 1 && i + BIG <= n - 1) : (i + BIG <= n))) {
+            HIPCHK(hipGraphLaunch(e->g_mid_big, e->stream)); e->mid_big_warm = true;
             i += BIG; continue;
         }
         if (single && MID_GROUP > 1 && e->g_mid && (pg ? (i >= 1 && i + MID_GROUP <= n - 1) : (i + MID_GROUP <= n))) {
