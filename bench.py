@@ -421,9 +421,21 @@ def main():
     if sim_comm:
         local_rank = 0
         os.environ["DQN_SIM_WORLD"] = str(world)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run (one rank per GPU, loopback rendezvous on a free port); rank 0 of the
+        # child prints the ONE JSON line, the child's return code is ours.  The torchrun form the driver uses for N > 1 arrives with WORLD_SIZE set and skips this.
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=env).returncode)
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: a launcher's world size must equal --gpus (plain `python bench.py --gpus N` launches itself)", file=sys.stderr)
         sys.exit(2)
 
     if args.dp_overlap == 1:

@@ -505,7 +505,7 @@ __device__ __forceinline__ void prio_block_run(const PrioArgs& P, StepState* sta
     const float seg = P.tree[1] / (float)P.B;
     if (P.distinct) {      // draws -> LDS, dedupe, publish; without room for the scratch (20 bytes per draw) nothing is pre-drawn: the next sample() draws itself
         const unsigned have = lds_bytes ? lds_bytes : 8192u;
-        if ((unsigned)P.B * 20u + 8u > have) return;
+        if ((unsigned)P.B * 20u + 8u > have) { if (threadIdx.x == 0) state->pre_valid = 0; __syncthreads(); return; }      // (a stale pre_valid would let the next gather reuse the batch it already consumed)
         long long* list = sidx; long long* taken = sidx + P.B; float* tp = reinterpret_cast<float*>(sidx + 2 * P.B); int* any = reinterpret_cast<int*>(tp + P.B);
         for (int i = threadIdx.x; i < P.B; i += blockDim.x) list[i] = tree_descend(P.tree, P.cap2, size, P.seed, ctr, i, seg);
         __syncthreads();

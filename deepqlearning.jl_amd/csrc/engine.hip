@@ -122,7 +122,7 @@ void read_opts(EngineOpts& o, bool comm_only) {
     o.mid_group = I("DQN_MID_GROUP", 4); o.mid_big = I("DQN_MID_BIG", 16); o.sim_world = I("DQN_SIM_WORLD", 0); o.no_graph_upload = F("DQN_NO_GRAPH_UPLOAD");
     o.no_rollout_cycle = F("DQN_NO_ROLLOUT_CYCLE"); o.no_u8_arena = F("DQN_NO_U8_ARENA"); o.head_fuse_maxb = I("DQN_HEAD_FUSE_MAXB", 1024); o.no_head_fuse = F("DQN_NO_HEAD_FUSE");
     o.head_dbg = I("DQN_HEAD_DBG", 0); o.prio_fork = F("DQN_PRIO_FORK"); o.prio_level = I("DQN_PRIO_LEVEL", 0); o.prio_nosplit = F("DQN_PRIO_NOSPLIT"); o.no_pregather = F("DQN_NO_PREGATHER");
-    o.no_red_head = F("DQN_NO_RED_HEAD"); o.no_head_cols4 = I("DQN_NO_HEAD_COLS4", 0); o.no_st_wt = F("DQN_NO_ST_WT");
+    o.dw_split = I("DQN_DW_SPLIT", 128); o.no_red_head = F("DQN_NO_RED_HEAD"); o.no_head_cols4 = I("DQN_NO_HEAD_COLS4", 0); o.no_st_wt = F("DQN_NO_ST_WT");
     o.lstm_dw_mfma = F("DQN_LSTM_DW_MFMA"); o.probe_no_tg = F("DQN_PROBE_NO_TG"); o.drqn_probe = I("DQN_DRQN_PROBE", 0); o.drqn_stamps = F("DQN_DRQN_STAMPS"); o.tiny_stop = I("DQN_TINY_STOP", 0);
 }
 static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out, const dqn_hparams* hp, bool allow_cg = true) {
@@ -203,6 +203,7 @@ static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers
     e->mid_group = e->opt.mid_group;      // middle steps of dqn_train_steps per graph launch (1 = one step per graph: no grouped graphs at all)
     e->mid_big = e->opt.mid_group > 1 ? e->opt.mid_big : 0;
     { const int lopt = (e->opt.fwd_m32 > 0 ? DQN_LOPT_FWD_M32 : 0) | (e->opt.fwd_m32 == 0 ? DQN_LOPT_NO_FWD_M32 : 0) | (e->opt.no_dx_wide ? DQN_LOPT_NO_DX_WIDE : 0) | (e->opt.no_fwd_wres ? DQN_LOPT_NO_FWD_WRES : 0) |
+                       ((std::min(255, std::max(0, e->opt.dw_split / 16)) & 0xff) << 8) | 
                        ((!e->opt.no_st_wt && (long long)hp->batch_size * (hp->recurrence ? hp->trace_length : 1) <= 64) ? DQN_LOPT_ST_WT : 0); for (int i = 0; i < e->nl; i++) e->L[i].opt = lopt; }
     if (e->opt.sim_world >= 1 && !hp->recurrence) { e->sim_world = e->opt.sim_world; e->world = e->opt.sim_world; }   // tests: one process plays k identical ranks
     dqn_layer_plan defp[DQN_MAX_LAYERS];
@@ -742,9 +743,10 @@ static inline void cpu_relax() {
 #define DQN_MAIL_TIMEOUT_S 30        /* a publish that has not arrived after this long while the stream is still busy: a kernel of the step is hung -- say so */
 static inline double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 static int mail_err_msg(int err, unsigned long long step) {
-    if (err == 2) return fail("AssertionError: all(new_priorities .> 0f0) (train step %llu)", step);
-    if (err == 3) return fail("internal error: a pre-gathered batch was consumed after the replay changed (StepState::pre_valid != 2; train step %llu)", step);
-    return fail("device-side error %d in train step %llu", err, step);
+    // (`step` is the step counter at PUBLISH time: inside dqn_train_steps(n) / a rollout cycle only the last step publishes, so the failure is at or before it)
+    if (err == 2) return fail("AssertionError: all(new_priorities .> 0f0) (at or before train step %llu)", step);
+    if (err == 3) return fail("internal error: a pre-gathered batch was consumed after the replay changed (StepState::pre_valid != 2; at or before train step %llu)", step);
+    return fail("device-side error %d at or before train step %llu", err, step);
 }
 // wait until publish `ticket` has arrived (its record holds seq == ticket).  Returns 0 = arrived, 1 = not yet (wait == false), -1 = error (message set)
 static int mail_arrive(dqn_engine* e, unsigned long long ticket, bool wait) {
@@ -849,6 +851,7 @@ extern "C" int dqn_train_step_async(dqn_engine_t* e, const int64_t* idx, uint64_
         float l = 0.0f, g = 0.0f;
         if (run_step(e, idx == nullptr)) return -1;
         if (fetch_scalars(e, &l, &g)) return -1;
+        if (mail_sweep(e)) return -1;      // (the stream is idle: every device-published record has arrived -- their error fields are looked at before the host's own record is numbered past them)
         const unsigned long long t = ++e->pub_issued; e->mail_swept = t;
         StepMail* m = e->mail_host + (t & (DQN_MAIL_SLOTS - 1));
         m->loss = l; m->gnorm = g; m->err = 0; m->step = 0; __atomic_store_n(&m->seq, t, __ATOMIC_RELEASE);
@@ -1058,6 +1061,17 @@ extern "C" int dqn_comm_init(dqn_engine_t* e, const void* id128, int rank, int w
     if (cgp && !e->plan_defaulted)
         return fail("dqn_comm_init: this engine was created with a column-group dW plan (dw_kc < 0: the fused single-device recurrent step); replicas need dw_kc >= 0 -- "
                     "create the engine with plan = NULL (the default plan is then re-derived for replicas here) or with contiguous dW chunks");
+    Id128 id; memcpy(id.b, id128, 128);
+    const int rc = g_rccl.CommInitRank(&e->comm, world, id, rank);
+    if (rc) return fail("ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    // (the communicator first: a failed ncclCommInitRank leaves plan, partials, program and graphs as they were)
+    read_opts(e->opt, /*comm_only*/ true);      // the communicator switches, as of this call
+    e->rank = rank; e->world = world; e->sim_world = 0; e->force_comm = e->opt.force_allreduce != 0; e->dp_one_state = 0;
+    // the launch program depends on the exchange mode and the world size: rebuild it on the next step
+    drop_graphs(e); HIPCHK(hipStreamSynchronize(e->stream));
+    for (void* p : e->prog_allocs) hipFree(p);
+    e->prog_allocs.clear(); e->prog.clear(); e->prog_built = false; e->prog_post_begin = 0; e->final_reduce_step = -1; memset(&e->adam_segs, 0, sizeof e->adam_segs);
+    hipFree(e->dp_send); hipFree(e->dp_recv); e->dp_send = e->dp_recv = nullptr; e->dp_gather = e->dp_pack_folds = e->dp_adam_folds = false; e->dp_count = 0;
     if (cgp) {
         HIPCHK(hipStreamSynchronize(e->stream));
         dqn_layer_plan defp[DQN_MAX_LAYERS]; default_plan(e->L, e->nl, e->B, defp, &e->hp, /*allow_cg*/ false);
@@ -1071,16 +1085,6 @@ extern "C" int dqn_comm_init(dqn_engine_t* e, const void* id128, int rank, int w
         HIPCHK(hipMemcpy(e->L_dev, e->L, sizeof(LayerDev) * e->nl, hipMemcpyHostToDevice));
         if (pmax > e->partials_elems) { hipFree(e->partials); e->partials = nullptr; DM(e->partials, 2 * pmax); e->partials_elems = pmax; }
     }
-    Id128 id; memcpy(id.b, id128, 128);
-    const int rc = g_rccl.CommInitRank(&e->comm, world, id, rank);
-    if (rc) return fail("ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
-    read_opts(e->opt, /*comm_only*/ true);      // the communicator switches, as of this call
-    e->rank = rank; e->world = world; e->sim_world = 0; e->force_comm = e->opt.force_allreduce != 0; e->dp_one_state = 0;
-    // the launch program depends on the exchange mode and the world size: rebuild it on the next step
-    drop_graphs(e); HIPCHK(hipStreamSynchronize(e->stream));
-    for (void* p : e->prog_allocs) hipFree(p);
-    e->prog_allocs.clear(); e->prog.clear(); e->prog_built = false; e->prog_post_begin = 0; e->final_reduce_step = -1; memset(&e->adam_segs, 0, sizeof e->adam_segs);
-    hipFree(e->dp_send); hipFree(e->dp_recv); e->dp_send = e->dp_recv = nullptr; e->dp_gather = e->dp_pack_folds = e->dp_adam_folds = false; e->dp_count = 0;
     return 0;
 }
 

@@ -59,7 +59,9 @@ int gemm_set_ktrace(unsigned long long*) { return -1; }     // not a trace build
 // (MI355X guide, "boundary" row: + B / 6 TB/s behind B dirty bytes) and at B = 32 the step is ten short launches that each leave 1-13 MB behind; write-through stores
 // stream out while the launch still runs.  r05, same box, alternating (profiles/r05_l_store_ab.txt): config 2 7960 -> 8115 steps/s with every output write-through (dW only:
 // 8050; activations / slabs / dX only: 7970); config 5 (B = 512: launches of 45-105 us) 1642 -> 1632, so large batches keep plain / non-temporal stores.
-// (inline asm: invisible to hipcc's wait counting -- nothing in a kernel reads these back, and a wave's stores complete before it ends)
+// INVARIANT (inline asm: these stores are invisible to hipcc's vmcnt bookkeeping): NOTHING in the same kernel may read data stored through st_out4 / st_grad4 / adam_st4.
+// A tail or last-arriver consumer added later needs an explicit `s_waitcnt vmcnt(0)` in the producer BEFORE its release (fence + ticket), as red_head.hip does --
+// __threadfence() alone is not enough, the compiler may drop its vmcnt wait when it sees no pending stores.  (A wave's stores complete before it ends: a kernel boundary is safe.)
 __device__ __forceinline__ void st_out4(f32x4* p, const f32x4& v, int wt) {
     if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
     else *p = v;
@@ -122,8 +124,9 @@ template <int NT> struct FwdCfg { static constexpr int NW = 16 * NT; static cons
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // M32 (NT == 4 only; experiment, DQN_FWD_M32=1): the 64-column x 64-channel tile as 2 x 2 blocks of v_mfma_f32_32x32x2_f32, one per wave, instead of four
 // 16x16x4 accumulators per wave -- 32 instead of 40 fragment reads and 16 instead of 32 MFMA instructions per wave and K tile
-template <int NT, bool XU8 = false, int KT = F_KT_DEF, bool M32 = false>
-__global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S, int kc) {
+// one unit of a forward launch: problem p, channels n0 .. n0 + 16 NT - 1, M-group mgrp (64 columns), chunk s
+template <int NT, bool XU8, int KT, bool M32>
+__device__ __forceinline__ void fwd_lds_body(const LayerDev& L, const GFwdProb& p, int S, int kc, int n0, int mgrp, int s) {
     constexpr int NW = FwdCfg<NT>::NW, SB = FwdCfg<NT>::SB, F_KT = KT;
     using AT = std::conditional_t<XU8, uint32_t, f32x4>;
     extern __shared__ float lds[];
@@ -131,20 +134,11 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     float* Bs = lds + 2 * F_KT * F_SA;                 // [2][F_KT][SB]
     int* koff_lds = (int*)(Bs + 2 * F_KT * SB);        // [K] (conv only)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
-    karg_warm<sizeof(LayerDev) + sizeof(GFwdProbs) + 8>();
     KTRACE_BEGIN()
     const bool conv = L.kind == DQN_LAYER_CONV;
-    int pi = 0;
-    while (pi < 3 && (int)blockIdx.x >= pr.wg_end[pi]) pi++;
-    const GFwdProb& p = pr.p[pi];
     constexpr unsigned ESZ = XU8 ? 1u : 4u;            // bytes per arena element
     const unsigned ldb = (unsigned)p.ldx * ESZ;        // bytes per input row
-    const int wg_begin = pi == 0 ? 0 : pr.wg_end[pi - 1];
-    int w = xcd_remap(blockIdx.x - wg_begin, pr.wg_end[pi] - wg_begin);
-    const int ngroups = L.N / NW;                      // (NW is a power of two; the decodes below go through reciprocals: fdiv_*, common.h)
-    int ng, mgrp, s;
-    { int w2; fdiv_qr(w, fdiv_of(ngroups), w2, ng); fdiv_qr(w2, fdiv_of(p.mgroups), s, mgrp); }
-    const int n0 = ng * NW, ctiles = p.ncols >> 4;
+    const int ctiles = p.ncols >> 4;
     const int k0 = s * kc, k1 = min(L.K, k0 + kc), nkt = (k1 - k0) / F_KT;
 
     // ---- this thread's slice of the A tile: column group (t & 15) -> M-tile j = (t&15)>>2, float4 (t&3); rows t>>4, +16
@@ -353,6 +347,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
             if (S == 1) { act_v4(v, bias, L.act); }
             st_out4(reinterpret_cast<f32x4*>(p.out + (size_t)s * per_s + ((size_t)n * L.npos + pos) * p.ncols + ct * 16 + (cc & 15)), v, L.opt & DQN_LOPT_ST_WT);
         }
+        KTRACE(7); KTRACE_END();
         return;
     }
     constexpr int HS = F_KT / 8;                       // MFMA steps per half tile
@@ -400,6 +395,23 @@ __global__ __launch_bounds__(256) void k_fwd_lds(LayerDev L, GFwdProbs pr, int S
     }
     KTRACE(7); KTRACE_END();
 }
+// the kernel: workgroup -> (problem, N-group, M-group, chunk), XCD-contiguous within a problem.
+// (r06, measured and dropped: the launch's last units as two halves along N, as the dW sections do -- conv2 / conv3 forward at B = 512 76.9 / 55.3 -> 76.6 / 54.8 us with 320 units cut,
+//  78.1 / 58.0 with 640: the 16-channel-per-wave half body is slower per FLOP than the 32x32x2 one and these launches' second round is short; profiles/r06_g_split_ab.txt)
+template <int NT, bool XU8 = false, int KT = F_KT_DEF, bool M32 = false>
+__global__ __launch_bounds__(256, (NT == 4 && KT == 16 && M32) ? 6 : 1)      // (the large 32x32x2 launches: six waves per SIMD, accumulators in plain VGPRs -- r06 same box: conv2 / conv3 forward 78.1 / 56.2 -> 76.9 / 55.3 us)
+void k_fwd_lds(LayerDev L, GFwdProbs pr, int S, int kc) {
+    karg_warm<sizeof(LayerDev) + sizeof(GFwdProbs) + 8>();
+    int pi = 0;
+    while (pi < 3 && (int)blockIdx.x >= pr.wg_end[pi]) pi++;
+    const GFwdProb& p = pr.p[pi];
+    const int wg_begin = pi == 0 ? 0 : pr.wg_end[pi - 1];
+    const int w = xcd_remap(blockIdx.x - wg_begin, pr.wg_end[pi] - wg_begin);
+    const int ngroups = L.N / (16 * NT);               // (the decodes go through reciprocals: fdiv_*, common.h)
+    int ng, mgrp, s;
+    { int w2; fdiv_qr(w, fdiv_of(ngroups), w2, ng); fdiv_qr(w2, fdiv_of(p.mgroups), s, mgrp); }
+    fwd_lds_body<NT, XU8, KT, M32>(L, p, S, kc, ng * 16 * NT, mgrp, s);
+}
 
 // =====================================================================================================================
 // forward with the layer's WEIGHTS RESIDENT in LDS (r04; large-batch launches of a narrow layer whose [K][N] block fits beside the A tiles -- the first
@@ -426,6 +438,7 @@ __global__ __launch_bounds__(256) void k_fwd_wres(LayerDev L, GFwdProbs pr) {
     int* koff_lds = (int*)(Bres + L.K * NW);           // [K]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     karg_warm<sizeof(LayerDev) + sizeof(GFwdProbs)>();
+    KTRACE_BEGIN()
     const bool conv = L.kind == DQN_LAYER_CONV;
     int pi = 0;
     while (pi < 3 && (int)blockIdx.x >= pr.wg_end[pi]) pi++;
@@ -601,6 +614,7 @@ __global__ __launch_bounds__(256) void k_fwd_wres(LayerDev L, GFwdProbs pr) {
         go0 = go1; tile_of(gi + 2, go1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the dummy tail loads
+    KTRACE_SET(3, 100); KTRACE(7); KTRACE_END();
 #undef WRES_WAIT
 #undef WRES_STEP
 }
@@ -661,6 +675,9 @@ void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* 
         const int per_cu = (int)((size_t)(160 * 1024) / (lds_b + 256)) < 3 ? (int)((size_t)(160 * 1024) / (lds_b + 256)) : 3;
         const int slots = 256 * per_cu; int end = 0; long wgt[4], wgt_total = 0;
         for (int i = 0; i < nprob; i++) { wgt[i] = (pr.p[i].mtiles + 4 * MT - 1) / (4 * MT); wgt_total += wgt[i]; }
+        // (r06, measured and dropped: EQUAL tile counts -- t = ceil(tiles / slots) tiles per workgroup, ceil(tiles_i / t) workgroups per problem, 480 instead of 512 -- because the ktrace
+        //  shows workgroups walking 4 or 5 tiles and the launch ending a whole tile after its median workgroup: 105.6 vs 105.7 us, profiles/r06_h_ab.txt; fewer M-tiles per wave
+        //  (finer tiles: DQN_WRES_MT = 2 / 1) cost 3 us, profiles/r06_g_split_ab.txt)
         for (int i = 0; i < 4; i++) {
             if (i < nprob) { long w = (slots * wgt[i] + wgt_total / 2) / wgt_total; if (w < 1) w = 1; if (w > wgt[i]) w = wgt[i]; end += (int)w; }
             pr.wg_end[i] = end;
@@ -722,8 +739,9 @@ __device__ __forceinline__ void lds_st4(float* p, f32x4 v) {
     *reinterpret_cast<f32x2*>(p + 2) = (f32x2){v.z, v.w};
 }
 
+struct DwUnit { int pi, ng, mr, s; };      // problem (sibling layer), channel group of 16 NT, 64-row tile, split-K chunk
 template <int NT, bool XU8 = false>
-__device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& pr, int nprob, int ldx, int B, int S, int kc, int bid, int nblocks, DwStride ds, int probe = 0) {
+__device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& pr, int ldx, int B, int S, int kc, const DwUnit& u, DwStride ds, int probe = 0) {
     constexpr int NW = 16 * NT;
     using AT = std::conditional_t<XU8, uint32_t, f32x4>;
     constexpr int BQ = (NW * 8 + 255) / 256;          // float4 per thread for the B tile (1 or 2)
@@ -732,10 +750,7 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
     float* Bs = lds + 2 * 64 * W_ST;                   // [2][NW][W_ST]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const bool conv = L.kind == DQN_LAYER_CONV;
-    const int mrows = (L.K + 63) / 64, ngroups = L.N / NW;
-    int w = xcd_remap(bid, nblocks);
-    int pi, ng, mr, s;                                 // (decodes through reciprocals: fdiv_*, common.h)
-    { int w2, w3; fdiv_qr(w, fdiv_of(nprob), w2, pi); fdiv_qr(w2, fdiv_of(ngroups), w3, ng); fdiv_qr(w3, fdiv_of(mrows), s, mr); }
+    const int pi = u.pi, ng = u.ng, mr = u.mr, s = u.s;
     const GDwProb& p = pr.p[pi];
     const int n0 = ng * NW;
     const int KK = L.npos * B, j0 = s * kc, j1 = min(KK, j0 + kc);
@@ -893,8 +908,31 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
     }
     if (do_bias) out[(size_t)L.K * L.N + n0 + tid] = dbacc;
 }
+// The dW section of a launch: `nblocks` workgroups = nfull whole units (64 rows x 16 NT channels x one chunk) followed by 2 * nsplit HALF units -- the launch's last
+// nsplit units cut in two along N (8 NT channels each; NT >= 2).  r06 ktrace at B = 512 (profiles/r06_b_ktrace_bwd_b512.txt): a backward launch ends in a drain as long as
+// one dW workgroup lives (16-19 us of a 45-77 us launch) at ~40 % occupancy -- the dispatcher runs out of workgroups while the last round is still whole; halves at the end
+// halve the drain.  Every output element keeps its chain (a half contracts the same samples in the same order for half of the channels): bit-identical.
+template <int NT, bool XU8>
+__device__ __forceinline__ void dw_section(const LayerDev& L, const GDwProbs& pr, int nprob, int ldx, int B, int S, int kc, int bid, int nblocks, int nsplit, DwStride ds, int probe = 0) {
+    const int mrows = (L.K + 63) / 64, ngroups = L.N / (16 * NT), nfull = nblocks - 2 * nsplit;
+    int w, half = -1;
+    if (NT == 1 || bid < nfull) w = xcd_remap(bid, nfull);
+    else { const int hw = xcd_remap(bid - nfull, 2 * nsplit); w = nfull + (hw >> 1); half = hw & 1; }
+    DwUnit u;                                          // (decodes through reciprocals: fdiv_*, common.h)
+    { int w2, w3; fdiv_qr(w, fdiv_of(nprob), w2, u.pi); fdiv_qr(w2, fdiv_of(ngroups), w3, u.ng); fdiv_qr(w3, fdiv_of(mrows), u.s, u.mr); }
+    // (r06, measured and dropped: the bias-carrying units (mr == 0: 10-20 % longer, profiles/r06_c_ktrace_groups_b512.txt) leading the section -- conv2's pair 67.6 -> 66.8 us, nothing elsewhere)
+    if constexpr (NT >= 2) { if (half >= 0) { u.ng = 2 * u.ng + half; dw_lds_body<NT / 2, XU8>(L, pr, ldx, B, S, kc, u, ds, probe); return; } }
+    dw_lds_body<NT, XU8>(L, pr, ldx, B, S, kc, u, ds, probe);
+}
+// halves at the end of a dW section: only where a unit is long enough to matter (>= 4 K tiles: large batches) and the tile can be cut (NT >= 2);
+// DQN_DW_SPLIT (LayerDev::opt bits 8..15, in units of 16) = how many of the last units are cut, at most half of them
+static int dw_split_units(const LayerDev& L, int NT, int units, int B) {
+    const int KK = L.npos * B, kc = dqn_chunk_len(KK, L.dw_kc), v = 16 * ((L.opt >> 8) & 0xff);
+    if (NT < 4 || kc < 128 || v == 0) return 0;      // (NT = 2 -> 1: the 16-channel body has no transposed epilogue and conv1's 1024 workgroups are all resident at once -- measured 43.9 -> 54.6 us)
+    return v < units / 2 ? v : units / 2;
+}
 template <int NT, bool XU8 = false>
-__global__ __launch_bounds__(256) void k_dw_lds(LayerDev L, GDwProbs pr, int nprob, int ldx, int B, int S, int kc, DwStride ds, GemmTail tail) {
+__global__ __launch_bounds__(256) void k_dw_lds(LayerDev L, GDwProbs pr, int nprob, int ldx, int B, int S, int kc, DwStride ds, int nsplit, GemmTail tail) {
     // dispatch order: [priority block][tail: VALU tasks, Adam job][dW workgroups] -- the bandwidth-bound tail starts at once and the short dW
     // workgroups fill the slots beside it (at the END of the grid the tail would wait for LDS: every workgroup of a launch reserves the tile size)
     karg_warm<sizeof(LayerDev) + sizeof(GDwProbs) + 32 + sizeof(DwStride) + sizeof(GemmTail)>();
@@ -903,7 +941,7 @@ __global__ __launch_bounds__(256) void k_dw_lds(LayerDev L, GDwProbs pr, int npr
     if (pre_ && blockIdx.x == 0) { extern __shared__ float lds[]; prio_block_run(tail.adam.prio, tail.adam.state, reinterpret_cast<long long*>(lds), tail.lds_bytes); KTRACE_SET(3, 0); KTRACE(7); KTRACE_END(); return; }
     const int bid = (int)blockIdx.x - pre_, ntail = (int)gemm_tail_blocks(tail) - pre_;
     if (bid < ntail) { gemm_tail_run(tail, (unsigned)bid); KTRACE_SET(3, 2); KTRACE(7); KTRACE_END(); return; }
-    dw_lds_body<NT, XU8>(L, pr, nprob, ldx, B, S, kc, bid - ntail, (int)gridDim.x - pre_ - ntail, ds);
+    dw_section<NT, XU8>(L, pr, nprob, ldx, B, S, kc, bid - ntail, (int)gridDim.x - pre_ - ntail, nsplit, ds);
     KTRACE_SET(3, 3);
     KTRACE(7); KTRACE_END();
 }
@@ -918,17 +956,18 @@ void launch_gemm_dw(hipStream_t st, const LayerDev& L, int nprob, const float* c
     GDwProbs pr;
     for (int i = 0; i < 2; i++) { const int j = i < nprob ? i : 0; pr.p[i].X = X[j]; pr.p[i].dpre = dpre[j]; pr.p[i].out = out[j]; }
     const int NT = L.N % 64 == 0 ? 4 : (L.N % 32 == 0 ? 2 : 1);
-    const int grid = ((L.K + 63) / 64) * (L.N / (16 * NT)) * S * nprob + (int)gemm_tail_blocks(tail);
+    const int units = ((L.K + 63) / 64) * (L.N / (16 * NT)) * S * nprob, nsplit = tpr > 0 ? 0 : dw_split_units(L, NT, units, B);
+    const int grid = units + nsplit + (int)gemm_tail_blocks(tail);
     const size_t lds = (size_t)(2 * 64 * W_ST + 2 * 16 * NT * W_ST) * 4;
     tail.lds_bytes = (unsigned)lds; tail.probe = HOST_PROBE();
     if (L.xu8) {
-        if (NT == 4) hipLaunchKernelGGL((k_dw_lds<4, true>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, tail);
-        else if (NT == 2) hipLaunchKernelGGL((k_dw_lds<2, true>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, tail);
-        else hipLaunchKernelGGL((k_dw_lds<1, true>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, tail);
+        if (NT == 4) hipLaunchKernelGGL((k_dw_lds<4, true>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, nsplit, tail);
+        else if (NT == 2) hipLaunchKernelGGL((k_dw_lds<2, true>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, nsplit, tail);
+        else hipLaunchKernelGGL((k_dw_lds<1, true>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, nsplit, tail);
     }
-    else if (NT == 4) hipLaunchKernelGGL((k_dw_lds<4>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, tail);
-    else if (NT == 2) hipLaunchKernelGGL((k_dw_lds<2>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, tail);
-    else hipLaunchKernelGGL((k_dw_lds<1>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, tail);
+    else if (NT == 4) hipLaunchKernelGGL((k_dw_lds<4>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, nsplit, tail);
+    else if (NT == 2) hipLaunchKernelGGL((k_dw_lds<2>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, nsplit, tail);
+    else hipLaunchKernelGGL((k_dw_lds<1>), dim3(grid), dim3(256), lds, st, L, pr, nprob, ldx, B, S, kc, ds, nsplit, tail);
 }
 
 // =====================================================================================================================
@@ -1321,13 +1360,13 @@ __global__ __launch_bounds__(256) void k_dx_lds(LayerDev L, GDxArgs A, int B, in
 // dW and dX of one layer are independent given dpre: ONE launch runs both (blocks [0, dw_blocks) do dW, the rest dX), which
 // saves a dispatch and lets the latency-bound dX workgroups share the machine with the dW ones.
 template <int NT, bool WIDE>
-__global__ __launch_bounds__(256) void k_dwdx_lds(LayerDev Lw, GDwProbs pr, int nprob, int ldx, int B, int Sw, int kcw, int dw_blocks,
+__global__ __launch_bounds__(256) void k_dwdx_lds(LayerDev Lw, GDwProbs pr, int nprob, int ldx, int B, int Sw, int kcw, int dw_blocks, int dw_nsplit,
                                                   LayerDev Lx, GDxArgs A, int Sx, int kcx, int dx_gx, GemmTail tail) {
     // the few, long-latency dX workgroups are dispatched FIRST so that they run for the whole kernel while the many short dW
     // workgroups fill the remaining CUs (dispatch order is blockIdx order); a tail of small VALU tasks comes last
     // dispatch order: [priority block][dX workgroups][tail: VALU tasks, Adam job][dW workgroups]: the long-latency dX chains start first, the
     // bandwidth-bound tail streams beside them, the many short dW workgroups fill the slots as they free up
-    karg_warm<2 * sizeof(LayerDev) + sizeof(GDwProbs) + sizeof(GDxArgs) + sizeof(GemmTail) + 64>();
+    karg_warm<2 * sizeof(LayerDev) + sizeof(GDwProbs) + sizeof(GDxArgs) + sizeof(GemmTail) + 68>();
     KTRACE_BEGIN()      // record: {grid, block, entry, role (0 prio, 1 dX, 2 tail, 3 dW), -, -, -, exit}  (tools/ktrace_bwd.py)
     const int pre_ = (tail.has_adam && tail.adam.prio.n > 0) ? 1 : 0;
     const int probe = KTRACE_PROBE();
@@ -1341,7 +1380,7 @@ __global__ __launch_bounds__(256) void k_dwdx_lds(LayerDev Lw, GDwProbs pr, int 
         KTRACE_SET(3, 1);
     }
     else if (bid < dx_blocks + ntail) { gemm_tail_run(tail, (unsigned)(bid - dx_blocks)); KTRACE_SET(3, 2); }
-    else { if (!(probe & 1)) dw_lds_body<NT>(Lw, pr, nprob, ldx, B, Sw, kcw, bid - dx_blocks - ntail, dw_blocks, DwStride{Lw.npos * B, 0, 0}, probe); KTRACE_SET(3, 3); }
+    else { if (!(probe & 1)) dw_section<NT, false>(Lw, pr, nprob, ldx, B, Sw, kcw, bid - dx_blocks - ntail, dw_blocks, dw_nsplit, DwStride{Lw.npos * B, 0, 0}, probe); KTRACE_SET(3, 3); }
     KTRACE(7); KTRACE_END();
 }
 bool gemm_dx_eligible(const LayerDev& L, int B, int ldy, int nsrc) { return dx_mode(L, nsrc, B, ldy) >= 0; }
@@ -1368,7 +1407,7 @@ void launch_gemm_dwdx(hipStream_t st, const LayerDev& Lw, int nprob, const float
     GDwProbs pr;
     for (int i = 0; i < 2; i++) { const int j = i < nprob ? i : 0; pr.p[i].X = X[j]; pr.p[i].dpre = dpre_w[j]; pr.p[i].out = out_w[j]; }
     const int NT = Lw.N % 64 == 0 ? 4 : (Lw.N % 32 == 0 ? 2 : 1);
-    const int dw_blocks = ((Lw.K + 63) / 64) * (Lw.N / (16 * NT)) * Sw * nprob;
+    const int dw_units = ((Lw.K + 63) / 64) * (Lw.N / (16 * NT)) * Sw * nprob, dw_nsplit = dw_split_units(Lw, NT, dw_units, B), dw_blocks = dw_units + dw_nsplit;
     const bool dense = Lx.kind == DQN_LAYER_DENSE;
     const int Sx = dense ? dqn_nchunks(Lx.N, Lx.dx_kc) : 1, kcx = dqn_chunk_len(Lx.N, Lx.dx_kc);
     GDxArgs a; a.nsrc = nsrc; a.out = out_x; a.ysrc = ysrc; a.ldy = ldy; a.act_src = act_src;
@@ -1383,7 +1422,7 @@ void launch_gemm_dwdx(hipStream_t st, const LayerDev& Lw, int nprob, const float
     if (pj == 2 && dense && B >= 512 && lds < (size_t)(160 * 1024 / 3 + 1024)) lds = (size_t)(160 * 1024 / 3 + 1024);
     tail.lds_bytes = (unsigned)lds; tail.probe = HOST_PROBE();
     const int grid = dw_blocks + gx * (B / dx_cols(pj)) + (int)gemm_tail_blocks(tail);
-#define DWDX_LAUNCH(NTv, Wv) hipLaunchKernelGGL((k_dwdx_lds<NTv, Wv>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, Lx, a, Sx, kcx, gx, tail)
+#define DWDX_LAUNCH(NTv, Wv) hipLaunchKernelGGL((k_dwdx_lds<NTv, Wv>), dim3(grid), dim3(256), lds, st, Lw, pr, nprob, ldx, B, Sw, kcw, dw_blocks, dw_nsplit, Lx, a, Sx, kcx, gx, tail)
     if (pj == 2) { if (NT == 4) DWDX_LAUNCH(4, true); else if (NT == 2) DWDX_LAUNCH(2, true); else DWDX_LAUNCH(1, true); }
     else { if (NT == 4) DWDX_LAUNCH(4, false); else if (NT == 2) DWDX_LAUNCH(2, false); else DWDX_LAUNCH(1, false); }
 #undef DWDX_LAUNCH

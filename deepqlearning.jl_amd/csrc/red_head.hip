@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_red_head(const RedHeadArgs A, int bump_
     if (tid < 96) {      // ONE branch around the whole round; inside it every load is unconditional (slab index clamped)
         // (both nets' pointers are scalars selected per lane: indexing the record with a per-lane `net` would be a vector load of the pointer)
         const float *pt0 = T.part[0], *pt1 = T.part[1], *pbs0 = T.pbias[0], *pbs1 = T.pbias[1];
-        const int net = slot == 2 ? 1 : 0, ncols = net ? B : ncon, col = 4 * g + (slot == 1 ? B : 0);
+        const int net = slot == 2 ? 1 : 0, ncols = net ? B : ncon, col = 4 * g + ((slot == 1 && double_q) ? B : 0);      // (!double_q: ncon == B, slot 1 is discarded below -- it re-reads slot 0's piece instead of running B floats past the row)
         const float* p = (net ? pt1 : pt0) + ((size_t)(32 * c + f) * ncols + col);
         const size_t per_s = (size_t)K * ncols;
 #pragma unroll

@@ -23,11 +23,19 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_bench_two_ranks_script_path():
+@pytest.mark.parametrize("launcher", ["torchrun", "self"])
+def test_bench_two_ranks_script_path(launcher):
+    """launcher = torchrun: the form the driver uses for N > 1; self: plain `python bench.py --gpus 2` (no WORLD_SIZE), which re-execs itself under
+    torch.distributed.run on a free loopback port and propagates the return code"""
     env = dict(os.environ, DQN_BENCH_SIM_COMM="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ge.ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--replay", "512", "--env-steps", "8", "--profile-steps", "1",
-           "--sustained-steps", "40", "--cpu-seconds", "1"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    bench_args = ["--gpus", "2", "--steps", "6", "--warmup", "3", "--replay", "512", "--env-steps", "8", "--profile-steps", "1", "--sustained-steps", "40", "--cpu-seconds", "1"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+               os.path.join(ge.ROOT, "bench.py")] + bench_args
+    else:
+        cmd = [sys.executable, os.path.join(ge.ROOT, "bench.py")] + bench_args
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ge.ROOT)
     assert p.returncode == 0, p.stderr[-4000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]

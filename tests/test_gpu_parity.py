@@ -563,6 +563,24 @@ def test_config5_nature_b512_u8_bit_exact(pkg):
     np.testing.assert_array_equal(gpu.replay_priorities(), cpu.replay_priorities())
 
 
+@pytest.mark.parametrize("split", [0, 16, 4096])
+def test_dw_section_half_units_bit_exact(pkg, monkeypatch, split):
+    """dw_section (csrc/nn_gemm.hip, r06): the last DQN_DW_SPLIT units of a large-batch dW section (64-channel tiles, chunks of >= 4 K tiles) run as two
+    halves along N so that a backward launch does not end in a drain of whole units.  Another assignment of the same chains to workgroups: bit-identical to
+    the twin with none (0), a few (16) and as many as allowed (4096 -> half of the section's units) of the units cut; the default (128) is what every other
+    large-batch test runs."""
+    net = nature_dueling()
+    monkeypatch.setenv("DQN_DW_SPLIT", str(split))
+    gpu, cpu, hp = make_pair(pkg, net, 256, cap=1024, obs_dtype=1, gamma=0.99)
+    monkeypatch.delenv("DQN_DW_SPLIT", raising=False)
+    cpu.set_threads(64)
+    fill((gpu, cpu), net, 700, seed=split + 5, u8=True)
+    set_same_params((gpu, cpu), net, seed=4)
+    assert_step_bit_exact(gpu, cpu)
+    assert_step_bit_exact(gpu, cpu)
+    np.testing.assert_array_equal(gpu.get_params(0), cpu.get_params(0))
+
+
 @pytest.mark.parametrize("B,u8,off", [(128, True, False), (160, True, False), (144, True, False), (128, False, False), (144, False, False), (128, True, True)])
 def test_weights_resident_first_conv_forward_bit_exact(pkg, monkeypatch, B, u8, off):
     """k_fwd_wres (csrc/nn_gemm.hip): from 2048 M-groups up the forward of a layer of <= 32 channels keeps its weights in LDS and walks the output with

@@ -13,7 +13,7 @@ import __graft_entry__ as ge  # noqa: E402
 import importlib
 import argparse
 TPU = float(os.environ.get("TICKS_PER_US", "100"))
-args = argparse.Namespace(batch=int(os.environ.get("KT_BATCH", "32")), u8=False, replay=2000, no_graph=True, no_mfma=False, conv_kc=0, fc_kc=0, envs_per_rank=32, device_fill=False)
+args = argparse.Namespace(batch=int(os.environ.get("KT_BATCH", "32")), u8=bool(os.environ.get("KT_U8")), replay=int(os.environ.get("KT_REPLAY", "2000")), no_graph=True, no_mfma=False, conv_kc=0, fc_kc=0, envs_per_rank=32, device_fill=False)
 pkg = ge.load_package()
 pkg.nn = importlib.import_module(pkg.__name__ + ".nn"); pkg.envs = importlib.import_module(pkg.__name__ + ".envs")
 eng, *_ = bench.build_workload(pkg, args, 0, 0)
@@ -42,6 +42,22 @@ for grid in sorted(set(bw[:, 0])):
         q = r[:, 3] == role
         e0 = (a0[q] - T0) / 100; e1 = (a1[q] - T0) / 100
         print(f"   {roles[int(role)]:5s} wall: entries {e0.min():6.2f} .. {e0.max():6.2f} (median {np.median(e0):6.2f}), exits {e1.min():6.2f} .. {e1.max():6.2f} (median {np.median(e1):6.2f}) us")
+    if os.environ.get("KT_TIMELINE"):      # live workgroups per role every KT_TIMELINE us of the launch (common 100 MHz clock)
+        dt = float(os.environ["KT_TIMELINE"]); span = (a1.max() - T0) / 100
+        for t in np.arange(0.0, span, dt):
+            live = [(int(role), int(((a0[r[:, 3] == role] - T0) / 100 <= t).sum() - ((a1[r[:, 3] == role] - T0) / 100 <= t).sum())) for role in sorted(set(r[:, 3]))]
+            print(f"      t={t:6.1f} us  live: " + "  ".join(f"{roles[k]} {v}" for k, v in live))
+    if os.environ.get("KT_GROUPS"):      # what decides a dW workgroup's lifetime: its XCD (blockIdx & 7), its position in the dispatch order, its row tile?
+        q = r[:, 3] == 3
+        if q.any():
+            b = r[q, 1]; e0 = (a0[q] - T0) / 100; e1 = (a1[q] - T0) / 100; life = e1 - e0
+            print("      dW wall lifetime by XCD (blockIdx & 7): " + "  ".join(f"{x}: {np.median(life[(b & 7) == x]):5.1f}/{life[(b & 7) == x].max():5.1f}" for x in range(8)))
+            for m in (4, 8, 9):
+                bb = b - b.min(); n = len(bb); qn, rn = n >> 3, n & 7; x = bb & 7; i = bb >> 3
+                w = np.where(x < rn, x * (qn + 1), rn * (qn + 1) + (x - rn) * qn) + i
+                print(f"      dW wall lifetime by (unit index mod {m}) (median/max): " + "  ".join(f"{k}: {np.median(life[w % m == k]):5.1f}/{life[w % m == k].max():5.1f}" for k in range(m)))
+            o = np.argsort(e0); k = max(1, len(o) // 8)
+            print("      dW wall lifetime by entry order (eighths; median entry -> median lifetime): " + "  ".join(f"{np.median(e0[o[j:j + k]]):5.1f}->{np.median(life[o[j:j + k]]):5.1f}" for j in range(0, len(o), k)))
     for role in sorted(set(r[:, 3])):
         q = r[r[:, 3] == role]
         life = (q[:, 7] - q[:, 2]) / TPU
