@@ -182,7 +182,7 @@ def roofline_block(pkg, eng, layers, batch, u8, world, value, ms_per_step, prof_
     ARENA_ELEM_BYTES[0] = eng.batch_arena_elem_bytes()
     cfg2 = batch == 32 and not u8 and world == 1
     cfg5 = batch == 512 and u8 and world == 1
-    PMC_OK[0] = cfg2     # the committed PMC passes are runs of the single-GPU config-2 bench (a replica's Adam launch is a different kernel: traffic = null)
+    PMC_OK[0] = "cfg2" if cfg2 else ("cfg5" if cfg5 else None)     # the committed PMC passes are runs of the single-GPU config-2 / config-5 bench (a replica's Adam launch is a different kernel: traffic = null)
     obs_b = 1 if u8 else 4
     step_flops = step_flops_analytic(g2, B, ncon)
     # ---- headline: the train step is a dense contraction => bound by the fp32 MFMA peak;
@@ -311,6 +311,24 @@ def secondary_block(pkg, args, device):
         e5.close(); out["config5"] = r
     except Exception as ex:
         out["config5"] = {"error": repr(ex)}
+    # ---- config 5's shape with the REFERENCE's sampling semantics (hp.sample_distinct = 1, ...replay.jl:85): since r06 the priority workgroup that rides a backward launch dedupes
+    # the list it pre-draws and the Adam launch pre-gathers it, as in the default mode.  200 000 transitions (11 GB of rows: the fill of a second 1e6 replay is not worth the seconds)
+    try:
+        a5d = _ap.Namespace(**vars(args)); a5d.batch = 512; a5d.u8 = True; a5d.replay = 200_000; a5d.device_fill = True; a5d.distinct = True
+        e5d, _, _, _, _, _ = build_workload(pkg, a5d, 0, device)
+        r = timed_steps(e5d, 100, 10)
+        names = [n for n, _ in e5d.profile_step(steady=True)]
+        a5d.distinct = False
+        e5d.close()
+        e5s, _, _, _, _, _ = build_workload(pkg, a5d, 0, device)
+        rs = timed_steps(e5s, 100, 10)
+        e5s.close()
+        r.update(workload="configs[4] shape with hp.sample_distinct = 1 (the reference's replace=false draws): " + workload_name(a5d, 1), launches_per_step=len(names), launch_names=names,
+                 stratified_same_replay_steps_per_s=rs["steps_per_s"], ratio_to_stratified=r["steps_per_s"] / rs["steps_per_s"],
+                 parity_gate="tests/test_gpu_parity.py::test_train_steps_with_distinct_sampling_bit_exact[B512_config5_shape]")
+        out["config5_distinct"] = r
+    except Exception as ex:
+        out["config5_distinct"] = {"error": repr(ex)}
     # ---- what a replica step costs BEFORE any wire time, measured at world 1 through a real RCCL communicator (ncclCommInitRank + ncclAllGather of one rank inside the step
     # graph): the numbers a future multi-GPU SCALE line can be checked against.  Nothing here is a scaling measurement.
     try:
@@ -871,12 +889,14 @@ def pmc_traffic(op):
     import glob
     if not PMC_OK[0]:
         return {}
-    kname = {"adam": "k_adam", "adam+gather": "k_adam_pg", "sample_gather": "k_gather_fb", "gather": "k_gather_fb"}.get(op)
+    cfg5 = PMC_OK[0] == "cfg5"      # config 5 (u8 replay, byte arena): its own kernels, its own passes (profiles/*_cfg5_pmc_fetch.txt / _write.txt, tools/gpu_pmc_cfg5.sh)
+    kname = ({"adam": "k_adam", "adam+gather": "k_adam_pg_u8", "gather": "k_gather_fb_u8b"} if cfg5 else
+             {"adam": "k_adam", "adam+gather": "k_adam_pg", "sample_gather": "k_gather_fb", "gather": "k_gather_fb"}).get(op)
     if kname is None:
         return {}
     def last(pattern):
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
-            if "cfg5" in path:
+            if ("cfg5" in os.path.basename(path)) != cfg5:
                 continue
             for line in open(path):
                 f = line.split()

@@ -291,54 +291,75 @@ __device__ __forceinline__ long long tree_descend(const float* __restrict__ tree
 }
 #endif
 #ifdef __HIPCC__
-// hp.sample_distinct (...replay.jl:85, replace=false): after the stratified draws, ONE lane visits the positions in ascending order and redraws every
-// index an earlier position already took by successive sampling on the residual priorities -- u * (total - taken mass) walked down the tree, a
-// child's mass being its stored sum minus the priorities of the taken leaves below it (in the order they were taken), 0 when no untaken leaf is
-// left below it; Philox lane B + i, word 3 offset by the attempt; after 8 attempts the first untaken leaf in index order.  Sequential by
-// construction (each redraw excludes the ones before it); duplicates are rare unless one priority dominates.  taken / tp: B entries of scratch.
+// hp.sample_distinct (...replay.jl:85, replace=false): after the stratified draws the positions are visited in ascending order and every index an earlier
+// position already took is redrawn by successive sampling on the residual priorities -- u * (total - taken mass) walked down the tree, a child's mass being its
+// stored sum minus the priorities of the taken leaves below it (in the order they were taken), 0 when no untaken leaf is left below it; Philox lane B + i,
+// word 3 offset by the attempt; after 8 attempts the first untaken leaf in index order.  Sequential by construction (each redraw excludes the ones before it).
+//
+// r06: executed by ONE WAVE instead of one lane, so that large batches can keep distinct draws on the fast path (the priority workgroup of a backward launch):
+//   * taken[i] / tp[i] arrive FILLED with every position's stratified draw and its priority, tp[i] NEGATED where the draw repeats an earlier position's DRAW
+//     (sample_distinct_block computes that in parallel).  Position i is a duplicate iff its draw equals an earlier draw, or an earlier REDRAWN leaf: an earlier position
+//     with the same draw either kept it or was redrawn because someone before it holds it -- so until the first redraw the flag alone decides, afterwards the wave scans the
+//     final leaves of the positions before i (64 per step);
+//   * the serial parts of a redraw keep their order but only over the entries that matter: "which taken leaves lie below this child" is a ballot over the taken list, the
+//     subtractions then run over the set bits in ascending order (level l sees ~nt / 2^l of them: ~2 nt per descent instead of 2 L nt).
+// Every lane computes the same scalars (wave-uniform control flow); same arithmetic, same order, same Philox words as the one-lane form the CPU twin restates: identical lists.
+__device__ __forceinline__ bool sdw_taken_before(const long long* taken, int n, long long leaf, int lane) {      // leaf in taken[0, n)?  (one wave)
+    bool hit = false;
+    for (int j0 = 0; j0 < n; j0 += 64) { const int j = j0 + lane; hit = hit || (j < n && taken[j] == leaf); }
+    return __ballot(hit) != 0ull;
+}
 __device__ __forceinline__ void sample_distinct_fix(const float* __restrict__ tree, long long cap2, long long size, unsigned long long seed, unsigned long long ctr,
                                                     int B, long long* idx, long long* taken, float* tp) {
     int L = 0; for (long long w = cap2; w > 1; w >>= 1) L++;
-    if (size < B) return;
-    int nt = 0;
+    const int lane = threadIdx.x & 63;
+    if (size < B) { for (int i = lane; i < B; i += 64) tp[i] = fabsf(tp[i]); return; }
+    int nr = 0;                                        // redraws so far
     for (int i = 0; i < B; i++) {
-        bool dup = false; for (int j = 0; j < nt; j++) if (taken[j] == idx[i]) { dup = true; break; }
-        long long leaf = idx[i];
-        if (dup) {
-            bool ok = false;
-            for (int att = 0; att < 8 && !ok; att++) {
-                float R = tree[1]; for (int j = 0; j < nt; j++) R = R - tp[j];
-                uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)(B + i), 0x5A4D504Cu + (uint32_t)(att + 1)};
-                philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), c);
-                float t = (float)(c[0] >> 8) * (1.0f / 16777216.0f) * R;
-                long long node = 1;
-                for (int lev = 0; lev < L; lev++) {
-                    float m[2];
+        const float f = tp[i]; const long long x = taken[i];
+        bool dup = f < 0.0f;
+        if (!dup && nr > 0) dup = sdw_taken_before(taken, i, x, lane);
+        if (!dup) continue;                            // taken[i] / tp[i] already hold this position's leaf and priority
+        const int nt = i;
+        long long leaf = x; bool ok = false;
+        for (int att = 0; att < 8 && !ok; att++) {
+            float R = tree[1]; for (int j = 0; j < nt; j++) R = R - tp[j];
+            uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)(B + i), 0x5A4D504Cu + (uint32_t)(att + 1)};
+            philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), c);
+            float t = (float)(c[0] >> 8) * (1.0f / 16777216.0f) * R;
+            long long node = 1;
+            for (int lev = 0; lev < L; lev++) {
+                float m[2];
 #pragma unroll
-                    for (int ch = 0; ch < 2; ch++) {
-                        const long long cn = 2 * node + ch; const int sh = L - lev - 1;
-                        long long lo = (cn << sh) - cap2, hi = ((cn + 1) << sh) - cap2; if (hi > size) hi = size;
-                        long long cnt = hi > lo ? hi - lo : 0; float v = tree[cn];
-                        for (int j = 0; j < nt; j++) if (((taken[j] + cap2) >> sh) == cn) { v = v - tp[j]; cnt--; }
-                        m[ch] = (cnt > 0 && v > 0.0f) ? v : 0.0f;
+                for (int ch = 0; ch < 2; ch++) {
+                    const long long cn = 2 * node + ch; const int sh = L - lev - 1;
+                    long long lo = (cn << sh) - cap2, hi = ((cn + 1) << sh) - cap2; if (hi > size) hi = size;
+                    long long cnt = hi > lo ? hi - lo : 0; float v = tree[cn];
+                    for (int j0 = 0; j0 < nt; j0 += 64) {      // the taken leaves below cn, in the order they were taken
+                        const int j = j0 + lane;
+                        unsigned long long mb = __ballot(j < nt && ((taken[j] + cap2) >> sh) == cn);
+                        while (mb) { const int b = __ffsll((long long)mb) - 1; mb &= mb - 1; v = v - tp[j0 + b]; cnt--; }
                     }
-                    if (t < m[0] || !(m[1] > 0.0f)) node = 2 * node; else { t -= m[0]; node = 2 * node + 1; }
+                    m[ch] = (cnt > 0 && v > 0.0f) ? v : 0.0f;
                 }
-                leaf = node - cap2; if (leaf >= size) leaf = size - 1;
-                ok = true; for (int j = 0; j < nt; j++) if (taken[j] == leaf) { ok = false; break; }
+                if (t < m[0] || !(m[1] > 0.0f)) node = 2 * node; else { t -= m[0]; node = 2 * node + 1; }
             }
-            if (!ok) for (leaf = 0; leaf < size; leaf++) { bool tk = false; for (int j = 0; j < nt; j++) if (taken[j] == leaf) { tk = true; break; } if (!tk) break; }
-            idx[i] = leaf;
+            leaf = node - cap2; if (leaf >= size) leaf = size - 1;
+            ok = !sdw_taken_before(taken, nt, leaf, lane);
         }
-        taken[nt] = leaf; tp[nt] = tree[cap2 + leaf]; nt++;
+        if (!ok) for (leaf = 0; leaf < size; leaf++) if (!sdw_taken_before(taken, nt, leaf, lane)) break;
+        __builtin_amdgcn_wave_barrier();               // every lane is past its reads of taken / tp for this position
+        if (lane == 0) { idx[i] = leaf; taken[i] = leaf; tp[i] = tree[cap2 + leaf]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();      // LDS operations of a wave execute in order: the next position reads these
+        nr++;
     }
 }
 #endif
 #ifdef __HIPCC__
-// hp.sample_distinct, by a whole workgroup: `list` holds the B stratified draws; every lane tests its draws against the ones before them (out of `taken`, O(B) per lane) and
-// only when some draw repeats an earlier one does ONE lane run the sequential redraw -- without a duplicate it would change nothing.  Every thread of the workgroup calls;
-// taken: B long longs, tp: B floats, any: one int of scratch (LDS).  k_sample, the priority block's pre-draw and the fused sample + gather workgroups all go through here:
-// the same list whichever of them draws it (r05: the reference's replace=false semantics on the fast path, ...replay.jl:85).
+// hp.sample_distinct, by a whole workgroup: `list` holds the B stratified draws; every lane tests its draws against the ones before them (out of `taken`, O(B) per lane),
+// fetches their priorities, and only when some draw repeats an earlier one does wave 0 run the sequential redraw -- without a duplicate it would change nothing.  Every thread
+// of the workgroup calls; taken: B long longs, tp: B floats, any: one int of scratch (LDS).  k_sample, the priority block's pre-draw, the fused sample + gather workgroups and
+// the single-launch step all go through here: the same list whichever of them draws it (the reference's replace=false semantics on the fast path, ...replay.jl:85).
 __device__ __forceinline__ void sample_distinct_block(const float* __restrict__ tree, long long cap2, long long size, unsigned long long seed, unsigned long long ctr,
                                                       int B, long long* list, long long* taken, float* tp, int* any) {
     if (threadIdx.x == 0) *any = 0;
@@ -346,11 +367,24 @@ __device__ __forceinline__ void sample_distinct_block(const float* __restrict__ 
     __syncthreads();
     for (int i = threadIdx.x; i < B; i += blockDim.x) {
         const long long v = taken[i]; bool d = false;
-        for (int j = 0; j < i; j++) d = d || taken[j] == v;
+        int j = 0;
+        for (; j + 8 <= i; j += 8) {                   // eight independent LDS reads per round (one read per iteration was a dependent ~100-cycle round trip each: 21 us of a priority block at B = 512)
+            long long w[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) w[u] = taken[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) d = d || w[u] == v;
+        }
+        for (; j < i; j++) d = d || taken[j] == v;
         if (d) *any = 1;
+        tp[i] = d ? -1.0f : 1.0f;                      // (the sign is the flag; the priorities are only needed -- and only fetched -- when something repeats)
     }
     __syncthreads();
-    if (*any && threadIdx.x == 0) sample_distinct_fix(tree, cap2, size, seed, ctr, B, list, taken, tp);
+    if (*any) {
+        for (int i = threadIdx.x; i < B; i += blockDim.x) tp[i] = tp[i] * tree[cap2 + taken[i]];      // priorities are > 0: the sign survives
+        __syncthreads();
+        if (threadIdx.x < 64) sample_distinct_fix(tree, cap2, size, seed, ctr, B, list, taken, tp);
+    }
     __syncthreads();
 }
 #endif

@@ -429,7 +429,9 @@ int build_program(dqn_engine* e) {
     };
     auto prio_args = [&]() { PrioArgs pa; memset(&pa, 0, sizeof pa); pa.n = B; pa.cap2 = e->cap2; pa.idx = e->idx; pa.td = e->td; pa.eps = e->hp.prio_eps; pa.alpha = e->hp.prio_alpha; pa.tree = e->tree;
                               // hp.sample_distinct: pre-drawn (and deduped by the priority block) for the small batches whose fused sample + gather launch understands the list
-                              const bool dist_ok = !e->hp.sample_distinct || (Bb <= 64 && !(e->hp.obs_dtype == DQN_OBS_U8 && !e->arena_u8 && (e->E & 3) == 0));
+                              // r06: ... and for the large batches whose priority workgroup rides a backward launch (prio_in_bwd): the list it leaves in idx_pre is final -- the
+                              // Adam launch's pre-gather reads it as it reads a stratified one
+                              const bool dist_ok = !e->hp.sample_distinct || (Bb <= 64 && !(e->hp.obs_dtype == DQN_OBS_U8 && !e->arena_u8 && (e->E & 3) == 0)) || (Bb > 64 && e->prio_in_bwd);
                               if ((Bb <= 64 || e->prio_in_bwd) && dist_ok) { pa.idx_pre = e->idx_pre; pa.seed = e->hp.seed; pa.B = Bb; pa.distinct = e->hp.sample_distinct ? 1 : 0; }      // the fused sample+gather launch (B <= 64) consumes them
                               return pa; };
     const bool prio_in_adam = e->hp.prioritized_replay && !rec && (Bb <= 64 || e->prio_in_bwd);      // larger batches: a backward launch's workgroup, or the side stream (prio_fork)
@@ -437,7 +439,7 @@ int build_program(dqn_engine* e) {
     // workgroup 0 of the first LDS-tiled backward launch instead
     // large batches: the priority update runs on the side stream (prio_fork) and draws the next indices there; k_td takes the pre-drawn batch
     const bool pg_want = e->hp.prioritized_replay && !rec && (prio_in_adam ? (fuse_heads || e->prio_in_bwd) : e->prio_forked) && !early && !e->sim_world &&
-                         (e->hp.obs_dtype != DQN_OBS_U8 || e->arena_u8) && !e->opt.no_pregather && (!e->hp.sample_distinct || Bb <= 64);      // distinct mode at B > 64: sample launch + gather launch every step      // u8 rows: only onto the byte arena
+                         (e->hp.obs_dtype != DQN_OBS_U8 || e->arena_u8) && !e->opt.no_pregather && (!e->hp.sample_distinct || Bb <= 64 || e->prio_in_bwd);      // u8 rows: only onto the byte arena; distinct mode at B > 64 without a carrying backward launch: sample launch + gather launch every step
     // layer l's gradient is final: queue its parameter range (split-K layers: as a slab segment)
     auto adam_queue = [&](int l, const std::vector<RSeg>& segs_known) {
         const LayerDev& L = e->L[l]; PItem it; it.beg = L.w_off; it.end = l + 1 < e->nl ? e->L[l + 1].w_off : e->Pint; it.part = nullptr; it.S = 0;

@@ -157,17 +157,33 @@ __device__ __forceinline__ void gather_u8b_body(const unsigned char* __restrict_
         for (int i = 0; i < 4; i++) { const int ii = (i + rot) & 3; d[ii] = ii == 0 ? vv[0] : ii == 1 ? vv[1] : ii == 2 ? vv[2] : vv[3]; }
     }
     __syncthreads();
-    // 32 lanes x 4 columns = one 128-byte segment of a feature row of the arena; a wave writes 2 feature rows per instruction
-    const int c4 = threadIdx.x & 31, r8 = threadIdx.x >> 5;
-#pragma unroll 4
-    for (int p = 0; p < 32; p++) {
-        const int fl = p * 8 + r8, f = f0 + fl, c = c0 + 4 * c4, sh = 8 * (fl & 3), w = fl >> 2;
-        if (f >= E) continue;
-        uint32_t o = 0; const int rot = c4 >> 3;       // lanes 8 apart sit on the same bank (4 c4 mod 32): each reads a different one of its four columns per instruction
+    // 32 lanes x 4 columns = one 128-byte segment of a feature row of the arena; a wave writes 2 feature rows per instruction.
+    // r06: a lane reads the FOUR words (4 features each) of its four columns once and transposes the 4 x 4 bytes in registers (v_perm_b32: two stages of four) into the four
+    // output words of features 4 wg .. 4 wg + 3 -- 32 LDS reads and 64 byte permutes per thread instead of 128 reads and ~400 shift / mask / or instructions (each word was
+    // re-read by the four iterations that took one byte of it).  The reads are rotated per 8-lane block as before (lanes 8 apart sit on one bank); the rotation is undone
+    // by the second stage's per-lane selectors.
+    const int c4 = threadIdx.x & 31, r8 = threadIdx.x >> 5, rot = c4 >> 3, c = c0 + 4 * c4;
+    // word r_i = column (i + rot) & 3.  Stage 1: t0 = {r0.b0, r1.b0, r0.b1, r1.b1}, t1 = {r0.b2, r1.b2, r0.b3, r1.b3}, u0 / u1 likewise from r2, r3.
+    // Stage 2, perm(u, t, sel): byte b_even of r_i sits at selector index {0, 1, 4, 5}[i], b_odd at {2, 3, 6, 7}[i]; output byte u (column u) takes r_{(u - rot) & 3}
+    uint32_t selE = 0, selO = 0;
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int uu = (u + rot) & 3; o |= ((tile32[(4 * c4 + uu) * 65 + w] >> sh) & 0xffu) << (8 * uu); }
-        if (c + 3 < ld) *reinterpret_cast<uint32_t*>(x0b + (size_t)f * ld + c) = o;
-        else for (int u = 0; u < 4; u++) if (c + u < ld) x0b[(size_t)f * ld + c + u] = (unsigned char)(o >> (8 * u));
+    for (int u = 0; u < 4; u++) { const int i = (u - rot) & 3, pe = (i & 1) + ((i >> 1) << 2); selE |= (uint32_t)pe << (8 * u); selO |= (uint32_t)(pe + 2) << (8 * u); }
+    const uint32_t* tc = tile32 + (4 * c4) * 65;
+    const int o0 = ((0 + rot) & 3) * 65, o1 = ((1 + rot) & 3) * 65, o2 = ((2 + rot) & 3) * 65, o3 = ((3 + rot) & 3) * 65;
+#pragma unroll 4
+    for (int p = 0; p < 8; p++) {
+        const int wg = p * 8 + r8, f = f0 + 4 * wg;
+        if (f >= E) continue;
+        const uint32_t r0 = tc[o0 + wg], r1 = tc[o1 + wg], r2 = tc[o2 + wg], r3 = tc[o3 + wg];
+        const uint32_t t0 = __builtin_amdgcn_perm(r1, r0, 0x05010400u), t1 = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
+        const uint32_t u0 = __builtin_amdgcn_perm(r3, r2, 0x05010400u), u1 = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
+        const uint32_t o[4] = {__builtin_amdgcn_perm(u0, t0, selE), __builtin_amdgcn_perm(u0, t0, selO), __builtin_amdgcn_perm(u1, t1, selE), __builtin_amdgcn_perm(u1, t1, selO)};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (f + j >= E) break;
+            if (c + 3 < ld) *reinterpret_cast<uint32_t*>(x0b + (size_t)(f + j) * ld + c) = o[j];
+            else for (int u = 0; u < 4; u++) if (c + u < ld) x0b[(size_t)(f + j) * ld + c + u] = (unsigned char)(o[j] >> (8 * u));
+        }
     }
     if (bx == 0) { gather_batch_meta(meta, rows, c0, B, cap2, tree, state); gather_batch_meta(meta, rows + 64, c0 + 64, B, cap2, tree, state); }
 }

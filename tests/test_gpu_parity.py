@@ -760,16 +760,19 @@ def test_sampler_distinct_gpu_equals_twin(pkg):
 
 
 @pytest.mark.parametrize("netf,B,cap,kw", [(small_conv_dueling, 32, 64, {}), (small_conv_dueling, 128, 200, {}), (cfg1_mlp_dueling, 32, 64, {}), (cfg1_mlp_dueling, 32, 64, dict(_tiny=False)),
-                                           (mid_conv_dueling, 16, 64, dict(obs_dtype=1))],
-                         ids=["B32_fused_heads", "B128_large_batch_path", "cfg1_single_launch_step", "cfg1_multi_launch", "u8_byte_arena"])
+                                           (mid_conv_dueling, 16, 64, dict(obs_dtype=1)), (nature_dueling, 512, 1024, dict(obs_dtype=1))],
+                         ids=["B32_fused_heads", "B128_large_batch_path", "cfg1_single_launch_step", "cfg1_multi_launch", "u8_byte_arena", "B512_config5_shape"])
 def test_train_steps_with_distinct_sampling_bit_exact(pkg, netf, B, cap, kw):
     """train steps in distinct mode (...replay.jl:85, replace=false): sampled indices never repeat inside a batch even with a dominant priority, and indices / TD errors /
     loss / parameters equal the twin's bit for bit, single steps and train_steps(n).  r05: at B <= 64 the mode keeps the fast path -- the priority block dedupes the list
     it pre-draws, the fused sample + gather workgroups (and the single-launch step) dedupe a list they draw themselves, dqn_train_steps pre-gathers as in the default
-    mode; larger batches keep the sample launch + gather launch."""
+    mode.  r06: larger batches too -- the priority workgroup that rides a backward launch dedupes its pre-drawn list (one wave runs the sequential redraw, common.h
+    sample_distinct_fix) and the Adam launch pre-gathers it; B512_config5_shape is BASELINE configs[4]'s network and batch with ONE dominant priority, i.e. ~500 redraws per batch."""
     net = netf()
     u8 = kw.get("obs_dtype", 0) == 1
     gpu, cpu, hp = make_pair(pkg, net, B, cap=cap, sample_distinct=1, learning_rate=1e-3, **kw)
+    if B >= 512:
+        cpu.set_threads(64)
     fill((gpu, cpu), net, cap, seed=4, u8=u8)
     set_same_params((gpu, cpu), net)
     big = np.full(cap, 0.01, np.float32); big[5] = 50.0                 # one transition dominates: the stratified default would repeat it
@@ -806,6 +809,9 @@ def test_train_steps_with_distinct_sampling_bit_exact(pkg, netf, B, cap, kw):
     names = [n for n, _ in gpu.profile_step()]
     if B <= 64 and (not u8 or gpu.batch_arena_elem_bytes() == 1):
         assert "sample" not in names, names          # no separate sample launch on the small-batch path (u8 rows into a FLOAT arena keep it: that gather kernel has its own index code)
+    if B >= 512:                                      # inside dqn_train_steps the large-batch step has neither a sample nor a gather launch: the previous step's Adam launch gathered the deduped list
+        steady = [n for n, _ in gpu.profile_step(steady=True)]
+        assert "sample" not in steady and "gather" not in steady and any(n.startswith("adam+gather") for n in steady), steady
     gpu.close(); cpu.close()
 
 
