@@ -355,6 +355,11 @@ def secondary_block(pkg, args, device):
                                                 "unpack_sum_us": round(L.get("dp_sum_ranks", 0.0), 2), "launches": {k: round(v, 2) for k, v in L.items()}},
                            "exchange_bytes_per_rank": xb, "rccl_nranks": e3.comm_info()["rccl_nranks"],
                            "model": {f"N={N}": model(N) for N in (2, 4, 8)},
+                           # weak-scaling efficiency the model implies at N = 8 (per-rank work fixed): plain single-GPU step / predicted replica step.  Both all-gather shapes are
+                           # listed because which one RCCL picks on 8 point-to-point-linked GPUs is not observable at world 1.  A PREDICTION, not a measurement.
+                           "efficiency_N8": ({"direct_links": round(plain_us / model(8)["predicted_step_us_direct"], 3), "ring": round(plain_us / model(8)["predicted_step_us_ring"], 3),
+                                              "assumptions": "plain step measured in this run; replica step at world 1 measured through a real communicator; + 2.1 us per extra rank block in the wide dW (calibrated on the simulated 8-rank run); all-gather = exchange_bytes_per_rank / 153 GB/s (direct: every peer over its own link, concurrently; ring: N - 1 hops); + 15 us RCCL launch / protocol latency (a guess: not measurable at world 1); no overlap of the exchange with compute (DQN_DP_OVERLAP off: its fork + join cost 26 us at world 1)"}
+                                             if plain_us else None),
                            "note": "world-1 measurement through a real communicator + a point-to-point xGMI model (153 GB/s per link, one link per peer pair); predicted_step_us = replica step + 2.1 us per extra rank block in the wide dW + all-gather + 15 us RCCL latency; UNMEASURED beyond world 1"}
         e3.close()
     except Exception as ex:
@@ -459,7 +464,7 @@ def main():
     if args.dp_overlap == 1:
         os.environ["DQN_DP_OVERLAP"] = "1"
     elif args.dp_overlap == 0:
-        os.environ.pop("DQN_DP_OVERLAP", None)
+        os.environ["DQN_DP_OVERLAP"] = "0"      # (unset = the engine decides from the world size and the exchange bytes, engine_program.hip)
     import torch
     if not torch.cuda.is_available():
         print("bench.py: no HIP device visible; the engine has no CPU fallback", file=sys.stderr)

@@ -36,7 +36,7 @@ struct EngineOpts {
     int no_head_cols4 = 0;        // DQN_NO_HEAD_COLS4=1: keep k_head_td (one workgroup per column) at large batches where k_head_cols4 (red_head.hip) would apply (A/B); =2: k_head_cols4 without the transposed copies (its fallback loader, under test)
     int no_red_head = 0;          // DQN_NO_RED_HEAD: keep k_reduce_multi + k_head_td where the fused reduce + head launch (red_head.hip) would apply (A/B, both schedules under test)
     int no_u8_arena = 0, head_fuse_maxb = 1024, no_head_fuse = 0, head_dbg = 0, prio_fork = 0, prio_level = 0, prio_nosplit = 0, no_pregather = 0, lstm_dw_mfma = 0;
-    int force_allreduce = 0, dp_allreduce = 0, dp_overlap = 0, dp_no_one_graph = 0;      // DQN_FORCE_ALLREDUCE / DQN_DP_ALLREDUCE / DQN_DP_OVERLAP / DQN_DP_NO_ONE_GRAPH
+    int force_allreduce = 0, dp_allreduce = 0, dp_overlap = -1 /* -1: decided from world size and bytes (engine_program.hip) */, dp_no_one_graph = 0;      // DQN_FORCE_ALLREDUCE / DQN_DP_ALLREDUCE / DQN_DP_OVERLAP / DQN_DP_NO_ONE_GRAPH
     // timing probes (wrong numbers, right schedule) and stamps
     int probe_no_tg = 0, drqn_probe = 0, drqn_stamps = 0, tiny_stop = 0;
 };

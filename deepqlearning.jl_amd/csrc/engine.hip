@@ -116,7 +116,7 @@ static int build_layers(const dqn_layer_desc* d, int n, const dqn_hparams* hp, L
 void read_opts(EngineOpts& o, bool comm_only) {
     auto I = [](const char* k, int dflt) { const char* v = getenv(k); return v ? atoi(v) : dflt; };
     auto F = [](const char* k) { return getenv(k) != nullptr ? 1 : 0; };
-    o.force_allreduce = F("DQN_FORCE_ALLREDUCE"); o.dp_allreduce = F("DQN_DP_ALLREDUCE"); o.dp_overlap = F("DQN_DP_OVERLAP"); o.dp_no_one_graph = F("DQN_DP_NO_ONE_GRAPH");
+    o.force_allreduce = F("DQN_FORCE_ALLREDUCE"); o.dp_allreduce = F("DQN_DP_ALLREDUCE"); o.dp_overlap = I("DQN_DP_OVERLAP", -1); o.dp_no_one_graph = F("DQN_DP_NO_ONE_GRAPH");
     if (comm_only) return;
     o.adam_mode = I("DQN_ADAM_MODE", 0); o.no_tiny = F("DQN_NO_TINY"); o.fwd_m32 = I("DQN_FWD_M32", -1); o.no_dx_wide = F("DQN_NO_DX_WIDE"); o.no_fwd_wres = F("DQN_NO_FWD_WRES");
     o.mid_group = I("DQN_MID_GROUP", 4); o.mid_big = I("DQN_MID_BIG", 16); o.sim_world = I("DQN_SIM_WORLD", 0); o.no_graph_upload = F("DQN_NO_GRAPH_UPLOAD");

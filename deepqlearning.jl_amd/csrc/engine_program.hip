@@ -484,9 +484,16 @@ int build_program(dqn_engine* e) {
     };
     // dp_overlap: with fused heads the operands of the flagged wide dense layers (X from the forward pass, dpre from k_head_td) are final HERE, before any
     // backward launch: pack and exchange them now, on the exchange stream, while the conv backward runs (SURVEY 8e "overlapped with backward")
-    // OPT-IN (DQN_DP_OVERLAP=1): measured at world 1, where there is nothing to hide, the fork + join of the exchange stream cost 26 us per step (one-graph
-    // replica step 155.8 -> 181.9 us) -- it pays once the first all-gather takes longer than that, which only a multi-GPU box can tell
-    bool overlap_cand = dp_on && n_dp > 0 && fuse_heads && levels.size() >= 2 && e->opt.dp_overlap;
+    // Measured at world 1, where there is nothing to hide, the fork + join of the exchange stream cost 26 us per step (one-graph replica step 155.8 -> 181.9 us): it pays
+    // once the first all-gather takes longer than that.  r06: decided HERE from the world size and the bytes instead of by an environment knob -- the wide operands of one
+    // rank over W - 1 ring hops of one 153 GB/s xGMI link + 15 us of collective latency (the worst shape RCCL can pick on point-to-point links; unmeasured: no multi-GPU
+    // box) against the 26 us; DQN_DP_OVERLAP = 1 / 0 still forces it (tests, A/B on real hardware)
+    bool want_overlap = e->opt.dp_overlap > 0;
+    if (e->opt.dp_overlap < 0 && dp_on) {
+        double bytes_a = 0.0; for (int i = 0; i < e->nl; i++) if (dp_layer[i]) bytes_a += 4.0 * (double)(e->L[i].K + e->L[i].N) * (double)B;
+        want_overlap = W >= 2 && !e->sim_world && (double)(W - 1) * bytes_a / 153e9 * 1e6 + 15.0 > 26.0;
+    }
+    bool overlap_cand = dp_on && n_dp > 0 && fuse_heads && levels.size() >= 2 && want_overlap;
     if (overlap_cand) for (int i = 0; i < e->nl; i++) if (dp_layer[i]) { bool in_lvl = false; for (int l : levels[levels.size() - 2]) in_lvl = in_lvl || l == i; overlap_cand = overlap_cand && in_lvl; }
     e->dp_overlap = false; e->prog_pre1_end = 0;
     if (overlap_cand) { e->prog.push_back({"dp_pack_wide", [](dqn_engine* en) { if (en->dp_overlap) launch_dp_pack(en->stream, en->dp_pk_a); }}); e->prog_pre1_end = e->prog.size(); }

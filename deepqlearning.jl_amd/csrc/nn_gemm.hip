@@ -409,6 +409,9 @@ void k_fwd_lds(LayerDev L, GFwdProbs pr, int S, int kc) {
     const int w = xcd_remap(blockIdx.x - wg_begin, pr.wg_end[pi] - wg_begin);
     const int ngroups = L.N / (16 * NT);               // (the decodes go through reciprocals: fdiv_*, common.h)
     int ng, mgrp, s;
+    // (r06, measured and dropped: a BLOCKED decode for the wide dense layers at large batches -- an XCD's share covering nb N-groups x a run of M-groups instead of every N-group
+    //  x two M-groups, so that its L2 streams a fraction of the weights instead of all of them (FETCH_SIZE 240 MB for 45 MB of operands, profiles/r06_a_cfg5_fetch_pmc.txt):
+    //  nb = 2 / 4 / 8 leave the 3136 -> 512 pair's forward at 95.2-96.5 us, as it was (profiles/r06_m_fwd_nb.txt) -- fabric traffic is not what bounds this launch)
     { int w2; fdiv_qr(w, fdiv_of(ngroups), w2, ng); fdiv_qr(w2, fdiv_of(p.mgroups), s, mgrp); }
     fwd_lds_body<NT, XU8, KT, M32>(L, p, S, kc, ng * 16 * NT, mgrp, s);
 }
@@ -1419,6 +1422,7 @@ void launch_gemm_dwdx(hipStream_t st, const LayerDev& Lw, int nprob, const float
     size_t lds = lds_w > lds_x ? lds_w : lds_x;
     // the dense pair at B >= 512 runs better with TWO workgroups per CU than with the three its 46.6 KB allow (measured r04, config 5, same box, alternating: 81.7 -> 76.8 us;
     // the conv launches lose 8-11 % the same way and keep three): the request is raised past a third of the CU's LDS
+    // (r06, with the dW section's half units in place: three per CU measure the same -- 74.5 vs 74.5-75.3 us, profiles/r06_l_fc3wg_ab.txt -- the request stays)
     if (pj == 2 && dense && B >= 512 && lds < (size_t)(160 * 1024 / 3 + 1024)) lds = (size_t)(160 * 1024 / 3 + 1024);
     tail.lds_bytes = (unsigned)lds; tail.probe = HOST_PROBE();
     const int grid = dw_blocks + gx * (B / dx_cols(pj)) + (int)gemm_tail_blocks(tail);
