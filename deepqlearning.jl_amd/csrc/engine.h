@@ -24,7 +24,6 @@ struct ProfEntry { const char* name; hipEvent_t a, b; };
 // library besides trace builds), kept in the engine: no function-local statics, nothing process-wide, a second engine in the same process never inherits the
 // first one's switches.  The communicator switches (force_allreduce, dp_*) are re-read by dqn_comm_init, the call that makes them meaningful.
 struct EngineOpts {
-    int adam_mode = 0;            // DQN_ADAM_MODE=1: Adam jobs carried by the backward launches (measured slower; parity-tested)
     int no_tiny = 0;              // DQN_NO_TINY: networks that fit in LDS take the multi-launch program
     int fwd_m32 = -1 /* -1: large launches only */, no_dx_wide = 0, no_fwd_wres = 0;      // DQN_FWD_M32 / DQN_NO_DX_WIDE / DQN_NO_FWD_WRES -> LayerDev::opt bits
     int mid_group = 4, mid_big = 16;                   // DQN_MID_GROUP / DQN_MID_BIG: middle steps of dqn_train_steps per graph (mid_big also needs mid_group > 1)
@@ -35,7 +34,7 @@ struct EngineOpts {
     int no_st_wt = 0;             // DQN_NO_ST_WT: small-batch engines keep plain / non-temporal output stores in the GEMM launches (A/B)
     int no_head_cols4 = 0;        // DQN_NO_HEAD_COLS4=1: keep k_head_td (one workgroup per column) at large batches where k_head_cols4 (red_head.hip) would apply (A/B); =2: k_head_cols4 without the transposed copies (its fallback loader, under test)
     int no_red_head = 0;          // DQN_NO_RED_HEAD: keep k_reduce_multi + k_head_td where the fused reduce + head launch (red_head.hip) would apply (A/B, both schedules under test)
-    int no_u8_arena = 0, head_fuse_maxb = 1024, no_head_fuse = 0, head_dbg = 0, prio_fork = 0, prio_level = 0, prio_nosplit = 0, no_pregather = 0, lstm_dw_mfma = 0;
+    int no_u8_arena = 0, head_fuse_maxb = 1024, no_head_fuse = 0, head_dbg = 0, prio_fork = 0, no_pregather = 0, lstm_dw_mfma = 0;
     int force_allreduce = 0, dp_allreduce = 0, dp_overlap = -1 /* -1: decided from world size and bytes (engine_program.hip) */, dp_no_one_graph = 0;      // DQN_FORCE_ALLREDUCE / DQN_DP_ALLREDUCE / DQN_DP_OVERLAP / DQN_DP_NO_ONE_GRAPH
     // timing probes (wrong numbers, right schedule) and stamps
     int probe_no_tg = 0, drqn_probe = 0, drqn_stamps = 0, tiny_stop = 0;
@@ -72,7 +71,6 @@ struct dqn_engine {
     // graphs: [0] = step with sampling, [1] = step on given indices; with a communicator the step is cut in two
     hipGraphExec_t g_full[2] = {nullptr, nullptr}, g_pre[2] = {nullptr, nullptr}, g_post = nullptr;
     bool arena_u8 = false;  // the observation arena x0 holds bytes (u8 replay, first layer converts in its tile loads): set by build_program
-    int adam_mode = 0;      // env DQN_ADAM_MODE at creation: 1 = Adam jobs carried by the backward launches (engine_program.hip)
     unsigned long long* ktrace_buf = nullptr;     // dqn_debug_ktrace (trace builds): owned by the engine, freed with it
     // comm
     void* comm = nullptr; int rank = 0, world = 1; bool force_comm = false;

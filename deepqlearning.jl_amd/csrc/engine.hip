@@ -118,12 +118,16 @@ void read_opts(EngineOpts& o, bool comm_only) {
     auto F = [](const char* k) { return getenv(k) != nullptr ? 1 : 0; };
     o.force_allreduce = F("DQN_FORCE_ALLREDUCE"); o.dp_allreduce = F("DQN_DP_ALLREDUCE"); o.dp_overlap = I("DQN_DP_OVERLAP", -1); o.dp_no_one_graph = F("DQN_DP_NO_ONE_GRAPH");
     if (comm_only) return;
-    o.adam_mode = I("DQN_ADAM_MODE", 0); o.no_tiny = F("DQN_NO_TINY"); o.fwd_m32 = I("DQN_FWD_M32", -1); o.no_dx_wide = F("DQN_NO_DX_WIDE"); o.no_fwd_wres = F("DQN_NO_FWD_WRES");
-    o.mid_group = I("DQN_MID_GROUP", 4); o.mid_big = I("DQN_MID_BIG", 16); o.sim_world = I("DQN_SIM_WORLD", 0); o.no_graph_upload = F("DQN_NO_GRAPH_UPLOAD");
-    o.no_rollout_cycle = F("DQN_NO_ROLLOUT_CYCLE"); o.no_u8_arena = F("DQN_NO_U8_ARENA"); o.head_fuse_maxb = I("DQN_HEAD_FUSE_MAXB", 1024); o.no_head_fuse = F("DQN_NO_HEAD_FUSE");
-    o.head_dbg = I("DQN_HEAD_DBG", 0); o.prio_fork = F("DQN_PRIO_FORK"); o.prio_level = I("DQN_PRIO_LEVEL", 0); o.prio_nosplit = F("DQN_PRIO_NOSPLIT"); o.no_pregather = F("DQN_NO_PREGATHER");
-    o.dw_split = I("DQN_DW_SPLIT", 128); o.no_red_head = F("DQN_NO_RED_HEAD"); o.no_head_cols4 = I("DQN_NO_HEAD_COLS4", 0); o.no_st_wt = F("DQN_NO_ST_WT");
-    o.lstm_dw_mfma = F("DQN_LSTM_DW_MFMA"); o.probe_no_tg = F("DQN_PROBE_NO_TG"); o.drqn_probe = I("DQN_DRQN_PROBE", 0); o.drqn_stamps = F("DQN_DRQN_STAMPS"); o.tiny_stop = I("DQN_TINY_STOP", 0);
+    // switches that keep a SECOND SCHEDULE of the same arithmetic under parity tests (tests/ name each of them) or that a tool under tools/ drives
+    o.no_tiny = F("DQN_NO_TINY"); o.fwd_m32 = I("DQN_FWD_M32", -1); o.no_fwd_wres = F("DQN_NO_FWD_WRES"); o.sim_world = I("DQN_SIM_WORLD", 0); o.no_pregather = F("DQN_NO_PREGATHER");
+    o.no_red_head = F("DQN_NO_RED_HEAD"); o.no_head_cols4 = I("DQN_NO_HEAD_COLS4", 0); o.dw_split = I("DQN_DW_SPLIT", 128); o.drqn_stamps = F("DQN_DRQN_STAMPS");
+    // r06 removed (the constants they set are now the only behaviour): DQN_ADAM_MODE, DQN_PRIO_LEVEL, DQN_PRIO_NOSPLIT, DQN_PRIO_FORK, DQN_HEAD_FUSE_MAXB,
+    // DQN_NO_HEAD_FUSE, DQN_NO_U8_ARENA, DQN_LSTM_DW_MFMA, DQN_NO_GRAPH_UPLOAD, DQN_NO_ST_WT, DQN_NO_DX_WIDE, DQN_NO_ROLLOUT_CYCLE, DQN_MID_GROUP, DQN_MID_BIG
+    // (docs/history/r06.md lists each with the number that decided it)
+#ifdef DQN_KTRACE
+    // TIMING PROBES (wrong numbers, right schedule): trace builds only -- the product library does not read them
+    o.head_dbg = I("DQN_HEAD_DBG", 0); o.probe_no_tg = F("DQN_PROBE_NO_TG"); o.drqn_probe = I("DQN_DRQN_PROBE", 0); o.tiny_stop = I("DQN_TINY_STOP", 0);
+#endif
 }
 static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out, const dqn_hparams* hp, bool allow_cg = true) {
     bool rec = false; for (int i = 0; i < n; i++) rec = rec || L[i].kind == DQN_LAYER_LSTM;
@@ -199,7 +203,7 @@ static int engine_init(dqn_engine* e, const dqn_layer_desc* layers, int n_layers
     if (build_layers(layers, n_layers, hp, e->L, &e->last_base, &e->last_val, &e->last_adv, &e->P, &e->Pint)) return -1;
     e->nl = n_layers;
     read_opts(e->opt);      // every experiment / test switch, once; nothing below (or later) looks at the environment
-    e->adam_mode = e->opt.adam_mode; e->no_tiny = e->opt.no_tiny != 0;
+    e->no_tiny = e->opt.no_tiny != 0;
     e->mid_group = e->opt.mid_group;      // middle steps of dqn_train_steps per graph launch (1 = one step per graph: no grouped graphs at all)
     e->mid_big = e->opt.mid_group > 1 ? e->opt.mid_big : 0;
     { const int lopt = (e->opt.fwd_m32 > 0 ? DQN_LOPT_FWD_M32 : 0) | (e->opt.fwd_m32 == 0 ? DQN_LOPT_NO_FWD_M32 : 0) | (e->opt.no_dx_wide ? DQN_LOPT_NO_DX_WIDE : 0) | (e->opt.no_fwd_wres ? DQN_LOPT_NO_FWD_WRES : 0) |

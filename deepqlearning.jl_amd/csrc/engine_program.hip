@@ -410,16 +410,9 @@ int build_program(dqn_engine* e) {
     // The final k_adam is left with the first level's layers and the beta-power tick.
     bool segs_ok = true;
     for (int i = 0; i < e->nl; i++) { const LayerDev& L = e->L[i]; if (L.kind != DQN_LAYER_LSTM && dqn_nchunks(L.npos * B, L.dw_kc) > 1) segs_ok = segs_ok && L.w_off % 4 == 0 && ((size_t)(L.K + 1) * L.N) % 4 == 0; }
-    // MEASURED (profiles/README.md, r02_c): at config 2 this does NOT pay -- every workgroup of a launch reserves the launch's LDS tile, so the tail
-    // only runs in the slots the GEMM workgroups leave, and the conv layers' slab sums (49-134 dependent-by-rounds loads per element), hidden
-    // under the 92 MB stream of the single Adam launch, become exposed: 159.3 vs 156.9 us/step.  A second stream inside the graph (fork/join)
-    // costs ~50 us/step on this stack.  So the default is ONE Adam launch (DQN_ADAM_MODE=0); DQN_ADAM_MODE=1 selects the carried jobs (kept
-    // parity-tested: tests/test_gpu_parity.py::test_adam_jobs_carried_by_backward_launches).
-    const int adam_mode = e->adam_mode;      // read once, at dqn_engine_create
-    const bool early = !rec && !e->comm && !e->sim_world && segs_ok && adam_mode == 1;
-    struct PItem { unsigned long long beg, end; const float* part; int S; };      // part != nullptr: split-K slabs to reduce; else a streamable range
-    std::vector<PItem> adam_pending; std::vector<int> adam_after_tail; int gmax_next = 0; bool prio_placed = false, prio_draw_pending = false;
-    int prio_skip = e->opt.prio_level;      // experiment knob: which LDS-tiled backward launch carries the priority block (0 = the first)
+    // (removed in r06: DQN_ADAM_MODE=1, the Adam update of layers whose gradient is already final carried as tail workgroups of the backward launches -- measured slower in
+    //  rounds 2, 3, 4 and, as "the stream in the free CU slots", 5: 159.3 vs 156.9 us/step in r02, +3.4 us per carrying launch for -2.75 us of Adam in r05; docs/history/r02.md, r05.md)
+    bool prio_placed = false, prio_draw_pending = false;
     auto base_job = [&]() {
         AdamJob J; memset(&J, 0, sizeof J);
         J.p = e->p_on; J.m = e->m; J.v = e->v; J.g = e->grad; J.g_out = e->grad; J.state = e->state; J.gmax_part = e->gmax_part;
@@ -438,40 +431,8 @@ int build_program(dqn_engine* e) {
     // pre-gather (common.h PreGather): needs the priority block (which also draws the next indices) OUT of the Adam launch -- it rides as
     // workgroup 0 of the first LDS-tiled backward launch instead
     // large batches: the priority update runs on the side stream (prio_fork) and draws the next indices there; k_td takes the pre-drawn batch
-    const bool pg_want = e->hp.prioritized_replay && !rec && (prio_in_adam ? (fuse_heads || e->prio_in_bwd) : e->prio_forked) && !early && !e->sim_world &&
+    const bool pg_want = e->hp.prioritized_replay && !rec && (prio_in_adam ? (fuse_heads || e->prio_in_bwd) : e->prio_forked) && !e->sim_world &&
                          (e->hp.obs_dtype != DQN_OBS_U8 || e->arena_u8) && !e->opt.no_pregather && (!e->hp.sample_distinct || Bb <= 64 || e->prio_in_bwd);      // u8 rows: only onto the byte arena; distinct mode at B > 64 without a carrying backward launch: sample launch + gather launch every step
-    // layer l's gradient is final: queue its parameter range (split-K layers: as a slab segment)
-    auto adam_queue = [&](int l, const std::vector<RSeg>& segs_known) {
-        const LayerDev& L = e->L[l]; PItem it; it.beg = L.w_off; it.end = l + 1 < e->nl ? e->L[l + 1].w_off : e->Pint; it.part = nullptr; it.S = 0;
-        for (const RSeg& r : segs_known) if (r.out == e->grad + L.w_off) { it.part = r.part; it.S = r.S; it.end = it.beg + r.elems; }
-        adam_pending.push_back(it);
-    };
-    // one job out of the queue: every slab segment, and streamable ranges up to `budget` elements (a range is cut at a multiple of 4 when the
-    // budget runs out, so that the stream can be spread over several carrier launches); what does not fit the job's tables stays queued
-    auto make_job = [&](unsigned long long budget, bool tick) {
-        AdamJob J = base_job(); std::vector<PItem> left; unsigned long long streamed = 0, slabbed = 0;
-        std::sort(adam_pending.begin(), adam_pending.end(), [](const PItem& x, const PItem& y) { return x.beg < y.beg; });
-        for (PItem it : adam_pending) {
-            if (it.part) {
-                if (J.segs.n == 8) { left.push_back(it); continue; }
-                const int q = J.segs.n++; J.segs.beg[q] = it.beg; J.segs.end[q] = it.end; J.segs.part[q] = it.part; J.segs.S[q] = it.S; slabbed += it.end - it.beg;
-                continue;
-            }
-            if (streamed >= budget) { left.push_back(it); continue; }
-            if (it.end - it.beg > budget - streamed) { PItem rest = it; it.end = it.beg + ((budget - streamed + 3) / 4) * 4; rest.beg = it.end; if (rest.beg < rest.end) left.push_back(rest); }
-            if (J.nr > 0 && J.end[J.nr - 1] == it.beg) J.end[J.nr - 1] = it.end;
-            else if (J.nr < 4) { J.beg[J.nr] = it.beg; J.end[J.nr] = it.end; J.nr++; }
-            else { left.push_back(it); continue; }
-            streamed += it.end - it.beg;
-        }
-        adam_pending = left;
-        J.segs.blocks = (unsigned)((slabbed + 255) / 256);
-        J.sblocks = streamed ? (unsigned)adam_blocks((size_t)streamed) : 0u; J.tick = tick ? 1 : 0; if (tick && J.sblocks == 0) J.sblocks = 1;
-        if (!tick && J.sblocks > 512) J.sblocks = 512;      // carried by a backward launch: two streaming workgroups per CU leave the slots beside them to the GEMM workgroups
-        J.slot0 = gmax_next; gmax_next += (int)(J.segs.blocks + J.sblocks);
-        return J;
-    };
-    auto pending_stream = [&]() { unsigned long long n = 0; for (const PItem& it : adam_pending) if (!it.part) n += it.end - it.beg; return n; };
     bool joined = false;
     std::vector<VTask> tail_pend;    // small tasks waiting for a launch to ride on (fused heads: their dW/db and the loss fold)
     auto make_tail = [&](std::vector<VTask>& v) {
@@ -511,7 +472,6 @@ int build_program(dqn_engine* e) {
                 if (S > 1) { RSeg r; memset(&r, 0, sizeof r); r.part = part; r.S = S; r.elems = (unsigned long long)(L.K + 1) * L.N; r.mode = 2; r.out = e->grad + L.w_off; final_segs.push_back(r); }
             }
             VTask f; memset(&f, 0, sizeof f); f.kind = 3; f.dpre = hl_buf; f.B = B; f.out = &e->state->loss; tail_pend.push_back(f);
-            if (early) for (int l : lv) adam_after_tail.push_back(l);
             continue;
         }
         bool dw_done_sibling = false;   // the level's two sibling layers got their dW from one fused launch
@@ -628,20 +588,14 @@ int build_program(dqn_engine* e) {
             if (dwl.on || dxl.on) tail = make_tail(tail_pend);                       // rides in the last workgroups of this level's LDS-tiled launch
             else { for (auto& t : tail_pend) pend.push_back(t); tail_pend.clear(); } // or joins this level's VALU task table
         }
-        if (early && (dwl.on || dxl.on) && (!adam_pending.empty() || (prio_in_adam && !prio_placed))) {
-            // this launch and the li launches below it share the queued stream evenly
-            tail.adam = make_job((pending_stream() / (unsigned long long)(li + 1) + 3) / 4 * 4, false); tail.has_adam = 1;
-            if (prio_in_adam && !prio_placed) { tail.adam.prio = prio_args(); prio_placed = true; }
-        }
-        else if (pg_want && prio_in_adam && (dwl.on || dxl.on) && prio_draw_pending) {      // second half of a split priority block: the next sample()'s draws
+        if (pg_want && prio_in_adam && (dwl.on || dxl.on) && prio_draw_pending) {      // second half of a split priority block: the next sample()'s draws
             tail.adam = base_job(); tail.adam.prio = prio_args(); tail.adam.prio.phase = 2; tail.has_adam = 1; prio_draw_pending = false; prio_placed = true;
         }
-        else if (pg_want && prio_in_adam && (dwl.on || dxl.on) && !prio_placed && !prio_draw_pending && prio_skip-- <= 0) {
+        else if (pg_want && prio_in_adam && (dwl.on || dxl.on) && !prio_placed && !prio_draw_pending) {
             // the block rides as workgroup 0 of this launch.  When a LATER backward launch can carry a workgroup too, the block is SPLIT: update_priorities!
             // here, the draws there -- each half shorter than the dX chains it hides under (r03 ktrace: the whole block lived 11 us, longer than any)
             bool later = false;
-            const bool no_split = e->opt.prio_nosplit != 0;
-            for (int lj = li - 1; lj >= 0 && !later && !no_split; lj--) for (int l2 : levels[lj]) {
+            for (int lj = li - 1; lj >= 0 && !later; lj--) for (int l2 : levels[lj]) {
                 const LayerDev& L2 = e->L[l2]; const int ldx2 = L2.src < 0 ? ld0 : ncon;
                 if (mf && L2.kind != DQN_LAYER_LSTM && !dp_layer[l2] && gemm_dw_eligible(L2, B, ldx2)) later = true;
             }
@@ -660,14 +614,8 @@ int build_program(dqn_engine* e) {
         else if (dwl.on) { const DwL a = dwl; dwl.on = false; e->prog.push_back({tailed(a.name), [=](dqn_engine* en) { launch_gemm_dw(en->stream, a.L, a.nprob, a.X, a.ldx, a.d, B, a.o, 0, 0, 0, tail); }}); }
         else if (dxl.on) { const DxL a = dxl; dxl.on = false; e->prog.push_back({tailed(a.name), [=](dqn_engine* en) { launch_gemm_dx(en->stream, a.L, a.nsrc, a.W, a.d, B, a.out, a.ys, ncon, a.act_src, tail); }}); }
         flush_dw(); flush_dx();
-        if (early) {      // gradients final from here on: this level's layers, and the fused heads whose dW tasks this level carried
-            for (int l : lv) adam_queue(l, final_segs);
-            for (int l : adam_after_tail) adam_queue(l, final_segs);
-            adam_after_tail.clear();
-        }
     }
     if (!tail_pend.empty()) { std::vector<VTask> own(tail_pend); tail_pend.clear(); flush_valu(e, own, "head_dw"); }      // single-level network: nothing to ride on
-    if (early) { for (int l : adam_after_tail) adam_queue(l, final_segs); adam_after_tail.clear(); }
     if (e->prio_forked) e->prog.push_back({"prio_join", [](dqn_engine* en) { hipStreamWaitEvent(en->stream, en->ev_join, 0); }});
     memset(&e->adam_segs, 0, sizeof e->adam_segs);
     {
@@ -761,15 +709,7 @@ int build_program(dqn_engine* e) {
         }
         if (!e->dp_adam_folds) e->prog.push_back({"dp_sum_ranks", [=](dqn_engine* en) { launch_dp_unpack_sum(en->stream, dsum); }});
     }
-    if (early) {
-        // whatever is still pending (the first level's layers; layers that found no carrier) + the beta-power tick (+ the priority update if no
-        // backward launch could carry it)
-        std::vector<AdamJob> jobs;
-        bool first = true;
-        do { AdamJob J = make_job(~0ull, first); if (first && prio_in_adam && !prio_placed) { J.prio = prio_args(); if (prio_draw_pending) { J.prio.phase = 2; prio_draw_pending = false; } prio_placed = true; } jobs.push_back(J); first = false; } while (!adam_pending.empty());
-        e->prog.push_back({"adam_rest", [=](dqn_engine* en) { for (const AdamJob& J : jobs) launch_adam(en->stream, J); }});
-        e->gmax_used = gmax_next;
-    } else {
+    {
         AdamJob J = base_job();
         J.nr = 1; J.beg[0] = 0; J.end[0] = e->Pint; J.sblocks = (unsigned)adam_blocks(e->Pint); J.tick = 1; J.slot0 = 0;
         if (e->hp.prioritized_replay && !rec && !e->prio_forked && !prio_placed) { J.prio = prio_args(); if (prio_draw_pending) { J.prio.phase = 2; prio_draw_pending = false; } }

@@ -94,11 +94,10 @@ __device__ __forceinline__ const float* uniform_ptr(const float* p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (const float*)(((unsigned long long)hi << 32) | lo);
 }
-// tail workgroups of a backward launch: VALU tasks first, then the Adam stream (blk counts from the first tail workgroup)
+// tail workgroups of a backward launch: small VALU tasks (blk counts from the first tail workgroup).  The record's AdamJob carries only the priority block these days (workgroup 0
+// of the launch, GEMM_TAIL_PROLOGUE); the Adam STREAM as tail workgroups (DQN_ADAM_MODE=1, r02-r05) was removed in r06 after losing four rounds running
 __device__ __forceinline__ void gemm_tail_run(const GemmTail& tail, unsigned blk) {
-    if (blk < tail.blocks) { valu_task_run<false>(tail.tasks, tail.n, blk); return; }
-    extern __shared__ float lds[];         // every LDS-tiled launch allocates > 8.3 KB
-    adam_job_run(tail.adam, (int)(blk - tail.blocks), nullptr, lds, true);
+    if (blk < tail.blocks) valu_task_run<false>(tail.tasks, tail.n, blk);
 }
 // the priority block of a carried Adam job is workgroup 0 of the launch: its ~14 dependent tree levels need the whole launch to hide under
 #define GEMM_TAIL_PROLOGUE(tail, bid_var, main_var)                                                                                     \
