@@ -346,7 +346,7 @@ def secondary_block(pkg, args, device):
         link = 153e9      # one xGMI link, bytes/s (MI355X guide)
         def model(N):      # replica step at N ranks = measured world-1 replica step + (N - 1) more K tiles in the wide dW + the all-gather over point-to-point links
             wide = sum(v for k, v in L.items() if k.startswith("dp_dw"))
-            per_tile = 2.1      # us per additional rank block (one more 32-sample K tile per workgroup): calibrated on the simulated 8-rank run (profiles/r01_k_dp8_*: 25.8 us at N = 8)
+            per_tile = 2.1      # us per additional rank block (one more 32-sample K tile per workgroup): calibrated on the simulated 8-rank run (profiles/history/r01_k_dp8_*: 25.8 us at N = 8)
             ag_direct = xb / link * 1e6 if N > 1 else 0.0; ag_ring = (N - 1) * xb / link * 1e6
             return {"wide_dw_us": round(wide + per_tile * (N - 1), 1), "allgather_direct_us": round(ag_direct, 1), "allgather_ring_us": round(ag_ring, 1), "rccl_latency_us": "10-20 (not measurable at world 1)",
                     "predicted_step_us_direct": round(r["ms_per_step"] * 1e3 + per_tile * (N - 1) + ag_direct + 15.0, 1), "predicted_step_us_ring": round(r["ms_per_step"] * 1e3 + per_tile * (N - 1) + ag_ring + 15.0, 1)}
@@ -796,6 +796,10 @@ def cpu_baseline(pkg, layers, hp, params, env, args):
     use_torch = tval > port
     return {"value": tval if use_torch else port, "unit": "steps/s", "cores": tc.get("threads") if use_torch else tw.get("cores"), "kind": "port",
             "value_source": "torch_cpu (eager PyTorch CPU, oneDNN)" if use_torch else "twin (oracle/dqn_ref.c)",
+            # one place for "how many cores" (VERDICT r05 weak 12): the threads the quoted value USED, and what the box HAS (logical CPUs; physical cores of the NUMA node the
+            # workers were pinned to x nodes).  The ports stop scaling at 16 threads (probed 1 / 8 / 16 / 32 / all): more cores are there, they do not make this step faster
+            "cores_used": tc.get("threads") if use_torch else tw.get("cores"),
+            "cores_available": {"logical_cpus": ncpu, "physical_cores_one_numa_node": len(plan["cores"]), "numa_nodes": plan["nodes"], "physical_cores_box": len(plan["cores"]) * plan["nodes"]},
             "port_value": port, "port_cores": tw.get("cores"), "nproc": ncpu, "numa_node": plan["node"], "numa_nodes": plan["nodes"], "pinned_physical_cores": len(plan["cores"]),
             "single_thread_value": tw.get("single_thread_value"),
             "median_ms": tw.get("median_ms"), "p10_ms": tw.get("p10_ms"), "p90_ms": tw.get("p90_ms"), "p90_over_p10": tw.get("p90_over_p10"), "medians_ms": tw.get("medians_ms"),

@@ -111,7 +111,7 @@ __device__ __forceinline__ void adam_job_run(const AdamJob& J, int bid, long lon
                 gmax = fmaxf(gmax, adam_upd(g4.y, m4.y, v4.y, p4.y, J.f64mode, J.lr, J.b1, J.b2, J.eps, bp1, bp2, J.gscale));
                 gmax = fmaxf(gmax, adam_upd(g4.z, m4.z, v4.z, p4.z, J.f64mode, J.lr, J.b1, J.b2, J.eps, bp1, bp2, J.gscale));
                 gmax = fmaxf(gmax, adam_upd(g4.w, m4.w, v4.w, p4.w, J.f64mode, J.lr, J.b1, J.b2, J.eps, bp1, bp2, J.gscale));
-                // m and v are next read a whole step later: small-batch engines store them write-through (J.wt; r05 same-box A/B, profiles/r05_m_store_ab.txt: +0.5 %; p too: -0.2 %)
+                // m and v are next read a whole step later: small-batch engines store them write-through (J.wt; r05 same-box A/B, profiles/history/r05_m_store_ab.txt: +0.5 %; p too: -0.2 %)
                 adam_st4(reinterpret_cast<float4*>(J.m) + i, m4, J.wt | (DQN_ADAM_ST & 1)); adam_st4(reinterpret_cast<float4*>(J.v) + i, v4, J.wt | (DQN_ADAM_ST & 1)); adam_st4(reinterpret_cast<float4*>(J.p) + i, p4, DQN_ADAM_ST & 2);
             }
         }

@@ -186,7 +186,7 @@ int build_program(dqn_engine* e) {
         if (ok) {
             const LayerDev& Pa = e->L[rh_pa]; const int S = dqn_nchunks(Pa.K, Pa.fwd_kc); rh_S = S;
             // S > 1: k_red_head (split-K producers, small batches).  S == 1 -- finished activations of an unsplit forward, i.e. large batches: k_head_cols4, one workgroup per
-            // column group (k_red_head's (group, stream, chunk) decomposition is SLOWER there: 27.4 vs 21.3 us for k_head_td at B = 512, profiles/r05_k_cfg5_red_head_ab.txt --
+            // column group (k_red_head's (group, stream, chunk) decomposition is SLOWER there: 27.4 vs 21.3 us for k_head_td at B = 512, profiles/history/r05_k_cfg5_red_head_ab.txt --
             // 4096 workgroups each staging both streams' head weights)
             ok = Pa.kind == DQN_LAYER_DENSE && (S > 1 || e->opt.no_head_cols4 != 1) && dqn_chunk_len(La.K, La.fwd_kc) == 32 && dqn_nchunks(La.K, La.fwd_kc) * 32 == La.K;
             if (ok && hv_l >= 0) { const LayerDev& Pv = e->L[rh_pv]; const LayerDev& Lv = e->L[hv_l];

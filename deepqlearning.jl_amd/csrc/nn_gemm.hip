@@ -57,7 +57,7 @@ int gemm_set_ktrace(unsigned long long*) { return -1; }     // not a trace build
 // Output tiles of the GEMM launches (activations, split-K slabs, dX tiles, dW slabs / gradients) are stored WRITE-THROUGH (sc1) by the small-batch engines
 // (LayerDev::opt & DQN_LOPT_ST_WT, set at dqn_engine_create for <= 64 columns per sequence set).  A kernel boundary writes back what its launch left dirty in the eight L2s
 // (MI355X guide, "boundary" row: + B / 6 TB/s behind B dirty bytes) and at B = 32 the step is ten short launches that each leave 1-13 MB behind; write-through stores
-// stream out while the launch still runs.  r05, same box, alternating (profiles/r05_l_store_ab.txt): config 2 7960 -> 8115 steps/s with every output write-through (dW only:
+// stream out while the launch still runs.  r05, same box, alternating (profiles/history/r05_l_store_ab.txt): config 2 7960 -> 8115 steps/s with every output write-through (dW only:
 // 8050; activations / slabs / dX only: 7970); config 5 (B = 512: launches of 45-105 us) 1642 -> 1632, so large batches keep plain / non-temporal stores.
 // INVARIANT (inline asm: these stores are invisible to hipcc's vmcnt bookkeeping): NOTHING in the same kernel may read data stored through st_out4 / st_grad4 / adam_st4.
 // A tail or last-arriver consumer added later needs an explicit `s_waitcnt vmcnt(0)` in the producer BEFORE its release (fence + ticket), as red_head.hip does --
@@ -276,7 +276,7 @@ __device__ __forceinline__ void fwd_lds_body(const LayerDev& L, const GFwdProb& 
     };
     if constexpr (!M32) {
         // r05: a wave whose M-tile lies beyond the problem -- the target net's 32 columns are 2 of a dense workgroup's 4 M-tiles, so waves 2 and 3 of those workgroups
-        // contracted padding: 4/3 of the algorithmic MFMAs in the FC forward (SQ_VALU_MFMA_BUSY_CYCLES 12.85 M vs 9.6 M, profiles/r04_y_pmc_sq.txt), issued on SIMDs the
+        // contracted padding: 4/3 of the algorithmic MFMAs in the FC forward (SQ_VALU_MFMA_BUSY_CYCLES 12.85 M vs 9.6 M, profiles/history/r04_y_pmc_sq.txt), issued on SIMDs the
         // co-resident workgroup's waves need.  Such a wave still moves its share of both operand tiles -- the loads, LDS stores and barriers of the pipeline below, in the same
         // order -- but reads no fragments and issues no MFMAs.  The productive waves' instruction stream is unchanged (a separate path, not a predicate in the loop).
         if (!__builtin_amdgcn_readfirstlane((int)(mgrp * 4 + wave < p.mtiles))) {
@@ -875,7 +875,7 @@ __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& p
         //   reads   (ds_read_b128: banks mod 64 per 16-lane group {0-3,12-15,20-27} / {4-11,16-19,28-31} / +32): each group reads 64 CONTIGUOUS floats
         //           (one row of NW = 64, two adjacent rows of NW = 32) -- every bank once.
         // The round-3 layout (the wave's own rows of the A tile, stride 34) needed no barrier but conflicted 2-way on both sides: 12-14 % of the backward
-        // launches' LDS cycles (profiles/r03_q_pmc_sq.txt).  One barrier: every wave is past its last fragment read before the tile is overwritten.
+        // launches' LDS cycles (profiles/history/r03_q_pmc_sq.txt).  One barrier: every wave is past its last fragment read before the tile is overwritten.
         __syncthreads();
         float* T = lds;
 #pragma unroll

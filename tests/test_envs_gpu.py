@@ -89,7 +89,7 @@ def test_rollout_with_fused_acting_head_bit_exact(pkg, envs, monkeypatch, n_envs
     """r05: the device env loop on a network whose dueling streams have split-K hidden layers (the Nature shape class): its train steps take the fused reduce + head launch
     (red_head.hip).  Trajectories, replay, priorities, parameters and evaluation equal the twin's bit for bit, and the schedule without the fused launch (DQN_NO_RED_HEAD)
     walks the same trajectory.  (An ACTING form of that launch -- reduce + heads of the policy forward in one -- was built and measured no faster: 9.6 us vs 4.7 + 4.8,
-    profiles/r05_o_acting_step_with_fused_head_dropped.txt; dropped.)"""
+    profiles/history/r05_o_acting_step_with_fused_head_dropped.txt; dropped.)"""
     net = EC.testmdp_wide_fc_dueling()
     outs = []
     for fused in (True, False):
