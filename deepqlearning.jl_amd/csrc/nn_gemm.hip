@@ -742,6 +742,10 @@ __device__ __forceinline__ void lds_st4(float* p, f32x4 v) {
 }
 
 struct DwUnit { int pi, ng, mr, s; };      // problem (sibling layer), channel group of 16 NT, 64-row tile, split-K chunk
+// (r06, built, bit-exact, measured and removed -- VERDICT r05 item 1a: the 64 x 64 dW tile as 2 x 2 blocks of v_mfma_f32_32x32x2_f32, one per wave, on K-MAJOR LDS tiles ([32 samples][65]:
+//  conflict-free fragment reads and ds_write_b32 staging stores): 32 instead of 40 fragment reads and 16 instead of 32 MFMA instructions per wave and K tile.  Config 5, same box, three
+//  alternations: FC / conv2 / conv3 pairs 74.4 / 68.2 / 46.9 -> 74.1 / 69.6 / 47.3 us (599.1-601.0 vs 598.2-601.1 us per step); config 2 125.9 -> 127.4 us (its epilogue stored single
+//  dwords).  Fragment reads and MFMA issue do not bound this body either, as r05's "a quarter of the fragment reads changes nothing" said.  profiles/r06_s_dw_m32_ab.txt)
 template <int NT, bool XU8 = false>
 __device__ __forceinline__ void dw_lds_body(const LayerDev& L, const GDwProbs& pr, int ldx, int B, int S, int kc, const DwUnit& u, DwStride ds, int probe = 0) {
     constexpr int NW = 16 * NT;
