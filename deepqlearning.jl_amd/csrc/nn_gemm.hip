@@ -409,7 +409,7 @@ void k_fwd_lds(LayerDev L, GFwdProbs pr, int S, int kc) {
     const int ngroups = L.N / (16 * NT);               // (the decodes go through reciprocals: fdiv_*, common.h)
     int ng, mgrp, s;
     // (r06, measured and dropped: a BLOCKED decode for the wide dense layers at large batches -- an XCD's share covering nb N-groups x a run of M-groups instead of every N-group
-    //  x two M-groups, so that its L2 streams a fraction of the weights instead of all of them (FETCH_SIZE 240 MB for 45 MB of operands, profiles/r06_a_cfg5_fetch_pmc.txt):
+    //  x two M-groups, so that its L2 streams a fraction of the weights instead of all of them (FETCH_SIZE 240 MB for 45 MB of operands, profiles/r06_q_cfg5_pmc_fetch.txt):
     //  nb = 2 / 4 / 8 leave the 3136 -> 512 pair's forward at 95.2-96.5 us, as it was (profiles/r06_m_fwd_nb.txt) -- fabric traffic is not what bounds this launch)
     { int w2; fdiv_qr(w, fdiv_of(ngroups), w2, ng); fdiv_qr(w2, fdiv_of(p.mgroups), s, mgrp); }
     fwd_lds_body<NT, XU8, KT, M32>(L, p, S, kc, ng * 16 * NT, mgrp, s);
