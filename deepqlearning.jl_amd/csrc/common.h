@@ -620,6 +620,7 @@ struct RedHeadStream {
 };
 struct RedHeadArgs {
     int B, nA, K, S, ncon, nstream, NO, double_q;      // K hidden rows (= head inputs), S slabs, NO = head outputs of both streams (nA, + 1 with a value stream)
+    int pm;                                            // the slabs are PIECE-MAJOR: [S][column quad][K][4] (written so by the forward launch, GFwdProb::pm)
     float gamma;
     RedHeadStream st[2];
     const int* bm_a; const float *bm_r, *bm_done, *bm_w;      // batch scalars of the B columns (written by the gather launch)
@@ -762,7 +763,8 @@ int gemm_set_ktrace(unsigned long long* p);   // debug (-DDQN_KTRACE builds): pe
 #define DQN_LOPT_NO_FWD_WRES 8  /* DQN_NO_FWD_WRES: large-batch forwards of a narrow layer take the per-tile kernel instead of the weights-resident persistent one (A/B) */
 void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* const* W, const float* const* bias, const float* const* X,
                      const int* ldx, const int* col0, const int* ncols, float* const* out /* Y, or split-K partial slabs */,
-                     float* const* outT = nullptr /* optional, dense unsplit layers: a TRANSPOSED copy [column][feature] of Y per problem (k_head_td's input columns) */);
+                     float* const* outT = nullptr /* optional, dense unsplit layers: a TRANSPOSED copy [column][feature] of Y per problem (k_head_td's input columns) */,
+                     int piece_major = 0 /* dense split-K layers whose slabs only k_red_head reads: slabs laid out [S][column quad][N][4] (GFwdProb::pm, nn_gemm.hip) */);
 
 // ---- DRQN (drqn.hip): EpisodeReplayBuffer gather, LSTM recurrence / BPTT steps, recurrent TD
 struct LstmSeq {          // one sequence set advancing one time step: B columns starting at column c0 (+ t*B) of [*][ld] arrays

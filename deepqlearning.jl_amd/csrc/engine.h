@@ -30,6 +30,7 @@ struct EngineOpts {
     int sim_world = 0;            // DQN_SIM_WORLD=k: one process plays k ranks (tests)
     int no_graph_upload = 0;      // DQN_NO_GRAPH_UPLOAD
     int no_rollout_cycle = 0;     // DQN_NO_ROLLOUT_CYCLE
+    int no_rh_pm = 0;             // DQN_NO_RH_PM (A/B, r06): the hidden layers' split-K slabs stay [S][N][columns] where k_red_head reads them (default: piece-major, GFwdProb::pm)
     int dw_split = 128;            // DQN_DW_SPLIT=n: the last n units of a large-batch dW section run as two halves along N (nn_gemm.hip dw_section; 0 = off; LayerDev::opt bits 8..15 in units of 16)
     int no_st_wt = 0;             // DQN_NO_ST_WT: small-batch engines keep plain / non-temporal output stores in the GEMM launches (A/B)
     int no_head_cols4 = 0;        // DQN_NO_HEAD_COLS4=1: keep k_head_td (one workgroup per column) at large batches where k_head_cols4 (red_head.hip) would apply (A/B); =2: k_head_cols4 without the transposed copies (its fallback loader, under test)

@@ -175,7 +175,7 @@ int build_program(dqn_engine* e) {
     // ---------------- r05: when the head layers sit on dense hidden layers whose forward ran split-K, the split-K reduce AND the head level are ONE chip-filling launch
     // (red_head.hip: workgroup = 4 batch columns x stream x plan chunk of 32 hidden rows, the last arriver of a column group does TD + the heads' dX) instead of
     // k_reduce_multi (384 workgroups) + k_head_td (B workgroups)
-    bool fuse_rh = false; int rh_pa = -1, rh_pv = -1, rh_S = 0; const float* rh_part[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [stream][net]
+    bool fuse_rh = false, rh_pm = false; int rh_pa = -1, rh_pv = -1, rh_S = 0; const float* rh_part[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [stream][net]
     const float* rh_partT[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     if (fuse_heads && levels.size() >= 2 && !e->opt.no_red_head && !e->opt.probe_no_tg && !e->opt.head_dbg) {
         const LayerDev& La = e->L[ha_l]; rh_pa = La.src; rh_pv = hv_l >= 0 ? e->L[hv_l].src : -1;
@@ -229,7 +229,11 @@ int build_program(dqn_engine* e) {
                 if (wantT[q.l] && q.S == 1 && Lq.kind == DQN_LAYER_DENSE) { a.outT[i] = actT[q.l][q.net] = palloc(e, (size_t)Lq.out_feat * q.ncols); any_t = true; }
             }
             if (any_t) for (int i = 0; i < n; i++) if (!a.outT[i]) { any_t = false; for (int j = 0; j < n; j++) { if (a.outT[j]) actT[pr[ids[j]].l][pr[ids[j]].net] = nullptr; a.outT[j] = nullptr; } break; }      // all problems of the launch or none
-            e->prog.push_back({name, [=](dqn_engine* en) { launch_gemm_fwd(en->stream, L, n, a.W, a.bias, a.X, a.ldx, a.col0, a.ncols, a.out, any_t ? a.outT : nullptr); }});
+            // split-K slabs that only k_red_head reads are written piece-major (GFwdProb::pm): every problem of the launch belongs to the head's producer layers
+            bool pm_all = fuse_rh && rh_S > 1 && !e->opt.no_rh_pm; for (int i = 0; i < n; i++) pm_all = pm_all && (pr[ids[i]].l == rh_pa || pr[ids[i]].l == rh_pv) && pr[ids[i]].S > 1;
+            if (pm_all) rh_pm = true;
+            const int pm = pm_all ? 1 : 0;
+            e->prog.push_back({name, [=](dqn_engine* en) { launch_gemm_fwd(en->stream, L, n, a.W, a.bias, a.X, a.ldx, a.col0, a.ncols, a.out, any_t ? a.outT : nullptr, pm); }});
             for (int id : ids) done[id] = true;
         };
         if (mf) {
@@ -314,7 +318,7 @@ int build_program(dqn_engine* e) {
             RedHeadArgs h; memset(&h, 0, sizeof h);
             const LayerDev& La = e->L[ha_l];
             h.B = B; h.nA = e->nA; h.K = La.K; h.S = dqn_nchunks(e->L[rh_pa].K, e->L[rh_pa].fwd_kc); h.ncon = ncon; h.nstream = hv_l >= 0 ? 2 : 1; h.NO = e->nA + (hv_l >= 0 ? 1 : 0); h.double_q = e->hp.double_q;
-            h.gamma = e->hp.gamma;
+            h.gamma = e->hp.gamma; h.pm = rh_pm ? 1 : 0;
             for (int st = 0; st < h.nstream; st++) {
                 const int hl_ = st == 0 ? ha_l : hv_l, pl_ = st == 0 ? rh_pa : rh_pv; const LayerDev& H = e->L[hl_]; const LayerDev& P = e->L[pl_]; RedHeadStream& T = h.st[st];
                 T.part[0] = rh_part[st][0]; T.part[1] = rh_part[st][1]; T.partT[0] = rh_partT[st][0]; T.partT[1] = rh_partT[st][1]; T.pbias[0] = e->p_on + P.b_off; T.pbias[1] = e->p_tg + P.b_off; T.pact = P.act;

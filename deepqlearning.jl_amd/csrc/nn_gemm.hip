@@ -111,7 +111,9 @@ __device__ __forceinline__ void gemm_tail_run(const GemmTail& tail, unsigned blk
 // workgroup tile = 4 M-tiles (16 columns each, drawn from consecutive (pos, column-tile) pairs; wave w owns M-tile w)
 //                  x NT N-tiles (16*NT output channels), K walked in tiles of 32.
 // =====================================================================================================================
-struct GFwdProb { const float* W; const float* bias; const float* X; int ldx, col0, ncols; float* out; int mtiles, mgroups; float* outT; };      // outT: optional transposed copy [column][N] (dense, one chunk)
+struct GFwdProb { const float* W; const float* bias; const float* X; int ldx, col0, ncols; float* out; int mtiles, mgroups; float* outT;      // outT: optional transposed copy [column][N] (dense, one chunk)
+                  int pm; };   // pm (dense, split-K slabs read by k_red_head only): PIECE-MAJOR slabs [S][column quad][N][4] instead of [S][N][columns] -- the 32 hidden rows x 16 bytes a
+                               // (column group, chunk) workgroup of k_red_head reads per slab are then 512 contiguous bytes instead of 32 pieces 256 bytes apart
 struct GFwdProbs { GFwdProb p[4]; int wg_end[4]; };   // up to 4 problems of one geometry per launch: {val,adv} x {online,target}
 
 constexpr int F_KT_DEF = 32;    // K tile depth of the small-batch launches; launches of >= 1024 workgroups use 16-deep tiles (see launch_gemm_fwd).  64-deep tiles measured slower (r03) and were removed
@@ -386,7 +388,8 @@ __device__ __forceinline__ void fwd_lds_body(const LayerDev& L, const GFwdProb& 
             if constexpr (KT == 16) act_v4(v, bias, L.act);      // (large launches; for the lone waves of the 32-deep form the per-element switch measures 1.9 % FASTER per step, same box)
             else { v.x = act_f(v.x + bias, L.act); v.y = act_f(v.y + bias, L.act); v.z = act_f(v.z + bias, L.act); v.w = act_f(v.w + bias, L.act); }
         }
-        st_out4(reinterpret_cast<f32x4*>(p.out + (size_t)s * per_s + ((size_t)n * L.npos + pos) * p.ncols + ct * 16 + 4 * kq), v, L.opt & DQN_LOPT_ST_WT);
+        const size_t o_el = p.pm ? ((size_t)(ct * 4 + kq) * L.N + n) * 4 : ((size_t)n * L.npos + pos) * p.ncols + ct * 16 + 4 * kq;
+        st_out4(reinterpret_cast<f32x4*>(p.out + (size_t)s * per_s + o_el), v, L.opt & DQN_LOPT_ST_WT);
         if (p.outT) {      // (dense, one chunk) the same activations with a batch column's features contiguous: k_head_td reads its columns as runs instead of one 64-byte sector per element
             float* o = p.outT + (size_t)(ct * 16 + 4 * kq) * L.N + n;
             o[0] = v.x; o[L.N] = v.y; o[2 * (size_t)L.N] = v.z; o[3 * (size_t)L.N] = v.w;
@@ -655,14 +658,15 @@ bool gemm_fwd_eligible(const LayerDev& L, int nprob, const int* ldx, const int* 
     return true;
 }
 void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* const* W, const float* const* bias, const float* const* X,
-                     const int* ldx, const int* col0, const int* ncols, float* const* out, float* const* outT) {
+                     const int* ldx, const int* col0, const int* ncols, float* const* out, float* const* outT, int piece_major) {
     const int S = dqn_nchunks(L.K, L.fwd_kc), kc = dqn_chunk_len(L.K, L.fwd_kc);
+    if (piece_major && (L.kind != DQN_LAYER_DENSE || S <= 1)) piece_major = 0;
     GFwdProbs pr; long mg_total = 0;
     for (int i = 0; i < 4; i++) {
         const int j = i < nprob ? i : 0;
         GFwdProb& q = pr.p[i];
         q.W = W[j]; q.bias = bias[j]; q.X = X[j]; q.ldx = ldx[j]; q.col0 = col0[j]; q.ncols = ncols[j]; q.out = out[j]; q.outT = (outT && S == 1 && L.kind == DQN_LAYER_DENSE) ? outT[j] : nullptr;
-        q.mtiles = L.npos * (ncols[j] / 16); q.mgroups = (q.mtiles + 3) / 4;
+        q.mtiles = L.npos * (ncols[j] / 16); q.mgroups = (q.mtiles + 3) / 4; q.pm = piece_major;
         if (i < nprob) mg_total += q.mgroups;
     }
     const bool want_t = pr.p[0].outT != nullptr;
@@ -708,7 +712,7 @@ void launch_gemm_fwd(hipStream_t st, const LayerDev& L, int nprob, const float* 
 #define FWD_LAUNCH(NT_, U8_, KT_) hipLaunchKernelGGL((k_fwd_lds<NT_, U8_, KT_>), dim3(end), dim3(256), lds, st, L, pr, S, kc)
 #define FWD_PICK(U8_, KT_) do { if (NT == 4) FWD_LAUNCH(4, U8_, KT_); else if (NT == 2) FWD_LAUNCH(2, U8_, KT_); else FWD_LAUNCH(1, U8_, KT_); } while (0)
     // 32x32x2 MFMA blocks for the 64-channel tiles: large launches by default (r04), everywhere with DQN_FWD_M32=1, nowhere with =0 (read at dqn_engine_create)
-    const int m32 = ((L.opt & DQN_LOPT_NO_FWD_M32) || want_t) ? 0 : ((L.opt & DQN_LOPT_FWD_M32) || k16) ? 1 : 0;
+    const int m32 = ((L.opt & DQN_LOPT_NO_FWD_M32) || want_t || piece_major) ? 0 : ((L.opt & DQN_LOPT_FWD_M32) || k16) ? 1 : 0;
     if (m32 && NT == 4 && !L.xu8) { if (k16) hipLaunchKernelGGL((k_fwd_lds<4, false, 16, true>), dim3(end), dim3(256), lds, st, L, pr, S, kc); else hipLaunchKernelGGL((k_fwd_lds<4, false, F_KT_DEF, true>), dim3(end), dim3(256), lds, st, L, pr, S, kc); }
     else if (L.xu8) { if (k16) FWD_PICK(true, 16); else FWD_PICK(true, F_KT_DEF); }
     else { if (k16) FWD_PICK(false, 16); else FWD_PICK(false, F_KT_DEF); }

@@ -204,7 +204,8 @@ __global__ __launch_bounds__(256) void k_red_head(const RedHeadArgs A, int bump_
         // (both nets' pointers are scalars selected per lane: indexing the record with a per-lane `net` would be a vector load of the pointer)
         const float *pt0 = T.part[0], *pt1 = T.part[1], *pbs0 = T.pbias[0], *pbs1 = T.pbias[1];
         const int net = slot == 2 ? 1 : 0, ncols = net ? B : ncon, col = 4 * g + ((slot == 1 && double_q) ? B : 0);      // (!double_q: ncon == B, slot 1 is discarded below -- it re-reads slot 0's piece instead of running B floats past the row)
-        const float* p = (net ? pt1 : pt0) + ((size_t)(32 * c + f) * ncols + col);
+        // (piece-major slabs: the 32 rows of this chunk and column quad are 512 contiguous bytes; else one 16-byte piece per 4 * ncols bytes)
+        const float* p = (net ? pt1 : pt0) + (A.pm ? ((size_t)(col >> 2) * K + (size_t)(32 * c + f)) * 4 : (size_t)(32 * c + f) * ncols + col);
         const size_t per_s = (size_t)K * ncols;
 #pragma unroll
         for (int s = 0; s < SMAX; s++) sl[s] = *gptr(reinterpret_cast<const f32x4r*>(p + (size_t)(s < S ? s : S - 1) * per_s));
