@@ -627,6 +627,7 @@ struct RedHeadArgs {
     float *w_is, *td, *q_on_s, *q_on_sp, *q_tg_sp, *ytarget, *hl; int* best;
     StepState* stt; long long* idx; const long long* idx_pre;
     float* partials;                   // [B/4][3 slots][4 columns][NO][K/32] chunk sums of the head outputs
+    float* ypm;                        // k_red_head: [B/4][nstream][K][4] piece-major copy of the online hidden activations of the s columns (the last arriver's act' operand); null: read y_on
     unsigned* tickets;                 // [B/4] arrival counters (zero between launches: the last arriver re-arms its group's)
     unsigned long long* stamps;        // timing probe (DQN_DRQN_STAMPS at create, tools/red_head_phases.py), else null
 };

@@ -333,6 +333,7 @@ int build_program(dqn_engine* e) {
             h.idx = e->idx; h.idx_pre = e->idx_pre;
             const int Gc = B / 4, NC = h.K / 32;
             h.partials = palloc(e, (size_t)Gc * 12 * h.NO * NC); h.tickets = (unsigned*)palloc(e, (size_t)Gc);
+            h.ypm = (h.S > 1 && !e->opt.no_rh_pm) ? palloc(e, (size_t)Gc * h.nstream * h.K * 4) : nullptr;
             HIPCHK(hipMemset(h.tickets, 0, (size_t)Gc * 4));      // armed once; every launch's last arrivers re-arm their groups
             if (e->opt.drqn_stamps) { h.stamps = (unsigned long long*)palloc(e, 64); HIPCHK(hipMemset(h.stamps, 0, 256)); e->drqn_stamps = h.stamps; }
             const RedHeadArgs* h_dev = upload(e, std::vector<RedHeadArgs>(1, h));

@@ -115,9 +115,8 @@ template <bool TRANS> __device__ __forceinline__ void rh_dx_row(const RhDx& X, c
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
     if (st_) {      // the value head: one output, dq index nA
         const float wv = w[0];
-        float d0 = dqr[0][0], d1 = dqr[1][0], d2 = dqr[2][0], d3 = dqr[3][0];
-#pragma unroll
-        for (int o = 1; o < 9; o++) if (o == nA) { d0 = dqr[0][o]; d1 = dqr[1][o]; d2 = dqr[2][o]; d3 = dqr[3][o]; }
+        const float d0 = dqr[0][8], d1 = dqr[1][8], d2 = dqr[2][8], d3 = dqr[3][8];      // slot 8 = the value head's dq (index nA of the column's NO values), put there by the caller:
+                                                                                           // picked out of the register array by a RUN-TIME index it sent the whole array through scratch
         a0 = fmaf(d0, wv, a0); a1 = fmaf(d1, wv, a1); a2 = fmaf(d2, wv, a2); a3 = fmaf(d3, wv, a3);
     } else if (Ns == 4) {
         const f32x4r w4 = *reinterpret_cast<const f32x4r*>(w);
@@ -162,6 +161,7 @@ __global__ __launch_bounds__(256) void k_red_head(const RedHeadArgs A, int bump_
     float* dq = qs + ((12 * nA + 3) & ~3);             // [4][NO]      dL/d(pre-activation) of the heads for the group's four columns
     float* bm = dq + ((4 * NO + 3) & ~3);              // [4][4]       batch scalars: a (bits), r, done, w of the group's columns
     int* flag = reinterpret_cast<int*>(bm + 16);       // [1]          "this workgroup is the group's last arriver"
+    f32x4r* ys = reinterpret_cast<f32x4r*>(bm + 20);   // [K * nstream] the group's four columns of both hidden layers (last arriver: act' operand of the heads' dX)
     // TIMING PROBE (DQN_DRQN_STAMPS at create; null in production): 100 MHz s_memrealtime stamps, common to all XCDs.  [0..5] = workgroup 0's phases, [8..15] = group 0's last
     // arriver, [16] = latest exit of any last arriver, [17] = earliest entry of any workgroup (both as atomics)
     unsigned long long* const stamps = A.stamps;
@@ -224,7 +224,11 @@ __global__ __launch_bounds__(256) void k_red_head(const RedHeadArgs A, int bump_
         // (S == 1: `part` IS the hidden layer's finished activation -- an unsplit forward, large batches -- and the online s columns are already where the backward pass reads them)
         if (slot == 1 && !double_q) tot = (f32x4r){0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4r*>(act + (slot * 32 + f) * 4) = tot;
-        if (slot == 0 && S > 1) st_sc1_x4(T.y_on + (size_t)(32 * c + f) * ncon + 4 * g, tot);      // the backward pass (head dW) and the group's last arriver (act') read it
+        if (slot == 0 && S > 1) {
+            st_sc1_x4(T.y_on + (size_t)(32 * c + f) * ncon + 4 * g, tot);      // the backward pass (head dW tasks, the hidden layers' act') reads it
+            // r06: ... and a second, piece-major copy [group][stream][K][4] for the group's last arriver, whose round of loads then is 1 KB per instruction instead of 64 pieces ncon * 4 bytes apart
+            if (A.ypm) st_sc1_x4(A.ypm + (((size_t)g * nstream + stream) * K + (size_t)(32 * c + f)) * 4, tot);
+        }
     }
     if (bk) {
         if (take_pre && tid - 192 < B) *gptr(A.idx + (tid - 192)) = idx_v;
@@ -273,7 +277,8 @@ __global__ __launch_bounds__(256) void k_red_head(const RedHeadArgs A, int bump_
     // dX items and their registers -- r05 stamps: 2.6 us "dX" on the TD wave, all of it waiting for store acknowledgements)
     f32x4r yv[6];
 #pragma unroll
-    for (int u = 0; u < 6; u++) { int i = (tid < 192 ? tid : 0) + 192 * u; if (i >= KS) i = KS - 1; const int st_ = i >= K ? 1 : 0, k = i - st_ * K; yv[u] = ld_sc1_x4((st_ ? y1p : y0p) + (size_t)k * ncon + 4 * g); }
+    for (int u = 0; u < 6; u++) { int i = (tid < 192 ? tid : 0) + 192 * u; if (i >= KS) i = KS - 1; const int st_ = i >= K ? 1 : 0, k = i - st_ * K;
+                                  yv[u] = A.ypm ? ld_sc1_x4(A.ypm + ((size_t)g * KS + i) * 4) : ld_sc1_x4((st_ ? y1p : y0p) + (size_t)k * ncon + 4 * g); }
     {
         const int t2 = tid < nout ? tid : 0;
         const int o = t2 % NO, sj = t2 / NO, sl_ = sj >> 2;
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(256) void k_red_head(const RedHeadArgs A, int bump_
         const float* pp = Pg + (size_t)t2 * NC;
         float pv[16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) pv[q] = ld_sc1(pp + (q < NC ? q : NC - 1));
+        for (int q = 0; q < 16; q++) pv[q] = ld_sc1(pp + (q < NC ? q : NC - 1));      // (r06: four 16-byte requests instead of sixteen 4-byte ones measured the same: 1.56 vs 1.64 us for this round of loads)
         const float hb = *gptr((st_ ? (net ? hb11 : hb10) : (net ? hb01 : hb00)) + n);
         float tot = pv[0];
 #pragma unroll
@@ -289,6 +294,14 @@ __global__ __launch_bounds__(256) void k_red_head(const RedHeadArgs A, int bump_
         if (tid < nout) hv[tid] = (sl_ == 1 && !double_q) ? 0.0f : rh_act<TRANS>(tot + hb, st_ ? ha1 : ha0);
     }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(yv[0]), "+v"(yv[1]), "+v"(yv[2]), "+v"(yv[3]), "+v"(yv[4]), "+v"(yv[5])::"memory");
+    // r06: the y pieces go through LDS so that the dX loop below can stay ROLLED (everything after the ticket is code only the eight last arrivers ever execute, each on another CU, cold in
+    // the instruction cache: the six unrolled, three-way specialised dX items were ~1400 instructions).  What the stamps charged to this phase -- 2.4-2.7 us for ~150 instructions of
+    // arithmetic -- was something else, though: rh_dx_row picked the value head's dq out of the register array by a RUN-TIME index, the array went through scratch, and the scratch loads'
+    // vmcnt waits made every row wait for the previous row's global store to be acknowledged.  With the index gone (slot 8 of dqr): 1.8 us, and no scratch in the kernel
+    if (tid < 192) {
+#pragma unroll
+        for (int u = 0; u < 6; u++) { const int i = tid + 192 * u; if (i < KS) ys[i] = yv[u]; }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     RH_STAMP_L(10); RH_STAMP_L(11);
     if (tid >= 192 && tid < 196) rh_td_column<TRANS>(A, hv, bm, dq, tid - 192, 4 * g + tid - 192);
@@ -301,13 +314,10 @@ __global__ __launch_bounds__(256) void k_red_head(const RedHeadArgs A, int bump_
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int o = 0; o < 9; o++) dqr[j][o] = dq[j * NO + (o < NO ? o : NO - 1)];      // (clamped: see above)
-#pragma unroll
-    for (int u = 0; u < 6; u++) {
-        const int i = tid + 192 * u;
-        if (tid < 192 && i < KS) {
-            rh_dx_row<TRANS>(dxa, Won, dqr, i, yv[u], g);
-        }
+        for (int o = 0; o < 9; o++) dqr[j][o] = dq[j * NO + (o == 8 ? (nA < NO ? nA : NO - 1) : (o < NO ? o : NO - 1))];      // (clamped: see above; slot 8 = the value head's, see rh_dx_row)
+    if (tid < 192) {
+#pragma unroll 1
+        for (int i = tid; i < KS; i += 192) rh_dx_row<TRANS>(dxa, Won, dqr, i, ys[i], g);
     }
     RH_STAMP_L(13);
     if (stamps && tid == 0) atomicMax(stamps + 16, __builtin_amdgcn_s_memrealtime());
@@ -501,7 +511,7 @@ __global__ __launch_bounds__(256) void k_head_cols4(const RedHeadArgs A, int bum
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int o = 0; o < 9; o++) dqr[j][o] = dq[j * NO + (o < NO ? o : NO - 1)];
+        for (int o = 0; o < 9; o++) dqr[j][o] = dq[j * NO + (o == 8 ? (nA < NO ? nA : NO - 1) : (o < NO ? o : NO - 1))];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const int i = tid + 256 * u;
@@ -526,6 +536,7 @@ size_t red_head_lds_bytes(const RedHeadArgs& a) {
     const size_t nmax = (size_t)std::max(a.st[0].N, a.nstream > 1 ? a.st[1].N : 0);
     size_t f = 384 + 32 * nmax + (size_t)a.K * a.st[0].N + (a.nstream > 1 ? (size_t)a.K * a.st[1].N : 0);
     f += ((12 * (size_t)a.NO + 3) & ~(size_t)3) + ((12 * (size_t)a.nA + 3) & ~(size_t)3) + ((4 * (size_t)a.NO + 3) & ~(size_t)3) + 16 + 4;
+    f += 4 * (size_t)a.K * a.nstream;      // ys: the last arriver's y pieces
     return f * sizeof(float);
 }
 // shapes this launch covers (the caller has already checked: fused head level, dense split-K producers of both nets, distinct producers per stream): chunks of 32 hidden rows,
