@@ -1370,7 +1370,8 @@ __global__ __launch_bounds__(256) void k_dx_lds(LayerDev L, GDxArgs A, int B, in
 // dW and dX of one layer are independent given dpre: ONE launch runs both (blocks [0, dw_blocks) do dW, the rest dX), which
 // saves a dispatch and lets the latency-bound dX workgroups share the machine with the dW ones.
 template <int NT, bool WIDE>
-__global__ __launch_bounds__(256) void k_dwdx_lds(LayerDev Lw, GDwProbs pr, int nprob, int ldx, int B, int Sw, int kcw, int dw_blocks, int dw_nsplit,
+__global__ __launch_bounds__(256, WIDE ? 1 : 4)      // small batches: <= 128 registers, i.e. FOUR workgroups per CU (r06: at 135 the 800 dX workgroups of conv2's pair ran on 768 slots -- a second round for 32 of them)
+void k_dwdx_lds(LayerDev Lw, GDwProbs pr, int nprob, int ldx, int B, int Sw, int kcw, int dw_blocks, int dw_nsplit,
                                                   LayerDev Lx, GDxArgs A, int Sx, int kcx, int dx_gx, GemmTail tail) {
     // the few, long-latency dX workgroups are dispatched FIRST so that they run for the whole kernel while the many short dW
     // workgroups fill the remaining CUs (dispatch order is blockIdx order); a tail of small VALU tasks comes last
