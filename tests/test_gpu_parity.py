@@ -421,11 +421,14 @@ def test_fused_reduce_head_launch_both_schedules(pkg, monkeypatch, netf, B, kw):
     bit-exact against the twin -- single steps, explicit indices, the pipelined dqn_train_steps -- and against each other."""
     net = netf()
     outs = []
-    for fused in (True, False):
-        if not fused:
-            monkeypatch.setenv("DQN_NO_RED_HEAD", "1")
+    # r06: the fused launch's slabs are piece-major ([S][column quad][N][4], written so by the forward launch) and its last arriver reads a piece-major copy of the hidden
+    # activations; DQN_NO_RH_PM keeps the [S][N][columns] form -- a third schedule of the same chains
+    for fused, env in ((True, None), (True, "DQN_NO_RH_PM"), (False, "DQN_NO_RED_HEAD")):
+        if env:
+            monkeypatch.setenv(env, "1")
         gpu, cpu, hp = make_pair(pkg, net, B, cap=max(128, B + 40), **kw)
-        monkeypatch.delenv("DQN_NO_RED_HEAD", raising=False)
+        if env:
+            monkeypatch.delenv(env, raising=False)
         fill((gpu, cpu), net, max(100, B + 20), seed=5)
         set_same_params((gpu, cpu), net, seed=3)
         for _ in range(2):
@@ -444,7 +447,8 @@ def test_fused_reduce_head_launch_both_schedules(pkg, monkeypatch, netf, B, kw):
             assert not any("fwd_reduce" in n for n in names), names
         outs.append((gpu.get_params(0), gpu.get_adam_state()[0]))
         gpu.close(); cpu.close()
-    np.testing.assert_array_equal(outs[0][0], outs[1][0]); np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    for o in outs[1:]:
+        np.testing.assert_array_equal(outs[0][0], o[0]); np.testing.assert_array_equal(outs[0][1], o[1])
 
 
 @pytest.mark.parametrize("netf,B,kw", [(nature_dueling, 128, dict(gamma=0.99)), (nature_dueling, 132, dict(gamma=0.99, double_q=0)), (_wide_fc_dueling_tanh, 160, dict(gamma=0.95)),
