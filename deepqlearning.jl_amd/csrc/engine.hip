@@ -155,7 +155,12 @@ static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out, c
         if (L[i].kind == DQN_LAYER_DENSE && L[i].N < 16 && B >= 128 && rec) out[i].dw_kc = 64;
         if (L[i].kind == DQN_LAYER_CONV) {   // positions per chunk so that (K/64 row tiles) x chunks >= ~512 workgroups
             const int tgt = 512;      // (r03: 256 / 128 workgroups measured no faster)
-            const int st = (tgt + (L[i].K + 63) / 64 - 1) / ((L[i].K + 63) / 64); int ppc = L[i].npos / st; if (ppc < 1) ppc = 1; out[i].dw_kc = ppc * B;
+            const int mrows_ = (L[i].K + 63) / 64, st = (tgt + mrows_ - 1) / mrows_; int ppc = L[i].npos / st; if (ppc < 1) ppc = 1;
+            // r06: an EVEN number of 32-sample K tiles per chunk where a chunk is 3+ of them -- the dW loop is software-pipelined two tiles per round and an odd count pays a
+            // clamped half round -- as long as >= 3/4 of the target workgroups remain (config 2's 8x8 layer: 3 -> 4 positions, 536 -> 400 workgroups: 10.1 -> 9.45 us,
+            // profiles/r06_conv_dw_chunk_probe.txt; 5 / 6 / 8 positions: 10.4 / 10.8 / 11.3)
+            if (B % 32 == 0 && B < 128) { const int kt = ppc * (B / 32); if (kt >= 3 && (kt & 1) && (B / 32) % 2 == 1 && ((L[i].npos + ppc) / (ppc + 1)) * mrows_ * 4 >= 3 * tgt) ppc += 1; }
+            out[i].dw_kc = ppc * B;
             // large batches: a position is 4+ K tiles deep, so chunks are cut in SAMPLES (32-aligned, they may start inside a position) to land
             // on <= 1024 workgroups -- whole positions gave 536 workgroups for the 8x8 conv layer at B = 512, i.e. three on some CUs and two on the rest
             if (B >= 128 && B % 32 == 0) {
