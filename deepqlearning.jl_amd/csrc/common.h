@@ -861,7 +861,22 @@ struct ReplayMeta { long long cap, cap2; int* a; float* r; unsigned char* done; 
 void launch_env_observe(hipStream_t st, const EnvDev& V, void* rows, int rows_u8, float* x);
 struct ActHeads { HeadSrc val, adv; int dueling; float* q_out; int* amax; };     // last-layer outputs of the acting forward (adv doubles as the plain Q head)
 void launch_env_step(hipStream_t st, const EnvDev& V, RolloutDev* rs, const ActHeads& Hd, const ReplayMeta& R);
-void launch_env_observe2(hipStream_t st, const EnvDev& V, const RolloutDev* rs, int rows_u8, void* s_rows, void* sp_rows, long long cap, float* x);
+// grouped: rs is an array with one record per group of four copies (ticked by k_act_head's last arrivers); tree != nullptr: workgroup 0 rebuilds the sum-tree ancestors of the n new leaves
+void launch_env_observe2(hipStream_t st, const EnvDev& V, const RolloutDev* rs, int rows_u8, void* s_rows, void* sp_rows, long long cap, float* x, int grouped = 0, const ReplayMeta* tree = nullptr);
+// ---- the acting step's tail in one launch (act_head.hip): split-K reduce of the last hidden layer + heads + Q / argmax + eps-greedy + act! + add_exp!'s per-experience part
+#define DQN_ROLL_RECORDS 257           // RolloutDev records per env set: [g] = group g of four copies (n <= 1024); record 0 doubles as "the" record of the four-launch tail
+struct ActHeadStream { const float* part; const float* pbias; int pact; const float* W; const float* hbias; int N, hact; };      // hidden layer slabs [S][K][n] / bias / activation; head weights [K][N], bias, activation
+struct ActHeadArgs {
+    int n, nA, K, S, nstream, NO, pm;  // n copies, K hidden rows (= head inputs), S slabs, NO head outputs of both streams; pm: piece-major slabs [S][n/4][K][4]
+    ActHeadStream st[2];               // 0 = advantage / plain Q head, 1 = value head
+    float* partials;                   // [n/4][4][NO][K/32] chunk sums of the head outputs
+    unsigned* tickets;                 // [n/4] arrival counters (zero between launches)
+    float* q_out; int* amax;           // Q columns [n][nA], greedy actions (parity / inspection)
+    RolloutDev* rs;                    // [n/4] records
+    EnvDev V; ReplayMeta R;
+};
+bool act_head_ok(int n, int K, int S, int nA, int nstream, int N0, int N1);
+void launch_act_head(hipStream_t st, const ActHeadArgs& a);
 void launch_env_reset_pending(hipStream_t st, const EnvDev& V, const RolloutDev* rs, int force_all);
 
 // ---- data-parallel exchange (dp.hip)

@@ -30,6 +30,7 @@ struct EngineOpts {
     int sim_world = 0;            // DQN_SIM_WORLD=k: one process plays k ranks (tests)
     int no_graph_upload = 0;      // DQN_NO_GRAPH_UPLOAD
     int no_rollout_cycle = 0;     // DQN_NO_ROLLOUT_CYCLE
+    int no_act_head = 0;          // DQN_NO_ACT_HEAD (A/B, both schedules under test): the acting step keeps k_reduce_multi + heads + k_env_step where the fused tail (act_head.hip) would apply
     int no_rh_pm = 0;             // DQN_NO_RH_PM (A/B, r06): the hidden layers' split-K slabs stay [S][N][columns] where k_red_head reads them (default: piece-major, GFwdProb::pm)
     int dw_split = 128;            // DQN_DW_SPLIT=n: the last n units of a large-batch dW section run as two halves along N (nn_gemm.hip dw_section; 0 = off; LayerDev::opt bits 8..15 in units of 16)
     int no_st_wt = 0;             // DQN_NO_ST_WT: small-batch engines keep plain / non-temporal output stores in the GEMM launches (A/B)
@@ -96,7 +97,8 @@ struct dqn_engine {
     // cycle: ONE graph of `cycle_F` acting steps (+ a plain sampled train step when cycle_train) -- the device loop's unit of work between two
     // train steps; a graph launch costs ~5 us of stream time, a GridWorld vector step 28
     struct ActProg { std::vector<Step> steps; int n = 0; hipGraphExec_t graph = nullptr; std::vector<void*> allocs;
-                     hipGraphExec_t cycle = nullptr; int cycle_F = 0; bool cycle_train = false; };
+                     hipGraphExec_t cycle = nullptr; int cycle_F = 0; bool cycle_train = false;
+                     hipGraphExec_t envc = nullptr; int envc_due = 0; };      // envc: one vector step of the reference's cadence (the acting step + its `envc_due` pipelined train steps) as ONE graph
     ActProg act, evalp; std::vector<Step>* sink = nullptr; std::vector<void*>* alloc_sink = nullptr; RolloutDev *roll = nullptr, *eval_roll = nullptr;
     EnvDev eval_env{}; int eval_n = 0;
     std::vector<Step> prog; size_t prog_post_begin = 0, prog_pre1_end = 0; bool prog_built = false, step_sampled = true, prio_forked = false, prio_in_bwd = false;

@@ -120,7 +120,7 @@ void read_opts(EngineOpts& o, bool comm_only) {
     if (comm_only) return;
     // switches that keep a SECOND SCHEDULE of the same arithmetic under parity tests (tests/ name each of them) or that a tool under tools/ drives
     o.no_tiny = F("DQN_NO_TINY"); o.fwd_m32 = I("DQN_FWD_M32", -1); o.no_fwd_wres = F("DQN_NO_FWD_WRES"); o.sim_world = I("DQN_SIM_WORLD", 0); o.no_pregather = F("DQN_NO_PREGATHER");
-    o.no_red_head = F("DQN_NO_RED_HEAD"); o.no_head_cols4 = I("DQN_NO_HEAD_COLS4", 0); o.dw_split = I("DQN_DW_SPLIT", 128); o.no_rh_pm = F("DQN_NO_RH_PM"); o.drqn_stamps = F("DQN_DRQN_STAMPS");
+    o.no_red_head = F("DQN_NO_RED_HEAD"); o.no_head_cols4 = I("DQN_NO_HEAD_COLS4", 0); o.dw_split = I("DQN_DW_SPLIT", 128); o.no_rh_pm = F("DQN_NO_RH_PM"); o.no_act_head = F("DQN_NO_ACT_HEAD"); o.drqn_stamps = F("DQN_DRQN_STAMPS");
     // r06 removed (the constants they set are now the only behaviour): DQN_ADAM_MODE, DQN_PRIO_LEVEL, DQN_PRIO_NOSPLIT, DQN_PRIO_FORK, DQN_HEAD_FUSE_MAXB,
     // DQN_NO_HEAD_FUSE, DQN_NO_U8_ARENA, DQN_LSTM_DW_MFMA, DQN_NO_GRAPH_UPLOAD, DQN_NO_ST_WT, DQN_NO_DX_WIDE, DQN_NO_ROLLOUT_CYCLE, DQN_MID_GROUP, DQN_MID_BIG
     // (docs/history/r06.md lists each with the number that decided it)
@@ -315,11 +315,12 @@ void drop_graphs(dqn_engine* e) {
     for (int i = 0; i < 3; i++) if (e->g_pre1[i]) { hipGraphExecDestroy(e->g_pre1[i]); e->g_pre1[i] = nullptr; }
     for (int i = 0; i < 4; i++) if (e->g_dp_one[i]) { hipGraphExecDestroy(e->g_dp_one[i]); e->g_dp_one[i] = nullptr; }
     if (e->g_pre2) { hipGraphExecDestroy(e->g_pre2); e->g_pre2 = nullptr; }
-    for (dqn_engine::ActProg* a : {&e->act, &e->evalp}) { if (a->graph) { hipGraphExecDestroy(a->graph); a->graph = nullptr; } if (a->cycle) { hipGraphExecDestroy(a->cycle); a->cycle = nullptr; } }
+    for (dqn_engine::ActProg* a : {&e->act, &e->evalp}) { if (a->graph) { hipGraphExecDestroy(a->graph); a->graph = nullptr; } if (a->cycle) { hipGraphExecDestroy(a->cycle); a->cycle = nullptr; } if (a->envc) { hipGraphExecDestroy(a->envc); a->envc = nullptr; } }
 }
 void drop_act(dqn_engine* e, dqn_engine::ActProg& a) {
     if (a.graph) { hipGraphExecDestroy(a.graph); a.graph = nullptr; }
     if (a.cycle) { hipGraphExecDestroy(a.cycle); a.cycle = nullptr; }
+    if (a.envc) { hipGraphExecDestroy(a.envc); a.envc = nullptr; }
     if (!a.allocs.empty()) hipStreamSynchronize(e->stream);
     for (void* p : a.allocs) hipFree(p);
     a.allocs.clear(); a.steps.clear(); a.n = 0;

@@ -41,10 +41,10 @@ extern "C" int dqn_envs_create(dqn_engine_t* e, const dqn_env_spec* sp) { if (!e
         for (int k = 0; k < V.n_reward; k++) { V.reward_xy[k][0] = sp->reward_xy[k][0]; V.reward_xy[k][1] = sp->reward_xy[k][1]; V.reward_val[k] = sp->reward_val[k]; }
         DM(V.gw_pos, (size_t)n * 2); DM(V.gw_prev, (size_t)n * 2);
     } else return fail("unknown environment kind %d", sp->kind);
-    DM(V.actions, n); DM(V.rewards, n); DM(V.dones, n); DM(V.pending, n); DM(V.ep_reward, n); DM(V.ep_step, n); DM(V.fin_eps, n); DM(V.fin_reward, n); DM(e->roll, 1);
+    DM(V.actions, n); DM(V.rewards, n); DM(V.dones, n); DM(V.pending, n); DM(V.ep_reward, n); DM(V.ep_step, n); DM(V.fin_eps, n); DM(V.fin_reward, n); DM(e->roll, DQN_ROLL_RECORDS);
     HIPCHK(hipMemsetAsync(V.fin_eps, 0, (size_t)n * 8, e->stream)); HIPCHK(hipMemsetAsync(V.fin_reward, 0, (size_t)n * 8, e->stream));
     HIPCHK(hipMemsetAsync(V.actions, 0, (size_t)n * 4, e->stream)); HIPCHK(hipMemsetAsync(V.rewards, 0, (size_t)n * 4, e->stream));
-    HIPCHK(hipMemsetAsync(e->roll, 0, sizeof(RolloutDev), e->stream));
+    HIPCHK(hipMemsetAsync(e->roll, 0, sizeof(RolloutDev) * DQN_ROLL_RECORDS, e->stream));
     e->has_envs = true;
     return dqn_envs_reset(e);
 }
@@ -69,8 +69,29 @@ static int build_act_program(dqn_engine* e, dqn_engine::ActProg& ap, const EnvDe
     for (size_t j = 0; j < std::max(val.size(), adv.size()); j++) { std::vector<int> lv; if (j < val.size()) lv.push_back(val[j]); if (j < adv.size()) lv.push_back(adv[j]); levels.push_back(lv); }
     const float* P = e->p_on;
     HeadSrc head[DQN_MAX_LAYERS];
+    // the fused tail (act_head.hip): reduce of the heads' producers + heads + Q / argmax + eps-greedy + act! + add_exp!'s per-experience part in ONE launch, where the shapes allow
+    // (the conditions of the train step's fused reduce + head launch, engine_program.hip); else k_reduce_multi + the heads' forward + k_env_step
+    const int lq = e->hp.dueling ? e->last_adv : e->last_base, lvh = e->hp.dueling ? e->last_val : -1;
+    bool use_ah = !e->opt.no_act_head && levels.size() >= 2; int ah_pa = -1, ah_pv = -1, ah_S = 0; bool ah_pm = false; const float* ah_part[2] = {nullptr, nullptr};
+    if (use_ah) {
+        const LayerDev& La = e->L[lq]; ah_pa = La.src; ah_pv = lvh >= 0 ? e->L[lvh].src : -1;
+        bool ok = La.kind == DQN_LAYER_DENSE && ah_pa >= 0 && (lvh < 0 || (e->L[lvh].kind == DQN_LAYER_DENSE && ah_pv >= 0 && ah_pv != ah_pa));
+        auto in_lv = [&](const std::vector<int>& v, int l) { for (int x : v) if (x == l) return true; return false; };
+        const auto& hl = levels.back(); const auto& pl = levels[levels.size() - 2];
+        if (ok) ok = (int)hl.size() == (lvh >= 0 ? 2 : 1) && in_lv(hl, lq) && (lvh < 0 || in_lv(hl, lvh)) && (int)pl.size() == (lvh >= 0 ? 2 : 1) && in_lv(pl, ah_pa) && (lvh < 0 || in_lv(pl, ah_pv));
+        if (ok) {
+            const LayerDev& Pa = e->L[ah_pa]; ah_S = dqn_nchunks(Pa.K, Pa.fwd_kc);
+            ok = Pa.kind == DQN_LAYER_DENSE && Pa.N == La.K && dqn_chunk_len(La.K, La.fwd_kc) == 32 && dqn_nchunks(La.K, La.fwd_kc) * 32 == La.K;
+            if (ok && lvh >= 0) { const LayerDev& Pv = e->L[ah_pv]; const LayerDev& Lv = e->L[lvh];
+                ok = Pv.kind == DQN_LAYER_DENSE && Pv.N == Pa.N && dqn_nchunks(Pv.K, Pv.fwd_kc) == ah_S && dqn_chunk_len(Lv.K, Lv.fwd_kc) == 32 && Lv.K == La.K; }
+            if (ok) ok = act_head_ok(n, La.K, ah_S, e->nA, lvh >= 0 ? 2 : 1, La.N, lvh >= 0 ? e->L[lvh].N : 0);
+        }
+        use_ah = ok;
+    }
     for (size_t li = 0; li < levels.size(); li++) {
         const auto& lv = levels[li]; const bool last = li + 1 == levels.size();
+        if (use_ah && last) break;                          // the head level runs inside k_act_head
+        const bool ah_prod = use_ah && li + 2 == levels.size();      // this level = the heads' producers: their slabs stay unreduced
         struct Prob { int l; const float* X; float *Y, *part; int S; };
         std::vector<Prob> pr;
         for (int l : lv) { const LayerDev& L = e->L[l]; Prob q; q.l = l; q.X = L.src < 0 ? e->pol_x : e->pol_act[L.src]; q.Y = e->pol_act[l]; q.S = dqn_nchunks(L.K, L.fwd_kc);
@@ -81,7 +102,9 @@ static int build_act_program(dqn_engine* e, dqn_engine::ActProg& ap, const EnvDe
             const LayerDev L = e->L[pr[ids[0]].l]; const int np = (int)ids.size();
             struct A { const float *W[4], *bias[4], *X[4]; int ldx[4], col0[4], ncols[4]; float* out[4]; } a;
             for (int i = 0; i < np; i++) { const Prob& q = pr[ids[i]]; const LayerDev& Lq = e->L[q.l]; a.W[i] = P + Lq.w_off; a.bias[i] = P + Lq.b_off; a.X[i] = q.X; a.ldx[i] = n; a.col0[i] = 0; a.ncols[i] = n; a.out[i] = q.S > 1 ? q.part : q.Y; }
-            ap.steps.push_back({name, [=](dqn_engine* en) { launch_gemm_fwd(en->stream, L, np, a.W, a.bias, a.X, a.ldx, a.col0, a.ncols, a.out); }});
+            // slabs only k_act_head reads are written piece-major (GFwdProb::pm), when ONE launch produces them all
+            const int pm = (ah_prod && ah_S > 1 && np == (int)pr.size() && !e->opt.no_rh_pm) ? 1 : 0; if (pm) ah_pm = true;
+            ap.steps.push_back({name, [=](dqn_engine* en) { launch_gemm_fwd(en->stream, L, np, a.W, a.bias, a.X, a.ldx, a.col0, a.ncols, a.out, nullptr, pm); }});
             for (int id : ids) done[id] = true;
         };
         if (mf && pr.size() <= 4) {
@@ -102,6 +125,7 @@ static int build_act_program(dqn_engine* e, dqn_engine::ActProg& ap, const EnvDe
         for (const Prob& q : pr) {
             const LayerDev& L = e->L[q.l];
             HeadSrc h; h.p = q.Y; h.ld = n; h.S = 1; h.per_s = 0; h.bias = P + L.b_off; h.act = L.act;
+            if (ah_prod) { ah_part[q.l == ah_pa ? 0 : 1] = q.S > 1 ? q.part : q.Y; head[q.l] = h; continue; }      // reduced inside k_act_head (S == 1: the finished activation)
             if (q.S > 1) {
                 if (last) { h.p = q.part; h.S = q.S; h.per_s = (unsigned long long)L.out_feat * n; }      // reduced on the fly by k_env_step
                 else { RSeg r; memset(&r, 0, sizeof r); r.part = q.part; r.S = q.S; r.elems = (unsigned long long)L.out_feat * n; r.mode = 0; r.bias = P + L.b_off; r.per_n = L.npos * n; r.act = L.act; r.out = q.Y; segs.push_back(r); }
@@ -110,13 +134,29 @@ static int build_act_program(dqn_engine* e, dqn_engine::ActProg& ap, const EnvDe
         }
         emit_reduce(e, segs, pname(e, "act_reduce", e->L[lv[0]].kind, lv[0]));
     }
+    ReplayMeta R; R.cap = e->cap; R.cap2 = e->cap2; R.a = e->ra; R.r = e->rr; R.done = e->rdone; R.tree = e->tree; R.state = e->state; R.eps = e->hp.prio_eps; R.alpha = e->hp.prio_alpha;
+    const bool u8 = e->hp.obs_dtype == DQN_OBS_U8;
+    void *srows = e->s_rows, *sprows = e->sp_rows; float* px = e->pol_x; const long long cap = e->cap; const EnvDev Vc = V;
+    if (use_ah) {
+        ActHeadArgs h; memset(&h, 0, sizeof h);
+        const LayerDev& La = e->L[lq];
+        h.n = n; h.nA = e->nA; h.K = La.K; h.S = ah_S; h.nstream = lvh >= 0 ? 2 : 1; h.NO = e->nA + (lvh >= 0 ? 1 : 0); h.pm = ah_pm ? 1 : 0;
+        for (int st = 0; st < 2; st++) {
+            const int hl_ = (st == 1 && lvh >= 0) ? lvh : lq, pl_ = (st == 1 && lvh >= 0) ? ah_pv : ah_pa; const LayerDev& H = e->L[hl_]; const LayerDev& Pl = e->L[pl_]; ActHeadStream& T = h.st[st];
+            T.part = ah_part[(st == 1 && lvh >= 0) ? 1 : 0]; T.pbias = P + Pl.b_off; T.pact = Pl.act; T.W = P + H.w_off; T.hbias = P + H.b_off; T.N = H.N; T.hact = H.act;
+        }
+        const int Gc = n / 4, NC = La.K / 32;
+        h.partials = palloc(e, (size_t)Gc * 4 * h.NO * NC); h.tickets = (unsigned*)palloc(e, (size_t)Gc);
+        hipMemsetAsync(h.tickets, 0, (size_t)Gc * 4, e->stream);
+        h.q_out = e->pol_q; h.amax = e->pol_a; h.rs = rs; h.V = V; h.R = R;
+        e->sink = nullptr; e->alloc_sink = nullptr;
+        ap.steps.push_back({"act_head_step", [=](dqn_engine* en) { launch_act_head(en->stream, h); }});
+        ap.steps.push_back({"env_observe_tree", [=](dqn_engine* en) { launch_env_observe2(en->stream, Vc, rs, u8, srows, sprows, cap, px, 1, &R); }});
+        ap.n = n; return 0;
+    }
     e->sink = nullptr; e->alloc_sink = nullptr;
-    const int lq = e->hp.dueling ? e->last_adv : e->last_base;
     ActHeads Hd; memset(&Hd, 0, sizeof Hd); Hd.adv = head[lq]; if (e->hp.dueling) Hd.val = head[e->last_val]; Hd.dueling = e->hp.dueling; Hd.q_out = e->pol_q; Hd.amax = e->pol_a;
     // act!, add_exp!, observe, episode bookkeeping
-    const bool u8 = e->hp.obs_dtype == DQN_OBS_U8;
-    ReplayMeta R; R.cap = e->cap; R.cap2 = e->cap2; R.a = e->ra; R.r = e->rr; R.done = e->rdone; R.tree = e->tree; R.state = e->state; R.eps = e->hp.prio_eps; R.alpha = e->hp.prio_alpha;
-    void *srows = e->s_rows, *sprows = e->sp_rows; float* px = e->pol_x; const long long cap = e->cap; const EnvDev Vc = V;
     ap.steps.push_back({"env_step_commit", [=](dqn_engine* en) { launch_env_step(en->stream, Vc, rs, Hd, R); }});
     ap.steps.push_back({"env_observe", [=](dqn_engine* en) { launch_env_observe2(en->stream, Vc, rs, u8, srows, sprows, cap, px); }});
     ap.n = n; return 0;
@@ -145,6 +185,28 @@ static int cycle_graph(dqn_engine* e, dqn_engine::ActProg& ap, int F, bool with_
     HIPCHK(hipGraphInstantiate(&ap.cycle, g, nullptr, nullptr, 0)); HIPCHK(hipGraphDestroy(g));
     ap.cycle_F = F; ap.cycle_train = with_train; return 0;
 }
+// one vector step of the reference's cadence (src/solver.jl:136-140: a train step every train_freq ENV steps) as ONE graph: the acting step, then its `due` train steps
+// back to back with the pipelined gather of dqn_train_steps (step i's Adam launch gathers step i + 1's batch) -- one graph launch instead of the acting graph + the
+// first / grouped / last graphs of a dqn_train_steps(due) call
+static int envc_graph(dqn_engine* e, dqn_engine::ActProg& ap, int due) {
+    if (ap.envc && ap.envc_due == due) return 0;
+    if (ap.envc) { hipGraphExecDestroy(ap.envc); ap.envc = nullptr; }
+    hipGraph_t g;
+    (void)hipGetLastError();
+    const bool pg = e->pg_ok;
+    HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+    for (auto& s : ap.steps) s.fn(e);
+    for (int i = 0; i < due; i++) { e->step_take_pre = pg && i > 0; e->step_pregather = pg && i + 1 < due; enqueue_step(e, true, PH_ALL); }
+    e->step_take_pre = e->step_pregather = false;
+    hipError_t lerr = hipGetLastError();
+    if (e->launch_failed) { e->launch_failed = false; if (lerr == hipSuccess) lerr = hipErrorInvalidValue; }
+    HIPCHK(hipStreamEndCapture(e->stream, &g));
+    if (lerr != hipSuccess) { hipGraphDestroy(g); return fail("HIP error %s while capturing the env-cadence cycle", hipGetErrorString(lerr)); }
+    HIPCHK(hipGraphInstantiate(&ap.envc, g, nullptr, nullptr, 0)); HIPCHK(hipGraphDestroy(g));
+    if (!e->opt.no_graph_upload) (void)hipGraphUpload(ap.envc, e->stream);
+    (void)hipGetLastError();
+    ap.envc_due = due; return 0;
+}
 extern "C" int dqn_rollout(dqn_engine_t* e, int n_steps, const dqn_rollout_cfg* cfg, dqn_rollout_stats* out) { if (!e) return fail("null engine handle");
     HIPCHK(hipSetDevice(e->device));
     if (!e->has_envs) return fail("no device environments: call dqn_envs_create");
@@ -153,7 +215,8 @@ extern "C" int dqn_rollout(dqn_engine_t* e, int n_steps, const dqn_rollout_cfg* 
     if (build_act_program(e, e->act, V, e->roll)) return -1;
     if (cfg->train_freq > 0 && build_program(e)) return -1;       // may reallocate split-K workspaces: before any capture
     RolloutDev h; h.t = cfg->t0 - 1; h.widx = ((e->widx - n) % e->cap + e->cap) % e->cap; h.eps_start = cfg->eps_start; h.eps_stop = cfg->eps_stop; h.eps_steps = cfg->eps_steps; h.pad = 0;
-    HIPCHK(hipMemcpyAsync(e->roll, &h, sizeof h, hipMemcpyHostToDevice, e->stream)); HIPCHK(hipStreamSynchronize(e->stream));   // h lives on this stack frame
+    { std::vector<RolloutDev> hs(DQN_ROLL_RECORDS, h);      // one record per group of four copies (k_act_head ticks its group's), record 0 = the four-launch tail's
+      HIPCHK(hipMemcpyAsync(e->roll, hs.data(), sizeof(RolloutDev) * DQN_ROLL_RECORDS, hipMemcpyHostToDevice, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); }   // hs lives in this scope
     launch_env_observe(e->stream, V, nullptr, 0, e->pol_x);
     const bool graph = e->hp.use_graph && !e->profiling;
     if (graph && act_graph(e, e->act)) return -1;
@@ -168,6 +231,16 @@ extern "C" int dqn_rollout(dqn_engine_t* e, int n_steps, const dqn_rollout_cfg* 
     for (int k = 0; k < n_steps; k++) {
         const long long t = cfg->t0 + k;
         if (envc) {
+            // the whole vector step as one graph where every vector step owes the same number of train steps and the replay holds a batch once this step's experiences are in
+            if (graph && single && !e->opt.no_rollout_cycle && !e->tiny && cfg->train_freq > 0 && n % cfg->train_freq == 0 && n / cfg->train_freq <= 64 && std::min(e->cap, e->size + n) >= e->B) {
+                const int due_c = n / cfg->train_freq;
+                e->step_publish = false;
+                if (envc_graph(e, e->act, due_c)) return -1;
+                HIPCHK(hipGraphLaunch(e->act.envc, e->stream));
+                e->widx = (e->widx + n) % e->cap; e->size = std::min(e->cap, e->size + n); trained += due_c;
+                if (cfg->target_update_freq > 0 && (t * n) / cfg->target_update_freq != ((t - 1) * n) / cfg->target_update_freq) { if (dqn_sync_target(e)) return -1; }
+                continue;
+            }
             if (graph) HIPCHK(hipGraphLaunch(e->act.graph, e->stream));
             else for (auto& s : e->act.steps) { prof_begin(e, s.name); s.fn(e); prof_end(e); }
             e->widx = (e->widx + n) % e->cap; e->size = std::min(e->cap, e->size + n);
@@ -223,14 +296,15 @@ extern "C" int dqn_evaluate(dqn_engine_t* e, int n_eval, int max_episode_length,
         if (W.kind == DQN_ENV_TESTMDP) { DM(W.tm_s, (size_t)n_eval * 4); DM(W.tm_prev, (size_t)n_eval * 4); DM(W.tm_t, n_eval); }
         else { DM(W.gw_pos, (size_t)n_eval * 2); DM(W.gw_prev, (size_t)n_eval * 2); }
         DM(W.actions, n_eval); DM(W.rewards, n_eval); DM(W.dones, n_eval); DM(W.pending, n_eval); DM(W.ep_reward, n_eval); DM(W.ep_step, n_eval); DM(W.fin_eps, n_eval); DM(W.fin_reward, n_eval);
-        DM(e->eval_roll, 1);
+        DM(e->eval_roll, DQN_ROLL_RECORDS);
         e->eval_n = n_eval;
     }
     if (W.seed != seed || W.max_episode_length != max_episode_length) { W.seed = seed; W.max_episode_length = max_episode_length; drop_act(e, e->evalp); }   // baked into the program
     if (build_act_program(e, e->evalp, W, e->eval_roll)) return -1;
     RolloutDev h; memset(&h, 0, sizeof h);                                   // t = 0; eps schedule (0, 0, 1): always greedy
     h.eps_steps = 1.0f;
-    HIPCHK(hipMemcpyAsync(e->eval_roll, &h, sizeof h, hipMemcpyHostToDevice, e->stream)); HIPCHK(hipStreamSynchronize(e->stream));
+    { std::vector<RolloutDev> hs(DQN_ROLL_RECORDS, h);
+      HIPCHK(hipMemcpyAsync(e->eval_roll, hs.data(), sizeof(RolloutDev) * DQN_ROLL_RECORDS, hipMemcpyHostToDevice, e->stream)); HIPCHK(hipStreamSynchronize(e->stream)); }
     HIPCHK(hipMemsetAsync(W.fin_reward, 0, (size_t)n_eval * 8, e->stream));
     launch_env_reset_pending(e->stream, W, e->eval_roll, 1);                   // reset!(env), resetstate!(policy)
     launch_env_observe(e->stream, W, nullptr, 0, e->pol_x);

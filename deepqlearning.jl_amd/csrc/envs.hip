@@ -58,6 +58,68 @@ void launch_env_observe(hipStream_t st, const EnvDev& V, void* rows, int rows_u8
     hipLaunchKernelGGL(k_env_observe, dim3(blocks), dim3(256), 0, st, V, rows, rows_u8, x);
 }
 
+// add_exp!'s tree part for n new leaves at ring positions start .. start + n - 1 (already stored): their sum-tree ancestors, replay size, pre_valid.  One workgroup;
+// lvl[0][i] = leaf i's new priority (non-wrapping range), published by a barrier before the call.  Runs at the end of k_env_step, or -- with k_act_head doing the
+// per-copy work -- as workgroup 0 of the observe launch.
+__device__ __forceinline__ void env_tree_rebuild(const ReplayMeta& R, const int n, const long long start, float (*lvl)[1024], float (*rim)[2]) {
+    const long long s0 = start % R.cap, e0 = (start + n - 1) % R.cap;
+    const bool wrap = n >= R.cap || e0 < s0;
+    if (!wrap) {
+        // the n new leaves are one contiguous range: rebuild their ancestors out of LDS.  Only the two children at the rim of
+        // each level's dirty range come from the (unchanged) tree; all of those are fetched up front in one round of loads.
+        int nlev = 0; for (long long w = R.cap2; w > 1; w >>= 1) nlev++;
+        if ((int)threadIdx.x < 2 * nlev) {
+            const int d = threadIdx.x >> 1, right = threadIdx.x & 1;
+            const long long lo = s0 >> d, hi = e0 >> d, width = R.cap2 >> d;
+            float v = 0.0f;
+            if (!right && (lo & 1)) v = R.tree[width + lo - 1];
+            if (right && !(hi & 1)) v = R.tree[width + hi + 1];
+            rim[d][right] = v;
+        }
+        __syncthreads();
+        long long lo = s0, hi = e0, width = R.cap2; int cur = 0, d = 0;
+        for (; d < nlev && hi - lo >= 2; d++) {
+            const long long plo = lo >> 1, phi = hi >> 1;
+            for (long long pp = plo + threadIdx.x; pp <= phi; pp += blockDim.x) {
+                const long long c0 = 2 * pp, c1 = 2 * pp + 1;
+                const float l = c0 < lo ? rim[d][0] : lvl[cur][c0 - lo];
+                const float r = c1 > hi ? rim[d][1] : lvl[cur][c1 - lo];
+                const float sum = l + r;
+                lvl[cur ^ 1][pp - plo] = sum; R.tree[(width >> 1) + pp] = sum;
+            }
+            __syncthreads();
+            lo = plo; hi = phi; width >>= 1; cur ^= 1;
+        }
+        if (threadIdx.x == 0) {
+            // the dirty range is down to <= 2 nodes: the rest of the path to the root is a serial chain, walked without barriers
+            float v0 = lvl[cur][0], v1 = hi > lo ? lvl[cur][1] : 0.0f;
+            for (; d < nlev; d++) {
+                const long long plo = lo >> 1, phi = hi >> 1;
+                float n0, n1 = 0.0f;
+                if (hi == lo) n0 = (lo & 1) ? rim[d][0] + v0 : v0 + rim[d][1];
+                else if (plo == phi) n0 = v0 + v1;
+                else { n0 = rim[d][0] + v0; n1 = v1 + rim[d][1]; }
+                R.tree[(width >> 1) + plo] = n0; if (phi > plo) R.tree[(width >> 1) + phi] = n1;
+                v0 = n0; v1 = n1; lo = plo; hi = phi; width >>= 1;
+            }
+        }
+    } else {
+        __syncthreads();
+        long long lo[2], hi[2]; int nr = 1;
+        if (n >= R.cap) { lo[0] = 0; hi[0] = R.cap - 1; }
+        else { lo[0] = s0; hi[0] = R.cap - 1; lo[1] = 0; hi[1] = e0; nr = 2; }
+        for (long long width = R.cap2; width > 1; width >>= 1) {
+            for (int q = 0; q < nr; q++) {
+                const long long a0 = (width + lo[q]) >> 1, a1 = (width + hi[q]) >> 1;
+                for (long long node = a0 + threadIdx.x; node <= a1; node += blockDim.x) R.tree[node] = R.tree[2 * node] + R.tree[2 * node + 1];
+                lo[q] >>= 1; hi[q] >>= 1;
+            }
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) { long long s = R.state->size + n; R.state->size = s > R.cap ? R.cap : s; R.state->pre_valid = 0; }     // the tree changed: pre-drawn indices are stale
+}
+
 // ONE workgroup, thread i = env i (n <= 1024):
 //   tick the step counter and the ring cursor; apply the reset the previous step left pending (src/solver.jl:99-132);
 //   Q column of the env's observation from the head outputs (split-K slabs reduced on the fly; dueling (v + a) - mean(a),
@@ -183,62 +245,7 @@ __global__ __launch_bounds__(1024) void k_env_step(EnvDev V, RolloutDev* rs, Act
         R.tree[R.cap2 + slot] = pr; lvl[0][i] = pr;
     }
     if (V.eval_mode) return;                                    // no add_exp! (uniform branch: eval_mode is a kernel argument)
-    const long long s0 = start % R.cap, e0 = (start + n - 1) % R.cap;
-    const bool wrap = n >= R.cap || e0 < s0;
-    if (!wrap) {
-        // the n new leaves are one contiguous range: rebuild their ancestors out of LDS.  Only the two children at the rim of
-        // each level's dirty range come from the (unchanged) tree; all of those are fetched up front in one round of loads.
-        int nlev = 0; for (long long w = R.cap2; w > 1; w >>= 1) nlev++;
-        if ((int)threadIdx.x < 2 * nlev) {
-            const int d = threadIdx.x >> 1, right = threadIdx.x & 1;
-            const long long lo = s0 >> d, hi = e0 >> d, width = R.cap2 >> d;
-            float v = 0.0f;
-            if (!right && (lo & 1)) v = R.tree[width + lo - 1];
-            if (right && !(hi & 1)) v = R.tree[width + hi + 1];
-            rim[d][right] = v;
-        }
-        __syncthreads();
-        long long lo = s0, hi = e0, width = R.cap2; int cur = 0, d = 0;
-        for (; d < nlev && hi - lo >= 2; d++) {
-            const long long plo = lo >> 1, phi = hi >> 1;
-            for (long long pp = plo + threadIdx.x; pp <= phi; pp += blockDim.x) {
-                const long long c0 = 2 * pp, c1 = 2 * pp + 1;
-                const float l = c0 < lo ? rim[d][0] : lvl[cur][c0 - lo];
-                const float r = c1 > hi ? rim[d][1] : lvl[cur][c1 - lo];
-                const float sum = l + r;
-                lvl[cur ^ 1][pp - plo] = sum; R.tree[(width >> 1) + pp] = sum;
-            }
-            __syncthreads();
-            lo = plo; hi = phi; width >>= 1; cur ^= 1;
-        }
-        if (threadIdx.x == 0) {
-            // the dirty range is down to <= 2 nodes: the rest of the path to the root is a serial chain, walked without barriers
-            float v0 = lvl[cur][0], v1 = hi > lo ? lvl[cur][1] : 0.0f;
-            for (; d < nlev; d++) {
-                const long long plo = lo >> 1, phi = hi >> 1;
-                float n0, n1 = 0.0f;
-                if (hi == lo) n0 = (lo & 1) ? rim[d][0] + v0 : v0 + rim[d][1];
-                else if (plo == phi) n0 = v0 + v1;
-                else { n0 = rim[d][0] + v0; n1 = v1 + rim[d][1]; }
-                R.tree[(width >> 1) + plo] = n0; if (phi > plo) R.tree[(width >> 1) + phi] = n1;
-                v0 = n0; v1 = n1; lo = plo; hi = phi; width >>= 1;
-            }
-        }
-    } else {
-        __syncthreads();
-        long long lo[2], hi[2]; int nr = 1;
-        if (n >= R.cap) { lo[0] = 0; hi[0] = R.cap - 1; }
-        else { lo[0] = s0; hi[0] = R.cap - 1; lo[1] = 0; hi[1] = e0; nr = 2; }
-        for (long long width = R.cap2; width > 1; width >>= 1) {
-            for (int q = 0; q < nr; q++) {
-                const long long a0 = (width + lo[q]) >> 1, a1 = (width + hi[q]) >> 1;
-                for (long long node = a0 + threadIdx.x; node <= a1; node += blockDim.x) R.tree[node] = R.tree[2 * node] + R.tree[2 * node + 1];
-                lo[q] >>= 1; hi[q] >>= 1;
-            }
-            __syncthreads();
-        }
-    }
-    if (threadIdx.x == 0) { long long s = R.state->size + n; R.state->size = s > R.cap ? R.cap : s; R.state->pre_valid = 0; }     // the tree changed: pre-drawn indices are stale
+    env_tree_rebuild(R, n, start, lvl, rim);
 }
 void launch_env_step(hipStream_t st, const EnvDev& V, RolloutDev* rs, const ActHeads& Hd, const ReplayMeta& R) {
     hipLaunchKernelGGL(k_env_step, dim3(1), dim3(1024), 0, st, V, rs, Hd, R);
@@ -265,15 +272,25 @@ __device__ __forceinline__ void obs_vec(const EnvDev& V, uint32_t sw, int px_, i
     }
 }
 template <typename RowT, int VEC>
-__global__ __launch_bounds__(256) void k_env_observe2(EnvDev V, const RolloutDev* __restrict__ rs, RowT* __restrict__ s_rows, RowT* __restrict__ sp_rows,
-                                                      long long cap, float* __restrict__ x, unsigned bx, unsigned rows_blocks) {
+__global__ __launch_bounds__(256) void k_env_observe2(EnvDev V, const RolloutDev* __restrict__ rs0, RowT* __restrict__ s_rows, RowT* __restrict__ sp_rows,
+                                                      long long cap, float* __restrict__ x, unsigned bx, unsigned rows_blocks, int grouped, int tree_wg, ReplayMeta R) {
     typedef RowT RowV __attribute__((ext_vector_type(VEC)));
     typedef float FloatV __attribute__((ext_vector_type(VEC)));
     const unsigned n = V.n, E = V.E;
-    if (blockIdx.x < rows_blocks) {
-        const unsigned i = blockIdx.x / bx, fv = (blockIdx.x - i * bx) * blockDim.x + threadIdx.x;
+    if (tree_wg && blockIdx.x == 0) {
+        // (k_act_head did the per-copy part of add_exp!) workgroup 0, dispatched first: the new leaves' ancestors, beside the row writers instead of in front of them
+        __shared__ float lvl[2][1024]; __shared__ float rim[48][2];
+        const long long start = rs0->widx;                          // ticked by k_act_head: first ring position of this step's n experiences
+        for (unsigned i = threadIdx.x; i < n; i += blockDim.x) { long long slot = start + i; if (slot >= cap) slot -= cap; lvl[0][i] = R.tree[R.cap2 + slot]; }
+        env_tree_rebuild(R, (int)n, start, lvl, rim);
+        return;
+    }
+    const unsigned blk = blockIdx.x - (unsigned)tree_wg;
+    if (blk < rows_blocks) {
+        const unsigned i = blk / bx, fv = (blk - i * bx) * blockDim.x + threadIdx.x;
         if (fv >= E / VEC) return;
         const unsigned f = fv * VEC;
+        const RolloutDev* rs = rs0 + (grouped ? (i >> 2) : 0u);
         long long slot = rs->widx + i; if (slot >= cap) slot -= cap;
         uint32_t sw0 = 0x01010101u, sw1; int p0x = 0, p0y = 0, p1x, p1y;
         load_state(V, (int)i, &sw1, &p1x, &p1y);
@@ -289,9 +306,10 @@ __global__ __launch_bounds__(256) void k_env_observe2(EnvDev V, const RolloutDev
         for (int u = 0; u < VEC; u++) r[u] = sizeof(RowT) == 1 ? (RowT)ob[u] : (RowT)of[u];
         *(RowV*)(sp_rows + dst) = *(const RowV*)r;
     } else {
-        const unsigned nv = n / VEC, qv = (blockIdx.x - rows_blocks) * blockDim.x + threadIdx.x;
+        const unsigned nv = n / VEC, qv = (blk - rows_blocks) * blockDim.x + threadIdx.x;
         if (qv >= nv * E) return;
         const unsigned f = qv / nv, i0 = (qv - f * nv) * VEC;             // VEC | n: the VEC elements share the feature
+        const RolloutDev* rs = rs0 + (grouped ? (i0 >> 2) : 0u);          // (grouped: VEC == 4, the four copies are one group; every group's record holds the same t)
         const unsigned long long t = (unsigned long long)rs->t;
         float nx[VEC];
 #pragma unroll
@@ -303,14 +321,16 @@ __global__ __launch_bounds__(256) void k_env_observe2(EnvDev V, const RolloutDev
         *(FloatV*)(x + (size_t)f * n + i0) = *(const FloatV*)nx;
     }
 }
-void launch_env_observe2(hipStream_t st, const EnvDev& V, const RolloutDev* rs, int rows_u8, void* s_rows, void* sp_rows, long long cap, float* x) {
+void launch_env_observe2(hipStream_t st, const EnvDev& V, const RolloutDev* rs, int rows_u8, void* s_rows, void* sp_rows, long long cap, float* x, int grouped, const ReplayMeta* tree) {
     const bool v4 = V.E % 4 == 0 && V.n % 4 == 0; const unsigned vec = v4 ? 4 : 1;
     const unsigned bx = (V.E / vec + 255) / 256, rows_blocks = V.eval_mode ? 0 : bx * V.n, x_blocks = (unsigned)(((size_t)V.n / vec * V.E + 255) / 256);
-    const dim3 g(rows_blocks + x_blocks), b(256);
-    if (rows_u8) { if (v4) hipLaunchKernelGGL((k_env_observe2<unsigned char, 4>), g, b, 0, st, V, rs, (unsigned char*)s_rows, (unsigned char*)sp_rows, cap, x, bx, rows_blocks);
-                   else hipLaunchKernelGGL((k_env_observe2<unsigned char, 1>), g, b, 0, st, V, rs, (unsigned char*)s_rows, (unsigned char*)sp_rows, cap, x, bx, rows_blocks); }
-    else { if (v4) hipLaunchKernelGGL((k_env_observe2<float, 4>), g, b, 0, st, V, rs, (float*)s_rows, (float*)sp_rows, cap, x, bx, rows_blocks);
-           else hipLaunchKernelGGL((k_env_observe2<float, 1>), g, b, 0, st, V, rs, (float*)s_rows, (float*)sp_rows, cap, x, bx, rows_blocks); }
+    const int tw = (tree && !V.eval_mode) ? 1 : 0; ReplayMeta R; memset(&R, 0, sizeof R); if (tw) R = *tree;
+    if (grouped && !v4) grouped = 0;      // (callers only group when n % 4 == 0; the four-byte path reads record 0)
+    const dim3 g(rows_blocks + x_blocks + tw), b(256);
+    if (rows_u8) { if (v4) hipLaunchKernelGGL((k_env_observe2<unsigned char, 4>), g, b, 0, st, V, rs, (unsigned char*)s_rows, (unsigned char*)sp_rows, cap, x, bx, rows_blocks, grouped, tw, R);
+                   else hipLaunchKernelGGL((k_env_observe2<unsigned char, 1>), g, b, 0, st, V, rs, (unsigned char*)s_rows, (unsigned char*)sp_rows, cap, x, bx, rows_blocks, grouped, tw, R); }
+    else { if (v4) hipLaunchKernelGGL((k_env_observe2<float, 4>), g, b, 0, st, V, rs, (float*)s_rows, (float*)sp_rows, cap, x, bx, rows_blocks, grouped, tw, R);
+           else hipLaunchKernelGGL((k_env_observe2<float, 1>), g, b, 0, st, V, rs, (float*)s_rows, (float*)sp_rows, cap, x, bx, rows_blocks, grouped, tw, R); }
 }
 
 // apply pending resets (end of a rollout call) or reset everything (dqn_envs_reset)

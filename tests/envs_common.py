@@ -21,6 +21,11 @@ def testmdp_wide_fc_dueling(h=20, w=20, stack=4):
     return O.Network((stack, h, w), b, v, a)
 
 
+def testmdp_wide_fc_plain(h=20, w=20, stack=4):
+    """the same trunk with a plain (non-dueling) Q head: one stream through the fused acting tail"""
+    return O.Network((stack, h, w), [O.Conv(4, stack, 32, R, 2), O.Conv(3, 32, 32, R, 1), O.Dense(32 * 7 * 7, 64, R), O.Dense(64, 4, I)])
+
+
 def gridworld_mlp_dueling():
     b, v, a = O.create_dueling_network([O.Dense(2, 32, R), O.Dense(32, 4, I)])   # README.md:38
     return O.Network((2,), b, v, a)

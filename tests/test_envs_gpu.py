@@ -115,6 +115,50 @@ def test_rollout_with_fused_acting_head_bit_exact(pkg, envs, monkeypatch, n_envs
     np.testing.assert_array_equal(outs[0][0], outs[1][0]); np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("case", ["wide_fc_dueling", "wide_fc_dueling_u8", "wide_fc_plain", "gridworld", "small_fc_dueling"])
+def test_rollout_fused_acting_tail_both_schedules(pkg, envs, monkeypatch, case):
+    """r06: the acting step's tail as ONE launch -- k_act_head (act_head.hip): split-K reduce of the heads' producers + heads + Q / argmax + eps-greedy +
+    act! + add_exp!'s per-experience part, one wave per (four copies, stream, plan chunk) with a ticketed last arriver -- and the sum-tree ancestors as workgroup 0 of the observe
+    launch.  Trajectories, replay (rows, metadata, priorities incl. a wrapping ring), episode statistics, parameters and evaluation equal the twin's bit for bit, and the
+    four-launch tail (DQN_NO_ACT_HEAD=1) walks the same trajectory.  Cases: split-K dueling streams (the Nature shape class; f32 and u8 rows), a plain Q head (one stream),
+    the GridWorld MLP (unsplit producers, one chunk), a dueling net whose producers are unsplit."""
+    grid = case == "gridworld"
+    net = {"wide_fc_dueling": EC.testmdp_wide_fc_dueling, "wide_fc_dueling_u8": EC.testmdp_wide_fc_dueling, "wide_fc_plain": EC.testmdp_wide_fc_plain, "gridworld": EC.gridworld_mlp_dueling,
+           "small_fc_dueling": EC.testmdp_conv_dueling}[case]()
+    n_envs = {"wide_fc_dueling": 8, "wide_fc_dueling_u8": 12, "wide_fc_plain": 4, "gridworld": 64, "small_fc_dueling": 8}[case]
+    outs = []
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("DQN_NO_ACT_HEAD", "1")
+        g, t, hp = make_pair(pkg, net, B=8, cap=1024 if grid else 80, obs_dtype=1 if case.endswith("u8") else 0)
+        monkeypatch.delenv("DQN_NO_ACT_HEAD", raising=False)
+        EC.same_params([g, t], net)
+        spec = envs.SimpleGridWorld(n=n_envs) if grid else envs.TestMDP((14, 12) if case == "small_fc_dueling" else (20, 20), 4, 6, n=n_envs, seed=3)
+        for h in (g, t):
+            h.envs_create(spec, max_episode_length=20 if grid else 100, seed=17)
+        compare_state(g, t)
+        t0 = 1
+        for chunk, cad in ((1, False), (4, False), (3, True), (9, False), (5, True), (6, False)):      # the 80-slot ring wraps; episodes end every 5 steps (TestMDP) / within 20 (GridWorld)
+            kw = dict(t0=t0, train_freq=2 if cad else 3, target_update_freq=7, eps=(0.6, 0.05, 15.0), env_step_cadence=cad)      # cad: n / 2 train steps per vector step, the whole vector step as one graph
+            sg = g.rollout(chunk, **kw); st = t.rollout(chunk, **kw)
+            t0 += chunk
+            assert sg == st, (sg, st)
+            compare_state(g, t)
+            np.testing.assert_array_equal(g.get_params(0), t.get_params(0))
+            np.testing.assert_array_equal(g.get_params(1), t.get_params(1))
+        idx = (np.arange(8, dtype=np.int64) * 7) % int(g.replay_size()[0])
+        for x, y in zip(g.get_batch(idx), t.get_batch(idx)):
+            np.testing.assert_array_equal(x, y)
+        assert g.evaluate(8, 50, seed=5) == t.evaluate(8, 50, seed=5)
+        assert g.evaluate(4, 30, seed=6) == t.evaluate(4, 30, seed=6)
+        compare_state(g, t)
+        outs.append((g.get_params(0), g.replay_priorities(), g.envs_peek()))
+        g.close(); t.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0]); np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    for x, y in zip(outs[0][2], outs[1][2]):
+        np.testing.assert_array_equal(x, y)
+
+
 def test_rollout_env_step_cadence_bit_exact(pkg, envs):
     """r05 (VERDICT r04 missing #4): dqn_rollout with cadence_env_steps = 1 trains every train_freq ENV steps like the reference's loop (src/solver.jl:136-140) -- n / train_freq
     train steps per vector step, run back to back through the pipelined dqn_train_steps path -- and syncs the target net on env-step multiples: trajectories, replay,
