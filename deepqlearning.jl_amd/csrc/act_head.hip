@@ -15,6 +15,8 @@
 //   D. the group's LAST arriver adds the chunk sums in ascending order (+ bias, activation), and lanes 0-3 run k_env_step's per-copy body for their copy: the pending
 //      reset, the Q column + argmax, the eps-greedy draw, the transition, the replay metadata and the leaf priority.  It ticks the group's copy of the rollout
 //      counters: RolloutDev is an array with one record per group, so that nobody reads a counter another workgroup of the same launch writes.
+// (r06, measured and dropped: ONE workgroup of 16 waves per group -- the chunk sums handed over through LDS, no write-through partials, no ticket: three fabric round trips
+//  fewer, but eight workgroups pulling 114 KB of slabs each: 10.6 vs 9.3 us, profiles/r06_ae_act_step_new.txt.)
 // What is left of k_env_step -- the sum-tree ancestors of the n new leaves, replay size, pre_valid -- runs as workgroup 0 of the observe launch (envs.hip), beside
 // the row writers instead of in front of them.  No workgroup waits for another one.  Same arithmetic, same order as the launches this replaces: bit-identical
 // trajectories (tests/test_envs_gpu.py, both schedules: DQN_NO_ACT_HEAD=1 keeps the four-launch tail).
@@ -56,47 +58,46 @@ __global__ __launch_bounds__(64) void k_act_head(const ActHeadArgs A) {
     const float* part = stream ? A.st[1].part : A.st[0].part; const float* pbias = stream ? A.st[1].pbias : A.st[0].pbias; const float* Wg = stream ? A.st[1].W : A.st[0].W;
     const int N = stream ? A.st[1].N : A.st[0].N, pact = stream ? A.st[1].pact : A.st[0].pact, o0 = stream ? nA : 0;
     RolloutDev* const rs = A.rs + g;
-    // the group's rollout record and the heads' biases are requested at entry as well (only the last arriver uses them: scalar loads, no round trip behind the ticket)
-    const long long rs_t = rs->t, rs_widx = rs->widx; const float rs_e0 = rs->eps_start, rs_e1 = rs->eps_stop, rs_es = rs->eps_steps;
+    // ---- A. ONE round of loads, the same instructions on every lane (no divergent branch around a load: the compiler serialises the two sides' loads on register reuse --
+    // first build: the head weights' round trip stood in front of half the slab loads, the slab round trip in front of the env state's; lanes 32-63 repeat lanes 0-31's slab
+    // addresses, which costs nothing).  What only the group's last arriver uses is requested here as well -- the group's rollout record, the heads' biases, the four copies' env
+    // state -- through a lane-dependent (opaque zero) address, so that the values stay in vector registers until they are used instead of being waited for on the spot
+    int vz = 0; asm volatile("" : "+v"(vz));
+    const RolloutDev* rsv = rs + vz;
+    const long long rs_t = rsv->t, rs_widx = rsv->widx; const float rs_e0 = rsv->eps_start, rs_e1 = rsv->eps_stop, rs_es = rsv->eps_steps;
     float hb_v = 0.0f; int ha_v = 0;
     {
         const int t2 = lane < 4 * NO ? lane : 0, o = t2 % NO, st_ = o >= nA ? 1 : 0, nn = o - (st_ ? nA : 0);
         const float* hb0 = A.st[0].hbias; const float* hb1 = A.st[1].hbias;
         hb_v = *gp((st_ ? hb1 : hb0) + nn); ha_v = st_ ? A.st[1].hact : A.st[0].hact;
     }
-    // ---- A. one round of loads
-    f32x4h sl[SMAX]; float pb = 0.0f, wv[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4h sl[SMAX]; float pb, wv[4];
     const int i_env = 4 * g + (lane & 3);
-    unsigned char pend_v = 0; uint32_t sw_v = 0x01010101u; int px_v = 0, py_v = 0, tm_v = 0, eps_step_v = 0; float ep_rew_v = 0.0f;
-    if (lane < 32) {
-        const int row = 32 * c + lane;
+    const int f = lane & 31, row = 32 * c + f, wtot = 32 * N;
+    {
         const float* p = part + (A.pm ? ((size_t)g * K + row) * 4 : (size_t)row * n + 4 * g);
         const size_t per_s = (size_t)K * n;
 #pragma unroll
         for (int s = 0; s < SMAX; s++) sl[s] = *gp(reinterpret_cast<const f32x4h*>(p + (size_t)(s < S ? s : S - 1) * per_s));
         pb = *gp(pbias + row);
-        if (lane < 4) {      // the copy's env state (only the group's last arriver uses it; four lanes of loads in the round everybody pays anyway)
-            pend_v = *gp(V.pending + i_env); eps_step_v = *gp(V.ep_step + i_env); ep_rew_v = *gp(V.ep_reward + i_env);
-            if (V.kind == DQN_ENV_TESTMDP) { sw_v = *gp(reinterpret_cast<const uint32_t*>(V.tm_s + i_env * 4)); tm_v = *gp(V.tm_t + i_env); }
-            else { px_v = *gp(V.gw_pos + i_env * 2); py_v = *gp(V.gw_pos + i_env * 2 + 1); }
-        }
-    } else {
-        const int tot = 32 * N;
 #pragma unroll
-        for (int u = 0; u < 4; u++) { int i = lane - 32 + 32 * u; if (i >= tot) i = tot - 1; wv[u] = *gp(Wg + (size_t)32 * c * N + i); }      // N <= 4 per round of 128; N in 5..8: second round below
+        for (int u = 0; u < 4; u++) { int i = lane + 64 * u; if (i >= wtot) i = wtot - 1; wv[u] = *gp(Wg + (size_t)32 * c * N + i); }      // the chunk's 32 x N head weights (N <= 8)
     }
+    // the copy's env state: two words whose addresses are selected, not branched on (TestMDP: the four state bytes, the time; SimpleGridWorld: x, y)
+    const bool tmdp = V.kind == DQN_ENV_TESTMDP;
+    const int* w0p = tmdp ? reinterpret_cast<const int*>(V.tm_s) + i_env : V.gw_pos + 2 * i_env;
+    const int* w1p = tmdp ? V.tm_t + i_env : V.gw_pos + 2 * i_env + 1;
+    const int w0_v = *gp(w0p), w1_v = *gp(w1p);
+    unsigned char pend_v = *gp(V.pending + i_env); int eps_step_v = *gp(V.ep_step + i_env); float ep_rew_v = *gp(V.ep_reward + i_env);
     if (lane < 32) {
         f32x4h tot = sl[0];
 #pragma unroll
         for (int s = 1; s < SMAX; s++) if (s < S) { tot.x = tot.x + sl[s].x; tot.y = tot.y + sl[s].y; tot.z = tot.z + sl[s].z; tot.w = tot.w + sl[s].w; }
         if (S > 1) { tot.x = act_f(tot.x + pb, pact); tot.y = act_f(tot.y + pb, pact); tot.z = act_f(tot.z + pb, pact); tot.w = act_f(tot.w + pb, pact); }      // (S == 1: `part` IS the finished activation)
         *reinterpret_cast<f32x4h*>(act + lane * 4) = tot;
-    } else {
-        const int tot = 32 * N;
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int i = lane - 32 + 32 * u; if (i < tot) Wl[i] = wv[u]; }
-        if (N > 4) for (int i = lane - 32 + 128; i < tot; i += 32) Wl[i] = *gp(Wg + (size_t)32 * c * N + i);
     }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int i = lane + 64 * u; if (i < wtot) Wl[i] = wv[u]; }
     __syncthreads();
     // ---- B. chunk sums: item (copy j, output nn), one k-ascending chain of 32 from +0
     float* Pg = A.partials + (size_t)g * 4 * NO * NC;      // [j][o][chunk]
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(64) void k_act_head(const ActHeadArgs A) {
     if (lane >= 4) return;
     // ---- k_env_step's per-copy body (envs.hip), one lane per copy
     const int i = i_env;
+    uint32_t sw_v = tmdp ? (uint32_t)w0_v : 0x01010101u; int tm_v = tmdp ? w1_v : 0, px_v = tmdp ? 0 : w0_v, py_v = tmdp ? 0 : w1_v;
     const unsigned long long t_prev = (unsigned long long)rs_t, t = t_prev + 1;
     const long long start = (rs_widx + n) % R.cap;
     float eps = rs_e0 - (float)t * ((rs_e0 - rs_e1) / rs_es);     // LinearDecaySchedule, fp32
