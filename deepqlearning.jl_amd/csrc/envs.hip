@@ -300,11 +300,11 @@ __global__ __launch_bounds__(256) void k_env_observe2(EnvDev V, const RolloutDev
         obs_vec<VEC>(V, sw0, p0x, p0y, (int)f, of, ob);
 #pragma unroll
         for (int u = 0; u < VEC; u++) r[u] = sizeof(RowT) == 1 ? (RowT)ob[u] : (RowT)of[u];
-        *(RowV*)(s_rows + dst) = *(const RowV*)r;
+        __builtin_nontemporal_store(*(const RowV*)r, (RowV*)(s_rows + dst));      // ring rows are next read by a gather, steps later: streamed past the L2s (a kernel boundary otherwise writes back what the launch left dirty)
         obs_vec<VEC>(V, sw1, p1x, p1y, (int)f, of, ob);
 #pragma unroll
         for (int u = 0; u < VEC; u++) r[u] = sizeof(RowT) == 1 ? (RowT)ob[u] : (RowT)of[u];
-        *(RowV*)(sp_rows + dst) = *(const RowV*)r;
+        __builtin_nontemporal_store(*(const RowV*)r, (RowV*)(sp_rows + dst));
     } else {
         const unsigned nv = n / VEC, qv = (blk - rows_blocks) * blockDim.x + threadIdx.x;
         if (qv >= nv * E) return;
@@ -318,7 +318,9 @@ __global__ __launch_bounds__(256) void k_env_observe2(EnvDev V, const RolloutDev
             if (V.pending[i0 + u] && !V.eval_mode) reset_state(V, (int)(i0 + u), t, &sw, &tm, &px, &py);
             unsigned char b; nx[u] = obs_elem(V, sw, px, py, (int)f, &b);
         }
-        *(FloatV*)(x + (size_t)f * n + i0) = *(const FloatV*)nx;
+        { typedef float obs_f4 __attribute__((ext_vector_type(4)));      // the policy input is read by the very next launch, mostly from other XCDs: written through (sc1) as it is produced
+          if constexpr (VEC == 4) { const obs_f4 v = {nx[0], nx[1], nx[2], nx[3]}; asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(x + (size_t)f * n + i0), "v"(v) : "memory"); }
+          else *(FloatV*)(x + (size_t)f * n + i0) = *(const FloatV*)nx; }
     }
 }
 void launch_env_observe2(hipStream_t st, const EnvDev& V, const RolloutDev* rs, int rows_u8, void* s_rows, void* sp_rows, long long cap, float* x, int grouped, const ReplayMeta* tree) {
