@@ -153,6 +153,7 @@ PROTOS = {
     "envs_reset": [_vp],
     "rollout": [_vp, C.c_int, _P(RolloutCfg), _P(RolloutStats)],
     "envs_peek": [_vp, _f32p, _i32p, _f32p, _u8p],
+    "envs_info": [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "evaluate": [_vp, C.c_int, C.c_int, C.c_uint64, _f64p, _f64p],
     "replay_export": [_vp, C.c_int64, C.c_int64, _vp, _vp, _i32p, _f32p, _u8p, _f32p],
     "replay_import": [_vp, C.c_int64, _vp, _vp, _i32p, _f32p, _u8p, _f32p],
@@ -482,6 +483,12 @@ class Handle:
         r, st = C.c_double(), C.c_double()
         self._check(self.f["evaluate"](self._h, int(n_eval), int(max_episode_length), int(seed), C.byref(r), C.byref(st)))
         return r.value, st.value
+
+    def envs_info(self):
+        """(n_envs, fused_tail): fused_tail = the acting step's tail runs as one launch (act_head.hip)"""
+        n, f = C.c_int32(), C.c_int32()
+        self._check(self.f["envs_info"](self._h, C.byref(n), C.byref(f)))
+        return n.value, bool(f.value)
 
     def envs_peek(self):
         n = self.n_envs

@@ -96,7 +96,7 @@ struct dqn_engine {
     // acting programs (forward on n columns + env kernels), one for the training envs and one for the evaluation envs
     // cycle: ONE graph of `cycle_F` acting steps (+ a plain sampled train step when cycle_train) -- the device loop's unit of work between two
     // train steps; a graph launch costs ~5 us of stream time, a GridWorld vector step 28
-    struct ActProg { std::vector<Step> steps; int n = 0; hipGraphExec_t graph = nullptr; std::vector<void*> allocs;
+    struct ActProg { std::vector<Step> steps; int n = 0; bool fused_tail = false; hipGraphExec_t graph = nullptr; std::vector<void*> allocs;
                      hipGraphExec_t cycle = nullptr; int cycle_F = 0; bool cycle_train = false;
                      hipGraphExec_t envc = nullptr; int envc_due = 0; };      // envc: one vector step of the reference's cadence (the acting step + its `envc_due` pipelined train steps) as ONE graph
     ActProg act, evalp; std::vector<Step>* sink = nullptr; std::vector<void*>* alloc_sink = nullptr; RolloutDev *roll = nullptr, *eval_roll = nullptr;

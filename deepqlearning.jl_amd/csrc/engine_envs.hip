@@ -152,9 +152,9 @@ static int build_act_program(dqn_engine* e, dqn_engine::ActProg& ap, const EnvDe
         e->sink = nullptr; e->alloc_sink = nullptr;
         ap.steps.push_back({"act_head_step", [=](dqn_engine* en) { launch_act_head(en->stream, h); }});
         ap.steps.push_back({"env_observe_tree", [=](dqn_engine* en) { launch_env_observe2(en->stream, Vc, rs, u8, srows, sprows, cap, px, 1, &R); }});
-        ap.n = n; return 0;
+        ap.n = n; ap.fused_tail = true; return 0;
     }
-    e->sink = nullptr; e->alloc_sink = nullptr;
+    e->sink = nullptr; e->alloc_sink = nullptr; ap.fused_tail = false;
     ActHeads Hd; memset(&Hd, 0, sizeof Hd); Hd.adv = head[lq]; if (e->hp.dueling) Hd.val = head[e->last_val]; Hd.dueling = e->hp.dueling; Hd.q_out = e->pol_q; Hd.amax = e->pol_a;
     // act!, add_exp!, observe, episode bookkeeping
     ap.steps.push_back({"env_step_commit", [=](dqn_engine* en) { launch_env_step(en->stream, Vc, rs, Hd, R); }});
@@ -326,6 +326,14 @@ extern "C" int dqn_evaluate(dqn_engine_t* e, int n_eval, int max_episode_length,
     for (int i = 0; i < n_eval; i++) { r += fr[i]; s += (double)st[i]; }      // avg_r += r_tot; avg_steps += step, episode order
     if (avg_reward) *avg_reward = r / n_eval;
     if (avg_steps) *avg_steps = s / n_eval;
+    return 0;
+}
+extern "C" int dqn_envs_info(dqn_engine_t* e, int* n_envs, int* fused_tail) { if (!e) return fail("null engine handle");
+    HIPCHK(hipSetDevice(e->device));
+    if (!e->has_envs) return fail("no device environments: call dqn_envs_create");
+    if (build_act_program(e, e->act, e->env, e->roll)) return -1;
+    if (n_envs) *n_envs = e->env.n;
+    if (fused_tail) *fused_tail = e->act.fused_tail ? 1 : 0;
     return 0;
 }
 extern "C" int dqn_envs_peek(dqn_engine_t* e, float* obs, int32_t* actions, float* rewards, uint8_t* dones) { if (!e) return fail("null engine handle");

@@ -252,6 +252,10 @@ int dqn_rollout(dqn_engine_t* e, int n_vector_steps, const dqn_rollout_cfg* cfg,
 int dqn_evaluate(dqn_engine_t* e, int n_eval, int max_episode_length, uint64_t seed, double* avg_reward, double* avg_steps);
 /* inspection (parity tests): current observations float[n][C][H][W], last actions int32[n], last rewards float[n], last dones uint8[n] */
 int dqn_envs_peek(dqn_engine_t* e, float* obs, int32_t* actions, float* rewards, uint8_t* dones);
+/* inspection (parity tests, which must know WHICH schedule they compared): n_envs of the training set; fused_tail = 1 when the acting step of that set runs its tail as one
+ * launch (act_head.hip: reduce + heads + Q / argmax + eps-greedy + act! + add_exp!'s per-experience part), 0 for the general four-launch tail.  Builds the acting program
+ * (as dqn_rollout would) if it does not exist yet. */
+int dqn_envs_info(dqn_engine_t* e, int* n_envs, int* fused_tail);
 
 /* ---- checkpoint / resume (absent in the reference, which only saves the best network: src/solver.jl:290-318).
  * Together with dqn_get/set_params, dqn_get/set_adam_state these make a run resumable bit for bit: the replay in its storage type
