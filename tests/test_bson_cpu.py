@@ -63,3 +63,33 @@ def test_bytes_follow_the_bson_spec():
     assert i > 0
     j = data.index(b"\x05data\x00" + struct.pack("<i", 24) + b"\x00")
     assert data[j + 11:j + 11 + 24] == flat[:6].tobytes()
+
+
+def test_third_party_bson_decoder_reads_the_file():
+    """A BSON implementation this repository did not write -- PyMongo's `bson` (C extension or pure Python; skipped where the package is absent) -- decodes the bytes of
+    qnetwork.bson to the same tagged documents: BSON.jl's array lowering {"tag": "array", "type": {"tag": "datatype", "name": ["Core", "Float32"], "params": []},
+    "size": [Int64 ...], "data": binary} with the raw little-endian Float32 payload in Julia memory order.  Spec-level validity by an independent reader; what stays unverified is
+    BSON.jl's own raising of these tags (no Julia in this image)."""
+    pb = pytest.importorskip("bson")
+    if not hasattr(pb, "decode"):
+        pytest.skip("a `bson` module without decode(): not PyMongo's")
+    net = nn.create_dueling_network(nn.Chain(nn.Conv(3, 2, 4, nn.relu, 1), nn.flattenbatch, nn.Dense(36, 8, nn.relu), nn.Dense(8, 3)))
+    shapes = bson.julia_param_shapes(net)
+    flat = np.random.default_rng(5).standard_normal(sum(n for _, n in shapes)).astype(np.float32)
+    data = bson.dumps_qnetwork(flat, shapes)
+    doc = pb.decode(data)
+    assert list(doc) == ["qnetwork"] and len(doc["qnetwork"]) == len(shapes)
+    off = 0
+    for e, (size, n) in zip(doc["qnetwork"], shapes):
+        assert list(e) == ["tag", "type", "size", "data"] and e["tag"] == "array"
+        assert e["type"] == {"tag": "datatype", "name": ["Core", "Float32"], "params": []}
+        assert [int(x) for x in e["size"]] == list(size) and all(type(x).__name__ in ("Int64", "int") for x in e["size"])
+        payload = bytes(e["data"])
+        assert len(payload) == 4 * n and payload == flat[off:off + n].tobytes()
+        off += n
+    assert off == flat.size
+    # and the other way round: what PyMongo encodes from the same tagged documents is byte for byte what this module writes (one canonical encoding: int64 sizes, subtype-0 binary)
+    from bson.int64 import Int64
+    tagged = {"qnetwork": [{"tag": "array", "type": {"tag": "datatype", "name": ["Core", "Float32"], "params": []}, "size": [Int64(x) for x in size],
+                            "data": pb.Binary(flat[o:o + n].tobytes(), 0)} for (size, n), o in zip(shapes, np.cumsum([0] + [n for _, n in shapes[:-1]]).tolist())]}
+    assert pb.encode(tagged) == data
