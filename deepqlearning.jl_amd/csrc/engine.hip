@@ -160,6 +160,11 @@ static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out, c
             // clamped half round -- as long as >= 3/4 of the target workgroups remain (config 2's 8x8 layer: 3 -> 4 positions, 536 -> 400 workgroups: 10.1 -> 9.45 us,
             // profiles/r06_conv_dw_chunk_probe.txt; 5 / 6 / 8 positions: 10.4 / 10.8 / 11.3)
             if (B % 32 == 0 && B < 128) { const int kt = ppc * (B / 32); if (kt >= 3 && (kt & 1) && (B / 32) % 2 == 1 && ((L[i].npos + ppc) / (ppc + 1)) * mrows_ * 4 >= 3 * tgt) ppc += 1; }
+            // r06: a conv layer that HAS a dX (every one but the first) computes its dW in the launch that also carries that dX -- chains of lone waves on most of the chip's
+            // slots -- and there the target of ~512 dW workgroups is wrong: THREE K tiles per chunk (config 2: 81 -> 27 chunks = 216 workgroups beside the second convolution's 800
+            // dX workgroups, 49 -> 17 for the third) shorten both that launch and, with a third of the slabs, the Adam launch: 8374 -> 8555 steps/s
+            // (profiles/r06_zh_conv_dw_chunk_probe.txt: 2 / 3 / 4 / 5 / 6 / 9 positions: launch 15.1 / 12.7 / 14.4 / 14.4 / 15.0 / 17.9 us)
+            if (B % 32 == 0 && B < 128 && L[i].src >= 0) { const int tpp = B / 32; ppc = (3 + tpp - 1) / tpp; if (ppc > L[i].npos) ppc = L[i].npos; }
             out[i].dw_kc = ppc * B;
             // large batches: a position is 4+ K tiles deep, so chunks are cut in SAMPLES (32-aligned, they may start inside a position) to land
             // on <= 1024 workgroups -- whole positions gave 536 workgroups for the 8x8 conv layer at B = 512, i.e. three on some CUs and two on the rest

@@ -178,6 +178,8 @@ int ref_plan_default(const dqn_layer_desc* d, int n, const dqn_hparams* hp, dqn_
         if (posB) { int mrows = (K + 63) / 64; int st = (512 + mrows - 1) / mrows; int ppc = (h * w) / st; if (ppc < 1) ppc = 1;
             /* small batches: an even number of 32-sample K tiles per chunk of 3+ tiles, while >= 3/4 of the 512 target workgroups remain */
             if (B % 32 == 0 && B < 128) { int kt = ppc * (B / 32); if (kt >= 3 && (kt & 1) && (B / 32) % 2 == 1 && ((h * w + ppc) / (ppc + 1)) * mrows * 4 >= 3 * 512) ppc += 1; }
+            /* small batches, every conv layer but the network's first (its dW shares a launch with its dX): three K tiles per chunk */
+            if (B % 32 == 0 && B < 128 && i > 0) { int tpp = B / 32; ppc = (3 + tpp - 1) / tpp; if (ppc > h * w) ppc = h * w; }
             out[i].dw_kc = ppc * B;
             if (B >= 128 && B % 32 == 0) {      /* large batches: sample-granular chunks, <= 1024 workgroups */
                 int KK = h * w * B; int ch = 1024 / mrows; if (ch < 1) ch = 1;

@@ -23,6 +23,8 @@ p = nn.glorot_params(net, seed=1)
 base = pkg.default_plan(layers, hp)
 print("default plan (fwd_kc, dx_kc, dw_kc):", base[:3])
 cases = [("default", {})] + [(f"conv1 {k} pos", {0: k}) for k in (4, 5, 6, 8)] + [(f"conv3 {k} pos", {2: k}) for k in (2,)] + [("default", {})]
+if os.environ.get("PROBE_CASES"):      # e.g. PROBE_CASES="1:2,1:4,2:4,1:3+2:4" (layer index : positions per chunk; + joins layers of one case)
+    cases = [("default", {})] + [(c, {int(x.split(":")[0]): int(x.split(":")[1]) for x in c.split("+")}) for c in os.environ["PROBE_CASES"].split(",")] + [("default", {})]      # "1:3+2:4" = both at once
 for rep in range(2):
     for name, chg in cases:
         plan = [(q[0], q[1], chg[i] * B) if i in chg else q for i, q in enumerate(base)]
