@@ -146,7 +146,10 @@ static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out, c
             const int S = join ? 2 : 4; const int kc = ((L[i].N + S - 1) / S + 31) / 32 * 32; if (kc < L[i].N) out[i].dx_kc = kc;
         } else if (L[i].kind == DQN_LAYER_CONV && B <= 64) {
             const int valid = ((L[i].kh + L[i].sh - 1) / L[i].sh) * ((L[i].kw + L[i].sw - 1) / L[i].sw), raw = ((valid + 3) / 4) * L[i].sw;
-            if (raw < L[i].kh * L[i].kw) out[i].dx_kc = raw;
+            // r06: ... but only where the chain of an output element is longer than eight K tiles (valid taps x channels > 256): the 4x4 / stride-2 layer of the Nature net has four
+            // valid taps x 64 channels and runs faster as ONE chain per element than as four (its launch 12.6 -> 11.8 us with the dW workgroups of the rule below beside it;
+            // 4 / 8 raw taps per chunk: 12.1; profiles/r06_zj_plan_probe_dx.txt); the 3x3 layer (nine taps x 64) keeps its three chunks (unsplit: 15.4 vs 11.7 us)
+            if (raw < L[i].kh * L[i].kw && valid * L[i].N > 256) out[i].dx_kc = raw;
         }
         out[i].dw_kc = 0;
         // head layers at large batches, recurrent networks only (their dW is a launch of its own): 64-sample chains on 8x more threads instead of one

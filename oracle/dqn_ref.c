@@ -171,7 +171,7 @@ int ref_plan_default(const dqn_layer_desc* d, int n, const dqn_hparams* hp, dqn_
             int S = join ? 2 : 4; int kc = ((nout + S - 1) / S + 31) / 32 * 32; if (kc < nout) out[i].dx_kc = kc;
         } else if (d[i].kind == DQN_LAYER_CONV && B <= 64) {                    /* RAW taps per chunk so that an interior position has <= 4 non-empty chunks */
             int valid = ((d[i].kh + d[i].sh - 1) / d[i].sh) * ((d[i].kw + d[i].sw - 1) / d[i].sw); int raw = ((valid + 3) / 4) * d[i].sw;
-            if (raw < d[i].kh * d[i].kw) out[i].dx_kc = raw;
+            if (raw < d[i].kh * d[i].kw && valid * d[i].cout > 256) out[i].dx_kc = raw;      /* ... where an element's chain is longer than eight K tiles */
         }
         out[i].dw_kc = 0;
         if (d[i].kind == DQN_LAYER_DENSE && d[i].n_out < 16 && B >= 128 && rec) out[i].dw_kc = 64;      /* recurrent networks only */
