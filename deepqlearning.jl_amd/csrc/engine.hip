@@ -135,8 +135,10 @@ static void default_plan(const LayerDev* L, int n, int B, dqn_layer_plan* out, c
         out[i].fwd_kc = 0;
         // (small batches only: at B >= 128 the 3 B columns of a step already fill the chip -- 512 workgroups for the 3136 -> 512 layers of config 5 --
         // and the split only bought slab traffic plus a reduce launch: 16 us of the 807 us step, r03_g)
-        if (L[i].K > 1024 && B < 128) { const int s = (L[i].K + 543) / 544; int kc = (L[i].K + s - 1) / s; kc = (kc + 31) / 32 * 32; out[i].fwd_kc = kc; }      // r06: chunks of up to 17 K tiles (the 3136-wide
-        // layers: 6 slabs of 544 instead of 7 of 448: forward launch 14.9 -> 14.0 us, +1.0 % steps/s; 416 / 480 / 512 / 576 / 608 / 640: 14.5 / 15.7 / 16.1 / 14.3 / 14.9 / 15.0 us, profiles/r06_zl_plan_probe_fwd.txt)
+        if (L[i].K > 1024 && B < 128) { const int s = (L[i].K + 511) / 512; int kc = (L[i].K + s - 1) / s; kc = (kc + 3) / 4 * 4; out[i].fwd_kc = kc; }
+        // (r06: chunks of 544 -- six slabs instead of seven for the 3136-wide layers -- looked 1 % faster until the probe showed why: fewer slabs dropped the launch below the tile
+        //  picker's workgroup threshold, which then chose 16-channel tiles; with those tiles chosen for dense layers outright (fwd_pick_nt, nn_gemm.hip) seven slabs of 448 win:
+        //  forward launch 14.9 (448, 32-channel tiles) -> 14.0 (544, 16) -> 13.2 us (448, 16); profiles/r06_zl_plan_probe_fwd.txt, r06_zo_fwd_nt_probe.txt)
         else if (L[i].kind == DQN_LAYER_DENSE && L[i].N < 16 && L[i].K >= 128) out[i].fwd_kc = 32;   // heads: 16+ short chains instead of one long one (at any batch: unsplit, the B = 512 head launch took 25 us instead of 7 + 6)
         out[i].dx_kc = (L[i].kind != DQN_LAYER_CONV && L[i].N > 512) ? 256 : 0;
         // small batches (the 32 x 32 output tiles of k_dx_units, nn_gemm.hip): cut the dX contraction so that an output tile has up to four

@@ -163,7 +163,7 @@ int ref_plan_default(const dqn_layer_desc* d, int n, const dqn_hparams* hp, dqn_
         if (d[i].stream == DQN_STREAM_BASE) { bc = c; bh = h; bw = w; has_base = 1; }
         int B = hp->batch_size; const int nout = d[i].kind == DQN_LAYER_LSTM ? 4 * d[i].n_out : d[i].n_out;
         out[i].fwd_kc = 0;
-        if (K > 1024 && B < 128) { int s = (K + 543) / 544; int kc = (K + s - 1) / s; kc = (kc + 31) / 32 * 32; out[i].fwd_kc = kc; }      /* chunks of up to 17 K tiles of 32 */
+        if (K > 1024 && B < 128) { int s = (K + 511) / 512; int kc = (K + s - 1) / s; kc = (kc + 3) / 4 * 4; out[i].fwd_kc = kc; }
         else if (d[i].kind == DQN_LAYER_DENSE && d[i].n_out < 16 && K >= 128) out[i].fwd_kc = 32;
         out[i].dx_kc = 0;
         if (d[i].kind != DQN_LAYER_CONV && nout > 512) out[i].dx_kc = 256;
