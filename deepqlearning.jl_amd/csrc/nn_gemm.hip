@@ -645,7 +645,10 @@ static int fwd_pick_nt(const LayerDev& L, long mgroups_total, int S) {
         // (r03: 1024-2048 measured slower for the conv layers -- the A tile is re-read more often.  r06: a DENSE layer re-reads nothing -- its weights stream once whatever the
         //  tile -- and the 3136 -> 512 pair's forward at config 2 runs 14.9 -> 13.2 us on 896 workgroups of 16 channels instead of 448 of 32; the first convolution on 1200
         //  instead of 600: 13.4 -> 14.1; profiles/r06_zo_fwd_nt_probe.txt)
-        const long min_wgs = (L.kind == DQN_LAYER_DENSE && S > 1) ? 800 : 400;      // (S > 1: the split-K forward of small batches; the unsplit large-batch launches keep their tiles)
+#ifndef DQN_FWD_MIN_WGS_CONV
+#define DQN_FWD_MIN_WGS_CONV 400      /* (probe builds: tools/build_variant.sh <name> -DDQN_FWD_MIN_WGS_CONV=...) */
+#endif
+        const long min_wgs = (L.kind == DQN_LAYER_DENSE && S > 1) ? 800 : DQN_FWD_MIN_WGS_CONV;      // (S > 1: the split-K forward of small batches; the unsplit large-batch launches keep their tiles)
         if (wgs >= min_wgs) return nt;
         if (wgs > best_wgs) { best_wgs = wgs; best = nt; }
     }
