@@ -403,7 +403,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=80)      # >= 64: the 16-step grouped graph of dqn_train_steps is first launched by a call of 64+ steps -- with the default K = 300 that is the timed call unless the warm-up is one too (r06: one default-flag run in ~16 read 6904 instead of ~8300 steps/s, 7 ms inside the K-step call)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--replay", type=int, default=10000, help="transitions per rank (the reference fixes none for this shape)")
     ap.add_argument("--envs-per-rank", type=int, default=32, help="config 3: 256 envs / 8 ranks")
