@@ -138,7 +138,10 @@ __global__ __launch_bounds__(64) void k_act_head(const ActHeadArgs A) {
     const long long start = (rs_widx + n) % R.cap;
     float eps = rs_e0 - (float)t * ((rs_e0 - rs_e1) / rs_es);     // LinearDecaySchedule, fp32
     if (!(rs_es > 0.0f) || eps < rs_e1) eps = rs_e1;
-    if (lane == 0) { rs->t = (long long)t; rs->widx = start; }      // this group's record: its only reader in this launch is this wave
+    // this group's record.  Every wave of the group requested it at entry (phase A) and only this one -- the last arriver -- uses what it got; the others are past their ticket
+    // or will find it taken, and drop the value: no workgroup ever USES a word another workgroup of the same launch writes (the next launch reads the ticked record behind a
+    // kernel boundary)
+    if (lane == 0) { rs->t = (long long)t; rs->widx = start; }
     if (V.eval_mode && pend_v) return;                              // evaluation: one episode per copy, finished copies idle
     if (pend_v) {
         V.fin_eps[i] += 1; V.fin_reward[i] += (double)ep_rew_v; ep_rew_v = 0.0f; eps_step_v = 0;
