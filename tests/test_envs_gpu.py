@@ -117,17 +117,17 @@ def test_rollout_with_fused_acting_head_bit_exact(pkg, envs, monkeypatch, n_envs
     np.testing.assert_array_equal(outs[0][0], outs[1][0]); np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("case", ["wide_fc_dueling", "wide_fc_dueling_u8", "wide_fc_dueling_s13", "wide_fc_plain", "gridworld", "gridworld_1024", "small_fc_dueling"])
+@pytest.mark.parametrize("case", ["wide_fc_dueling", "wide_fc_dueling_u8", "wide_fc_dueling_s13", "wide_fc_plain", "wide_fc_dueling_uniform", "gridworld", "gridworld_1024", "small_fc_dueling"])
 def test_rollout_fused_acting_tail_both_schedules(pkg, envs, monkeypatch, case):
     """r06: the acting step's tail as ONE launch -- k_act_head (act_head.hip): split-K reduce of the heads' producers + heads + Q / argmax + eps-greedy +
     act! + add_exp!'s per-experience part, one wave per (four copies, stream, plan chunk) with a ticketed last arriver -- and the sum-tree ancestors as workgroup 0 of the observe
     launch.  Trajectories, replay (rows, metadata, priorities incl. a wrapping ring), episode statistics, parameters and evaluation equal the twin's bit for bit, and the
-    four-launch tail (DQN_NO_ACT_HEAD=1) walks the same trajectory.  Cases: split-K dueling streams (the Nature shape class; f32 and u8 rows), a plain Q head (one stream),
+    four-launch tail (DQN_NO_ACT_HEAD=1) walks the same trajectory.  Cases: split-K dueling streams (the Nature shape class; f32 and u8 rows; 13 slabs; uniform replay without double-Q), a plain Q head (one stream),
     the GridWorld MLP (unsplit producers, one chunk), a dueling net whose producers are unsplit."""
     grid = case.startswith("gridworld")      # (gridworld_1024: the largest copy count, 256 groups = every RolloutDev record in use)
-    net = {"wide_fc_dueling": EC.testmdp_wide_fc_dueling, "wide_fc_dueling_u8": EC.testmdp_wide_fc_dueling, "wide_fc_dueling_s13": EC.testmdp_wide_fc_dueling, "wide_fc_plain": EC.testmdp_wide_fc_plain,
+    net = {"wide_fc_dueling": EC.testmdp_wide_fc_dueling, "wide_fc_dueling_u8": EC.testmdp_wide_fc_dueling, "wide_fc_dueling_s13": EC.testmdp_wide_fc_dueling, "wide_fc_dueling_uniform": EC.testmdp_wide_fc_dueling, "wide_fc_plain": EC.testmdp_wide_fc_plain,
            "gridworld": EC.gridworld_mlp_dueling, "gridworld_1024": EC.gridworld_mlp_dueling, "small_fc_dueling": EC.testmdp_conv_dueling}[case]()
-    n_envs = {"wide_fc_dueling": 8, "wide_fc_dueling_u8": 12, "wide_fc_dueling_s13": 8, "wide_fc_plain": 4, "gridworld": 64, "gridworld_1024": 1024, "small_fc_dueling": 8}[case]
+    n_envs = {"wide_fc_dueling": 8, "wide_fc_dueling_u8": 12, "wide_fc_dueling_s13": 8, "wide_fc_dueling_uniform": 8, "wide_fc_plain": 4, "gridworld": 64, "gridworld_1024": 1024, "small_fc_dueling": 8}[case]
     # plan edits (the twin takes the same plan): 13 slabs per hidden layer (the 16-slab instantiation of the launch); 32-row chunks for the plain net's 64-input head (the default
     # plan leaves it unsplit, which the launch does not cover)
     plan_edit = {"wide_fc_dueling_s13": lambda pl: [(128, dx, dw) if fk == 392 else (fk, dx, dw) for fk, dx, dw in pl],
@@ -136,7 +136,8 @@ def test_rollout_fused_acting_tail_both_schedules(pkg, envs, monkeypatch, case):
     for fused in (True, False):
         if not fused:
             monkeypatch.setenv("DQN_NO_ACT_HEAD", "1")
-        g, t, hp = make_pair(pkg, net, B=8, cap=(3000 if n_envs == 1024 else 1024) if grid else 80, plan_edit=plan_edit, obs_dtype=1 if case.endswith("u8") else 0)
+        extra = dict(prioritized_replay=0, double_q=0) if case.endswith("uniform") else {}      # uniform replay (add_exp! with priority 0f0, no pre-drawn batches), plain Q targets
+        g, t, hp = make_pair(pkg, net, B=8, cap=(3000 if n_envs == 1024 else 1024) if grid else 80, plan_edit=plan_edit, obs_dtype=1 if case.endswith("u8") else 0, **extra)
         monkeypatch.delenv("DQN_NO_ACT_HEAD", raising=False)
         EC.same_params([g, t], net)
         spec = envs.SimpleGridWorld(n=n_envs) if grid else envs.TestMDP((14, 12) if case == "small_fc_dueling" else (20, 20), 4, 6, n=n_envs, seed=3)
